@@ -1,0 +1,384 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref) -- build container only.
+
+    make -C oracle ref && python oracle/gen_golden.py
+
+Every array written here is either an input (seeded synthetic complex baseband,
+bit patterns, filter coefficients) or the output the reference's own compiled
+functions produced for that input.  The reference cannot travel to the GPU box;
+these vectors can.  TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refbind  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **kw)
+    print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024.0))
+
+
+def awgn(rng, n, sigma):
+    return (sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(np.complex64)
+
+
+def normal_bits(rng, tscb, tsc):
+    """148-bit normal burst: 3 tail, 57 data, steal, 26 TSC at bit 61, steal, 57 data, 3 tail
+    (GSM/GSML1FEC.cpp:726)."""
+    bits = rng.integers(0, 2, 148).astype(np.int8)
+    bits[:3] = 0
+    bits[-3:] = 0
+    bits[61:87] = tscb[tsc]
+    return bits
+
+
+def rach_bits(rng, rachb):
+    """8 bits 01010101 + 41-bit sync + 36 payload + 63 zeros (sigProcLibTest.cpp:38-47 layout)."""
+    bits = np.zeros(148, np.int8)
+    bits[:8] = [0, 1, 0, 1, 0, 1, 0, 1]
+    bits[8:49] = rachb
+    bits[49:85] = rng.integers(0, 2, 36)
+    return bits
+
+
+def pack(bursts):
+    lens = np.array([len(b) for b in bursts], np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    return np.concatenate(bursts).astype(np.complex64), off, lens
+
+
+def gen_tables():
+    kw = {}
+    for sps in (1, 2, 4):
+        r = refbind.Ref(sps)
+        c, s = r.trig_tables()
+        rot, rev = r.rotation()
+        mids = [r.midamble(t) for t in range(8)]
+        rs, rt, rg = r.rach()
+        p = "sps%d_" % sps
+        kw.update({p + "rot": rot, p + "rev": rev, p + "pulse": r.pulse().real.copy(),
+                   p + "mid": np.stack([m[0] for m in mids]),
+                   p + "mid_toa": np.array([m[1] for m in mids], np.float32),
+                   p + "mid_gain": np.array([m[2] for m in mids], np.complex64),
+                   p + "rach": rs, p + "rach_toa": np.float32(rt), p + "rach_gain": np.complex64(rg)})
+        kw["cosT"] = c
+        kw["sinT"] = s
+    tscb, dummy, rachb = r.gsm_bits()
+    kw.update(training_sequence=tscb, dummy_burst=dummy, rach_synch=rachb)
+    r52 = refbind.Ref(1, "52m")
+    kw["sps1_52m_mid_toa"] = np.array([r52.midamble(t)[1] for t in range(8)], np.float32)
+    # sinc(M_PI_F * d) on the 1/512 grid d in [-11, 11]: every argument interpolatePoint /
+    # delayVector can form on the path; float32(pi) * float32(d)
+    r = refbind.Ref(4)
+    k = np.arange(-11 * 512, 11 * 512 + 1)
+    d = (k / 512.0).astype(np.float32)
+    arg = (np.float32(np.pi) * d).astype(np.float32)
+    kw["sinc_grid"] = np.array([r.sinc(a) for a in arg], np.float32)
+    xs = np.random.default_rng(7).uniform(-40, 40, 4096).astype(np.float32)
+    kw["trig_x"] = xs
+    kw["trig_sin"] = np.array([r.sinLookup(x) for x in xs], np.float32)
+    kw["trig_cos"] = np.array([r.cosLookup(x) for x in xs], np.float32)
+    kw["trig_sinc"] = np.array([r.sinc(x) for x in xs], np.float32)
+    save("tables.npz", **kw)
+
+
+def gen_modulate():
+    rng = np.random.default_rng(11)
+    kw = {}
+    for sps in (1, 4):
+        r = refbind.Ref(sps)
+        tscb, dummy, rachb = r.gsm_bits()
+        bits = [dummy, normal_bits(rng, tscb, 3), rach_bits(rng, rachb), np.zeros(148, np.int8),
+                np.ones(148, np.int8), normal_bits(rng, tscb, 7)]
+        guards = [8, 9, 8, 9, 8, 9]
+        outs = [r.modulate(b, g) for b, g in zip(bits, guards)]
+        x, off, lens = pack(outs)
+        kw.update({"sps%d_bits" % sps: np.stack(bits), "sps%d_guard" % sps: np.array(guards, np.int32),
+                   "sps%d_x" % sps: x, "sps%d_off" % sps: off, "sps%d_len" % sps: lens})
+    save("modulate.npz", **kw)
+
+
+def synth_normal(r, rng, tscb, it, sps, sigmas=(0.0, 0.1, 0.3)):
+    tsc = it % 8
+    bits = normal_bits(rng, tscb, tsc)
+    x = r.modulate(bits, 8 + (it % 4 == 0))
+    A = rng.uniform(300, 3000) * np.exp(2j * np.pi * rng.uniform())
+    x = (x * np.complex64(A)).astype(np.complex64)
+    d = np.float32(rng.uniform(-1.5, 1.5))
+    x = r.delay_vector(x, d)
+    x = (x + awgn(rng, x.size, sigmas[it % len(sigmas)] * abs(A))).astype(np.complex64)
+    return x, bits, tsc, np.complex64(A), d
+
+
+def gen_normal(sps, n, name):
+    r = refbind.Ref(sps)
+    rng = np.random.default_rng(100 + sps)
+    tscb, _, _ = r.gsm_bits()
+    X, BITS, TSC, A, D = [], [], [], [], []
+    for it in range(n):
+        x, bits, tsc, a, d = synth_normal(r, rng, tscb, it, sps)
+        # edge cases the reference handles (SURVEY 8a' items 2, 12): silence, noise only,
+        # midamble far out of the search window, clipped amplitude
+        if it == n - 1: x = np.zeros_like(x)
+        if it == n - 2: x = awgn(rng, x.size, 50.0)
+        if it == n - 3: x = r.delay_vector(x, 30.0 * sps)
+        if it == n - 4: x = (x * np.complex64(1e-3)).astype(np.complex64)
+        X.append(x); BITS.append(bits); TSC.append(tsc); A.append(a); D.append(d)
+    ok, amp, toa, ptm = [], [], [], []
+    soft = np.zeros((n, 157), np.float32); nsoft = []
+    chan = np.zeros((n, 6 * sps), np.complex64); chan_len = []; chan_off = np.zeros(n, np.float32)
+    en_ok = []; en_pwr = []
+    for it, x in enumerate(X):
+        ra = r.analyze_traffic(x, TSC[it], 3.0, req_chan=True)
+        rb = r.analyze_traffic(x, TSC[it], 3.0, req_chan=False)
+        assert ra["ok"] == rb["ok"] and ra["amp"] == rb["amp"] and ra["toa"] == rb["toa"]
+        ok.append(ra["ok"]); amp.append(ra["amp"]); toa.append(ra["toa"])
+        chan_len.append(len(ra.get("chan", [])))
+        if "chan" in ra:
+            chan[it] = ra["chan"]; chan_off[it] = ra["chan_off"]
+        # demodulate whenever amp != 0 (also for undetected bursts: exercises the demod path)
+        if ra["amp"] != 0:
+            s = r.demodulate(x, ra["amp"], ra["toa"])
+            soft[it, :len(s)] = s; nsoft.append(len(s))
+        else:
+            nsoft.append(0)
+        e = r.energy_detect(x, 20 * sps, 250.0)
+        en_ok.append(e[0]); en_pwr.append(e[1])
+    x, off, lens = pack(X)
+    save(name, sps=sps, x=x, off=off, len=lens, bits=np.stack(BITS), tsc=np.array(TSC, np.int32),
+         tx_amp=np.array(A), tx_delay=np.array(D, np.float32),
+         ok=np.array(ok, np.uint8), amp=np.array(amp, np.complex64), toa=np.array(toa, np.float32),
+         soft=soft, nsoft=np.array(nsoft, np.int32), chan=chan, chan_len=np.array(chan_len, np.int32),
+         chan_off=chan_off, energy_ok=np.array(en_ok, np.uint8), energy_pwr=np.array(en_pwr, np.float32),
+         energy_thresh=np.float32(250.0))
+
+
+def gen_rach(sps, n, name):
+    r = refbind.Ref(sps)
+    rng = np.random.default_rng(200 + sps)
+    _, _, rachb = r.gsm_bits()
+    X, BITS, D = [], [], []
+    for it in range(n):
+        bits = rach_bits(rng, rachb)
+        x = r.modulate(bits, 8 + (it % 4 == 0))
+        A = rng.uniform(300, 3000) * np.exp(2j * np.pi * rng.uniform())
+        x = (x * np.complex64(A)).astype(np.complex64)
+        d = np.float32(rng.integers(0, 61) * sps + rng.uniform())
+        x = r.delay_vector(x, d)
+        x = (x + awgn(rng, x.size, (0.0, 0.1, 0.3)[it % 3] * abs(A))).astype(np.complex64)
+        if it == n - 1: x = np.zeros_like(x)
+        if it == n - 2: x = awgn(rng, x.size, 50.0)
+        if it == n - 3: x = r.delay_vector(x, 100.0 * sps)   # valley window runs off the end
+        X.append(x); BITS.append(bits); D.append(d)
+    ok, amp, toa = [], [], []
+    soft = np.zeros((n, 157), np.float32); nsoft = []
+    for it, x in enumerate(X):
+        rr = r.detect_rach(x, 5.0)
+        ok.append(rr["ok"]); amp.append(rr["amp"]); toa.append(rr["toa"])
+        if rr["amp"] != 0:
+            s = r.demodulate(x, rr["amp"], rr["toa"])
+            soft[it, :len(s)] = s; nsoft.append(len(s))
+        else:
+            nsoft.append(0)
+    x, off, lens = pack(X)
+    save(name, sps=sps, x=x, off=off, len=lens, bits=np.stack(BITS), tx_delay=np.array(D, np.float32),
+         ok=np.array(ok, np.uint8), amp=np.array(amp, np.complex64), toa=np.array(toa, np.float32),
+         soft=soft, nsoft=np.array(nsoft, np.int32))
+
+
+def gen_primitives():
+    rng = np.random.default_rng(300)
+    r = refbind.Ref(4)
+
+    def cn(n):
+        return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    kw = {}
+    i = 0
+    for span in range(5):
+        for (ar, br) in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+            for (na, nb) in [(40, 7), (40, 8), (7, 40), (1, 1)]:
+                a = cn(na); b = cn(nb)
+                if ar: a = a.real.astype(np.complex64)
+                if br: b = b.real.astype(np.complex64)
+                kw["conv%d_a" % i] = a; kw["conv%d_b" % i] = b
+                kw["conv%d_meta" % i] = np.array([span, ar, br], np.int32)
+                kw["conv%d_conv" % i] = r.convolve(a, b, span, ar, br)
+                kw["conv%d_corr" % i] = r.correlate(a, b, span, ar, br)
+                i += 1
+    kw["nconv"] = np.int32(i)
+    nd = 40
+    xs, ds, ys = [], [], []
+    for k in range(nd):
+        n = int(rng.integers(5, 300)); x = cn(n); d = np.float32(rng.uniform(-8, 8))
+        if k % 8 == 0: d = np.float32(np.round(d))
+        if k % 8 == 1: d = np.float32(np.round(d) + 0.005)
+        xs.append(x); ds.append(d); ys.append(r.delay_vector(x, d))
+    x, off, lens = pack(xs)
+    kw.update(delay_x=x, delay_off=off, delay_len=lens, delay_d=np.array(ds, np.float32), delay_y=np.concatenate(ys))
+    ixs = np.array([rng.uniform(-3, lens[k] + 3) for k in range(nd)], np.float32)
+    kw["interp_ix"] = ixs
+    kw["interp_y"] = np.array([r.interpolate_point(xs[k], ixs[k]) for k in range(nd)], np.complex64)
+    pk = [r.peak_detect(xs[k]) for k in range(nd)]
+    kw["peak_val"] = np.array([p[0] for p in pk], np.complex64)
+    kw["peak_idx"] = np.array([p[1] for p in pk], np.float32)
+    kw["peak_avg"] = np.array([p[2] for p in pk], np.float32)
+    pz = r.peak_detect(np.zeros(40, np.complex64))
+    kw["peak_zero"] = np.array([pz[0].real, pz[0].imag, pz[1], pz[2]], np.float32)
+    save("primitives.npz", **kw)
+
+
+def gen_resample():
+    rng = np.random.default_rng(400)
+    r = refbind.Ref(4)
+    rcv, snd = r.lpf_raw()
+    snd961 = np.concatenate([snd, [0.0]]).astype(np.float32)   # tap[960] = 0
+    kw = dict(rcvLPF_651_raw=rcv, sendLPF_961_raw=snd961)
+    kw["lpf651_gain260"] = r.create_lpf651(260.0)
+    kw["lpf651_gain65"] = r.create_lpf651(65.0)
+    kw["lpf651_gain96"] = r.create_lpf651(96.0)
+
+    def cn(n, scale=1.0):
+        return (scale * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    # RX direction as the radio interface drives it (radioInterface.cpp:230-246): 192 history +
+    # 864 new samples at 400 kS/s -> 65*sps/96; int16-valued samples
+    for sps in (1, 4):
+        x = np.round(cn(1056, 3000.0).view(np.float32)).view(np.complex64)
+        kw["rx%d_x" % sps] = x
+        kw["rx%d_y651" % sps] = r.polyphase_resample(x, 65 * sps, 96, kw["lpf651_gain260"] if sps == 4 else kw["lpf651_gain65"])
+    # the RX call site really uses the 961 table with gain 65*sps (radioInterface.cpp:233)
+    g = np.float32(260.0)
+    s = snd961.astype(np.float64).sum()
+    lpf961 = (snd961 * np.float32(g / s)).astype(np.float32)
+    kw["lpf961_gain260"] = lpf961
+    kw["rx4_y961"] = r.polyphase_resample(kw["rx4_x"], 260, 96, lpf961)
+    # TX direction (radioInterface.cpp:137-144): 96 : 65*sps with the 651 table, gain 96
+    x = cn(2 * 260 + 625 * 4)
+    kw["tx4_x"] = x
+    kw["tx4_y"] = r.polyphase_resample(x, 96, 260, kw["lpf651_gain96"])
+    save("resample.npz", **kw)
+
+
+def gen_dfe():
+    """Config 5: Transceiver52M pullRadioVector flow at sps=1 (Transceiver52M/Transceiver.cpp:268-407):
+    energyDetect(stride 4) -> analyzeTrafficBurst(maxTOA=4, requestChannel) -> scale chan by 1/amp ->
+    designDFE(Nf=7) -> scale burst by 1/amp -> equalizeBurst(TOA - chanOffset).  Inputs are integers
+    with |v| <= 2048 (fp16-exact)."""
+    r = refbind.Ref(1, "52m")
+    rng = np.random.default_rng(500)
+    tscb, _, _ = r.gsm_bits()
+    n = 64
+    X, BITS, TSC = [], [], []
+    for it in range(n):
+        tsc = it % 8
+        bits = normal_bits(rng, tscb, tsc)
+        x = r.modulate(bits, 8 + (it % 4 == 0))
+        A = rng.uniform(200, 900) * np.exp(2j * np.pi * rng.uniform())
+        x = (x * np.complex64(A)).astype(np.complex64)
+        x = r.delay_vector(x, np.float32(rng.uniform(-1.0, 1.0)))
+        ch = np.array([1, 0.4 + 0.2j, 0], np.complex64) if it % 2 else np.array([1, 0, 0], np.complex64)
+        x = r.convolve(x, ch, refbind.START_ONLY)
+        x = (x + awgn(rng, x.size, (0.01, 0.05, 0.1)[it % 3] * abs(A))).astype(np.complex64)
+        x = np.clip(np.round(x.view(np.float32)), -2048, 2048).astype(np.float32).view(np.complex64)
+        X.append(x); BITS.append(bits); TSC.append(tsc)
+    ok, amp, toa, en = [], [], [], []
+    chan = np.zeros((n, 6), np.complex64); chan_off = np.zeros(n, np.float32); chan_len = []
+    W = np.zeros((n, 7), np.complex64); Bf = np.zeros((n, 5), np.complex64)
+    soft = np.zeros((n, 157), np.float32); snr = np.zeros(n, np.float32)
+    thr = np.float32(10.0)
+    for it, x in enumerate(X):
+        en.append(r.energy_detect(x, 20, thr))
+        ra = r.analyze_traffic(x, TSC[it], 3.0, req_chan=True, max_toa=4)
+        ok.append(ra["ok"]); amp.append(ra["amp"]); toa.append(ra["toa"])
+        chan_len.append(len(ra.get("chan", [])))
+        if ra["ok"]:
+            a = ra["amp"]
+            snr[it] = np.float32(np.float32(a.imag * a.imag + a.real * a.real) / np.float32(thr * thr + np.float32(1.0)))
+            chan[it] = ra["chan"]; chan_off[it] = ra["chan_off"]
+            # scaleVector(*channelResp, complex(1,0)/amplitude): 1/amp formed by the reference itself
+            n2 = np.float32(a.imag * a.imag + a.real * a.real)
+            inv = complex(np.float32(a.real / n2), np.float32(-a.imag / n2))
+            chn = r.scale_vector(ra["chan"], inv)
+            w, b = r.design_dfe(chn, float(snr[it]), 7)
+            W[it] = w; Bf[it, :len(b)] = b
+            xs = r.scale_vector(x, inv)
+            s = r.equalize(xs, np.float32(ra["toa"] - ra["chan_off"]), w, b)
+            soft[it, :len(s)] = s
+    x, off, lens = pack(X)
+    save("dfe_52m_sps1.npz", x=x, off=off, len=lens, bits=np.stack(BITS), tsc=np.array(TSC, np.int32),
+         energy_thresh=thr, energy_ok=np.array([e[0] for e in en], np.uint8),
+         energy_pwr=np.array([e[1] for e in en], np.float32),
+         ok=np.array(ok, np.uint8), amp=np.array(amp, np.complex64), toa=np.array(toa, np.float32),
+         chan=chan, chan_len=np.array(chan_len, np.int32), chan_off=chan_off, snr=snr, w=W, b=Bf, soft=soft)
+    nerr = sum(int(((soft[i, :148] > 0.5) != BITS[i]).sum()) for i in range(n) if ok[i])
+    print("  dfe: detected %d/%d, hard-bit errors after DFE: %d" % (sum(ok), n, nerr))
+
+
+def gen_config1():
+    """BASELINE config 1: the sigProcLibTest.cpp call sequence (Transceiver/sigProcLibTest.cpp:29-181)
+    at sps=1 on the Transceiver/ variant, CommSig->BitVector, SoftSig->SoftVector.
+    The 961-tap LPF is built here with tap[960]=0 instead of createLPF(...,961,...) (SURVEY a21:
+    that call reads one float past sendLPF_961[])."""
+    sps = 1
+    r = refbind.Ref(sps)
+    rng = np.random.default_rng(600)
+    tscb, _, rachb = r.gsm_bits()
+    kw = {}
+    # RACH leg (sigProcLibTest.cpp:38-53): "01010101" + sync + 99 zeros, guard 9
+    rb = np.zeros(148, np.int8); rb[:8] = [0, 1, 0, 1, 0, 1, 0, 1]; rb[8:49] = rachb
+    xr = r.modulate(rb, 9)
+    rr = r.detect_rach(xr, 5.0)
+    kw.update(rach_bits=rb, rach_x=xr, rach_ok=np.uint8(rr["ok"]), rach_amp=rr["amp"], rach_toa=rr["toa"])
+    # normal-burst leg (sigProcLibTest.cpp:76-167)
+    pay = np.array([int(c) for c in "0000101010100111110010101010010110101110011000111001101010000"], np.int8)
+    bits = np.concatenate([pay, tscb[0], pay]).astype(np.int8)
+    x = r.modulate(bits, 0)                                     # :84-85 guard 0
+    rcv, snd = r.lpf_raw()
+    snd961 = np.concatenate([snd, [0.0]]).astype(np.float32)
+    lpf_tx = r.create_lpf651(96.0)                              # :91  createLPF(.,651,P=96)
+    ssum = snd961.astype(np.float64).sum()
+    lpf_rx = (snd961 * np.float32(np.float32(65.0) / ssum)).astype(np.float32)   # :98 createLPF(.,961,P=65)
+    up = r.polyphase_resample(x, 96, 65, lpf_tx)                # :105-108
+    dn = r.polyphase_resample(up, 65, 96, lpf_rx)               # :112-113
+    dl = r.delay_vector(dn, np.float32(6.932))                  # :125
+    ch = np.array([9000.0, np.float32(0.4) * np.float32(9000.0), 0, np.float32(-1.2) * 0], np.complex64)  # :133-137
+    rx = r.convolve(dl, ch, refbind.NO_DELAY)                   # :139
+    ra = r.analyze_traffic(rx, 0, 8.0, req_chan=True)           # :146 (before the noise is added)
+    noise_pwr = 0.001 / np.float32(np.sqrt(np.float32(2)))      # :143
+    rxn = (rx + awgn(rng, rx.size, float(np.sqrt(2 * noise_pwr)))).astype(np.complex64)   # :147
+    soft = r.demodulate(rxn, ra["amp"], ra["toa"])              # :152
+    kw.update(bits=bits, mod=x, up=up, dn=dn, delayed=dl, rx=rx, rx_noisy=rxn, ok=np.uint8(ra["ok"]),
+              amp=ra["amp"], toa=ra["toa"], chan=ra.get("chan", np.zeros(0, np.complex64)),
+              chan_off=np.float32(ra.get("chan_off", 0)), soft=soft, lpf_tx=lpf_tx, lpf_rx=lpf_rx)
+    if ra["ok"]:
+        snr = np.float32(1.0 / noise_pwr)
+        w, b = r.design_dfe(ra["chan"], float(snr), 7)          # :159
+        eq = r.equalize(rxn, np.float32(ra["toa"] - ra["chan_off"]), w, b)   # :164
+        kw.update(dfe_snr=snr, dfe_w=w, dfe_b=b, eq_soft=eq)
+        print("  config1: rach ok=%s toa=%.4f; TSC detect ok, TOA %.4f amp %s; slicer bit errors %d, DFE bit errors %d" % (
+            rr["ok"], rr["toa"], ra["toa"], ra["amp"], int(((soft[:148] > 0.5) != bits).sum()),
+            int(((eq[:148] > 0.5) != bits).sum())))
+    save("config1_loopback.npz", **kw)
+
+
+if __name__ == "__main__":
+    if not refbind.available():
+        sys.exit("oracle/_ref not built: run `make -C oracle ref` in the build container")
+    gen_tables()
+    gen_modulate()
+    gen_normal(4, 96, "normal_sps4.npz")
+    gen_normal(1, 64, "normal_sps1.npz")
+    gen_rach(4, 48, "rach_sps4.npz")
+    gen_rach(1, 32, "rach_sps1.npz")
+    gen_primitives()
+    gen_resample()
+    gen_dfe()
+    gen_config1()

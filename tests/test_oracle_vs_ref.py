@@ -1,0 +1,125 @@
+"""Randomised bit-exact comparison of the CPU oracle against the REAL reference library
+(oracle/_ref, built in place from /root/reference by `make -C oracle ref`).  Runs only where
+that library exists (the build container); the golden-vector tests cover the GPU box."""
+import numpy as np
+import pytest
+
+import oraclebind
+import refbind
+from util import assert_beq
+
+pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built (reference absent)")
+
+
+def cn(rng, n):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+def awgn(rng, n, s):
+    return (s * cn(rng, n) / np.sqrt(2)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("sps", [1, 2, 4])
+def test_burst_paths(sps):
+    rng = np.random.default_rng(1000 + sps)
+    r = refbind.Ref(sps); o = oraclebind.Oracle(sps)
+    tscb, _, rachb = r.gsm_bits()
+    for it in range(160):
+        tsc = it % 8
+        bits = rng.integers(0, 2, 148).astype(np.int8); bits[61:87] = tscb[tsc]
+        x = r.modulate(bits, 8 + (it % 4 == 0))
+        assert_beq(x, o.modulate(bits, 8 + (it % 4 == 0)), "modulate")
+        A = rng.uniform(300, 3000) * np.exp(2j * np.pi * rng.uniform())
+        x = r.delay_vector((x * np.complex64(A)).astype(np.complex64), np.float32(rng.uniform(-2.5, 2.5)))
+        x = (x + awgn(rng, x.size, (0, 0.1, 0.3, 1.0)[it % 4] * abs(A))).astype(np.complex64)
+        ra = r.analyze_traffic(x, tsc, 3.0, req_chan=bool(it & 1)); oa = o.analyze_traffic(x, tsc, 3.0, req_chan=bool(it & 1))
+        assert ra["ok"] == oa["ok"] and ra["amp"] == oa["amp"] and ra["toa"] == oa["toa"], (it, ra, oa)
+        assert ("chan" in ra) == ("chan" in oa)
+        if "chan" in ra:
+            assert_beq(ra["chan"], oa["chan"]); assert ra["chan_off"] == oa["chan_off"]
+        if ra["amp"] != 0:
+            assert_beq(r.demodulate(x, ra["amp"], ra["toa"]), o.demodulate(x, oa["amp"], oa["toa"]), "demod")
+        assert r.energy_detect(x, 20 * sps, 100.0) == o.energy_detect(x, 20 * sps, 100.0)
+    for it in range(60):
+        bits = np.zeros(148, np.int8); bits[:8] = [0, 1, 0, 1, 0, 1, 0, 1]; bits[8:49] = rachb
+        bits[49:85] = rng.integers(0, 2, 36)
+        x = r.modulate(bits, 8 + (it % 4 == 0))
+        A = rng.uniform(300, 3000) * np.exp(2j * np.pi * rng.uniform())
+        x = r.delay_vector((x * np.complex64(A)).astype(np.complex64), np.float32(rng.integers(0, 61) * sps + rng.uniform()))
+        x = (x + awgn(rng, x.size, (0, 0.1, 0.3, 2.0)[it % 4] * abs(A))).astype(np.complex64)
+        rr = r.detect_rach(x); ro = o.detect_rach(x)
+        assert rr["ok"] == ro["ok"] and rr["amp"] == ro["amp"] and rr["toa"] == ro["toa"], (it, rr, ro)
+        if rr["amp"] != 0:
+            assert_beq(r.demodulate(x, rr["amp"], rr["toa"]), o.demodulate(x, ro["amp"], ro["toa"]), "demod")
+
+
+def test_primitives_random():
+    rng = np.random.default_rng(2000)
+    r = refbind.Ref(4); o = oraclebind.Oracle(4)
+    for span in range(5):
+        for (ar, br) in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+            for (na, nb) in [(50, 7), (50, 8), (7, 50), (30, 30), (1, 1), (5, 1)]:
+                a = cn(rng, na); b = cn(rng, nb)
+                if ar: a = a.real.astype(np.complex64)
+                if br: b = b.real.astype(np.complex64)
+                assert_beq(r.convolve(a, b, span, ar, br), o.convolve(a, b, span, ar, br))
+                assert_beq(r.correlate(a, b, span, ar, br), o.correlate(a, b, span, ar, br))
+    for it in range(200):
+        n = int(rng.integers(5, 700)); x = cn(rng, n); d = np.float32(rng.uniform(-8, 8))
+        if it % 10 == 0: d = np.float32(np.round(d))
+        if it % 10 == 1: d = np.float32(np.round(d) + 0.005)
+        assert_beq(r.delay_vector(x, d), o.delay_vector(x, d))
+        ix = np.float32(rng.uniform(-3, n + 3))
+        assert r.interpolate_point(x, ix) == o.interpolate_point(x, ix)
+        assert r.peak_detect(x) == o.peak_detect(x)
+    xs = rng.uniform(-60, 60, 3000).astype(np.float32)
+    for x in xs:
+        assert r.sinc(x) == o.sinc(x) and r.sinLookup(x) == o.sinLookup(x) and r.cosLookup(x) == o.cosLookup(x)
+
+
+def test_resample_random():
+    rng = np.random.default_rng(3000)
+    r = refbind.Ref(4); o = oraclebind.Oracle(4)
+    rcv, snd = r.lpf_raw()
+    snd961 = np.concatenate([snd, [0]]).astype(np.float32)
+    assert_beq(r.create_lpf651(260.0), o.create_lpf(rcv, 260.0))
+    lrx = o.create_lpf(snd961, 260.0); ltx = o.create_lpf(rcv, 96.0)
+    for (n, P, Q, l) in [(1056, 260, 96, lrx), (1056, 260, 96, o.create_lpf(rcv, 260.0)), (3000, 96, 260, ltx),
+                         (300, 65, 96, ltx), (100, 3, 2, ltx[:101].copy()), (17, 260, 96, lrx)]:
+        x = cn(rng, n)
+        assert_beq(r.polyphase_resample(x, P, Q, l), o.polyphase_resample(x, P, Q, l), "resample %d %d %d" % (n, P, Q))
+
+
+@pytest.mark.parametrize("variant", ["", "52m"])
+def test_dfe_flow(variant):
+    rng = np.random.default_rng(4000)
+    r = refbind.Ref(1, variant); o = oraclebind.Oracle(1, variant52m=(variant == "52m"))
+    for t in range(8):
+        sq, toa, g = r.midamble(t)
+        assert_beq(sq, o.mid[t]); assert np.float32(toa) == o.mid_toa[t] and np.complex64(g) == o.mid_gain[t]
+    tscb, _, _ = r.gsm_bits()
+    for it in range(150):
+        tsc = it % 8
+        bits = rng.integers(0, 2, 148).astype(np.int8); bits[61:87] = tscb[tsc]
+        x = r.modulate(bits, 8 + (it % 4 == 0))
+        A = rng.uniform(300, 2000) * np.exp(2j * np.pi * rng.uniform())
+        x = r.delay_vector((x * np.complex64(A)).astype(np.complex64), np.float32(rng.uniform(-1.5, 1.5)))
+        ch = np.array([1, 0.4 + 0.2j, 0], np.complex64) if it % 2 else np.array([1, 0, 0.3j], np.complex64)
+        x = r.convolve(x, ch, refbind.START_ONLY)
+        x = (x + awgn(rng, x.size, (0.02, 0.1, 0.2)[it % 3] * abs(A))).astype(np.complex64)
+        mt = (0, 4, 6)[it % 3]
+        ra = r.analyze_traffic(x, tsc, 3.0, req_chan=True, max_toa=mt)
+        oa = o.analyze_traffic(x, tsc, 3.0, req_chan=True, max_toa=mt)
+        assert ra["ok"] == oa["ok"] and ra["amp"] == oa["amp"] and ra["toa"] == oa["toa"], (it, ra, oa)
+        assert r.energy_detect(x, 20, 5.0) == o.energy_detect(x, 20, 5.0)
+        if "chan" in ra:
+            assert_beq(ra["chan"], oa["chan"]); assert ra["chan_off"] == oa["chan_off"]
+            inv = 1 / complex(ra["amp"])
+            chn = r.scale_vector(ra["chan"], inv)
+            assert_beq(chn, o.scale_vector(ra["chan"], inv))
+            snr = float(abs(ra["amp"]) ** 2 / 101.0)
+            d1 = r.design_dfe(chn, snr, 7); d2 = o.design_dfe(chn, snr, 7)
+            assert_beq(d1[0], d2[0]); assert_beq(d1[1], d2[1])
+            xs = r.scale_vector(x, inv)
+            t = np.float32(ra["toa"] - ra["chan_off"])
+            assert_beq(r.equalize(xs, t, d1[0], d1[1]), o.equalize(xs, t, d1[0], d1[1]), "equalize")
