@@ -1,0 +1,231 @@
+/*
+ * trxsig.h -- C-ABI of libtrxsig: the MI355X (gfx950) burst-processing path of the
+ * OpenBTS software transceiver.
+ *
+ * This is the drop-in boundary for the reference's `sigProcLib.h` seam
+ * (Transceiver/sigProcLib.h:101-384) as it is driven by
+ * Transceiver::pullRadioVector / addRadioVector (Transceiver/Transceiver.cpp:271-410,
+ * 100-113) and RadioInterface::pullBuffer / pushBuffer (Transceiver/radioInterface.cpp:
+ * 197-273, 123-194).  Plain pointers and sizes only; no C++ or torch types.  Every entry
+ * point names the reference interface it replaces.
+ *
+ * Conventions
+ *  - complex samples are interleaved float32 {re, im} (the layout of the reference's
+ *    Complex<float>, Transceiver/Complex.h:39-44, inside Vector<complex>).
+ *  - "d_" pointers are DEVICE pointers on the context's GPU; "h_" pointers are host.
+ *  - a batch is B bursts packed in one sample array: burst b occupies
+ *    samples[offset[b] .. offset[b]+length[b]).  offset[b] must be even (16-byte
+ *    aligned bursts); length[b] a multiple of sps with 92*sps <= length[b] <= 157*sps
+ *    (the reference's own limits: sigProcLib.cpp:215-216, 951, 1045-1050).
+ *  - all work is enqueued on the context's HIP stream (trxsig_set_stream) and is
+ *    asynchronous; the library never synchronises unless the entry point's comment says so.
+ *  - return value: 0 on success, negative TRXSIG_E* on error; no exceptions cross the ABI.
+ *  - results are bit-identical to the reference's float32 arithmetic (see DESIGN.md,
+ *    "Numerical contract"), except where an entry point's comment states a tolerance.
+ *  - There is NO CPU fallback: without a gfx950 device trxsig_create fails.
+ */
+#ifndef TRXSIG_H
+#define TRXSIG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRXSIG_ABI_VERSION 1
+
+typedef struct trxsig_ctx trxsig_ctx;
+typedef struct { float re, im; } trxsig_c32;
+
+enum {
+  TRXSIG_OK = 0,
+  TRXSIG_EINVAL = -1,   /* bad argument */
+  TRXSIG_ENODEV = -2,   /* no usable gfx950 device / HIP runtime error at create */
+  TRXSIG_EHIP = -3,     /* HIP runtime error (see trxsig_last_error) */
+  TRXSIG_ENOMEM = -4
+};
+
+/* per-burst status byte written by the detect entry points */
+enum {
+  TRXSIG_F_ENERGY = 1,   /* energyDetect() passed           (sigProcLib.cpp:916-932)      */
+  TRXSIG_F_DETECT = 2,   /* correlator peak/valley test passed (sigProcLib.cpp:913,1035)   */
+  TRXSIG_F_BADLEN = 128  /* length[b]/offset[b] violates the conventions above; burst skipped */
+};
+
+/* ---- library set-up: sigProcLibSetup / sigProcLibDestroy (sigProcLib.h:110-113) -------------
+ * trxsig_create = generateGSMPulse(2,sps) + sigProcLibSetup(sps) + generateRACHSequence +
+ * generateMidamble(0..7) (the calls of Transceiver.cpp:62-64, 424, 553), built on the host and
+ * uploaded once.  device = HIP device ordinal.  sps in {1,2,4}. */
+int  trxsig_abi_version(void);
+int  trxsig_create(trxsig_ctx **out, int device, int sps);
+void trxsig_destroy(trxsig_ctx *ctx);
+int  trxsig_sps(const trxsig_ctx *ctx);
+int  trxsig_device(const trxsig_ctx *ctx);
+/* stream = hipStream_t (NULL = the device's null stream).  One context per calling thread. */
+int  trxsig_set_stream(trxsig_ctx *ctx, void *hip_stream);
+/* hipStreamSynchronize on the context's stream */
+int  trxsig_synchronize(trxsig_ctx *ctx);
+const char *trxsig_last_error(const trxsig_ctx *ctx);
+/* pre-size the internal device workspace for batches up to max_bursts (allocates; call outside
+ * any timed or graph-captured region).  The batch entry points grow it on demand otherwise. */
+int  trxsig_reserve(trxsig_ctx *ctx, int max_bursts);
+
+/* ---- constant tables ------------------------------------------------------------------------
+ * The constant tables (trig lookup, GMSK rotation, pulse, 8 midambles, RACH sequence, sinc grid)
+ * live in ONE device blob so that a multi-GPU job can build them on rank 0 and broadcast them
+ * (RCCL ncclBroadcast over xGMI) instead of rebuilding per rank: SURVEY 8e.
+ *   trxsig_tables_bytes   size of the blob
+ *   trxsig_tables_device  device pointer of this context's blob
+ *   trxsig_create_from_tables  build a context on `device` from a blob that is already in that
+ *                         device's memory (d_blob); copies it, validates header + checksum.
+ *   trxsig_tables_export  copy the blob to host memory (synchronises)
+ *   trxsig_tables_build_host  build the blob into host memory without touching any device
+ *                         (what rank 0 uploads; also lets the table construction be tested on CPU) */
+size_t trxsig_tables_bytes(int sps);
+int    trxsig_tables_build_host(int sps, void *h_buf, size_t cap);
+void  *trxsig_tables_device(trxsig_ctx *ctx);
+int    trxsig_create_from_tables(trxsig_ctx **out, int device, const void *d_blob, size_t bytes);
+int    trxsig_tables_export(trxsig_ctx *ctx, void *h_buf, size_t cap);
+
+/* host-side view of the tables (for the C++ facade and tests); pointers valid for ctx lifetime */
+typedef struct {
+  int sps;
+  const float *cos_table;            /* 1025: cosTable  (sigProcLib.cpp:39,207-212) */
+  const float *sin_table;            /* 1025: sinTable                              */
+  const trxsig_c32 *gmsk_rotation;   /* 157*sps: GMSKRotation (sigProcLib.cpp:214-225) */
+  const trxsig_c32 *gmsk_reverse;    /* 157*sps: GMSKReverseRotation                   */
+  const float *gsm_pulse;            /* 2*sps+1: generateGSMPulse(2,sps) (sigProcLib.cpp:411-430) */
+  const trxsig_c32 *midamble[8];     /* 16*sps each: gMidambles[t]->sequence (sigProcLib.cpp:779-828) */
+  float midamble_toa[8];
+  trxsig_c32 midamble_gain[8];
+  const trxsig_c32 *rach;            /* 41*sps: gRACHSequence->sequence (sigProcLib.cpp:830-857) */
+  float rach_toa;
+  trxsig_c32 rach_gain;
+} trxsig_tables_view;
+int trxsig_tables_view_get(const trxsig_ctx *ctx, trxsig_tables_view *out);
+
+/* ---- RX hot path ----------------------------------------------------------------------------
+ * trxsig_detect_demod_normal_batch
+ *   For every burst: energyDetect(burst, 20*sps, energy_thresh) -> analyzeTrafficBurst(burst, tsc,
+ *   detect_thresh, sps, &amp, &TOA) -> on detection demodulateBurst(burst, pulse, sps, amp, TOA):
+ *   the TSC leg of Transceiver::pullRadioVector (Transceiver.cpp:298, 327-335, 385-388 /
+ *   Transceiver52M/Transceiver.cpp:382-389) with the sequential threshold state machine left to
+ *   the caller (SURVEY 8a' item 14).  Replaces sigProcLib.h:246-249, 277-285, 316-320.
+ *
+ *   d_flags[b]   status byte (TRXSIG_F_*)
+ *   d_amp[b]     amplitude estimate (0 when the reference returns "bogus result")
+ *   d_toa[b]     time of arrival in samples
+ *   d_avgpwr[b]  energyDetect's avgPwr                                   (may be NULL)
+ *   d_soft       B x soft_stride floats; the first nsoft (<= min(157, length/sps)) soft bits of
+ *                demodulateBurst for detected bursts, zeros otherwise
+ *   d_hard       B x soft_stride bytes, SoftVector::bit() = soft > 0.5F (BitVector.h:415-420)
+ *                                                                        (may be NULL)
+ *   Bursts whose energy test fails are reported undetected (amp = 0, TOA = 0), as the reference
+ *   does not run the correlator for them (Transceiver.cpp:298-306).  energy_thresh < 0 disables
+ *   the energy gate (every burst is analysed; TRXSIG_F_ENERGY is set). */
+int trxsig_detect_demod_normal_batch(trxsig_ctx *ctx,
+                                     const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                     const int32_t *d_length, int B,
+                                     int tsc, float detect_thresh, float energy_thresh,
+                                     uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                     float *d_avgpwr,
+                                     float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+
+#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
+/* trxsig_detect_demod_rach_batch: same for access bursts: detectRACHBurst(burst, detect_thresh,
+ *   sps, &amp, &TOA) + demodulateBurst (Transceiver.cpp:362-366, 385-388; sigProcLib.h:263-267).
+ *   Tolerance: amp/TOA/soft/hard are bit-identical; the detect flag can differ from the
+ *   reference only when the reference's peak-to-valley ratio is within 1e-5 (relative) of
+ *   detect_thresh (the valley power is summed in a different order). */
+int trxsig_detect_demod_rach_batch(trxsig_ctx *ctx,
+                                   const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                   const int32_t *d_length, int B,
+                                   float detect_thresh, float energy_thresh,
+                                   uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                   float *d_avgpwr,
+                                   float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+
+#endif /* TRXSIG_NEXT */
+
+/* trxsig_demodulate_batch: demodulateBurst alone with caller-supplied amp/TOA
+ *   (sigProcLib.h:316-320; used for RACH after detect and by TRANSMIT_LOGGING,
+ *   Transceiver.cpp:115-136).  d_enable[b]==0 skips burst b (zeros out); NULL = all. */
+int trxsig_demodulate_batch(trxsig_ctx *ctx,
+                            const trxsig_c32 *d_samples, const int32_t *d_offset,
+                            const int32_t *d_length, int B,
+                            const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
+                            float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+
+#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
+/* ---- TX path: modulateBurst (sigProcLib.h:171-174) as called by Transceiver::addRadioVector
+ *   (Transceiver.cpp:100-113): bits -> GMSK-rotated impulses -> pulse shaping, then scaleVector by
+ *   a real gain.  d_bits: B x 148 bytes (only bit 0 is used, BitVector.cpp:54-63); d_guard[b] =
+ *   guard period in symbols (8 or 9); output burst b at d_out[d_out_offset[b]..] with
+ *   sps*(148+guard) samples; d_gain may be NULL (no scaling pass, as generateMidamble's use). */
+int trxsig_modulate_batch(trxsig_ctx *ctx, const uint8_t *d_bits, const int32_t *d_guard,
+                          const float *d_gain, int B,
+                          trxsig_c32 *d_out, const int32_t *d_out_offset);
+
+/* ---- rate conversion: polyphaseResampleVector (sigProcLib.h:352-354) -------------------------
+ * S independent streams (one per ARFCN).  Stream s: input d_in + s*in_stride (n_in samples),
+ * output d_out + s*out_stride, ceil(n_in*P/Q) samples each, exactly the reference's indexing
+ * (sigProcLib.cpp:1171-1205).  d_lpf: L real taps on the device (createLPF output). */
+int trxsig_resample_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, int n_in, int64_t in_stride,
+                          int S, int P, int Q, const float *d_lpf, int L,
+                          trxsig_c32 *d_out, int64_t out_stride);
+int trxsig_resample_out_len(int n_in, int P, int Q);
+
+/* int16 I/Q <-> float: RadioInterface::unUSRPifyVector / USRPifyVector
+ *   (radioInterface.cpp:74-116).  swap_iq = 1 reproduces the non-SWLOOPBACK I/Q flip on RX. */
+int trxsig_unpack_int16(trxsig_ctx *ctx, const int16_t *d_iq, int64_t n_samples, int swap_iq,
+                        trxsig_c32 *d_out);
+int trxsig_pack_int16(trxsig_ctx *ctx, const trxsig_c32 *d_in, int64_t n_samples, int16_t *d_iq);
+
+/* ---- equaliser: analyzeTrafficBurst(requestChannel) + designDFE + equalizeBurst ---------------
+ *   (sigProcLib.h:277-285, 366-370, 382-386; Transceiver.cpp:327-349, 391-396; the windowed
+ *   Transceiver52M form with maxTOA when variant52m != 0: Transceiver52M/sigProcLib.cpp:966-1076).
+ *   sps must be 1 for equalizeBurst ("Assumes symbol-rate sampling", sigProcLib.cpp:1342).
+ *   Per burst: detect + channel estimate; scale channel by 1/amp; SNR = |amp|^2/(thr^2+1);
+ *   designDFE(chan, SNR, 7); equalizeBurst(burst/amp, TOA-chanOffset, w, b).
+ *   d_w: B x 7, d_b: B x 5 complex (may be NULL). */
+int trxsig_equalize_normal_batch(trxsig_ctx *ctx,
+                                 const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                 const int32_t *d_length, int B,
+                                 int tsc, float detect_thresh, float energy_thresh,
+                                 int variant52m, int max_toa,
+                                 uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                 trxsig_c32 *d_w, trxsig_c32 *d_b,
+                                 float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+
+#endif /* TRXSIG_NEXT */
+
+/* ---- convenience: host-buffer single-call wrappers (copy in, run, copy out, synchronise).
+ *   These exist so Transceiver::pullRadioVector can keep calling one burst at a time; they are
+ *   PCIe-inclusive and are never what bench.py times. */
+int trxsig_detect_demod_normal_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples,
+                                    const int32_t *h_offset, const int32_t *h_length, int B,
+                                    int tsc, float detect_thresh, float energy_thresh,
+                                    uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
+                                    float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
+#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
+int trxsig_detect_demod_rach_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples,
+                                  const int32_t *h_offset, const int32_t *h_length, int B,
+                                  float detect_thresh, float energy_thresh,
+                                  uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
+                                  float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
+int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *h_guard,
+                         const float *h_gain, int B, trxsig_c32 *h_out, const int32_t *h_out_offset,
+                         int64_t out_samples);
+
+#endif /* TRXSIG_NEXT */
+
+/* ---- measurement helpers (HIP events on the context's stream; used by bench.py) --------------- */
+int trxsig_timer_start(trxsig_ctx *ctx);
+int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRXSIG_H */

@@ -1,0 +1,179 @@
+"""openbts-ttsou_amd: MI355X-native burst processing for the OpenBTS software transceiver.
+
+The product is the C-ABI shared library `libtrxsig.so` (include/trxsig.h; sources in csrc/).  This
+Python module is plumbing only: a ctypes binding used by tests/ and bench.py to hand torch device
+buffers and streams to the library.  There is no CPU fallback anywhere in this package: loading
+fails loudly if the library is missing, and creating a context fails without a gfx950 GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrxsig.so")
+
+F_ENERGY, F_DETECT, F_BADLEN = 1, 2, 128
+
+
+class TrxSigError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/ into libtrxsig.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libtrxsig.so.  torch (if used) must be imported first so that the library binds to
+    the HIP runtime torch already loaded (same libamdhip64.so.7 soname) and device pointers are
+    shared between the two."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrxSigError("libtrxsig.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C openbts-ttsou_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+        L.trxsig_abi_version.restype = i32
+        L.trxsig_create.argtypes = [C.POINTER(vp), i32, i32]
+        L.trxsig_create_from_tables.argtypes = [C.POINTER(vp), i32, vp, C.c_size_t]
+        L.trxsig_destroy.argtypes = [vp]; L.trxsig_destroy.restype = None
+        L.trxsig_sps.argtypes = [vp]; L.trxsig_device.argtypes = [vp]
+        L.trxsig_set_stream.argtypes = [vp, vp]
+        L.trxsig_synchronize.argtypes = [vp]
+        L.trxsig_last_error.argtypes = [vp]; L.trxsig_last_error.restype = C.c_char_p
+        L.trxsig_reserve.argtypes = [vp, i32]
+        L.trxsig_tables_bytes.argtypes = [i32]; L.trxsig_tables_bytes.restype = C.c_size_t
+        L.trxsig_tables_device.argtypes = [vp]; L.trxsig_tables_device.restype = vp
+        L.trxsig_tables_build_host.argtypes = [i32, vp, C.c_size_t]
+        L.trxsig_tables_export.argtypes = [vp, vp, C.c_size_t]
+        L.trxsig_detect_demod_normal_batch.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp,
+                                                       i32, i32]
+        L.trxsig_demodulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32]
+        L.trxsig_timer_start.argtypes = [vp]
+        L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
+        _lib = L
+    return _lib
+
+
+def tables_dtype():
+    """numpy view of the TrxTables blob (csrc/trxsig_tables.h)."""
+    import numpy as np
+    return np.dtype([("magic", "<u4"), ("version", "<u4"), ("sps", "<u4"), ("bytes", "<u4"), ("checksum", "<u4"),
+                     ("pad0", "<u4", 3), ("cosT", "<f4", 1028), ("sinT", "<f4", 1028), ("rot", "<c8", 628),
+                     ("rev", "<c8", 628), ("pulse", "<f4", 12), ("mid", "<c8", (8, 64)), ("mid_toa", "<f4", 8),
+                     ("mid_gain", "<c8", 8), ("rach", "<c8", 164), ("rach_toa", "<f4"), ("pad1", "<f4"),
+                     ("rach_gain", "<c8"), ("mid_ctap", "<c8", (8, 16)), ("sinc_grid", "<f4", (512, 24))])
+
+
+def build_tables_host(sps):
+    """The constant-table blob built on the host (no device needed): uint8 array."""
+    import numpy as np
+    n = lib().trxsig_tables_bytes(sps)
+    buf = np.zeros(n, np.uint8)
+    rc = lib().trxsig_tables_build_host(sps, buf.ctypes.data, n)
+    if rc != 0:
+        raise TrxSigError("trxsig_tables_build_host(%d) failed (%d)" % (sps, rc))
+    return buf
+
+
+def _ptr(t):
+    """torch tensor / int / None -> device address."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+class TrxSig:
+    """One library context = one GPU + one stream (trxsig.h)."""
+
+    def __init__(self, sps=4, device=0, tables_blob=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        if tables_blob is None:
+            rc = self.L.trxsig_create(C.byref(self.h), device, sps)
+        else:
+            rc = self.L.trxsig_create_from_tables(C.byref(self.h), device, _ptr(tables_blob),
+                                                  tables_blob.numel() * tables_blob.element_size())
+        if rc != 0:
+            raise TrxSigError("trxsig_create failed (%d): no gfx950 device or bad arguments; "
+                              "this library has no CPU fallback" % rc)
+        self.sps = self.L.trxsig_sps(self.h)
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.trxsig_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise TrxSigError("%s failed (%d): %s" % (what, rc, self.L.trxsig_last_error(self.h).decode()))
+
+    def set_stream(self, stream_handle):
+        self._chk(self.L.trxsig_set_stream(self.h, stream_handle), "trxsig_set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        self._chk(self.L.trxsig_synchronize(self.h), "trxsig_synchronize")
+
+    def reserve(self, max_bursts):
+        self._chk(self.L.trxsig_reserve(self.h, max_bursts), "trxsig_reserve")
+
+    def tables_bytes(self):
+        return self.L.trxsig_tables_bytes(self.sps)
+
+    def tables_device_ptr(self):
+        return self.L.trxsig_tables_device(self.h)
+
+    def tables_export(self):
+        import numpy as np
+        buf = np.zeros(self.tables_bytes(), np.uint8)
+        self._chk(self.L.trxsig_tables_export(self.h, buf.ctypes.data, buf.size), "trxsig_tables_export")
+        return buf
+
+    def detect_demod_normal(self, samples, offset, length, tsc, flags, amp, toa, soft, avgpwr=None, hard=None,
+                            detect_thresh=3.0, energy_thresh=0.0, nsoft=148, soft_stride=None):
+        B = offset.numel() if hasattr(offset, "numel") else len(offset)
+        if soft_stride is None:
+            soft_stride = soft.shape[-1] if soft is not None and hasattr(soft, "shape") else nsoft
+        self._chk(self.L.trxsig_detect_demod_normal_batch(
+            self.h, _ptr(samples), _ptr(offset), _ptr(length), B, tsc, detect_thresh, energy_thresh,
+            _ptr(flags), _ptr(amp), _ptr(toa), _ptr(avgpwr), _ptr(soft), _ptr(hard), nsoft, soft_stride),
+            "trxsig_detect_demod_normal_batch")
+
+    def demodulate(self, samples, offset, length, amp, toa, soft, enable=None, hard=None, nsoft=148,
+                   soft_stride=None):
+        B = offset.numel()
+        if soft_stride is None:
+            soft_stride = soft.shape[-1]
+        self._chk(self.L.trxsig_demodulate_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), B, _ptr(amp),
+                                                 _ptr(toa), _ptr(enable), _ptr(soft), _ptr(hard), nsoft,
+                                                 soft_stride), "trxsig_demodulate_batch")
+
+    def timer_start(self):
+        self._chk(self.L.trxsig_timer_start(self.h), "trxsig_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.L.trxsig_timer_stop(self.h, C.byref(ms)), "trxsig_timer_stop")
+        return ms.value

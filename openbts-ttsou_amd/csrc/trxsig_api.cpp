@@ -1,0 +1,316 @@
+// trxsig_api.cpp -- the C-ABI of libtrxsig (include/trxsig.h): context, tables, workspace and the
+// batch entry points that enqueue the gfx950 kernels.  No signal processing happens on the host
+// here except the init-time table construction (trxsig_tablegen.cpp); there is no CPU fallback.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "trxsig.h"
+#include "trxsig_launch.h"
+#include "trxsig_tablegen.h"
+
+struct trxsig_ctx {
+  int device = -1;
+  int sps = 0;
+  hipStream_t stream = nullptr;
+  TrxTables *h_tables = nullptr;     // host copy
+  TrxTables *d_tables = nullptr;     // device blob
+  // workspace (device)
+  int cap_bursts = 0;
+  trx_c32 *d_rec = nullptr;          // [slots][cap_bursts] detect -> peak records
+  // staging for the *_host wrappers
+  size_t stage_bytes = 0;
+  void *d_stage = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+namespace {
+
+int fail(trxsig_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+  }
+  return code;
+}
+
+#define HIPCHK(c, call)                                          \
+  do {                                                           \
+    hipError_t e_ = (call);                                      \
+    if (e_ != hipSuccess) return fail((c), TRXSIG_EHIP, #call, e_); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int check_device(int device, std::string &why) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { why = "no HIP device visible (libtrxsig has no CPU fallback)"; return TRXSIG_ENODEV; }
+  if (device < 0 || device >= n) { why = "device ordinal out of range"; return TRXSIG_ENODEV; }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) { why = "hipGetDeviceProperties failed"; return TRXSIG_ENODEV; }
+  if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+    why = std::string("device is ") + p.gcnArchName + ", libtrxsig is built for gfx950 only";
+    return TRXSIG_ENODEV;
+  }
+  return TRXSIG_OK;
+}
+
+int finish_create(trxsig_ctx *c) {
+  HIPCHK(c, hipEventCreate(&c->ev0));
+  HIPCHK(c, hipEventCreate(&c->ev1));
+  return TRXSIG_OK;
+}
+
+int ensure_ws(trxsig_ctx *c, int B) {
+  if (B <= c->cap_bursts) return TRXSIG_OK;
+  int cap = (B + 255) & ~255;
+  if (c->d_rec) { HIPCHK(c, hipFree(c->d_rec)); c->d_rec = nullptr; c->cap_bursts = 0; }
+  HIPCHK(c, hipMalloc((void **)&c->d_rec, sizeof(trx_c32) * (size_t)trx_rec_slots(c->sps) * cap));
+  c->cap_bursts = cap;
+  return TRXSIG_OK;
+}
+
+int ensure_stage(trxsig_ctx *c, size_t bytes) {
+  if (bytes <= c->stage_bytes) return TRXSIG_OK;
+  if (c->d_stage) { HIPCHK(c, hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
+  bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+  HIPCHK(c, hipMalloc(&c->d_stage, bytes));
+  c->stage_bytes = bytes;
+  return TRXSIG_OK;
+}
+
+bool bad_batch(const void *s, const void *o, const void *l, int B) { return B < 0 || (B > 0 && (!s || !o || !l)); }
+
+}  // namespace
+
+extern "C" {
+
+int trxsig_abi_version(void) { return TRXSIG_ABI_VERSION; }
+
+int trxsig_create(trxsig_ctx **out, int device, int sps) {
+  if (!out) return TRXSIG_EINVAL;
+  *out = nullptr;
+  if (!(sps == 1 || sps == 2 || sps == 4)) return TRXSIG_EINVAL;
+  std::string why;
+  int rc = check_device(device, why);
+  if (rc != TRXSIG_OK) { std::fprintf(stderr, "trxsig_create: %s\n", why.c_str()); return rc; }
+  trxsig_ctx *c = new (std::nothrow) trxsig_ctx;
+  if (!c) return TRXSIG_ENOMEM;
+  c->device = device; c->sps = sps;
+  DeviceGuard g(device);
+  c->h_tables = (TrxTables *)std::malloc(sizeof(TrxTables));
+  if (!c->h_tables || trx_build_tables(c->h_tables, sps) != 0) { trxsig_destroy(c); return TRXSIG_ENOMEM; }
+  if (hipMalloc((void **)&c->d_tables, sizeof(TrxTables)) != hipSuccess ||
+      hipMemcpy(c->d_tables, c->h_tables, sizeof(TrxTables), hipMemcpyHostToDevice) != hipSuccess ||
+      finish_create(c) != TRXSIG_OK) {
+    std::fprintf(stderr, "trxsig_create: device allocation/upload failed\n");
+    trxsig_destroy(c);
+    return TRXSIG_EHIP;
+  }
+  *out = c;
+  return TRXSIG_OK;
+}
+
+int trxsig_create_from_tables(trxsig_ctx **out, int device, const void *d_blob, size_t bytes) {
+  if (!out || !d_blob || bytes != sizeof(TrxTables)) return TRXSIG_EINVAL;
+  *out = nullptr;
+  std::string why;
+  int rc = check_device(device, why);
+  if (rc != TRXSIG_OK) { std::fprintf(stderr, "trxsig_create_from_tables: %s\n", why.c_str()); return rc; }
+  trxsig_ctx *c = new (std::nothrow) trxsig_ctx;
+  if (!c) return TRXSIG_ENOMEM;
+  c->device = device;
+  DeviceGuard g(device);
+  c->h_tables = (TrxTables *)std::malloc(sizeof(TrxTables));
+  if (!c->h_tables) { trxsig_destroy(c); return TRXSIG_ENOMEM; }
+  if (hipMalloc((void **)&c->d_tables, sizeof(TrxTables)) != hipSuccess ||
+      hipMemcpy(c->d_tables, d_blob, sizeof(TrxTables), hipMemcpyDeviceToDevice) != hipSuccess ||
+      hipMemcpy(c->h_tables, c->d_tables, sizeof(TrxTables), hipMemcpyDeviceToHost) != hipSuccess) {
+    trxsig_destroy(c);
+    return TRXSIG_EHIP;
+  }
+  if (!trx_tables_valid(c->h_tables)) {
+    std::fprintf(stderr, "trxsig_create_from_tables: blob failed validation (magic/version/checksum)\n");
+    trxsig_destroy(c);
+    return TRXSIG_EINVAL;
+  }
+  c->sps = (int)c->h_tables->sps;
+  if (finish_create(c) != TRXSIG_OK) { trxsig_destroy(c); return TRXSIG_EHIP; }
+  *out = c;
+  return TRXSIG_OK;
+}
+
+void trxsig_destroy(trxsig_ctx *c) {
+  if (!c) return;
+  {
+    DeviceGuard g(c->device);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+  }
+  std::free(c->h_tables);
+  delete c;
+}
+
+int trxsig_sps(const trxsig_ctx *c) { return c ? c->sps : TRXSIG_EINVAL; }
+int trxsig_device(const trxsig_ctx *c) { return c ? c->device : TRXSIG_EINVAL; }
+int trxsig_set_stream(trxsig_ctx *c, void *s) { if (!c) return TRXSIG_EINVAL; c->stream = (hipStream_t)s; return TRXSIG_OK; }
+int trxsig_synchronize(trxsig_ctx *c) {
+  if (!c) return TRXSIG_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+const char *trxsig_last_error(const trxsig_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int trxsig_reserve(trxsig_ctx *c, int max_bursts) {
+  if (!c || max_bursts < 0) return TRXSIG_EINVAL;
+  DeviceGuard g(c->device);
+  return ensure_ws(c, max_bursts);
+}
+
+size_t trxsig_tables_bytes(int sps) { (void)sps; return sizeof(TrxTables); }
+int trxsig_tables_build_host(int sps, void *h_buf, size_t cap) {
+  if (!h_buf || cap < sizeof(TrxTables)) return TRXSIG_EINVAL;
+  return trx_build_tables((TrxTables *)h_buf, sps) == 0 ? TRXSIG_OK : TRXSIG_EINVAL;
+}
+void *trxsig_tables_device(trxsig_ctx *c) { return c ? (void *)c->d_tables : nullptr; }
+int trxsig_tables_export(trxsig_ctx *c, void *h_buf, size_t cap) {
+  if (!c || !h_buf || cap < sizeof(TrxTables)) return TRXSIG_EINVAL;
+  DeviceGuard g(c->device);
+  HIPCHK(c, hipMemcpy(h_buf, c->d_tables, sizeof(TrxTables), hipMemcpyDeviceToHost));
+  return TRXSIG_OK;
+}
+
+int trxsig_tables_view_get(const trxsig_ctx *c, trxsig_tables_view *v) {
+  if (!c || !v) return TRXSIG_EINVAL;
+  const TrxTables *T = c->h_tables;
+  v->sps = c->sps;
+  v->cos_table = T->cosT; v->sin_table = T->sinT;
+  v->gmsk_rotation = (const trxsig_c32 *)T->rot; v->gmsk_reverse = (const trxsig_c32 *)T->rev;
+  v->gsm_pulse = T->pulse;
+  for (int t = 0; t < 8; t++) {
+    v->midamble[t] = (const trxsig_c32 *)T->mid[t];
+    v->midamble_toa[t] = T->mid_toa[t];
+    v->midamble_gain[t].re = T->mid_gain[t].r; v->midamble_gain[t].im = T->mid_gain[t].i;
+  }
+  v->rach = (const trxsig_c32 *)T->rach;
+  v->rach_toa = T->rach_toa;
+  v->rach_gain.re = T->rach_gain.r; v->rach_gain.im = T->rach_gain.i;
+  return TRXSIG_OK;
+}
+
+// ---- RX hot path ---------------------------------------------------------------------------------
+int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                     const int32_t *d_length, int B, int tsc, float detect_thresh,
+                                     float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                     float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft,
+                                     int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_samples, d_offset, d_length, B) || tsc < 0 || tsc > 7 || nsoft < 0 || nsoft > 157 ||
+      soft_stride < nsoft || (B > 0 && (!d_flags || !d_amp || !d_toa || (nsoft > 0 && !d_soft))))
+    return fail(c, TRXSIG_EINVAL, "trxsig_detect_demod_normal_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_ws(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
+                                  B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
+                                  (trx_c32 *)d_amp, d_toa, d_avgpwr));
+  if (nsoft > 0)
+    HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                               (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
+                               soft_stride));
+  return TRXSIG_OK;
+}
+
+int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                            const int32_t *d_length, int B, const trxsig_c32 *d_amp, const float *d_toa,
+                            const uint8_t *d_enable, float *d_soft, uint8_t *d_hard, int nsoft,
+                            int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_samples, d_offset, d_length, B) || nsoft < 0 || nsoft > 157 || soft_stride < nsoft ||
+      (B > 0 && (!d_amp || !d_toa || !d_soft)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_demodulate_batch: bad argument");
+  if (B == 0 || nsoft == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                             (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride));
+  return TRXSIG_OK;
+}
+
+// ---- host-buffer wrappers (PCIe-inclusive convenience; never the timed path) ------------------------
+int trxsig_detect_demod_normal_host(trxsig_ctx *c, const trxsig_c32 *h_samples, const int32_t *h_offset,
+                                    const int32_t *h_length, int B, int tsc, float detect_thresh,
+                                    float energy_thresh, uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
+                                    float *h_avgpwr, float *h_soft, int nsoft, int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(h_samples, h_offset, h_length, B) || (B > 0 && (!h_flags || !h_amp || !h_toa)) || nsoft < 0 ||
+      nsoft > 157 || soft_stride < nsoft || (nsoft > 0 && B > 0 && !h_soft))
+    return fail(c, TRXSIG_EINVAL, "trxsig_detect_demod_normal_host: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  int64_t total = 0;
+  for (int b = 0; b < B; b++) {
+    if (h_offset[b] < 0 || h_length[b] < 0) return fail(c, TRXSIG_EINVAL, "negative offset/length");
+    int64_t e = (int64_t)h_offset[b] + h_length[b];
+    if (e > total) total = e;
+  }
+  DeviceGuard g(c->device);
+  auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+  const size_t o_s = 0, o_off = o_s + up(sizeof(trx_c32) * (size_t)total), o_len = o_off + up(4 * (size_t)B),
+               o_fl = o_len + up(4 * (size_t)B), o_amp = o_fl + up((size_t)B), o_toa = o_amp + up(8 * (size_t)B),
+               o_pwr = o_toa + up(4 * (size_t)B), o_soft = o_pwr + up(4 * (size_t)B),
+               end = o_soft + up(4 * (size_t)B * soft_stride);
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  HIPCHK(c, hipMemcpyAsync(d + o_s, h_samples, sizeof(trx_c32) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_off, h_offset, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_len, h_length, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
+  rc = trxsig_detect_demod_normal_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), B,
+                                        tsc, detect_thresh, energy_thresh, (uint8_t *)(d + o_fl),
+                                        (trxsig_c32 *)(d + o_amp), (float *)(d + o_toa), (float *)(d + o_pwr),
+                                        (float *)(d + o_soft), nullptr, nsoft, soft_stride);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_flags, d + o_fl, (size_t)B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_amp, d + o_amp, 8 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_toa, d + o_toa, 4 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+  if (h_avgpwr) HIPCHK(c, hipMemcpyAsync(h_avgpwr, d + o_pwr, 4 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+  if (nsoft > 0)
+    HIPCHK(c, hipMemcpyAsync(h_soft, d + o_soft, 4 * (size_t)B * soft_stride, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+// ---- measurement helpers ------------------------------------------------------------------------------
+int trxsig_timer_start(trxsig_ctx *c) {
+  if (!c) return TRXSIG_EINVAL;
+  DeviceGuard g(c->device);
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  return TRXSIG_OK;
+}
+int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
+  if (!c || !ms) return TRXSIG_EINVAL;
+  DeviceGuard g(c->device);
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return TRXSIG_OK;
+}
+
+}  // extern "C"

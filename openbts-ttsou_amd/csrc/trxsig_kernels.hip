@@ -1,0 +1,469 @@
+// trxsig_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the OpenBTS burst-processing path.
+//
+// Numerical contract: every float32 operation below is the reference's operation,
+// in the reference's order, separately rounded.  This file is compiled with -ffp-contract=off
+// (no v_fma/v_mac is ever formed from a*b+c) and with hipcc's default correctly-rounded
+// division and square root, so the outputs are bit-identical to Transceiver/sigProcLib.cpp
+// built for x86-64 (which has neither FMA contraction nor reassociation).  Where a sum's order
+// is changed for parallelism the comment says why the result cannot change (only additions of
+// +-0 are skipped or reordered).
+//
+// Work decomposition (64-wide wavefronts, no MFMA -- these are short O(N*K) filters):
+//   k_tsc_corr   : 16 lanes (one DPP row) per burst, 4 bursts per wave.  Midamble correlation
+//                  over the 36-symbol window with the 16 non-zero taps, energy detect, argmax,
+//                  and a small per-burst record of the lags around the peak.
+//   k_tsc_peak   : one LANE per burst.  The serial part of the reference (early-late bisection of
+//                  peakDetect, valley RMS, threshold) has no parallelism inside a burst, so it is
+//                  run for 64 bursts at once from the transposed records.
+//   k_demod      : one wave per burst.  1/amp scaling, 21-tap fractional-delay filter evaluated
+//                  only at the decimated symbol instants, reverse GMSK rotation, soft slicer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trxsig_tables.h"
+#include "trxsig_launch.h"
+
+namespace {
+
+typedef trx_c32 cx;
+
+__device__ __forceinline__ cx mk(float r, float i) { cx z; z.r = r; z.i = i; return z; }
+// Complex<float>::operator* (Transceiver/Complex.h:83): (r*a.r - i*a.i, r*a.i + i*a.r)
+__device__ __forceinline__ cx cmul(cx x, cx a) { return mk(x.r * a.r - x.i * a.i, x.r * a.i + x.i * a.r); }
+__device__ __forceinline__ cx cmulr(cx x, float a) { return mk(x.r * a, x.i * a); }       // Complex.h:84
+__device__ __forceinline__ cx cadd(cx x, cx a) { return mk(x.r + a.r, x.i + a.i); }
+__device__ __forceinline__ float norm2(cx x) { return x.i * x.i + x.r * x.r; }            // Complex.h:119
+__device__ __forceinline__ cx cinv(cx x) { float n = norm2(x); return mk(x.r / n, -x.i / n); }  // Complex.h:154-160
+__device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }               // Complex.h:85
+
+#define TRX_PI_F 3.14159274101257324f             /* (float)M_PI, sigProcLib.cpp:43 */
+#define TRX_2PI_F 6.28318548202514648f            /* (float)(2.0*M_PI), :44 */
+
+// lane i of a 16-lane DPP row reads lane i+N of the same row (row_shl:N)
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {
+  if (N == 0) return v;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
+// sinLookup (sigProcLib.cpp:177-188) and sinc (:567-571) against the uploaded trig table
+__device__ __forceinline__ float dev_sin_lookup(const float *__restrict__ sinT, float x) {
+  float arg = x * (1 / TRX_2PI_F);
+  while (arg > 1.0F) arg -= 1.0F;
+  while (arg < 0.0F) arg += 1.0F;
+  const float argT = arg * (float)TRX_TABLESIZE;
+  const int argI = (int)argT;
+  const float delta = argT - argI;
+  const float iDelta = 1.0F - delta;
+  return iDelta * sinT[argI] + delta * sinT[argI + 1];
+}
+__device__ __forceinline__ float dev_sinc(const float *__restrict__ sinT, float x) {
+  if ((x >= 0.01F) || (x <= -0.01F)) return dev_sin_lookup(sinT, x) / x;
+  return 1.0F;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_corr: analyzeTrafficBurst's correlation (sigProcLib.cpp:951-955) + energyDetect (:916-932)
+//   + peakDetect's argmax (:673-680).
+//
+// corr[t] = sum_j tmp[j]*w[t+s-j] with tmp = reverse(conj(midamble)), s = 8*sps-1, over the window
+// w = burst[56*sps, 92*sps).  Only every sps-th midamble tap is non-zero, so with tap k = m/sps the
+// sum is  sum_{k=15..0} w[t - 8*sps + sps*k] * conj(mid[sps*k])  in that order (ascending j).  The
+// skipped taps are exact zeros: their products are +-0 and adding them never changes a value.
+// Likewise out-of-range samples are read as 0 from the padded LDS window instead of being skipped.
+//
+// Lane r of a row handles lags t = r + 16*c.  For sps=4 the sample index r + 4*(4c+k) depends on
+// (c,k) only through 4c+k, so the 144 (c,k) pairs touch 48 distinct LDS words per lane.
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+struct CorrGeom {
+  static constexpr int NL = 36 * SPS;                    // lags (window length)
+  static constexpr int NC = (NL + 15) / 16;              // lags per lane
+  static constexpr int FRONT = 8 * SPS;                  // zero pad in front of the window
+  static constexpr int WPAD = NC * 16 + 15 * SPS + 1;    // padded window length
+  static constexpr int H = (5 * SPS + 1 > 12) ? 5 * SPS + 1 : 12;   // record half width
+  static constexpr int NS = 2 * H + 1;                   // corr slots in a record (+1 meta slot)
+  static constexpr int NE = 20 * SPS;                    // energyDetect window
+  static constexpr int NEQ = (NE + 15) / 16;
+};
+
+// energy += norm2(x[I]) for I = 0 .. NE-1 strictly in order; norm I lives in lane I%16 of
+// register nrm[I/16], and lane 0 of the row pulls it over with a DPP row shift.
+template <int SPS, int I>
+__device__ __forceinline__ float energy_chain(float acc, const float (&nrm)[CorrGeom<SPS>::NEQ]) {
+  if constexpr (I < CorrGeom<SPS>::NE) {
+    acc = acc + row_shl<I % 16>(nrm[I / 16]);
+    return energy_chain<SPS, I + 1>(acc, nrm);
+  } else {
+    return acc;
+  }
+}
+
+template <int SPS>
+__global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ T,
+                                                  const cx *__restrict__ samples,
+                                                  const int32_t *__restrict__ offset,
+                                                  const int32_t *__restrict__ length, int B, int tsc,
+                                                  cx *__restrict__ rec, int Bpad) {
+  typedef CorrGeom<SPS> G;
+  __shared__ cx win[16][G::WPAD];
+  __shared__ cx cor[16][G::NL];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 4, r = lane & 15;
+  const int slot = wave * 4 + row;                        // burst slot in this workgroup
+  const int b = blockIdx.x * 16 + slot;
+  const bool live = b < B;
+  int off = 0, len = 0;
+  if (live) { off = offset[b]; len = length[b]; }
+  const bool good = live && (off >= 0) && ((off & 1) == 0) && (len >= 92 * SPS) && (len <= 157 * SPS) &&
+                    (len % SPS == 0);
+  const cx *x = samples + off;
+
+  // ---- stage the window into LDS (16-byte loads: 2 samples per lane per load) ----
+  for (int q = r; q < G::WPAD / 2 + 1; q += 16) {          // zero everything first (pads included)
+    if (2 * q < G::WPAD) win[slot][2 * q] = mk(0, 0);
+    if (2 * q + 1 < G::WPAD) win[slot][2 * q + 1] = mk(0, 0);
+  }
+  __syncthreads();
+  if (good) {
+    const float4 *xw = reinterpret_cast<const float4 *>(x + 56 * SPS);
+    for (int q = r; q < G::NL / 2; q += 16) {
+      float4 v = xw[q];
+      win[slot][G::FRONT + 2 * q] = mk(v.x, v.y);
+      win[slot][G::FRONT + 2 * q + 1] = mk(v.z, v.w);
+    }
+  }
+
+  // ---- energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order ----
+  float nrm[G::NEQ];
+#pragma unroll
+  for (int q = 0; q < G::NEQ; q++) {
+    const int i = r + 16 * q;
+    cx v = mk(0, 0);
+    if (good && i < G::NE) v = x[i];
+    nrm[q] = norm2(v);
+  }
+  float energy = energy_chain<SPS, 0>(0.0f, nrm);
+  // lane 0 of the row now holds the reference's energy; broadcast it to the row
+  energy = __shfl(energy, lane & 48, 64);
+  __syncthreads();
+
+  // ---- correlation: 16 non-zero taps, k descending = j ascending ----
+  cx tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) tap[k] = T->mid_ctap[tsc][k];
+
+  float bestP = 0.0f;
+  int bestT = -1;
+#pragma unroll
+  for (int c = 0; c < G::NC; c++) {
+    const int t = r + 16 * c;
+    cx acc = mk(0, 0);
+#pragma unroll
+    for (int k = 15; k >= 0; k--) acc = cadd(acc, cmul(win[slot][t + SPS * k], tap[k]));
+    if (t < G::NL) {
+      cor[slot][t] = acc;
+      const float p = norm2(acc);
+      if (p > bestP) { bestP = p; bestT = t; }             // strict >, first maximum (:675)
+    }
+  }
+  // first maximum over the row: larger power wins, equal power -> smaller lag
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    const float oP = __shfl_xor(bestP, m, 64);
+    const int oT = __shfl_xor(bestT, m, 64);
+    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
+    if (take) { bestP = oP; bestT = oT; }
+  }
+  __syncthreads();
+
+  // ---- record: corr[M-H .. M+H] (zeros outside [0,NL)), then {M, energy} ----
+  if (live) {
+    const int M = bestT;
+    for (int s = r; s <= G::NS; s += 16) {
+      cx v = mk(0, 0);
+      if (s < G::NS) {
+        const int lag = M - G::H + s;
+        if (lag >= 0 && lag < G::NL) v = cor[slot][lag];
+      } else {
+        v = mk(__int_as_float(good ? M : -2), energy);   // M = -2 marks an invalid burst
+      }
+      rec[(size_t)s * Bpad + b] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak: one lane per burst.  peakDetect's early-late bisection (sigProcLib.cpp:684-701),
+//   the bogus-TOA check, the valley RMS, the detection threshold, amp = peak/gain and the TOA
+//   bookkeeping of analyzeTrafficBurst (:959-1000, 1035), plus energyDetect's decision (:929-931).
+//
+// interpolatePoint(ix) = sum_{i} corr[i]*sinc(pi*(i-ix)), i from max(0,floor(ix)-10) to
+// min(floor(ix)+11, n-1)-1.  ix stays on the 1/512 grid, so sinc(pi*(i-ix)) comes from
+// sinc_grid[f][j] with f = frac(ix)*512, j = i-floor(ix)+10 (trxsig_tables.h).  early and late
+// differ by exactly 2.0, hence share f.  Entries the reference would skip are zeros here.
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+__global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T,
+                                                 const cx *__restrict__ rec, int Bpad, int B, int tsc,
+                                                 float detect_thresh, float energy_thresh,
+                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                 float *__restrict__ toa_out,
+                                                 float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  __shared__ cx loc[26][64];                               // [24],[25] stay zero                               // lags M-12 .. M+11 of each lane's burst
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+
+  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+#pragma unroll
+  for (int j = 0; j < 24; j++) {
+    const int lag = M - 12 + j;
+    cx v = rec[(size_t)(G::H - 12 + j) * Bpad + bb];
+    if (lag > G::NL - 2) v = mk(0, 0);                     // interpolatePoint never uses the last sample (:646)
+    loc[j][lane] = v;
+  }
+  loc[24][lane] = mk(0, 0);
+  loc[25][lane] = mk(0, 0);
+  __syncthreads();
+
+  // interpolate at ix (I = floor(ix) relative to M, f = frac*512)
+  auto interp2 = [&](float ix, int dI2, cx &pa, cx &pb) {
+    // pa = interpolatePoint(ix), pb = interpolatePoint(ix + dI2) -- same fractional part
+    const float fl = floorf(ix);
+    const int I = (int)fl;
+    const int f = (int)((ix - fl) * 512.0f);
+    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f]);
+    float s[24];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const float4 v = row[q];
+      s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
+    }
+    int base = I - M + 2;                                  // loc index of tap j = 0 (0..3 by construction)
+    base = base < 0 ? 0 : (base > 3 ? 3 : base);
+    pa = mk(0, 0); pb = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 21; j++) {
+      const int ia = base + j, ib = base + j + dI2;
+      pa = cadd(pa, cmulr(loc[ia][lane], s[j]));
+      pb = cadd(pb, cmulr(loc[ib][lane], s[j]));
+    }
+  };
+
+  float early = (float)M - 1, late = (float)M + 1;
+  float incr = 0.5f;
+  bool active = true;
+#pragma unroll 1
+  for (int step = 0; step < 9; step++) {                   // incr = 2^-1 .. 2^-9  (> 1/1024)
+    cx e, l;
+    interp2(early, 2, e, l);
+    if (active) {
+      const float ne = norm2(e), nl = norm2(l);
+      if (ne < nl) early += incr;
+      else if (ne > nl) early -= incr;
+      else active = false;                                 // "else break" (:695)
+      if (active) { incr = incr * 0.5f; late = early + 2.0f; }
+    }
+  }
+  (void)late;
+  const float peakIx = early + 1.0f;
+  cx peak, dummy;
+  interp2(peakIx, 0, peak, dummy);
+
+  // ---- analyzeTrafficBurst tail ----
+  float toa = peakIx;
+  cx amp = peak;
+  bool detected = false;
+  // energy_thresh < 0 disables the gate (trxsig.h)
+  const bool energy_ok = good && (energy_thresh < 0.0f ||
+                                  energy / (float)(unsigned)G::NE > energy_thresh * energy_thresh);
+  if (!(toa < 0.0f) && !(toa > (float)G::NL) && good) {
+    const int p = (int)rintf(toa);
+    float valley = 0.0f;
+    int numRms = 0;
+#pragma unroll 1
+    for (int i = 2 * SPS; i <= 5 * SPS; i++) {             // :971-980, this order
+      const int lo = p - i, hi = p + i;
+      if (lo >= 0) { valley += norm2(rec[(size_t)(lo - M + G::H) * Bpad + bb]); numRms++; }
+      if (hi < G::NL) { valley += norm2(rec[(size_t)(hi - M + G::H) * Bpad + bb]); numRms++; }
+    }
+    if (numRms < 2) {
+      amp = mk(0, 0);
+    } else {
+      const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);   // :989
+      const float peakToMean = sqrtf(norm2(amp)) / RMS;   // Complex::abs() via double sqrt == sqrtf
+      amp = cdiv(amp, T->mid_gain[tsc]);                   // :997
+      toa = toa - T->mid_toa[tsc];                         // :998
+      toa = toa - (float)((66 - 56) * SPS);                // :1000
+      detected = peakToMean > detect_thresh;
+    }
+  } else {
+    amp = mk(0, 0);                                        // "bogus result" (:964-968); TOA left as is
+  }
+  if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
+
+  if (live) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_demod: demodulateBurst (sigProcLib.cpp:1056-1097): scaleVector(1/amp) -> delayVector(-TOA) ->
+//   GMSKReverseRotate -> decimateVector(sps) -> vectorSlicer.  One wave per burst.
+//
+// Only the decimated outputs are ever looked at, so the 21-tap fractional-delay FIR (:584-590) is
+// evaluated at t = sps*m - intOffset only.  The scaled burst sits in LDS in polyphase order
+// (sample n at [n % sps][n / sps]) so that the 64 lanes' stride-sps reads are contiguous.
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+__global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
+                                               const cx *__restrict__ samples,
+                                               const int32_t *__restrict__ offset,
+                                               const int32_t *__restrict__ length, int B,
+                                               const cx *__restrict__ amp_in,
+                                               const float *__restrict__ toa_in,
+                                               const uint8_t *__restrict__ flags, int need_mask,
+                                               float *__restrict__ soft, uint8_t *__restrict__ hard,
+                                               int nsoft, int stride) {
+  constexpr int PADN = 12;                                 // zero samples in front (multiple of SPS, >= 10)
+  constexpr int QLEN = (157 * SPS + 2 * PADN) / SPS + 1;   // entries per phase
+  __shared__ cx ph[4][SPS][QLEN];
+  __shared__ float taps[4][24];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  const bool live = b < B;                                 // wave-uniform
+  const int bb = live ? b : B - 1;
+  float *sb = soft + (size_t)bb * stride;
+  uint8_t *hb = hard ? hard + (size_t)bb * stride : nullptr;
+  const int off = offset[bb], N = length[bb];
+  const cx amp = amp_in[bb];
+  const float toa = toa_in[bb];
+  const bool good = (off >= 0) && ((off & 1) == 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0) &&
+                    (fabsf(toa) <= 4096.0f);               // also rejects NaN/inf TOA
+  bool enabled = live && good;
+  if (flags) enabled = enabled && (need_mask ? ((flags[bb] & need_mask) == need_mask) : (flags[bb] != 0));
+  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066)
+
+  // delayVector(-TOA) bookkeeping (:577-582)
+  const float delay = enabled ? -toa : 0.0f;
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  const bool filt = fabs((double)frac) > 1e-2;
+  if (filt && lane < 21) taps[wave][lane] = dev_sinc(T->sinT, TRX_PI_F * ((float)(lane - 10) - frac));  // :588
+
+  // ---- stage scaled samples, polyphase, zero padded ----
+  cx(*P)[QLEN] = ph[wave];
+  for (int i = lane; i < SPS * QLEN; i += 64) P[i / QLEN][i % QLEN] = mk(0, 0);
+  __syncthreads();
+  if (enabled) {
+    const float4 *xv = reinterpret_cast<const float4 *>(samples + off);
+    for (int q = lane; q < N / 2; q += 64) {
+      const float4 v = xv[q];
+      const cx a = cmul(mk(v.x, v.y), inv), c = cmul(mk(v.z, v.w), inv);   // scaleVector (:713-723)
+      const int n0 = 2 * q + PADN, n1 = n0 + 1;
+      P[n0 % SPS][n0 / SPS] = a;
+      P[n1 % SPS][n1 / SPS] = c;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  if (!enabled) {
+    for (int m = lane; m < nsoft; m += 64) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
+    return;
+  }
+
+  float tp[21];
+#pragma unroll
+  for (int j = 0; j < 21; j++) tp[j] = filt ? taps[wave][j] : 0.0f;
+
+  const cx *rev = T->rev;
+  for (int m = lane; m < nsoft; m += 64) {
+    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
+    cx y = mk(0, 0);
+    if (t >= 0 && t < N) {
+      if (filt) {
+#pragma unroll
+        for (int j = 0; j < 21; j++) {                     // convolve(...,NO_DELAY), 21 real taps (:590)
+          const int n = t + 10 - j + PADN;                 // >= 2, < N + 22: inside the padded array
+          y = cadd(y, cmulr(P[n % SPS][n / SPS], tp[j]));
+        }
+      } else {
+        const int n = t + PADN;
+        y = P[n % SPS][n / SPS];
+      }
+    }
+    const cx rv = rev[SPS * m];
+    const float re = rv.r * y.r - rv.i * y.i;              // real part of GMSKReverseRotate (:259-262)
+    float v = (float)(0.5 * (double)(re + 1.0F));          // vectorSlicer (:513-515)
+    if (v > 1.0f) v = 1.0f;
+    if (v < 0.0f) v = 0.0f;
+    sb[m] = v;
+    if (hb) hb[m] = v > 0.5F;                              // SoftVector::bit (BitVector.h:415-420)
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int trx_rec_slots(int sps) {
+  switch (sps) {
+    case 1: return CorrGeom<1>::NS + 1;
+    case 2: return CorrGeom<2>::NS + 1;
+    case 4: return CorrGeom<4>::NS + 1;
+  }
+  return 0;
+}
+
+template <int S>
+static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                              const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
+                              trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr) {
+  k_tsc_corr<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, tsc, rec, Bpad);
+  k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
+                                                          flags, amp, toa, avgpwr);
+}
+
+hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                                 const int32_t *off, const int32_t *len, int B, int tsc,
+                                 float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
+                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr) {
+  if (B <= 0) return hipSuccess;
+  switch (sps) {
+    case 1: launch_tsc_detect<1>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr); break;
+    case 2: launch_tsc_detect<2>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr); break;
+    case 4: launch_tsc_detect<4>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                            const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
+                            const float *toa, const uint8_t *flags, int need_mask, float *soft,
+                            uint8_t *hard, int nsoft, int stride) {
+  if (B <= 0) return hipSuccess;
+  const dim3 grid((B + 3) / 4), block(256);
+  switch (sps) {
+    case 1: k_demod<1><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
+    case 2: k_demod<2><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
+    case 4: k_demod<4><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,69 @@
+"""Host-side (no GPU) checks of the product library: it loads, exports every symbol include/trxsig.h
+declares, refuses to create a context without a gfx950 device (no CPU fallback), and its init-time
+table construction is bit-identical to the reference's tables (tests/golden/tables.npz)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _pkg
+from util import assert_beq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    m = _pkg.load()
+    if not os.path.exists(m.LIB_PATH):
+        m.build()
+    return m
+
+
+def test_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "trxsig.h")).read()
+    hdr = re.sub(r"#ifdef TRXSIG_NEXT.*?#endif /\* TRXSIG_NEXT \*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(trxsig_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 15
+    L = pkg.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.trxsig_abi_version() == 1
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.TrxSigError):
+        pkg.TrxSig(4)
+
+
+@pytest.mark.parametrize("sps", [1, 2, 4])
+def test_tables_match_reference(pkg, golden, sps):
+    g = golden("tables.npz")
+    blob = pkg.build_tables_host(sps)
+    dt = pkg.tables_dtype()
+    assert dt.itemsize == blob.size == pkg.lib().trxsig_tables_bytes(sps)
+    T = blob.view(dt)[0]
+    p = "sps%d_" % sps
+    assert T["sps"] == sps and T["bytes"] == blob.size
+    assert_beq(T["cosT"][:1025], g["cosT"]); assert_beq(T["sinT"][:1025], g["sinT"])
+    assert_beq(T["rot"][:157 * sps], g[p + "rot"]); assert_beq(T["rev"][:157 * sps], g[p + "rev"])
+    assert_beq(T["pulse"][:2 * sps + 1], g[p + "pulse"])
+    assert_beq(np.ascontiguousarray(T["mid"][:, :16 * sps]), g[p + "mid"])
+    assert_beq(T["mid_toa"], g[p + "mid_toa"]); assert_beq(T["mid_gain"], g[p + "mid_gain"])
+    assert_beq(T["rach"][:41 * sps], g[p + "rach"])
+    assert T["rach_toa"] == g[p + "rach_toa"] and T["rach_gain"] == g[p + "rach_gain"]
+    # derived tables
+    assert_beq(np.ascontiguousarray(T["mid_ctap"]), np.conj(g[p + "mid"][:, ::sps]).astype(np.complex64))
+    grid = g["sinc_grid"]                      # sinc(pi*d), d = k/512, k = -5632..5632
+    f = np.arange(512)[:, None]; j = np.arange(21)[None, :]
+    k = (j - 10) * 512 - f                      # d = (j-10) - f/512
+    assert_beq(np.ascontiguousarray(T["sinc_grid"][:, :21]), grid[k + 11 * 512])
+    assert not T["sinc_grid"][:, 21:].any()
+    # zero taps of the unit-pulse midamble really are zeros (the kernels skip them)
+    mask = np.ones(16 * sps, bool); mask[::sps] = False
+    assert not g[p + "mid"][:, mask].any()
