@@ -14,9 +14,10 @@
  *    Complex<float>, Transceiver/Complex.h:39-44, inside Vector<complex>).
  *  - "d_" pointers are DEVICE pointers on the context's GPU; "h_" pointers are host.
  *  - a batch is B bursts packed in one sample array: burst b occupies
- *    samples[offset[b] .. offset[b]+length[b]).  offset[b] must be even (16-byte
- *    aligned bursts); length[b] a multiple of sps with 92*sps <= length[b] <= 157*sps
- *    (the reference's own limits: sigProcLib.cpp:215-216, 951, 1045-1050).
+ *    samples[offset[b] .. offset[b]+length[b]).  offset[b] >= 0 (even offsets, i.e. 16-byte
+ *    aligned bursts, take the wide-load path); length[b] a multiple of sps with
+ *    92*sps <= length[b] <= 157*sps (the reference's own limits: sigProcLib.cpp:215-216,
+ *    951, 1045-1050).
  *  - all work is enqueued on the context's HIP stream (trxsig_set_stream) and is
  *    asynchronous; the library never synchronises unless the entry point's comment says so.
  *  - return value: 0 on success, negative TRXSIG_E* on error; no exceptions cross the ABI.

@@ -116,8 +116,7 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
   const bool live = b < B;
   int off = 0, len = 0;
   if (live) { off = offset[b]; len = length[b]; }
-  const bool good = live && (off >= 0) && ((off & 1) == 0) && (len >= 92 * SPS) && (len <= 157 * SPS) &&
-                    (len % SPS == 0);
+  const bool good = live && (off >= 0) && (len >= 92 * SPS) && (len <= 157 * SPS) && (len % SPS == 0);
   const cx *x = samples + off;
 
   // ---- stage the window into LDS (16-byte loads: 2 samples per lane per load) ----
@@ -127,11 +126,15 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
   }
   __syncthreads();
   if (good) {
-    const float4 *xw = reinterpret_cast<const float4 *>(x + 56 * SPS);
-    for (int q = r; q < G::NL / 2; q += 16) {
-      float4 v = xw[q];
-      win[slot][G::FRONT + 2 * q] = mk(v.x, v.y);
-      win[slot][G::FRONT + 2 * q + 1] = mk(v.z, v.w);
+    if (((off + 56 * SPS) & 1) == 0) {                     // 16-byte aligned window: 2 samples per load
+      const float4 *xw = reinterpret_cast<const float4 *>(x + 56 * SPS);
+      for (int q = r; q < G::NL / 2; q += 16) {
+        float4 v = xw[q];
+        win[slot][G::FRONT + 2 * q] = mk(v.x, v.y);
+        win[slot][G::FRONT + 2 * q + 1] = mk(v.z, v.w);
+      }
+    } else {
+      for (int q = r; q < G::NL; q += 16) win[slot][G::FRONT + q] = x[56 * SPS + q];
     }
   }
 
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
   const int off = offset[bb], N = length[bb];
   const cx amp = amp_in[bb];
   const float toa = toa_in[bb];
-  const bool good = (off >= 0) && ((off & 1) == 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0) &&
+  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0) &&
                     (fabsf(toa) <= 4096.0f);               // also rejects NaN/inf TOA
   bool enabled = live && good;
   if (flags) enabled = enabled && (need_mask ? ((flags[bb] & need_mask) == need_mask) : (flags[bb] != 0));
@@ -370,13 +373,25 @@ __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
   for (int i = lane; i < SPS * QLEN; i += 64) P[i / QLEN][i % QLEN] = mk(0, 0);
   __syncthreads();
   if (enabled) {
-    const float4 *xv = reinterpret_cast<const float4 *>(samples + off);
-    for (int q = lane; q < N / 2; q += 64) {
-      const float4 v = xv[q];
-      const cx a = cmul(mk(v.x, v.y), inv), c = cmul(mk(v.z, v.w), inv);   // scaleVector (:713-723)
-      const int n0 = 2 * q + PADN, n1 = n0 + 1;
-      P[n0 % SPS][n0 / SPS] = a;
-      P[n1 % SPS][n1 / SPS] = c;
+    const cx *xb = samples + off;
+    if ((off & 1) == 0) {                                  // 16-byte aligned burst: 2 samples per load
+      const float4 *xv = reinterpret_cast<const float4 *>(xb);
+      for (int q = lane; q < N / 2; q += 64) {
+        const float4 v = xv[q];
+        const cx a = cmul(mk(v.x, v.y), inv), c = cmul(mk(v.z, v.w), inv);   // scaleVector (:713-723)
+        const int n0 = 2 * q + PADN, n1 = n0 + 1;
+        P[n0 % SPS][n0 / SPS] = a;
+        P[n1 % SPS][n1 / SPS] = c;
+      }
+      if ((N & 1) && lane == 0) {
+        const int n0 = N - 1 + PADN;
+        P[n0 % SPS][n0 / SPS] = cmul(xb[N - 1], inv);
+      }
+    } else {
+      for (int n = lane; n < N; n += 64) {
+        const int n0 = n + PADN;
+        P[n0 % SPS][n0 / SPS] = cmul(xb[n], inv);
+      }
     }
   }
   __syncthreads();

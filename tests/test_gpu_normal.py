@@ -96,14 +96,18 @@ def test_ragged_and_bad_bursts(pkg, ctx):
     length2[5] = 91 * sps          # too short for the midamble window
     length2[6] = 158 * sps         # longer than the rotation table
     length2[7] = 624 + 1           # not a multiple of sps
-    off2[8] = off2[8] + 1          # not 16-byte aligned
+    off2[8] = -4                   # negative offset
+    off2[9] = off2[9] + 1          # odd offset is legal (8-byte aligned path); shifts the burst by a sample
     gb = GpuBatch(np.concatenate([x, np.zeros(700, np.complex64)]), off2, length2)
     ctx[sps].detect_demod_normal(gb.x, gb.off, gb.len, 3, gb.flags, gb.amp, gb.toa, gb.soft)
     r = gb.results()
     bad = np.array([5, 6, 7, 8])
     assert np.all(r["flags"][bad] == pkg.F_BADLEN)
     assert not r["soft"][bad].any() and not r["amp"][bad].any()
-    good = np.setdiff1d(np.arange(37), bad)
+    x9 = x[off[9] + 1:off[9] + 1 + length[9]]
+    r9 = o.analyze_traffic(np.concatenate([x9, np.zeros(length[9] - len(x9), np.complex64)]), 3)
+    assert r["amp"][9] == r9["amp"] and r["toa"][9] == r9["toa"]
+    good = np.setdiff1d(np.arange(37), np.append(bad, 9))
     assert_veq((r["flags"][good] & pkg.F_DETECT) != 0, ok[good].astype(bool))
     assert_veq(r["amp"][good], amp[good]); assert_veq(r["toa"][good], toa[good])
     assert_veq(r["soft"][good], soft[good])
