@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbursts/s of the burst detect+demod hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE config 2 -- 65,536 normal bursts per GPU, 156.25 symbols at
+4 samples/symbol (628/624/624/624 complex float32 samples), one training sequence per batch,
+synthetic GMSK bursts with random gain, sub-sample delay and AWGN (SNR inf/20/10 dB), resident in
+HBM before the timed region.  A "step" is one pass of trxsig_detect_demod_normal_batch over the
+batch: energy detect + TSC correlate + peak/valley detect + GMSK demodulation to 148 soft bits.
+Multi-GPU: each rank owns an independent batch (weak scaling); the only collective is the
+init-time RCCL broadcast of the constant tables.  `value` is whole-job bursts/s over all ranks,
+timed between barriers, MAX over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SPS = 4
+TSC = 2
+BURSTS_PER_GPU = 65536
+NSOFT = 148
+# algorithmic bytes per burst: read 8*625 + write 4*148 soft + 16 B metadata
+ALG_READ = 8 * 625
+ALG_WRITE = 4 * NSOFT + 16
+ALG_BYTES = ALG_READ + ALG_WRITE
+# per-kernel algorithmic bytes per burst (DESIGN.md "Kernels"):
+KERNEL_ALG_BYTES = {
+    "k_tsc_corr": 8 * 36 * SPS + 8 * 20 * SPS + 8 * 44,     # window + energy window read, record write
+    "k_tsc_peak": 8 * 44 + 13 + 4,                          # record read, flags/amp/toa/avgpwr write
+    "k_demod": ALG_READ + 13 + 4 * NSOFT,                   # whole burst + amp/toa/flags read, soft write
+    "k_normal_fused": ALG_BYTES,
+}
+
+
+def cpu_baseline(x_host, off, length, sps, tsc, target_seconds=8.0):
+    """The CPU oracle (a port of the reference's algorithm, oracle/sigproc_oracle.c) timed on this
+    box's host cores over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oraclebind
+    o = oraclebind.Oracle(sps)
+    cores = min(os.cpu_count() or 1, 16)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    B = len(off)
+    t0 = time.perf_counter()
+    o.normal_batch(x_host, off[:1024], length[:1024], tsc, nthreads=1)
+    t1 = time.perf_counter() - t0
+    o.normal_batch(x_host, off, length, tsc, nthreads=cores)            # warm
+    t0 = time.perf_counter()
+    o.normal_batch(x_host, off, length, tsc, nthreads=cores)
+    tp = time.perf_counter() - t0
+    reps = max(1, int(target_seconds / max(tp, 1e-3)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o.normal_batch(x_host, off, length, tsc, nthreads=cores)
+    tt = time.perf_counter() - t0
+    return {"value": round(B * reps / tt / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
+            "single_thread_Mbursts_per_s": round(1024 / t1 / 1e6, 6),
+            "sample": "%d passes over the first %d bursts of the GPU batch (analyzeTrafficBurst + "
+                      "demodulateBurst, oracle/sigproc_oracle.c, %d OpenMP threads, %.1f s)" % (reps, B, cores, tt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bursts", type=int, default=BURSTS_PER_GPU, help="bursts per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import _pkg
+    pkg = _pkg.load()
+    from openbts_ttsou_amd import dist as tdist
+    from openbts_ttsou_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        rank, world = tdist.init_from_env("nccl")
+    else:
+        rank, local = 0, 0
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dev = torch.device("cuda", local)
+
+    # constant tables: built once on rank 0, broadcast over RCCL (xGMI), validated, then each rank's
+    # context is created from the received device blob
+    if world > 1:
+        _, tbl = tdist.broadcast_tables(pkg, SPS, device=dev, src=0)
+        ctx = pkg.TrxSig(SPS, local, tables_blob=tbl)
+    else:
+        ctx = pkg.TrxSig(SPS, local)
+    ctx.use_torch_stream()
+
+    B = args.bursts
+    x, off, length, meta = synth.normal_batch_torch(SPS, B, TSC, seed=0xB5E55ED0 + rank, device=dev)
+    xf = torch.view_as_real(x).contiguous()
+    flags = torch.zeros(B, dtype=torch.uint8, device=dev)
+    amp = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+    toa = torch.zeros(B, dtype=torch.float32, device=dev)
+    soft = torch.zeros(B, NSOFT, dtype=torch.float32, device=dev)
+    ctx.reserve(B)
+
+    def step():
+        ctx.detect_demod_normal(xf, off, length, TSC, flags, amp, toa, soft, detect_thresh=3.0,
+                                energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_collect()
+    ctx.profile_enable(False)
+    elapsed = tdist.max_over_ranks(elapsed, dev)
+
+    # results sanity (outside the timed region): detections and hard bits of the clean bursts
+    det = (flags & pkg.F_DETECT) != 0
+    clean = det & (meta["sigma"] <= 0.1)
+    hard_ok = bool(((soft[clean] > 0.5).to(torch.uint8) == meta["bits"][clean]).all().item())
+    det_frac = float(det.float().mean().item())
+
+    if rank != 0:
+        return
+    value = world * B * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+    dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
+    roof = None
+    if dom[0]:
+        avg_ms = dom[1][0] / max(dom[1][1], 1)
+        achieved = KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES) * B / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_kernel_ms": round(avg_ms, 4),
+                "alg_bytes_per_burst": KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES),
+                "pipeline_achieved": round(ALG_BYTES * B * args.steps / (ev_ms * 1e-3) / 1e9, 1),
+                "pipeline_frac": round(ALG_BYTES * B * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}}
+    out = {
+        "metric": "Mbursts/s (156.25-sym @ 4 sps) demod+detect", "value": round(value, 3), "unit": "Mbursts/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config2: %d normal bursts/GPU, sps=4, 628/624/624/624 complex f32 samples, "
+                               "TSC %d, detect (thr 3.0) + demod to %d soft bits" % (B, TSC, NSOFT),
+                   "bursts_per_gpu": B, "sps": SPS, "parallelism": "burst-sharded x%d (no data-path collective)" % world},
+        "hip_event_ms_per_step": round(ev_ms / args.steps, 4),
+        "detected_frac": round(det_frac, 4), "clean_hard_bits_ok": hard_ok,
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        n = min(B, 16384)
+        end = int(off[n - 1].item() + length[n - 1].item())
+        xh = x[:end].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(xh, off[:n].cpu().numpy(), length[:n].cpu().numpy(), SPS, TSC)
+        if args.check:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oraclebind
+            ok, oamp, otoa, osoft = oraclebind.Oracle(SPS).normal_batch(xh, off[:n].cpu().numpy(),
+                                                                        length[:n].cpu().numpy(), TSC, nthreads=8)
+            same = (np.array_equal(det[:n].cpu().numpy(), ok.astype(bool)) and
+                    np.array_equal(soft[:n].cpu().numpy(), osoft) and np.array_equal(toa[:n].cpu().numpy(), otoa))
+            out["oracle_check_first_%d" % n] = bool(same)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -222,9 +222,21 @@ int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *
 
 #endif /* TRXSIG_NEXT */
 
-/* ---- measurement helpers (HIP events on the context's stream; used by bench.py) --------------- */
+/* ---- measurement helpers (HIP events on the context's stream; used by bench.py) ---------------
+ * trxsig_timer_*: one start/stop event pair around whatever the caller enqueues in between.
+ * trxsig_profile_*: when enabled, every kernel launch made by the library is bracketed by its own
+ *   event pair on the context's stream; trxsig_profile_collect synchronises, adds up the elapsed
+ *   time and launch count per kernel and resets.  kernel ids: TRXSIG_K_*. */
 int trxsig_timer_start(trxsig_ctx *ctx);
 int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
+enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_K_RACH_CORR = 3,
+       TRXSIG_K_RACH_PEAK = 4, TRXSIG_K_MODULATE = 5, TRXSIG_K_RESAMPLE = 6, TRXSIG_K_EQUALIZE = 7,
+       TRXSIG_K_CONVERT = 8, TRXSIG_K_COUNT = 9 };
+const char *trxsig_kernel_name(int kernel_id);
+int trxsig_profile_enable(trxsig_ctx *ctx, int on);
+int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);
+/* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
+int trxsig_tables_validate_host(const void *h_blob, size_t bytes);
 
 #ifdef __cplusplus
 }

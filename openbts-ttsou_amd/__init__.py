@@ -60,6 +60,10 @@ def lib():
         L.trxsig_demodulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
+        L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
+        L.trxsig_profile_enable.argtypes = [vp, i32]
+        L.trxsig_profile_collect.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+        L.trxsig_tables_validate_host.argtypes = [vp, C.c_size_t]
         _lib = L
     return _lib
 
@@ -83,6 +87,11 @@ def build_tables_host(sps):
     if rc != 0:
         raise TrxSigError("trxsig_tables_build_host(%d) failed (%d)" % (sps, rc))
     return buf
+
+
+def tables_valid(blob):
+    """True if a host uint8 array holds a valid table blob (header + checksum)."""
+    return lib().trxsig_tables_validate_host(blob.ctypes.data, blob.size) == 0
 
 
 def _ptr(t):
@@ -169,6 +178,16 @@ class TrxSig:
         self._chk(self.L.trxsig_demodulate_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), B, _ptr(amp),
                                                  _ptr(toa), _ptr(enable), _ptr(soft), _ptr(hard), nsoft,
                                                  soft_stride), "trxsig_demodulate_batch")
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.trxsig_profile_enable(self.h, int(on)), "trxsig_profile_enable")
+
+    def profile_collect(self):
+        """{kernel name: (total_ms, launches)} since the last collect (synchronises)."""
+        n = 9
+        ms = (C.c_float * n)(); cnt = (C.c_int * n)()
+        self._chk(self.L.trxsig_profile_collect(self.h, ms, cnt), "trxsig_profile_collect")
+        return {self.L.trxsig_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
     def timer_start(self):
         self._chk(self.L.trxsig_timer_start(self.h), "trxsig_timer_start")

@@ -8,12 +8,50 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "trxsig.h"
 #include "trxsig_launch.h"
 #include "trxsig_tablegen.h"
 
+struct EventProfiler : TrxProfiler {
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(int id, hipStream_t st) override {
+    Rec r = { id, get(), get() };
+    if (r.a) (void)hipEventRecord(r.a, st);
+    recs.push_back(r);
+  }
+  void end(int id, hipStream_t st) override {
+    if (!recs.empty() && recs.back().id == id && recs.back().b) (void)hipEventRecord(recs.back().b, st);
+  }
+  void collect(float *ms, int *n) {
+    for (Rec &r : recs) {
+      float t = 0;
+      if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+        ms[r.id] += t; n[r.id]++;
+      }
+      if (r.a) pool.push_back(r.a);
+      if (r.b) pool.push_back(r.b);
+    }
+    recs.clear();
+  }
+  ~EventProfiler() override {
+    float ms[TRXSIG_K_COUNT] = {0}; int n[TRXSIG_K_COUNT] = {0};
+    collect(ms, n);
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+  }
+};
+
 struct trxsig_ctx {
+  EventProfiler *prof = nullptr;
   int device = -1;
   int sps = 0;
   hipStream_t stream = nullptr;
@@ -163,6 +201,7 @@ void trxsig_destroy(trxsig_ctx *c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c->prof;
   }
   std::free(c->h_tables);
   delete c;
@@ -231,11 +270,11 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   if (rc != TRXSIG_OK) return rc;
   HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
-                                  (trx_c32 *)d_amp, d_toa, d_avgpwr));
+                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
-                               soft_stride));
+                               soft_stride, c->prof));
   return TRXSIG_OK;
 }
 
@@ -250,7 +289,7 @@ int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const in
   if (B == 0 || nsoft == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
-                             (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride));
+                             (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride, c->prof));
   return TRXSIG_OK;
 }
 
@@ -311,6 +350,31 @@ int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
   HIPCHK(c, hipEventSynchronize(c->ev1));
   HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
   return TRXSIG_OK;
+}
+
+const char *trxsig_kernel_name(int id) {
+  static const char *names[TRXSIG_K_COUNT] = { "k_tsc_corr", "k_tsc_peak", "k_demod", "k_rach_corr", "k_rach_peak",
+                                               "k_modulate", "k_resample", "k_equalize", "k_convert" };
+  return (id >= 0 && id < TRXSIG_K_COUNT) ? names[id] : "?";
+}
+int trxsig_profile_enable(trxsig_ctx *c, int on) {
+  if (!c) return TRXSIG_EINVAL;
+  DeviceGuard g(c->device);
+  if (on && !c->prof) c->prof = new (std::nothrow) EventProfiler;
+  if (!on && c->prof) { delete c->prof; c->prof = nullptr; }
+  return TRXSIG_OK;
+}
+int trxsig_profile_collect(trxsig_ctx *c, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]) {
+  if (!c || !total_ms || !launches) return TRXSIG_EINVAL;
+  for (int i = 0; i < TRXSIG_K_COUNT; i++) { total_ms[i] = 0; launches[i] = 0; }
+  if (!c->prof) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  c->prof->collect(total_ms, launches);
+  return TRXSIG_OK;
+}
+int trxsig_tables_validate_host(const void *h_blob, size_t bytes) {
+  if (!h_blob || bytes != sizeof(TrxTables)) return TRXSIG_EINVAL;
+  return trx_tables_valid((const TrxTables *)h_blob) ? TRXSIG_OK : TRXSIG_EINVAL;
 }
 
 }  // extern "C"

@@ -448,21 +448,25 @@ int trx_rec_slots(int sps) {
 template <int S>
 static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                               const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
-                              trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr) {
+                              trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                              TrxProfiler *prof) {
+  if (prof) prof->begin(TRXSIG_K_TSC_CORR, st);
   k_tsc_corr<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, tsc, rec, Bpad);
+  if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
   k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
                                                           flags, amp, toa, avgpwr);
+  if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
 }
 
 hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
-                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr) {
+                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   switch (sps) {
-    case 1: launch_tsc_detect<1>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr); break;
-    case 2: launch_tsc_detect<2>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr); break;
-    case 4: launch_tsc_detect<4>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr); break;
+    case 1: launch_tsc_detect<1>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 2: launch_tsc_detect<2>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 4: launch_tsc_detect<4>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -471,14 +475,16 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
 hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,
-                            uint8_t *hard, int nsoft, int stride) {
+                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   const dim3 grid((B + 3) / 4), block(256);
+  if (prof) prof->begin(TRXSIG_K_DEMOD, st);
   switch (sps) {
     case 1: k_demod<1><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
     case 2: k_demod<2><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
     case 4: k_demod<4><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
     default: return hipErrorInvalidValue;
   }
+  if (prof) prof->end(TRXSIG_K_DEMOD, st);
   return hipGetLastError();
 }

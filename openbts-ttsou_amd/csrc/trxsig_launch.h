@@ -6,17 +6,25 @@
 #include "trxsig.h"
 #include "trxsig_tables.h"
 
+// optional per-kernel event bracketing (trxsig_profile_*): called by the launchers around each kernel
+struct TrxProfiler {
+  virtual void begin(int kernel_id, hipStream_t st) = 0;
+  virtual void end(int kernel_id, hipStream_t st) = 0;
+  virtual ~TrxProfiler() {}
+};
+
 // number of complex slots per burst in the detect->peak record (SoA, [slot][Bpad])
 int trx_rec_slots(int sps);
 
 hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
-                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr);
+                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                                 TrxProfiler *prof);
 
 // need_mask != 0: burst enabled iff (flags[b] & need_mask) == need_mask; need_mask == 0: iff flags[b] != 0;
 // flags == NULL: every burst enabled.
 hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,
-                            uint8_t *hard, int nsoft, int stride);
+                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);

@@ -116,3 +116,71 @@ def rach_batch(sps, B, seed=0, sigmas=(0.0, 0.1, 0.3), max_delay_sym=60):
     delay = rng.integers(0, max_delay_sym + 1, B) * sps + rng.uniform(size=B)
     x, off, length, amp, sig = _finish(rng, modulate(bits, sps), B, sps, delay, sigmas)
     return x, off, length, dict(bits=bits, amp=amp, delay=delay.astype(np.float32), sigma=sig)
+
+
+# ---- torch (device) generators for the full-size benchmark workloads -----------------------------
+def _torch_batch(bits, sps, delay, amp, sigma, device, gen):
+    """bits [B,148] uint8 (torch, device) -> packed complex64 bursts on `device` (628/624/624/624)."""
+    import torch
+    B = bits.shape[0]
+    nsym = 157
+    N = nsym * sps
+    k = torch.arange(148, device=device)
+    rot = torch.tensor([1, 1j, -1, -1j], dtype=torch.complex64, device=device)[k % 4]
+    sym = (2.0 * bits.to(torch.float32) - 1.0).to(torch.complex64) * rot[None, :]
+    up = torch.zeros(B, N + 2 * sps, dtype=torch.complex64, device=device)
+    up[:, sps:sps + 148 * sps:sps] = sym
+    p = torch.from_numpy(gsm_pulse(sps)).to(device)
+    base = torch.zeros(B, N, dtype=torch.complex64, device=device)
+    for j in range(2 * sps + 1):
+        base += p[j] * up[:, 2 * sps - j:2 * sps - j + N]
+    # delay: integer part by gather, fractional part by 21-tap sinc
+    di = torch.floor(delay)
+    fr = (delay - di).to(torch.float32)
+    j = torch.arange(21, device=device, dtype=torch.float32)
+    taps = torch.sinc(j[None, :] - 10 - fr[:, None])
+    pad = torch.zeros(B, N + 20, dtype=torch.complex64, device=device)
+    pad[:, 10:10 + N] = base
+    y = torch.zeros(B, N, dtype=torch.complex64, device=device)
+    for jj in range(21):
+        y += taps[:, jj:jj + 1] * pad[:, 20 - jj:20 - jj + N]
+    idx = torch.arange(N, device=device)[None, :] - di.to(torch.int64)[:, None]
+    valid = (idx >= 0) & (idx < N)
+    y = torch.where(valid, torch.gather(y, 1, idx.clamp(0, N - 1)), torch.zeros((), dtype=torch.complex64, device=device))
+    noise = torch.randn(B, N, 2, device=device, generator=gen)
+    noise = torch.view_as_complex(noise) * (0.70710678 * sigma * amp.abs())[:, None]
+    y = y * amp[:, None] + noise
+    guard, length, off = burst_lengths(B, sps)
+    keep = torch.arange(N, device=device)[None, :] < torch.from_numpy(length).to(device)[:, None]
+    x = y[keep].contiguous()                         # row-major: burst after burst
+    return x, torch.from_numpy(off.astype(np.int32)).to(device), torch.from_numpy(length).to(device)
+
+
+def normal_batch_torch(sps, B, tsc, seed=0, device="cuda:0", sigmas=(0.0, 0.1, 0.3), max_delay=1.5,
+                       chunk=8192):
+    """Config 2 workload generated on the GPU: returns (x complex64 packed, off int32, len int32, meta)
+    with meta = dict(bits uint8 [B,148], amp complex64 [B], delay float32 [B], sigma float32 [B])."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    tsb = torch.tensor([int(c) for c in TRAINING_SEQUENCE[tsc]], dtype=torch.uint8, device=dev)
+    xs, bits_all, amp_all, delay_all, sig_all = [], [], [], [], []
+    sig_choices = torch.tensor(sigmas, dtype=torch.float32, device=dev)
+    assert chunk % 4 == 0
+    for s in range(0, B, chunk):
+        n = min(chunk, B - s)
+        bits = torch.randint(0, 2, (n, 148), device=dev, generator=gen, dtype=torch.uint8)
+        bits[:, :3] = 0; bits[:, -3:] = 0; bits[:, 61:87] = tsb
+        mag = 300 + 2700 * torch.rand(n, device=dev, generator=gen)
+        ph = 2 * np.pi * torch.rand(n, device=dev, generator=gen)
+        amp = torch.polar(mag, ph)
+        delay = (2 * torch.rand(n, device=dev, generator=gen) - 1) * max_delay
+        sigma = sig_choices[(torch.arange(n, device=dev) + s) % len(sigmas)]
+        x, _, _ = _torch_batch(bits, sps, delay, amp, sigma, dev, gen)
+        xs.append(x); bits_all.append(bits); amp_all.append(amp); delay_all.append(delay); sig_all.append(sigma)
+    guard, length, off = burst_lengths(B, sps)
+    x = torch.cat(xs)
+    meta = dict(bits=torch.cat(bits_all), amp=torch.cat(amp_all), delay=torch.cat(delay_all),
+                sigma=torch.cat(sig_all))
+    return (x, torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(length).to(dev), meta)
