@@ -325,12 +325,33 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
 
 // ---------------------------------------------------------------------------------------------
 // k_demod: demodulateBurst (sigProcLib.cpp:1056-1097): scaleVector(1/amp) -> delayVector(-TOA) ->
-//   GMSKReverseRotate -> decimateVector(sps) -> vectorSlicer.  One wave per burst.
+//   GMSKReverseRotate -> decimateVector(sps) -> vectorSlicer.  One wave per burst, no workgroup
+//   barrier (each wave owns its LDS slice).
 //
 // Only the decimated outputs are ever looked at, so the 21-tap fractional-delay FIR (:584-590) is
-// evaluated at t = sps*m - intOffset only.  The scaled burst sits in LDS in polyphase order
-// (sample n at [n % sps][n / sps]) so that the 64 lanes' stride-sps reads are contiguous.
+// evaluated at t = sps*m - intOffset only.  The scaled burst is staged in LDS *already shifted by
+// the integer delay* (sample n at position u = n + intOffset + C) and in polyphase order (position
+// u at [u % sps][u / sps]): output m then reads positions sps*m + 10 - j + C, whose phase and
+// offset are compile-time constants, so every tap is one ds_read_b64 at base+immediate and the 64
+// lanes of a read are contiguous (no bank conflicts).  The 21 real taps are wave-uniform and live
+// in SGPRs: from the sinc grid when -TOA lies on the 1/512 grid (always, after peakDetect), else
+// computed with the reference's table sinc.
 // ---------------------------------------------------------------------------------------------
+template <int SPS>
+struct DemodGeom {
+  static constexpr int C = 52;                                   // position of sample 0 at intOffset 0 (multiple of 4)
+  static constexpr int QLEN = 157 + (10 + C + SPS - 1) / SPS;    // entries per phase
+  static constexpr int U = SPS * QLEN;                           // positions
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from
+  // reordering them across the point where lanes start reading what other lanes wrote.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int SPS>
 __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
                                                const cx *__restrict__ samples,
@@ -341,93 +362,114 @@ __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
                                                const uint8_t *__restrict__ flags, int need_mask,
                                                float *__restrict__ soft, uint8_t *__restrict__ hard,
                                                int nsoft, int stride) {
-  constexpr int PADN = 12;                                 // zero samples in front (multiple of SPS, >= 10)
-  constexpr int QLEN = (157 * SPS + 2 * PADN) / SPS + 1;   // entries per phase
-  __shared__ cx ph[4][SPS][QLEN];
-  __shared__ float taps[4][24];
+  typedef DemodGeom<SPS> G;
+  __shared__ cx ph[4][G::U];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  const bool live = b < B;                                 // wave-uniform
-  const int bb = live ? b : B - 1;
-  float *sb = soft + (size_t)bb * stride;
-  uint8_t *hb = hard ? hard + (size_t)bb * stride : nullptr;
-  const int off = offset[bb], N = length[bb];
-  const cx amp = amp_in[bb];
-  const float toa = toa_in[bb];
-  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0) &&
-                    (fabsf(toa) <= 4096.0f);               // also rejects NaN/inf TOA
-  bool enabled = live && good;
-  if (flags) enabled = enabled && (need_mask ? ((flags[bb] & need_mask) == need_mask) : (flags[bb] != 0));
-  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066)
-
-  // delayVector(-TOA) bookkeeping (:577-582)
-  const float delay = enabled ? -toa : 0.0f;
-  const int io = (int)floorf(delay);
-  const float frac = delay - (float)io;
-  const bool filt = fabs((double)frac) > 1e-2;
-  if (filt && lane < 21) taps[wave][lane] = dev_sinc(T->sinT, TRX_PI_F * ((float)(lane - 10) - frac));  // :588
-
-  // ---- stage scaled samples, polyphase, zero padded ----
-  cx(*P)[QLEN] = ph[wave];
-  for (int i = lane; i < SPS * QLEN; i += 64) P[i / QLEN][i % QLEN] = mk(0, 0);
-  __syncthreads();
-  if (enabled) {
-    const cx *xb = samples + off;
-    if ((off & 1) == 0) {                                  // 16-byte aligned burst: 2 samples per load
-      const float4 *xv = reinterpret_cast<const float4 *>(xb);
-      for (int q = lane; q < N / 2; q += 64) {
-        const float4 v = xv[q];
-        const cx a = cmul(mk(v.x, v.y), inv), c = cmul(mk(v.z, v.w), inv);   // scaleVector (:713-723)
-        const int n0 = 2 * q + PADN, n1 = n0 + 1;
-        P[n0 % SPS][n0 / SPS] = a;
-        P[n1 % SPS][n1 / SPS] = c;
-      }
-      if ((N & 1) && lane == 0) {
-        const int n0 = N - 1 + PADN;
-        P[n0 % SPS][n0 / SPS] = cmul(xb[N - 1], inv);
-      }
-    } else {
-      for (int n = lane; n < N; n += 64) {
-        const int n0 = n + PADN;
-        P[n0 % SPS][n0 / SPS] = cmul(xb[n], inv);
-      }
-    }
-  }
-  __syncthreads();
-  if (!live) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;                     // wave-uniform
+  if (b >= B) return;
+  float *sb = soft + (size_t)b * stride;
+  uint8_t *hb = hard ? hard + (size_t)b * stride : nullptr;
+  const int off = offset[b], N = length[b];
+  const cx amp = amp_in[b];
+  const float toa = toa_in[b];
+  bool enabled = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0) &&
+                 (fabsf(toa) <= 4096.0f);                  // also rejects NaN/inf TOA
+  if (flags) enabled = enabled && (need_mask ? ((flags[b] & need_mask) == need_mask) : (flags[b] != 0));
   if (!enabled) {
     for (int m = lane; m < nsoft; m += 64) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
     return;
   }
+  const cx *xb = samples + off;
 
+  // ---- issue the burst's loads first (16-byte path: 2 samples per lane per load) ----
+  constexpr int NLD = (157 * SPS / 2 + 63) / 64;           // float4 loads per lane
+  const bool wide = (off & 1) == 0;
+  float4 v[NLD];
+  if (wide) {
+    const float4 *xv = reinterpret_cast<const float4 *>(xb);
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int q = lane + 64 * i;
+      v[i] = (q < N / 2) ? xv[q] : make_float4(0, 0, 0, 0);
+    }
+  }
+
+  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066)
+  // delayVector(-TOA) bookkeeping (:577-582)
+  const float delay = -toa;
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  const bool filt = fabs((double)frac) > 1e-2;
   float tp[21];
+  {
+    const float f512 = frac * 512.0f;
+    const int f = (int)f512;
+    if ((float)f == f512) {                                // on the 1/512 grid: sinc_grid[f][j] (uniform -> s_load)
 #pragma unroll
-  for (int j = 0; j < 21; j++) tp[j] = filt ? taps[wave][j] : 0.0f;
+      for (int j = 0; j < 21; j++) tp[j] = T->sinc_grid[f][j];
+    } else {
+      const float tv = dev_sinc(T->sinT, TRX_PI_F * ((float)(lane - 10) - frac));   // :588
+#pragma unroll
+      for (int j = 0; j < 21; j++) tp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tv), j));
+    }
+  }
 
-  const cx *rev = T->rev;
-  for (int m = lane; m < nsoft; m += 64) {
-    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
-    cx y = mk(0, 0);
-    if (t >= 0 && t < N) {
-      if (filt) {
+  // ---- stage scaled samples at position n + io + C; zero the positions left uncovered ----
+  cx *P = ph[wave];
+  const int lo = io + G::C, hi = N + io + G::C;            // samples occupy positions [lo, hi)
+  for (int u = lane; u < lo && u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
+  for (int u = (hi > 0 ? hi : 0) + lane; u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
+  if (wide) {
 #pragma unroll
-        for (int j = 0; j < 21; j++) {                     // convolve(...,NO_DELAY), 21 real taps (:590)
-          const int n = t + 10 - j + PADN;                 // >= 2, < N + 22: inside the padded array
-          y = cadd(y, cmulr(P[n % SPS][n / SPS], tp[j]));
-        }
-      } else {
-        const int n = t + PADN;
-        y = P[n % SPS][n / SPS];
+    for (int i = 0; i < NLD; i++) {
+      const int q = lane + 64 * i;
+      if (q < N / 2) {
+        const cx a = cmul(mk(v[i].x, v[i].y), inv), c = cmul(mk(v[i].z, v[i].w), inv);   // scaleVector (:713-723)
+        const int u0 = 2 * q + lo, u1 = u0 + 1;
+        if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = a;
+        if (u1 >= 0 && u1 < G::U) P[(u1 % SPS) * G::QLEN + u1 / SPS] = c;
       }
     }
-    const cx rv = rev[SPS * m];
-    const float re = rv.r * y.r - rv.i * y.i;              // real part of GMSKReverseRotate (:259-262)
-    float v = (float)(0.5 * (double)(re + 1.0F));          // vectorSlicer (:513-515)
-    if (v > 1.0f) v = 1.0f;
-    if (v < 0.0f) v = 0.0f;
-    sb[m] = v;
-    if (hb) hb[m] = v > 0.5F;                              // SoftVector::bit (BitVector.h:415-420)
+    if ((N & 1) && lane == 0) {
+      const int u0 = N - 1 + lo;
+      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[N - 1], inv);
+    }
+  } else {
+    for (int n = lane; n < N; n += 64) {
+      const int u0 = n + lo;
+      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[n], inv);
+    }
+  }
+  wave_lds_fence();
+
+  const cx *rev = T->rev;
+  for (int m0 = 0; m0 < nsoft; m0 += 64) {
+    const int m = m0 + lane;
+    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
+    cx y = mk(0, 0);
+    if (m < nsoft && t >= 0 && t < N) {
+      if (filt) {
+#pragma unroll
+        for (int j = 0; j < 21; j++) {                     // convolve(...,NO_DELAY), 21 real taps, j ascending (:590)
+          constexpr int dummy = 0; (void)dummy;
+          const int k = 10 - j + G::C;                     // position = SPS*m + k
+          y = cadd(y, cmulr(P[(k % SPS) * G::QLEN + k / SPS + m], tp[j]));
+        }
+      } else {
+        y = P[(G::C % SPS) * G::QLEN + G::C / SPS + m];
+      }
+    }
+    if (m < nsoft) {
+      const cx rv = rev[SPS * m];
+      const float re = rv.r * y.r - rv.i * y.i;            // real part of GMSKReverseRotate (:259-262)
+      float sv = (float)(0.5 * (double)(re + 1.0F));       // vectorSlicer (:513-515)
+      if (sv > 1.0f) sv = 1.0f;
+      if (sv < 0.0f) sv = 0.0f;
+      sb[m] = sv;
+      if (hb) hb[m] = sv > 0.5F;                           // SoftVector::bit (BitVector.h:415-420)
+    }
   }
 }
 

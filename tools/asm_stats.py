@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Static instruction mix per kernel from `make -C openbts-ttsou_amd/csrc asm` output, and a check that
+every v_fma/v_mac in the kernels belongs to an IEEE division expansion (v_div_scale ... v_div_fixup):
+the numerical contract forbids contracted multiply-adds anywhere else."""
+import re
+import sys
+from collections import Counter
+
+path = sys.argv[1] if len(sys.argv) > 1 else "openbts-ttsou_amd/csrc/trxsig_kernels.gfx950.s"
+only = sys.argv[2] if len(sys.argv) > 2 else ""
+text = open(path).read()
+for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
+    name, body = m.group(1), m.group(2)
+    if only and only not in name:
+        continue
+    ins = [l.strip() for l in body.split("\n") if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    ops = [i.split()[0] for i in ins]
+    c = Counter()
+    for o in ops:
+        if o.startswith("v_"): c["valu"] += 1
+        elif o.startswith("s_waitcnt"): c["waitcnt"] += 1
+        elif o.startswith("s_barrier"): c["barrier"] += 1
+        elif o.startswith("s_"): c["salu"] += 1
+        elif o.startswith("ds_"): c["lds"] += 1
+        elif o.startswith(("global_", "buffer_", "flat_")): c["vmem"] += 1
+    fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma|mac|fmac|mad|pk_fma)", o)]
+    # a division expansion keeps its fma's between v_div_scale and v_div_fixup
+    bad = 0
+    for i in fma:
+        lo = max(0, i - 14); hi = min(len(ops), i + 14)
+        if not any(o.startswith("v_div_scale") or o.startswith("v_rcp") for o in ops[lo:i]) or \
+           not any(o.startswith("v_div_f") for o in ops[i:hi]):
+            bad += 1
+    kind = re.search(r"\d+(k_\w+?)ILi(\d)", name)
+    label = "%s<sps=%s>" % (kind.group(1), kind.group(2)) if kind else name[:50]
+    print("%-28s total %5d  %s  fma %d (outside a division: %d)" % (label, len(ops), dict(c), len(fma), bad))
