@@ -46,6 +46,14 @@ __device__ __forceinline__ float row_shl(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
 }
 
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from
+  // reordering them across the point where lanes start reading what other lanes wrote.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // sinLookup (sigProcLib.cpp:177-188) and sinc (:567-571) against the uploaded trig table
 __device__ __forceinline__ float dev_sin_lookup(const float *__restrict__ sinT, float x) {
   float arg = x * (1 / TRX_2PI_F);
@@ -80,7 +88,8 @@ struct CorrGeom {
   static constexpr int NL = 36 * SPS;                    // lags (window length)
   static constexpr int NC = (NL + 15) / 16;              // lags per lane
   static constexpr int FRONT = 8 * SPS;                  // zero pad in front of the window
-  static constexpr int WPAD = NC * 16 + 15 * SPS + 1;    // padded window length
+  static constexpr int WPAD0 = NC * 16 + 15 * SPS + 1;   // padded window length needed
+  static constexpr int WPAD = ((WPAD0 + 15) / 32) * 32 + 16;   // rounded up to 16 (mod 32): rows 32 dwords apart (mod 64)
   static constexpr int H = (5 * SPS + 1 > 12) ? 5 * SPS + 1 : 12;   // record half width
   static constexpr int NS = 2 * H + 1;                   // corr slots in a record (+1 meta slot)
   static constexpr int NE = 20 * SPS;                    // energyDetect window
@@ -106,8 +115,9 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
                                                   const int32_t *__restrict__ length, int B, int tsc,
                                                   cx *__restrict__ rec, int Bpad) {
   typedef CorrGeom<SPS> G;
-  __shared__ cx win[16][G::WPAD];
-  __shared__ cx cor[16][G::NL];
+  // one LDS row per burst, owned by the 16 lanes of its DPP row; no workgroup barrier anywhere.
+  // The row first holds the zero-padded window, later (same storage) the correlation.
+  __shared__ cx rows[16][G::WPAD];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane >> 4, r = lane & 15;
@@ -117,28 +127,28 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
   int off = 0, len = 0;
   if (live) { off = offset[b]; len = length[b]; }
   const bool good = live && (off >= 0) && (len >= 92 * SPS) && (len <= 157 * SPS) && (len % SPS == 0);
-  const cx *x = samples + off;
+  const cx *x = samples + (good ? off : 0);
+  cx *W = rows[slot];
 
-  // ---- stage the window into LDS (16-byte loads: 2 samples per lane per load) ----
-  for (int q = r; q < G::WPAD / 2 + 1; q += 16) {          // zero everything first (pads included)
-    if (2 * q < G::WPAD) win[slot][2 * q] = mk(0, 0);
-    if (2 * q + 1 < G::WPAD) win[slot][2 * q + 1] = mk(0, 0);
-  }
-  __syncthreads();
-  if (good) {
-    if (((off + 56 * SPS) & 1) == 0) {                     // 16-byte aligned window: 2 samples per load
-      const float4 *xw = reinterpret_cast<const float4 *>(x + 56 * SPS);
-      for (int q = r; q < G::NL / 2; q += 16) {
-        float4 v = xw[q];
-        win[slot][G::FRONT + 2 * q] = mk(v.x, v.y);
-        win[slot][G::FRONT + 2 * q + 1] = mk(v.z, v.w);
-      }
-    } else {
-      for (int q = r; q < G::NL; q += 16) win[slot][G::FRONT + q] = x[56 * SPS + q];
+  // ---- issue all global loads first: window (2 samples per 16-byte load) and energy window ----
+  constexpr int NWQ = (G::NL / 2 + 15) / 16;               // float4 loads per lane
+  const bool wide = ((off + 56 * SPS) & 1) == 0;
+  float4 wv[NWQ];
+  cx wn[2 * NWQ];
+  if (good && wide) {
+    const float4 *xw = reinterpret_cast<const float4 *>(x + 56 * SPS);
+#pragma unroll
+    for (int i = 0; i < NWQ; i++) {
+      const int q = r + 16 * i;
+      wv[i] = (q < G::NL / 2) ? xw[q] : make_float4(0, 0, 0, 0);
+    }
+  } else if (good) {
+#pragma unroll
+    for (int i = 0; i < 2 * NWQ; i++) {
+      const int q = r + 16 * i;
+      wn[i] = (q < G::NL) ? x[56 * SPS + q] : mk(0, 0);
     }
   }
-
-  // ---- energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order ----
   float nrm[G::NEQ];
 #pragma unroll
   for (int q = 0; q < G::NEQ; q++) {
@@ -147,10 +157,33 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
     if (good && i < G::NE) v = x[i];
     nrm[q] = norm2(v);
   }
+
+  // ---- zero pads, then the window ----
+  for (int q = r; q < G::FRONT; q += 16) W[q] = mk(0, 0);
+  for (int q = G::FRONT + G::NL + r; q < G::WPAD; q += 16) W[q] = mk(0, 0);
+  if (good && wide) {
+#pragma unroll
+    for (int i = 0; i < NWQ; i++) {
+      const int q = r + 16 * i;
+      if (q < G::NL / 2) {
+        W[G::FRONT + 2 * q] = mk(wv[i].x, wv[i].y);
+        W[G::FRONT + 2 * q + 1] = mk(wv[i].z, wv[i].w);
+      }
+    }
+  } else if (good) {
+#pragma unroll
+    for (int i = 0; i < 2 * NWQ; i++) {
+      const int q = r + 16 * i;
+      if (q < G::NL) W[G::FRONT + q] = wn[i];
+    }
+  } else {
+    for (int q = G::FRONT + r; q < G::FRONT + G::NL; q += 16) W[q] = mk(0, 0);
+  }
+
+  // ---- energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order ----
   float energy = energy_chain<SPS, 0>(0.0f, nrm);
-  // lane 0 of the row now holds the reference's energy; broadcast it to the row
-  energy = __shfl(energy, lane & 48, 64);
-  __syncthreads();
+  energy = __shfl(energy, lane & 48, 64);                  // lane 0 of the row holds it
+  wave_lds_fence();
 
   // ---- correlation: 16 non-zero taps, k descending = j ascending ----
   cx tap[16];
@@ -159,15 +192,32 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
 
   float bestP = 0.0f;
   int bestT = -1;
+  cx cval[G::NC];
+  constexpr int CG = (SPS == 4) ? 3 : 1;                   // lags per register group
+  constexpr int UPC = 16 / SPS;                            // stride-SPS sample steps per 16 lags
+  constexpr int NU = UPC * (CG - 1) + 16;
+#pragma unroll
+  for (int c0 = 0; c0 < G::NC; c0 += CG) {
+    cx sv[NU];                                             // sv[u] = W[r + 16*c0 + SPS*u]
+#pragma unroll
+    for (int u = 0; u < NU; u++) sv[u] = W[r + 16 * c0 + SPS * u];
+#pragma unroll
+    for (int cc = 0; cc < CG; cc++) {
+      if (c0 + cc < G::NC) {
+        cx acc = mk(0, 0);
+#pragma unroll
+        for (int k = 15; k >= 0; k--) acc = cadd(acc, cmul(sv[UPC * cc + k], tap[k]));
+        cval[c0 + cc] = acc;
+      }
+    }
+  }
+  wave_lds_fence();                                        // every lane is done reading the window
 #pragma unroll
   for (int c = 0; c < G::NC; c++) {
     const int t = r + 16 * c;
-    cx acc = mk(0, 0);
-#pragma unroll
-    for (int k = 15; k >= 0; k--) acc = cadd(acc, cmul(win[slot][t + SPS * k], tap[k]));
     if (t < G::NL) {
-      cor[slot][t] = acc;
-      const float p = norm2(acc);
+      W[t] = cval[c];
+      const float p = norm2(cval[c]);
       if (p > bestP) { bestP = p; bestT = t; }             // strict >, first maximum (:675)
     }
   }
@@ -179,7 +229,7 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
     const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
     if (take) { bestP = oP; bestT = oT; }
   }
-  __syncthreads();
+  wave_lds_fence();
 
   // ---- record: corr[M-H .. M+H] (zeros outside [0,NL)), then {M, energy} ----
   if (live) {
@@ -188,7 +238,7 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
       cx v = mk(0, 0);
       if (s < G::NS) {
         const int lag = M - G::H + s;
-        if (lag >= 0 && lag < G::NL) v = cor[slot][lag];
+        if (lag >= 0 && lag < G::NL) v = W[lag];
       } else {
         v = mk(__int_as_float(good ? M : -2), energy);   // M = -2 marks an invalid burst
       }
@@ -215,70 +265,82 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
                                                  float *__restrict__ toa_out,
                                                  float *__restrict__ avgpwr_out) {
   typedef CorrGeom<SPS> G;
-  __shared__ cx loc[26][64];                               // [24],[25] stay zero                               // lags M-12 .. M+11 of each lane's burst
+  __shared__ cx loc[26][64];                               // lags M-12 .. M+11 of each lane's burst; [24],[25] zero
+  __shared__ float pw[G::NS][64];                          // |corr|^2 of lags M-H .. M+H (valley power)
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
   const bool live = b < B;
   const int bb = live ? b : B - 1;
 
+  // ---- everything this lane will need from the record, loaded up front (coalesced across lanes) ----
   const cx meta = rec[(size_t)G::NS * Bpad + bb];
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
   const bool good = M != -2;
 #pragma unroll
-  for (int j = 0; j < 24; j++) {
-    const int lag = M - 12 + j;
-    cx v = rec[(size_t)(G::H - 12 + j) * Bpad + bb];
-    if (lag > G::NL - 2) v = mk(0, 0);                     // interpolatePoint never uses the last sample (:646)
-    loc[j][lane] = v;
+  for (int s = 0; s < G::NS; s++) {
+    const cx v = rec[(size_t)s * Bpad + bb];
+    pw[s][lane] = norm2(v);
+    const int j = s - (G::H - 12);
+    if (j >= 0 && j < 24) {
+      const int lag = M - 12 + j;
+      loc[j][lane] = (lag > G::NL - 2) ? mk(0, 0) : v;     // interpolatePoint never uses the last sample (:646)
+    }
   }
   loc[24][lane] = mk(0, 0);
   loc[25][lane] = mk(0, 0);
-  __syncthreads();
+  // (each lane only ever reads its own column: no barrier needed)
 
-  // interpolate at ix (I = floor(ix) relative to M, f = frac*512)
-  auto interp2 = [&](float ix, int dI2, cx &pa, cx &pb) {
-    // pa = interpolatePoint(ix), pb = interpolatePoint(ix + dI2) -- same fractional part
-    const float fl = floorf(ix);
-    const int I = (int)fl;
-    const int f = (int)((ix - fl) * 512.0f);
-    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f]);
-    float s[24];
+  // sinc rows: the step's row is known one step ahead up to the sign of the early/late decision,
+  // so both candidates are fetched while the current step computes.
+  auto load_row = [&](int f, float (&s)[24]) {
+    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       const float4 v = row[q];
       s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
     }
+  };
+  // pa = interpolatePoint(ix), pb = interpolatePoint(ix + dI2): same fractional part, row s
+  auto interp2 = [&](float ix, int dI2, const float (&s)[24], cx &pa, cx &pb) {
+    const int I = (int)floorf(ix);
     int base = I - M + 2;                                  // loc index of tap j = 0 (0..3 by construction)
     base = base < 0 ? 0 : (base > 3 ? 3 : base);
     pa = mk(0, 0); pb = mk(0, 0);
 #pragma unroll
     for (int j = 0; j < 21; j++) {
-      const int ia = base + j, ib = base + j + dI2;
-      pa = cadd(pa, cmulr(loc[ia][lane], s[j]));
-      pb = cadd(pb, cmulr(loc[ib][lane], s[j]));
+      pa = cadd(pa, cmulr(loc[base + j][lane], s[j]));
+      pb = cadd(pb, cmulr(loc[base + j + dI2][lane], s[j]));
     }
   };
+  auto frac512 = [](float ix) { return (int)((ix - floorf(ix)) * 512.0f); };
 
-  float early = (float)M - 1, late = (float)M + 1;
+  float early = (float)M - 1;
   float incr = 0.5f;
   bool active = true;
+  float cur[24], up[24], dn[24];
+  load_row(0, cur);                                        // early = M-1 is an integer
 #pragma unroll 1
   for (int step = 0; step < 9; step++) {                   // incr = 2^-1 .. 2^-9  (> 1/1024)
+    load_row(frac512(early + incr), up);                   // candidates for the next step / the final point
+    load_row(frac512(early - incr), dn);
     cx e, l;
-    interp2(early, 2, e, l);
+    interp2(early, 2, cur, e, l);
+    const float ne = norm2(e), nl = norm2(l);
+    const bool goUp = ne < nl, goDn = ne > nl;
     if (active) {
-      const float ne = norm2(e), nl = norm2(l);
-      if (ne < nl) early += incr;
-      else if (ne > nl) early -= incr;
+      if (goUp) early += incr;
+      else if (goDn) early -= incr;
       else active = false;                                 // "else break" (:695)
-      if (active) { incr = incr * 0.5f; late = early + 2.0f; }
+      if (active) incr = incr * 0.5f;
     }
+    const bool moved = active;                             // row changes only if the index moved
+#pragma unroll
+    for (int j = 0; j < 24; j++) cur[j] = moved ? (goUp ? up[j] : dn[j]) : cur[j];
   }
-  (void)late;
-  const float peakIx = early + 1.0f;
+  const float peakIx = early + 1.0f;                       // same fractional part as `early`: row = cur
   cx peak, dummy;
-  interp2(peakIx, 0, peak, dummy);
+  interp2(peakIx, 0, cur, peak, dummy);
 
   // ---- analyzeTrafficBurst tail ----
   float toa = peakIx;
@@ -291,11 +353,14 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
     const int p = (int)rintf(toa);
     float valley = 0.0f;
     int numRms = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 2 * SPS; i <= 5 * SPS; i++) {             // :971-980, this order
       const int lo = p - i, hi = p + i;
-      if (lo >= 0) { valley += norm2(rec[(size_t)(lo - M + G::H) * Bpad + bb]); numRms++; }
-      if (hi < G::NL) { valley += norm2(rec[(size_t)(hi - M + G::H) * Bpad + bb]); numRms++; }
+      int slo = lo - M + G::H, shi = hi - M + G::H;        // 0 .. NS-1 because |p - M| <= 1
+      slo = slo < 0 ? 0 : slo; shi = shi > G::NS - 1 ? G::NS - 1 : shi;
+      const float vlo = pw[slo][lane], vhi = pw[shi][lane];
+      if (lo >= 0) { valley += vlo; numRms++; }
+      if (hi < G::NL) { valley += vhi; numRms++; }
     }
     if (numRms < 2) {
       amp = mk(0, 0);
@@ -343,14 +408,6 @@ struct DemodGeom {
   static constexpr int QLEN = 157 + (10 + C + SPS - 1) / SPS;    // entries per phase
   static constexpr int U = SPS * QLEN;                           // positions
 };
-
-__device__ __forceinline__ void wave_lds_fence() {
-  // LDS operations of one wave execute in issue order; this only stops the compiler from
-  // reordering them across the point where lanes start reading what other lanes wrote.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <int SPS>
 __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
