@@ -40,6 +40,16 @@ KERNEL_ALG_BYTES = {
 }
 
 
+def measured_traffic(kernel, bursts):
+    """HBM bytes per launch of `kernel` from the committed PMC run (profiles/traffic.json: rocprofv3
+    FETCH_SIZE x2 + WRITE_SIZE, separate passes, same bench command), scaled to this batch size."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"][kernel]
+        return int(t["hbm_bytes_per_launch"] * (bursts / float(t["bursts_per_launch"])))
+    except Exception:
+        return None
+
+
 def cpu_baseline(x_host, off, length, sps, tsc, target_seconds=8.0):
     """The CPU oracle (a port of the reference's algorithm, oracle/sigproc_oracle.c) timed on this
     box's host cores over a bounded sample of the same workload."""
@@ -161,7 +171,8 @@ def main():
         avg_ms = dom[1][0] / max(dom[1][1], 1)
         achieved = KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES) * B / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom[0], B),
+                "alg_bytes_per_launch": KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES) * B,
                 "avg_kernel_ms": round(avg_ms, 4),
                 "alg_bytes_per_burst": KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES),
                 "pipeline_achieved": round(ALG_BYTES * B * args.steps / (ev_ms * 1e-3) / 1e9, 1),
