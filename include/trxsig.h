@@ -134,12 +134,10 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *ctx,
                                      float *d_avgpwr,
                                      float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
-#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 /* trxsig_detect_demod_rach_batch: same for access bursts: detectRACHBurst(burst, detect_thresh,
  *   sps, &amp, &TOA) + demodulateBurst (Transceiver.cpp:362-366, 385-388; sigProcLib.h:263-267).
- *   Tolerance: amp/TOA/soft/hard are bit-identical; the detect flag can differ from the
- *   reference only when the reference's peak-to-valley ratio is within 1e-5 (relative) of
- *   detect_thresh (the valley power is summed in a different order). */
+ *   The 41*sps-tap correlation is evaluated over every lag exactly as the reference does
+ *   (same terms, same order), so flags/amp/TOA/soft/hard are all bit-identical. */
 int trxsig_detect_demod_rach_batch(trxsig_ctx *ctx,
                                    const trxsig_c32 *d_samples, const int32_t *d_offset,
                                    const int32_t *d_length, int B,
@@ -148,7 +146,6 @@ int trxsig_detect_demod_rach_batch(trxsig_ctx *ctx,
                                    float *d_avgpwr,
                                    float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
-#endif /* TRXSIG_NEXT */
 
 /* trxsig_demodulate_batch: demodulateBurst alone with caller-supplied amp/TOA
  *   (sigProcLib.h:316-320; used for RACH after detect and by TRANSMIT_LOGGING,
@@ -210,12 +207,12 @@ int trxsig_detect_demod_normal_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples
                                     int tsc, float detect_thresh, float energy_thresh,
                                     uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
                                     float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
-#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 int trxsig_detect_demod_rach_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples,
                                   const int32_t *h_offset, const int32_t *h_length, int B,
                                   float detect_thresh, float energy_thresh,
                                   uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
                                   float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
+#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *h_guard,
                          const float *h_gain, int B, trxsig_c32 *h_out, const int32_t *h_out_offset,
                          int64_t out_samples);

@@ -57,6 +57,9 @@ def lib():
         L.trxsig_tables_export.argtypes = [vp, vp, C.c_size_t]
         L.trxsig_detect_demod_normal_batch.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp,
                                                        i32, i32]
+        L.trxsig_detect_demod_rach_batch.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32]
+        L.trxsig_detect_demod_normal_host.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, i32, i32]
+        L.trxsig_detect_demod_rach_host.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_demodulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
@@ -169,6 +172,37 @@ class TrxSig:
             self.h, _ptr(samples), _ptr(offset), _ptr(length), B, tsc, detect_thresh, energy_thresh,
             _ptr(flags), _ptr(amp), _ptr(toa), _ptr(avgpwr), _ptr(soft), _ptr(hard), nsoft, soft_stride),
             "trxsig_detect_demod_normal_batch")
+
+    def detect_demod_rach(self, samples, offset, length, flags, amp, toa, soft, avgpwr=None, hard=None,
+                          detect_thresh=5.0, energy_thresh=0.0, nsoft=148, soft_stride=None):
+        B = offset.numel() if hasattr(offset, "numel") else len(offset)
+        if soft_stride is None:
+            soft_stride = soft.shape[-1] if soft is not None and hasattr(soft, "shape") else nsoft
+        self._chk(self.L.trxsig_detect_demod_rach_batch(
+            self.h, _ptr(samples), _ptr(offset), _ptr(length), B, detect_thresh, energy_thresh,
+            _ptr(flags), _ptr(amp), _ptr(toa), _ptr(avgpwr), _ptr(soft), _ptr(hard), nsoft, soft_stride),
+            "trxsig_detect_demod_rach_batch")
+
+    def detect_demod_host(self, x, off, length, tsc=None, detect_thresh=None, energy_thresh=0.0, nsoft=148):
+        """Host-buffer convenience call (numpy in/out, PCIe-inclusive): tsc=None -> RACH path."""
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); off = np.ascontiguousarray(off, np.int32)
+        length = np.ascontiguousarray(length, np.int32)
+        B = len(off)
+        flags = np.zeros(B, np.uint8); amp = np.zeros(B, np.complex64); toa = np.zeros(B, np.float32)
+        pwr = np.zeros(B, np.float32); soft = np.zeros((B, nsoft), np.float32)
+        a = lambda v: v.ctypes.data
+        if tsc is None:
+            rc = self.L.trxsig_detect_demod_rach_host(self.h, a(x), a(off), a(length), B,
+                                                      5.0 if detect_thresh is None else detect_thresh, energy_thresh,
+                                                      a(flags), a(amp), a(toa), a(pwr), a(soft), nsoft, nsoft)
+        else:
+            rc = self.L.trxsig_detect_demod_normal_host(self.h, a(x), a(off), a(length), B, tsc,
+                                                        3.0 if detect_thresh is None else detect_thresh,
+                                                        energy_thresh, a(flags), a(amp), a(toa), a(pwr), a(soft),
+                                                        nsoft, nsoft)
+        self._chk(rc, "trxsig_detect_demod_*_host")
+        return dict(flags=flags, amp=amp, toa=toa, pwr=pwr, soft=soft)
 
     def demodulate(self, samples, offset, length, amp, toa, soft, enable=None, hard=None, nsoft=148,
                    soft_stride=None):

@@ -117,7 +117,10 @@ int ensure_ws(trxsig_ctx *c, int B) {
   if (B <= c->cap_bursts) return TRXSIG_OK;
   int cap = (B + 255) & ~255;
   if (c->d_rec) { HIPCHK(c, hipFree(c->d_rec)); c->d_rec = nullptr; c->cap_bursts = 0; }
-  HIPCHK(c, hipMalloc((void **)&c->d_rec, sizeof(trx_c32) * (size_t)trx_rec_slots(c->sps) * cap));
+  size_t per_burst = sizeof(trx_c32) * (size_t)trx_rec_slots(c->sps);
+  const size_t rach = sizeof(float) * (size_t)trx_rach_rec_floats(c->sps);
+  if (rach > per_burst) per_burst = rach;
+  HIPCHK(c, hipMalloc((void **)&c->d_rec, per_burst * cap));
   c->cap_bursts = cap;
   return TRXSIG_OK;
 }
@@ -278,6 +281,28 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   return TRXSIG_OK;
 }
 
+int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                   const int32_t *d_length, int B, float detect_thresh, float energy_thresh,
+                                   uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr,
+                                   float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_samples, d_offset, d_length, B) || nsoft < 0 || nsoft > 157 || soft_stride < nsoft ||
+      (B > 0 && (!d_flags || !d_amp || !d_toa || (nsoft > 0 && !d_soft))))
+    return fail(c, TRXSIG_EINVAL, "trxsig_detect_demod_rach_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_ws(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, trx_launch_rach_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
+                                   B, detect_thresh, energy_thresh, (float *)c->d_rec, c->cap_bursts, d_flags,
+                                   (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+  if (nsoft > 0)
+    HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                               (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
+                               soft_stride, c->prof));
+  return TRXSIG_OK;
+}
+
 int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
                             const int32_t *d_length, int B, const trxsig_c32 *d_amp, const float *d_toa,
                             const uint8_t *d_enable, float *d_soft, uint8_t *d_hard, int nsoft,
@@ -294,14 +319,14 @@ int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const in
 }
 
 // ---- host-buffer wrappers (PCIe-inclusive convenience; never the timed path) ------------------------
-int trxsig_detect_demod_normal_host(trxsig_ctx *c, const trxsig_c32 *h_samples, const int32_t *h_offset,
-                                    const int32_t *h_length, int B, int tsc, float detect_thresh,
-                                    float energy_thresh, uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
-                                    float *h_avgpwr, float *h_soft, int nsoft, int soft_stride) {
+static int detect_demod_host(trxsig_ctx *c, bool rach, const trxsig_c32 *h_samples, const int32_t *h_offset,
+                             const int32_t *h_length, int B, int tsc, float detect_thresh, float energy_thresh,
+                             uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa, float *h_avgpwr, float *h_soft,
+                             int nsoft, int soft_stride) {
   if (!c) return TRXSIG_EINVAL;
   if (bad_batch(h_samples, h_offset, h_length, B) || (B > 0 && (!h_flags || !h_amp || !h_toa)) || nsoft < 0 ||
       nsoft > 157 || soft_stride < nsoft || (nsoft > 0 && B > 0 && !h_soft))
-    return fail(c, TRXSIG_EINVAL, "trxsig_detect_demod_normal_host: bad argument");
+    return fail(c, TRXSIG_EINVAL, "trxsig_detect_demod_*_host: bad argument");
   if (B == 0) return TRXSIG_OK;
   int64_t total = 0;
   for (int b = 0; b < B; b++) {
@@ -321,10 +346,16 @@ int trxsig_detect_demod_normal_host(trxsig_ctx *c, const trxsig_c32 *h_samples, 
   HIPCHK(c, hipMemcpyAsync(d + o_s, h_samples, sizeof(trx_c32) * (size_t)total, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + o_off, h_offset, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + o_len, h_length, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
-  rc = trxsig_detect_demod_normal_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), B,
-                                        tsc, detect_thresh, energy_thresh, (uint8_t *)(d + o_fl),
+  if (rach)
+    rc = trxsig_detect_demod_rach_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), B,
+                                        detect_thresh, energy_thresh, (uint8_t *)(d + o_fl),
                                         (trxsig_c32 *)(d + o_amp), (float *)(d + o_toa), (float *)(d + o_pwr),
                                         (float *)(d + o_soft), nullptr, nsoft, soft_stride);
+  else
+    rc = trxsig_detect_demod_normal_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len),
+                                          B, tsc, detect_thresh, energy_thresh, (uint8_t *)(d + o_fl),
+                                          (trxsig_c32 *)(d + o_amp), (float *)(d + o_toa), (float *)(d + o_pwr),
+                                          (float *)(d + o_soft), nullptr, nsoft, soft_stride);
   if (rc != TRXSIG_OK) return rc;
   HIPCHK(c, hipMemcpyAsync(h_flags, d + o_fl, (size_t)B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h_amp, d + o_amp, 8 * (size_t)B, hipMemcpyDeviceToHost, c->stream));
@@ -334,6 +365,22 @@ int trxsig_detect_demod_normal_host(trxsig_ctx *c, const trxsig_c32 *h_samples, 
     HIPCHK(c, hipMemcpyAsync(h_soft, d + o_soft, 4 * (size_t)B * soft_stride, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return TRXSIG_OK;
+}
+
+int trxsig_detect_demod_normal_host(trxsig_ctx *c, const trxsig_c32 *h_samples, const int32_t *h_offset,
+                                    const int32_t *h_length, int B, int tsc, float detect_thresh,
+                                    float energy_thresh, uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
+                                    float *h_avgpwr, float *h_soft, int nsoft, int soft_stride) {
+  if (tsc < 0 || tsc > 7) return TRXSIG_EINVAL;
+  return detect_demod_host(c, false, h_samples, h_offset, h_length, B, tsc, detect_thresh, energy_thresh, h_flags,
+                           h_amp, h_toa, h_avgpwr, h_soft, nsoft, soft_stride);
+}
+int trxsig_detect_demod_rach_host(trxsig_ctx *c, const trxsig_c32 *h_samples, const int32_t *h_offset,
+                                  const int32_t *h_length, int B, float detect_thresh, float energy_thresh,
+                                  uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa, float *h_avgpwr,
+                                  float *h_soft, int nsoft, int soft_stride) {
+  return detect_demod_host(c, true, h_samples, h_offset, h_length, B, 0, detect_thresh, energy_thresh, h_flags, h_amp,
+                           h_toa, h_avgpwr, h_soft, nsoft, soft_stride);
 }
 
 // ---- measurement helpers ------------------------------------------------------------------------------

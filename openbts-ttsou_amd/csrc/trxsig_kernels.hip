@@ -248,51 +248,19 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_tsc_peak: one lane per burst.  peakDetect's early-late bisection (sigProcLib.cpp:684-701),
-//   the bogus-TOA check, the valley RMS, the detection threshold, amp = peak/gain and the TOA
-//   bookkeeping of analyzeTrafficBurst (:959-1000, 1035), plus energyDetect's decision (:929-931).
+// peak_bisect: peakDetect's early-late bisection (sigProcLib.cpp:684-701) for ONE burst per lane.
+//   loc[j][lane], j = 0..23, holds the correlation at lags M-12 .. M+11 (M = integer argmax) with
+//   zeros wherever interpolatePoint would skip a term (lag < 0, lag > n-2); loc[24], loc[25] = 0.
 //
 // interpolatePoint(ix) = sum_{i} corr[i]*sinc(pi*(i-ix)), i from max(0,floor(ix)-10) to
 // min(floor(ix)+11, n-1)-1.  ix stays on the 1/512 grid, so sinc(pi*(i-ix)) comes from
 // sinc_grid[f][j] with f = frac(ix)*512, j = i-floor(ix)+10 (trxsig_tables.h).  early and late
-// differ by exactly 2.0, hence share f.  Entries the reference would skip are zeros here.
+// differ by exactly 2.0, hence share f.  The row needed by the next step is known one step ahead up
+// to the sign of the early/late decision, so both candidates are fetched while the current step
+// computes.  Returns the interpolated peak; *peakIx = its (fractional) index.
 // ---------------------------------------------------------------------------------------------
-template <int SPS>
-__global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T,
-                                                 const cx *__restrict__ rec, int Bpad, int B, int tsc,
-                                                 float detect_thresh, float energy_thresh,
-                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
-                                                 float *__restrict__ toa_out,
-                                                 float *__restrict__ avgpwr_out) {
-  typedef CorrGeom<SPS> G;
-  __shared__ cx loc[26][64];                               // lags M-12 .. M+11 of each lane's burst; [24],[25] zero
-  __shared__ float pw[G::NS][64];                          // |corr|^2 of lags M-H .. M+H (valley power)
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x * 64 + lane;
-  const bool live = b < B;
-  const int bb = live ? b : B - 1;
-
-  // ---- everything this lane will need from the record, loaded up front (coalesced across lanes) ----
-  const cx meta = rec[(size_t)G::NS * Bpad + bb];
-  const int M = __float_as_int(meta.r);
-  const float energy = meta.i;
-  const bool good = M != -2;
-#pragma unroll
-  for (int s = 0; s < G::NS; s++) {
-    const cx v = rec[(size_t)s * Bpad + bb];
-    pw[s][lane] = norm2(v);
-    const int j = s - (G::H - 12);
-    if (j >= 0 && j < 24) {
-      const int lag = M - 12 + j;
-      loc[j][lane] = (lag > G::NL - 2) ? mk(0, 0) : v;     // interpolatePoint never uses the last sample (:646)
-    }
-  }
-  loc[24][lane] = mk(0, 0);
-  loc[25][lane] = mk(0, 0);
-  // (each lane only ever reads its own column: no barrier needed)
-
-  // sinc rows: the step's row is known one step ahead up to the sign of the early/late decision,
-  // so both candidates are fetched while the current step computes.
+__device__ __forceinline__ cx peak_bisect(const TrxTables *__restrict__ T, const cx (*loc)[64], int lane, int M,
+                                          float *peakIx) {
   auto load_row = [&](int f, float (&s)[24]) {
     const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
 #pragma unroll
@@ -338,9 +306,53 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
 #pragma unroll
     for (int j = 0; j < 24; j++) cur[j] = moved ? (goUp ? up[j] : dn[j]) : cur[j];
   }
-  const float peakIx = early + 1.0f;                       // same fractional part as `early`: row = cur
+  *peakIx = early + 1.0f;                                  // same fractional part as `early`: row = cur
   cx peak, dummy;
-  interp2(peakIx, 0, cur, peak, dummy);
+  interp2(*peakIx, 0, cur, peak, dummy);
+  return peak;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak: one lane per burst.  peakDetect's early-late bisection (sigProcLib.cpp:684-701),
+//   the bogus-TOA check, the valley RMS, the detection threshold, amp = peak/gain and the TOA
+//   bookkeeping of analyzeTrafficBurst (:959-1000, 1035), plus energyDetect's decision (:929-931).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+__global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T,
+                                                 const cx *__restrict__ rec, int Bpad, int B, int tsc,
+                                                 float detect_thresh, float energy_thresh,
+                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                 float *__restrict__ toa_out,
+                                                 float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  __shared__ cx loc[26][64];                               // lags M-12 .. M+11 of each lane's burst; [24],[25] zero
+  __shared__ float pw[G::NS][64];                          // |corr|^2 of lags M-H .. M+H (valley power)
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+
+  // ---- everything this lane will need from the record, loaded up front (coalesced across lanes) ----
+  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+#pragma unroll
+  for (int s = 0; s < G::NS; s++) {
+    const cx v = rec[(size_t)s * Bpad + bb];
+    pw[s][lane] = norm2(v);
+    const int j = s - (G::H - 12);
+    if (j >= 0 && j < 24) {
+      const int lag = M - 12 + j;
+      loc[j][lane] = (lag > G::NL - 2) ? mk(0, 0) : v;     // interpolatePoint never uses the last sample (:646)
+    }
+  }
+  loc[24][lane] = mk(0, 0);
+  loc[25][lane] = mk(0, 0);
+  // (each lane only ever reads its own column: no barrier needed)
+
+  float peakIx;
+  const cx peak = peak_bisect(T, loc, lane, M, &peakIx);
 
   // ---- analyzeTrafficBurst tail ----
   float toa = peakIx;
@@ -376,6 +388,189 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
     amp = mk(0, 0);                                        // "bogus result" (:964-968); TOA left as is
   }
   if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
+
+  if (live) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rach_corr: detectRACHBurst's correlation (sigProcLib.cpp:867-869) over ALL lags with the dense
+//   41*sps-tap access-burst sequence, energyDetect, argmax and the record for k_rach_peak.
+//   One wave per burst; lane handles lags t = lane + 64*c.
+//
+// corr[t] = sum_j tmp[j]*x[t+s-j], tmp = reverse(conj(rach)), i.e. sum_{m=Lb-1..0} x[t-F+m]*conj(rach[m])
+// with F = Lb/2, accumulated in that order (ascending j) -- every term of the reference, nothing
+// factored or reordered, so corr is bit-identical; out-of-range samples are zeros in the padded LDS
+// copy instead of being skipped (adds +-0).
+//
+// Record per burst (SoA, [slot][Bpad]): complex slots 0..23 = corr[M-12..M+11], slot 24 = {M, energy};
+// then NVAL float slots = |corr|^2 at lags M-1+57*sps .. M+1+107*sps for the valley sum (:888-893).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+struct RachGeom {
+  static constexpr int LB = 41 * SPS;                      // taps
+  static constexpr int F = LB / 2;                         // front pad
+  static constexpr int NMAX = 157 * SPS;
+  static constexpr int NCL = (NMAX + 63) / 64;             // lags per lane
+  static constexpr int XPAD = 64 * NCL + LB;               // padded burst length
+  static constexpr int V0 = 57 * SPS - 1, V1 = 107 * SPS + 1;   // valley lags relative to M
+  static constexpr int NVAL = V1 - V0 + 1;
+  static constexpr int NE = 20 * SPS;
+  static constexpr int NEQ = (NE + 15) / 16;
+  static constexpr int CSLOTS = 25;                        // complex slots
+};
+
+template <int SPS>
+__global__ __launch_bounds__(256) void k_rach_corr(const TrxTables *__restrict__ T,
+                                                   const cx *__restrict__ samples,
+                                                   const int32_t *__restrict__ offset,
+                                                   const int32_t *__restrict__ length, int B,
+                                                   cx *__restrict__ rec, float *__restrict__ recv, int Bpad) {
+  typedef RachGeom<SPS> G;
+  __shared__ cx xs[4][G::XPAD];                            // zero-padded burst, later reused for corr
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int off = offset[b], N = length[b];
+  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
+  const cx *x = samples + (good ? off : 0);
+  cx *X = xs[wave];
+
+  for (int i = lane; i < G::XPAD; i += 64) {
+    const int n = i - G::F;
+    X[i] = (good && n >= 0 && n < N) ? x[n] : mk(0, 0);
+  }
+  // energyDetect on the first 20*sps samples, strictly in order (row 0 of the wave does the chain)
+  float nrm[G::NEQ];
+#pragma unroll
+  for (int q = 0; q < G::NEQ; q++) {
+    const int i = (lane & 15) + 16 * q;
+    cx v = mk(0, 0);
+    if (good && i < G::NE) v = x[i];
+    nrm[q] = norm2(v);
+  }
+  float energy = energy_chain<SPS, 0>(0.0f, nrm);
+  energy = __shfl(energy, 0, 64);
+  wave_lds_fence();
+
+  cx acc[G::NCL];
+#pragma unroll
+  for (int c = 0; c < G::NCL; c++) acc[c] = mk(0, 0);
+  const cx *rseq = T->rach;
+#pragma unroll 4
+  for (int m = G::LB - 1; m >= 0; m--) {
+    const cx rm = rseq[m];
+    const cx tp = mk(rm.r, -rm.i);                         // conj (:487)
+#pragma unroll
+    for (int c = 0; c < G::NCL; c++) acc[c] = cadd(acc[c], cmul(X[lane + 64 * c + m], tp));
+  }
+  wave_lds_fence();                                        // all lanes are done with the samples
+
+  float bestP = 0.0f;
+  int bestT = -1;
+#pragma unroll
+  for (int c = 0; c < G::NCL; c++) {
+    const int t = lane + 64 * c;
+    if (t < N && good) {
+      X[t] = acc[c];
+      const float p = norm2(acc[c]);
+      if (p > bestP) { bestP = p; bestT = t; }             // strict >, first maximum (:675)
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const float oP = __shfl_xor(bestP, m, 64);
+    const int oT = __shfl_xor(bestT, m, 64);
+    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
+    if (take) { bestP = oP; bestT = oT; }
+  }
+  wave_lds_fence();
+
+  const int M = bestT;
+  if (lane < G::CSLOTS) {
+    cx v = mk(0, 0);
+    if (lane < 24) {
+      const int lag = M - 12 + lane;
+      if (good && lag >= 0 && lag < N) v = X[lag];
+    } else {
+      v = mk(__int_as_float(good ? M : -2), energy);
+    }
+    rec[(size_t)lane * Bpad + b] = v;
+  }
+  for (int s = lane; s < G::NVAL; s += 64) {
+    const int lag = M + G::V0 + s;
+    float p = 0.0f;
+    if (good && lag >= 0 && lag < N) p = norm2(X[lag]);
+    recv[(size_t)s * Bpad + b] = p;
+  }
+}
+
+// k_rach_peak: one lane per burst: peakDetect bisection, bogus-TOA check, valley RMS over
+//   peak+57*sps .. peak+107*sps, threshold, amp = peak/gain, TOA bookkeeping (sigProcLib.cpp:873-913).
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ T,
+                                                  const cx *__restrict__ rec, const float *__restrict__ recv,
+                                                  const int32_t *__restrict__ length, int Bpad, int B,
+                                                  float detect_thresh, float energy_thresh,
+                                                  uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                  float *__restrict__ toa_out,
+                                                  float *__restrict__ avgpwr_out) {
+  typedef RachGeom<SPS> G;
+  __shared__ cx loc[26][64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+  const cx meta = rec[(size_t)24 * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+  const int N = length[bb];
+#pragma unroll
+  for (int j = 0; j < 24; j++) {
+    const cx v = rec[(size_t)j * Bpad + bb];
+    const int lag = M - 12 + j;
+    loc[j][lane] = (lag > N - 2) ? mk(0, 0) : v;           // interpolatePoint never uses the last sample (:646)
+  }
+  loc[24][lane] = mk(0, 0);
+  loc[25][lane] = mk(0, 0);
+
+  float peakIx;
+  const cx peak = peak_bisect(T, loc, lane, M, &peakIx);
+
+  float toa = peakIx;
+  cx amp = mk(0, 0);
+  bool detected = false;
+  const bool energy_ok = good && (energy_thresh < 0.0f ||
+                                  energy / (float)(unsigned)G::NE > energy_thresh * energy_thresh);
+  if (!(toa < 0.0f) && !(toa > (float)N) && good) {        // :878-882
+    const int p = (int)rintf(toa);
+    float valley = 0.0f, numSamples = 0.0f;
+#pragma unroll 4
+    for (int i = 57 * SPS; i <= 107 * SPS; i++) {          // :888-893, this order, stop at the end
+      const int lag = p + i;
+      int sl = lag - M - G::V0;                            // 0 .. NVAL-1 because |p - M| <= 1
+      sl = sl < 0 ? 0 : (sl > G::NVAL - 1 ? G::NVAL - 1 : sl);
+      const float v = recv[(size_t)sl * Bpad + bb];
+      if (lag < N) { valley += v; numSamples += 1.0f; }
+    }
+    if (numSamples >= 2) {
+      const float RMS = (float)((double)sqrtf(valley / numSamples) + 0.00001);      // :901
+      const float peakToMean = sqrtf(norm2(peak)) / RMS;
+      amp = cdiv(peak, T->rach_gain);                      // :905
+      toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
+      detected = peakToMean > detect_thresh;
+    }
+  }
+  if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }
 
   if (live) {
     uint8_t fl = 0;
@@ -566,6 +761,44 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
     case 1: launch_tsc_detect<1>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
     case 2: launch_tsc_detect<2>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
     case 4: launch_tsc_detect<4>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+int trx_rach_rec_floats(int sps) {            // floats per burst in the rach record (complex slots + valley)
+  switch (sps) {
+    case 1: return 2 * RachGeom<1>::CSLOTS + RachGeom<1>::NVAL;
+    case 2: return 2 * RachGeom<2>::CSLOTS + RachGeom<2>::NVAL;
+    case 4: return 2 * RachGeom<4>::CSLOTS + RachGeom<4>::NVAL;
+  }
+  return 0;
+}
+
+template <int S>
+static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                               const int32_t *len, int B, float detect_thresh, float energy_thresh, float *ws,
+                               int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                               TrxProfiler *prof) {
+  trx_c32 *rec = (trx_c32 *)ws;
+  float *recv = ws + (size_t)2 * RachGeom<S>::CSLOTS * Bpad;
+  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
+  k_rach_corr<S><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(dT, samples, off, len, B, rec, recv, Bpad);
+  if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
+  k_rach_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, recv, len, Bpad, B, detect_thresh,
+                                                           energy_thresh, flags, amp, toa, avgpwr);
+  if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
+}
+
+hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                                  const int32_t *off, const int32_t *len, int B, float detect_thresh,
+                                  float energy_thresh, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp,
+                                  float *toa, float *avgpwr, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  switch (sps) {
+    case 1: launch_rach_detect<1>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 2: launch_rach_detect<2>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 4: launch_rach_detect<4>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -1,0 +1,81 @@
+"""GPU parity, access (RACH) bursts: detectRACHBurst + demodulateBurst through the C-ABI against the
+golden vectors of the real reference and the CPU oracle on random batches.  Value-exact."""
+import numpy as np
+import pytest
+
+import _pkg
+import oraclebind
+import synth
+from util import GpuBatch, assert_veq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _pkg.load()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = {s: pkg.TrxSig(s, 0) for s in (1, 2, 4)}
+    for v in c.values():
+        v.use_torch_stream()
+    return c
+
+
+@pytest.mark.parametrize("name", ["rach_sps4.npz", "rach_sps1.npz"])
+def test_golden_rach(pkg, ctx, golden, name):
+    g = golden(name)
+    sps = int(g["sps"]); t = ctx[sps]
+    gb = GpuBatch(g["x"], g["off"], g["len"], nsoft=148, stride=148)
+    t.detect_demod_rach(gb.x, gb.off, gb.len, gb.flags, gb.amp, gb.toa, gb.soft, avgpwr=gb.pwr, hard=gb.hard,
+                        detect_thresh=5.0, energy_thresh=-1.0)
+    r = gb.results()
+    det = (r["flags"] & pkg.F_DETECT) != 0
+    assert_veq(det, g["ok"].astype(bool), "detect flags")
+    assert_veq(r["amp"], g["amp"], "amp"); assert_veq(r["toa"], g["toa"], "toa")
+    for i in range(len(det)):
+        if det[i]:
+            assert_veq(r["soft"][i], g["soft"][i, :148], "soft %d" % i)
+            assert_veq(r["hard"][i], (g["soft"][i, :148] > 0.5).astype(np.uint8))
+        else:
+            assert not r["soft"][i].any()
+
+
+@pytest.mark.parametrize("sps,B", [(4, 1024), (2, 256), (1, 512)])
+def test_random_rach_vs_oracle(pkg, ctx, sps, B):
+    o = oraclebind.Oracle(sps)
+    x, off, length, meta = synth.rach_batch(sps, B, seed=4321 + sps, sigmas=(0.0, 0.1, 0.3, 3.0))
+    gb = GpuBatch(x, off, length, nsoft=148, stride=148)
+    ctx[sps].detect_demod_rach(gb.x, gb.off, gb.len, gb.flags, gb.amp, gb.toa, gb.soft, hard=gb.hard,
+                               energy_thresh=-1.0)   # the oracle batch has no energy gate (late bursts start silent)
+    r = gb.results()
+    ok, amp, toa, soft = o.rach_batch(x, off, length, nthreads=8)
+    assert_veq((r["flags"] & pkg.F_DETECT) != 0, ok.astype(bool), "detect")
+    assert_veq(r["amp"], amp, "amp"); assert_veq(r["toa"], toa, "toa")
+    assert_veq(r["soft"], soft, "soft")
+    # physics: clean access bursts are found at their true delay and demodulate to the sent payload
+    clean = np.flatnonzero(ok.astype(bool) & (meta["sigma"] <= 0.1))
+    assert len(clean) > B // 4
+    assert np.abs(r["toa"][clean] - meta["delay"][clean]).max() < 0.75
+    assert np.array_equal(r["hard"][clean][:, 8:85], meta["bits"][clean][:, 8:85])
+
+
+def test_host_wrappers(pkg, ctx, golden):
+    """The PCIe-inclusive host-buffer entry points give the same answers."""
+    g = golden("rach_sps4.npz")
+    r = ctx[4].detect_demod_host(g["x"], g["off"], g["len"], tsc=None, energy_thresh=-1.0)
+    assert_veq((r["flags"] & pkg.F_DETECT) != 0, g["ok"].astype(bool))
+    assert_veq(r["amp"], g["amp"]); assert_veq(r["toa"], g["toa"])
+    g = golden("normal_sps4.npz")
+    sel = np.flatnonzero(g["tsc"] == 3)
+    x = np.concatenate([g["x"][o:o + n] for o, n in zip(g["off"][sel], g["len"][sel])])
+    ln = g["len"][sel]; off = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.int32)
+    r = ctx[4].detect_demod_host(x, off, ln, tsc=3, energy_thresh=-1.0)
+    assert_veq((r["flags"] & pkg.F_DETECT) != 0, g["ok"][sel].astype(bool))
+    assert_veq(r["amp"], g["amp"][sel]); assert_veq(r["toa"], g["toa"][sel])
+    det = (r["flags"] & pkg.F_DETECT) != 0
+    assert_veq(r["soft"][det], g["soft"][sel][det][:, :148])
