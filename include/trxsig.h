@@ -156,7 +156,6 @@ int trxsig_demodulate_batch(trxsig_ctx *ctx,
                             const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
                             float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
-#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 /* ---- TX path: modulateBurst (sigProcLib.h:171-174) as called by Transceiver::addRadioVector
  *   (Transceiver.cpp:100-113): bits -> GMSK-rotated impulses -> pulse shaping, then scaleVector by
  *   a real gain.  d_bits: B x 148 bytes (only bit 0 is used, BitVector.cpp:54-63); d_guard[b] =
@@ -181,6 +180,7 @@ int trxsig_unpack_int16(trxsig_ctx *ctx, const int16_t *d_iq, int64_t n_samples,
                         trxsig_c32 *d_out);
 int trxsig_pack_int16(trxsig_ctx *ctx, const trxsig_c32 *d_in, int64_t n_samples, int16_t *d_iq);
 
+#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 /* ---- equaliser: analyzeTrafficBurst(requestChannel) + designDFE + equalizeBurst ---------------
  *   (sigProcLib.h:277-285, 366-370, 382-386; Transceiver.cpp:327-349, 391-396; the windowed
  *   Transceiver52M form with maxTOA when variant52m != 0: Transceiver52M/sigProcLib.cpp:966-1076).
@@ -212,12 +212,9 @@ int trxsig_detect_demod_rach_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples,
                                   float detect_thresh, float energy_thresh,
                                   uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
                                   float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
-#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *h_guard,
                          const float *h_gain, int B, trxsig_c32 *h_out, const int32_t *h_out_offset,
                          int64_t out_samples);
-
-#endif /* TRXSIG_NEXT */
 
 /* ---- measurement helpers (HIP events on the context's stream; used by bench.py) ---------------
  * trxsig_timer_*: one start/stop event pair around whatever the caller enqueues in between.

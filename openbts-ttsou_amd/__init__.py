@@ -61,6 +61,12 @@ def lib():
         L.trxsig_detect_demod_normal_host.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_detect_demod_rach_host.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_demodulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32]
+        L.trxsig_modulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+        L.trxsig_modulate_host.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.c_int64]
+        L.trxsig_resample_batch.argtypes = [vp, vp, i32, C.c_int64, i32, i32, i32, vp, i32, vp, C.c_int64]
+        L.trxsig_resample_out_len.argtypes = [i32, i32, i32]
+        L.trxsig_unpack_int16.argtypes = [vp, vp, C.c_int64, i32, vp]
+        L.trxsig_pack_int16.argtypes = [vp, vp, C.c_int64, vp]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
@@ -212,6 +218,37 @@ class TrxSig:
         self._chk(self.L.trxsig_demodulate_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), B, _ptr(amp),
                                                  _ptr(toa), _ptr(enable), _ptr(soft), _ptr(hard), nsoft,
                                                  soft_stride), "trxsig_demodulate_batch")
+
+    def modulate(self, bits, guard, out, out_offset, gain=None):
+        """bits [B,148] uint8, guard [B] int32, out packed complex (as float32 pairs), out_offset [B] int32."""
+        self._chk(self.L.trxsig_modulate_batch(self.h, _ptr(bits), _ptr(guard), _ptr(gain), guard.numel(), _ptr(out),
+                                               _ptr(out_offset)), "trxsig_modulate_batch")
+
+    def modulate_host(self, bits, guard, gain=None):
+        import numpy as np
+        bits = np.ascontiguousarray(bits, np.uint8); guard = np.ascontiguousarray(guard, np.int32)
+        B = len(guard)
+        length = (self.sps * (148 + guard)).astype(np.int32)
+        off = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
+        out = np.zeros(int(length.sum()), np.complex64)
+        g = None if gain is None else np.ascontiguousarray(gain, np.float32)
+        self._chk(self.L.trxsig_modulate_host(self.h, bits.ctypes.data, guard.ctypes.data,
+                                              None if g is None else g.ctypes.data, B, out.ctypes.data,
+                                              off.ctypes.data, out.size), "trxsig_modulate_host")
+        return out, off, length
+
+    def resample_out_len(self, n_in, P, Q):
+        return self.L.trxsig_resample_out_len(n_in, P, Q)
+
+    def resample(self, x, n_in, in_stride, S, P, Q, lpf, out, out_stride):
+        self._chk(self.L.trxsig_resample_batch(self.h, _ptr(x), n_in, in_stride, S, P, Q, _ptr(lpf), lpf.numel(),
+                                               _ptr(out), out_stride), "trxsig_resample_batch")
+
+    def unpack_int16(self, iq, n, out, swap_iq=True):
+        self._chk(self.L.trxsig_unpack_int16(self.h, _ptr(iq), n, int(swap_iq), _ptr(out)), "trxsig_unpack_int16")
+
+    def pack_int16(self, x, n, iq):
+        self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
     def profile_enable(self, on=True):
         self._chk(self.L.trxsig_profile_enable(self.h, int(on)), "trxsig_profile_enable")

@@ -3,6 +3,7 @@
 // here except the init-time table construction (trxsig_tablegen.cpp); there is no CPU fallback.
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -315,6 +316,85 @@ int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const in
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                              (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride, c->prof));
+  return TRXSIG_OK;
+}
+
+// ---- TX path, rate conversion, sample format ---------------------------------------------------------
+int trxsig_modulate_batch(trxsig_ctx *c, const uint8_t *d_bits, const int32_t *d_guard, const float *d_gain, int B,
+                          trxsig_c32 *d_out, const int32_t *d_out_offset) {
+  if (!c) return TRXSIG_EINVAL;
+  if (B < 0 || (B > 0 && (!d_bits || !d_guard || !d_out || !d_out_offset)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_modulate_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_modulate(c->stream, c->sps, c->d_tables, d_bits, d_guard, d_gain, B, (trx_c32 *)d_out,
+                                d_out_offset, c->prof));
+  return TRXSIG_OK;
+}
+
+int trxsig_resample_out_len(int n_in, int P, int Q) {
+  if (n_in < 0 || P <= 0 || Q <= 0) return TRXSIG_EINVAL;
+  return (int)std::ceil(n_in * (float)P / (float)Q);       // sigProcLib.cpp:1171
+}
+
+int trxsig_resample_batch(trxsig_ctx *c, const trxsig_c32 *d_in, int n_in, int64_t in_stride, int S, int P, int Q,
+                          const float *d_lpf, int L, trxsig_c32 *d_out, int64_t out_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n_in < 0 || S < 0 || P <= 0 || Q <= 0 || L <= 0 || (S > 0 && (!d_in || !d_out || !d_lpf)) ||
+      (int64_t)n_in * Q > (int64_t)1 << 40)
+    return fail(c, TRXSIG_EINVAL, "trxsig_resample_batch: bad argument");
+  const int nout = trxsig_resample_out_len(n_in, P, Q);
+  if (S == 0 || nout == 0) return TRXSIG_OK;
+  if (S > 65535) return fail(c, TRXSIG_EINVAL, "trxsig_resample_batch: more than 65535 streams");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_resample(c->stream, (const trx_c32 *)d_in, n_in, in_stride, S, P, Q, d_lpf, L,
+                                (trx_c32 *)d_out, out_stride, nout, c->prof));
+  return TRXSIG_OK;
+}
+
+int trxsig_unpack_int16(trxsig_ctx *c, const int16_t *d_iq, int64_t n, int swap_iq, trxsig_c32 *d_out) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n < 0 || (n > 0 && (!d_iq || !d_out))) return fail(c, TRXSIG_EINVAL, "trxsig_unpack_int16: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_convert(c->stream, 0, d_iq, n, swap_iq, d_out, c->prof));
+  return TRXSIG_OK;
+}
+int trxsig_pack_int16(trxsig_ctx *c, const trxsig_c32 *d_in, int64_t n, int16_t *d_iq) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n < 0 || (n > 0 && (!d_iq || !d_in))) return fail(c, TRXSIG_EINVAL, "trxsig_pack_int16: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_convert(c->stream, 1, d_in, n, 0, d_iq, c->prof));
+  return TRXSIG_OK;
+}
+
+int trxsig_modulate_host(trxsig_ctx *c, const uint8_t *h_bits, const int32_t *h_guard, const float *h_gain, int B,
+                         trxsig_c32 *h_out, const int32_t *h_out_offset, int64_t out_samples) {
+  if (!c) return TRXSIG_EINVAL;
+  if (B < 0 || out_samples < 0 || (B > 0 && (!h_bits || !h_guard || !h_out || !h_out_offset)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_modulate_host: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  for (int b = 0; b < B; b++)
+    if (h_guard[b] < 0 || h_guard[b] > 9 || h_out_offset[b] < 0 ||
+        (int64_t)h_out_offset[b] + (int64_t)c->sps * (148 + h_guard[b]) > out_samples)
+      return fail(c, TRXSIG_EINVAL, "trxsig_modulate_host: guard/offset out of range");
+  DeviceGuard g(c->device);
+  auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+  const size_t o_bits = 0, o_g = up((size_t)B * 148), o_off = o_g + up(4 * (size_t)B), o_gain = o_off + up(4 * (size_t)B),
+               o_out = o_gain + up(4 * (size_t)B), end = o_out + up(8 * (size_t)out_samples);
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  HIPCHK(c, hipMemcpyAsync(d + o_bits, h_bits, (size_t)B * 148, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_g, h_guard, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_off, h_out_offset, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
+  if (h_gain) HIPCHK(c, hipMemcpyAsync(d + o_gain, h_gain, 4 * (size_t)B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(d + o_out, 0, 8 * (size_t)out_samples, c->stream));
+  rc = trxsig_modulate_batch(c, (const uint8_t *)(d + o_bits), (const int32_t *)(d + o_g),
+                             h_gain ? (const float *)(d + o_gain) : nullptr, B, (trxsig_c32 *)(d + o_out),
+                             (const int32_t *)(d + o_off));
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_out, 8 * (size_t)out_samples, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return TRXSIG_OK;
 }
 

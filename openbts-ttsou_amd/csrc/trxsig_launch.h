@@ -35,3 +35,12 @@ hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const 
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,
                             uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
+
+hipError_t trx_launch_modulate(hipStream_t st, int sps, const TrxTables *dT, const uint8_t *bits, const int32_t *guard,
+                               const float *gain, int B, trx_c32 *out, const int32_t *out_off, TrxProfiler *prof);
+hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long long in_stride, int S, int P, int Q,
+                               const float *lpf, int L, trx_c32 *out, long long out_stride, int nout,
+                               TrxProfiler *prof);
+// pack != 0: complex float -> int16 I/Q; else int16 I/Q -> complex float (swap: I/Q flipped)
+hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
+                              TrxProfiler *prof);
