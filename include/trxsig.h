@@ -180,14 +180,16 @@ int trxsig_unpack_int16(trxsig_ctx *ctx, const int16_t *d_iq, int64_t n_samples,
                         trxsig_c32 *d_out);
 int trxsig_pack_int16(trxsig_ctx *ctx, const trxsig_c32 *d_in, int64_t n_samples, int16_t *d_iq);
 
-#ifdef TRXSIG_NEXT /* declared for the next milestone; not exported yet */
 /* ---- equaliser: analyzeTrafficBurst(requestChannel) + designDFE + equalizeBurst ---------------
  *   (sigProcLib.h:277-285, 366-370, 382-386; Transceiver.cpp:327-349, 391-396; the windowed
  *   Transceiver52M form with maxTOA when variant52m != 0: Transceiver52M/sigProcLib.cpp:966-1076).
  *   sps must be 1 for equalizeBurst ("Assumes symbol-rate sampling", sigProcLib.cpp:1342).
  *   Per burst: detect + channel estimate; scale channel by 1/amp; SNR = |amp|^2/(thr^2+1);
- *   designDFE(chan, SNR, 7); equalizeBurst(burst/amp, TOA-chanOffset, w, b).
- *   d_w: B x 7, d_b: B x 5 complex (may be NULL). */
+ *   designDFE(chan, SNR, 7); equalizeBurst(burst/amp, TOA-chanOffset, w, b).  thr is the
+ *   energy_thresh argument (the reference uses its adaptive mEnergyThreshold, whose sequential
+ *   update stays with the caller: SURVEY 8a' item 14); energy_thresh < 0 disables the gate and
+ *   uses thr = 0.  d_w: B x 7, d_b: B x 5 complex, written for detected bursts (may be NULL).
+ *   max_toa (52M variant only): 0..17. */
 int trxsig_equalize_normal_batch(trxsig_ctx *ctx,
                                  const trxsig_c32 *d_samples, const int32_t *d_offset,
                                  const int32_t *d_length, int B,
@@ -196,8 +198,6 @@ int trxsig_equalize_normal_batch(trxsig_ctx *ctx,
                                  uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
                                  trxsig_c32 *d_w, trxsig_c32 *d_b,
                                  float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
-
-#endif /* TRXSIG_NEXT */
 
 /* ---- convenience: host-buffer single-call wrappers (copy in, run, copy out, synchronise).
  *   These exist so Transceiver::pullRadioVector can keep calling one burst at a time; they are

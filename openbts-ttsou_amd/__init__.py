@@ -61,6 +61,8 @@ def lib():
         L.trxsig_detect_demod_normal_host.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_detect_demod_rach_host.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_demodulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32]
+        L.trxsig_equalize_normal_batch.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, vp, vp, vp,
+                                                   vp, vp, i32, i32]
         L.trxsig_modulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L.trxsig_modulate_host.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.c_int64]
         L.trxsig_resample_batch.argtypes = [vp, vp, i32, C.c_int64, i32, i32, i32, vp, i32, vp, C.c_int64]
@@ -218,6 +220,16 @@ class TrxSig:
         self._chk(self.L.trxsig_demodulate_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), B, _ptr(amp),
                                                  _ptr(toa), _ptr(enable), _ptr(soft), _ptr(hard), nsoft,
                                                  soft_stride), "trxsig_demodulate_batch")
+
+    def equalize_normal(self, samples, offset, length, tsc, flags, amp, toa, soft, w=None, b=None, hard=None,
+                        detect_thresh=3.0, energy_thresh=0.0, variant52m=True, max_toa=4, nsoft=148,
+                        soft_stride=None):
+        if soft_stride is None:
+            soft_stride = soft.shape[-1]
+        self._chk(self.L.trxsig_equalize_normal_batch(
+            self.h, _ptr(samples), _ptr(offset), _ptr(length), offset.numel(), tsc, detect_thresh, energy_thresh,
+            int(variant52m), max_toa, _ptr(flags), _ptr(amp), _ptr(toa), _ptr(w), _ptr(b), _ptr(soft), _ptr(hard),
+            nsoft, soft_stride), "trxsig_equalize_normal_batch")
 
     def modulate(self, bits, guard, out, out_offset, gain=None):
         """bits [B,148] uint8, guard [B] int32, out packed complex (as float32 pairs), out_offset [B] int32."""

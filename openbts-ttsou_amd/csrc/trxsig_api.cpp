@@ -61,6 +61,9 @@ struct trxsig_ctx {
   // workspace (device)
   int cap_bursts = 0;
   trx_c32 *d_rec = nullptr;          // [slots][cap_bursts] detect -> peak records
+  // equaliser scratch: toa_eq [B], w [B*7], b [B*5], xd [B*160]
+  int eq_cap = 0;
+  char *d_eq = nullptr;
   // staging for the *_host wrappers
   size_t stage_bytes = 0;
   void *d_stage = nullptr;
@@ -203,6 +206,7 @@ void trxsig_destroy(trxsig_ctx *c) {
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_eq) (void)hipFree(c->d_eq);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c->prof;
@@ -316,6 +320,40 @@ int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const in
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                              (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride, c->prof));
+  return TRXSIG_OK;
+}
+
+// ---- equaliser path (sps = 1) ------------------------------------------------------------------------
+int trxsig_equalize_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                 const int32_t *d_length, int B, int tsc, float detect_thresh, float energy_thresh,
+                                 int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                 trxsig_c32 *d_w, trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
+                                 int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "trxsig_equalize_normal_batch: equalizeBurst needs sps == 1");
+  if (bad_batch(d_samples, d_offset, d_length, B) || tsc < 0 || tsc > 7 || nsoft < 0 || nsoft > 157 ||
+      soft_stride < nsoft || max_toa < 0 || max_toa > 17 ||
+      (B > 0 && (!d_flags || !d_amp || !d_toa || (nsoft > 0 && !d_soft))))
+    return fail(c, TRXSIG_EINVAL, "trxsig_equalize_normal_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  constexpr int XS = 160;
+  if (B > c->eq_cap) {
+    const int cap = (B + 255) & ~255;
+    if (c->d_eq) { HIPCHK(c, hipFree(c->d_eq)); c->d_eq = nullptr; c->eq_cap = 0; }
+    HIPCHK(c, hipMalloc((void **)&c->d_eq, (size_t)cap * (4 + 8 * 7 + 8 * 5 + 8 * XS)));
+    c->eq_cap = cap;
+  }
+  const size_t cap = (size_t)c->eq_cap;
+  float *toa_eq = (float *)c->d_eq;
+  trx_c32 *w = (trx_c32 *)(c->d_eq + cap * 4);
+  trx_c32 *bq = (trx_c32 *)(c->d_eq + cap * (4 + 56));
+  trx_c32 *xd = (trx_c32 *)(c->d_eq + cap * (4 + 56 + 40));
+  if (d_w) w = (trx_c32 *)d_w;
+  if (d_b) bq = (trx_c32 *)d_b;
+  HIPCHK(c, trx_launch_equalize(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
+                                detect_thresh, energy_thresh, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
+                                toa_eq, w, bq, xd, XS, d_soft, d_hard, nsoft, soft_stride, c->prof));
   return TRXSIG_OK;
 }
 

@@ -44,3 +44,11 @@ hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long lo
 // pack != 0: complex float -> int16 I/Q; else int16 I/Q -> complex float (swap: I/Q flipped)
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
                               TrxProfiler *prof);
+
+// sps = 1 equaliser path; xd: B x xstride complex scratch (xstride >= 157), toa_eq: B floats scratch,
+// w: B x 7, bq: B x 5 complex
+hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                               const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
+                               int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
+                               trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
+                               int nsoft, int stride, TrxProfiler *prof);

@@ -301,7 +301,10 @@ def gen_dfe():
         chan_len.append(len(ra.get("chan", [])))
         if ra["ok"]:
             a = ra["amp"]
-            snr[it] = np.float32(np.float32(a.imag * a.imag + a.real * a.real) / np.float32(thr * thr + np.float32(1.0)))
+            # amplitude.norm2()/(mEnergyThreshold*mEnergyThreshold+1.0): float / double -> double -> float
+            # (Transceiver52M/Transceiver.cpp:336)
+            n2a = np.float32(np.float32(a.imag * a.imag) + np.float32(a.real * a.real))
+            snr[it] = np.float32(np.float64(n2a) / (np.float64(np.float32(thr * thr)) + 1.0))
             chan[it] = ra["chan"]; chan_off[it] = ra["chan_off"]
             # scaleVector(*channelResp, complex(1,0)/amplitude): 1/amp formed by the reference itself
             n2 = np.float32(a.imag * a.imag + a.real * a.real)
@@ -370,6 +373,10 @@ def gen_config1():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # regenerate selected files only, e.g. `gen_golden.py dfe`
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     if not refbind.available():
         sys.exit("oracle/_ref not built: run `make -C oracle ref` in the build container")
     gen_tables()
