@@ -1,0 +1,220 @@
+// sigProcLib_trx.h -- source-compatible C++ facade over libtrxsig for code written against the
+// reference's Transceiver/sigProcLib.h (OpenBTS).  Header only; link with -ltrxsig.
+//
+// It re-creates the names a Transceiver / RadioInterface translation unit uses -- `complex`,
+// `signalVector`, `BitVector`, `SoftVector`, sigProcLibSetup, generateGSMPulse, modulateBurst,
+// generateMidamble, generateRACHSequence, energyDetect, analyzeTrafficBurst, detectRACHBurst,
+// demodulateBurst, polyphaseResampleVector, createLPF -- with the reference's argument meaning,
+// ownership (functions returning a pointer allocate with `new`, the caller deletes:
+// Transceiver.cpp:112,407,672) and error behaviour (NULL / false, amplitude set to 0 on a "bogus
+// result": sigProcLib.cpp:878-882, 964-968).  Every call that processes samples runs on the GPU
+// through the C-ABI's host-buffer entry points (one PCIe round trip per call); nothing here computes
+// on the CPU.  A real deployment batches instead -- see INTEGRATION.md.
+//
+// Not provided: the free-standing vector primitives (convolve, correlate, delayVector, peakDetect,
+// interpolatePoint, ...).  Transceiver.cpp and radioInterface.cpp never call them (SURVEY 8b lists
+// the call sites); inside the library they only exist fused into the burst-level kernels.
+#ifndef SIGPROCLIB_TRX_H
+#define SIGPROCLIB_TRX_H
+
+#include <cstddef>
+#include <cstring>
+#include <vector>
+
+#include "trxsig.h"
+
+namespace trxfacade {
+
+// Complex<float> as the path uses it (Transceiver/Complex.h:39-151): storage + accessors only.
+struct complex {
+  float r, i;
+  complex(float re = 0.0f, float im = 0.0f) : r(re), i(im) {}
+  float real() const { return r; }
+  float imag() const { return i; }
+  float norm2() const { return i * i + r * r; }
+};
+
+// Vector<T> subset (CommonLibs/Vector.h:42-252): contiguous, owning.
+template <class T>
+class Vector {
+ public:
+  typedef T *iterator;
+  typedef const T *const_iterator;
+  explicit Vector(size_t n = 0) : d_(n) {}
+  size_t size() const { return d_.size(); }
+  T *begin() { return d_.data(); }
+  const T *begin() const { return d_.data(); }
+  T *end() { return d_.data() + d_.size(); }
+  const T *end() const { return d_.data() + d_.size(); }
+  T &operator[](size_t k) { return d_[k]; }
+  const T &operator[](size_t k) const { return d_[k]; }
+  void fill(const T &v) { for (auto &e : d_) e = v; }
+ private:
+  std::vector<T> d_;
+};
+
+// signalVector (sigProcLib.h:51-99)
+class signalVector : public Vector<complex> {
+ public:
+  explicit signalVector(size_t n = 0) : Vector<complex>(n), realOnly_(false) {}
+  bool isRealOnly() const { return realOnly_; }
+  void isRealOnly(bool v) { realOnly_ = v; }
+ private:
+  bool realOnly_;
+};
+
+// BitVector: one bit per char, consumers mask with 0x01 (CommonLibs/BitVector.cpp:54-63)
+class BitVector : public Vector<char> {
+ public:
+  explicit BitVector(size_t n = 0) : Vector<char>(n) {}
+  explicit BitVector(const char *s) : Vector<char>(std::strlen(s)) {
+    for (size_t k = 0; k < size(); k++) (*this)[k] = (s[k] == '1');
+  }
+  bool bit(size_t k) const { return (*this)[k] & 0x01; }
+};
+
+// SoftVector: float 0..1, bit() = > 0.5F (CommonLibs/BitVector.h:415-420)
+class SoftVector : public Vector<float> {
+ public:
+  explicit SoftVector(size_t n = 0) : Vector<float>(n) {}
+  bool bit(size_t k) const { return (*this)[k] > 0.5F; }
+};
+
+// ---- library state (the reference keeps process globals, sigProcLib.cpp:39-59) ----------------
+struct State {
+  trxsig_ctx *ctx = nullptr;
+  int sps = 0;
+  int device = 0;
+};
+inline State &state() { static State s; return s; }
+
+inline void sigProcLibDestroy(void) {                         // sigProcLib.h:113
+  State &s = state();
+  if (s.ctx) { trxsig_destroy(s.ctx); s.ctx = nullptr; }
+}
+// sigProcLibSetup (sigProcLib.h:110): also builds the pulse, the 8 midambles and the RACH sequence,
+// which the reference creates through separate calls at start-up (Transceiver.cpp:62-64,424,553).
+inline bool sigProcLibSetup(int samplesPerSymbol, int device = 0) {
+  State &s = state();
+  sigProcLibDestroy();
+  s.sps = samplesPerSymbol; s.device = device;
+  return trxsig_create(&s.ctx, device, samplesPerSymbol) == TRXSIG_OK;
+}
+
+// generateGSMPulse(2, sps) (sigProcLib.h:137-138): a copy of the table built at set-up
+inline signalVector *generateGSMPulse(int symbolLength, int samplesPerSymbol) {
+  State &s = state();
+  if (!s.ctx || symbolLength != 2 || samplesPerSymbol != s.sps) return NULL;
+  trxsig_tables_view v;
+  if (trxsig_tables_view_get(s.ctx, &v) != TRXSIG_OK) return NULL;
+  signalVector *p = new signalVector(2 * s.sps + 1);
+  for (int k = 0; k < 2 * s.sps + 1; k++) (*p)[k] = complex(v.gsm_pulse[k], 0.0f);
+  p->isRealOnly(true);
+  return p;
+}
+// generateMidamble / generateRACHSequence (sigProcLib.h:227-239): built at set-up; these only check.
+inline bool generateMidamble(signalVector &, int samplesPerSymbol, int TSC) {
+  return state().ctx && samplesPerSymbol == state().sps && TSC >= 0 && TSC <= 7;
+}
+inline bool generateRACHSequence(signalVector &, int samplesPerSymbol) {
+  return state().ctx && samplesPerSymbol == state().sps;
+}
+
+// modulateBurst (sigProcLib.h:171-174).  gsmPulse must be the library's pulse (it is the only one
+// Transceiver ever passes, Transceiver.cpp:68,105); 148-bit bursts, guard 0..9.
+inline signalVector *modulateBurst(const BitVector &wBurst, const signalVector &, int guardPeriodLength,
+                                   int samplesPerSymbol) {
+  State &s = state();
+  if (!s.ctx || samplesPerSymbol != s.sps || wBurst.size() != 148 || guardPeriodLength < 0 || guardPeriodLength > 9)
+    return NULL;
+  uint8_t bits[148];
+  for (int k = 0; k < 148; k++) bits[k] = (uint8_t)wBurst[k];
+  const int32_t guard = guardPeriodLength, off = 0;
+  const int n = s.sps * (148 + guardPeriodLength);
+  signalVector *out = new signalVector(n);
+  if (trxsig_modulate_host(s.ctx, bits, &guard, NULL, 1, (trxsig_c32 *)out->begin(), &off, n) != TRXSIG_OK) {
+    delete out;
+    return NULL;
+  }
+  return out;
+}
+
+namespace detail {
+inline bool detect(bool rach, signalVector &rxBurst, unsigned TSC, float thresh, float energyThresh,
+                   complex *amplitude, float *TOA, float *avgPwr, bool *energyOk) {
+  State &s = state();
+  if (!s.ctx) return false;
+  const int32_t off = 0, len = (int32_t)rxBurst.size();
+  uint8_t flags = 0; trxsig_c32 amp = {0, 0}; float toa = 0, pwr = 0;
+  int rc = rach ? trxsig_detect_demod_rach_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), &off, &len, 1, thresh,
+                                                energyThresh, &flags, &amp, &toa, &pwr, NULL, 0, 0)
+                : trxsig_detect_demod_normal_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), &off, &len, 1, (int)TSC,
+                                                  thresh, energyThresh, &flags, &amp, &toa, &pwr, NULL, 0, 0);
+  if (rc != TRXSIG_OK) return false;
+  if (amplitude) *amplitude = complex(amp.re, amp.im);
+  if (TOA) *TOA = toa;
+  if (avgPwr) *avgPwr = pwr;
+  if (energyOk) *energyOk = (flags & TRXSIG_F_ENERGY) != 0;
+  return (flags & TRXSIG_F_DETECT) != 0;
+}
+}  // namespace detail
+
+// energyDetect (sigProcLib.h:246-249); windowLength must be 20*sps, the only value the Transceiver
+// uses (Transceiver.cpp:298)
+inline bool energyDetect(signalVector &rxBurst, unsigned windowLength, float detectThreshold, float *avgPwr = NULL) {
+  if (windowLength != 20u * (unsigned)state().sps) return false;
+  bool ok = false;
+  detail::detect(false, rxBurst, 0, 1e30f, detectThreshold, NULL, NULL, avgPwr, &ok);
+  return ok;
+}
+// analyzeTrafficBurst (sigProcLib.h:277-285) without channel estimation (requestChannel: use
+// trxsig_equalize_normal_batch, which fuses estimate + designDFE + equalizeBurst)
+inline bool analyzeTrafficBurst(signalVector &rxBurst, unsigned TSC, float detectThreshold, int samplesPerSymbol,
+                                complex *amplitude, float *TOA, bool requestChannel = false,
+                                signalVector **channelResponse = NULL, float *channelResponseOffset = NULL) {
+  (void)channelResponse; (void)channelResponseOffset;
+  if (requestChannel || samplesPerSymbol != state().sps || TSC > 7) return false;
+  return detail::detect(false, rxBurst, TSC, detectThreshold, -1.0f, amplitude, TOA, NULL, NULL);
+}
+// detectRACHBurst (sigProcLib.h:263-267)
+inline bool detectRACHBurst(signalVector &rxBurst, float detectThreshold, int samplesPerSymbol, complex *amplitude,
+                            float *TOA) {
+  if (samplesPerSymbol != state().sps) return false;
+  return detail::detect(true, rxBurst, 0, detectThreshold, -1.0f, amplitude, TOA, NULL, NULL);
+}
+// demodulateBurst (sigProcLib.h:316-320): returns N/sps soft bits; caller deletes
+inline SoftVector *demodulateBurst(const signalVector &rxBurst, const signalVector &, int samplesPerSymbol,
+                                   complex channel, float TOA) {
+  State &s = state();
+  if (!s.ctx || samplesPerSymbol != s.sps) return NULL;
+  const int ns = (int)(rxBurst.size() / (size_t)s.sps);
+  SoftVector *out = new SoftVector(ns);
+  trxsig_c32 a = {channel.r, channel.i};
+  if (trxsig_demodulate_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), a, TOA, out->begin(),
+                             ns) != TRXSIG_OK) {
+    delete out;
+    return NULL;
+  }
+  return out;
+}
+
+}  // namespace trxfacade
+
+#ifndef TRXFACADE_NO_GLOBAL_NAMES   /* the reference's names are namespace-less (sigProcLib.h) */
+using trxfacade::analyzeTrafficBurst;
+using trxfacade::BitVector;
+using trxfacade::complex;
+using trxfacade::demodulateBurst;
+using trxfacade::detectRACHBurst;
+using trxfacade::energyDetect;
+using trxfacade::generateGSMPulse;
+using trxfacade::generateMidamble;
+using trxfacade::generateRACHSequence;
+using trxfacade::modulateBurst;
+using trxfacade::signalVector;
+using trxfacade::sigProcLibDestroy;
+using trxfacade::sigProcLibSetup;
+using trxfacade::SoftVector;
+#endif
+
+#endif  // SIGPROCLIB_TRX_H

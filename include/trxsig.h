@@ -212,6 +212,9 @@ int trxsig_detect_demod_rach_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples,
                                   float detect_thresh, float energy_thresh,
                                   uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
                                   float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
+/* one burst, caller-supplied amp/TOA: demodulateBurst (sigProcLib.h:316-320) */
+int trxsig_demodulate_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples, int n_samples,
+                           trxsig_c32 amp, float toa, float *h_soft, int nsoft);
 int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *h_guard,
                          const float *h_gain, int B, trxsig_c32 *h_out, const int32_t *h_out_offset,
                          int64_t out_samples);

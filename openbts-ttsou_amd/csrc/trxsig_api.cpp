@@ -501,6 +501,34 @@ int trxsig_detect_demod_rach_host(trxsig_ctx *c, const trxsig_c32 *h_samples, co
                            h_toa, h_avgpwr, h_soft, nsoft, soft_stride);
 }
 
+int trxsig_demodulate_host(trxsig_ctx *c, const trxsig_c32 *h_samples, int n, trxsig_c32 amp, float toa,
+                           float *h_soft, int nsoft) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_samples || !h_soft || n <= 0 || nsoft < 0 || nsoft > 157)
+    return fail(c, TRXSIG_EINVAL, "trxsig_demodulate_host: bad argument");
+  DeviceGuard g(c->device);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_s = 0, o_off = up(8 * (size_t)n), o_len = o_off + 256, o_amp = o_len + 256, o_toa = o_amp + 256,
+               o_soft = o_toa + 256, end = o_soft + up(4 * 160);
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  const int32_t zero = 0, len = n;
+  HIPCHK(c, hipMemcpyAsync(d + o_s, h_samples, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_off, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_len, &len, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_amp, &amp, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_toa, &toa, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));              // the scalars above live on this stack frame
+  rc = trxsig_demodulate_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), 1,
+                               (trxsig_c32 *)(d + o_amp), (float *)(d + o_toa), nullptr, (float *)(d + o_soft),
+                               nullptr, nsoft, 160);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_soft, d + o_soft, 4 * (size_t)nsoft, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
 // ---- measurement helpers ------------------------------------------------------------------------------
 int trxsig_timer_start(trxsig_ctx *c) {
   if (!c) return TRXSIG_EINVAL;
