@@ -67,6 +67,7 @@ struct trxsig_ctx {
   // staging for the *_host wrappers
   size_t stage_bytes = 0;
   void *d_stage = nullptr;
+  int variant = 1;                   // peak kernel: 1 = four lanes per burst (k_tsc_peak4), 0 = one lane per burst
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 };
@@ -112,6 +113,7 @@ int check_device(int device, std::string &why) {
 }
 
 int finish_create(trxsig_ctx *c) {
+  if (const char *v = std::getenv("TRXSIG_TSC_VARIANT")) c->variant = std::atoi(v);
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   return TRXSIG_OK;
@@ -276,9 +278,9 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   DeviceGuard g(c->device);
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
-  HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
+  HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
-                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->variant, c->prof));
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,

@@ -23,6 +23,13 @@
 #include "trxsig_tables.h"
 #include "trxsig_launch.h"
 
+#ifndef TRX_CORR_CG
+#define TRX_CORR_CG 3
+#endif
+#ifndef TRX_CORR_WPS
+#define TRX_CORR_WPS 1
+#endif
+
 namespace {
 
 typedef trx_c32 cx;
@@ -35,6 +42,8 @@ __device__ __forceinline__ cx cadd(cx x, cx a) { return mk(x.r + a.r, x.i + a.i)
 __device__ __forceinline__ float norm2(cx x) { return x.i * x.i + x.r * x.r; }            // Complex.h:119
 __device__ __forceinline__ cx cinv(cx x) { float n = norm2(x); return mk(x.r / n, -x.i / n); }  // Complex.h:154-160
 __device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }               // Complex.h:85
+
+struct TapArg { float v[32]; };   // conj'd non-zero midamble taps passed as a kernel argument => SGPRs
 
 #define TRX_PI_F 3.14159274101257324f             /* (float)M_PI, sigProcLib.cpp:43 */
 #define TRX_2PI_F 6.28318548202514648f            /* (float)(2.0*M_PI), :44 */
@@ -98,21 +107,38 @@ struct CorrGeom {
 
 // energy += norm2(x[I]) for I = 0 .. NE-1 strictly in order; norm I lives in lane I%16 of
 // register nrm[I/16], and lane 0 of the row pulls it over with a DPP row shift.
+// One instruction per step: v_add_f32 with the DPP row shift on the incoming operand (hipcc does not
+// fold v_mov_dpp into the add and would hoist all 80 moves, costing 80 VGPRs).  The DPP operand
+// (nrm) is written long before the chain; the s_nop covers the VALU-write -> DPP-read wait states
+// that hipcc does not insert around inline asm.
+template <int N>
+__device__ __forceinline__ float add_row_shl(float acc, float v) {
+  float r;
+  if (N == 0) asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(acc));
+  else asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                    : "=v"(r) : "v"(v), "v"(acc), "n"(N));
+  return r;
+}
 template <int SPS, int I>
-__device__ __forceinline__ float energy_chain(float acc, const float (&nrm)[CorrGeom<SPS>::NEQ]) {
+__device__ __forceinline__ float energy_chain_step(float acc, const float (&nrm)[CorrGeom<SPS>::NEQ]) {
   if constexpr (I < CorrGeom<SPS>::NE) {
-    acc = acc + row_shl<I % 16>(nrm[I / 16]);
-    return energy_chain<SPS, I + 1>(acc, nrm);
+    acc = add_row_shl<I % 16>(acc, nrm[I / 16]);
+    return energy_chain_step<SPS, I + 1>(acc, nrm);
   } else {
     return acc;
   }
 }
+template <int SPS, int I>
+__device__ __forceinline__ float energy_chain(float acc, const float (&nrm)[CorrGeom<SPS>::NEQ]) {
+  asm volatile("s_nop 1");
+  return energy_chain_step<SPS, I>(acc, nrm);
+}
 
 template <int SPS>
-__global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ T,
+__global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables *__restrict__ T,
                                                   const cx *__restrict__ samples,
                                                   const int32_t *__restrict__ offset,
-                                                  const int32_t *__restrict__ length, int B, int tsc,
+                                                  const int32_t *__restrict__ length, int B, TapArg taps,
                                                   cx *__restrict__ rec, int Bpad) {
   typedef CorrGeom<SPS> G;
   // one LDS row per burst, owned by the 16 lanes of its DPP row; no workgroup barrier anywhere.
@@ -188,12 +214,12 @@ __global__ __launch_bounds__(256) void k_tsc_corr(const TrxTables *__restrict__ 
   // ---- correlation: 16 non-zero taps, k descending = j ascending ----
   cx tap[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) tap[k] = T->mid_ctap[tsc][k];
+  for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
 
   float bestP = 0.0f;
   int bestT = -1;
   cx cval[G::NC];
-  constexpr int CG = (SPS == 4) ? 3 : 1;                   // lags per register group
+  constexpr int CG = (SPS == 4) ? TRX_CORR_CG : 1;         // lags per register group
   constexpr int UPC = 16 / SPS;                            // stride-SPS sample steps per 16 lags
   constexpr int NU = UPC * (CG - 1) + 16;
 #pragma unroll
@@ -390,6 +416,173 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
   if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
 
   if (live) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak4: the peak logic of k_tsc_peak with FOUR lanes per burst (16 bursts per wave): lanes
+// {0,1,2,3} of a quad own the four independent 21-term chains of a bisection step (early.re,
+// early.im, late.re, late.im); |.|^2 and the early/late comparison are exchanged inside the quad with
+// DPP quad_perm, and the sinc row is shared by the quad (each lane keeps a quarter, taps are
+// broadcast by quad_perm).  Same arithmetic, a quarter of the dependent-chain length per lane and
+// four times as many waves in flight as the lane-per-burst form.
+// (A fully fused corr+peak kernel was tried and measured slower: the correlator wants 4 bursts per
+// wave and >200 VGPRs once both phases live in one kernel -- DESIGN.md, "What did not work".)
+// ---------------------------------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// A sinc_grid row (24 floats) is shared by the 4 lanes of a quad: lane q keeps float4 #q and #(q+4)
+// (8 floats), tap j is broadcast from lane (j/4)%4 with a DPP quad_perm.
+struct QRow { float4 a, b; };
+
+template <int J>
+__device__ __forceinline__ float qrow_tap(const QRow &w) {
+  constexpr int f4 = J / 4, src = f4 % 4, comp = J % 4;
+  const float4 &v = (f4 < 4) ? w.a : w.b;
+  const float x = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
+  return quad_perm<src * 0x55>(x);                         // quad_perm:[src,src,src,src]
+}
+
+template <bool MASK, int J>
+__device__ __forceinline__ float qchain(const float *p, int slot0, int zslot, const QRow &w, float acc) {
+  if constexpr (J < 21) {
+    float v = p[J * 32];
+    if (MASK && slot0 + J > zslot) v = 0.0f;               // interpolatePoint never uses the last sample (:646)
+    acc = acc + v * qrow_tap<J>(w);
+    return qchain<MASK, J + 1>(p, slot0, zslot, w, acc);
+  } else {
+    return acc;
+  }
+}
+
+template <int SPS, bool MASK>
+__device__ __forceinline__ void quad_bisect(const TrxTables *__restrict__ T, const float *rcf, int bi, int q, int M,
+                                            int zslot, float *peakIx, float *pk_own, float *pk_partner) {
+  typedef CorrGeom<SPS> G;
+  const int c = q & 1, late = q >> 1;
+  auto load_row = [&](int f) {
+    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+    QRow w;
+    w.a = row[q];
+    w.b = (q < 2) ? row[q + 4] : make_float4(0, 0, 0, 0);
+    return w;
+  };
+  // one chain of interpolatePoint: sum_j comp(corr[slot0 + j]) * s[j], j ascending
+  auto chain = [&](int slot0, const QRow &w) {
+    const float *p = rcf + ((size_t)slot0 * 16 + bi) * 2 + c;
+    return qchain<MASK, 0>(p, slot0, zslot, w, 0.0f);
+  };
+  auto frac512 = [](float ix) { return (int)((ix - floorf(ix)) * 512.0f); };
+  auto slot_of = [&](float ix) {
+    int base = (int)floorf(ix) - M + 2;                    // 0..3 by construction
+    base = base < 0 ? 0 : (base > 3 ? 3 : base);
+    return base + (G::H - 12);
+  };
+
+  float early = (float)M - 1;
+  float incr = 0.5f;
+  bool active = true;
+  QRow cur = load_row(0);
+#pragma unroll 1
+  for (int step = 0; step < 9; step++) {
+    const QRow up = load_row(frac512(early + incr));
+    const QRow dn = load_row(frac512(early - incr));
+    const float a = chain(slot_of(early) + 2 * late, cur);
+    const float sq = a * a;
+    const float osq = quad_perm<0xB1>(sq);                 // partner component: lanes 0<->1, 2<->3
+    const float nrm = c ? (sq + osq) : (osq + sq);         // i*i + r*r (Complex.h:119)
+    const float onrm = quad_perm<0x4E>(nrm);               // the other point: lanes 0,1 <-> 2,3
+    const float ne = late ? onrm : nrm, nl = late ? nrm : onrm;
+    const bool goUp = ne < nl, goDn = ne > nl;
+    if (active) {
+      if (goUp) early += incr;
+      else if (goDn) early -= incr;
+      else active = false;                                 // "else break" (:695)
+      if (active) incr = incr * 0.5f;
+    }
+    if (active) cur = goUp ? up : dn;                      // the row changes only if the index moved
+  }
+  *peakIx = early + 1.0f;
+  const float a = chain(slot_of(*peakIx), cur);            // every lane: its own component of the peak
+  *pk_own = a;
+  *pk_partner = quad_perm<0xB1>(a);
+}
+
+template <int SPS>
+__global__ __launch_bounds__(64) void k_tsc_peak4(const TrxTables *__restrict__ T, const cx *__restrict__ rec,
+                                                  int Bpad, int B, int tsc, float detect_thresh, float energy_thresh,
+                                                  uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                  float *__restrict__ toa_out, float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  __shared__ cx rc[G::NS + 1][16];                         // records of 16 bursts: corr[M-H .. M+H], then {M, energy}
+  const int lane = threadIdx.x;
+  const int b0 = blockIdx.x * 16;
+  // ---- stage the 16 records (each slot row is 16 consecutive bursts = one 128-byte line) ----
+  for (int i = lane; i < (G::NS + 1) * 16; i += 64) {
+    const int s = i >> 4, bi = i & 15;
+    const int b = b0 + bi;
+    rc[s][bi] = rec[(size_t)s * Bpad + (b < B ? b : B - 1)];
+  }
+  wave_lds_fence();
+
+  const int bi = lane >> 2, q = lane & 3;
+  const int b = b0 + bi;
+  const bool live = b < B;
+  const cx meta = rc[G::NS][bi];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+  const int zslot = (G::NL - 2) - (M - G::H);              // slots above this hold the unused last sample
+  const bool needMask = zslot < G::H + 13;                 // ... and it is within reach of the interpolator
+  float peakIx, pkOwn, pkOther;
+  const float *rcf = reinterpret_cast<const float *>(&rc[0][0]);
+  if (__ballot(needMask) != 0) quad_bisect<SPS, true>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
+  else quad_bisect<SPS, false>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
+
+  if (q == 0 && live) {                                    // one lane per burst finishes analyzeTrafficBurst
+    float toa = peakIx;
+    cx amp = mk(pkOwn, pkOther);
+    bool detected = false;
+    const bool energy_ok = good && (energy_thresh < 0.0f ||
+                                    energy / (float)(unsigned)G::NE > energy_thresh * energy_thresh);
+    if (!(toa < 0.0f) && !(toa > (float)G::NL) && good) {
+      const int p = (int)rintf(toa);
+      float valley = 0.0f;
+      int numRms = 0;
+#pragma unroll
+      for (int i = 2 * SPS; i <= 5 * SPS; i++) {           // :971-980, this order
+        const int lo = p - i, hi = p + i;
+        int slo = lo - M + G::H, shi = hi - M + G::H;      // 0 .. NS-1 because |p - M| <= 1
+        slo = slo < 0 ? 0 : slo; shi = shi > G::NS - 1 ? G::NS - 1 : shi;
+        const float vlo = norm2(rc[slo][bi]), vhi = norm2(rc[shi][bi]);
+        if (lo >= 0) { valley += vlo; numRms++; }
+        if (hi < G::NL) { valley += vhi; numRms++; }
+      }
+      if (numRms < 2) {
+        amp = mk(0, 0);
+      } else {
+        const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);   // :989
+        const float peakToMean = sqrtf(norm2(amp)) / RMS; // Complex::abs() via double sqrt == sqrtf
+        amp = cdiv(amp, T->mid_gain[tsc]);                 // :997
+        toa = toa - T->mid_toa[tsc];                       // :998
+        toa = toa - (float)((66 - 56) * SPS);              // :1000
+        detected = peakToMean > detect_thresh;
+      }
+    } else {
+      amp = mk(0, 0);                                      // "bogus result" (:964-968); TOA left as is
+    }
+    if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
     uint8_t fl = 0;
     if (!good) fl = TRXSIG_F_BADLEN;
     else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
@@ -1154,27 +1347,34 @@ int trx_rec_slots(int sps) {
 }
 
 template <int S>
-static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples, const int32_t *off,
                               const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
                               trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                              TrxProfiler *prof) {
+                              int variant, TrxProfiler *prof) {
+  TapArg ta;
+  for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
   if (prof) prof->begin(TRXSIG_K_TSC_CORR, st);
-  k_tsc_corr<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, tsc, rec, Bpad);
+  k_tsc_corr<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
   if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
-  k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
-                                                          flags, amp, toa, avgpwr);
+  if (variant == 0)
+    k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
+                                                            flags, amp, toa, avgpwr);
+  else
+    k_tsc_peak4<S><<<dim3((B + 15) / 16), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
+                                                             flags, amp, toa, avgpwr);
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
 }
 
-hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
-                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof) {
+                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, int variant,
+                                 TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   switch (sps) {
-    case 1: launch_tsc_detect<1>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
-    case 2: launch_tsc_detect<2>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
-    case 4: launch_tsc_detect<4>(st, dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 1: launch_tsc_detect<1>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
+    case 2: launch_tsc_detect<2>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
+    case 4: launch_tsc_detect<4>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

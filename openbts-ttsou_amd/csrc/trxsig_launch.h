@@ -16,10 +16,12 @@ struct TrxProfiler {
 // number of complex slots per burst in the detect->peak record (SoA, [slot][Bpad])
 int trx_rec_slots(int sps);
 
-hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+// dT: device tables, hT: the host copy (the midamble taps travel as a kernel argument)
+hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
                                  uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                                 int variant /* 0: lane-per-burst peak kernel, 1: quad-per-burst */,
                                  TrxProfiler *prof);
 
 // RACH detect: ws = workspace of trx_rach_rec_floats(sps) * Bpad floats
