@@ -33,6 +33,7 @@ ALG_WRITE = 4 * NSOFT + 16
 ALG_BYTES = ALG_READ + ALG_WRITE
 # per-kernel algorithmic bytes per burst (DESIGN.md "Kernels"):
 KERNEL_ALG_BYTES = {
+    "k_rach_corr": ALG_READ + 1012, "k_rach_peak": 1012 + 17,
     "k_tsc_corr": 8 * 36 * SPS + 8 * 20 * SPS + 8 * 44,     # window + energy window read, record write
     "k_tsc_peak": 8 * 44 + 13 + 4,                          # record read, flags/amp/toa/avgpwr write
     "k_demod": ALG_READ + 13 + 4 * NSOFT,                   # whole burst + amp/toa/flags read, soft write
@@ -88,6 +89,8 @@ def main():
     ap.add_argument("--bursts", type=int, default=BURSTS_PER_GPU, help="bursts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
+    ap.add_argument("--workload", choices=["normal", "rach"], default="normal",
+                    help="normal = BASELINE config 2 (the headline metric); rach = config 3 (side measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,7 +121,11 @@ def main():
     ctx.use_torch_stream()
 
     B = args.bursts
-    x, off, length, meta = synth.normal_batch_torch(SPS, B, TSC, seed=0xB5E55ED0 + rank, device=dev)
+    rach = args.workload == "rach"
+    if rach:
+        x, off, length, meta = synth.rach_batch_torch(SPS, B, seed=0xB5E55ED0 + rank, device=dev)
+    else:
+        x, off, length, meta = synth.normal_batch_torch(SPS, B, TSC, seed=0xB5E55ED0 + rank, device=dev)
     xf = torch.view_as_real(x).contiguous()
     flags = torch.zeros(B, dtype=torch.uint8, device=dev)
     amp = torch.zeros(B, 2, dtype=torch.float32, device=dev)
@@ -127,8 +134,12 @@ def main():
     ctx.reserve(B)
 
     def step():
-        ctx.detect_demod_normal(xf, off, length, TSC, flags, amp, toa, soft, detect_thresh=3.0,
-                                energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+        if rach:
+            ctx.detect_demod_rach(xf, off, length, flags, amp, toa, soft, detect_thresh=5.0, energy_thresh=-1.0,
+                                  nsoft=NSOFT, soft_stride=NSOFT)
+        else:
+            ctx.detect_demod_normal(xf, off, length, TSC, flags, amp, toa, soft, detect_thresh=3.0,
+                                    energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
 
     def barrier():
         if world > 1:
@@ -158,7 +169,8 @@ def main():
     # results sanity (outside the timed region): detections and hard bits of the clean bursts
     det = (flags & pkg.F_DETECT) != 0
     clean = det & (meta["sigma"] <= 0.1)
-    hard_ok = bool(((soft[clean] > 0.5).to(torch.uint8) == meta["bits"][clean]).all().item())
+    cols = slice(8, 85) if rach else slice(0, 148)
+    hard_ok = bool(((soft[clean][:, cols] > 0.5).to(torch.uint8) == meta["bits"][clean][:, cols]).all().item())
     det_frac = float(det.float().mean().item())
 
     if rank != 0:
@@ -182,14 +194,16 @@ def main():
         "metric": "Mbursts/s (156.25-sym @ 4 sps) demod+detect", "value": round(value, 3), "unit": "Mbursts/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "config2: %d normal bursts/GPU, sps=4, 628/624/624/624 complex f32 samples, "
-                               "TSC %d, detect (thr 3.0) + demod to %d soft bits" % (B, TSC, NSOFT),
+        "config": {"workload": ("config3: %d access bursts/GPU, sps=4, detectRACHBurst over all lags (thr 5.0) + demod "
+                                "to %d soft bits" % (B, NSOFT)) if rach else
+                               ("config2: %d normal bursts/GPU, sps=4, 628/624/624/624 complex f32 samples, "
+                                "TSC %d, detect (thr 3.0) + demod to %d soft bits" % (B, TSC, NSOFT)),
                    "bursts_per_gpu": B, "sps": SPS, "parallelism": "burst-sharded x%d (no data-path collective)" % world},
         "hip_event_ms_per_step": round(ev_ms / args.steps, 4),
         "detected_frac": round(det_frac, 4), "clean_hard_bits_ok": hard_ok,
         "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not rach:
         n = min(B, 16384)
         end = int(off[n - 1].item() + length[n - 1].item())
         xh = x[:end].cpu().numpy()

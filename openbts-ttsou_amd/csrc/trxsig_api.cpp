@@ -67,6 +67,7 @@ struct trxsig_ctx {
   // staging for the *_host wrappers
   size_t stage_bytes = 0;
   void *d_stage = nullptr;
+  int rach_variant = 1;              // 1 = k_rach_fast (approximate-then-exact), 0 = exact at every lag
   int variant = 1;                   // peak kernel: 1 = four lanes per burst (k_tsc_peak4), 0 = one lane per burst
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -114,6 +115,7 @@ int check_device(int device, std::string &why) {
 
 int finish_create(trxsig_ctx *c) {
   if (const char *v = std::getenv("TRXSIG_TSC_VARIANT")) c->variant = std::atoi(v);
+  if (const char *v = std::getenv("TRXSIG_RACH_VARIANT")) c->rach_variant = std::atoi(v);
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   return TRXSIG_OK;
@@ -300,9 +302,13 @@ int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, c
   DeviceGuard g(c->device);
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
-  HIPCHK(c, trx_launch_rach_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
-                                   B, detect_thresh, energy_thresh, (float *)c->d_rec, c->cap_bursts, d_flags,
-                                   (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+  if (c->rach_variant == 1)
+    HIPCHK(c, trx_launch_rach_fast(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                                   detect_thresh, energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+  else
+    HIPCHK(c, trx_launch_rach_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
+                                     B, detect_thresh, energy_thresh, (float *)c->d_rec, c->cap_bursts, d_flags,
+                                     (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,

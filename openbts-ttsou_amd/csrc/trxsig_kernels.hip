@@ -454,22 +454,22 @@ __device__ __forceinline__ float qrow_tap(const QRow &w) {
   return quad_perm<src * 0x55>(x);                         // quad_perm:[src,src,src,src]
 }
 
-template <bool MASK, int J>
+template <bool MASK, int STR, int J>
 __device__ __forceinline__ float qchain(const float *p, int slot0, int zslot, const QRow &w, float acc) {
   if constexpr (J < 21) {
-    float v = p[J * 32];
+    float v = p[J * 2 * STR];
     if (MASK && slot0 + J > zslot) v = 0.0f;               // interpolatePoint never uses the last sample (:646)
     acc = acc + v * qrow_tap<J>(w);
-    return qchain<MASK, J + 1>(p, slot0, zslot, w, acc);
+    return qchain<MASK, STR, J + 1>(p, slot0, zslot, w, acc);
   } else {
     return acc;
   }
 }
 
-template <int SPS, bool MASK>
+// HOFF: slot of lag M-12; STR: complex entries per slot row (bursts side by side)
+template <int HOFF, int STR, bool MASK>
 __device__ __forceinline__ void quad_bisect(const TrxTables *__restrict__ T, const float *rcf, int bi, int q, int M,
                                             int zslot, float *peakIx, float *pk_own, float *pk_partner) {
-  typedef CorrGeom<SPS> G;
   const int c = q & 1, late = q >> 1;
   auto load_row = [&](int f) {
     const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
@@ -480,14 +480,14 @@ __device__ __forceinline__ void quad_bisect(const TrxTables *__restrict__ T, con
   };
   // one chain of interpolatePoint: sum_j comp(corr[slot0 + j]) * s[j], j ascending
   auto chain = [&](int slot0, const QRow &w) {
-    const float *p = rcf + ((size_t)slot0 * 16 + bi) * 2 + c;
-    return qchain<MASK, 0>(p, slot0, zslot, w, 0.0f);
+    const float *p = rcf + ((size_t)slot0 * STR + bi) * 2 + c;
+    return qchain<MASK, STR, 0>(p, slot0, zslot, w, 0.0f);
   };
   auto frac512 = [](float ix) { return (int)((ix - floorf(ix)) * 512.0f); };
   auto slot_of = [&](float ix) {
     int base = (int)floorf(ix) - M + 2;                    // 0..3 by construction
     base = base < 0 ? 0 : (base > 3 ? 3 : base);
-    return base + (G::H - 12);
+    return base + HOFF;
   };
 
   float early = (float)M - 1;
@@ -547,8 +547,8 @@ __global__ __launch_bounds__(64) void k_tsc_peak4(const TrxTables *__restrict__ 
   const bool needMask = zslot < G::H + 13;                 // ... and it is within reach of the interpolator
   float peakIx, pkOwn, pkOther;
   const float *rcf = reinterpret_cast<const float *>(&rc[0][0]);
-  if (__ballot(needMask) != 0) quad_bisect<SPS, true>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
-  else quad_bisect<SPS, false>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
+  if (__ballot(needMask) != 0) quad_bisect<G::H - 12, 16, true>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
+  else quad_bisect<G::H - 12, 16, false>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
 
   if (q == 0 && live) {                                    // one lane per burst finishes analyzeTrafficBurst
     float toa = peakIx;
@@ -773,6 +773,295 @@ __global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ 
     amp_out[b] = amp;
     toa_out[b] = toa;
     if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rach_fast: detectRACHBurst (sigProcLib.cpp:860-914) with the SAME results as k_rach_corr +
+//   k_rach_peak at a fraction of the arithmetic.  One wave per burst.
+//
+// Only three things in detectRACHBurst depend on exact correlation values: which lag is the
+// maximum, the 24 lags around it that peakDetect interpolates, and (through one comparison) the
+// valley power.  So:
+//  1. an APPROXIMATE correlation at all lags: the access-burst sequence is GMSK-modulated symbols,
+//     rach[m] = sum_k p[m+sps-sps*k] * c_k, hence corr[t] = sum_k conj(c_k) * z[t-F-sps+sps*k] with
+//     z = x filtered by the (2*sps+1)-tap pulse, minus two edge terms for the pulse tails the
+//     reference's NO_DELAY convolution dropped (sigProcLib.cpp:559); with c_k ~ (+-1)*i^k the 41-tap sum
+//     is additions only.  Measured error of |corr|^2 <= 1.2e-5 of the maximum (tools/).
+//  2. every lag whose approximate power is within RACH_DELTA (4e-3, >300x that error) of the
+//     approximate maximum, plus the 26 lags around the approximate argmax, is recomputed EXACTLY (the
+//     reference's 41*sps-term sum in its order, one lag per lane); the exact first-maximum among them
+//     is the reference's argmax because no other lag can reach it.  If the exact argmax moved by more
+//     than one lag its neighbourhood is recomputed too.
+//  3. peakDetect's bisection runs on the exact neighbourhood (four lanes, quad_bisect).
+//  4. the valley RMS uses the approximate powers; if peak/RMS lands within 1e-3 (relative) of the
+//     threshold -- where a 1e-5 error could matter -- the valley lags are recomputed exactly and summed
+//     in the reference's order, so the detect decision is the reference's in every case.
+// If more far-away candidates turn up than fit in one pass (flat noise, silence) the burst takes
+// the exact route for all lags.
+// ---------------------------------------------------------------------------------------------
+#define RACH_DELTA 4e-3f
+#define RACH_GUARD 1e-3f
+__device__ __constant__ const signed char kRachSym[41] = {           // 2*bit-1 of gRACHSynchSequence (GSM/GSMCommon.cpp:57)
+  -1, 1, -1, -1, 1, -1, 1, 1, -1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, 1, -1, -1, -1, 1, 1, 1, 1, -1,
+  -1, -1 };
+
+template <int SPS>
+struct RachFast {
+  typedef RachGeom<SPS> R;
+  static constexpr int XF = R::F + SPS;                     // X[i] = x[i - XF]
+  static constexpr int XPAD = 64 * R::NCL + R::LB + 4 * SPS + 8;
+  static constexpr int ZPAD = 64 * R::NCL + 40 * SPS + 1;   // Zs[i] = sum_j p[j] X[i+j]
+  static constexpr int NB = 26;                             // lags M~-13 .. M~+12 always recomputed
+};
+
+// exact corr[t] (sigProcLib.cpp:474-503 + 322-366): sum over m = LB-1 .. 0 of x[t-F+m]*conj(rach[m])
+template <int SPS>
+__device__ __forceinline__ cx rach_exact_lag(const cx *X, const cx *__restrict__ rseq, int t) {
+  typedef RachGeom<SPS> R;
+  cx acc = mk(0, 0);
+  const cx *xp = X + t + SPS;                              // X index of x[t-F+m] is t + m + SPS
+#pragma unroll 4
+  for (int m = R::LB - 1; m >= 0; m--) {
+    const cx rm = rseq[m];
+    acc = cadd(acc, cmul(xp[m], mk(rm.r, -rm.i)));
+  }
+  return acc;
+}
+
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+                                                   const int32_t *__restrict__ offset,
+                                                   const int32_t *__restrict__ length, int B,
+                                                   float detect_thresh, float energy_thresh,
+                                                   uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                   float *__restrict__ toa_out, float *__restrict__ avgpwr_out) {
+  typedef RachGeom<SPS> R;
+  typedef RachFast<SPS> Q;
+  __shared__ cx xs[1][Q::XPAD];
+  __shared__ cx zs[1][Q::ZPAD];                             // pulse-filtered burst; later approx powers (float view)
+  __shared__ cx exv[1][64];                                 // exact correlation of the selected lags
+  __shared__ int exl[1][64];                                // ... and which lags they are
+  __shared__ cx nb[1][26];                                  // exact neighbourhood corr[M-12..M+11] (+2 zero slots)
+
+  const int lane = threadIdx.x;
+  constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int off = offset[b], N = length[b];
+  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
+  if (!good) {
+    if (lane == 0) { flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = 0.0f; }
+    return;
+  }
+  const cx *x = samples + off;
+  cx *X = xs[wave];
+  cx *Z = zs[wave];
+  float *PW = reinterpret_cast<float *>(Z);
+  const cx *rseq = T->rach;
+
+  for (int i = lane; i < Q::XPAD; i += 64) {
+    const int n = i - Q::XF;
+    X[i] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
+  }
+  float nrm[R::NEQ];
+#pragma unroll
+  for (int q = 0; q < R::NEQ; q++) {
+    const int i = (lane & 15) + 16 * q;
+    cx v = mk(0, 0);
+    if (i < R::NE) v = x[i];
+    nrm[q] = norm2(v);
+  }
+  float energy = energy_chain<SPS, 0>(0.0f, nrm);
+  energy = __shfl(energy, 0, 64);
+  const bool energy_ok = energy_thresh < 0.0f || energy / (float)(unsigned)R::NE > energy_thresh * energy_thresh;
+  if (!energy_ok) {                                        // Transceiver.cpp:298-306: correlator not run
+    if (lane == 0) { flags[b] = 0; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE; }
+    return;
+  }
+  wave_lds_fence();
+
+  // ---- 1. approximate correlation at all lags (FMA allowed: this pass only steers) ----
+  float pul[2 * SPS + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * SPS + 1; j++) pul[j] = T->pulse[j];
+  for (int i = lane; i < Q::ZPAD; i += 64) {
+    float zr = 0.0f, zi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2 * SPS + 1; j++) {
+      const cx v = X[i + j];
+      zr = __builtin_fmaf(pul[j], v.r, zr); zi = __builtin_fmaf(pul[j], v.i, zi);
+    }
+    Z[i] = mk(zr, zi);
+  }
+  wave_lds_fence();
+  float pw[R::NCL];
+  float bestP = 0.0f;
+  int bestT = -1;
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) {
+    const int t = lane + 64 * c;
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 41; k++) {                         // conj(c_k) z, c_k = sym_k i^k: additions only
+      const cx z = Z[t + SPS * k];
+      const float sg = (float)kRachSym[k];
+      if ((k & 3) == 0) { ar += sg * z.r; ai += sg * z.i; }
+      else if ((k & 3) == 1) { ar += sg * z.i; ai -= sg * z.r; }
+      else if ((k & 3) == 2) { ar -= sg * z.r; ai -= sg * z.i; }
+      else { ar -= sg * z.i; ai += sg * z.r; }
+    }
+    // pulse tails the reference's modulateBurst dropped: before symbol 0 (j < sps) and after symbol 40 (j = 2 sps)
+    float e0r = 0.0f, e0i = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = __builtin_fmaf(pul[j], v.r, e0r); e0i = __builtin_fmaf(pul[j], v.i, e0i); }
+    const float s0 = (float)kRachSym[0], s40 = (float)kRachSym[40];
+    ar -= s0 * e0r; ai -= s0 * e0i;                        // k = 0: conj(c_0) = s0
+    const cx v40 = X[t + 42 * SPS];
+    ar -= s40 * pul[2 * SPS] * v40.r; ai -= s40 * pul[2 * SPS] * v40.i;   // k = 40: i^40 = 1
+    const float p = (t < N) ? ar * ar + ai * ai : -1.0f;
+    pw[c] = p;
+    if (p > bestP) { bestP = p; bestT = t; }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const float oP = __shfl_xor(bestP, m, 64);
+    const int oT = __shfl_xor(bestT, m, 64);
+    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
+    if (take) { bestP = oP; bestT = oT; }
+  }
+  wave_lds_fence();                                        // everybody is done reading Z
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) PW[lane + 64 * c] = pw[c];   // approximate powers (lags >= N hold -1)
+
+  // ---- 2. exact recomputation of the contenders ----
+  const int Ma = bestT;                                    // approximate argmax (-1: silence)
+  const float cut = bestP * (1.0f - RACH_DELTA);
+  const int nb0 = Ma - 13;                                 // neighbourhood lags nb0 .. nb0+25
+  int nfar = 0;
+  int *LG = exl[wave];
+  if (lane < Q::NB) LG[lane] = nb0 + lane;
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) {
+    const int t = lane + 64 * c;
+    const bool far = (t < N) && (pw[c] >= cut) && (t < nb0 || t >= nb0 + Q::NB);
+    const unsigned long long mask = __ballot(far);
+    const int pos = nfar + __popcll(mask & ((1ull << lane) - 1ull));
+    if (far && pos < 64 - Q::NB) LG[Q::NB + pos] = t;
+    nfar += __popcll(mask);
+  }
+  wave_lds_fence();
+  int M;                                                   // exact argmax
+  if (Ma < 0 || nfar > 64 - Q::NB) {
+    // flat or silent burst: exact correlation at every lag (the k_rach_corr route)
+    float bP = 0.0f; int bT = -1;
+    for (int c = 0; c < R::NCL; c++) {
+      const int t = lane + 64 * c;
+      if (t < N) {
+        const cx v = rach_exact_lag<SPS>(X, rseq, t);
+        const float p = norm2(v);
+        if (p > bP) { bP = p; bT = t; }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const float oP = __shfl_xor(bP, m, 64);
+      const int oT = __shfl_xor(bT, m, 64);
+      const bool take = (oP > bP) || (oP == bP && oT >= 0 && (bT < 0 || oT < bT));
+      if (take) { bP = oP; bT = oT; }
+    }
+    M = bT;
+    if (lane < 24) {
+      const int lag = M - 12 + lane;
+      nb[wave][lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
+    }
+  } else {
+    const int nl = Q::NB + nfar;
+    const int t = lane < nl ? LG[lane] : -1;
+    cx v = mk(0, 0);
+    const bool valid = t >= 0 && t < N;
+    if (valid) v = rach_exact_lag<SPS>(X, rseq, t);
+    exv[wave][lane] = v;
+    float bP = valid ? norm2(v) : 0.0f;
+    int bT = (valid && bP > 0.0f) ? t : -1;
+    if (bT < 0) bP = 0.0f;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const float oP = __shfl_xor(bP, m, 64);
+      const int oT = __shfl_xor(bT, m, 64);
+      const bool take = (oP > bP) || (oP == bP && oT >= 0 && (bT < 0 || oT < bT));
+      if (take) { bP = oP; bT = oT; }
+    }
+    M = bT;
+    wave_lds_fence();
+    if (M >= nb0 + 12 && M <= nb0 + 14) {                  // |M - Ma| <= 1: [M-12, M+11] lies inside the recomputed lags
+      if (lane < 24) nb[wave][lane] = exv[wave][M - 12 + lane - nb0];
+    } else if (lane < 24) {
+      const int lag = M - 12 + lane;
+      nb[wave][lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
+    }
+  }
+  if (lane < 24) {                                         // interpolatePoint never uses the last sample (:646)
+    const int lag = M - 12 + lane;
+    if (lag > N - 2 || lag < 0) nb[wave][lane] = mk(0, 0);
+  }
+  if (lane >= 24 && lane < 26) nb[wave][lane] = mk(0, 0);
+  wave_lds_fence();
+
+  // ---- 3. peakDetect's bisection on the exact neighbourhood (lanes 0..3) ----
+  float peakIx, pkOwn, pkOther;
+  quad_bisect<0, 1, false>(T, reinterpret_cast<const float *>(nb[wave]), 0, lane & 3, M, 1 << 30, &peakIx, &pkOwn,
+                           &pkOther);
+  peakIx = __shfl(peakIx, 0, 64); pkOwn = __shfl(pkOwn, 0, 64); pkOther = __shfl(pkOther, 0, 64);
+  const cx peak = mk(pkOwn, pkOther);
+
+  // ---- 4. detectRACHBurst tail (:875-913) ----
+  float toa = peakIx;
+  cx amp = mk(0, 0);
+  bool detected = false;
+  if (!(toa < 0.0f) && !(toa > (float)N)) {
+    const int p = (int)rintf(toa);
+    const int i0 = 57 * SPS, i1 = 107 * SPS;
+    int last = N - 1 - p;                                  // largest i with p + i < N
+    if (last > i1) last = i1;
+    const int cnt = last - i0 + 1;                         // numSamples
+    if (cnt >= 2) {
+      float vs = 0.0f;
+      for (int i = i0 + lane; i <= last; i += 64) vs += PW[p + i];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
+      float RMS = (float)((double)sqrtf(vs / (float)cnt) + 0.00001);
+      float peakToMean = sqrtf(norm2(peak)) / RMS;
+      if (fabsf(peakToMean - detect_thresh) <= RACH_GUARD * fabsf(detect_thresh) || !(vs == vs)) {
+        // too close to call from approximate powers: the reference's valley, exactly (:888-901)
+        float *VX = reinterpret_cast<float *>(exv[wave]);
+        float valley = 0.0f;
+        for (int base = i0; base <= last; base += 64) {
+          const int i = base + lane;
+          float pv = 0.0f;
+          if (i <= last) pv = norm2(rach_exact_lag<SPS>(X, rseq, p + i));
+          wave_lds_fence();
+          VX[lane] = pv;
+          wave_lds_fence();
+          if (lane == 0) {
+            const int n = (last - base + 1) < 64 ? (last - base + 1) : 64;
+            for (int k = 0; k < n; k++) valley += VX[k];
+          }
+        }
+        valley = __shfl(valley, 0, 64);
+        RMS = (float)((double)sqrtf(valley / (float)cnt) + 0.00001);
+        peakToMean = sqrtf(norm2(peak)) / RMS;
+      }
+      amp = cdiv(peak, T->rach_gain);                      // :905
+      toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
+      detected = peakToMean > detect_thresh;
+    }
+  }
+  if (lane == 0) {
+    flags[b] = TRXSIG_F_ENERGY | (detected ? TRXSIG_F_DETECT : 0);
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
   }
 }
 
@@ -1402,6 +1691,23 @@ static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c3
   k_rach_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, recv, len, Bpad, B, detect_thresh,
                                                            energy_thresh, flags, amp, toa, avgpwr);
   if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
+}
+
+hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                                const int32_t *off, const int32_t *len, int B, float detect_thresh,
+                                float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                                TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  const dim3 grid(B), block(64);
+  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
+  switch (sps) {
+    case 1: k_rach_fast<1><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    case 2: k_rach_fast<2><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    case 4: k_rach_fast<4><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (prof) prof->end(TRXSIG_K_RACH_CORR, st);
+  return hipGetLastError();
 }
 
 hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,

@@ -184,3 +184,31 @@ def normal_batch_torch(sps, B, tsc, seed=0, device="cuda:0", sigmas=(0.0, 0.1, 0
     meta = dict(bits=torch.cat(bits_all), amp=torch.cat(amp_all), delay=torch.cat(delay_all),
                 sigma=torch.cat(sig_all))
     return (x, torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(length).to(dev), meta)
+
+
+def rach_batch_torch(sps, B, seed=0, device="cuda:0", sigmas=(0.0, 0.1, 0.3), max_delay_sym=60, chunk=8192):
+    """Config 3 workload generated on the GPU (access bursts arriving 0..max_delay_sym symbols late)."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    sync = torch.tensor([int(c) for c in RACH_SYNCH], dtype=torch.uint8, device=dev)
+    xs, bits_all, amp_all, delay_all, sig_all = [], [], [], [], []
+    sig_choices = torch.tensor(sigmas, dtype=torch.float32, device=dev)
+    for s in range(0, B, chunk):
+        n = min(chunk, B - s)
+        bits = torch.zeros(n, 148, dtype=torch.uint8, device=dev)
+        bits[:, 1:8:2] = 1
+        bits[:, 8:49] = sync
+        bits[:, 49:85] = torch.randint(0, 2, (n, 36), device=dev, generator=gen, dtype=torch.uint8)
+        mag = 300 + 2700 * torch.rand(n, device=dev, generator=gen)
+        ph = 2 * np.pi * torch.rand(n, device=dev, generator=gen)
+        amp = torch.polar(mag, ph)
+        delay = (torch.randint(0, max_delay_sym + 1, (n,), device=dev, generator=gen) * sps).to(torch.float32) + \
+            torch.rand(n, device=dev, generator=gen)
+        sigma = sig_choices[(torch.arange(n, device=dev) + s) % len(sigmas)]
+        x, _, _ = _torch_batch(bits, sps, delay, amp, sigma, dev, gen)
+        xs.append(x); bits_all.append(bits); amp_all.append(amp); delay_all.append(delay); sig_all.append(sigma)
+    guard, length, off = burst_lengths(B, sps)
+    meta = dict(bits=torch.cat(bits_all), amp=torch.cat(amp_all), delay=torch.cat(delay_all), sigma=torch.cat(sig_all))
+    return (torch.cat(xs), torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(length).to(dev), meta)

@@ -79,3 +79,36 @@ def test_host_wrappers(pkg, ctx, golden):
     assert_veq(r["amp"], g["amp"][sel]); assert_veq(r["toa"], g["toa"][sel])
     det = (r["flags"] & pkg.F_DETECT) != 0
     assert_veq(r["soft"][det], g["soft"][sel][det][:, :148])
+
+
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_rach_variants_agree_with_oracle(pkg, variant, monkeypatch):
+    """Both RACH kernels (exact-at-every-lag and approximate-then-exact) against the oracle, including
+    noise-only, silent, clipped and late bursts where the approximate pass has to hand over."""
+    monkeypatch.setenv("TRXSIG_RACH_VARIANT", variant)
+    sps, B = 4, 768
+    t = pkg.TrxSig(sps, 0); t.use_torch_stream()
+    o = oraclebind.Oracle(sps)
+    x, off, length, meta = synth.rach_batch(sps, B, seed=977, sigmas=(0.0, 0.05, 0.3, 1.0, 5.0), max_delay_sym=100)
+    rng = np.random.default_rng(3)
+    for i in range(0, B, 16):                       # noise only
+        x[off[i]:off[i] + length[i]] = (rng.standard_normal(length[i]) + 1j * rng.standard_normal(length[i])) * 40
+    for i in range(5, B, 64):                       # silence
+        x[off[i]:off[i] + length[i]] = 0
+    for i in range(7, B, 64):                       # constant (flat correlation)
+        x[off[i]:off[i] + length[i]] = 100 + 50j
+    gb = GpuBatch(x, off, length)
+    t.detect_demod_rach(gb.x, gb.off, gb.len, gb.flags, gb.amp, gb.toa, gb.soft, energy_thresh=-1.0)
+    r = gb.results()
+    ok, amp, toa, soft = o.rach_batch(x, off, length, nthreads=8)
+    assert_veq((r["flags"] & pkg.F_DETECT) != 0, ok.astype(bool), "detect")
+    assert_veq(r["amp"], amp, "amp"); assert_veq(r["toa"], toa, "toa"); assert_veq(r["soft"], soft, "soft")
+    # a threshold placed exactly on bursts' own peak-to-valley ratios forces the exact-valley hand-over
+    ptm = np.array([o.detect_rach(x[off[i]:off[i] + length[i]])["peak_to_mean"] for i in range(64)], np.float32)
+    for i in np.flatnonzero(ptm > 0)[:12]:
+        for thr in (ptm[i], np.nextafter(ptm[i], np.float32(0)), np.nextafter(ptm[i], np.float32(1e9))):
+            gb1 = GpuBatch(x[off[i]:off[i] + length[i]], [0], [length[i]])
+            t.detect_demod_rach(gb1.x, gb1.off, gb1.len, gb1.flags, gb1.amp, gb1.toa, gb1.soft, detect_thresh=float(thr),
+                                energy_thresh=-1.0)
+            want = o.detect_rach(x[off[i]:off[i] + length[i]], thresh=float(thr))["ok"]
+            assert bool(gb1.results()["flags"][0] & pkg.F_DETECT) == want, (i, thr)
