@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrxsig.so")
+LIB_PATH = os.environ.get("TRXSIG_LIB", os.path.join(_HERE, "libtrxsig.so"))   # TRXSIG_LIB: tuning builds
 
 F_ENERGY, F_DETECT, F_BADLEN = 1, 2, 128
 

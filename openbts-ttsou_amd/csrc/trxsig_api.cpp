@@ -68,7 +68,7 @@ struct trxsig_ctx {
   size_t stage_bytes = 0;
   void *d_stage = nullptr;
   int rach_variant = 1;              // 1 = k_rach_fast (approximate-then-exact), 0 = exact at every lag
-  int variant = 1;                   // peak kernel: 1 = four lanes per burst (k_tsc_peak4), 0 = one lane per burst
+  int variant = 0;                   // reserved for A/B builds of the TSC kernels (TRXSIG_TSC_VARIANT)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 };

@@ -29,6 +29,12 @@
 #ifndef TRX_CORR_WPS
 #define TRX_CORR_WPS 1
 #endif
+#ifndef TRX_CORR_ROUNDS
+#define TRX_CORR_ROUNDS 1
+#endif
+#ifndef TRX_DEMOD_WAVES
+#define TRX_DEMOD_WAVES 4
+#endif
 
 namespace {
 
@@ -134,88 +140,77 @@ __device__ __forceinline__ float energy_chain(float acc, const float (&nrm)[Corr
   return energy_chain_step<SPS, I>(acc, nrm);
 }
 
+// One round = 4 bursts of one wave.  corr_issue puts a round's global loads in flight (8 bytes per lane
+// per load, any alignment); corr_round consumes them.  k_tsc_corr issues the loads of BOTH of its
+// rounds before working on the first, so the second round's HBM latency hides under arithmetic
+// (workgroups of a launch otherwise march through their load and math phases in lockstep: the phase
+// costs of the single-round kernel measured perfectly additive).
 template <int SPS>
-__global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables *__restrict__ T,
-                                                  const cx *__restrict__ samples,
-                                                  const int32_t *__restrict__ offset,
-                                                  const int32_t *__restrict__ length, int B, TapArg taps,
-                                                  cx *__restrict__ rec, int Bpad) {
+struct CorrIn {
+  static constexpr int NW = (CorrGeom<SPS>::NL + 15) / 16;     // window samples per lane
+  cx w[NW];
+  cx e[CorrGeom<SPS>::NEQ];
+  int b;
+  bool live, good;
+};
+
+template <int SPS>
+__device__ __forceinline__ void corr_issue(CorrIn<SPS> &in, int b, int B, int r, const cx *__restrict__ samples,
+                                           const int32_t *__restrict__ offset, const int32_t *__restrict__ length) {
   typedef CorrGeom<SPS> G;
-  // one LDS row per burst, owned by the 16 lanes of its DPP row; no workgroup barrier anywhere.
-  // The row first holds the zero-padded window, later (same storage) the correlation.
-  __shared__ cx rows[16][G::WPAD];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = lane >> 4, r = lane & 15;
-  const int slot = wave * 4 + row;                        // burst slot in this workgroup
-  const int b = blockIdx.x * 16 + slot;
-  const bool live = b < B;
+  in.b = b;
+  in.live = b < B;
   int off = 0, len = 0;
-  if (live) { off = offset[b]; len = length[b]; }
-  const bool good = live && (off >= 0) && (len >= 92 * SPS) && (len <= 157 * SPS) && (len % SPS == 0);
-  const cx *x = samples + (good ? off : 0);
-  cx *W = rows[slot];
-
-  // ---- issue all global loads first: window (2 samples per 16-byte load) and energy window ----
-  constexpr int NWQ = (G::NL / 2 + 15) / 16;               // float4 loads per lane
-  const bool wide = ((off + 56 * SPS) & 1) == 0;
-  float4 wv[NWQ];
-  cx wn[2 * NWQ];
-  if (good && wide) {
-    const float4 *xw = reinterpret_cast<const float4 *>(x + 56 * SPS);
+  if (in.live) { off = offset[b]; len = length[b]; }
+  in.good = in.live && (off >= 0) && (len >= 92 * SPS) && (len <= 157 * SPS) && (len % SPS == 0);
+  const cx *x = samples + (in.good ? off : 0);
 #pragma unroll
-    for (int i = 0; i < NWQ; i++) {
-      const int q = r + 16 * i;
-      wv[i] = (q < G::NL / 2) ? xw[q] : make_float4(0, 0, 0, 0);
-    }
-  } else if (good) {
-#pragma unroll
-    for (int i = 0; i < 2 * NWQ; i++) {
-      const int q = r + 16 * i;
-      wn[i] = (q < G::NL) ? x[56 * SPS + q] : mk(0, 0);
-    }
+  for (int i = 0; i < CorrIn<SPS>::NW; i++) {
+    const int q = r + 16 * i;
+    in.w[i] = (in.good && q < G::NL) ? x[56 * SPS + q] : mk(0, 0);
   }
-  float nrm[G::NEQ];
 #pragma unroll
   for (int q = 0; q < G::NEQ; q++) {
     const int i = r + 16 * q;
-    cx v = mk(0, 0);
-    if (good && i < G::NE) v = x[i];
-    nrm[q] = norm2(v);
+    in.e[q] = (in.good && i < G::NE) ? x[i] : mk(0, 0);
   }
+}
 
-  // ---- zero pads, then the window ----
+template <int SPS>
+__device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 *E, int lane, int r, const cx (&tap)[16],
+                                           cx *__restrict__ rec, int Bpad) {
+  typedef CorrGeom<SPS> G;
+  // ---- window (zero padded) and the energy window's norms into LDS ----
   for (int q = r; q < G::FRONT; q += 16) W[q] = mk(0, 0);
   for (int q = G::FRONT + G::NL + r; q < G::WPAD; q += 16) W[q] = mk(0, 0);
-  if (good && wide) {
 #pragma unroll
-    for (int i = 0; i < NWQ; i++) {
-      const int q = r + 16 * i;
-      if (q < G::NL / 2) {
-        W[G::FRONT + 2 * q] = mk(wv[i].x, wv[i].y);
-        W[G::FRONT + 2 * q + 1] = mk(wv[i].z, wv[i].w);
-      }
-    }
-  } else if (good) {
+  for (int i = 0; i < CorrIn<SPS>::NW; i++) {
+    const int q = r + 16 * i;
+    if (q < G::NL) W[G::FRONT + q] = in.w[i];
+  }
+  {
+    float *ef = reinterpret_cast<float *>(E);
 #pragma unroll
-    for (int i = 0; i < 2 * NWQ; i++) {
-      const int q = r + 16 * i;
-      if (q < G::NL) W[G::FRONT + q] = wn[i];
+    for (int q = 0; q < G::NEQ; q++) {
+      const int i = r + 16 * q;
+      if (i < G::NE) ef[i] = norm2(in.e[q]);
     }
-  } else {
-    for (int q = G::FRONT + r; q < G::FRONT + G::NL; q += 16) W[q] = mk(0, 0);
+  }
+  wave_lds_fence();
+  // ---- energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order (:925-928).  Every
+  //      lane of the row adds the norms up sequentially (same address in a row -> broadcast reads);
+  //      a DPP row-shift chain does the same but issues ~5x slower per step. ----
+  float energy = 0.0f;
+#pragma unroll
+  for (int i4 = 0; i4 < (G::NE + 3) / 4; i4++) {
+    const float4 e = E[i4];
+    energy = energy + e.x;
+    if (4 * i4 + 1 < G::NE) energy = energy + e.y;
+    if (4 * i4 + 2 < G::NE) energy = energy + e.z;
+    if (4 * i4 + 3 < G::NE) energy = energy + e.w;
   }
 
-  // ---- energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order ----
-  float energy = energy_chain<SPS, 0>(0.0f, nrm);
-  energy = __shfl(energy, lane & 48, 64);                  // lane 0 of the row holds it
-  wave_lds_fence();
-
   // ---- correlation: 16 non-zero taps, k descending = j ascending ----
-  cx tap[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
-
   float bestP = 0.0f;
   int bestT = -1;
   cx cval[G::NC];
@@ -258,7 +253,7 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
   wave_lds_fence();
 
   // ---- record: corr[M-H .. M+H] (zeros outside [0,NL)), then {M, energy} ----
-  if (live) {
+  if (in.live) {
     const int M = bestT;
     for (int s = r; s <= G::NS; s += 16) {
       cx v = mk(0, 0);
@@ -266,11 +261,41 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
         const int lag = M - G::H + s;
         if (lag >= 0 && lag < G::NL) v = W[lag];
       } else {
-        v = mk(__int_as_float(good ? M : -2), energy);   // M = -2 marks an invalid burst
+        v = mk(__int_as_float(in.good ? M : -2), energy);  // M = -2 marks an invalid burst
       }
-      rec[(size_t)s * Bpad + b] = v;
+      rec[(size_t)s * Bpad + in.b] = v;
     }
   }
+  wave_lds_fence();                                        // record reads done before the row is reused
+  (void)lane;
+}
+
+template <int SPS>
+__global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables *__restrict__ T,
+                                                  const cx *__restrict__ samples,
+                                                  const int32_t *__restrict__ offset,
+                                                  const int32_t *__restrict__ length, int B, TapArg taps,
+                                                  cx *__restrict__ rec, int Bpad) {
+  typedef CorrGeom<SPS> G;
+  // one LDS row per burst, owned by the 16 lanes of its DPP row; no workgroup barrier anywhere.
+  // The row first holds the zero-padded window, later (same storage) the correlation.
+  __shared__ cx rows[16][G::WPAD];
+  __shared__ float4 enr[16][(G::NE + 3) / 4];              // |x[i]|^2, i < 20*sps, per burst
+  (void)T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 4, r = lane & 15;
+  const int slot = wave * 4 + row;                         // burst slot in this workgroup
+
+  cx tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
+
+  CorrIn<SPS> in[TRX_CORR_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++)
+    corr_issue<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
+#pragma unroll
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++) corr_round<SPS>(in[i], rows[slot], enr[slot], lane, r, tap, rec, Bpad);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -285,10 +310,11 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
 // to the sign of the early/late decision, so both candidates are fetched while the current step
 // computes.  Returns the interpolated peak; *peakIx = its (fractional) index.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ cx peak_bisect(const TrxTables *__restrict__ T, const cx (*loc)[64], int lane, int M,
-                                          float *peakIx) {
+template <int LW, typename TAB>
+__device__ __forceinline__ cx peak_bisect(const TAB &tab, const cx (*loc)[LW], int lane, int M, float *peakIx) {
+  // tab: float[512][24], either TrxTables::sinc_grid in global memory or a copy in LDS
   auto load_row = [&](int f, float (&s)[24]) {
-    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+    const float4 *row = reinterpret_cast<const float4 *>(tab[f & 511]);
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       const float4 v = row[q];
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
   // (each lane only ever reads its own column: no barrier needed)
 
   float peakIx;
-  const cx peak = peak_bisect(T, loc, lane, M, &peakIx);
+  const cx peak = peak_bisect<64>(T->sinc_grid, loc, lane, M, &peakIx);
 
   // ---- analyzeTrafficBurst tail ----
   float toa = peakIx;
@@ -427,14 +453,11 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_tsc_peak4: the peak logic of k_tsc_peak with FOUR lanes per burst (16 bursts per wave): lanes
-// {0,1,2,3} of a quad own the four independent 21-term chains of a bisection step (early.re,
-// early.im, late.re, late.im); |.|^2 and the early/late comparison are exchanged inside the quad with
-// DPP quad_perm, and the sinc row is shared by the quad (each lane keeps a quarter, taps are
-// broadcast by quad_perm).  Same arithmetic, a quarter of the dependent-chain length per lane and
-// four times as many waves in flight as the lane-per-burst form.
-// (A fully fused corr+peak kernel was tried and measured slower: the correlator wants 4 bursts per
-// wave and >200 VGPRs once both phases live in one kernel -- DESIGN.md, "What did not work".)
+// quad_bisect: peakDetect's bisection with FOUR lanes per burst: lanes {0,1,2,3} of a quad own the
+// four independent 21-term chains of a step (early.re, early.im, late.re, late.im); |.|^2 and the
+// early/late comparison are exchanged inside the quad with DPP quad_perm, and the sinc row is shared
+// by the quad (each lane keeps a quarter, taps are broadcast by quad_perm).  Same arithmetic as
+// peak_bisect.  Used where one wave owns one burst (k_rach_fast).
 // ---------------------------------------------------------------------------------------------
 
 template <int CTRL>
@@ -517,80 +540,6 @@ __device__ __forceinline__ void quad_bisect(const TrxTables *__restrict__ T, con
   const float a = chain(slot_of(*peakIx), cur);            // every lane: its own component of the peak
   *pk_own = a;
   *pk_partner = quad_perm<0xB1>(a);
-}
-
-template <int SPS>
-__global__ __launch_bounds__(64) void k_tsc_peak4(const TrxTables *__restrict__ T, const cx *__restrict__ rec,
-                                                  int Bpad, int B, int tsc, float detect_thresh, float energy_thresh,
-                                                  uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
-                                                  float *__restrict__ toa_out, float *__restrict__ avgpwr_out) {
-  typedef CorrGeom<SPS> G;
-  __shared__ cx rc[G::NS + 1][16];                         // records of 16 bursts: corr[M-H .. M+H], then {M, energy}
-  const int lane = threadIdx.x;
-  const int b0 = blockIdx.x * 16;
-  // ---- stage the 16 records (each slot row is 16 consecutive bursts = one 128-byte line) ----
-  for (int i = lane; i < (G::NS + 1) * 16; i += 64) {
-    const int s = i >> 4, bi = i & 15;
-    const int b = b0 + bi;
-    rc[s][bi] = rec[(size_t)s * Bpad + (b < B ? b : B - 1)];
-  }
-  wave_lds_fence();
-
-  const int bi = lane >> 2, q = lane & 3;
-  const int b = b0 + bi;
-  const bool live = b < B;
-  const cx meta = rc[G::NS][bi];
-  const int M = __float_as_int(meta.r);
-  const float energy = meta.i;
-  const bool good = M != -2;
-  const int zslot = (G::NL - 2) - (M - G::H);              // slots above this hold the unused last sample
-  const bool needMask = zslot < G::H + 13;                 // ... and it is within reach of the interpolator
-  float peakIx, pkOwn, pkOther;
-  const float *rcf = reinterpret_cast<const float *>(&rc[0][0]);
-  if (__ballot(needMask) != 0) quad_bisect<G::H - 12, 16, true>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
-  else quad_bisect<G::H - 12, 16, false>(T, rcf, bi, q, M, zslot, &peakIx, &pkOwn, &pkOther);
-
-  if (q == 0 && live) {                                    // one lane per burst finishes analyzeTrafficBurst
-    float toa = peakIx;
-    cx amp = mk(pkOwn, pkOther);
-    bool detected = false;
-    const bool energy_ok = good && (energy_thresh < 0.0f ||
-                                    energy / (float)(unsigned)G::NE > energy_thresh * energy_thresh);
-    if (!(toa < 0.0f) && !(toa > (float)G::NL) && good) {
-      const int p = (int)rintf(toa);
-      float valley = 0.0f;
-      int numRms = 0;
-#pragma unroll
-      for (int i = 2 * SPS; i <= 5 * SPS; i++) {           // :971-980, this order
-        const int lo = p - i, hi = p + i;
-        int slo = lo - M + G::H, shi = hi - M + G::H;      // 0 .. NS-1 because |p - M| <= 1
-        slo = slo < 0 ? 0 : slo; shi = shi > G::NS - 1 ? G::NS - 1 : shi;
-        const float vlo = norm2(rc[slo][bi]), vhi = norm2(rc[shi][bi]);
-        if (lo >= 0) { valley += vlo; numRms++; }
-        if (hi < G::NL) { valley += vhi; numRms++; }
-      }
-      if (numRms < 2) {
-        amp = mk(0, 0);
-      } else {
-        const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);   // :989
-        const float peakToMean = sqrtf(norm2(amp)) / RMS; // Complex::abs() via double sqrt == sqrtf
-        amp = cdiv(amp, T->mid_gain[tsc]);                 // :997
-        toa = toa - T->mid_toa[tsc];                       // :998
-        toa = toa - (float)((66 - 56) * SPS);              // :1000
-        detected = peakToMean > detect_thresh;
-      }
-    } else {
-      amp = mk(0, 0);                                      // "bogus result" (:964-968); TOA left as is
-    }
-    if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
-    uint8_t fl = 0;
-    if (!good) fl = TRXSIG_F_BADLEN;
-    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
-    flags[b] = fl;
-    amp_out[b] = amp;
-    toa_out[b] = toa;
-    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -737,7 +686,7 @@ __global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ 
   loc[25][lane] = mk(0, 0);
 
   float peakIx;
-  const cx peak = peak_bisect(T, loc, lane, M, &peakIx);
+  const cx peak = peak_bisect<64>(T->sinc_grid, loc, lane, M, &peakIx);
 
   float toa = peakIx;
   cx amp = mk(0, 0);
@@ -1079,15 +1028,19 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
 // in SGPRs: from the sinc grid when -TOA lies on the 1/512 grid (always, after peakDetect), else
 // computed with the reference's table sinc.
 // ---------------------------------------------------------------------------------------------
-template <int SPS>
+template <int SPS, int NSMAX>
 struct DemodGeom {
-  static constexpr int C = 52;                                   // position of sample 0 at intOffset 0 (multiple of 4)
-  static constexpr int QLEN = 157 + (10 + C + SPS - 1) / SPS;    // entries per phase
+  // Output m reads positions SPS*m + (10 - j) + C, j = 0..20, so with C >= 10 every read lands in
+  // [0, SPS*(NSMAX-1) + 20 + C] whatever the delay is; samples shifted outside that range are never
+  // read and are simply not written.  NSMAX = 148 (the soft bits that go on the wire) keeps the
+  // staged burst under 5 KB, i.e. 32 waves (bursts in flight) per CU instead of 28.
+  static constexpr int C = 12;                                   // position of sample 0 at intOffset 0 (multiple of 4)
+  static constexpr int QLEN = NSMAX + (20 + C) / SPS + 1;        // entries per phase
   static constexpr int U = SPS * QLEN;                           // positions
 };
 
-template <int SPS, bool RAW>
-__global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
+template <int SPS, bool RAW, int NSMAX>
+__global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables *__restrict__ T,
                                                const cx *__restrict__ samples,
                                                const int32_t *__restrict__ offset,
                                                const int32_t *__restrict__ length, int B,
@@ -1098,12 +1051,12 @@ __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
                                                int nsoft, int stride) {
   // RAW: `soft` is really a complex array (stride complex per burst) that receives the delayed,
   // scaled burst itself (every sample, no rotation/slicing): the delayVector step of equalizeBurst.
-  typedef DemodGeom<SPS> G;
-  __shared__ cx ph[4][G::U];
+  typedef DemodGeom<SPS, NSMAX> G;
+  __shared__ cx ph[TRX_DEMOD_WAVES][G::U];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x * 4 + wave;                     // wave-uniform
+  const int b = blockIdx.x * TRX_DEMOD_WAVES + wave;       // wave-uniform
   if (b >= B) return;
   float *sb = soft + (size_t)b * stride;
   uint8_t *hb = hard ? hard + (size_t)b * stride : nullptr;
@@ -1158,7 +1111,21 @@ __global__ __launch_bounds__(256) void k_demod(const TrxTables *__restrict__ T,
   const int lo = io + G::C, hi = N + io + G::C;            // samples occupy positions [lo, hi)
   for (int u = lane; u < lo && u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
   for (int u = (hi > 0 ? hi : 0) + lane; u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
-  if (wide) {
+  if (wide && lo >= 0 && (N & 1) == 0 && (SPS % 2) == 0) {
+    // common case: nothing falls off the front; the tail past U is never read and is not written.  Lane's pair (2q, 2q+1), q = lane + 64 i, sits at positions
+    // u0 = 2q + lo, u0 + 1; successive i move both by 128 positions = 128/SPS entries of the same phase.
+    const int ua = 2 * lane + lo, ub = ua + 1;
+    cx *pa = P + (ua % SPS) * G::QLEN + ua / SPS;
+    cx *pb = P + (ub % SPS) * G::QLEN + ub / SPS;
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int q = lane + 64 * i;
+      if (q < N / 2) {
+        if (ua + 128 * i < G::U) pa[i * (128 / SPS)] = cmul(mk(v[i].x, v[i].y), inv);   // scaleVector (:713-723)
+        if (ub + 128 * i < G::U) pb[i * (128 / SPS)] = cmul(mk(v[i].z, v[i].w), inv);
+      }
+    }
+  } else if (wide) {
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const int q = lane + 64 * i;
@@ -1643,14 +1610,11 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   TapArg ta;
   for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
   if (prof) prof->begin(TRXSIG_K_TSC_CORR, st);
-  k_tsc_corr<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
+  k_tsc_corr<S><<<dim3((B + 16 * TRX_CORR_ROUNDS - 1) / (16 * TRX_CORR_ROUNDS)), dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
   if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
-  if (variant == 0)
-    k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
-                                                            flags, amp, toa, avgpwr);
-  else
-    k_tsc_peak4<S><<<dim3((B + 15) / 16), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
-                                                             flags, amp, toa, avgpwr);
+  (void)variant;
+  k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
+                                                          flags, amp, toa, avgpwr);
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
 }
 
@@ -1729,14 +1693,24 @@ hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const 
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,
                             uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
-  const dim3 grid((B + 3) / 4), block(256);
+  const dim3 grid((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), block(64 * TRX_DEMOD_WAVES);
   if (prof) prof->begin(TRXSIG_K_DEMOD, st);
+#define TRX_DEMOD_CASE(S)                                                                                          \
+  case S:                                                                                                          \
+    if (nsoft <= 148)                                                                                              \
+      k_demod<S, false, 148><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, \
+                                                     nsoft, stride);                                              \
+    else                                                                                                           \
+      k_demod<S, false, 157><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, \
+                                                     nsoft, stride);                                              \
+    break;
   switch (sps) {
-    case 1: k_demod<1, false><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
-    case 2: k_demod<2, false><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
-    case 4: k_demod<4, false><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, nsoft, stride); break;
+    TRX_DEMOD_CASE(1)
+    TRX_DEMOD_CASE(2)
+    TRX_DEMOD_CASE(4)
     default: return hipErrorInvalidValue;
   }
+#undef TRX_DEMOD_CASE
   if (prof) prof->end(TRXSIG_K_DEMOD, st);
   return hipGetLastError();
 }
@@ -1786,7 +1760,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
                                                         variant52m, max_toa, flags, amp, toa, toa_eq, w, bq);
-  k_demod<1, true><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
+  k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
                                                            TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
   k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);

@@ -1,0 +1,28 @@
+"""Numerical-contract audit on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles): outside
+hipcc's correctly-rounded division / sqrt expansions no kernel may contain a fused multiply-add --
+except k_rach_fast, whose approximate steering pass uses explicit fmaf and recomputes everything it
+hands on exactly."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_kernels_have_no_contracted_fma():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openbts-ttsou_amd", "csrc"), "asm"],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.check_output(["python3", os.path.join(ROOT, "tools", "asm_stats.py"),
+                                   os.path.join(ROOT, "openbts-ttsou_amd", "csrc", "trxsig_kernels.gfx950.s")], text=True)
+    rows = [l for l in out.splitlines() if "outside a division" in l]
+    assert len(rows) >= 20
+    for l in rows:
+        n = int(re.search(r"outside a division: (\d+)", l).group(1))
+        if "k_rach_fast" in l:
+            assert n > 0            # the explicit fmaf of the approximate pass
+        else:
+            assert n == 0, l

