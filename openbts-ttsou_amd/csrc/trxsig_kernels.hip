@@ -1039,6 +1039,106 @@ struct DemodGeom {
   static constexpr int U = SPS * QLEN;                           // positions
 };
 
+// everything of demodulateBurst after the burst's loads have been issued (v[] = the 16-byte loads of
+// the `wide` path, in flight): scale, stage, filter at the decimated instants, rotate, slice, store
+template <int SPS, bool RAW, int NSMAX>
+__device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *P, const cx *xb, int N, bool wide,
+                                           const float4 (&v)[(157 * SPS / 2 + 63) / 64], cx amp, float toa, int lane,
+                                           float *sb, uint8_t *hb, cx *rawout, int nsoft) {
+  typedef DemodGeom<SPS, NSMAX> G;
+  constexpr int NLD = (157 * SPS / 2 + 63) / 64;
+  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066)
+  // delayVector(-TOA) bookkeeping (:577-582)
+  const float delay = -toa;
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  const bool filt = fabs((double)frac) > 1e-2;
+  float tp[21];
+  {
+    const float f512 = frac * 512.0f;
+    const int f = (int)f512;
+    if ((float)f == f512) {                                // on the 1/512 grid: sinc_grid[f][j] (uniform -> s_load)
+#pragma unroll
+      for (int j = 0; j < 21; j++) tp[j] = T->sinc_grid[f][j];
+    } else {
+      const float tv = dev_sinc(T->sinT, TRX_PI_F * ((float)(lane - 10) - frac));   // :588
+#pragma unroll
+      for (int j = 0; j < 21; j++) tp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tv), j));
+    }
+  }
+
+  // ---- stage scaled samples at position n + io + C; zero the positions left uncovered ----
+  const int lo = io + G::C, hi = N + io + G::C;            // samples occupy positions [lo, hi)
+  for (int u = lane; u < lo && u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
+  for (int u = (hi > 0 ? hi : 0) + lane; u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
+  if (wide && lo >= 0 && (N & 1) == 0 && (SPS % 2) == 0) {
+    // common case: nothing falls off the front; the tail past U is never read and is not written.
+    // Lane's pair (2q, 2q+1), q = lane + 64 i, sits at positions
+    // u0 = 2q + lo, u0 + 1; successive i move both by 128 positions = 128/SPS entries of the same phase.
+    const int ua = 2 * lane + lo, ub = ua + 1;
+    cx *pa = P + (ua % SPS) * G::QLEN + ua / SPS;
+    cx *pb = P + (ub % SPS) * G::QLEN + ub / SPS;
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int q = lane + 64 * i;
+      if (q < N / 2) {
+        if (ua + 128 * i < G::U) pa[i * (128 / SPS)] = cmul(mk(v[i].x, v[i].y), inv);   // scaleVector (:713-723)
+        if (ub + 128 * i < G::U) pb[i * (128 / SPS)] = cmul(mk(v[i].z, v[i].w), inv);
+      }
+    }
+  } else if (wide) {
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      const int q = lane + 64 * i;
+      if (q < N / 2) {
+        const cx a = cmul(mk(v[i].x, v[i].y), inv), c = cmul(mk(v[i].z, v[i].w), inv);   // scaleVector (:713-723)
+        const int u0 = 2 * q + lo, u1 = u0 + 1;
+        if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = a;
+        if (u1 >= 0 && u1 < G::U) P[(u1 % SPS) * G::QLEN + u1 / SPS] = c;
+      }
+    }
+    if ((N & 1) && lane == 0) {
+      const int u0 = N - 1 + lo;
+      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[N - 1], inv);
+    }
+  } else {
+    for (int n = lane; n < N; n += 64) {
+      const int u0 = n + lo;
+      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[n], inv);
+    }
+  }
+  wave_lds_fence();
+
+  const cx *rev = T->rev;
+  for (int m0 = 0; m0 < nsoft; m0 += 64) {
+    const int m = m0 + lane;
+    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
+    cx y = mk(0, 0);
+    if (m < nsoft && t >= 0 && t < N) {
+      if (filt) {
+#pragma unroll
+        for (int j = 0; j < 21; j++) {                     // convolve(...,NO_DELAY), 21 real taps, j ascending (:590)
+          const int k = 10 - j + G::C;                     // position = SPS*m + k
+          y = cadd(y, cmulr(P[(k % SPS) * G::QLEN + k / SPS + m], tp[j]));
+        }
+      } else {
+        y = P[(G::C % SPS) * G::QLEN + G::C / SPS + m];
+      }
+    }
+    if (RAW) {
+      if (m < nsoft) rawout[m] = y;
+    } else if (m < nsoft) {
+      const cx rv = rev[SPS * m];
+      const float re = rv.r * y.r - rv.i * y.i;            // real part of GMSKReverseRotate (:259-262)
+      float sv = (float)(0.5 * (double)(re + 1.0F));       // vectorSlicer (:513-515)
+      if (sv > 1.0f) sv = 1.0f;
+      if (sv < 0.0f) sv = 0.0f;
+      sb[m] = sv;
+      if (hb) hb[m] = sv > 0.5F;                           // SoftVector::bit (BitVector.h:415-420)
+    }
+  }
+}
+
 template <int SPS, bool RAW, int NSMAX>
 __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables *__restrict__ T,
                                                const cx *__restrict__ samples,
@@ -1085,98 +1185,8 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables 
       v[i] = (q < N / 2) ? xv[q] : make_float4(0, 0, 0, 0);
     }
   }
-
-  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066)
-  // delayVector(-TOA) bookkeeping (:577-582)
-  const float delay = -toa;
-  const int io = (int)floorf(delay);
-  const float frac = delay - (float)io;
-  const bool filt = fabs((double)frac) > 1e-2;
-  float tp[21];
-  {
-    const float f512 = frac * 512.0f;
-    const int f = (int)f512;
-    if ((float)f == f512) {                                // on the 1/512 grid: sinc_grid[f][j] (uniform -> s_load)
-#pragma unroll
-      for (int j = 0; j < 21; j++) tp[j] = T->sinc_grid[f][j];
-    } else {
-      const float tv = dev_sinc(T->sinT, TRX_PI_F * ((float)(lane - 10) - frac));   // :588
-#pragma unroll
-      for (int j = 0; j < 21; j++) tp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tv), j));
-    }
-  }
-
-  // ---- stage scaled samples at position n + io + C; zero the positions left uncovered ----
-  cx *P = ph[wave];
-  const int lo = io + G::C, hi = N + io + G::C;            // samples occupy positions [lo, hi)
-  for (int u = lane; u < lo && u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
-  for (int u = (hi > 0 ? hi : 0) + lane; u < G::U; u += 64) P[(u % SPS) * G::QLEN + u / SPS] = mk(0, 0);
-  if (wide && lo >= 0 && (N & 1) == 0 && (SPS % 2) == 0) {
-    // common case: nothing falls off the front; the tail past U is never read and is not written.  Lane's pair (2q, 2q+1), q = lane + 64 i, sits at positions
-    // u0 = 2q + lo, u0 + 1; successive i move both by 128 positions = 128/SPS entries of the same phase.
-    const int ua = 2 * lane + lo, ub = ua + 1;
-    cx *pa = P + (ua % SPS) * G::QLEN + ua / SPS;
-    cx *pb = P + (ub % SPS) * G::QLEN + ub / SPS;
-#pragma unroll
-    for (int i = 0; i < NLD; i++) {
-      const int q = lane + 64 * i;
-      if (q < N / 2) {
-        if (ua + 128 * i < G::U) pa[i * (128 / SPS)] = cmul(mk(v[i].x, v[i].y), inv);   // scaleVector (:713-723)
-        if (ub + 128 * i < G::U) pb[i * (128 / SPS)] = cmul(mk(v[i].z, v[i].w), inv);
-      }
-    }
-  } else if (wide) {
-#pragma unroll
-    for (int i = 0; i < NLD; i++) {
-      const int q = lane + 64 * i;
-      if (q < N / 2) {
-        const cx a = cmul(mk(v[i].x, v[i].y), inv), c = cmul(mk(v[i].z, v[i].w), inv);   // scaleVector (:713-723)
-        const int u0 = 2 * q + lo, u1 = u0 + 1;
-        if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = a;
-        if (u1 >= 0 && u1 < G::U) P[(u1 % SPS) * G::QLEN + u1 / SPS] = c;
-      }
-    }
-    if ((N & 1) && lane == 0) {
-      const int u0 = N - 1 + lo;
-      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[N - 1], inv);
-    }
-  } else {
-    for (int n = lane; n < N; n += 64) {
-      const int u0 = n + lo;
-      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[n], inv);
-    }
-  }
-  wave_lds_fence();
-
-  const cx *rev = T->rev;
-  for (int m0 = 0; m0 < nsoft; m0 += 64) {
-    const int m = m0 + lane;
-    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
-    cx y = mk(0, 0);
-    if (m < nsoft && t >= 0 && t < N) {
-      if (filt) {
-#pragma unroll
-        for (int j = 0; j < 21; j++) {                     // convolve(...,NO_DELAY), 21 real taps, j ascending (:590)
-          constexpr int dummy = 0; (void)dummy;
-          const int k = 10 - j + G::C;                     // position = SPS*m + k
-          y = cadd(y, cmulr(P[(k % SPS) * G::QLEN + k / SPS + m], tp[j]));
-        }
-      } else {
-        y = P[(G::C % SPS) * G::QLEN + G::C / SPS + m];
-      }
-    }
-    if (RAW) {
-      if (m < nsoft) reinterpret_cast<cx *>(soft)[(size_t)b * stride + m] = y;
-    } else if (m < nsoft) {
-      const cx rv = rev[SPS * m];
-      const float re = rv.r * y.r - rv.i * y.i;            // real part of GMSKReverseRotate (:259-262)
-      float sv = (float)(0.5 * (double)(re + 1.0F));       // vectorSlicer (:513-515)
-      if (sv > 1.0f) sv = 1.0f;
-      if (sv < 0.0f) sv = 0.0f;
-      sb[m] = sv;
-      if (hb) hb[m] = sv > 0.5F;                           // SoftVector::bit (BitVector.h:415-420)
-    }
-  }
+  demod_core<SPS, RAW, NSMAX>(T, ph[wave], xb, N, wide, v, amp, toa, lane, sb, hb,
+                              RAW ? reinterpret_cast<cx *>(soft) + (size_t)b * stride : nullptr, nsoft);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1766,3 +1776,4 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }
+

@@ -60,3 +60,4 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
                                int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
                                trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
                                int nsoft, int stride, TrxProfiler *prof);
+
