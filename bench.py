@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--workload", choices=["normal", "rach"], default="normal",
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3 (side measurement)")
+    ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="A/B: normal-burst implementation (trxsig_set_tuning); default = the library's")
     args = ap.parse_args()
 
     import numpy as np
@@ -119,6 +121,8 @@ def main():
     else:
         ctx = pkg.TrxSig(SPS, local)
     ctx.use_torch_stream()
+    if args.path is not None:
+        ctx.set_tuning(normal_path=args.path)
 
     B = args.bursts
     rach = args.workload == "rach"

@@ -228,10 +228,18 @@ int trxsig_timer_start(trxsig_ctx *ctx);
 int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
 enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_K_RACH_CORR = 3,
        TRXSIG_K_RACH_PEAK = 4, TRXSIG_K_MODULATE = 5, TRXSIG_K_RESAMPLE = 6, TRXSIG_K_EQUALIZE = 7,
-       TRXSIG_K_CONVERT = 8, TRXSIG_K_COUNT = 9 };
+       TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_COUNT = 10 };
 const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);
+/* Implementation choice for A/B measurements; results are bit-identical whatever is selected.
+ *   TRXSIG_TUNE_NORMAL_PATH: 0 = three kernels (correlate, peak, demodulate), 1 = one fused kernel
+ *     with a wave per burst, 2 = fused with two bursts per wave (fused paths need nsoft <= 148,
+ *     otherwise the call falls back to 0).  Initial value: env TRXSIG_TSC_VARIANT or the default.
+ *   TRXSIG_TUNE_RACH_PATH: 0 = exact correlation at every lag, 1 = approximate-then-exact.
+ *     Initial value: env TRXSIG_RACH_VARIANT or the default. */
+enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1 };
+int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes);
 

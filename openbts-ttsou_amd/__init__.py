@@ -73,6 +73,7 @@ def lib():
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
         L.trxsig_profile_enable.argtypes = [vp, i32]
+        L.trxsig_set_tuning.argtypes = [vp, i32, i32]
         L.trxsig_profile_collect.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
         L.trxsig_tables_validate_host.argtypes = [vp, C.c_size_t]
         _lib = L
@@ -262,12 +263,19 @@ class TrxSig:
     def pack_int16(self, x, n, iq):
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
+    def set_tuning(self, normal_path=None, rach_path=None):
+        """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
+        if normal_path is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 0, int(normal_path)), "trxsig_set_tuning")
+        if rach_path is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 1, int(rach_path)), "trxsig_set_tuning")
+
     def profile_enable(self, on=True):
         self._chk(self.L.trxsig_profile_enable(self.h, int(on)), "trxsig_profile_enable")
 
     def profile_collect(self):
         """{kernel name: (total_ms, launches)} since the last collect (synchronises)."""
-        n = 9
+        n = 10                                   # TRXSIG_K_COUNT
         ms = (C.c_float * n)(); cnt = (C.c_int * n)()
         self._chk(self.L.trxsig_profile_collect(self.h, ms, cnt), "trxsig_profile_collect")
         return {self.L.trxsig_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}

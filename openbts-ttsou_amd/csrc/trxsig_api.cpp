@@ -280,6 +280,14 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   DeviceGuard g(c->device);
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
+  if (c->variant >= 1 && c->variant <= 3 && nsoft <= 148) {
+    // one kernel for the whole leg: every burst crosses HBM once (k_normal_fused)
+    HIPCHK(c, trx_launch_normal_fused(c->stream, c->sps, c->variant == 1 ? 64 : (c->variant == 2 ? 32 : 16), c->d_tables, c->h_tables,
+                                      (const trx_c32 *)d_samples, d_offset, d_length, B, tsc, detect_thresh,
+                                      energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft,
+                                      soft_stride, c->prof));
+    return TRXSIG_OK;
+  }
   HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
                                   (trx_c32 *)d_amp, d_toa, d_avgpwr, c->variant, c->prof));
@@ -555,8 +563,14 @@ int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
 
 const char *trxsig_kernel_name(int id) {
   static const char *names[TRXSIG_K_COUNT] = { "k_tsc_corr", "k_tsc_peak", "k_demod", "k_rach_corr", "k_rach_peak",
-                                               "k_modulate", "k_resample", "k_equalize", "k_convert" };
+                                               "k_modulate", "k_resample", "k_equalize", "k_convert", "k_normal_fused" };
   return (id >= 0 && id < TRXSIG_K_COUNT) ? names[id] : "?";
+}
+int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
+  if (!c) return TRXSIG_EINVAL;
+  if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 3) { c->variant = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 1) { c->rach_variant = value; return TRXSIG_OK; }
+  return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: unknown key or value");
 }
 int trxsig_profile_enable(trxsig_ctx *c, int on) {
   if (!c) return TRXSIG_EINVAL;

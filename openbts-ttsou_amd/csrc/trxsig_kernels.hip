@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "trxsig_tables.h"
 #include "trxsig_launch.h"
 
@@ -176,10 +178,45 @@ __device__ __forceinline__ void corr_issue(CorrIn<SPS> &in, int b, int B, int r,
   }
 }
 
-template <int SPS>
+// REC: write the detect->peak record (k_tsc_corr); otherwise the correlation just stays in W[0, NL)
+// (k_normal_quad).  M_out / energy_out: argmax lag and energy sum of the lane's burst.
+// EFIRST: E aliases the row (k_normal_quad): the energy window's norms are staged, summed and done
+// with before the correlation window is written over them.
+template <int SPS, bool REC, bool EFIRST = false>
 __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 *E, int lane, int r, const cx (&tap)[16],
-                                           cx *__restrict__ rec, int Bpad) {
+                                           cx *__restrict__ rec, int Bpad, int &M_out, float &energy_out) {
   typedef CorrGeom<SPS> G;
+  auto stage_norms = [&] {
+    float *ef = reinterpret_cast<float *>(E);
+#pragma unroll
+    for (int q = 0; q < G::NEQ; q++) {
+      const int i = r + 16 * q;
+      if (i < G::NE) ef[i] = norm2(in.e[q]);
+    }
+  };
+  // energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order (:925-928).  Every
+  // lane of the row adds the norms up sequentially (same address in a row -> broadcast reads);
+  // a DPP row-shift chain does the same but issues ~5x slower per step.
+  auto sum_norms = [&] {
+    float energy = 0.0f;
+#pragma unroll
+    for (int i4 = 0; i4 < (G::NE + 3) / 4; i4++) {
+      const float4 e = E[i4];
+      energy = energy + e.x;
+      if (4 * i4 + 1 < G::NE) energy = energy + e.y;
+      if (4 * i4 + 2 < G::NE) energy = energy + e.z;
+      if (4 * i4 + 3 < G::NE) energy = energy + e.w;
+    }
+    return energy;
+  };
+  float energy = 0.0f;
+  if (EFIRST) {
+    stage_norms();
+    wave_lds_fence();
+    energy = sum_norms();
+    asm volatile("" : "+v"(energy));                       // the sum is complete here, before the norms are overwritten
+    wave_lds_fence();
+  }
   // ---- window (zero padded) and the energy window's norms into LDS ----
   for (int q = r; q < G::FRONT; q += 16) W[q] = mk(0, 0);
   for (int q = G::FRONT + G::NL + r; q < G::WPAD; q += 16) W[q] = mk(0, 0);
@@ -188,27 +225,9 @@ __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 
     const int q = r + 16 * i;
     if (q < G::NL) W[G::FRONT + q] = in.w[i];
   }
-  {
-    float *ef = reinterpret_cast<float *>(E);
-#pragma unroll
-    for (int q = 0; q < G::NEQ; q++) {
-      const int i = r + 16 * q;
-      if (i < G::NE) ef[i] = norm2(in.e[q]);
-    }
-  }
+  if (!EFIRST) stage_norms();
   wave_lds_fence();
-  // ---- energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order (:925-928).  Every
-  //      lane of the row adds the norms up sequentially (same address in a row -> broadcast reads);
-  //      a DPP row-shift chain does the same but issues ~5x slower per step. ----
-  float energy = 0.0f;
-#pragma unroll
-  for (int i4 = 0; i4 < (G::NE + 3) / 4; i4++) {
-    const float4 e = E[i4];
-    energy = energy + e.x;
-    if (4 * i4 + 1 < G::NE) energy = energy + e.y;
-    if (4 * i4 + 2 < G::NE) energy = energy + e.z;
-    if (4 * i4 + 3 < G::NE) energy = energy + e.w;
-  }
+  if (!EFIRST) energy = sum_norms();
 
   // ---- correlation: 16 non-zero taps, k descending = j ascending ----
   float bestP = 0.0f;
@@ -252,8 +271,10 @@ __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 
   }
   wave_lds_fence();
 
+  M_out = bestT;
+  energy_out = energy;
   // ---- record: corr[M-H .. M+H] (zeros outside [0,NL)), then {M, energy} ----
-  if (in.live) {
+  if (REC && in.live) {
     const int M = bestT;
     for (int s = r; s <= G::NS; s += 16) {
       cx v = mk(0, 0);
@@ -279,8 +300,9 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
   typedef CorrGeom<SPS> G;
   // one LDS row per burst, owned by the 16 lanes of its DPP row; no workgroup barrier anywhere.
   // The row first holds the zero-padded window, later (same storage) the correlation.
-  __shared__ cx rows[16][G::WPAD];
-  __shared__ float4 enr[16][(G::NE + 3) / 4];              // |x[i]|^2, i < 20*sps, per burst
+  // The row first holds |x[i]|^2 of the energy window, then the zero-padded window, then the correlation.
+  static_assert(8 * G::WPAD >= 4 * G::NE, "the energy norms are staged in the row itself");
+  __shared__ __attribute__((aligned(16))) cx rows[16][G::WPAD];
   (void)T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane >> 4, r = lane & 15;
@@ -295,7 +317,11 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
   for (int i = 0; i < TRX_CORR_ROUNDS; i++)
     corr_issue<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
 #pragma unroll
-  for (int i = 0; i < TRX_CORR_ROUNDS; i++) corr_round<SPS>(in[i], rows[slot], enr[slot], lane, r, tap, rec, Bpad);
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
+    int M;
+    float energy;
+    corr_round<SPS, true, true>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1130,7 +1156,9 @@ __device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *
     } else if (m < nsoft) {
       const cx rv = rev[SPS * m];
       const float re = rv.r * y.r - rv.i * y.i;            // real part of GMSKReverseRotate (:259-262)
-      float sv = (float)(0.5 * (double)(re + 1.0F));       // vectorSlicer (:513-515)
+      // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)).  re + 1.0F is 0 or at least 2^-24 in
+      // magnitude, so halving it is exact in float as well and the double round trip can go.
+      float sv = (re + 1.0F) * 0.5F;
       if (sv > 1.0f) sv = 1.0f;
       if (sv < 0.0f) sv = 0.0f;
       sb[m] = sv;
@@ -1598,6 +1626,736 @@ __global__ __launch_bounds__(256) void k_pack_i16(const cx *__restrict__ in, lon
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_normal_fused: the whole normal-burst leg of pullRadioVector (energyDetect, analyzeTrafficBurst,
+//   demodulateBurst) for one burst per LPB lanes (LPB = 64: one wave per burst, LPB = 32: two bursts
+//   per wave), reading the burst from HBM exactly once and writing only the results.
+//
+//   The serial part of the reference -- peakDetect's 9-step early/late bisection (:684-701) -- is
+//   turned into 2 (LPB = 64) or 3 (LPB = 32) parallel "super-steps": the bisection is a binary
+//   decision tree whose node at depth d is reached with a known index offset, so the lanes evaluate
+//   interpolatePoint at the early and late points of EVERY node of the next NLV levels at once
+//   (2*(2^NLV - 1) points), and the decisions are then replayed along the one path the reference
+//   takes.  The last super-step also evaluates the 2^NLV possible final points.  Each point is the
+//   reference's own 21-term sum in the reference's order, so the chosen path and every value on it
+//   are bit-identical; the points off the path are discarded.
+//
+//   Per-burst scratch (window, correlation, norms, ...) lives in the burst's LDS slot and is
+//   overlaid by the demodulator's staging area once detection is done.  No workgroup barrier.
+// ---------------------------------------------------------------------------------------------
+#ifndef TRX_FUSED_WAVES
+#define TRX_FUSED_WAVES 4
+#endif
+
+template <int SPS, int LPB>
+struct FusedGeom {
+  typedef DemodGeom<SPS, 148> D;
+  static constexpr int NL = 36 * SPS;                      // correlation lags
+  static constexpr int NE = 20 * SPS;                      // energyDetect window
+  static constexpr int FRONT = 8 * SPS;                    // zero pad in front of the window
+  static constexpr int CG = (NL + LPB - 1) / LPB;          // lags per lane: t = SPS*CG*g + p + SPS*i
+  static constexpr int NSV = CG + 15;                      // window words a lane touches
+  static constexpr int GA = (NL + SPS * CG - 1) / (SPS * CG);   // lane groups that own real lags
+  static constexpr int WLEN = (GA * SPS * CG + 15 * SPS + 3) & ~3;
+  static constexpr int PADC = 24;                          // zero pad either side of the correlation
+  static constexpr int CLEN = NL + 2 * PADC;
+  static constexpr int NV = 2 * (3 * SPS + 1);             // valley terms
+  // scratch offsets in complex units (all even => 16-byte aligned)
+  static constexpr int O_W = 0;
+  static constexpr int O_C = O_W + WLEN;
+  static constexpr int O_E = O_C + CLEN;
+  static constexpr int O_LOC = O_E + NE / 2;
+  static constexpr int O_V = O_LOC + 26;
+  static constexpr int SCR = O_V + ((NV / 2 + 1) & ~1);
+  static constexpr int REG = ((D::U > SCR ? D::U : SCR) + 1) & ~1;
+  static constexpr int NLD = (157 * SPS / 2 + LPB - 1) / LPB;     // 16-byte sample pairs per lane
+  static constexpr int OPL = (148 + LPB - 1) / LPB;               // soft bits per lane: m = OPL*hl + i
+  static constexpr int BPW = 64 / LPB;                     // bursts per wave
+};
+
+// One super-step of the speculative bisection.  State on entry: early = M-1 + e/512, `active`.  Lane hl
+// evaluates node hp's early (add 0) or late (add 2) point, or (FIN) one of the 2^NLV candidate final
+// points (add 1); the node's index offset, in units of this super-step's smallest increment, and `add`
+// are lane constants that come from a table (FusedRel).
+template <int NLV, bool FIN>
+struct FusedRel {
+  static constexpr int NEV = 2 * ((1 << NLV) - 1);
+  static constexpr int NTOT = NEV + (FIN ? (1 << NLV) : 0);
+  int v[64];                                               // (offset << 2) | add; lanes past NTOT: the root's early point
+  constexpr FusedRel() : v() {
+    for (int hl = 0; hl < 64; hl++) {
+      int hp = 1, add = 0;
+      if (hl < NEV) { hp = (hl >> 1) + 1; add = 2 * (hl & 1); }
+      else if (FIN && hl < NTOT) { hp = (1 << NLV) + (hl - NEV); add = 1; }
+      int l = 0;
+      while ((hp >> (l + 1)) != 0) l++;                    // depth of the node below the super-step's root
+      int r = 0;
+      for (int k = 0; k < l; k++) r += (((hp >> (l - 1 - k)) & 1) ? 1 : -1) * (1 << (NLV - 1 - k));
+      v[hl] = r * 4 + add;
+    }
+  }
+};
+__device__ __constant__ const FusedRel<5, false> kFusedRel5;
+__device__ __constant__ const FusedRel<4, true> kFusedRel4F;
+__device__ __constant__ const FusedRel<4, false> kFusedRel4;
+__device__ __constant__ const FusedRel<1, true> kFusedRel1F;
+__device__ __constant__ const FusedRel<3, false> kFusedRel3;
+
+__device__ __forceinline__ void fused_row(const TrxTables *__restrict__ T, int e_lane, float (&s)[24]) {
+  const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[e_lane & 511]);   // frac(ix)*512
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const float4 v = row[q];
+    s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
+  }
+}
+
+// interpolatePoint (:650-657) at early + add: tap 0 sits at loc[floor(ix) - 10 - (M - 12)]
+__device__ __forceinline__ cx fused_point(const cx *loc, int e_lane, int add, const float (&s)[24]) {
+  const int base = 1 + (e_lane >> 9) + add;
+  cx pt = mk(0, 0);
+#pragma unroll
+  for (int j0 = 0; j0 < 21; j0 += 7) {                     // (chunked: keeps the LDS reads from piling up in VGPRs)
+    cx lv[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) lv[j] = loc[base + j0 + j];
+#pragma unroll
+    for (int j = 0; j < 7; j++) pt = cadd(pt, cmulr(lv[j], s[j0 + j]));   // j ascending
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return pt;
+}
+
+// Replays the NLV early/late decisions (:690-697) along the path the reference takes, from the lanes'
+// powers: even lane 2(h-1) holds node h's early point, its odd neighbour the late one.  inc0: first
+// increment (1/512 units).  FIN: `peak` = the candidate final point of the leaf reached.
+template <int LPB, int NLV, bool FIN>
+__device__ __forceinline__ void fused_decide(cx pt, int lane, int inc0, int &e, bool &active, cx &peak) {
+  const float pw = norm2(pt);
+  const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pw), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+  const unsigned long long mu = __builtin_amdgcn_ballot_w64(pw < other);   // even lanes: early < late
+  const unsigned long long md = __builtin_amdgcn_ballot_w64(pw > other);
+  typedef typename std::conditional<LPB == 64, unsigned long long, unsigned>::type mask_t;
+  const int sh = lane & (64 - LPB);                        // first lane of this burst
+  const mask_t bu = (mask_t)(mu >> sh), bd = (mask_t)(md >> sh);
+  int hq = 1;
+#pragma unroll
+  for (int k = 0; k < NLV; k++) {
+    const int ix = 2 * (hq - 1);
+    const bool up = (bu >> ix) & 1, dn = (bd >> ix) & 1;
+    const int step = inc0 >> k;
+    if (active) {
+      if (up) { e += step; hq = 2 * hq + 1; }
+      else if (dn) { e -= step; hq = 2 * hq; }
+      else active = false;                                 // "else break" (:695): e stays put from here on
+    }
+  }
+  if (FIN) {
+    const int src = (lane & ~(LPB - 1)) + 2 * ((1 << NLV) - 1) + ((hq - (1 << NLV)) & ((1 << NLV) - 1));
+    peak = mk(__shfl(pt.r, src, 64), __shfl(pt.i, src, 64));
+  }
+}
+
+// analyzeTrafficBurst after peakDetect (:959-1000, k_tsc_peak's arithmetic) plus energyDetect's decision,
+// for one burst per LPB lanes: every lane of the burst gets the same results.  State from the
+// bisection: peak index = M + e/512.  pw_at(lag) = |corr[lag]|^2, or 0 outside [0, n).  V: NV floats of
+// the burst's scratch (16-byte aligned).
+template <int SPS, int LPB, typename PWF>
+__device__ __forceinline__ void fused_tail(PWF pw_at, float *V, int hl, int M, int e, cx peak, bool good, float energy,
+                                           cx gain_inv, float mid_toa, float detect_thresh, float energy_thresh,
+                                           cx &amp, float &toa, bool &detected, bool &energy_ok) {
+  constexpr int NL = 36 * SPS, NE = 20 * SPS, NV = 2 * (3 * SPS + 1);
+  const float early = (float)(M - 1) + (float)e * 0.001953125f;   // exact: the reference's +-2^-k steps are exact too
+  toa = early + 1.0f;                                      // :699
+  amp = peak;
+  detected = false;
+  energy_ok = good && (energy_thresh < 0.0f || energy / (float)(unsigned)NE > energy_thresh * energy_thresh);
+  const bool sane = !(toa < 0.0f) && !(toa > (float)NL) && good;
+  const int pk = sane ? (int)rintf(toa) : 0;
+  // valley terms in the reference's order (:971-980): i = 2sps..5sps, (peak - i) then (peak + i);
+  // terms the reference skips (index < 0 or >= n) come back as +0: adding +0 to a sum of
+  // non-negative terms changes nothing, and numRms is counted arithmetically below.
+#pragma unroll
+  for (int t0 = 0; t0 < NV; t0 += LPB) {
+    const int tt = t0 + hl;
+    if (tt < NV) {
+      const int i = 2 * SPS + (tt >> 1);
+      V[tt] = pw_at((tt & 1) ? pk + i : pk - i);
+    }
+  }
+  wave_lds_fence();
+  if (sane) {
+    float valley = 0.0f;
+    const float4 *V4 = reinterpret_cast<const float4 *>(V);
+#pragma unroll
+    for (int q = 0; q < (NV + 3) / 4; q++) {
+      const float4 t = V4[q];
+      valley = valley + t.x;
+      if (4 * q + 1 < NV) valley = valley + t.y;
+      if (4 * q + 2 < NV) valley = valley + t.z;
+      if (4 * q + 3 < NV) valley = valley + t.w;
+    }
+    int nlo = (pk < 5 * SPS ? pk : 5 * SPS) - 2 * SPS + 1;           // i <= pk
+    int nhi = (NL - 1 - pk < 5 * SPS ? NL - 1 - pk : 5 * SPS) - 2 * SPS + 1;   // pk + i <= NL-1
+    nlo = nlo < 0 ? 0 : nlo; nhi = nhi < 0 ? 0 : nhi;
+    const int numRms = nlo + nhi;
+    if (numRms < 2) {
+      amp = mk(0, 0);
+    } else {
+      const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);   // :989
+      const float peakToMean = sqrtf(norm2(amp)) / RMS;
+      amp = cmul(amp, gain_inv);                           // amp / gain = amp * gain.inv() (Complex.h:85), :997
+      toa = toa - mid_toa;                                 // :998
+      toa = toa - (float)((66 - 56) * SPS);                // :1000
+      detected = peakToMean > detect_thresh;
+    }
+  } else {
+    amp = mk(0, 0);                                        // "bogus result" (:964-968); TOA left as is
+  }
+  if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
+}
+
+// demodulateBurst (k_demod's arithmetic) for one detected burst whose samples sit in registers: pair
+// q = hl + LPB*i of v[] holds samples 2q, 2q+1.  P: the burst's LDS staging area (DemodGeom<SPS,148>::U
+// entries); whatever it held before is dead.  LPB lanes per burst; lane hl writes soft bits OPL*hl .. +OPL-1.
+// staged(): called once the samples are in LDS and v[] is dead (k_normal_quad starts the next
+// burst's loads there, into the same registers).
+// tp_pre / rv_pre (optional): the 21 delay-filter taps for this TOA and the lane's OPL reverse-rotation
+// values, when the caller has fetched them ahead of time.
+template <int SPS, int LPB, typename HOOK>
+__device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx *P,
+                                            const float4 (&v)[FusedGeom<SPS, LPB>::NLD], int N, cx amp, float toa, int hl,
+                                            float *sb, uint8_t *hbp, int nsoft, HOOK staged,
+                                            const float *tp_pre = nullptr, const cx *rv_pre = nullptr) {
+  typedef FusedGeom<SPS, LPB> G;
+  typedef typename G::D D;
+  const bool lane_owner = G::OPL * hl < 148;
+  const int m0 = G::OPL * (lane_owner ? hl : 0);
+  wave_lds_fence();                                        // scratch is dead: the staging area takes its place
+  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066)
+  const float delay = -toa;
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  const bool filt = fabs((double)frac) > 1e-2;
+  float tp[21];
+  if (tp_pre) {
+#pragma unroll
+    for (int j = 0; j < 21; j++) tp[j] = tp_pre[j];
+  } else {
+    const float f512 = frac * 512.0f;
+    int f = (int)f512;
+    if ((float)f == f512) {                                // on the 1/512 grid (always, after peakDetect)
+      if (LPB == 64) {                                     // wave-uniform: the row comes in by s_load
+        f = __builtin_amdgcn_readfirstlane(f);
+#pragma unroll
+        for (int j = 0; j < 21; j++) tp[j] = T->sinc_grid[f & 511][j];
+      } else {
+        const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const float4 r4 = row[q];
+          if (4 * q < 21) tp[4 * q] = r4.x;
+          if (4 * q + 1 < 21) tp[4 * q + 1] = r4.y;
+          if (4 * q + 2 < 21) tp[4 * q + 2] = r4.z;
+          if (4 * q + 3 < 21) tp[4 * q + 3] = r4.w;
+        }
+      }
+    } else {                                               // (never after peakDetect; kept for completeness)
+      const float tv = dev_sinc(T->sinT, TRX_PI_F * ((float)(hl - 10) - frac));   // :588, tap hl in lane hl
+      const int first = (threadIdx.x & 63) & ~(LPB - 1);
+#pragma unroll
+      for (int j = 0; j < 21; j++) tp[j] = __shfl(tv, first + j, 64);
+    }
+  }
+  const int lo = io + D::C, hi = N + io + D::C;            // samples occupy positions [lo, hi)
+  for (int u = hl; u < lo && u < D::U; u += LPB) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
+  for (int u = (hi > 0 ? hi : 0) + hl; u < D::U; u += LPB) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
+  if (lo >= 0 && (N & 1) == 0 && (2 * LPB) % SPS == 0) {
+    // common case: nothing falls off the front, pairs are whole.  Pair q = hl + LPB*i sits at positions
+    // u = 2q + lo, u + 1; successive i move both by 2*LPB positions = 2*LPB/SPS entries of the same phase.
+    const int ua = 2 * hl + lo, ub = ua + 1;
+    cx *pa = P + (ua % SPS) * D::QLEN + ua / SPS;
+    cx *pb = P + (ub % SPS) * D::QLEN + ub / SPS;
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      if (2 * (hl + LPB * i) < N) {
+        if (ua + 2 * LPB * i < D::U) pa[i * (2 * LPB / SPS)] = cmul(mk(v[i].x, v[i].y), inv);   // scaleVector (:713-723)
+        if (ub + 2 * LPB * i < D::U) pb[i * (2 * LPB / SPS)] = cmul(mk(v[i].z, v[i].w), inv);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      const int n0 = 2 * (hl + LPB * i);
+      const int u0 = n0 + lo, u1 = u0 + 1;
+      if (n0 < N && u0 >= 0 && u0 < D::U) P[(u0 % SPS) * D::QLEN + u0 / SPS] = cmul(mk(v[i].x, v[i].y), inv);
+      if (n0 + 1 < N && u1 >= 0 && u1 < D::U) P[(u1 % SPS) * D::QLEN + u1 / SPS] = cmul(mk(v[i].z, v[i].w), inv);
+    }
+  }
+  wave_lds_fence();
+  staged();
+
+  const cx *rev = T->rev;
+  cx y[G::OPL];
+#pragma unroll
+  for (int i = 0; i < G::OPL; i++) y[i] = mk(0, 0);
+  if (filt) {
+    // convolve(...,NO_DELAY), 21 real taps, j ascending (:590).  Output m0+i, tap j reads position
+    // SPS*(m0+i) + c0 with c0 = 10 - j + C: the lane's OPL outputs share words, so walk the distinct
+    // words c = c0 + SPS*i downwards (= j upwards for every output) and feed each to its outputs.
+    constexpr int CMAX = 10 + D::C + SPS * (G::OPL - 1), CMIN = D::C - 10, NWD = CMAX - CMIN + 1;
+#pragma unroll
+    for (int w0 = 0; w0 < NWD; w0 += 8) {
+      cx wd[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int c = CMAX - (w0 + q);
+        if (c >= CMIN) wd[q] = P[(c % SPS) * D::QLEN + c / SPS + m0];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int c = CMAX - (w0 + q);
+#pragma unroll
+        for (int i = 0; i < G::OPL; i++) {
+          const int j = 10 + D::C + SPS * i - c;
+          if (c >= CMIN && j >= 0 && j <= 20) y[i] = cadd(y[i], cmulr(wd[q], tp[j]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::OPL; i++) y[i] = P[(D::C % SPS) * D::QLEN + D::C / SPS + m0 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < G::OPL; i++) {
+    const int m = m0 + i;
+    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
+    if (lane_owner && m < nsoft) {
+      const cx yy = (t >= 0 && t < N) ? y[i] : mk(0, 0);
+      const cx rv = rv_pre ? rv_pre[i] : rev[SPS * m];
+      const float re = rv.r * yy.r - rv.i * yy.i;          // real part of GMSKReverseRotate (:259-262)
+      // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)).  re + 1.0F is 0 or at least 2^-24 in
+      // magnitude, so halving it is exact in float as well and the double round trip can go.
+      float sv = (re + 1.0F) * 0.5F;
+      if (sv > 1.0f) sv = 1.0f;
+      if (sv < 0.0f) sv = 0.0f;
+      sb[m] = sv;
+      if (hbp) hbp[m] = sv > 0.5F;                         // SoftVector::bit (BitVector.h:415-420)
+    }
+  }
+}
+
+template <int SPS, int LPB>
+__global__ __launch_bounds__(64 * TRX_FUSED_WAVES) void k_normal_fused(
+    const TrxTables *__restrict__ T, const cx *__restrict__ samples, const int32_t *__restrict__ offset,
+    const int32_t *__restrict__ length, int B, TapArg taps, cx gain_inv, float mid_toa, float detect_thresh,
+    float energy_thresh, uint8_t *__restrict__ flags, cx *__restrict__ amp_out, float *__restrict__ toa_out,
+    float *__restrict__ avgpwr_out, float *__restrict__ soft, uint8_t *__restrict__ hard, int nsoft, int stride) {
+  typedef FusedGeom<SPS, LPB> G;
+  typedef typename G::D D;
+  __shared__ __attribute__((aligned(16))) cx region[TRX_FUSED_WAVES * G::BPW][G::REG];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hb = lane / LPB, hl = lane % LPB;
+  int b = (blockIdx.x * TRX_FUSED_WAVES + wave) * G::BPW + hb;
+  if (LPB == 64) b = __builtin_amdgcn_readfirstlane(b);
+  cx *R = region[wave * G::BPW + hb];
+  cx *W = R + G::O_W, *Cc = R + G::O_C, *loc = R + G::O_LOC;
+  float *E = reinterpret_cast<float *>(R + G::O_E);
+  float *V = reinterpret_cast<float *>(R + G::O_V);
+
+  const bool live = b < B;
+  int off = 0, N = 0;
+  if (live) { off = offset[b]; N = length[b]; }
+  const bool good = live && (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
+  const cx *xb = samples + (good ? off : 0);
+
+  // ---- the burst's only trip through HBM: pair q = hl + LPB*i holds samples 2q, 2q+1 ----
+  float4 v[G::NLD];
+  {
+    const bool wide = (off & 1) == 0;
+    const float4 *xv = reinterpret_cast<const float4 *>(xb);
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      const int q = hl + LPB * i, n0 = 2 * q;
+      float4 t = make_float4(0, 0, 0, 0);
+      if (good && n0 + 1 < N) {
+        if (wide) t = xv[q];
+        else { const cx a = xb[n0], c = xb[n0 + 1]; t = make_float4(a.r, a.i, c.r, c.i); }
+      } else if (good && n0 < N) {
+        const cx a = xb[n0]; t = make_float4(a.r, a.i, 0, 0);
+      }
+      v[i] = t;
+    }
+  }
+  cx tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
+
+  // ---- zero-padded correlation window w = burst[56*sps, 92*sps) and |x|^2 of the energy window ----
+  for (int q = hl; q < G::FRONT; q += LPB) W[q] = mk(0, 0);
+  for (int q = G::FRONT + G::NL + hl; q < G::WLEN; q += LPB) W[q] = mk(0, 0);
+  for (int q = hl; q < G::PADC; q += LPB) { Cc[q] = mk(0, 0); Cc[G::PADC + G::NL + q] = mk(0, 0); }
+#pragma unroll
+  for (int i = 0; i < G::NLD; i++) {
+    constexpr int W0 = 56 * SPS, W1 = 92 * SPS;            // both even: a pair is in or out as a whole
+    const int n0 = 2 * (hl + LPB * i);
+    if (2 * LPB * i < W1 && 2 * LPB * (i + 1) > W0) {
+      if (n0 >= W0 && n0 < W1) *reinterpret_cast<float4 *>(W + G::FRONT + n0 - W0) = v[i];
+    }
+    if (2 * LPB * i < G::NE) {
+      if (n0 < G::NE)
+        *reinterpret_cast<float2 *>(E + n0) = make_float2(norm2(mk(v[i].x, v[i].y)), norm2(mk(v[i].z, v[i].w)));
+    }
+  }
+  wave_lds_fence();
+
+  // ---- energyDetect: energy += norm2(x[i]) strictly in order (:925-928); broadcast reads ----
+  float energy = 0.0f;
+  {
+    // (in chunks, each pinned: otherwise hipcc keeps all NE norms -- 80 VGPRs -- live across the correlation)
+    const float4 *E4 = reinterpret_cast<const float4 *>(E);
+#pragma unroll
+    for (int c4 = 0; c4 < G::NE / 4; c4 += 4) {
+      float4 ev[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) ev[q] = (c4 + q < G::NE / 4) ? E4[c4 + q] : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (c4 + q < G::NE / 4) {
+          energy = energy + ev[q].x; energy = energy + ev[q].y; energy = energy + ev[q].z; energy = energy + ev[q].w;
+        }
+      }
+      asm volatile("" : "+v"(energy));                     // pin the chain here (else it is sunk to its use, norms and all)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- correlation with the 16 non-zero taps, k descending = j ascending (k_tsc_corr's arithmetic) ----
+  float bestP = 0.0f;
+  int bestT = -1;
+  {
+    const int g = hl / SPS, p = hl % SPS;
+    const bool owner = g < G::GA;
+    const int base = SPS * G::CG * (owner ? g : 0) + p;
+    cx sv[G::NSV];
+#pragma unroll
+    for (int u = 0; u < G::NSV; u++) sv[u] = W[base + SPS * u];
+#pragma unroll
+    for (int i = 0; i < G::CG; i++) {
+      cx acc = mk(0, 0);
+#pragma unroll
+      for (int k = 15; k >= 0; k--) acc = cadd(acc, cmul(sv[i + k], tap[k]));
+      const int t = base + SPS * i;
+      if (owner && t < G::NL) {
+        Cc[G::PADC + t] = acc;
+        const float pw = norm2(acc);
+        if (pw > bestP) { bestP = pw; bestT = t; }         // strict >, first maximum (:675)
+      }
+    }
+  }
+  // the first super-step's points do not depend on the data (early starts at M-1): fetch its sinc rows
+  // now, under the argmax reduction
+  const int relA = (LPB == 64) ? kFusedRel5.v[hl] : kFusedRel4.v[hl];
+  const int eA = (relA >> 2) * ((LPB == 64) ? 16 : 32);
+  float rowA[24];
+  fused_row(T, eA, rowA);
+#pragma unroll
+  for (int m = 1; m < LPB; m <<= 1) {                      // larger power wins, equal power -> smaller lag
+    const float oP = __shfl_xor(bestP, m, 64);
+    const int oT = __shfl_xor(bestT, m, 64);
+    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
+    if (take) { bestP = oP; bestT = oT; }
+  }
+  const int M = bestT;
+  wave_lds_fence();
+
+  // ---- lags M-12 .. M+11 as interpolatePoint sees them (never the last sample, :646) ----
+  if (hl < 26) {
+    const int lag = M - 12 + hl;
+    loc[hl] = (hl >= 24 || lag > G::NL - 2) ? mk(0, 0) : Cc[G::PADC + lag];
+  }
+  wave_lds_fence();
+
+  // ---- peakDetect's bisection, speculated (see the header) ----
+  int e = 0;                                               // early = M-1 + e/512
+  bool active = true;
+  cx peak = mk(0, 0);
+  if constexpr (LPB == 64) {
+    const cx ptA = fused_point(loc, eA, relA & 3, rowA);                    // levels 1-5: +-256 .. +-16
+    fused_decide<LPB, 5, false>(ptA, lane, 256, e, active, peak);
+    const int relB = kFusedRel4F.v[hl], eB = e + (relB >> 2);               // levels 6-9: +-8 .. +-1, and the finals
+    float rowB[24];
+    fused_row(T, eB, rowB);
+    const cx ptB = fused_point(loc, eB, relB & 3, rowB);
+    fused_decide<LPB, 4, true>(ptB, lane, 8, e, active, peak);
+  } else {
+    const cx ptA = fused_point(loc, eA, relA & 3, rowA);                    // levels 1-4: +-256 .. +-32
+    fused_decide<LPB, 4, false>(ptA, lane, 256, e, active, peak);
+    const int relB = kFusedRel4.v[hl], eB = e + 2 * (relB >> 2);            // levels 5-8: +-16 .. +-2
+    float rowB[24];
+    fused_row(T, eB, rowB);
+    const cx ptB = fused_point(loc, eB, relB & 3, rowB);
+    fused_decide<LPB, 4, false>(ptB, lane, 16, e, active, peak);
+    const int relC = kFusedRel1F.v[hl], eC = e + (relC >> 2);               // level 9: +-1, and the finals
+    float rowC[24];
+    fused_row(T, eC, rowC);
+    const cx ptC = fused_point(loc, eC, relC & 3, rowC);
+    fused_decide<LPB, 1, true>(ptC, lane, 1, e, active, peak);
+  }
+  if (!active) {
+    // the reference left its loop on equal powers (:695): the peak is interpolatePoint(early + 1)
+    // at the index where it stopped, which no lane has speculated.  Rare (e.g. an all-zero window).
+    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[e & 511]);
+    float s[24];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const float4 r4 = row[q];
+      s[4 * q] = r4.x; s[4 * q + 1] = r4.y; s[4 * q + 2] = r4.z; s[4 * q + 3] = r4.w;
+    }
+    const int base = 2 + (e >> 9);
+    cx pt = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(loc[base + j], s[j]));
+    peak = pt;
+  }
+  cx amp;
+  float toa;
+  bool detected, energy_ok;
+  fused_tail<SPS, LPB>([&](int lag) { return norm2(Cc[G::PADC + lag]); }, V, hl, M, e, peak, good, energy, gain_inv, mid_toa,
+                       detect_thresh, energy_thresh, amp, toa, detected, energy_ok);
+
+  if (live && hl == 0) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+  if (nsoft <= 0 || !live) return;                         // (LPB = 32: a dead upper half has nothing to write)
+
+  // ---- demodulateBurst (k_demod's arithmetic) from the samples still in registers ----
+  float *sb = soft + (size_t)b * stride;
+  uint8_t *hbp = hard ? hard + (size_t)b * stride : nullptr;
+  const bool lane_owner = G::OPL * hl < 148;
+  const int m0 = G::OPL * (lane_owner ? hl : 0);
+  if (!detected) {
+#pragma unroll
+    for (int i = 0; i < G::OPL; i++) {
+      const int m = m0 + i;
+      if (lane_owner && m < nsoft) { sb[m] = 0.0f; if (hbp) hbp[m] = 0; }
+    }
+    return;
+  }
+  fused_demod<SPS, LPB>(T, R, v, N, amp, toa, hl, sb, hbp, nsoft, [] {});
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_normal_quad: the normal-burst leg in one kernel with FOUR bursts per wave.
+//   Phase 1 (16 lanes per burst, k_tsc_corr's code): window + energy loads, correlation, argmax; the
+//     correlation stays in the burst's LDS row.
+//   Phase 2 (16 lanes per burst): peakDetect's bisection speculated three levels at a time (14 of the
+//     16 lanes evaluate the early/late points of the next 7 tree nodes, fused_point/fused_decide),
+//     3 super-steps + the final point; then analyzeTrafficBurst's tail.  Per-burst results live in
+//     the registers of the burst's lanes.
+//   Phase 3 (the whole wave per burst, one burst after the other): demodulateBurst (fused_demod) with
+//     the next burst's samples already in flight.  Its staging area overlays the four dead rows.
+//   The uniform per-burst work is shared by four bursts and the correlation runs with every lane
+//   busy, which is what the wave-per-burst kernel above cannot do; the price is that the window and
+//   the energy samples are read twice (the second time from L2).  No workgroup barrier.
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+__global__ __launch_bounds__(256) void k_normal_quad(
+    const TrxTables *__restrict__ T, const cx *__restrict__ samples, const int32_t *__restrict__ offset,
+    const int32_t *__restrict__ length, int B, TapArg taps, cx gain_inv, float mid_toa, float detect_thresh,
+    float energy_thresh, uint8_t *__restrict__ flags, cx *__restrict__ amp_out, float *__restrict__ toa_out,
+    float *__restrict__ avgpwr_out, float *__restrict__ soft, uint8_t *__restrict__ hard, int nsoft, int stride) {
+  typedef CorrGeom<SPS> G;
+  typedef FusedGeom<SPS, 64> F;
+  typedef typename F::D D;
+  static_assert(G::WPAD - G::NL >= 26 + F::NV / 2 + 1, "row has no room for the bisection scratch");
+  static_assert(4 * G::WPAD >= D::U, "four rows must hold the demodulator's staging area");
+  static_assert(8 * G::WPAD >= 4 * G::NE, "the energy norms are staged in the row itself");
+  __shared__ __attribute__((aligned(16))) cx rows[16][G::WPAD];
+  // sinc rows f = 0, 16, .., 496: all that the first two super-steps of the bisection can ask for
+  // (their nodes sit on multiples of 16/512), so only the last super-step and the final point gather from L2
+  __shared__ __attribute__((aligned(16))) float stab[32][24];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane >> 4, r = lane & 15;
+  const int slot = wave * 4 + row;
+  cx *W = rows[slot];
+  {
+    float tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int ix = threadIdx.x * 3 + k; tv[k] = T->sinc_grid[16 * (ix / 24)][ix % 24]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int ix = threadIdx.x * 3 + k; stab[ix / 24][ix % 24] = tv[k]; }
+  }
+
+  // ---- phase 1 ----
+  int M;
+  float energy;
+  CorrIn<SPS> in;
+  {
+    cx tap[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
+    corr_issue<SPS>(in, blockIdx.x * 16 + slot, B, r, samples, offset, length);
+    corr_round<SPS, false, true>(in, W, reinterpret_cast<float4 *>(W), lane, r, tap, nullptr, 0, M, energy);
+  }
+  const bool live = in.live, good = in.good;
+  const int b = in.b;
+  __syncthreads();                                         // the sinc rows of all four waves are in stab (the only barrier)
+
+  // ---- phase 2 ----
+  cx *loc = W + G::NL;                                     // lags M-12 .. M+11 as interpolatePoint sees them (:646)
+  float *V = reinterpret_cast<float *>(W + G::NL + 26);
+#pragma unroll
+  for (int j0 = 0; j0 < 26; j0 += 16) {
+    const int j = j0 + r;
+    if (j < 26) {
+      const int lag = M - 12 + j;
+      loc[j] = (j >= 24 || lag < 0 || lag > G::NL - 2) ? mk(0, 0) : W[lag];
+    }
+  }
+  wave_lds_fence();
+  int e = 0;                                               // early = M-1 + e/512
+  asm volatile("" : "+v"(e));                              // (opaque: keeps the first sinc-row fetch from being hoisted above phase 1)
+  bool active = true;
+  cx peak = mk(0, 0);
+  {
+    const int rel = kFusedRel3.v[r];
+#pragma unroll
+    for (int st = 0; st < 3; st++) {                       // increments 256,128,64 | 32,16,8 | 4,2,1
+      const int inc_last = 64 >> (3 * st);
+      const int el = e + (rel >> 2) * inc_last;
+      float srow[24];
+      if (st < 2) {                                        // nodes on multiples of 16/512: the LDS copy
+        const float4 *rw = reinterpret_cast<const float4 *>(stab[(el & 511) >> 4]);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const float4 t4 = rw[q];
+          srow[4 * q] = t4.x; srow[4 * q + 1] = t4.y; srow[4 * q + 2] = t4.z; srow[4 * q + 3] = t4.w;
+        }
+      } else {
+        fused_row(T, el, srow);
+      }
+      const cx pt = fused_point(loc, el, rel & 3, srow);
+      fused_decide<16, 3, false>(pt, lane, 4 * inc_last, e, active, peak);
+    }
+    // the loop ended (all nine steps, or the reference's `break` on equal powers): the peak is
+    // interpolatePoint(early + 1) at the index where it stopped (:699-700)
+    float srow[24];
+    fused_row(T, e, srow);
+    peak = fused_point(loc, e, 1, srow);
+  }
+  cx amp;
+  float toa;
+  bool detected, energy_ok;
+  fused_tail<SPS, 16>([&](int lag) { return (lag < 0 || lag >= G::NL) ? 0.0f : norm2(W[lag]); }, V, r, M, e, peak, good,
+                      energy, gain_inv, mid_toa, detect_thresh, energy_thresh, amp, toa, detected, energy_ok);
+  if (live && r == 0) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+  if (nsoft <= 0) return;
+
+  // ---- phase 3 ----
+  // delayVector's taps for each burst's TOA (fused_demod's arithmetic), fetched now by the burst's own
+  // lanes -- lane r holds taps r and r+16 -- so that phase 3 finds them in registers
+  float tap_lo, tap_hi;
+  {
+    const float delay = -toa;
+    const float frac = delay - (float)(int)floorf(delay);
+    const float f512 = frac * 512.0f;
+    const int f = (int)f512;
+    if ((float)f == f512) {                                // on the 1/512 grid (always, after peakDetect)
+      tap_lo = T->sinc_grid[f & 511][r];
+      tap_hi = T->sinc_grid[f & 511][16 + (r & 7)];
+    } else {
+      tap_lo = dev_sinc(T->sinT, TRX_PI_F * ((float)(r - 10) - frac));            // :588
+      tap_hi = dev_sinc(T->sinT, TRX_PI_F * ((float)(16 + (r & 7) - 10) - frac));
+    }
+  }
+  cx rvl[F::OPL];                                          // the lane's reverse-rotation values (same for every burst)
+#pragma unroll
+  for (int i = 0; i < F::OPL; i++) rvl[i] = T->rev[SPS * (F::OPL * (F::OPL * lane < 148 ? lane : 0) + i)];
+  wave_lds_fence();                                        // the rows are dead from here on
+  cx *P = rows[wave * 4];
+  const int b0 = blockIdx.x * 16 + wave * 4;
+  auto fetch = [&](int rr, int lane, float4 (&v)[F::NLD], int &N, bool &det) {
+    // per-burst scalars come from lane 16*rr; the samples: pair q = lane + 64*i holds samples 2q, 2q+1
+    det = __builtin_amdgcn_readlane((int)(detected && live), 16 * rr) != 0;
+    N = __builtin_amdgcn_readlane(in.good ? length[in.live ? b : 0] : 0, 16 * rr);
+    const int off = __builtin_amdgcn_readlane(in.good ? offset[in.live ? b : 0] : 0, 16 * rr);
+    const cx *xb = samples + off;
+    const bool wide = (off & 1) == 0;
+    const float4 *xv = reinterpret_cast<const float4 *>(xb);
+#pragma unroll
+    for (int i = 0; i < F::NLD; i++) {
+      const int q = lane + 64 * i, n0 = 2 * q;
+      float4 t = make_float4(0, 0, 0, 0);
+      if (det && n0 + 1 < N) {
+        if (wide) t = xv[q];
+        else { const cx a = xb[n0], c = xb[n0 + 1]; t = make_float4(a.r, a.i, c.r, c.i); }
+      } else if (det && n0 < N) {
+        const cx a = xb[n0]; t = make_float4(a.r, a.i, 0, 0);
+      }
+      v[i] = t;
+    }
+  };
+  float4 v[F::NLD];
+  int N;
+  bool det;
+  fetch(0, lane, v, N, det);
+#pragma unroll 1
+  for (int rr = 0; rr < 4; rr++) {
+    // (opaque copy of the lane id: otherwise every per-lane address of the loop body is hoisted out of
+    //  the loop and parked in VGPRs across phases -- 30 registers and spills)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    // the next burst's samples are requested before this one is touched (second register set)
+    float4 vn[F::NLD];
+    int Nn = 0;
+    bool detn = false;
+    if (rr < 3) fetch(rr + 1, ln, vn, Nn, detn);
+    const int bb = b0 + rr;
+    if (bb < B) {
+      float *sb = soft + (size_t)bb * stride;
+      uint8_t *hbp = hard ? hard + (size_t)bb * stride : nullptr;
+      if (det) {
+        const cx a = mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(amp.r), 16 * rr)),
+                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(amp.i), 16 * rr)));
+        const float ta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(toa), 16 * rr));
+        float tp[21];
+#pragma unroll
+        for (int j = 0; j < 21; j++)
+          tp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 16 ? tap_lo : tap_hi), 16 * rr + (j & 15)));
+        fused_demod<SPS, 64>(T, P, v, N, a, ta, ln, sb, hbp, nsoft, [] {}, tp, rvl);
+        wave_lds_fence();                                  // staging reads done before the next burst overwrites it
+      } else {
+        for (int m = ln; m < nsoft; m += 64) { sb[m] = 0.0f; if (hbp) hbp[m] = 0; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < F::NLD; i++) v[i] = vn[i];
+    N = Nn;
+    det = detn;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1640,6 +2398,61 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
     case 4: launch_tsc_detect<4>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+template <int S, int LPB>
+static void launch_normal_fused(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
+                                const int32_t *off, const int32_t *len, int B, int tsc, float detect_thresh,
+                                float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                                float *soft, uint8_t *hard, int nsoft, int stride) {
+  TapArg ta;
+  for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
+  // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
+  const trx_c32 g = hT->mid_gain[tsc];
+  const float n = g.i * g.i + g.r * g.r;
+  trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
+  if (LPB == 16) {
+    k_normal_quad<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc],
+                                                                detect_thresh, energy_thresh, flags, amp, toa, avgpwr,
+                                                                soft, hard, nsoft, stride);
+  } else {
+    constexpr int L = LPB == 16 ? 64 : LPB;
+    constexpr int per_wg = TRX_FUSED_WAVES * (64 / L);
+    k_normal_fused<S, L><<<dim3((B + per_wg - 1) / per_wg), dim3(64 * TRX_FUSED_WAVES), 0, st>>>(
+        dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft,
+        hard, nsoft, stride);
+  }
+}
+
+hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst, const TrxTables *dT, const TrxTables *hT,
+                                   const trx_c32 *samples, const int32_t *off, const int32_t *len, int B, int tsc,
+                                   float detect_thresh, float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa,
+                                   float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
+                                   TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (nsoft > 148 || (lanes_per_burst != 64 && lanes_per_burst != 32 && lanes_per_burst != 16)) return hipErrorInvalidValue;
+  if (prof) prof->begin(TRXSIG_K_NORMAL_FUSED, st);
+#define TRX_FUSED_CASE(S)                                                                                              \
+  case S:                                                                                                              \
+    if (lanes_per_burst == 64)                                                                                         \
+      launch_normal_fused<S, 64>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
+                                 avgpwr, soft, hard, nsoft, stride);                                                   \
+    else if (lanes_per_burst == 16)                                                                                    \
+      launch_normal_fused<S, 16>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
+                                 avgpwr, soft, hard, nsoft, stride);                                                   \
+    else                                                                                                               \
+      launch_normal_fused<S, 32>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
+                                 avgpwr, soft, hard, nsoft, stride);                                                   \
+    break;
+  switch (sps) {
+    TRX_FUSED_CASE(1)
+    TRX_FUSED_CASE(2)
+    TRX_FUSED_CASE(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRX_FUSED_CASE
+  if (prof) prof->end(TRXSIG_K_NORMAL_FUSED, st);
   return hipGetLastError();
 }
 

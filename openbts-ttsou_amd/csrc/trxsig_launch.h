@@ -24,6 +24,13 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
                                  int variant /* 0: lane-per-burst peak kernel, 1: quad-per-burst */,
                                  TrxProfiler *prof);
 
+// the whole normal-burst leg in one kernel (k_normal_fused); lanes_per_burst = 64 or 32, nsoft <= 148
+hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst, const TrxTables *dT, const TrxTables *hT,
+                                   const trx_c32 *samples, const int32_t *off, const int32_t *len, int B, int tsc,
+                                   float detect_thresh, float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa,
+                                   float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
+                                   TrxProfiler *prof);
+
 // RACH detect: ws = workspace of trx_rach_rec_floats(sps) * Bpad floats
 int trx_rach_rec_floats(int sps);
 hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
