@@ -84,15 +84,20 @@ def cpu_baseline(x_host, off, length, sps, tsc, target_seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--preheat-ms", type=float, default=40.0,
+                    help="untimed passes before the warm-up until this much GPU time has gone by: the device needs "
+                         "~15-20 ms of load to leave its idle clocks (measured: 496 Mbursts/s over the first 50 "
+                         "steps of a cold run, 573 once it has ramped), whatever --warmup/--steps the caller picks")
     ap.add_argument("--bursts", type=int, default=BURSTS_PER_GPU, help="bursts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--workload", choices=["normal", "rach"], default="normal",
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3 (side measurement)")
-    ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3],
+    ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3, 4],
                     help="A/B: normal-burst implementation (trxsig_set_tuning); default = the library's")
+    ap.add_argument("--generic-taps", action="store_true", help="A/B: correlators without the tap-class specialisation")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,6 +128,8 @@ def main():
     ctx.use_torch_stream()
     if args.path is not None:
         ctx.set_tuning(normal_path=args.path)
+    if args.generic_taps:
+        ctx.set_tuning(generic_taps=1)
 
     B = args.bursts
     rach = args.workload == "rach"
@@ -150,6 +157,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp (untimed, not part of W): see --preheat-ms
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        n_pre += 20
     for _ in range(args.warmup):
         step()
     # ---- the timed region: exactly K steps between barriers, nothing else on the stream ----
@@ -165,7 +180,7 @@ def main():
     # ---- per-kernel durations: the same K steps again with every launch bracketed by HIP events
     #      (kept out of the timed region: the extra event records stretch the gaps between kernels)
     ctx.profile_enable(True)
-    for _ in range(args.steps):
+    for _ in range(min(args.steps, 200)):
         step()
     prof = ctx.profile_collect()
     ctx.profile_enable(False)
@@ -203,7 +218,7 @@ def main():
                                ("config2: %d normal bursts/GPU, sps=4, 628/624/624/624 complex f32 samples, "
                                 "TSC %d, detect (thr 3.0) + demod to %d soft bits" % (B, TSC, NSOFT)),
                    "bursts_per_gpu": B, "sps": SPS, "parallelism": "burst-sharded x%d (no data-path collective)" % world},
-        "hip_event_ms_per_step": round(ev_ms / args.steps, 4),
+        "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "preheat_steps": n_pre,
         "detected_frac": round(det_frac, 4), "clean_hard_bits_ok": hard_ok,
         "roofline": roof,
     }

@@ -237,8 +237,11 @@ int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int 
  *     with a wave per burst, 2 = fused with two bursts per wave (fused paths need nsoft <= 148,
  *     otherwise the call falls back to 0).  Initial value: env TRXSIG_TSC_VARIANT or the default.
  *   TRXSIG_TUNE_RACH_PATH: 0 = exact correlation at every lag, 1 = approximate-then-exact.
- *     Initial value: env TRXSIG_RACH_VARIANT or the default. */
-enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1 };
+ *     Initial value: env TRXSIG_RACH_VARIANT or the default.
+ *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component"
+ *     specialisation (which is only taken when the actual taps have that form).  Default 0.
+ *     The 3 in TRXSIG_TUNE_NORMAL_PATH selects the fused kernel with four bursts per wave. */
+enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes);

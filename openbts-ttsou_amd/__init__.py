@@ -263,8 +263,10 @@ class TrxSig:
     def pack_int16(self, x, n, iq):
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
-    def set_tuning(self, normal_path=None, rach_path=None):
+    def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None):
         """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
+        if generic_taps is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 2, int(generic_taps)), "trxsig_set_tuning")
         if normal_path is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 0, int(normal_path)), "trxsig_set_tuning")
         if rach_path is not None:

@@ -68,7 +68,8 @@ struct trxsig_ctx {
   size_t stage_bytes = 0;
   void *d_stage = nullptr;
   int rach_variant = 1;              // 1 = k_rach_fast (approximate-then-exact), 0 = exact at every lag
-  int variant = 0;                   // reserved for A/B builds of the TSC kernels (TRXSIG_TSC_VARIANT)
+  int variant = 0;                   // normal-burst path (TRXSIG_TUNE_NORMAL_PATH / env TRXSIG_TSC_VARIANT)
+  int generic_taps = 0;              // 1: correlators without the tap-class specialisation (TRXSIG_TUNE_GENERIC_TAPS)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 };
@@ -280,17 +281,28 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   DeviceGuard g(c->device);
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
+  if (c->variant == 4) {
+    // detection (correlation + speculative bisection, four bursts per wave) in one kernel, then k_demod
+    HIPCHK(c, trx_launch_normal_fused(c->stream, c->sps, 16, c->d_tables, c->h_tables, (const trx_c32 *)d_samples,
+                                      d_offset, d_length, B, tsc, detect_thresh, energy_thresh, d_flags,
+                                      (trx_c32 *)d_amp, d_toa, d_avgpwr, nullptr, nullptr, 0, 0, c->generic_taps, c->prof));
+    if (nsoft > 0)
+      HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                                 (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
+                                 soft_stride, c->prof));
+    return TRXSIG_OK;
+  }
   if (c->variant >= 1 && c->variant <= 3 && nsoft <= 148) {
     // one kernel for the whole leg: every burst crosses HBM once (k_normal_fused)
     HIPCHK(c, trx_launch_normal_fused(c->stream, c->sps, c->variant == 1 ? 64 : (c->variant == 2 ? 32 : 16), c->d_tables, c->h_tables,
                                       (const trx_c32 *)d_samples, d_offset, d_length, B, tsc, detect_thresh,
                                       energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft,
-                                      soft_stride, c->prof));
+                                      soft_stride, c->generic_taps, c->prof));
     return TRXSIG_OK;
   }
   HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
-                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->variant, c->prof));
+                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->generic_taps, c->prof));
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
@@ -568,8 +580,9 @@ const char *trxsig_kernel_name(int id) {
 }
 int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (!c) return TRXSIG_EINVAL;
-  if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 3) { c->variant = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 4) { c->variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 1) { c->rach_variant = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_GENERIC_TAPS && value >= 0 && value <= 1) { c->generic_taps = value; return TRXSIG_OK; }
   return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: unknown key or value");
 }
 int trxsig_profile_enable(trxsig_ctx *c, int on) {

@@ -53,6 +53,47 @@ __device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }     
 
 struct TapArg { float v[32]; };   // conj'd non-zero midamble taps passed as a kernel argument => SGPRs
 
+// Tap classes.  The GMSK-rotated midamble taps are (+-1, eps) or (eps, +-1): one component is EXACTLY
+// +-1 for most of them (the same ones for every training sequence -- it is a property of the rotation
+// table), so the products with that component are exact and a*b + c with a single rounding (v_fma) is
+// bit-identical to the reference's separately rounded multiply and add.  That saves 2 of the 8
+// operations of a complex multiply-accumulate.  The class of every tap is a template parameter
+// (2 bits per tap: 0 generic, 1 real part exact, 2 imaginary part exact); the host derives it from the
+// actual taps and launches the generic instantiation whenever they do not match the expected pattern.
+// These are the only FMAs outside division/sqrt expansions; tools/asm_stats.py recognises them by the
+// marker comment.
+#define TRX_TAPS_GENERIC 0u
+template <int SPS> struct TapPattern {                     // taps 0,2,4.. real-exact, 1,3,5.. imaginary-exact
+  static constexpr unsigned value = (SPS == 4) ? 0x19999999u : 0x99999999u;   // sps 4: tap 15 is (eps, -0.99999994)
+};
+__device__ __forceinline__ float fma_exact(float a, float b, float c) {       // a*b + c, a*b exact (b = +-1, SGPR)
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fma_exact_subc(float a, float b, float c) {  // a*b - c
+  float r;
+  asm("v_fma_f32 %0, %1, %2, -%3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fma_exact_negab(float a, float b, float c) { // c - a*b
+  float r;
+  asm("v_fma_f32 %0, %1, -%2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+// x * a as Complex<float>::operator* computes it (Complex.h:83), a in SGPRs, CLS = the tap's class
+__device__ __forceinline__ cx cmul_tap(cx x, cx a, int cls) {
+  if (cls == 1) {                                          // a.r = +-1: x.r*a.r and x.i*a.r are exact
+    const float p = x.i * a.i, q = x.r * a.i;
+    return mk(fma_exact_subc(x.r, a.r, p), fma_exact(x.i, a.r, q));
+  }
+  if (cls == 2) {                                          // a.i = +-1: x.i*a.i and x.r*a.i are exact
+    const float p = x.r * a.r, q = x.i * a.r;
+    return mk(fma_exact_negab(x.i, a.i, p), fma_exact(x.r, a.i, q));
+  }
+  return cmul(x, a);
+}
+
 #define TRX_PI_F 3.14159274101257324f             /* (float)M_PI, sigProcLib.cpp:43 */
 #define TRX_2PI_F 6.28318548202514648f            /* (float)(2.0*M_PI), :44 */
 
@@ -182,7 +223,7 @@ __device__ __forceinline__ void corr_issue(CorrIn<SPS> &in, int b, int B, int r,
 // (k_normal_quad).  M_out / energy_out: argmax lag and energy sum of the lane's burst.
 // EFIRST: E aliases the row (k_normal_quad): the energy window's norms are staged, summed and done
 // with before the correlation window is written over them.
-template <int SPS, bool REC, bool EFIRST = false>
+template <int SPS, bool REC, bool EFIRST = false, unsigned TAPCLS = TRX_TAPS_GENERIC>
 __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 *E, int lane, int r, const cx (&tap)[16],
                                            cx *__restrict__ rec, int Bpad, int &M_out, float &energy_out) {
   typedef CorrGeom<SPS> G;
@@ -246,7 +287,7 @@ __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 
       if (c0 + cc < G::NC) {
         cx acc = mk(0, 0);
 #pragma unroll
-        for (int k = 15; k >= 0; k--) acc = cadd(acc, cmul(sv[UPC * cc + k], tap[k]));
+        for (int k = 15; k >= 0; k--) acc = cadd(acc, cmul_tap(sv[UPC * cc + k], tap[k], (TAPCLS >> (2 * k)) & 3));
         cval[c0 + cc] = acc;
       }
     }
@@ -291,7 +332,7 @@ __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 
   (void)lane;
 }
 
-template <int SPS>
+template <int SPS, unsigned TAPCLS>
 __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables *__restrict__ T,
                                                   const cx *__restrict__ samples,
                                                   const int32_t *__restrict__ offset,
@@ -320,7 +361,7 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
   for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
     int M;
     float energy;
-    corr_round<SPS, true, true>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+    corr_round<SPS, true, true, TAPCLS>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
   }
 }
 
@@ -1167,6 +1208,12 @@ __device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *
   }
 }
 
+template <int SPS, int LPB> struct FusedGeom;
+template <int SPS, int LPB, typename HOOK>
+__device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + LPB - 1) / LPB],
+                                            int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft, HOOK staged,
+                                            const float *tp_pre, const cx *rv_pre);
+
 template <int SPS, bool RAW, int NSMAX>
 __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables *__restrict__ T,
                                                const cx *__restrict__ samples,
@@ -1212,6 +1259,13 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables 
       const int q = lane + 64 * i;
       v[i] = (q < N / 2) ? xv[q] : make_float4(0, 0, 0, 0);
     }
+  }
+  // the common case (148 soft bits, even offset and length) goes through fused_demod: same arithmetic,
+  // but a lane owns three CONSECUTIVE soft bits, whose filter windows share 34 of their 63 staged words
+  // (measured: 68.0 -> 64.6 us per 64 K bursts)
+  if (!RAW && NSMAX == 148 && wide && (N & 1) == 0) {
+    fused_demod<SPS, 64>(T, ph[wave], v, N, amp, toa, lane, sb, hb, nsoft, [] {}, nullptr, nullptr);
+    return;
   }
   demod_core<SPS, RAW, NSMAX>(T, ph[wave], xb, N, wide, v, amp, toa, lane, sb, hb,
                               RAW ? reinterpret_cast<cx *>(soft) + (size_t)b * stride : nullptr, nsoft);
@@ -1824,10 +1878,9 @@ __device__ __forceinline__ void fused_tail(PWF pw_at, float *V, int hl, int M, i
 // tp_pre / rv_pre (optional): the 21 delay-filter taps for this TOA and the lane's OPL reverse-rotation
 // values, when the caller has fetched them ahead of time.
 template <int SPS, int LPB, typename HOOK>
-__device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx *P,
-                                            const float4 (&v)[FusedGeom<SPS, LPB>::NLD], int N, cx amp, float toa, int hl,
-                                            float *sb, uint8_t *hbp, int nsoft, HOOK staged,
-                                            const float *tp_pre = nullptr, const cx *rv_pre = nullptr) {
+__device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + LPB - 1) / LPB],
+                                            int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft, HOOK staged,
+                                            const float *tp_pre, const cx *rv_pre) {
   typedef FusedGeom<SPS, LPB> G;
   typedef typename G::D D;
   const bool lane_owner = G::OPL * hl < 148;
@@ -2152,7 +2205,7 @@ __global__ __launch_bounds__(64 * TRX_FUSED_WAVES) void k_normal_fused(
     }
     return;
   }
-  fused_demod<SPS, LPB>(T, R, v, N, amp, toa, hl, sb, hbp, nsoft, [] {});
+  fused_demod<SPS, LPB>(T, R, v, N, amp, toa, hl, sb, hbp, nsoft, [] {}, nullptr, nullptr);
 }
 
 
@@ -2170,7 +2223,7 @@ __global__ __launch_bounds__(64 * TRX_FUSED_WAVES) void k_normal_fused(
 //   busy, which is what the wave-per-burst kernel above cannot do; the price is that the window and
 //   the energy samples are read twice (the second time from L2).  No workgroup barrier.
 // ---------------------------------------------------------------------------------------------
-template <int SPS>
+template <int SPS, unsigned TAPCLS>
 __global__ __launch_bounds__(256) void k_normal_quad(
     const TrxTables *__restrict__ T, const cx *__restrict__ samples, const int32_t *__restrict__ offset,
     const int32_t *__restrict__ length, int B, TapArg taps, cx gain_inv, float mid_toa, float detect_thresh,
@@ -2208,7 +2261,7 @@ __global__ __launch_bounds__(256) void k_normal_quad(
 #pragma unroll
     for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
     corr_issue<SPS>(in, blockIdx.x * 16 + slot, B, r, samples, offset, length);
-    corr_round<SPS, false, true>(in, W, reinterpret_cast<float4 *>(W), lane, r, tap, nullptr, 0, M, energy);
+    corr_round<SPS, false, true, TAPCLS>(in, W, reinterpret_cast<float4 *>(W), lane, r, tap, nullptr, 0, M, energy);
   }
   const bool live = in.live, good = in.good;
   const int b = in.b;
@@ -2370,6 +2423,17 @@ int trx_rec_slots(int sps) {
   return 0;
 }
 
+// class of every tap (see TapPattern): 1 = real part exactly +-1, 2 = imaginary part exactly +-1, 0 = neither
+static unsigned tap_classes(const TrxTables *hT, int tsc) {
+  unsigned m = 0;
+  for (int k = 0; k < 16; k++) {
+    const trx_c32 a = hT->mid_ctap[tsc][k];
+    const unsigned c = (a.r == 1.0f || a.r == -1.0f) ? 1u : ((a.i == 1.0f || a.i == -1.0f) ? 2u : 0u);
+    m |= c << (2 * k);
+  }
+  return m;
+}
+
 template <int S>
 static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples, const int32_t *off,
                               const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
@@ -2378,9 +2442,12 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   TapArg ta;
   for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
   if (prof) prof->begin(TRXSIG_K_TSC_CORR, st);
-  k_tsc_corr<S><<<dim3((B + 16 * TRX_CORR_ROUNDS - 1) / (16 * TRX_CORR_ROUNDS)), dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
+  const dim3 cgrid((B + 16 * TRX_CORR_ROUNDS - 1) / (16 * TRX_CORR_ROUNDS));
+  if (!(variant & 1) && tap_classes(hT, tsc) == TapPattern<S>::value)
+    k_tsc_corr<S, TapPattern<S>::value><<<cgrid, dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
+  else
+    k_tsc_corr<S, TRX_TAPS_GENERIC><<<cgrid, dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
   if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
-  (void)variant;
   k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
                                                           flags, amp, toa, avgpwr);
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
@@ -2405,7 +2472,7 @@ template <int S, int LPB>
 static void launch_normal_fused(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
                                 const int32_t *off, const int32_t *len, int B, int tsc, float detect_thresh,
                                 float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                                float *soft, uint8_t *hard, int nsoft, int stride) {
+                                float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps) {
   TapArg ta;
   for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
   // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
@@ -2413,9 +2480,14 @@ static void launch_normal_fused(hipStream_t st, const TrxTables *dT, const TrxTa
   const float n = g.i * g.i + g.r * g.r;
   trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
   if (LPB == 16) {
-    k_normal_quad<S><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc],
-                                                                detect_thresh, energy_thresh, flags, amp, toa, avgpwr,
-                                                                soft, hard, nsoft, stride);
+    if (!generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value)
+      k_normal_quad<S, TapPattern<S>::value><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(
+          dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft,
+          hard, nsoft, stride);
+    else
+      k_normal_quad<S, TRX_TAPS_GENERIC><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(
+          dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft,
+          hard, nsoft, stride);
   } else {
     constexpr int L = LPB == 16 ? 64 : LPB;
     constexpr int per_wg = TRX_FUSED_WAVES * (64 / L);
@@ -2429,7 +2501,7 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
                                    const trx_c32 *samples, const int32_t *off, const int32_t *len, int B, int tsc,
                                    float detect_thresh, float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
-                                   TrxProfiler *prof) {
+                                   int generic_taps, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   if (nsoft > 148 || (lanes_per_burst != 64 && lanes_per_burst != 32 && lanes_per_burst != 16)) return hipErrorInvalidValue;
   if (prof) prof->begin(TRXSIG_K_NORMAL_FUSED, st);
@@ -2437,13 +2509,13 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
   case S:                                                                                                              \
     if (lanes_per_burst == 64)                                                                                         \
       launch_normal_fused<S, 64>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
-                                 avgpwr, soft, hard, nsoft, stride);                                                   \
+                                 avgpwr, soft, hard, nsoft, stride, generic_taps);                                                   \
     else if (lanes_per_burst == 16)                                                                                    \
       launch_normal_fused<S, 16>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
-                                 avgpwr, soft, hard, nsoft, stride);                                                   \
+                                 avgpwr, soft, hard, nsoft, stride, generic_taps);                                                   \
     else                                                                                                               \
       launch_normal_fused<S, 32>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
-                                 avgpwr, soft, hard, nsoft, stride);                                                   \
+                                 avgpwr, soft, hard, nsoft, stride, generic_taps);                                                   \
     break;
   switch (sps) {
     TRX_FUSED_CASE(1)

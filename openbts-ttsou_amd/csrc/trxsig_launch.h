@@ -21,7 +21,7 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
                                  uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                                 int variant /* 0: lane-per-burst peak kernel, 1: quad-per-burst */,
+                                 int variant /* bit 0: generic taps (no tap-class specialisation) */,
                                  TrxProfiler *prof);
 
 // the whole normal-burst leg in one kernel (k_normal_fused); lanes_per_burst = 64 or 32, nsoft <= 148
@@ -29,7 +29,7 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
                                    const trx_c32 *samples, const int32_t *off, const int32_t *len, int B, int tsc,
                                    float detect_thresh, float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
-                                   TrxProfiler *prof);
+                                   int generic_taps /* 1: no tap-class specialisation */, TrxProfiler *prof);
 
 // RACH detect: ws = workspace of trx_rach_rec_floats(sps) * Bpad floats
 int trx_rach_rec_floats(int sps);

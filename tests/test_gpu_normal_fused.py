@@ -13,7 +13,7 @@ from util import GpuBatch, assert_veq
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [1, 2, 3]       # 1: a wave per burst, 2: two bursts per wave, 3: four bursts per wave (k_normal_quad)
+PATHS = [1, 2, 3, 4]    # 1: a wave per burst, 2: two bursts per wave, 3: four bursts per wave (k_normal_quad), 4: k_normal_quad detection + k_demod
 
 
 @pytest.fixture(scope="module")
@@ -162,3 +162,17 @@ def test_ragged_and_bad_bursts(pkg, ctxs, path):
          run(ctxs[0, sps], xx, off2, length2, 3, nsoft=156, stride=157), "nsoft 156")
     gb = GpuBatch(xx, off2, length2)
     ctxs[path, sps].detect_demod_normal(gb.x, gb.off[:0], gb.len[:0], 3, gb.flags, gb.amp, gb.toa, gb.soft)
+
+
+@pytest.mark.parametrize("path", [0, 3])
+@pytest.mark.parametrize("sps", [1, 2, 4])
+def test_tap_class_specialisation_is_invisible(pkg, sps, path):
+    """The correlators' exact-product FMA form (taps with a component of exactly +-1) against the generic
+    complex multiply-accumulate: identical outputs, hostile windows included."""
+    a = pkg.TrxSig(sps, 0); a.use_torch_stream(); a.set_tuning(normal_path=path, generic_taps=0)
+    g = pkg.TrxSig(sps, 0); g.use_torch_stream(); g.set_tuning(normal_path=path, generic_taps=1)
+    for tsc in range(8):
+        x, off, length, meta = synth.normal_batch(sps, 515, tsc, seed=700 + tsc)
+        same(run(a, x, off, length, tsc), run(g, x, off, length, tsc), "tsc %d" % tsc)
+        x, off, length = hostile_batch(sps, tsc, seed=800 + tsc)
+        same(run(a, x, off, length, tsc, energy_thresh=-1.0), run(g, x, off, length, tsc, energy_thresh=-1.0), "hostile")

@@ -24,7 +24,10 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
         elif o.startswith("s_"): c["salu"] += 1
         elif o.startswith("ds_"): c["lds"] += 1
         elif o.startswith(("global_", "buffer_", "flat_")): c["vmem"] += 1
-    fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma_f|mac_f|fmac_f|mad_f|pk_fma)", o)]
+    # deliberate single-rounding multiply-adds whose product is exact (a tap component of exactly +-1):
+    # emitted through inline asm with a marker comment, bit-identical to the separate mul and add
+    exact = sum(1 for i in ins if "exact-product" in i)
+    fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma_f|mac_f|fmac_f|mad_f|pk_fma)", o) and "exact-product" not in ins[i]]
     # hipcc's correctly-rounded division / sqrt expansions keep their fma's next to
     # v_div_scale / v_rcp / v_div_fmas / v_div_fixup / v_sqrt / v_rsq (f32 and f64)
     bad = 0
@@ -34,4 +37,5 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
             bad += 1
     kind = re.search(r"\d+(k_\w+?)ILi(\d)", name)
     label = "%s<sps=%s>" % (kind.group(1), kind.group(2)) if kind else name[:50]
-    print("%-28s total %5d  %s  fma %d (outside a division: %d)" % (label, len(ops), dict(c), len(fma), bad))
+    print("%-28s total %5d  %s  fma %d (outside a division: %d)%s" % (
+        label, len(ops), dict(c), len(fma), bad, "  exact-product fma %d" % exact if exact else ""))
