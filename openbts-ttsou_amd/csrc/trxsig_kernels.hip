@@ -2223,7 +2223,7 @@ __global__ __launch_bounds__(64 * TRX_FUSED_WAVES) void k_normal_fused(
 //   busy, which is what the wave-per-burst kernel above cannot do; the price is that the window and
 //   the energy samples are read twice (the second time from L2).  No workgroup barrier.
 // ---------------------------------------------------------------------------------------------
-template <int SPS, unsigned TAPCLS>
+template <int SPS, unsigned TAPCLS, bool DEMOD>
 __global__ __launch_bounds__(256) void k_normal_quad(
     const TrxTables *__restrict__ T, const cx *__restrict__ samples, const int32_t *__restrict__ offset,
     const int32_t *__restrict__ length, int B, TapArg taps, cx gain_inv, float mid_toa, float detect_thresh,
@@ -2323,7 +2323,7 @@ __global__ __launch_bounds__(256) void k_normal_quad(
     toa_out[b] = toa;
     if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
   }
-  if (nsoft <= 0) return;
+  if (!DEMOD || nsoft <= 0) return;                        // DEMOD = false: detection only (k_demod follows)
 
   // ---- phase 3 ----
   // delayVector's taps for each burst's TOA (fused_demod's arithmetic), fetched now by the burst's own
@@ -2480,14 +2480,18 @@ static void launch_normal_fused(hipStream_t st, const TrxTables *dT, const TrxTa
   const float n = g.i * g.i + g.r * g.r;
   trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
   if (LPB == 16) {
-    if (!generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value)
-      k_normal_quad<S, TapPattern<S>::value><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(
-          dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft,
-          hard, nsoft, stride);
-    else
-      k_normal_quad<S, TRX_TAPS_GENERIC><<<dim3((B + 15) / 16), dim3(256), 0, st>>>(
-          dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft,
-          hard, nsoft, stride);
+    const dim3 qgrid((B + 15) / 16), qblock(256);
+#define TRX_QUAD_ARGS dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, \
+                      avgpwr, soft, hard, nsoft, stride
+    const bool spec = !generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value;
+    if (nsoft > 0) {
+      if (spec) k_normal_quad<S, TapPattern<S>::value, true><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
+      else k_normal_quad<S, TRX_TAPS_GENERIC, true><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
+    } else {
+      if (spec) k_normal_quad<S, TapPattern<S>::value, false><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
+      else k_normal_quad<S, TRX_TAPS_GENERIC, false><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
+    }
+#undef TRX_QUAD_ARGS
   } else {
     constexpr int L = LPB == 16 ? 64 : LPB;
     constexpr int per_wg = TRX_FUSED_WAVES * (64 / L);
