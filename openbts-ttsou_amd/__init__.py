@@ -69,6 +69,7 @@ def lib():
         L.trxsig_resample_out_len.argtypes = [i32, i32, i32]
         L.trxsig_unpack_int16.argtypes = [vp, vp, C.c_int64, i32, vp]
         L.trxsig_pack_int16.argtypes = [vp, vp, C.c_int64, vp]
+        L.trxsig_unpack_half.argtypes = [vp, vp, C.c_int64, vp]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
@@ -259,6 +260,9 @@ class TrxSig:
 
     def unpack_int16(self, iq, n, out, swap_iq=True):
         self._chk(self.L.trxsig_unpack_int16(self.h, _ptr(iq), n, int(swap_iq), _ptr(out)), "trxsig_unpack_int16")
+
+    def unpack_half(self, iq, n, out):
+        self._chk(self.L.trxsig_unpack_half(self.h, _ptr(iq), n, _ptr(out)), "trxsig_unpack_half")
 
     def pack_int16(self, x, n, iq):
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")

@@ -18,6 +18,7 @@
 //   k_demod      : one wave per burst.  1/amp scaling, 21-tap fractional-delay filter evaluated
 //                  only at the decimated symbol instants, reverse GMSK rotation, soft slicer.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -1670,6 +1671,14 @@ __global__ __launch_bounds__(256) void k_unpack_i16(const short2 *__restrict__ i
     out[i] = swap ? mk((float)v.y, (float)v.x) : mk((float)v.x, (float)v.y);
   }
 }
+// fp16 I/Q storage (BASELINE config 5): widening is exact, so every downstream result equals the
+// float pipeline's on the same values
+__global__ __launch_bounds__(256) void k_unpack_f16(const __half2 *__restrict__ iq, long long n, cx *__restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 v = __half22float2(iq[i]);
+    out[i] = mk(v.x, v.y);
+  }
+}
 __global__ __launch_bounds__(256) void k_pack_i16(const cx *__restrict__ in, long long n, short2 *__restrict__ iq) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const cx v = in[i];
@@ -2644,7 +2653,8 @@ hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long lon
   long long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (prof) prof->begin(TRXSIG_K_CONVERT, st);
-  if (pack) k_pack_i16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const trx_c32 *)in, n, (short2 *)out);
+  if (pack == 2) k_unpack_f16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const __half2 *)in, n, (trx_c32 *)out);
+  else if (pack) k_pack_i16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const trx_c32 *)in, n, (short2 *)out);
   else k_unpack_i16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const short2 *)in, n, swap, (trx_c32 *)out);
   if (prof) prof->end(TRXSIG_K_CONVERT, st);
   return hipGetLastError();

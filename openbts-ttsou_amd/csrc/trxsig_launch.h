@@ -56,7 +56,7 @@ hipError_t trx_launch_modulate(hipStream_t st, int sps, const TrxTables *dT, con
 hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long long in_stride, int S, int P, int Q,
                                const float *lpf, int L, trx_c32 *out, long long out_stride, int nout,
                                TrxProfiler *prof);
-// pack != 0: complex float -> int16 I/Q; else int16 I/Q -> complex float (swap: I/Q flipped)
+// pack: 0 = int16 I/Q -> complex float (swap: I/Q flipped), 1 = complex float -> int16 I/Q, 2 = fp16 I/Q -> complex float
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
                               TrxProfiler *prof);
 

@@ -96,3 +96,43 @@ def test_random_dfe_vs_oracle(pkg, t1, variant52m):
         assert_veq(r["soft"][i, :156], soft[:156], "soft %d" % i)
         nerr += int(((soft[:148] > 0.5) != meta["bits"][i]).sum())
     assert nerr < 0.02 * B * 148
+
+
+def test_config5_fp16_samples(pkg, t1):
+    """BASELINE config 5: bursts stored as fp16 I/Q (values restricted to fp16-exact integers, |v| <= 2048,
+    SURVEY 8d) -> trxsig_unpack_half -> the 52M equaliser leg.  The widening is exact, so the result must equal
+    both the float pipeline on the same numbers and the CPU oracle."""
+    import torch
+    from openbts_ttsou_amd import synth
+    B, tsc, thr, mt = 256, 3, 10.0, 4
+    x, off, length, meta = synth.normal_batch(1, B, tsc, seed=555, sigmas=(0.02, 0.1), max_delay=1.0)
+    for i in range(1, B, 2):                                            # {1, 0.4+0.2j, 0} multipath on odd bursts
+        s = x[off[i]:off[i] + length[i]]
+        s[1:] = s[1:] + np.complex64(0.4 + 0.2j) * s[:-1].copy()
+    scale = 2000.0 / np.abs(x.view(np.float32)).max()
+    q = np.clip(np.rint(x.view(np.float32) * scale), -2048, 2048).astype(np.float16)     # fp16-exact integers
+    xq = q.astype(np.float32).view(np.complex64)
+    assert np.array_equal(xq.view(np.float32), q.astype(np.float32))
+    d_half = torch.from_numpy(q.view(np.int16).copy()).cuda()
+    d_f32 = torch.zeros(len(xq), 2, device="cuda")
+    t1.unpack_half(d_half, len(xq), d_f32)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_f32.cpu().numpy().ravel(), q.astype(np.float32))
+    r = run_eq(t1, d_f32.cpu().numpy().view(np.complex64).ravel(), off, length, tsc, True, mt, thr)
+    rf = run_eq(t1, xq, off, length, tsc, True, mt, thr)
+    for k in r:
+        assert_veq(r[k], rf[k], k)
+    o = oraclebind.Oracle(1, variant52m=True)
+    ndet = 0
+    for i in range(0, B, 7):
+        s = xq[off[i]:off[i] + length[i]]
+        ok_e, _ = o.energy_detect(s, 20, thr)
+        assert bool(r["flags"][i] & pkg.F_ENERGY) == ok_e
+        if not ok_e:
+            continue
+        a = o.analyze_traffic(s, tsc, 3.0, req_chan=True, max_toa=mt)
+        assert bool(r["flags"][i] & pkg.F_DETECT) == a["ok"], i
+        if a["ok"]:
+            assert r["amp"][i] == a["amp"] and r["toa"][i] == a["toa"]
+            ndet += 1
+    assert ndet > 10
