@@ -267,8 +267,10 @@ class TrxSig:
     def pack_int16(self, x, n, iq):
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
-    def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None):
+    def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None):
         """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
+        if spec_peak is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 3, int(spec_peak)), "trxsig_set_tuning")
         if generic_taps is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 2, int(generic_taps)), "trxsig_set_tuning")
         if normal_path is not None:

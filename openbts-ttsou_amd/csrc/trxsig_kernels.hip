@@ -1764,6 +1764,8 @@ __device__ __constant__ const FusedRel<4, true> kFusedRel4F;
 __device__ __constant__ const FusedRel<4, false> kFusedRel4;
 __device__ __constant__ const FusedRel<1, true> kFusedRel1F;
 __device__ __constant__ const FusedRel<3, false> kFusedRel3;
+__device__ __constant__ const FusedRel<2, false> kFusedRel2;
+__device__ __constant__ const FusedRel<1, false> kFusedRel1;
 
 __device__ __forceinline__ void fused_row(const TrxTables *__restrict__ T, int e_lane, float (&s)[24]) {
   const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[e_lane & 511]);   // frac(ix)*512
@@ -2317,6 +2319,7 @@ __global__ __launch_bounds__(256) void k_normal_quad(
     float srow[24];
     fused_row(T, e, srow);
     peak = fused_point(loc, e, 1, srow);
+    asm volatile("" : "+v"(peak.r), "+v"(peak.i));         // (finished here: not to be interleaved with the tail)
   }
   cx amp;
   float toa;
@@ -2418,6 +2421,122 @@ __global__ __launch_bounds__(256) void k_normal_quad(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak8: k_tsc_peak's job (peakDetect's bisection + analyzeTrafficBurst's tail from the
+//   detect->peak record) with EIGHT lanes per burst and the bisection speculated two levels at a time
+//   (fused_point / fused_decide, see k_normal_fused): 6 dependent point evaluations instead of 10
+//   dependent steps of two, eight waves per SIMD instead of one.  The sinc rows of the first three
+//   super-steps (nodes on multiples of 16/512) come from an LDS copy; the last three gather from L2.
+//   Measured SLOWER than k_tsc_peak (25 vs 18 us per 64 K bursts): 48 lane-evaluations per burst instead
+//   of 19, each pulling 21 correlation words and a sinc row through the LDS, make it LDS-bandwidth
+//   bound (ablation: neither the L2 gathers nor occupancy matter).  Kept as an A/B option
+//   (TRXSIG_TUNE_SPECULATIVE_PEAK).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+struct Peak8Geom {
+  typedef CorrGeom<SPS> G;
+  static constexpr int NV = 2 * (3 * SPS + 1);
+  static constexpr int O_PW = 26 * 2;                                   // floats: after loc[26]
+  static constexpr int O_V = O_PW + ((G::NS + 3) & ~3);
+  static constexpr int STRIDE = O_V + ((NV + 3) & ~3);                  // floats per burst (multiple of 4)
+};
+
+template <int SPS>
+__global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restrict__ T, const cx *__restrict__ rec, int Bpad,
+                                                   int B, cx gain_inv, float mid_toa, float detect_thresh,
+                                                   float energy_thresh, uint8_t *__restrict__ flags,
+                                                   cx *__restrict__ amp_out, float *__restrict__ toa_out,
+                                                   float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  typedef Peak8Geom<SPS> P8;
+  __shared__ __attribute__((aligned(16))) float stab[32][24];            // sinc rows f = 0, 16, .., 496
+  __shared__ __attribute__((aligned(16))) float scratch[32][P8::STRIDE];
+  {
+    float tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int ix = threadIdx.x * 3 + k; tv[k] = T->sinc_grid[16 * (ix / 24)][ix % 24]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int ix = threadIdx.x * 3 + k; stab[ix / 24][ix % 24] = tv[k]; }
+  }
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 7;
+  const int slot = threadIdx.x >> 3;                       // burst slot in the workgroup
+  const int b = blockIdx.x * 32 + slot;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+  float *S = scratch[slot];
+  cx *loc = reinterpret_cast<cx *>(S);
+  float *pw = S + P8::O_PW, *V = S + P8::O_V;
+
+  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+#pragma unroll
+  for (int s0 = 0; s0 < G::NS; s0 += 8) {
+    const int sl = s0 + r;
+    if (sl < G::NS) {
+      const cx v = rec[(size_t)sl * Bpad + bb];
+      pw[sl] = norm2(v);
+      const int j = sl - (G::H - 12);
+      if (j >= 0 && j < 24) loc[j] = (M - 12 + j > G::NL - 2) ? mk(0, 0) : v;   // never the last sample (:646)
+    }
+  }
+  if (r < 2) loc[24 + r] = mk(0, 0);
+  __syncthreads();                                         // stab complete (the only barrier); also orders the scratch writes
+
+  int e = 0;                                               // early = M-1 + e/512
+  asm volatile("" : "+v"(e));
+  bool active = true;
+  cx peak = mk(0, 0);
+  {
+    const int rel2 = kFusedRel2.v[r], rel1 = kFusedRel1.v[r];
+#pragma unroll
+    for (int st = 0; st < 4; st++) {                       // increments 256,128 | 64,32 | 16,8 | 4,2
+      const int inc_last = 128 >> (2 * st);
+      const int el = e + (rel2 >> 2) * inc_last;
+      float srow[24];
+      if (st < 3) {                                        // nodes on multiples of 16/512: the LDS copy
+        const float4 *rw = reinterpret_cast<const float4 *>(stab[(el & 511) >> 4]);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const float4 t4 = rw[q];
+          srow[4 * q] = t4.x; srow[4 * q + 1] = t4.y; srow[4 * q + 2] = t4.z; srow[4 * q + 3] = t4.w;
+        }
+      } else {
+        fused_row(T, el, srow);
+      }
+      const cx pt = fused_point(loc, el, rel2 & 3, srow);
+      fused_decide<8, 2, false>(pt, lane, 2 * inc_last, e, active, peak);
+    }
+    {                                                      // the ninth step: +-1
+      float srow[24];
+      fused_row(T, e, srow);
+      const cx pt = fused_point(loc, e, rel1 & 3, srow);
+      fused_decide<8, 1, false>(pt, lane, 1, e, active, peak);
+    }
+    float srow[24];                                        // interpolatePoint(early + 1) where the loop stopped (:699-700)
+    fused_row(T, e, srow);
+    peak = fused_point(loc, e, 1, srow);
+    asm volatile("" : "+v"(peak.r), "+v"(peak.i));         // (finished here: not to be interleaved with the tail)
+  }
+  cx amp;
+  float toa;
+  bool detected, energy_ok;
+  fused_tail<SPS, 8>([&](int lag) { const int sl = lag - M + G::H; return (sl < 0 || sl >= G::NS) ? 0.0f : pw[sl]; }, V, r, M, e,
+                     peak, good, energy, gain_inv, mid_toa, detect_thresh, energy_thresh, amp, toa, detected, energy_ok);
+  if (live && r == 0) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -2457,8 +2576,17 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   else
     k_tsc_corr<S, TRX_TAPS_GENERIC><<<cgrid, dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
   if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
-  k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
-                                                          flags, amp, toa, avgpwr);
+  if (!(variant & 2)) {
+    k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
+                                                            flags, amp, toa, avgpwr);
+  } else {
+    // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
+    const trx_c32 g = hT->mid_gain[tsc];
+    const float n = g.i * g.i + g.r * g.r;
+    trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
+    k_tsc_peak8<S><<<dim3((B + 31) / 32), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
+                                                              energy_thresh, flags, amp, toa, avgpwr);
+  }
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
 }
 
