@@ -372,6 +372,79 @@ def gen_config1():
     save("config1_loopback.npz", **kw)
 
 
+BITVECTORTEST_MC = ("000000000000111100000000000001110000011100001101000011000000000000000111000011110000100100001010"
+                    "000010100000101000001010000010100000010000000000000000000000000000000000000000000000001100001111"
+                    "000000000000000000000000000000000000000000000000000010010000101000001010000010100000101000001010"
+                    "000001000000000000000000000000110000111100000000000001110000101000001100000001000000000000")
+
+
+def gen_fec():
+    """L1 FEC soft decode from the REAL reference BitVector / ViterbiR2O4 / Parity code
+    (oracle/_ref/libref_fec.so): XCCH blocks, RACH bursts, bare Viterbi runs incl. the input string of the
+    reference's own CommonLibs/BitVectorTest.cpp:72, parity / syndrome words."""
+    import reffec
+    r = reffec.RefFec()
+    rng = np.random.default_rng(20260104)
+
+    def wire(v):                        # Transceiver.cpp:669 + TRXManager.cpp:231
+        q = np.round(v.astype(np.float64) * 255.0).astype(np.int64).astype(np.uint8)
+        return (q.astype(np.float32) / np.float32(256.0)).astype(np.float32)
+
+    kw = {}
+    # --- XCCH: 96 blocks at several noise levels; every third through the UDP quantisation; some hopeless
+    nb = 96
+    d = rng.integers(0, 2, (nb, 184)).astype(np.uint8)
+    hard = np.stack([r.xcch_encode(d[i]) for i in range(nb)])                       # [nb,4,114]
+    sig = np.array([0.0, 0.05, 0.15, 0.25, 0.35, 0.5, 0.8, 2.0])[np.arange(nb) % 8]
+    soft = np.clip(hard * 0.8 + 0.1 + rng.normal(0, 1, hard.shape) * sig[:, None, None], 0, 1).astype(np.float32)
+    soft[5] = 0.5; soft[6] = 0.0; soft[7] = 1.0                                     # unknown / all-zero / all-one
+    soft[8, 2] = 0.5                                                                # one burst missing (fec:626-628)
+    wq = (np.arange(nb) % 3) == 0
+    soft[wq] = wire(soft[wq])
+    res = [r.xcch_decode(soft[i]) for i in range(nb)]
+    kw.update(xcch_d=d, xcch_hard=hard.astype(np.uint8), xcch_soft=soft, xcch_wire=wq,
+              xcch_ok=np.array([x["ok"] for x in res]), xcch_u=np.stack([x["u"] for x in res]),
+              xcch_dout=np.stack([x["d"] for x in res]),
+              xcch_syndrome=np.array([x["syndrome"] for x in res], np.uint64))
+    # --- RACH: valid access bursts for a known BSIC, noisy, and garbage
+    nr = 96
+    ra = rng.integers(0, 256, nr)
+    bsic = rng.integers(0, 64, nr)
+    e_hard = np.zeros((nr, 36), np.uint8)
+    for i in range(nr):
+        u = np.zeros(18, np.uint8)
+        u[:8] = r.lsb8msb(np.array([(ra[i] >> (7 - k)) & 1 for k in range(8)], np.uint8))
+        chk = r.parity(0x06f, 6, 8, u[:8])
+        sent = (~(chk ^ int(bsic[i]))) & 0x3f                    # decoder: bsic = (~sent ^ chk) & 0x3f (fec:490-493)
+        u[8:14] = [(sent >> (5 - k)) & 1 for k in range(6)]
+        e_hard[i] = r.encode(u)
+    sg = np.array([0.0, 0.1, 0.2, 0.3, 0.45, 1.0])[np.arange(nr) % 6]
+    e = np.clip(e_hard * 0.8 + 0.1 + rng.normal(0, 1, e_hard.shape) * sg[:, None], 0, 1).astype(np.float32)
+    e[4] = rng.random(36); e[5] = 0.5
+    rr = [r.rach_decode(e[i]) for i in range(nr)]
+    kw.update(rach_ra=ra, rach_bsic=bsic, rach_e=e, rach_u=np.stack([x["u"] for x in rr]),
+              rach_tail_ok=np.array([x["tail_ok"] for x in rr]), rach_bsic_out=np.array([x["bsic"] for x in rr]),
+              rach_ra_out=np.array([x["ra"] for x in rr]))
+    # --- bare Viterbi runs
+    mc = np.array([int(c) for c in BITVECTORTEST_MC], np.uint8)
+    kw.update(kat_c=mc, kat_u=r.soft_decode(mc.astype(np.float32), len(mc) // 2))
+    lens = [2, 4, 36, 50, 100, 378, 456]
+    for n in lens:
+        sv = rng.random(n).astype(np.float32)
+        kw["vit%d_in" % n] = sv
+        kw["vit%d_out" % n] = r.soft_decode(sv, n // 2)
+        bits = rng.integers(0, 2, n // 2).astype(np.uint8)
+        kw["enc%d_in" % n] = bits
+        kw["enc%d_out" % n] = r.encode(bits)
+    # --- parity / syndrome words
+    pb = rng.integers(0, 2, (16, 224)).astype(np.uint8)
+    kw.update(par_bits=pb,
+              par_xcch=np.array([r.parity(0x10004820009, 40, 224, pb[i, :184]) for i in range(16)], np.uint64),
+              syn_xcch=np.array([r.syndrome(0x10004820009, 40, 224, pb[i]) for i in range(16)], np.uint64),
+              par_rach=np.array([r.parity(0x06f, 6, 8, pb[i, :8]) for i in range(16)], np.uint64))
+    save("fec.npz", **kw)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:            # regenerate selected files only, e.g. `gen_golden.py dfe`
         for name in sys.argv[1:]:
@@ -389,3 +462,4 @@ if __name__ == "__main__":
     gen_resample()
     gen_dfe()
     gen_config1()
+    gen_fec()
