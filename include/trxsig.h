@@ -223,6 +223,30 @@ int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *
                          const float *h_gain, int B, trxsig_c32 *h_out, const int32_t *h_out_offset,
                          int64_t out_samples);
 
+/* ---- L1 FEC soft decode: the consumer of the soft bits (next row after the burst path) ---------
+ * SoftVector::decode with ViterbiR2O4 (rate 1/2, order 4, deferral 24; CommonLibs/BitVector.cpp:290-524),
+ * the Parity shift registers (CommonLibs/BitVector.h:39-112) and the decoder flows of GSM/GSML1FEC.cpp.
+ * d_soft is the soft-bit array the detect/demod calls produce: burst b at d_soft + b*soft_stride, 148
+ * values in [0,1].  wire_quantise != 0 applies what the UDP hop does to them in the reference chain --
+ * byte = (char)round(v*255.0) (Transceiver.cpp:669), v' = byte/256.0F (TRXManager.cpp:231) -- so the
+ * result is what GSM::XCCHL1Decoder / RACHL1Decoder would have produced behind TRXManager.
+ *
+ * XCCH (SACCH/SDCCH/BCCH..., GSML1FEC.cpp:584-653): block k = bursts 4k..4k+3 in arrival order (the "B"
+ *   index of GSM 05.03 4.1.4); e-bits = burst[3..59] and [88..144]; deinterleave, decode 456 -> 228,
+ *   invert the 40 parity bits, Fire-code syndrome.  d_frames: 23 octets per block = d[] after LSB8MSB,
+ *   packed MSB first (the L2 frame); d_ok[k] = 1 iff the syndrome is zero ("good frame").
+ * RACH (GSML1FEC.cpp:475-514): one access burst per entry, e = burst[49..84]; decode 36 -> 18;
+ *   d_tail_ok = the four tail bits are zero; d_bsic = the BSIC the parity word encodes (the caller
+ *   compares it with its own, :493); d_ra = the 8-bit RA.
+ * Generic: n_blocks independent SoftVector::decode runs, n_soft (even, <= 1024) values in, n_soft/2 bits out
+ *   (one per byte). */
+int trxsig_fec_xcch_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_blocks,
+                                 int wire_quantise, uint8_t *d_frames, uint8_t *d_ok);
+int trxsig_fec_rach_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_bursts,
+                                 int wire_quantise, uint8_t *d_tail_ok, uint8_t *d_bsic, uint8_t *d_ra);
+int trxsig_fec_viterbi_batch(trxsig_ctx *ctx, const float *d_soft, int n_soft, int64_t in_stride, int n_blocks,
+                             uint8_t *d_bits, int64_t out_stride);
+
 /* ---- measurement helpers (HIP events on the context's stream; used by bench.py) ---------------
  * trxsig_timer_*: one start/stop event pair around whatever the caller enqueues in between.
  * trxsig_profile_*: when enabled, every kernel launch made by the library is bracketed by its own
@@ -232,7 +256,7 @@ int trxsig_timer_start(trxsig_ctx *ctx);
 int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
 enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_K_RACH_CORR = 3,
        TRXSIG_K_RACH_PEAK = 4, TRXSIG_K_MODULATE = 5, TRXSIG_K_RESAMPLE = 6, TRXSIG_K_EQUALIZE = 7,
-       TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_COUNT = 10 };
+       TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_FEC = 10, TRXSIG_K_COUNT = 11 };
 const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);

@@ -70,6 +70,9 @@ def lib():
         L.trxsig_unpack_int16.argtypes = [vp, vp, C.c_int64, i32, vp]
         L.trxsig_pack_int16.argtypes = [vp, vp, C.c_int64, vp]
         L.trxsig_unpack_half.argtypes = [vp, vp, C.c_int64, vp]
+        L.trxsig_fec_xcch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.trxsig_fec_rach_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.trxsig_fec_viterbi_batch.argtypes = [vp, vp, i32, C.c_int64, i32, vp, C.c_int64]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
@@ -261,6 +264,19 @@ class TrxSig:
     def unpack_int16(self, iq, n, out, swap_iq=True):
         self._chk(self.L.trxsig_unpack_int16(self.h, _ptr(iq), n, int(swap_iq), _ptr(out)), "trxsig_unpack_int16")
 
+    def fec_xcch_decode(self, soft, n_blocks, frames, ok, wire=True, soft_stride=None):
+        self._chk(self.L.trxsig_fec_xcch_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_blocks,
+                                                      int(wire), _ptr(frames), _ptr(ok)), "trxsig_fec_xcch_decode_batch")
+
+    def fec_rach_decode(self, soft, n_bursts, tail_ok, bsic, ra, wire=True, soft_stride=None):
+        self._chk(self.L.trxsig_fec_rach_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_bursts,
+                                                      int(wire), _ptr(tail_ok), _ptr(bsic), _ptr(ra)),
+                  "trxsig_fec_rach_decode_batch")
+
+    def fec_viterbi(self, soft, n_soft, n_blocks, bits, in_stride=None, out_stride=None):
+        self._chk(self.L.trxsig_fec_viterbi_batch(self.h, _ptr(soft), n_soft, in_stride or soft.shape[-1], n_blocks,
+                                                  _ptr(bits), out_stride or bits.shape[-1]), "trxsig_fec_viterbi_batch")
+
     def unpack_half(self, iq, n, out):
         self._chk(self.L.trxsig_unpack_half(self.h, _ptr(iq), n, _ptr(out)), "trxsig_unpack_half")
 
@@ -283,7 +299,7 @@ class TrxSig:
 
     def profile_collect(self):
         """{kernel name: (total_ms, launches)} since the last collect (synchronises)."""
-        n = 10                                   # TRXSIG_K_COUNT
+        n = 11                                   # TRXSIG_K_COUNT
         ms = (C.c_float * n)(); cnt = (C.c_int * n)()
         self._chk(self.L.trxsig_profile_collect(self.h, ms, cnt), "trxsig_profile_collect")
         return {self.L.trxsig_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}

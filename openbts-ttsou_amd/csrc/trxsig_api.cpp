@@ -583,9 +583,39 @@ int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
 
 const char *trxsig_kernel_name(int id) {
   static const char *names[TRXSIG_K_COUNT] = { "k_tsc_corr", "k_tsc_peak", "k_demod", "k_rach_corr", "k_rach_peak",
-                                               "k_modulate", "k_resample", "k_equalize", "k_convert", "k_normal_fused" };
+                                               "k_modulate", "k_resample", "k_equalize", "k_convert", "k_normal_fused", "k_fec_viterbi" };
   return (id >= 0 && id < TRXSIG_K_COUNT) ? names[id] : "?";
 }
+int trxsig_fec_xcch_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_blocks, int wire,
+                                 uint8_t *d_frames, uint8_t *d_ok) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n_blocks < 0 || soft_stride < 148 || (n_blocks > 0 && (!d_soft || !d_frames || !d_ok)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_fec_xcch_decode_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_fec(c->stream, 1, d_soft, soft_stride, 456, 228, n_blocks, wire, d_frames, d_ok, nullptr, 0, c->prof));
+  return TRXSIG_OK;
+}
+int trxsig_fec_rach_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_bursts, int wire,
+                                 uint8_t *d_tail_ok, uint8_t *d_bsic, uint8_t *d_ra) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n_bursts < 0 || soft_stride < 85 || (n_bursts > 0 && (!d_soft || !d_tail_ok || !d_bsic || !d_ra)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_fec_rach_decode_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_fec(c->stream, 2, d_soft, soft_stride, 36, 18, n_bursts, wire, d_tail_ok, d_bsic, d_ra, 0, c->prof));
+  return TRXSIG_OK;
+}
+int trxsig_fec_viterbi_batch(trxsig_ctx *c, const float *d_soft, int n_soft, int64_t in_stride, int n_blocks,
+                             uint8_t *d_bits, int64_t out_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n_blocks < 0 || n_soft < 2 || n_soft > 1024 || (n_soft & 1) || in_stride < n_soft || out_stride < n_soft / 2 ||
+      (n_blocks > 0 && (!d_soft || !d_bits)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_fec_viterbi_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_fec(c->stream, 0, d_soft, in_stride, n_soft, n_soft / 2, n_blocks, 0, d_bits, nullptr, nullptr,
+                           out_stride, c->prof));
+  return TRXSIG_OK;
+}
+
 int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (!c) return TRXSIG_EINVAL;
   if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 4) { c->variant = value; return TRXSIG_OK; }

@@ -1,0 +1,234 @@
+// trxsig_fec.hip -- gfx950 kernel of the GSM L1 FEC soft decode that consumes the burst path's soft
+// bits: SoftVector::decode with the rate-1/2, order-4 Viterbi coder
+// (CommonLibs/BitVector.cpp:290-524, "bv:"), the Parity/Generator shift registers
+// (CommonLibs/BitVector.h:39-112, "bh:"), LSB8MSB + pack (bv:166-195, 541-552) and the XCCH / RACH
+// decoder flows (GSM/GSML1FEC.cpp:475-514, 584-653, "fec:"), optionally with the UDP hop's 8-bit
+// quantisation in between (Transceiver/Transceiver.cpp:669, TRXManager/TRXManager.cpp:231).
+//
+// Decomposition: the decoder has 16 survivors, so one block (code word) takes 16 lanes -- lane s IS
+// survivor s -- and a wave decodes four blocks.  Per trellis step a lane fetches its two predecessors
+// (survivors s>>1 and 8 + s>>1: ds_bpermute), adds the branch costs and keeps the cheaper one; the
+// first-minimum survivor (bv:382-393) is found with four DPP exchanges and its deferred input bit
+// (24 steps back) is the output.  Numerical contract as in trxsig_kernels.hip: float costs are added
+// exactly as the reference adds them (cost + (second-bit cost + first-bit cost), -ffp-contract=off),
+// so survivor selection, ties included, is bit-identical.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trxsig_launch.h"
+
+namespace {
+
+constexpr int kDeferral = 24;                              // 6*mOrder (bh:138)
+
+// coder output for the 5-bit input history idx: generator 0x19 in bit 1, 0x1b in bit 0 (bv:306-330),
+// two bits per entry, 32 entries
+constexpr unsigned apply_poly(unsigned val, unsigned poly) {
+  unsigned prod = val & poly, sum = prod;
+  for (unsigned i = 1; i < 5; i++) sum ^= prod >> i;
+  return sum & 1u;
+}
+constexpr unsigned long long gen_table() {
+  unsigned long long t = 0;
+  for (unsigned idx = 0; idx < 32; idx++)
+    t |= (unsigned long long)((apply_poly(idx, 0x19) << 1) | apply_poly(idx, 0x1b)) << (2 * idx);
+  return t;
+}
+constexpr unsigned long long kGen = gen_table();
+
+// The syndrome / parity registers are linear over GF(2) (they start from zero), so the word for a
+// bit string is the XOR of the words of its set bits.  XcchSyn::v[i] = syndromeShift response
+// (bh:69-74) to a single 1 at position i of a 224-bit code word, generator 0x10004820009 (40 bits);
+// RachPar::v[i] = encoderShift response (bh:80-85) to a single 1 at position i of 8 bits, generator 0x6f.
+struct XcchSyn {
+  unsigned long long v[224];
+  constexpr XcchSyn() : v() {
+    unsigned long long st = 1;                             // the bit has just been shifted in
+    for (int i = 223; i >= 0; i--) {
+      v[i] = st & ((1ULL << 40) - 1);
+      const unsigned long long fb = (st >> 39) & 1ULL;     // one more zero shifted in behind it
+      st <<= 1;
+      if (fb) st ^= 0x10004820009ULL;
+    }
+  }
+};
+struct RachPar {
+  unsigned v[8];
+  constexpr RachPar() : v() {
+    for (int i = 0; i < 8; i++) {
+      unsigned st = 0;
+      for (int k = 0; k < 8; k++) {
+        const unsigned fb = ((st >> 5) ^ (k == i ? 1u : 0u)) & 1u;
+        st <<= 1;
+        if (fb) st ^= 0x6fu;
+      }
+      v[i] = st & 0x3fu;
+    }
+  }
+};
+__device__ __constant__ const XcchSyn kXcchSyn;
+__device__ __constant__ const RachPar kRachPar;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the soft value as the GSM side sees it after the UDP hop
+__device__ __forceinline__ float wire_value(float v) {
+  const int q = (int)round((double)v * 255.0);             // (char) round(x*255.0), Transceiver.cpp:669
+  return (float)(unsigned char)q / 256.0F;                 // TRXManager.cpp:231
+}
+
+enum { FEC_GENERIC = 0, FEC_XCCH = 1, FEC_RACH = 2 };
+
+// MODE FEC_GENERIC: block b reads soft[b*in_stride + p], p < n, and writes nout bits as bytes to out0 + b*out_stride.
+// MODE FEC_XCCH   : block b = bursts 4b..4b+3 of soft[burst*in_stride + 0..147]; c[k] = i[k%4][j(k)] with the
+//                   e-bits at 3..59 and 88..144 (fec:607-608, 618-629); out0 = 23 octets per block, out1 = ok.
+// MODE FEC_RACH   : block b = burst b, e = burst[49..85) (fec:479); out0 = tail ok, out1 = BSIC, out2 = RA.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ soft, long long in_stride, int n, int nout,
+                                                    int nblk, int wire, uint8_t *__restrict__ out0,
+                                                    uint8_t *__restrict__ out1, uint8_t *__restrict__ out2,
+                                                    long long out_stride) {
+  extern __shared__ float4 ktab[];                         // [4 blocks][steps]: costs of coder bit 0/1 for both bits of a step
+  const int lane = threadIdx.x & 63, row = lane >> 4, s = lane & 15;
+  const int blk = blockIdx.x * 4 + row;
+  const bool live = blk < nblk;
+  const int steps = nout + kDeferral;
+  float2 *K2 = reinterpret_cast<float2 *>(ktab + (size_t)row * steps);
+
+  // ---- metric tables (bv:462-485), two positions per step ----
+  for (int p = s; p < 2 * steps; p += 16) {
+    float k0 = 0.5F, k1 = 0.5F;                            // pad with unknowns (bv:481-484)
+    if (p < n && live) {
+      float v;
+      if (MODE == FEC_XCCH) {
+        const int B = p & 3, j = 2 * ((49 * p) % 57) + ((p % 8) / 4);   // GSM 05.03 4.1.4 (fec:622-625)
+        v = soft[(size_t)(4 * blk + B) * in_stride + (j < 57 ? 3 + j : 88 + (j - 57))];
+      } else if (MODE == FEC_RACH) {
+        v = soft[(size_t)blk * in_stride + 49 + p];
+      } else {
+        v = soft[(size_t)blk * in_stride + p];
+      }
+      if (wire) v = wire_value(v);
+      const bool hard = v > 0.5F;                          // sliced() (bv:424-433)
+      float pVal = v;
+      if (pVal > 0.5F) pVal = 1.0F - pVal;
+      float ipVal = 1.0F - pVal;
+      if (pVal < 0.01F) pVal = (float)0.01;
+      if (ipVal < 0.01F) ipVal = (float)0.01;
+      const float match = 0.25F / ipVal, mismatch = 0.25F / pVal;
+      k0 = hard ? mismatch : match;                        // coder bit 0 mismatches a received 1
+      k1 = hard ? match : mismatch;
+    }
+    K2[p] = make_float2(k0, k1);
+  }
+  wave_fence();
+
+  // ---- the trellis: lane s is survivor s (bv:334-399) ----
+  float cost = 0.0f;
+  unsigned ist = 0, outw = 0;
+  const int srcA = (lane & 48) + (s >> 1), srcB = srcA + 8;
+  const float4 *K = ktab + (size_t)row * steps;
+  for (int t = 0; t < steps; t++) {
+    const float4 k = K[t];                                 // {first bit: cost of coder 0, 1; second bit: cost of coder 0, 1}
+    const float cA0 = __shfl(cost, srcA, 64), cB0 = __shfl(cost, srcB, 64);
+    const unsigned iA = (__shfl(ist, srcA, 64) << 1) | (s & 1), iB = (__shfl(ist, srcB, 64) << 1) | (s & 1);
+    const unsigned gA = (unsigned)(kGen >> (2 * (iA & 31))) & 3u, gB = (unsigned)(kGen >> (2 * (iB & 31))) & 3u;
+    // cost += cTab[m&1][1] + cTab[(m>>1)&1][0] (bv:365)
+    const float cA = cA0 + (((gA & 1u) ? k.w : k.z) + ((gA >> 1) ? k.y : k.x));
+    const float cB = cB0 + (((gB & 1u) ? k.w : k.z) + ((gB >> 1) ? k.y : k.x));
+    const bool takeA = cA < cB;                            // pruneCandidates (bv:371-379)
+    cost = takeA ? cA : cB;
+    ist = takeA ? iA : iB;
+    // minCost: first minimum over the 16 survivors (bv:382-393)
+    float mc = cost;
+    int mi = s;
+#define TRX_MIN_STEP(CTRL)                                                   \
+    {                                                                        \
+      const float oc = dpp_f<CTRL>(mc);                                      \
+      const int oi = dpp_i<CTRL>(mi);                                        \
+      const bool take = (oc < mc) || (oc == mc && oi < mi);                  \
+      mc = take ? oc : mc;                                                   \
+      mi = take ? oi : mi;                                                   \
+    }
+    TRX_MIN_STEP(0xB1)                                     // quad_perm [1,0,3,2]
+    TRX_MIN_STEP(0x4E)                                     // quad_perm [2,3,0,1]
+    TRX_MIN_STEP(0x141)                                    // row_half_mirror
+    TRX_MIN_STEP(0x140)                                    // row_mirror
+#undef TRX_MIN_STEP
+    const unsigned long long ob = __builtin_amdgcn_ballot_w64((ist >> kDeferral) & 1u);
+    if (t >= kDeferral) {
+      const int op = t - kDeferral;
+      const unsigned bit = (unsigned)(ob >> ((lane & 48) + mi)) & 1u;
+      if ((op >> 5) == s) outw |= bit << (op & 31);        // lane s collects output bits 32s .. 32s+31
+    }
+  }
+  if (!live) return;
+
+  if (MODE == FEC_GENERIC) {
+    for (int k = 0; k < 32; k++) {
+      const int i = 32 * s + k;
+      if (i < nout) out0[(size_t)blk * out_stride + i] = (uint8_t)((outw >> k) & 1u);
+    }
+  } else if (MODE == FEC_XCCH) {
+    // d[] = u[0..184) with every octet bit-reversed (LSB8MSB, fec:598) and packed MSB first: octet o is
+    // u[8o .. 8o+7] with u[8o] as its LSB, i.e. the bytes of the output words as they stand
+    for (int q = 0; q < 4; q++)
+      if (4 * s + q < 23) out0[(size_t)blk * 23 + 4 * s + q] = (uint8_t)(outw >> (8 * q));
+    // syndrome of d[]:~p[] (fec:644-651): XOR of the unit responses of the set bits
+    unsigned w = outw;
+    if (s == 5) w ^= 0xFF000000u;                          // parity bits 184..223 are inverted
+    if (s == 6) w ^= 0xFFFFFFFFu;
+    unsigned long long syn = 0;
+    if (s < 7) {
+      for (int k = 0; k < 32; k++) {
+        const unsigned long long r = kXcchSyn.v[32 * s + k];
+        if ((w >> k) & 1u) syn ^= r;
+      }
+    }
+    unsigned lo = (unsigned)syn, hi = (unsigned)(syn >> 32);
+    lo ^= (unsigned)dpp_i<0xB1>((int)lo); hi ^= (unsigned)dpp_i<0xB1>((int)hi);
+    lo ^= (unsigned)dpp_i<0x4E>((int)lo); hi ^= (unsigned)dpp_i<0x4E>((int)hi);
+    lo ^= (unsigned)dpp_i<0x141>((int)lo); hi ^= (unsigned)dpp_i<0x141>((int)hi);
+    lo ^= (unsigned)dpp_i<0x140>((int)lo); hi ^= (unsigned)dpp_i<0x140>((int)hi);
+    if (s == 0) out1[blk] = (lo | hi) == 0;
+  } else {
+    if (s == 0) {
+      const unsigned u = outw;                             // bit k = u[k]
+      const bool tail_ok = ((u >> 14) & 0xFu) == 0;        // fec:485
+      unsigned sent = 0, chk = 0;
+      for (int k = 0; k < 6; k++) sent |= ((u >> (8 + k)) & 1u) << (5 - k);     // peekField(8,6), MSB first
+      for (int i = 0; i < 8; i++) if ((u >> i) & 1u) chk ^= kRachPar.v[i];
+      out0[blk] = tail_ok;
+      out1[blk] = (uint8_t)((~sent ^ chk) & 0x3fu);        // fec:490-493
+      out2[blk] = (uint8_t)(u & 0xFFu);                    // RA = d[] after LSB8MSB, MSB first (fec:506-507)
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long in_stride, int n, int nout, int nblk,
+                          int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof) {
+  if (nblk <= 0) return hipSuccess;
+  if (nout <= 0 || nout > 512 || n < 0 || n > 2 * nout) return hipErrorInvalidValue;
+  const dim3 grid((nblk + 3) / 4), block(64);
+  const size_t lds = (size_t)4 * (nout + kDeferral) * sizeof(float4);
+  if (prof) prof->begin(TRXSIG_K_FEC, st);
+  switch (mode) {
+    case FEC_GENERIC: k_fec_viterbi<FEC_GENERIC><<<grid, block, lds, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    case FEC_XCCH: k_fec_viterbi<FEC_XCCH><<<grid, block, lds, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    case FEC_RACH: k_fec_viterbi<FEC_RACH><<<grid, block, lds, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (prof) prof->end(TRXSIG_K_FEC, st);
+  return hipGetLastError();
+}

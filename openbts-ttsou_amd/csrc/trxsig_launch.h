@@ -68,3 +68,10 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
                                trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
                                int nsoft, int stride, TrxProfiler *prof);
 
+
+// L1 FEC soft decode (trxsig_fec.hip).  mode 0: generic SoftVector::decode of nblk blocks of n soft values ->
+// nout bits (one byte each) at out0 + b*out_stride; mode 1: XCCH (four bursts per block, in_stride = floats per
+// burst): out0 = 23 octets per block, out1 = parity ok; mode 2: RACH (one burst per block): out0 = tail ok,
+// out1 = BSIC, out2 = RA.  wire != 0: the UDP hop's 8-bit quantisation of the soft values first.
+hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long in_stride, int n, int nout, int nblk,
+                          int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof);

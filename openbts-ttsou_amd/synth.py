@@ -100,6 +100,15 @@ def _finish(rng, base, B, sps, delay, sigma_choices):
     return x, off.astype(np.int32), length, amp, sig
 
 
+def bursts_from_bits(bits, sps, seed=0, sigmas=(0.0, 0.1, 0.3), max_delay=1.5):
+    """Caller-chosen 148-bit bursts [B,148] through the same channel model as normal_batch."""
+    rng = np.random.default_rng(seed)
+    B = bits.shape[0]
+    delay = rng.uniform(-max_delay, max_delay, B)
+    x, off, length, amp, sig = _finish(rng, modulate(bits, sps), B, sps, delay, sigmas)
+    return x, off, length, dict(bits=bits, amp=amp, delay=delay.astype(np.float32), sigma=sig)
+
+
 def normal_batch(sps, B, tsc, seed=0, sigmas=(0.0, 0.1, 0.3), max_delay=1.5):
     """Config 2 workload: B normal bursts with training sequence `tsc`."""
     rng = np.random.default_rng(seed)

@@ -1,0 +1,160 @@
+"""GPU parity of the L1 FEC soft decode (k_fec_viterbi) through the C-ABI: golden vectors
+captured from the real reference BitVector / ViterbiR2O4 / Parity code (incl. BitVectorTest.cpp's input),
+the CPU oracle on random batches (ties, unknowns, garbage), the UDP-hop quantisation, and the chain
+burst -> detect/demod -> FEC -> L2 frame end to end.  Bit-exact."""
+import numpy as np
+import pytest
+
+import _pkg
+import fecbind
+import oraclebind
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _pkg.load()
+
+
+@pytest.fixture(scope="module")
+def t(pkg):
+    c = pkg.TrxSig(4, 0)
+    c.use_torch_stream()
+    return c
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def gpu_viterbi(t, soft2d):
+    import torch
+    nb, n = soft2d.shape
+    bits = torch.full((nb, n // 2), 9, dtype=torch.uint8, device="cuda")
+    t.fec_viterbi(dev(soft2d.astype(np.float32)), n, nb, bits)
+    torch.cuda.synchronize()
+    return bits.cpu().numpy()
+
+
+def gpu_xcch(t, soft, wire):
+    import torch
+    nb = soft.shape[0] // 4
+    frames = torch.full((nb, 23), 9, dtype=torch.uint8, device="cuda"); ok = torch.full((nb,), 9, dtype=torch.uint8, device="cuda")
+    t.fec_xcch_decode(dev(soft.astype(np.float32)), nb, frames, ok, wire=wire)
+    torch.cuda.synchronize()
+    return frames.cpu().numpy(), ok.cpu().numpy()
+
+
+def gpu_rach(t, soft, wire):
+    import torch
+    n = soft.shape[0]
+    o = [torch.full((n,), 99, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    t.fec_rach_decode(dev(soft.astype(np.float32)), n, o[0], o[1], o[2], wire=wire)
+    torch.cuda.synchronize()
+    return np.stack([x.cpu().numpy() for x in o], axis=1)
+
+
+def bursts_from_ebits(rng, e4x114):
+    """[nb,4,114] e-bits -> [4*nb,148] bursts with the e-bits at 3..59 / 88..144 and junk elsewhere."""
+    nb = e4x114.shape[0]
+    s = rng.random((4 * nb, 148)).astype(np.float32)
+    x = e4x114.reshape(4 * nb, 114)
+    s[:, 3:60] = x[:, :57]; s[:, 88:145] = x[:, 57:]
+    return s
+
+
+def test_golden_viterbi(t, golden):
+    g = golden("fec.npz")
+    got = gpu_viterbi(t, g["kat_c"].astype(np.float32)[None, :])
+    assert np.array_equal(got[0], g["kat_u"])                       # CommonLibs/BitVectorTest.cpp:72
+    for n in (2, 4, 36, 50, 100, 378, 456):
+        assert np.array_equal(gpu_viterbi(t, g["vit%d_in" % n][None, :])[0], g["vit%d_out" % n]), n
+
+
+def test_golden_xcch_and_rach(t, golden):
+    g = golden("fec.npz")
+    rng = np.random.default_rng(11)
+    frames, ok = gpu_xcch(t, bursts_from_ebits(rng, g["xcch_soft"]), wire=False)
+    assert np.array_equal(ok.astype(bool), g["xcch_ok"])
+    assert np.array_equal(np.unpackbits(frames, axis=1), g["xcch_dout"])           # d[] even for bad frames
+    good = np.flatnonzero(ok)
+    assert np.array_equal(np.unpackbits(frames[good], axis=1), g["xcch_d"][good])  # = the frames that were sent
+    rs = rng.random((len(g["rach_e"]), 148)).astype(np.float32)
+    rs[:, 49:85] = g["rach_e"]
+    out = gpu_rach(t, rs, wire=False)
+    assert np.array_equal(out[:, 0].astype(bool), g["rach_tail_ok"])
+    assert np.array_equal(out[:, 1], g["rach_bsic_out"]) and np.array_equal(out[:, 2], g["rach_ra_out"])
+
+
+@pytest.mark.parametrize("wire", [False, True])
+def test_random_vs_oracle(t, wire):
+    o = fecbind.FecOracle()
+    rng = np.random.default_rng(123 + wire)
+    nb = 1027                                                       # ragged: not a multiple of 4 blocks per wave
+    d = rng.integers(0, 2, (nb, 184)).astype(np.uint8)
+    hard = np.zeros((nb, 4, 114), np.float32)
+    for i in range(nb):
+        dd = o.lsb8msb(d[i])
+        u = np.zeros(228, np.uint8); u[:184] = dd
+        par = (~o.parity(fecbind.XCCH_POLY, 40, dd)) & ((1 << 40) - 1)          # writeParityWord, inverted
+        u[184:224] = [(par >> (39 - k)) & 1 for k in range(40)]
+        c = o.encode(u)
+        k = np.arange(456)
+        hard[i, k % 4, 2 * ((49 * k) % 57) + ((k % 8) // 4)] = c
+    sig = np.array([0.0, 0.1, 0.2, 0.3, 0.4, 0.6, 1.5])[np.arange(nb) % 7]
+    soft = np.clip(hard * 0.8 + 0.1 + rng.normal(0, 1, hard.shape) * sig[:, None, None], 0, 1).astype(np.float32)
+    soft[3] = 0.5; soft[4, 1] = 0.5; soft[5] = rng.integers(0, 2, (4, 114))         # ties, a lost burst, hard garbage
+    b = bursts_from_ebits(rng, soft)
+    frames, ok = gpu_xcch(t, b, wire)
+    of, ook = o.xcch_decode_batch(b, wire=wire, nthreads=8)
+    assert np.array_equal(ok, ook) and np.array_equal(frames, of)
+    assert 0.3 * nb < ok.sum() < 0.8 * nb
+    clean = np.flatnonzero(sig <= 0.1); clean = clean[clean > 5]
+    assert ok[clean].all() and np.array_equal(np.unpackbits(frames[clean], axis=1), d[clean])
+    rs = rng.random((4099, 148)).astype(np.float32)
+    assert np.array_equal(gpu_rach(t, rs, wire), o.rach_decode_batch(rs, wire=wire, nthreads=8))
+    for n in (2, 38, 456, 1024):
+        sv = rng.random((37, n)).astype(np.float32)
+        sv[rng.random(sv.shape) < 0.2] = 0.5
+        want = np.stack([o.viterbi_decode(sv[i], n // 2) for i in range(len(sv))])
+        assert np.array_equal(gpu_viterbi(t, sv), want), n
+
+
+def test_end_to_end_burst_to_l2_frame(pkg, t):
+    """Four normal bursts carrying one XCCH block -> modulate -> channel -> detect + demodulate -> FEC: the
+    L2 frame comes back; the GPU chain equals the oracle chain bit for bit (wire quantisation on)."""
+    import torch
+    sps, tsc, nblk = 4, 5, 64
+    o = fecbind.FecOracle(); so = oraclebind.Oracle(sps)
+    rng = np.random.default_rng(2026)
+    d = rng.integers(0, 2, (nblk, 184)).astype(np.uint8)
+    bits = synth.normal_bits(rng, 4 * nblk, tsc)
+    for i in range(nblk):
+        dd = o.lsb8msb(d[i]); u = np.zeros(228, np.uint8); u[:184] = dd
+        par = (~o.parity(fecbind.XCCH_POLY, 40, dd)) & ((1 << 40) - 1)
+        u[184:224] = [(par >> (39 - k)) & 1 for k in range(40)]
+        c = o.encode(u)
+        k = np.arange(456)
+        e = np.zeros((4, 114), np.uint8); e[k % 4, 2 * ((49 * k) % 57) + ((k % 8) // 4)] = c
+        bits[4 * i:4 * i + 4, 3:60] = e[:, :57]; bits[4 * i:4 * i + 4, 88:145] = e[:, 57:]
+        bits[4 * i:4 * i + 4, 60] = 1; bits[4 * i:4 * i + 4, 87] = 1            # stealing flags (fec:716-717)
+    B = 4 * nblk
+    x, off, length, meta = synth.bursts_from_bits(bits, sps, seed=5, sigmas=(0.0, 0.1, 0.25))
+    from util import GpuBatch
+    gb = GpuBatch(x, off, length, nsoft=148, stride=148)
+    t.detect_demod_normal(gb.x, gb.off, gb.len, tsc, gb.flags, gb.amp, gb.toa, gb.soft, nsoft=148, soft_stride=148)
+    frames = torch.zeros(nblk, 23, dtype=torch.uint8, device="cuda"); ok = torch.zeros(nblk, dtype=torch.uint8, device="cuda")
+    t.fec_xcch_decode(gb.soft, nblk, frames, ok, wire=True)
+    torch.cuda.synchronize()
+    frames, ok = frames.cpu().numpy(), ok.cpu().numpy()
+    _, _, _, soft = so.normal_batch(x, off, length, tsc, nsoft=148, nthreads=8)
+    of, ook = o.xcch_decode_batch(soft[:, :148], wire=True, nthreads=4)
+    assert np.array_equal(ok, ook) and np.array_equal(frames, of)
+    assert ok.sum() >= 0.9 * nblk
+    good = np.flatnonzero(ok)
+    assert np.array_equal(np.unpackbits(frames[good], axis=1), d[good])
