@@ -6,10 +6,12 @@
 // quantisation in between (Transceiver/Transceiver.cpp:669, TRXManager/TRXManager.cpp:231).
 //
 // Decomposition: the decoder has 16 survivors, so one block (code word) takes 16 lanes -- lane s IS
-// survivor s -- and a wave decodes four blocks.  Per trellis step a lane fetches its two predecessors
+// survivor s -- and a wave decodes four blocks.  Measured (MI355X, 16 K XCCH blocks = 64 K bursts):
+// 102 us; it is bound by the ~50-instruction dependent chain of a trellis step (4 waves per SIMD), not
+// by memory -- the first version, whose whole-block metric table left 2.5 waves per SIMD, took 217 us.  Per trellis step a lane fetches its two predecessors
 // (survivors s>>1 and 8 + s>>1: ds_bpermute), adds the branch costs and keeps the cheaper one; the
-// first-minimum survivor (bv:382-393) is found with four DPP exchanges and its deferred input bit
-// (24 steps back) is the output.  Numerical contract as in trxsig_kernels.hip: float costs are added
+// first-minimum survivor (bv:382-393) is found with four DPP min exchanges + a ballot and its deferred
+// input bit (24 steps back) is the output.  Numerical contract as in trxsig_kernels.hip: float costs are added
 // exactly as the reference adds them (cost + (second-bit cost + first-bit cost), -ffp-contract=off),
 // so survivor selection, ties included, is bit-identical.
 #include <hip/hip_runtime.h>
@@ -20,6 +22,7 @@
 namespace {
 
 constexpr int kDeferral = 24;                              // 6*mOrder (bh:138)
+constexpr int kChunk = 64;                                 // trellis steps per table refill (8 positions per lane)
 
 // coder output for the 5-bit input history idx: generator 0x19 in bit 1, 0x1b in bit 0 (bv:306-330),
 // two bits per entry, 32 entries
@@ -97,79 +100,91 @@ __global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ so
                                                     int nblk, int wire, uint8_t *__restrict__ out0,
                                                     uint8_t *__restrict__ out1, uint8_t *__restrict__ out2,
                                                     long long out_stride) {
-  extern __shared__ float4 ktab[];                         // [4 blocks][steps]: costs of coder bit 0/1 for both bits of a step
+  // costs of coder bit 0/1 for both bits of a step, kChunk steps at a time: a small table keeps 8 waves
+  // per SIMD resident (the whole 252-step table of an XCCH block would be 4 KB per block: 2.5 waves)
+  __shared__ float4 ktab[4][kChunk];
   const int lane = threadIdx.x & 63, row = lane >> 4, s = lane & 15;
   const int blk = blockIdx.x * 4 + row;
   const bool live = blk < nblk;
   const int steps = nout + kDeferral;
-  float2 *K2 = reinterpret_cast<float2 *>(ktab + (size_t)row * steps);
+  float2 *K2 = reinterpret_cast<float2 *>(ktab[row]);
+  const float4 *K = ktab[row];
 
-  // ---- metric tables (bv:462-485), two positions per step ----
-  for (int p = s; p < 2 * steps; p += 16) {
-    float k0 = 0.5F, k1 = 0.5F;                            // pad with unknowns (bv:481-484)
-    if (p < n && live) {
-      float v;
-      if (MODE == FEC_XCCH) {
-        const int B = p & 3, j = 2 * ((49 * p) % 57) + ((p % 8) / 4);   // GSM 05.03 4.1.4 (fec:622-625)
-        v = soft[(size_t)(4 * blk + B) * in_stride + (j < 57 ? 3 + j : 88 + (j - 57))];
-      } else if (MODE == FEC_RACH) {
-        v = soft[(size_t)blk * in_stride + 49 + p];
-      } else {
-        v = soft[(size_t)blk * in_stride + p];
-      }
-      if (wire) v = wire_value(v);
-      const bool hard = v > 0.5F;                          // sliced() (bv:424-433)
-      float pVal = v;
-      if (pVal > 0.5F) pVal = 1.0F - pVal;
-      float ipVal = 1.0F - pVal;
-      if (pVal < 0.01F) pVal = (float)0.01;
-      if (ipVal < 0.01F) ipVal = (float)0.01;
-      const float match = 0.25F / ipVal, mismatch = 0.25F / pVal;
-      k0 = hard ? mismatch : match;                        // coder bit 0 mismatches a received 1
-      k1 = hard ? match : mismatch;
-    }
-    K2[p] = make_float2(k0, k1);
-  }
-  wave_fence();
-
-  // ---- the trellis: lane s is survivor s (bv:334-399) ----
-  float cost = 0.0f;
+  float cost = 0.0f;                                       // lane s is survivor s (bv:334-399)
   unsigned ist = 0, outw = 0;
   const int srcA = (lane & 48) + (s >> 1), srcB = srcA + 8;
-  const float4 *K = ktab + (size_t)row * steps;
-  for (int t = 0; t < steps; t++) {
-    const float4 k = K[t];                                 // {first bit: cost of coder 0, 1; second bit: cost of coder 0, 1}
-    const float cA0 = __shfl(cost, srcA, 64), cB0 = __shfl(cost, srcB, 64);
-    const unsigned iA = (__shfl(ist, srcA, 64) << 1) | (s & 1), iB = (__shfl(ist, srcB, 64) << 1) | (s & 1);
-    const unsigned gA = (unsigned)(kGen >> (2 * (iA & 31))) & 3u, gB = (unsigned)(kGen >> (2 * (iB & 31))) & 3u;
-    // cost += cTab[m&1][1] + cTab[(m>>1)&1][0] (bv:365)
-    const float cA = cA0 + (((gA & 1u) ? k.w : k.z) + ((gA >> 1) ? k.y : k.x));
-    const float cB = cB0 + (((gB & 1u) ? k.w : k.z) + ((gB >> 1) ? k.y : k.x));
-    const bool takeA = cA < cB;                            // pruneCandidates (bv:371-379)
-    cost = takeA ? cA : cB;
-    ist = takeA ? iA : iB;
-    // minCost: first minimum over the 16 survivors (bv:382-393)
-    float mc = cost;
-    int mi = s;
-#define TRX_MIN_STEP(CTRL)                                                   \
-    {                                                                        \
-      const float oc = dpp_f<CTRL>(mc);                                      \
-      const int oi = dpp_i<CTRL>(mi);                                        \
-      const bool take = (oc < mc) || (oc == mc && oi < mi);                  \
-      mc = take ? oc : mc;                                                   \
-      mi = take ? oi : mi;                                                   \
+  for (int c0 = 0; c0 < steps; c0 += kChunk) {
+    // ---- metric tables (bv:462-485) for steps c0 .. c0+kChunk-1: positions 2*c0 .. 2*c0 + 2*kChunk - 1,
+    //      eight per lane, their loads issued together ----
+    float vv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int p = 2 * c0 + s + 16 * q;
+      float v = 0.0f;
+      if (p < n && live) {
+        if (MODE == FEC_XCCH) {
+          const int B = p & 3, j = 2 * ((49 * p) % 57) + ((p % 8) / 4);   // GSM 05.03 4.1.4 (fec:622-625)
+          v = soft[(size_t)(4 * blk + B) * in_stride + (j < 57 ? 3 + j : 88 + (j - 57))];
+        } else if (MODE == FEC_RACH) {
+          v = soft[(size_t)blk * in_stride + 49 + p];
+        } else {
+          v = soft[(size_t)blk * in_stride + p];
+        }
+      }
+      vv[q] = v;
     }
-    TRX_MIN_STEP(0xB1)                                     // quad_perm [1,0,3,2]
-    TRX_MIN_STEP(0x4E)                                     // quad_perm [2,3,0,1]
-    TRX_MIN_STEP(0x141)                                    // row_half_mirror
-    TRX_MIN_STEP(0x140)                                    // row_mirror
-#undef TRX_MIN_STEP
-    const unsigned long long ob = __builtin_amdgcn_ballot_w64((ist >> kDeferral) & 1u);
-    if (t >= kDeferral) {
-      const int op = t - kDeferral;
-      const unsigned bit = (unsigned)(ob >> ((lane & 48) + mi)) & 1u;
-      if ((op >> 5) == s) outw |= bit << (op & 31);        // lane s collects output bits 32s .. 32s+31
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int p = 2 * c0 + s + 16 * q;
+      float k0 = 0.5F, k1 = 0.5F;                          // past the data: unknowns (bv:481-484)
+      if (p < n && live) {
+        float v = vv[q];
+        if (wire) v = wire_value(v);
+        const bool hard = v > 0.5F;                        // sliced() (bv:424-433)
+        float pVal = v;
+        if (pVal > 0.5F) pVal = 1.0F - pVal;
+        float ipVal = 1.0F - pVal;
+        if (pVal < 0.01F) pVal = (float)0.01;
+        if (ipVal < 0.01F) ipVal = (float)0.01;
+        const float match = 0.25F / ipVal, mismatch = 0.25F / pVal;
+        k0 = hard ? mismatch : match;                      // coder bit 0 mismatches a received 1
+        k1 = hard ? match : mismatch;
+      }
+      K2[s + 16 * q] = make_float2(k0, k1);
     }
+    wave_fence();
+
+    // ---- kChunk trellis steps ----
+    const int tend = (c0 + kChunk < steps) ? c0 + kChunk : steps;
+    for (int t = c0; t < tend; t++) {
+      const float4 k = K[t - c0];                          // {first bit: cost of coder 0, 1; second bit: cost of coder 0, 1}
+      const float cA0 = __shfl(cost, srcA, 64), cB0 = __shfl(cost, srcB, 64);
+      const unsigned iA = (__shfl(ist, srcA, 64) << 1) | (s & 1), iB = (__shfl(ist, srcB, 64) << 1) | (s & 1);
+      const unsigned gA = (unsigned)(kGen >> (2 * (iA & 31))) & 3u, gB = (unsigned)(kGen >> (2 * (iB & 31))) & 3u;
+      // cost += cTab[m&1][1] + cTab[(m>>1)&1][0] (bv:365)
+      const float cA = cA0 + (((gA & 1u) ? k.w : k.z) + ((gA >> 1) ? k.y : k.x));
+      const float cB = cB0 + (((gB & 1u) ? k.w : k.z) + ((gB >> 1) ? k.y : k.x));
+      const bool takeA = cA < cB;                          // pruneCandidates (bv:371-379)
+      cost = takeA ? cA : cB;
+      ist = takeA ? iA : iB;
+      if (t >= kDeferral) {
+        // minCost (bv:382-393): the FIRST survivor with the minimum cost.  The minimum itself by four DPP
+        // exchanges; the lanes that hold it by ballot; the first of them = lowest set bit of the row's mask.
+        float mc = cost;
+        mc = fminf(mc, dpp_f<0xB1>(mc));                   // quad_perm [1,0,3,2]
+        mc = fminf(mc, dpp_f<0x4E>(mc));                   // quad_perm [2,3,0,1]
+        mc = fminf(mc, dpp_f<0x141>(mc));                  // row_half_mirror
+        mc = fminf(mc, dpp_f<0x140>(mc));                  // row_mirror
+        const unsigned long long eq = __builtin_amdgcn_ballot_w64(cost == mc);
+        const unsigned long long ob = __builtin_amdgcn_ballot_w64((ist >> kDeferral) & 1u);
+        const unsigned rowmask = (unsigned)(eq >> (lane & 48)) & 0xFFFFu;
+        const int mi = __builtin_ctz(rowmask | 0x10000u);
+        const int op = t - kDeferral;
+        const unsigned bit = (unsigned)(ob >> ((lane & 48) + mi)) & 1u;
+        if ((op >> 5) == s) outw |= bit << (op & 31);      // lane s collects output bits 32s .. 32s+31
+      }
+    }
+    wave_fence();                                          // table reads done before the next chunk overwrites it
   }
   if (!live) return;
 
@@ -221,12 +236,11 @@ hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long
   if (nblk <= 0) return hipSuccess;
   if (nout <= 0 || nout > 512 || n < 0 || n > 2 * nout) return hipErrorInvalidValue;
   const dim3 grid((nblk + 3) / 4), block(64);
-  const size_t lds = (size_t)4 * (nout + kDeferral) * sizeof(float4);
   if (prof) prof->begin(TRXSIG_K_FEC, st);
   switch (mode) {
-    case FEC_GENERIC: k_fec_viterbi<FEC_GENERIC><<<grid, block, lds, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
-    case FEC_XCCH: k_fec_viterbi<FEC_XCCH><<<grid, block, lds, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
-    case FEC_RACH: k_fec_viterbi<FEC_RACH><<<grid, block, lds, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    case FEC_GENERIC: k_fec_viterbi<FEC_GENERIC><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    case FEC_XCCH: k_fec_viterbi<FEC_XCCH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    case FEC_RACH: k_fec_viterbi<FEC_RACH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
     default: return hipErrorInvalidValue;
   }
   if (prof) prof->end(TRXSIG_K_FEC, st);
