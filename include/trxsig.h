@@ -179,6 +179,9 @@ int trxsig_resample_out_len(int n_in, int P, int Q);
 int trxsig_unpack_int16(trxsig_ctx *ctx, const int16_t *d_iq, int64_t n_samples, int swap_iq,
                         trxsig_c32 *d_out);
 int trxsig_pack_int16(trxsig_ctx *ctx, const trxsig_c32 *d_in, int64_t n_samples, int16_t *d_iq);
+/* scaleVector(x, gain) + USRPifyVector in one pass: the tail of RadioInterface::pushBuffer
+ *   (radioInterface.cpp:149-152; the reference uses gain = 13500.0). */
+int trxsig_pack_int16_scaled(trxsig_ctx *ctx, const trxsig_c32 *d_in, int64_t n_samples, float gain, int16_t *d_iq);
 /* IEEE binary16 I/Q pairs (the sample storage format of BASELINE config 5) -> float.  The reference has
  * no such format (its radio side is int16, radioInterface.cpp:74-116); widening is exact, so results
  * downstream equal the float pipeline's on the same values.  d_iq: 2*n_samples binary16 values. */

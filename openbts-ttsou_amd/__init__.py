@@ -70,6 +70,7 @@ def lib():
         L.trxsig_unpack_int16.argtypes = [vp, vp, C.c_int64, i32, vp]
         L.trxsig_pack_int16.argtypes = [vp, vp, C.c_int64, vp]
         L.trxsig_unpack_half.argtypes = [vp, vp, C.c_int64, vp]
+        L.trxsig_pack_int16_scaled.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
         L.trxsig_fec_xcch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.trxsig_fec_rach_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.trxsig_fec_viterbi_batch.argtypes = [vp, vp, i32, C.c_int64, i32, vp, C.c_int64]
@@ -279,6 +280,9 @@ class TrxSig:
 
     def unpack_half(self, iq, n, out):
         self._chk(self.L.trxsig_unpack_half(self.h, _ptr(iq), n, _ptr(out)), "trxsig_unpack_half")
+
+    def pack_int16_scaled(self, x, n, gain, iq):
+        self._chk(self.L.trxsig_pack_int16_scaled(self.h, _ptr(x), n, float(gain), _ptr(iq)), "trxsig_pack_int16_scaled")
 
     def pack_int16(self, x, n, iq):
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")

@@ -426,6 +426,13 @@ int trxsig_unpack_int16(trxsig_ctx *c, const int16_t *d_iq, int64_t n, int swap_
   HIPCHK(c, trx_launch_convert(c->stream, 0, d_iq, n, swap_iq, d_out, c->prof));
   return TRXSIG_OK;
 }
+int trxsig_pack_int16_scaled(trxsig_ctx *c, const trxsig_c32 *d_in, int64_t n, float gain, int16_t *d_iq) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n < 0 || (n > 0 && (!d_iq || !d_in))) return fail(c, TRXSIG_EINVAL, "trxsig_pack_int16_scaled: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_convert(c->stream, 1, d_in, n, 0, d_iq, c->prof, gain));
+  return TRXSIG_OK;
+}
 int trxsig_unpack_half(trxsig_ctx *c, const uint16_t *d_iq, int64_t n, trxsig_c32 *d_out) {
   if (!c) return TRXSIG_EINVAL;
   if (n < 0 || (n > 0 && (!d_iq || !d_out))) return fail(c, TRXSIG_EINVAL, "trxsig_unpack_half: bad argument");

@@ -1679,9 +1679,13 @@ __global__ __launch_bounds__(256) void k_unpack_f16(const __half2 *__restrict__ 
     out[i] = mk(v.x, v.y);
   }
 }
-__global__ __launch_bounds__(256) void k_pack_i16(const cx *__restrict__ in, long long n, short2 *__restrict__ iq) {
+// gain != 1: scaleVector(x, gain) first (RadioInterface::pushBuffer, radioInterface.cpp:149: 13500.0).  The
+// reference multiplies by the complex (gain, 0): x.r*gain - x.i*0 and x.r*0 + x.i*gain, which for finite
+// samples equal x.r*gain and x.i*gain up to the sign of a zero, and the sign is lost in the cast.
+__global__ __launch_bounds__(256) void k_pack_i16(const cx *__restrict__ in, long long n, float gain, short2 *__restrict__ iq) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const cx v = in[i];
+    cx v = in[i];
+    if (gain != 1.0f) v = mk(v.r * gain, v.i * gain);
     short2 o;
     o.x = (short)(int)v.r;                                 // (short)itr->real(): truncation toward zero
     o.y = (short)(int)v.i;
@@ -2776,13 +2780,13 @@ hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long lo
 }
 
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
-                              TrxProfiler *prof) {
+                              TrxProfiler *prof, float gain) {
   if (n <= 0) return hipSuccess;
   long long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (prof) prof->begin(TRXSIG_K_CONVERT, st);
   if (pack == 2) k_unpack_f16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const __half2 *)in, n, (trx_c32 *)out);
-  else if (pack) k_pack_i16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const trx_c32 *)in, n, (short2 *)out);
+  else if (pack) k_pack_i16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const trx_c32 *)in, n, gain, (short2 *)out);
   else k_unpack_i16<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const short2 *)in, n, swap, (trx_c32 *)out);
   if (prof) prof->end(TRXSIG_K_CONVERT, st);
   return hipGetLastError();

@@ -58,7 +58,7 @@ hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long lo
                                TrxProfiler *prof);
 // pack: 0 = int16 I/Q -> complex float (swap: I/Q flipped), 1 = complex float -> int16 I/Q, 2 = fp16 I/Q -> complex float
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
-                              TrxProfiler *prof);
+                              TrxProfiler *prof, float gain = 1.0f /* pack == 1: scaleVector before the cast */);
 
 // sps = 1 equaliser path; xd: B x xstride complex scratch (xstride >= 157), toa_eq: B floats scratch,
 // w: B x 7, bq: B x 5 complex

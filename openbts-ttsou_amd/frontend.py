@@ -74,3 +74,67 @@ class RxFrontEnd:
         length = np.tile(lens, self.S)
         tnv = np.tile(np.array(tns, np.int32), self.S)
         return (used.view(-1, 2), torch.from_numpy(off).to(self.dev), torch.from_numpy(length).to(self.dev), tnv)
+
+
+INCHUNK_SYM = 65 * 9            # per sps: INCHUNK = INRATE*9 with INRATE = 65*sps (radioInterface.h)
+
+
+class TxBackEnd:
+    """Transmit back-end for S independent ARFCN streams: the data movement of RadioInterface::pushBuffer
+    (Transceiver/radioInterface.cpp:123-194) around libtrxsig's kernels -- modulated bursts are appended
+    to the send buffer; whenever it holds at least INCHUNK = 585*sps samples, [INHISTORY history | whole
+    chunks] goes through polyphaseResampleVector(P = 96, Q = 65*sps, sendLPF), scaleVector(gain) and
+    USRPifyVector, and the first OUTHISTORY outputs are dropped.  Numerics in the library; this class
+    only concatenates and slices device buffers."""
+
+    def __init__(self, ctx, n_streams, lpf_taps, gain=13500.0, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.S = n_streams
+        self.sps = ctx.sps
+        self.Q = 65 * self.sps
+        self.inchunk = INCHUNK_SYM * self.sps
+        self.inhistory = 2 * self.Q
+        self.gain = float(gain)
+        self.dev = torch.device(device)
+        self.lpf = torch.as_tensor(np.ascontiguousarray(lpf_taps, np.float32)).to(self.dev)
+        self.hist = torch.zeros(self.S, self.inhistory, 2, dtype=torch.float32, device=self.dev)
+        self.send = torch.zeros(self.S, 0, 2, dtype=torch.float32, device=self.dev)
+
+    def push_bursts(self, bits, guard, gain=None):
+        """bits: uint8 [S, nb, 148]; guard: int32 [nb] guard symbols per burst (same schedule on every stream);
+        gain: optional float32 [S, nb] (addRadioVector's power scaling).  modulateBurst for all of them."""
+        torch = self.torch
+        S, nb = bits.shape[0], bits.shape[1]
+        assert S == self.S
+        guard = np.ascontiguousarray(guard, np.int32)
+        lens = (self.sps * (148 + guard)).astype(np.int64)
+        tot = int(lens.sum())
+        off1 = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        off = (np.arange(S)[:, None] * tot + off1[None, :]).astype(np.int32).ravel()
+        out = torch.zeros(S, tot, 2, dtype=torch.float32, device=self.dev)
+        d_bits = torch.as_tensor(np.ascontiguousarray(bits, np.uint8).reshape(S * nb, 148)).to(self.dev)
+        d_guard = torch.from_numpy(np.tile(guard, S)).to(self.dev)
+        d_gain = None if gain is None else torch.as_tensor(np.ascontiguousarray(gain, np.float32).ravel()).to(self.dev)
+        self.ctx.modulate(d_bits, d_guard, out, torch.from_numpy(off).to(self.dev), gain=d_gain)
+        self.send = torch.cat([self.send, out], dim=1)
+
+    def pop_samples(self):
+        """int16 tensor [S, n, 2] for the radio (96/(65*sps) samples per modulator sample), or None while
+        less than one chunk is buffered."""
+        torch = self.torch
+        nch = self.send.shape[1] // self.inchunk
+        if nch == 0:
+            return None
+        ntr = nch * self.inchunk
+        inp = torch.cat([self.hist, self.send[:, :ntr]], dim=1).contiguous()        # [S, INHISTORY + ntr, 2]
+        n_in = inp.shape[1]
+        n_out = self.ctx.resample_out_len(n_in, OUTRATE, self.Q)
+        res = torch.zeros(self.S, n_out, 2, dtype=torch.float32, device=self.dev)
+        self.ctx.resample(inp, n_in, n_in, self.S, OUTRATE, self.Q, self.lpf, res, n_out)
+        iq = torch.zeros(self.S, n_out, 2, dtype=torch.int16, device=self.dev)
+        self.ctx.pack_int16_scaled(res, self.S * n_out, self.gain, iq)
+        self.hist = self.send[:, ntr - self.inhistory:ntr].clone()
+        self.send = self.send[:, ntr:].contiguous()
+        return iq[:, OUTHISTORY:]
