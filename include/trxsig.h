@@ -241,12 +241,23 @@ int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *
  * RACH (GSML1FEC.cpp:475-514): one access burst per entry, e = burst[49..84]; decode 36 -> 18;
  *   d_tail_ok = the four tail bits are zero; d_bsic = the BSIC the parity word encodes (the caller
  *   compares it with its own, :493); d_ra = the 8-bit RA.
+ * TCH/FACCH full rate (GSML1FEC.cpp:1030-1163): n_bursts consecutive bursts of one traffic channel; block m
+ *   (m < n_bursts/4 - 1) spans bursts 4m..4m+7 through the diagonal deinterleaver.  d_tch: 33 octets per
+ *   block = d[260] in GSM 05.03 order packed MSB first (the fixed g610BitOrder permutation into the
+ *   vocoder frame is left to the caller); d_tch_good = class-1a parity and tail bits check (decodeTCH's
+ *   `good` for a frame that is not stolen); d_stolen = the Hl stealing flag of the block's last burst;
+ *   d_facch / d_facch_ok (optional, both or neither) = the XCCH decode of the same block, which the
+ *   reference runs when the frame is stolen.  Bad-frame substitution (GSM 06.11, uses random()) stays
+ *   with the caller.
  * Generic: n_blocks independent SoftVector::decode runs, n_soft (even, <= 1024) values in, n_soft/2 bits out
  *   (one per byte). */
 int trxsig_fec_xcch_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_blocks,
                                  int wire_quantise, uint8_t *d_frames, uint8_t *d_ok);
 int trxsig_fec_rach_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_bursts,
                                  int wire_quantise, uint8_t *d_tail_ok, uint8_t *d_bsic, uint8_t *d_ra);
+int trxsig_fec_tch_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_bursts,
+                                int wire_quantise, uint8_t *d_tch, uint8_t *d_tch_good, uint8_t *d_facch,
+                                uint8_t *d_facch_ok, uint8_t *d_stolen);
 int trxsig_fec_viterbi_batch(trxsig_ctx *ctx, const float *d_soft, int n_soft, int64_t in_stride, int n_blocks,
                              uint8_t *d_bits, int64_t out_stride);
 

@@ -73,6 +73,7 @@ def lib():
         L.trxsig_pack_int16_scaled.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
         L.trxsig_fec_xcch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.trxsig_fec_rach_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.trxsig_fec_tch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.trxsig_fec_viterbi_batch.argtypes = [vp, vp, i32, C.c_int64, i32, vp, C.c_int64]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
@@ -273,6 +274,11 @@ class TrxSig:
         self._chk(self.L.trxsig_fec_rach_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_bursts,
                                                       int(wire), _ptr(tail_ok), _ptr(bsic), _ptr(ra)),
                   "trxsig_fec_rach_decode_batch")
+
+    def fec_tch_decode(self, soft, n_bursts, tch, tch_good, stolen, facch=None, facch_ok=None, wire=True, soft_stride=None):
+        self._chk(self.L.trxsig_fec_tch_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_bursts, int(wire),
+                                                     _ptr(tch), _ptr(tch_good), _ptr(facch), _ptr(facch_ok), _ptr(stolen)),
+                  "trxsig_fec_tch_decode_batch")
 
     def fec_viterbi(self, soft, n_soft, n_blocks, bits, in_stride=None, out_stride=None):
         self._chk(self.L.trxsig_fec_viterbi_batch(self.h, _ptr(soft), n_soft, in_stride or soft.shape[-1], n_blocks,

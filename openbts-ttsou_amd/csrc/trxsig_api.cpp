@@ -611,6 +611,22 @@ int trxsig_fec_rach_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_st
   HIPCHK(c, trx_launch_fec(c->stream, 2, d_soft, soft_stride, 36, 18, n_bursts, wire, d_tail_ok, d_bsic, d_ra, 0, c->prof));
   return TRXSIG_OK;
 }
+int trxsig_fec_tch_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_bursts, int wire,
+                                uint8_t *d_tch, uint8_t *d_tch_good, uint8_t *d_facch, uint8_t *d_facch_ok,
+                                uint8_t *d_stolen) {
+  if (!c) return TRXSIG_EINVAL;
+  const int nblk = n_bursts / 4 - 1;
+  if (n_bursts < 0 || soft_stride < 148 || (nblk > 0 && (!d_soft || !d_tch || !d_tch_good || !d_stolen)) ||
+      ((d_facch == nullptr) != (d_facch_ok == nullptr)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_fec_tch_decode_batch: bad argument");
+  if (nblk <= 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_fec(c->stream, 3, d_soft, soft_stride, 378, 189, nblk, wire, d_tch, d_tch_good, d_stolen, 0, c->prof));
+  if (d_facch)
+    HIPCHK(c, trx_launch_fec(c->stream, 1, d_soft, soft_stride, 456, 228, nblk, wire, d_facch, d_facch_ok, nullptr, 0,
+                             c->prof, 1));
+  return TRXSIG_OK;
+}
 int trxsig_fec_viterbi_batch(trxsig_ctx *c, const float *d_soft, int n_soft, int64_t in_stride, int n_blocks,
                              uint8_t *d_bits, int64_t out_stride) {
   if (!c) return TRXSIG_EINVAL;

@@ -69,6 +69,21 @@ struct RachPar {
     }
   }
 };
+struct TchPar {                                            // encoderShift response, 50 bits, generator 0x0b (3 bits)
+  unsigned v[50];
+  constexpr TchPar() : v() {
+    for (int i = 0; i < 50; i++) {
+      unsigned st = 0;
+      for (int k = 0; k < 50; k++) {
+        const unsigned fb = ((st >> 2) ^ (k == i ? 1u : 0u)) & 1u;
+        st <<= 1;
+        if (fb) st ^= 0x0bu;
+      }
+      v[i] = st & 7u;
+    }
+  }
+};
+__device__ __constant__ const TchPar kTchPar;
 __device__ __constant__ const XcchSyn kXcchSyn;
 __device__ __constant__ const RachPar kRachPar;
 
@@ -89,15 +104,19 @@ __device__ __forceinline__ float wire_value(float v) {
   return (float)(unsigned char)q / 256.0F;                 // TRXManager.cpp:231
 }
 
-enum { FEC_GENERIC = 0, FEC_XCCH = 1, FEC_RACH = 2 };
+enum { FEC_GENERIC = 0, FEC_XCCH = 1, FEC_RACH = 2, FEC_TCH = 3 };
 
 // MODE FEC_GENERIC: block b reads soft[b*in_stride + p], p < n, and writes nout bits as bytes to out0 + b*out_stride.
 // MODE FEC_XCCH   : block b = bursts 4b..4b+3 of soft[burst*in_stride + 0..147]; c[k] = i[k%4][j(k)] with the
 //                   e-bits at 3..59 and 88..144 (fec:607-608, 618-629); out0 = 23 octets per block, out1 = ok.
 // MODE FEC_RACH   : block b = burst b, e = burst[49..85) (fec:479); out0 = tail ok, out1 = BSIC, out2 = RA.
+// MODE FEC_TCH    : block b = bursts 4b..4b+7 (diagonal deinterleaver, fec:1108-1116), class 1 = c[0..378) decoded,
+//                   class 2 = c[378..456) sliced (fec:1133-1163); out0 = d[260] packed MSB first (33 octets),
+//                   out1 = good (parity of class 1a and tail), out2 = stolen (Hl of the block's last burst, fec:1077).
+// ilv8 (FEC_XCCH only): read c[] through the TCH deinterleaver instead -- the FACCH decode of a stolen block.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ soft, long long in_stride, int n, int nout,
-                                                    int nblk, int wire, uint8_t *__restrict__ out0,
+                                                    int nblk, int wire, int ilv8, uint8_t *__restrict__ out0,
                                                     uint8_t *__restrict__ out1, uint8_t *__restrict__ out2,
                                                     long long out_stride) {
   // costs of coder bit 0/1 for both bits of a step, kChunk steps at a time: a small table keeps 8 waves
@@ -122,8 +141,9 @@ __global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ so
       const int p = 2 * c0 + s + 16 * q;
       float v = 0.0f;
       if (p < n && live) {
-        if (MODE == FEC_XCCH) {
-          const int B = p & 3, j = 2 * ((49 * p) % 57) + ((p % 8) / 4);   // GSM 05.03 4.1.4 (fec:622-625)
+        if (MODE == FEC_XCCH || MODE == FEC_TCH) {
+          const int B = (MODE == FEC_TCH || ilv8) ? (p & 7) : (p & 3);      // burst within the block
+          const int j = 2 * ((49 * p) % 57) + ((p % 8) / 4);                // GSM 05.03 4.1.4 / 3.1.3 (fec:622-625, 1111)
           v = soft[(size_t)(4 * blk + B) * in_stride + (j < 57 ? 3 + j : 88 + (j - 57))];
         } else if (MODE == FEC_RACH) {
           v = soft[(size_t)blk * in_stride + 49 + p];
@@ -215,6 +235,39 @@ __global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ so
     lo ^= (unsigned)dpp_i<0x141>((int)lo); hi ^= (unsigned)dpp_i<0x141>((int)hi);
     lo ^= (unsigned)dpp_i<0x140>((int)lo); hi ^= (unsigned)dpp_i<0x140>((int)hi);
     if (s == 0) out1[blk] = (lo | hi) == 0;
+  } else if (MODE == FEC_TCH) {
+    // u[189] -> LDS (word w = bits 32w..32w+31), then d[] (fec:1141-1146) octet by octet
+    unsigned *uw = reinterpret_cast<unsigned *>(ktab[row]);
+    if (s < 6) uw[s] = outw;
+    wave_fence();
+    auto ubit = [&](int i) { return (uw[i >> 5] >> (i & 31)) & 1u; };
+    auto cbit = [&](int k) {                               // class 2: c[k] sliced, k >= 378
+      const int j = 2 * ((49 * k) % 57) + ((k % 8) / 4);
+      float v = soft[(size_t)(4 * blk + (k & 7)) * in_stride + (j < 57 ? 3 + j : 88 + (j - 57))];
+      if (wire) v = wire_value(v);
+      return v > 0.5F ? 1u : 0u;
+    };
+    auto dbit = [&](int q) -> unsigned {
+      if (q >= 260) return 0u;
+      if (q >= 182) return cbit(378 + q - 182);
+      const int k = q >> 1;
+      return (q & 1) ? ubit(184 - k) : ubit(k);
+    };
+    for (int o = s; o < 33; o += 16) {
+      unsigned byte = 0;
+      for (int q = 0; q < 8; q++) byte = (byte << 1) | dbit(8 * o + q);
+      out0[(size_t)blk * 33 + o] = (uint8_t)byte;
+    }
+    if (s == 0) {
+      unsigned calc = 0;
+      for (int i = 0; i < 50; i++) if (dbit(i)) calc ^= kTchPar.v[i];
+      const unsigned sent = (~((ubit(91) << 2) | (ubit(92) << 1) | ubit(93))) & 7u;      // peekField(91,3)
+      const unsigned tail = ubit(185) | ubit(186) | ubit(187) | ubit(188);
+      out1[blk] = (sent == calc) && (tail == 0);
+      float hl = soft[(size_t)(4 * blk + 7) * in_stride + 60];
+      if (wire) hl = wire_value(hl);
+      out2[blk] = hl > 0.5F;
+    }
   } else {
     if (s == 0) {
       const unsigned u = outw;                             // bit k = u[k]
@@ -232,15 +285,17 @@ __global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ so
 }  // namespace
 
 hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long in_stride, int n, int nout, int nblk,
-                          int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof) {
+                          int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof,
+                          int ilv8) {
   if (nblk <= 0) return hipSuccess;
   if (nout <= 0 || nout > 512 || n < 0 || n > 2 * nout) return hipErrorInvalidValue;
   const dim3 grid((nblk + 3) / 4), block(64);
   if (prof) prof->begin(TRXSIG_K_FEC, st);
   switch (mode) {
-    case FEC_GENERIC: k_fec_viterbi<FEC_GENERIC><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
-    case FEC_XCCH: k_fec_viterbi<FEC_XCCH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
-    case FEC_RACH: k_fec_viterbi<FEC_RACH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, out0, out1, out2, out_stride); break;
+    case FEC_GENERIC: k_fec_viterbi<FEC_GENERIC><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, ilv8, out0, out1, out2, out_stride); break;
+    case FEC_XCCH: k_fec_viterbi<FEC_XCCH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, ilv8, out0, out1, out2, out_stride); break;
+    case FEC_RACH: k_fec_viterbi<FEC_RACH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, ilv8, out0, out1, out2, out_stride); break;
+    case FEC_TCH: k_fec_viterbi<FEC_TCH><<<grid, block, 0, st>>>(soft, in_stride, n, nout, nblk, wire, ilv8, out0, out1, out2, out_stride); break;
     default: return hipErrorInvalidValue;
   }
   if (prof) prof->end(TRXSIG_K_FEC, st);

@@ -74,4 +74,6 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
 // burst): out0 = 23 octets per block, out1 = parity ok; mode 2: RACH (one burst per block): out0 = tail ok,
 // out1 = BSIC, out2 = RA.  wire != 0: the UDP hop's 8-bit quantisation of the soft values first.
 hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long in_stride, int n, int nout, int nblk,
-                          int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof);
+                          int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof,
+                          int ilv8 = 0 /* mode 1 through the 8-burst TCH deinterleaver (FACCH); mode 3 = TCH: out0 = 33
+                                          octets of d[260], out1 = good, out2 = stolen */);

@@ -191,6 +191,21 @@ int fo_rach_decode(const float *e36, uint8_t *u18, unsigned *bsic, unsigned *ra)
   return tail_ok;
 }
 
+/* TCHFACCHL1Decoder::decodeTCH(stolen = false) up to `good` (fec:1133-1163): class 1 = c[0..378) through the
+   Viterbi decoder, class 2 = c[378..456) sliced; d[] reassembled; 3-bit parity (0x0b) over class 1a; tail */
+int fo_tch_decode(const float *c456, uint8_t *u189, uint8_t *d260) {
+  uint8_t u[189], d[260];
+  fo_viterbi_decode(c456, 378, u, 189);
+  for (int i = 0; i < 78; i++) d[182 + i] = c456[378 + i] > 0.5F;
+  for (int k = 0; k <= 90; k++) { d[2 * k] = u[k]; d[2 * k + 1] = u[184 - k]; }
+  const unsigned sent = (~(unsigned)peek(u, 91, 3)) & 7u;
+  const unsigned calc = (unsigned)fo_parity(0x0b, 3, d, 50) & 7u;
+  const unsigned tail = (unsigned)peek(u, 185, 4);
+  if (u189) memcpy(u189, u, 189);
+  memcpy(d260, d, 260);
+  return sent == calc && tail == 0;
+}
+
 /* ---- batch forms over the burst path's output layout: soft[b][stride], 148 soft bits per burst ---- */
 
 /* nblk blocks of four consecutive bursts.  wire != 0: the UDP quantisation in between.  frames: 23
@@ -222,5 +237,42 @@ void fo_rach_decode_batch(const float *soft, int stride, int n, int wire, uint8_
     out3[3 * b] = (uint8_t)fo_rach_decode(e, NULL, &bsic, &ra);
     out3[3 * b + 1] = (uint8_t)bsic;
     out3[3 * b + 2] = (uint8_t)ra;
+  }
+}
+
+/* TCH/FACCH (fec:1030-1120): block m = bursts 4m .. 4m+7 of a traffic channel in arrival order, diagonal
+   deinterleaver c[k] = i[(k + blockOffset) % 8][j(k)] (fec:1108-1116), which for consecutive bursts is burst
+   4m + k%8.  nblk = nbursts/4 - 1.  Per block: tch[33] = d[260] packed MSB first (GSM 05.03 order, i.e. before
+   the g610BitOrder unmap), tch_good; facch[23] + facch_ok = XCCH decode of the same c[] (what the reference
+   runs when the frame is stolen); stolen = Hl (soft bit 60, fec:1077) of the block's last burst */
+void fo_tch_decode_batch(const float *soft, int stride, int nbursts, int wire, uint8_t *tch, uint8_t *tch_good,
+                         uint8_t *facch, uint8_t *facch_ok, uint8_t *stolen, int nthreads) {
+  const int nblk = nbursts / 4 - 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int m = 0; m < nblk; m++) {
+    float c[456];
+    for (int k = 0; k < 456; k++) {
+      const int j = 2 * ((49 * k) % 57) + ((k % 8) / 4);
+      const float v = soft[(size_t)(4 * m + k % 8) * stride + (j < 57 ? 3 + j : 88 + (j - 57))];
+      c[k] = wire ? fo_wire(v) : v;
+    }
+    uint8_t d[260], u[228], dd[184];
+    tch_good[m] = (uint8_t)fo_tch_decode(c, NULL, d);
+    for (int o = 0; o < 33; o++) {
+      unsigned b = 0;
+      for (int q = 0; q < 8; q++) b = (b << 1) | (8 * o + q < 260 ? d[8 * o + q] : 0u);
+      tch[m * 33 + o] = (uint8_t)b;
+    }
+    /* XCCHL1Decoder::decode on the same c[] (fec:1079-1089) */
+    fo_viterbi_decode(c, 456, u, 228);
+    uint8_t dp[224];
+    memcpy(dp, u, 224);
+    for (int i = 184; i < 224; i++) dp[i] ^= 1u;
+    facch_ok[m] = fo_syndrome(0x10004820009ULL, 40, dp, 224) == 0;
+    memcpy(dd, u, 184);
+    fo_lsb8msb(dd, 184);
+    for (int o = 0; o < 23; o++) facch[m * 23 + o] = (uint8_t)peek(dd, 8 * o, 8);
+    const float hl = soft[(size_t)(4 * m + 7) * stride + 60];
+    stolen[m] = (wire ? fo_wire(hl) : hl) > 0.5F;
   }
 }

@@ -20,6 +20,9 @@ void fo_lsb8msb(uint8_t *bits, int n);
 float fo_wire(float v);
 int fo_xcch_decode(const float *i4x114, uint8_t *u228, uint8_t *d184, uint64_t *syn);
 int fo_rach_decode(const float *e36, uint8_t *u18, unsigned *bsic, unsigned *ra);
+int fo_tch_decode(const float *c456, uint8_t *u189, uint8_t *d260);
+void fo_tch_decode_batch(const float *soft, int stride, int nbursts, int wire, uint8_t *tch, uint8_t *tch_good,
+                         uint8_t *facch, uint8_t *facch_ok, uint8_t *stolen, int nthreads);
 void fo_xcch_decode_batch(const float *soft, int stride, int nblk, int wire, uint8_t *frames, uint8_t *ok, int nthreads);
 void fo_rach_decode_batch(const float *soft, int stride, int n, int wire, uint8_t *out3, int nthreads);
 

@@ -23,6 +23,8 @@ class FecOracle:
         L.fo_wire.argtypes = [C.c_float]; L.fo_wire.restype = C.c_float
         L.fo_xcch_decode.argtypes = [f32p, u8p, u8p, C.POINTER(C.c_uint64)]
         L.fo_rach_decode.argtypes = [f32p, u8p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.fo_tch_decode.argtypes = [f32p, u8p, u8p]
+        L.fo_tch_decode_batch.argtypes = [f32p, C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, C.c_int]
         L.fo_xcch_decode_batch.argtypes = [f32p, C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_int]
         L.fo_rach_decode_batch.argtypes = [f32p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
 
@@ -63,6 +65,19 @@ class FecOracle:
         u = np.zeros(18, np.uint8); bsic = C.c_uint(); ra = C.c_uint()
         t = self.lib.fo_rach_decode(np.ascontiguousarray(e36, np.float32), u, C.byref(bsic), C.byref(ra))
         return dict(tail_ok=bool(t), u=u, bsic=int(bsic.value), ra=int(ra.value))
+
+    def tch_decode(self, c456):
+        u = np.zeros(189, np.uint8); d = np.zeros(260, np.uint8)
+        good = self.lib.fo_tch_decode(np.ascontiguousarray(c456, np.float32), u, d)
+        return dict(good=bool(good), u=u, d=d)
+
+    def tch_decode_batch(self, soft, wire=True, nthreads=8):
+        soft = np.ascontiguousarray(soft, np.float32)
+        nblk = soft.shape[0] // 4 - 1
+        tch = np.zeros((nblk, 33), np.uint8); good = np.zeros(nblk, np.uint8)
+        facch = np.zeros((nblk, 23), np.uint8); fok = np.zeros(nblk, np.uint8); stolen = np.zeros(nblk, np.uint8)
+        self.lib.fo_tch_decode_batch(soft, soft.shape[1], soft.shape[0], int(wire), tch, good, facch, fok, stolen, nthreads)
+        return dict(tch=tch, good=good, facch=facch, facch_ok=fok, stolen=stolen)
 
     def xcch_decode_batch(self, soft, wire=True, nthreads=8):
         soft = np.ascontiguousarray(soft, np.float32)

@@ -425,6 +425,18 @@ def gen_fec():
     kw.update(rach_ra=ra, rach_bsic=bsic, rach_e=e, rach_u=np.stack([x["u"] for x in rr]),
               rach_tail_ok=np.array([x["tail_ok"] for x in rr]), rach_bsic_out=np.array([x["bsic"] for x in rr]),
               rach_ra_out=np.array([x["ra"] for x in rr]))
+    # --- TCH/FS: class-1 Viterbi + class-2 slicing + 3-bit parity, from the reference's decodeTCH steps
+    nt = 64
+    td = rng.integers(0, 2, (nt, 260)).astype(np.uint8)
+    tc = np.stack([r.tch_encode(td[i]) for i in range(nt)]).astype(np.float32)
+    tsg = np.array([0.0, 0.1, 0.2, 0.3, 0.45, 0.7, 1.5, 0.0])[np.arange(nt) % 8]
+    tsoft = np.clip(tc * 0.8 + 0.1 + rng.normal(0, 1, tc.shape) * tsg[:, None], 0, 1).astype(np.float32)
+    tsoft[7] = 0.5
+    tw = (np.arange(nt) % 3) == 1
+    tsoft[tw] = wire(tsoft[tw])
+    tr = [r.tch_decode(tsoft[i]) for i in range(nt)]
+    kw.update(tch_d=td, tch_soft=tsoft, tch_good=np.array([x["good"] for x in tr]),
+              tch_u=np.stack([x["u"] for x in tr]), tch_dout=np.stack([x["d"] for x in tr]))
     # --- bare Viterbi runs
     mc = np.array([int(c) for c in BITVECTORTEST_MC], np.uint8)
     kw.update(kat_c=mc, kat_u=r.soft_decode(mc.astype(np.float32), len(mc) // 2))

@@ -121,4 +121,48 @@ int reffec_rach_decode(const float *e36, unsigned char *u18, unsigned *bsic, uns
   return tail_ok;
 }
 
+// TCHFACCHL1Encoder::encodeTCH (GSML1FEC.cpp:1251-1284) from d[260] in GSM 05.03 order (i.e. after the
+// g610BitOrder map, which is a fixed permutation left to the caller): -> c[456]
+void reffec_tch_encode(const unsigned char *d260, unsigned char *c456) {
+  Parity tchParity(0x0b, 3, 50);
+  ViterbiR2O4 coder;
+  BitVector mC(456), mTCHU(189), mTCHD(260);
+  BitVector mClass1_c(mC.head(378)), mClass1A_d(mTCHD.head(50)), mClass2_d(mTCHD.segment(182, 78));
+  for (int i = 0; i < 260; i++) mTCHD[i] = d260[i] & 0x01;
+  BitVector p = mTCHU.segment(91, 3);
+  tchParity.writeParityWord(mClass1A_d, p);
+  for (unsigned k = 0; k <= 90; k++) {
+    mTCHU[k] = mTCHD[2 * k];
+    mTCHU[184 - k] = mTCHD[2 * k + 1];
+  }
+  for (unsigned k = 185; k <= 188; k++) mTCHU[k] = 0;
+  mTCHU.encode(coder, mClass1_c);
+  mClass2_d.copyToSegment(mC, 378);
+  for (int i = 0; i < 456; i++) c456[i] = mC[i] & 0x01;
+}
+
+// TCHFACCHL1Decoder::decodeTCH(stolen = false) up to `good` (GSML1FEC.cpp:1133-1163): c[456] soft ->
+// u[189], d[260]; returns good
+int reffec_tch_decode(const float *c456, unsigned char *u189, unsigned char *d260) {
+  Parity tchParity(0x0b, 3, 50);
+  ViterbiR2O4 coder;
+  SoftVector mC(456);
+  for (int i = 0; i < 456; i++) mC[i] = c456[i];
+  BitVector mTCHU(189), mTCHD(260);
+  SoftVector mClass1_c(mC.head(378)), mClass2_c(mC.segment(378, 78));
+  BitVector mClass1A_d(mTCHD.head(50));
+  mClass1_c.decode(coder, mTCHU);
+  mClass2_c.sliced().copyToSegment(mTCHD, 182);
+  for (unsigned k = 0; k <= 90; k++) {
+    mTCHD[2 * k] = mTCHU[k];
+    mTCHD[2 * k + 1] = mTCHU[184 - k];
+  }
+  const unsigned sentParity = (~mTCHU.peekField(91, 3)) & 0x07;
+  const unsigned calcParity = mClass1A_d.parity(tchParity) & 0x07;
+  const unsigned tail = mTCHU.peekField(185, 4);
+  for (int i = 0; i < 189; i++) u189[i] = mTCHU[i] & 0x01;
+  for (int i = 0; i < 260; i++) d260[i] = mTCHD[i] & 0x01;
+  return (sentParity == calcParity) && (tail == 0);
+}
+
 }  // extern "C"

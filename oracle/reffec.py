@@ -28,6 +28,18 @@ class RefFec:
         L.reffec_xcch_encode.argtypes = [u8p, u8p]
         L.reffec_xcch_decode.argtypes = [f32p, u8p, u8p, C.POINTER(C.c_uint64)]
         L.reffec_rach_decode.argtypes = [f32p, u8p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.reffec_tch_encode.argtypes = [u8p, u8p]
+        L.reffec_tch_decode.argtypes = [f32p, u8p, u8p]
+
+    def tch_encode(self, d260):
+        out = np.zeros(456, np.uint8)
+        self.lib.reffec_tch_encode(np.ascontiguousarray(d260, np.uint8), out)
+        return out
+
+    def tch_decode(self, c456):
+        u = np.zeros(189, np.uint8); d = np.zeros(260, np.uint8)
+        good = self.lib.reffec_tch_decode(np.ascontiguousarray(c456, np.float32), u, d)
+        return dict(good=bool(good), u=u, d=d)
 
     def soft_decode(self, soft, nout):
         soft = np.ascontiguousarray(soft, np.float32)

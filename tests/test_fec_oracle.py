@@ -45,6 +45,48 @@ def test_golden_rach(o, golden):
         assert r["ra"] == int(g["rach_ra_out"][i]) and np.array_equal(r["u"], g["rach_u"][i]), i
 
 
+def test_golden_tch(o, golden):
+    g = golden("fec.npz")
+    for i in range(len(g["tch_good"])):
+        r = o.tch_decode(g["tch_soft"][i])
+        assert r["good"] == bool(g["tch_good"][i]), i
+        assert np.array_equal(r["u"], g["tch_u"][i]) and np.array_equal(r["d"], g["tch_dout"][i]), i
+    clean = np.flatnonzero(g["tch_good"] & (np.arange(len(g["tch_good"])) % 8 <= 1))
+    assert len(clean) >= 12 and np.array_equal(g["tch_dout"][clean], g["tch_d"][clean])
+    assert 0.3 < g["tch_good"].mean() < 0.9
+
+
+def tch_bursts(rng, c_blocks):
+    """[nblk,456] c[] per block -> [4*(nblk+1),148] bursts through the diagonal interleaver (GSM 05.03 3.1.3):
+    block m sits in the even e-bits of bursts 4m..4m+3 and the odd e-bits of bursts 4m+4..4m+7."""
+    nblk = c_blocks.shape[0]
+    s = rng.random((4 * (nblk + 1), 148)).astype(np.float32)
+    k = np.arange(456)
+    j = 2 * ((49 * k) % 57) + ((k % 8) // 4)
+    pos = np.where(j < 57, 3 + j, 88 + (j - 57))
+    for m in range(nblk):
+        s[4 * m + (k % 8), pos] = c_blocks[m]
+    return s
+
+
+def test_tch_batch_layout(o, golden):
+    g = golden("fec.npz")
+    rng = np.random.default_rng(8)
+    b = tch_bursts(rng, g["tch_soft"])
+    b[:, 60] = (np.arange(len(b)) % 3 == 0) * 0.9                  # Hl stealing flags
+    r = o.tch_decode_batch(b, wire=False, nthreads=2)
+    assert np.array_equal(r["good"].astype(bool), g["tch_good"])
+    assert np.array_equal(np.unpackbits(r["tch"], axis=1)[:, :260], g["tch_dout"])
+    assert np.array_equal(r["stolen"], ((4 * np.arange(len(r["stolen"])) + 7) % 3 == 0).astype(np.uint8))
+    # the FACCH leg is the XCCH decode of the same c[]
+    for m in (0, 5, 17):
+        i4 = np.zeros((4, 114), np.float32)
+        k = np.arange(456)
+        i4[k % 4, 2 * ((49 * k) % 57) + ((k % 8) // 4)] = g["tch_soft"][m]
+        x = o.xcch_decode(i4)
+        assert bool(r["facch_ok"][m]) == x["ok"] and np.array_equal(np.unpackbits(r["facch"][m]), x["d"])
+
+
 def test_batch_layout_and_wire(o, golden):
     """The batch forms read bursts as the transceiver delivers them (148 soft bits, e-bits at 3..59 and
     88..144, RACH payload at 49..84) and model the UDP hop's 8-bit quantisation."""
@@ -88,6 +130,10 @@ def test_random_vs_reference(o):
         e = rng.random(36).astype(np.float32)
         a, b = r.rach_decode(e), o.rach_decode(e)
         assert (a["tail_ok"], a["bsic"], a["ra"]) == (b["tail_ok"], b["bsic"], b["ra"]) and np.array_equal(a["u"], b["u"])
+        d = rng.integers(0, 2, 260).astype(np.uint8)
+        s = np.clip(r.tch_encode(d) * 0.8 + 0.1 + rng.normal(0, rng.choice([0.0, 0.1, 0.3, 0.6]), 456), 0, 1).astype(np.float32)
+        a, b = r.tch_decode(s), o.tch_decode(s)
+        assert a["good"] == b["good"] and np.array_equal(a["u"], b["u"]) and np.array_equal(a["d"], b["d"])
         n = int(rng.integers(1, 230)) * 2
         sv = rng.random(n).astype(np.float32)
         if it % 4 == 0:

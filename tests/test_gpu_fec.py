@@ -158,3 +158,53 @@ def test_end_to_end_burst_to_l2_frame(pkg, t):
     assert ok.sum() >= 0.9 * nblk
     good = np.flatnonzero(ok)
     assert np.array_equal(np.unpackbits(frames[good], axis=1), d[good])
+
+
+def test_tch_facch(t, golden):
+    """TCH/FACCH full rate: 8-burst diagonal deinterleaver, class-1 Viterbi, class-2 slicing, 3-bit parity +
+    tail, stealing flag, and the FACCH (XCCH) decode of the same blocks -- golden vectors of the reference's
+    decodeTCH steps, then random bursts against the oracle with and without the UDP-hop quantisation."""
+    import torch
+    from test_fec_oracle import tch_bursts
+    g = golden("fec.npz")
+    o = fecbind.FecOracle()
+    rng = np.random.default_rng(44)
+
+    def gpu(b, wire):
+        nbl = b.shape[0] // 4 - 1
+        tch = torch.full((nbl, 33), 7, dtype=torch.uint8, device="cuda")
+        outs = [torch.full((nbl,), 7, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        facch = torch.full((nbl, 23), 7, dtype=torch.uint8, device="cuda")
+        t.fec_tch_decode(dev(b.astype(np.float32)), b.shape[0], tch, outs[0], outs[1], facch=facch, facch_ok=outs[2], wire=wire)
+        torch.cuda.synchronize()
+        return dict(tch=tch.cpu().numpy(), good=outs[0].cpu().numpy(), stolen=outs[1].cpu().numpy(),
+                    facch=facch.cpu().numpy(), facch_ok=outs[2].cpu().numpy())
+
+    b = tch_bursts(rng, g["tch_soft"])
+    r = gpu(b, False)
+    assert np.array_equal(r["good"].astype(bool), g["tch_good"])
+    assert np.array_equal(np.unpackbits(r["tch"], axis=1)[:, :260], g["tch_dout"])
+    for wire in (False, True):
+        b = rng.random((4 * 1030 + 3, 148)).astype(np.float32)                 # ragged tail: the last 3 bursts are unused
+        b[rng.random(b.shape) < 0.1] = 0.5
+        # a third of the blocks carry valid TCH frames
+        nblk = b.shape[0] // 4 - 1
+        c = np.zeros((nblk, 456), np.float32)
+        for m in range(nblk):
+            d = rng.integers(0, 2, 260).astype(np.uint8)
+            u = np.zeros(189, np.uint8)
+            u[:91] = d[0:182:2]; u[184:93:-1] = d[1:182:2]
+            par = (~o.parity(0x0b, 3, d[:50])) & 7
+            u[91:94] = [(par >> 2) & 1, (par >> 1) & 1, par & 1]
+            c[m, :378] = o.encode(u); c[m, 378:] = d[182:]
+        valid = np.arange(nblk) % 3 == 0
+        bb = tch_bursts(rng, np.clip(c * 0.8 + 0.1 + rng.normal(0, 0.15, c.shape), 0, 1))
+        mask = np.repeat(valid, 4)
+        # keep the random junk where the block is not valid (both halves of the diagonal)
+        for m in np.flatnonzero(valid):
+            b[4 * m:4 * m + 8] = np.where(np.isin(np.arange(148), np.r_[3:60, 88:145])[None, :], bb[4 * m:4 * m + 8], b[4 * m:4 * m + 8])
+        got = gpu(b, wire)
+        want = o.tch_decode_batch(b, wire=wire, nthreads=8)
+        for k in ("tch", "good", "stolen", "facch", "facch_ok"):
+            assert np.array_equal(got[k], want[k]), (k, wire)
+        assert got["good"][valid].mean() > 0.5
