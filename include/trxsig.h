@@ -68,6 +68,8 @@ int  trxsig_device(const trxsig_ctx *ctx);
 int  trxsig_set_stream(trxsig_ctx *ctx, void *hip_stream);
 /* hipStreamSynchronize on the context's stream */
 int  trxsig_synchronize(trxsig_ctx *ctx);
+void *trxsig_get_stream(trxsig_ctx *ctx);      /* the hipStream_t the context enqueues on */
+int  trxsig_get_device(trxsig_ctx *ctx);
 const char *trxsig_last_error(const trxsig_ctx *ctx);
 /* pre-size the internal device workspace for batches up to max_bursts (allocates; call outside
  * any timed or graph-captured region).  The batch entry points grow it on demand otherwise. */
@@ -164,6 +166,24 @@ int trxsig_demodulate_batch(trxsig_ctx *ctx,
 int trxsig_modulate_batch(trxsig_ctx *ctx, const uint8_t *d_bits, const int32_t *d_guard,
                           const float *d_gain, int B,
                           trxsig_c32 *d_out, const int32_t *d_out_offset);
+
+/* The two halves of trxsig_equalize_normal_batch (declared further down) on their own, for callers that keep the reference's per-timeslot cache
+ * (Transceiver.cpp:317-349: channel estimate + DFE design only on the first burst of a slot or after 50
+ * frames; every burst is then equalised with the cached taps):
+ *   trxsig_estimate_dfe_batch: analyzeTrafficBurst(requestChannel) + scaleVector(chan, 1/amp) + designDFE, no
+ *     energy gate; snr_thresh = the threshold in SNR = |amp|^2/(thr^2+1) (the reference uses mEnergyThreshold
+ *     after its "-= 1" update, :338-340), or snr_value > 0 = the SNR estimate itself for every burst (a caller
+ *     that forms it in the reference's double arithmetic).  d_chan_off = chanRespOffset, d_w: B x 7, d_b: B x 5.
+ *   trxsig_equalize_taps_batch: scaleVector(burst, 1/amp) + equalizeBurst(burst, toa_eq, w, b) with the taps of
+ *     burst b at d_w + 7b, d_b + 5b; d_enable[b] & TRXSIG_F_DETECT selects the bursts to process (zeros otherwise). */
+int trxsig_estimate_dfe_batch(trxsig_ctx *ctx, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                              const int32_t *d_length, int B, int tsc, float detect_thresh, float snr_thresh,
+                              float snr_value, int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                              float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b);
+int trxsig_equalize_taps_batch(trxsig_ctx *ctx, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                               const int32_t *d_length, int B, const trxsig_c32 *d_amp, const float *d_toa_eq,
+                               const uint8_t *d_enable, const trxsig_c32 *d_w, const trxsig_c32 *d_b,
+                               float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
 /* ---- rate conversion: polyphaseResampleVector (sigProcLib.h:352-354) -------------------------
  * S independent streams (one per ARFCN).  Stream s: input d_in + s*in_stride (n_in samples),

@@ -321,3 +321,113 @@ class TrxSig:
         ms = C.c_float()
         self._chk(self.L.trxsig_timer_stop(self.h, C.byref(ms)), "trxsig_timer_stop")
         return ms.value
+
+
+class TrxHost:
+    """ctypes view of include/trxsig_transceiver.h: the per-ARFCN Transceiver orchestration (pullRadioVector,
+    addRadioVector / pushRadioVector, control commands, UDP datagram codecs) on top of the GPU library."""
+
+    def __init__(self, sps, device=0, start=(0, 0)):
+        import numpy as np
+        self.np = np
+        self.L = L = lib()
+        vp, i32 = C.c_void_p, C.c_int
+        L.trxsig_trx_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32]
+        L.trxsig_trx_destroy.argtypes = [vp]; L.trxsig_trx_destroy.restype = None
+        L.trxsig_trx_last_error.argtypes = [vp]; L.trxsig_trx_last_error.restype = C.c_char_p
+        L.trxsig_trx_control.argtypes = [vp, C.c_char_p, C.c_char_p, i32]
+        L.trxsig_trx_expected_corr_type.argtypes = [vp, i32, i32]
+        L.trxsig_trx_pull_radio_vector.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.trxsig_trx_encode_rx_datagram.argtypes = [i32, i32, i32, i32, vp, i32, vp]
+        L.trxsig_trx_decode_tx_datagram.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), vp]
+        L.trxsig_trx_add_radio_vector.argtypes = [vp, vp, i32, i32, i32]
+        L.trxsig_trx_push_radio_vector.argtypes = [vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]
+        L.trxsig_trx_energy_threshold.argtypes = [vp]; L.trxsig_trx_energy_threshold.restype = C.c_double
+        L.trxsig_trx_filler_modulus.argtypes = [vp, i32]
+        L.trxsig_trx_queue_size.argtypes = [vp]
+        L.trxsig_create_lpf_host.argtypes = [vp, i32, C.c_float, vp]
+        self.sps = sps
+        self.h = vp()
+        rc = L.trxsig_trx_create(C.byref(self.h), device, sps, start[0], start[1])
+        if rc != 0:
+            raise RuntimeError("trxsig_trx_create failed: %d" % rc)
+
+    def close(self):
+        if self.h:
+            self.L.trxsig_trx_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise RuntimeError("%s: %d (%s)" % (what, rc, self.L.trxsig_trx_last_error(self.h).decode()))
+        return rc
+
+    def control(self, msg):
+        buf = C.create_string_buffer(128)
+        self._chk(self.L.trxsig_trx_control(self.h, msg.encode(), buf, 128), "trxsig_trx_control")
+        return buf.value.decode()
+
+    def expected_corr_type(self, tn, fn):
+        return self.L.trxsig_trx_expected_corr_type(self.h, tn, fn)
+
+    def pull_radio_vector(self, x, tn, fn):
+        np = self.np
+        x = np.ascontiguousarray(x, np.complex64)
+        soft = np.zeros(160, np.float32)
+        ns, rssi, toa = C.c_int(), C.c_int(), C.c_int()
+        rc = self._chk(self.L.trxsig_trx_pull_radio_vector(self.h, x.ctypes.data, len(x), tn, fn, soft.ctypes.data,
+                                                           C.byref(ns), C.byref(rssi), C.byref(toa)), "trxsig_trx_pull_radio_vector")
+        if rc == 0:
+            return None
+        return soft[:ns.value].copy(), rssi.value, toa.value
+
+    def encode_rx_datagram(self, tn, fn, rssi, toa, soft):
+        np = self.np
+        soft = np.ascontiguousarray(soft, np.float32)
+        out = np.zeros(158, np.uint8)
+        self._chk(self.L.trxsig_trx_encode_rx_datagram(tn, fn, rssi, toa, soft.ctypes.data, len(soft), out.ctypes.data), "encode")
+        return out.tobytes()
+
+    def decode_tx_datagram(self, b):
+        np = self.np
+        a = np.frombuffer(b, np.uint8).copy()
+        tn, fn, rssi = C.c_int(), C.c_int(), C.c_int()
+        bits = np.zeros(148, np.uint8)
+        rc = self.L.trxsig_trx_decode_tx_datagram(a.ctypes.data, len(a), C.byref(tn), C.byref(fn), C.byref(rssi), bits.ctypes.data)
+        if rc != 0:
+            return None
+        return tn.value, fn.value, rssi.value, bits
+
+    def add_radio_vector(self, bits, rssi, tn, fn):
+        np = self.np
+        bits = np.ascontiguousarray(bits, np.uint8)
+        self._chk(self.L.trxsig_trx_add_radio_vector(self.h, bits.ctypes.data, rssi, tn, fn), "trxsig_trx_add_radio_vector")
+
+    def push_radio_vector(self, tn, fn):
+        np = self.np
+        out = np.zeros(157 * self.sps, np.complex64)
+        n, fq = C.c_int(), C.c_int()
+        self._chk(self.L.trxsig_trx_push_radio_vector(self.h, tn, fn, out.ctypes.data, C.byref(n), C.byref(fq)), "push")
+        return out[:n.value].copy(), bool(fq.value)
+
+    @property
+    def energy_threshold(self):
+        return self.L.trxsig_trx_energy_threshold(self.h)
+
+    def filler_modulus(self, tn):
+        return self.L.trxsig_trx_filler_modulus(self.h, tn)
+
+    def queue_size(self):
+        return self.L.trxsig_trx_queue_size(self.h)
+
+    def create_lpf(self, raw, gain):
+        np = self.np
+        raw = np.ascontiguousarray(raw, np.float32)
+        out = np.zeros(len(raw), np.float32)
+        self._chk(self.L.trxsig_create_lpf_host(raw.ctypes.data, len(raw), float(gain), out.ctypes.data), "create_lpf")
+        return out

@@ -224,6 +224,8 @@ void trxsig_destroy(trxsig_ctx *c) {
 int trxsig_sps(const trxsig_ctx *c) { return c ? c->sps : TRXSIG_EINVAL; }
 int trxsig_device(const trxsig_ctx *c) { return c ? c->device : TRXSIG_EINVAL; }
 int trxsig_set_stream(trxsig_ctx *c, void *s) { if (!c) return TRXSIG_EINVAL; c->stream = (hipStream_t)s; return TRXSIG_OK; }
+void *trxsig_get_stream(trxsig_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int trxsig_get_device(trxsig_ctx *c) { return c ? c->device : -1; }
 int trxsig_synchronize(trxsig_ctx *c) {
   if (!c) return TRXSIG_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -353,6 +355,57 @@ int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const in
 }
 
 // ---- equaliser path (sps = 1) ------------------------------------------------------------------------
+// equaliser scratch: per burst toa_eq (4 B), 7 + 5 complex taps, EQ_XS complex delayed samples
+static constexpr int EQ_XS = 160;
+static int ensure_eq(trxsig_ctx *c, int B) {
+  if (B > c->eq_cap) {
+    const int cap = (B + 255) & ~255;
+    if (c->d_eq) { HIPCHK(c, hipFree(c->d_eq)); c->d_eq = nullptr; c->eq_cap = 0; }
+    HIPCHK(c, hipMalloc((void **)&c->d_eq, (size_t)cap * (4 + 8 * 7 + 8 * 5 + 8 * EQ_XS)));
+    c->eq_cap = cap;
+  }
+  return TRXSIG_OK;
+}
+
+int trxsig_estimate_dfe_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
+                              int B, int tsc, float detect_thresh, float snr_thresh, float snr_value, int variant52m,
+                              int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_chan_off, trxsig_c32 *d_w,
+                              trxsig_c32 *d_b) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "trxsig_estimate_dfe_batch: the channel estimate / DFE path needs sps == 1");
+  if (bad_batch(d_samples, d_offset, d_length, B) || tsc < 0 || tsc > 7 || max_toa < 0 || max_toa > 17 || (snr_thresh < 0.0f && !(snr_value > 0.0f)) ||
+      (B > 0 && (!d_flags || !d_amp || !d_toa || !d_chan_off || !d_w || !d_b)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_estimate_dfe_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_eq(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
+                                    detect_thresh, snr_thresh, snr_value, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
+                                    (float *)c->d_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b, c->prof));
+  return TRXSIG_OK;
+}
+
+int trxsig_equalize_taps_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
+                               int B, const trxsig_c32 *d_amp, const float *d_toa_eq, const uint8_t *d_enable,
+                               const trxsig_c32 *d_w, const trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
+                               int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "trxsig_equalize_taps_batch: equalizeBurst needs sps == 1");
+  if (bad_batch(d_samples, d_offset, d_length, B) || nsoft < 0 || nsoft > 157 || soft_stride < nsoft ||
+      (B > 0 && (!d_amp || !d_toa_eq || !d_enable || !d_w || !d_b || (nsoft > 0 && !d_soft))))
+    return fail(c, TRXSIG_EINVAL, "trxsig_equalize_taps_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_eq(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  trx_c32 *xd = (trx_c32 *)(c->d_eq + (size_t)c->eq_cap * (4 + 56 + 40));
+  HIPCHK(c, trx_launch_equalize_taps(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                                     (const trx_c32 *)d_amp, d_toa_eq, d_enable, (const trx_c32 *)d_w, (const trx_c32 *)d_b,
+                                     xd, EQ_XS, d_soft, d_hard, nsoft, soft_stride, c->prof));
+  return TRXSIG_OK;
+}
+
 int trxsig_equalize_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
                                  const int32_t *d_length, int B, int tsc, float detect_thresh, float energy_thresh,
                                  int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
@@ -366,13 +419,9 @@ int trxsig_equalize_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, con
     return fail(c, TRXSIG_EINVAL, "trxsig_equalize_normal_batch: bad argument");
   if (B == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
-  constexpr int XS = 160;
-  if (B > c->eq_cap) {
-    const int cap = (B + 255) & ~255;
-    if (c->d_eq) { HIPCHK(c, hipFree(c->d_eq)); c->d_eq = nullptr; c->eq_cap = 0; }
-    HIPCHK(c, hipMalloc((void **)&c->d_eq, (size_t)cap * (4 + 8 * 7 + 8 * 5 + 8 * XS)));
-    c->eq_cap = cap;
-  }
+  constexpr int XS = EQ_XS;
+  int rc = ensure_eq(c, B);
+  if (rc != TRXSIG_OK) return rc;
   const size_t cap = (size_t)c->eq_cap;
   float *toa_eq = (float *)c->d_eq;
   trx_c32 *w = (trx_c32 *)(c->d_eq + cap * 4);

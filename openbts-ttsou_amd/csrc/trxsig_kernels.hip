@@ -1310,7 +1310,11 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
                                                   int max_toa, uint8_t *__restrict__ flags,
                                                   cx *__restrict__ amp_out, float *__restrict__ toa_out,
                                                   float *__restrict__ toa_eq, cx *__restrict__ w_out,
-                                                  cx *__restrict__ b_out) {
+                                                  cx *__restrict__ b_out, float snr_thresh, float snr_value,
+                                                  float *__restrict__ chan_off_out) {
+  // snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
+  // double arithmetic, Transceiver.cpp:340); else snr_thresh >= 0: the threshold that enters
+  // SNR = |amp|^2/(thr^2+1); else energy_thresh.  chan_off_out (optional): chanRespOffset (:343).
   __shared__ cx corr[EQ_NC][64];
   __shared__ cx shf[EQ_NC][64];
   const int lane = threadIdx.x;
@@ -1463,11 +1467,12 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   amp_out[b] = amp;
   toa_out[b] = toa;
   toa_eq[b] = toa - chanOff;                               // equalizeBurst(..., TOA - chanRespOffset, ...)
+  if (chan_off_out) chan_off_out[b] = chanOff;
   if (!detected) return;
 
   // ---- Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7) (:1246-1340) ----
-  const float thr = energy_thresh < 0.0f ? 0.0f : energy_thresh;
-  const float snr = (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0));
+  const float thr = snr_thresh >= 0.0f ? snr_thresh : (energy_thresh < 0.0f ? 0.0f : energy_thresh);
+  const float snr = snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0));
   const cx ainv = cdiv(mk(1.0f, 0.0f), amp);
 #pragma unroll
   for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
@@ -2800,7 +2805,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
-                                                        variant52m, max_toa, flags, amp, toa, toa_eq, w, bq);
+                                                        variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr);
   k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
                                                            TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
   k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
@@ -2808,3 +2813,30 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
   return hipGetLastError();
 }
 
+
+// the two halves of trx_launch_equalize on their own (the Transceiver facade caches DFE taps per timeslot):
+// channel estimate + designDFE only (energy gate off, explicit SNR threshold) ...
+hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                                   const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
+                                   float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
+                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
+  k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
+                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  return hipGetLastError();
+}
+// ... and scaleVector(burst, 1/amp) + equalizeBurst(burst, toa_eq, w, b) with caller-supplied taps (7 + 5 per burst)
+hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                                    const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
+                                    const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
+                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
+  k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
+      dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  return hipGetLastError();
+}

@@ -77,3 +77,14 @@ hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long
                           int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof,
                           int ilv8 = 0 /* mode 1 through the 8-burst TCH deinterleaver (FACCH); mode 3 = TCH: out0 = 33
                                           octets of d[260], out1 = good, out2 = stolen */);
+
+// the halves of trx_launch_equalize (see trxsig_kernels.hip): channel estimate + designDFE with an explicit SNR
+// threshold and no energy gate; equalizeBurst with caller-supplied taps (flags: DETECT bit = burst enabled)
+hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                                   const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
+                                   float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
+                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, TrxProfiler *prof);
+hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                                    const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
+                                    const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
+                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);

@@ -1,0 +1,433 @@
+// trxsig_transceiver.cpp -- the host-side Transceiver orchestration (include/trxsig_transceiver.h): the state
+// machine of Transceiver/Transceiver.cpp around libtrxsig's GPU calls.  All signal processing happens in the
+// kernels; what is computed here is exactly what the reference computes on the host between its sigProcLib
+// calls (thresholds, SNR, RSSI, timing offset, time arithmetic), in the reference's types (double where it
+// uses double).  Line references: Transceiver/Transceiver.cpp unless another file is named.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "trxsig_transceiver.h"
+
+namespace {
+
+constexpr int kHyperframe = 2048 * 26 * 51;                 // GSM/GSMCommon.h:306
+
+// GSM::Time (GSM/GSMCommon.h:327-455) and FNDelta / FNCompare (GSM/GSMCommon.cpp:161-176)
+struct Time {
+  int fn = 0, tn = 0;
+};
+int fn_delta(int v1, int v2) {
+  const int half = kHyperframe / 2;
+  int d = v1 - v2;
+  if (d >= half) d -= kHyperframe;
+  else if (d < -half) d += kHyperframe;
+  return d;
+}
+int fn_compare(int v1, int v2) { const int d = fn_delta(v1, v2); return d > 0 ? 1 : (d < 0 ? -1 : 0); }
+bool time_less(const Time &a, const Time &b) { return a.fn == b.fn ? a.tn < b.tn : fn_compare(a.fn, b.fn) < 0; }
+bool time_equal(const Time &a, const Time &b) { return a.fn == b.fn && a.tn == b.tn; }
+int time_minus(const Time &a, const Time &b) { return fn_delta(a.fn, b.fn); }        // operator-(Time): frames
+
+// the dummy burst of GSM 05.02 5.2.6 (gDummyBurst, GSM/GSMCommon.cpp)
+const char kDummyBurst[149] =
+    "0001111101101110110000010100100111000001001000100000001111100011100010111000101110001010111010010100"
+    "011001100111001111010011111000100101111101010000";
+
+struct Queued {
+  Time time;
+  std::vector<trxsig_c32> samples;
+};
+
+}  // namespace
+
+struct trxsig_trx {
+  trxsig_ctx *ctx = nullptr;
+  int sps = 1;
+  std::string err;
+  // control state (:83-91, 439-580)
+  bool on = false;
+  double txFreq = 0.0, rxFreq = 0.0;
+  int power = -10;
+  unsigned tsc = 0;
+  int chanType[8];
+  // receive state
+  double energyThreshold = 250.0;                           // :88
+  Time prevFalseDetectionTime;
+  bool haveChan[8];
+  float chanRespOffset[8];
+  float SNRestimate[8];
+  Time channelEstimateTime[8];
+  trxsig_c32 dfeW[8][7], dfeB[8][5];
+  // transmit state
+  int fillerModulus[8];
+  std::vector<trxsig_c32> fillerTable[102][8];
+  std::vector<Queued> queue;                                // earliest time first (VectorQueue)
+  // device scratch for the single-burst calls
+  char *d = nullptr;
+  size_t d_bytes = 0;
+};
+
+namespace {
+
+int fail(trxsig_trx *t, int code, const std::string &what) {
+  if (t) t->err = what;
+  return code;
+}
+#define TRX_HIP(t, call)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) return fail(t, TRXSIG_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define TRX_LIB(t, call)                                                                  \
+  do {                                                                                    \
+    int rc_ = (call);                                                                     \
+    if (rc_ != TRXSIG_OK) return fail(t, rc_, std::string(#call) + ": " + trxsig_last_error((t)->ctx)); \
+  } while (0)
+
+void set_modulus(trxsig_trx *t, int ts) {                   // setModulus (:183-204)
+  switch (t->chanType[ts]) {
+    case TRXSIG_CHAN_NONE: case TRXSIG_CHAN_I: case TRXSIG_CHAN_II: case TRXSIG_CHAN_III: t->fillerModulus[ts] = 26; break;
+    case TRXSIG_CHAN_IV: case TRXSIG_CHAN_VI: case TRXSIG_CHAN_V: t->fillerModulus[ts] = 51; break;
+    case TRXSIG_CHAN_VII: t->fillerModulus[ts] = 102; break;
+    default: break;
+  }
+}
+
+int expected_corr_type(const trxsig_trx *t, int tn, int fn) {       // :207-269
+  const unsigned burstFN = (unsigned)fn;
+  switch (t->chanType[tn & 7]) {
+    case TRXSIG_CHAN_NONE: return TRXSIG_CORR_OFF;
+    case TRXSIG_CHAN_I: return TRXSIG_CORR_TSC;
+    case TRXSIG_CHAN_II: return (burstFN % 2 == 1) ? TRXSIG_CORR_IDLE : TRXSIG_CORR_TSC;
+    case TRXSIG_CHAN_III: return TRXSIG_CORR_TSC;
+    case TRXSIG_CHAN_IV:
+    case TRXSIG_CHAN_VI: return ((burstFN % 51) % 10 < 2) ? TRXSIG_CORR_RACH : TRXSIG_CORR_OFF;
+    case TRXSIG_CHAN_V: {
+      const int mod51 = burstFN % 51;
+      if (mod51 <= 36 && mod51 >= 14) return TRXSIG_CORR_RACH;
+      if (mod51 == 4 || mod51 == 5) return TRXSIG_CORR_RACH;
+      if (mod51 == 45 || mod51 == 46) return TRXSIG_CORR_RACH;
+      return TRXSIG_CORR_TSC;
+    }
+    case TRXSIG_CHAN_VII:
+      if (burstFN % 51 == 12 || burstFN % 51 == 13 || burstFN % 51 == 14) return TRXSIG_CORR_IDLE;
+      return TRXSIG_CORR_TSC;
+    case TRXSIG_CHAN_LOOPBACK:
+      return (burstFN % 51 <= 50 && burstFN % 51 >= 48) ? TRXSIG_CORR_IDLE : TRXSIG_CORR_TSC;
+    default: return TRXSIG_CORR_OFF;
+  }
+}
+
+// modulateBurst(bits, pulse, 8 + (TN % 4 == 0), sps) [+ scaleVector(gain)] on the GPU
+int modulate(trxsig_trx *t, const uint8_t *bits, int tn, const float *gain, std::vector<trxsig_c32> &out) {
+  const int32_t guard = 8 + ((tn % 4) == 0), off = 0;
+  out.assign((size_t)t->sps * (148 + guard), trxsig_c32{0.0f, 0.0f});
+  TRX_LIB(t, trxsig_modulate_host(t->ctx, bits, &guard, gain, 1, out.data(), &off, (int64_t)out.size()));
+  return TRXSIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trxsig_trx_create(trxsig_trx **out, int device, int sps, int start_fn, int start_tn) {
+  if (!out) return TRXSIG_EINVAL;
+  *out = nullptr;
+  trxsig_trx *t = new trxsig_trx();
+  t->sps = sps;
+  int rc = trxsig_create(&t->ctx, device, sps);             // sigProcLibSetup + pulse + midambles + RACH sequence (:62-64, 424, 553)
+  if (rc != TRXSIG_OK) { delete t; return rc; }
+  const Time start{start_fn, start_tn};
+  t->prevFalseDetectionTime = start;
+  uint8_t dummy[148];
+  for (int i = 0; i < 148; i++) dummy[i] = kDummyBurst[i] == '1';
+  for (int i = 0; i < 8; i++) {                             // :68-85
+    std::vector<trxsig_c32> mod;
+    rc = modulate(t, dummy, i, nullptr, mod);
+    if (rc != TRXSIG_OK) { trxsig_destroy(t->ctx); delete t; return rc; }
+    t->fillerModulus[i] = 26;
+    for (int j = 0; j < 102; j++) t->fillerTable[j][i] = mod;
+    t->chanType[i] = TRXSIG_CHAN_NONE;
+    t->haveChan[i] = false;
+    t->chanRespOffset[i] = 0.0f;
+    t->SNRestimate[i] = 0.0f;
+    t->channelEstimateTime[i] = start;
+  }
+  // device scratch: one burst (<= 157*sps samples) + offsets + results + taps
+  t->d_bytes = 8 * (size_t)157 * sps + 4096;
+  if (hipMalloc((void **)&t->d, t->d_bytes) != hipSuccess) { trxsig_destroy(t->ctx); delete t; return TRXSIG_EHIP; }
+  *out = t;
+  return TRXSIG_OK;
+}
+
+void trxsig_trx_destroy(trxsig_trx *t) {
+  if (!t) return;
+  if (t->d) (void)hipFree(t->d);
+  if (t->ctx) trxsig_destroy(t->ctx);
+  delete t;
+}
+
+const char *trxsig_trx_last_error(const trxsig_trx *t) { return t ? t->err.c_str() : "null transceiver"; }
+trxsig_ctx *trxsig_trx_context(trxsig_trx *t) { return t ? t->ctx : nullptr; }
+double trxsig_trx_energy_threshold(const trxsig_trx *t) { return t ? t->energyThreshold : 0.0; }
+int trxsig_trx_filler_modulus(const trxsig_trx *t, int tn) { return (t && tn >= 0 && tn < 8) ? t->fillerModulus[tn] : -1; }
+int trxsig_trx_queue_size(const trxsig_trx *t) { return t ? (int)t->queue.size() : -1; }
+int trxsig_trx_expected_corr_type(const trxsig_trx *t, int tn, int fn) {
+  return (t && tn >= 0 && tn < 8) ? expected_corr_type(t, tn, fn) : TRXSIG_CORR_OFF;
+}
+
+int trxsig_trx_control(trxsig_trx *t, const char *buffer, char *response_out, int cap) {
+  if (!t || !buffer || !response_out || cap < 1) return TRXSIG_EINVAL;
+  char cmdcheck[4] = {0}, command[100] = {0}, response[100] = {0};
+  if (std::strlen(buffer) >= 100) return fail(t, TRXSIG_EINVAL, "control message longer than MAX_PACKET_LENGTH");
+  std::sscanf(buffer, "%3s %99s", cmdcheck, command);
+  if (std::strcmp(cmdcheck, "CMD") != 0) { response_out[0] = 0; return 0; }       // "bogus message": no response (:466-470)
+  if (std::strcmp(command, "POWEROFF") == 0) {
+    std::sprintf(response, "RSP POWEROFF 0");
+  } else if (std::strcmp(command, "POWERON") == 0) {
+    if (!t->txFreq || !t->rxFreq) std::sprintf(response, "RSP POWERON 1");
+    else {
+      std::sprintf(response, "RSP POWERON 0");
+      if (!t->on) { t->power = -20; t->on = true; }
+    }
+  } else if (std::strcmp(command, "SETPOWER") == 0) {
+    int dbPwr = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbPwr);
+    if (!t->on) std::sprintf(response, "RSP SETPOWER 1 %d", dbPwr);
+    else { t->power = dbPwr; std::sprintf(response, "RSP SETPOWER 0 %d", dbPwr); }
+  } else if (std::strcmp(command, "ADJPOWER") == 0) {
+    int dbStep = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbStep);
+    if (!t->on) std::sprintf(response, "RSP ADJPOWER 1 %d", t->power);
+    else { t->power += dbStep; std::sprintf(response, "RSP ADJPOWER 0 %d", t->power); }
+  } else if (std::strcmp(command, "RXTUNE") == 0) {
+    int freqKhz = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
+    if (t->on) std::sprintf(response, "RSP RXTUNE 1 %d", freqKhz);
+    else { t->rxFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP RXTUNE 0 %d", freqKhz); }
+  } else if (std::strcmp(command, "TXTUNE") == 0) {
+    int freqKhz = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
+    if (t->on) std::sprintf(response, "RSP TXTUNE 1 %d", freqKhz);
+    else { t->txFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP TXTUNE 0 %d", freqKhz); }
+  } else if (std::strcmp(command, "SETTSC") == 0) {
+    int TSC = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &TSC);
+    if (t->on || TSC < 0 || TSC > 7) std::sprintf(response, "RSP SETTSC 1 %d", TSC);   // (the reference does not range-check)
+    else { t->tsc = (unsigned)TSC; std::sprintf(response, "RSP SETTSC 0 %d", TSC); }
+  } else if (std::strcmp(command, "SETSLOT") == 0) {
+    int corrCode = 0, timeslot = 0;
+    std::sscanf(buffer, "%3s %99s %d %d", cmdcheck, command, &timeslot, &corrCode);
+    if (timeslot < 0 || timeslot > 7) { response_out[0] = 0; return 0; }           // returns without responding (:556-561)
+    t->chanType[timeslot] = corrCode;
+    set_modulus(t, timeslot);
+    std::sprintf(response, "RSP SETSLOT 0 %d %d", timeslot, corrCode);
+  }                                                          // unknown command: empty response buffer is sent (:571-575)
+  const int n = (int)std::strlen(response);
+  if (n + 1 > cap) return fail(t, TRXSIG_EINVAL, "response buffer too small");
+  std::memcpy(response_out, response, (size_t)n + 1);
+  return n;
+}
+
+int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n, int tn, int fn, float *h_soft,
+                                 int *n_soft, int *rssi_out, int *toa_out) {
+  if (!t || !h_burst || !h_soft || !n_soft || !rssi_out || !toa_out || tn < 0 || tn > 7 || n <= 0 || n > 157 * t->sps)
+    return fail(t, TRXSIG_EINVAL, "trxsig_trx_pull_radio_vector: bad argument");
+  const Time now{fn, tn};
+  const int corrType = expected_corr_type(t, tn, fn);
+  if (corrType == TRXSIG_CORR_OFF || corrType == TRXSIG_CORR_IDLE) return 0;      // :288-291
+  if (corrType == TRXSIG_CORR_TSC && t->sps != 1)
+    return fail(t, TRXSIG_EINVAL, "the TSC leg equalises (Transceiver.cpp:391-396) and needs sps == 1");
+
+  // ---- the burst's detection numbers from the GPU: avgPwr of energyDetect, and analyzeTrafficBurst /
+  //      detectRACHBurst (stateless, so running them ahead of the energy decision changes nothing) ----
+  const int32_t off = 0, len = n;
+  uint8_t flags = 0;
+  trxsig_c32 amplitude{0.0f, 0.0f};
+  float TOA = 0.0f, avgPwr = 0.0f;
+  const int nsoft = n / t->sps;
+  if (corrType == TRXSIG_CORR_TSC)
+    TRX_LIB(t, trxsig_detect_demod_normal_host(t->ctx, h_burst, &off, &len, 1, (int)t->tsc, 3.0f, -1.0f, &flags, &amplitude,
+                                               &TOA, &avgPwr, nullptr, 0, 0));
+  else
+    TRX_LIB(t, trxsig_detect_demod_rach_host(t->ctx, h_burst, &off, &len, 1, 5.0f, -1.0f, &flags, &amplitude, &TOA, &avgPwr,
+                                             h_soft, nsoft, nsoft));     // demodulateBurst(amp, TOA) rides along
+  if (flags & TRXSIG_F_BADLEN) return fail(t, TRXSIG_EINVAL, "burst length not accepted by the detector");
+
+  // ---- energyDetect's decision against the adaptive threshold (:298-306; sigProcLib.cpp:929-931) ----
+  const float thrF = (float)t->energyThreshold;
+  if (!(avgPwr > thrF * thrF)) {
+    const double framesElapsed = time_minus(now, t->prevFalseDetectionTime);
+    if (framesElapsed > 50) { t->energyThreshold -= 10.0; t->prevFalseDetectionTime = now; }
+    return 0;
+  }
+
+  const bool success = (flags & TRXSIG_F_DETECT) != 0;
+  if (corrType == TRXSIG_CORR_TSC) {
+    // per-timeslot channel / DFE cache (:313-325)
+    const double sinceEstimate = time_minus(now, t->channelEstimateTime[tn]);
+    bool estimateChannel = false;
+    if (sinceEstimate > 50 || !t->haveChan[tn]) { t->haveChan[tn] = false; estimateChannel = true; }
+    if (success) {
+      t->energyThreshold -= 1.0F;                          // :338-339
+      if (t->energyThreshold < 0.0) t->energyThreshold = 0.0;
+      const float n2 = amplitude.im * amplitude.im + amplitude.re * amplitude.re;          // Complex::norm2 (Complex.h:119)
+      t->SNRestimate[tn] = (float)(n2 / (t->energyThreshold * t->energyThreshold + 1.0));  // :340
+      if (estimateChannel) {                               // :341-349, on the GPU with this SNR
+        char *d = t->d;
+        hipStream_t st = (hipStream_t)trxsig_get_stream(t->ctx);
+        trxsig_c32 *d_x = (trxsig_c32 *)d;
+        char *p = d + 8 * (size_t)157 * t->sps;
+        int32_t *d_off = (int32_t *)p, *d_len = (int32_t *)(p + 16);
+        uint8_t *d_fl = (uint8_t *)(p + 32);
+        trxsig_c32 *d_amp = (trxsig_c32 *)(p + 64), *d_w = (trxsig_c32 *)(p + 128), *d_b = (trxsig_c32 *)(p + 256);
+        float *d_toa = (float *)(p + 96), *d_co = (float *)(p + 112);
+        TRX_HIP(t, hipMemcpyAsync(d_x, h_burst, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        TRX_HIP(t, hipMemcpyAsync(d_off, &off, 4, hipMemcpyHostToDevice, st));
+        TRX_HIP(t, hipMemcpyAsync(d_len, &len, 4, hipMemcpyHostToDevice, st));
+        // the SNR estimate goes in as formed above (the reference squares its DOUBLE threshold; the batch
+        // kernel's own formula squares a float one)
+        if (!(t->SNRestimate[tn] > 0.0f)) return fail(t, TRXSIG_EINVAL, "SNR estimate is not positive");
+        TRX_LIB(t, trxsig_estimate_dfe_batch(t->ctx, d_x, d_off, d_len, 1, (int)t->tsc, 3.0f, -1.0f, t->SNRestimate[tn], 0, 0,
+                                             d_fl, d_amp, d_toa, d_co, d_w, d_b));
+        uint8_t efl = 0;
+        TRX_HIP(t, hipMemcpyAsync(&efl, d_fl, 1, hipMemcpyDeviceToHost, st));
+        TRX_HIP(t, hipMemcpyAsync(&t->chanRespOffset[tn], d_co, 4, hipMemcpyDeviceToHost, st));
+        TRX_HIP(t, hipMemcpyAsync(t->dfeW[tn], d_w, 8 * 7, hipMemcpyDeviceToHost, st));
+        TRX_HIP(t, hipMemcpyAsync(t->dfeB[tn], d_b, 8 * 5, hipMemcpyDeviceToHost, st));
+        TRX_HIP(t, hipStreamSynchronize(st));
+        if (!(efl & TRXSIG_F_DETECT)) return fail(t, TRXSIG_EHIP, "channel estimate disagrees with the detector");
+        t->haveChan[tn] = true;
+        t->channelEstimateTime[tn] = now;
+      }
+    } else {
+      const double framesElapsed = time_minus(now, t->prevFalseDetectionTime);          // :352-357
+      t->energyThreshold += 10.0F * std::exp(-framesElapsed);
+      t->prevFalseDetectionTime = now;
+      t->haveChan[tn] = false;
+    }
+  } else {
+    if (success) {                                         // :367-371
+      t->energyThreshold -= 1.0F;
+      if (t->energyThreshold < 0.0) t->energyThreshold = 0.0;
+      t->haveChan[tn] = false;
+    } else {                                               // :372-376
+      const double framesElapsed = time_minus(now, t->prevFalseDetectionTime);
+      t->energyThreshold += 10.0F * std::exp(-framesElapsed);
+      t->prevFalseDetectionTime = now;
+    }
+  }
+  if (!success) return 0;
+
+  if (corrType == TRXSIG_CORR_TSC) {
+    // scaleVector(burst, 1/amp); equalizeBurst(burst, TOA - chanRespOffset[ts], sps, w[ts], b[ts]) (:391-396)
+    char *d = t->d;
+    hipStream_t st = (hipStream_t)trxsig_get_stream(t->ctx);
+    trxsig_c32 *d_x = (trxsig_c32 *)d;
+    char *p = d + 8 * (size_t)157 * t->sps;
+    int32_t *d_off = (int32_t *)p, *d_len = (int32_t *)(p + 16);
+    uint8_t *d_fl = (uint8_t *)(p + 32);
+    trxsig_c32 *d_amp = (trxsig_c32 *)(p + 64), *d_w = (trxsig_c32 *)(p + 128), *d_b = (trxsig_c32 *)(p + 256);
+    float *d_toa = (float *)(p + 96), *d_soft = (float *)(p + 512);
+    const float toa_eq = TOA - t->chanRespOffset[tn];
+    const uint8_t en = TRXSIG_F_DETECT;
+    TRX_HIP(t, hipMemcpyAsync(d_x, h_burst, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_off, &off, 4, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_len, &len, 4, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_fl, &en, 1, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_amp, &amplitude, 8, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_toa, &toa_eq, 4, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_w, t->dfeW[tn], 56, hipMemcpyHostToDevice, st));
+    TRX_HIP(t, hipMemcpyAsync(d_b, t->dfeB[tn], 40, hipMemcpyHostToDevice, st));
+    TRX_LIB(t, trxsig_equalize_taps_batch(t->ctx, d_x, d_off, d_len, 1, d_amp, d_toa, d_fl, d_w, d_b, d_soft, nullptr, nsoft, 160));
+    TRX_HIP(t, hipMemcpyAsync(h_soft, d_soft, 4 * (size_t)nsoft, hipMemcpyDeviceToHost, st));
+    TRX_HIP(t, hipStreamSynchronize(st));
+  }
+  *n_soft = nsoft;
+  // :400-402 -- Complex::abs() is (float)sqrt((double)norm2) (Complex.h:131)
+  const float n2 = amplitude.im * amplitude.im + amplitude.re * amplitude.re;
+  const float absA = (float)std::sqrt((double)n2);
+  *rssi_out = (int)std::floor(20.0 * std::log10(9450.0 / absA));
+  *toa_out = (int)std::round(TOA * 256.0 / t->sps);
+  return 1;
+}
+
+int trxsig_trx_encode_rx_datagram(int tn, int fn, int rssi, int toa, const float *soft, int n_soft, uint8_t *out) {
+  if (!soft || !out || n_soft < 148) return TRXSIG_EINVAL;
+  out[0] = (uint8_t)tn;                                     // :658-672
+  for (int i = 0; i < 4; i++) out[1 + i] = (uint8_t)((fn >> ((3 - i) * 8)) & 0xff);
+  out[5] = (uint8_t)rssi;
+  out[6] = (uint8_t)((toa >> 8) & 0xff);
+  out[7] = (uint8_t)(toa & 0xff);
+  for (int i = 0; i < 148; i++) out[8 + i] = (uint8_t)(int)std::round((double)soft[i] * 255.0);   // (char) round(x*255.0)
+  out[156] = 0;                                             // burstString[gSlotLen+9] = '\0'; [gSlotLen+8] is never written:
+  out[157] = 0;                                             // sent as 0 here
+  return TRXSIG_OK;
+}
+
+int trxsig_trx_decode_tx_datagram(const uint8_t *in, int len, int *tn, int *fn, int *rssi, uint8_t *bits) {
+  if (!in || !tn || !fn || !rssi || !bits) return TRXSIG_EINVAL;
+  if (len != TRXSIG_TX_DATAGRAM_BYTES) return TRXSIG_EINVAL;    // "badly formatted packet" (:590-593)
+  *tn = (int)(signed char)in[0];
+  unsigned long long frameNum = 0;
+  for (int i = 0; i < 4; i++) frameNum = (frameNum << 8) | (0x0ff & in[i + 1]);
+  *fn = (int)frameNum;
+  *rssi = (int)(signed char)in[5];                          // (int) buffer[5], char buffer
+  std::memcpy(bits, in + 6, 148);
+  return TRXSIG_OK;
+}
+
+int trxsig_trx_add_radio_vector(trxsig_trx *t, const uint8_t *bits, int RSSI, int tn, int fn) {
+  if (!t || !bits || tn < 0 || tn > 7) return fail(t, TRXSIG_EINVAL, "trxsig_trx_add_radio_vector: bad argument");
+  // scaleVector(*modBurst, pow(10,-RSSI/10)): integer division, double pow, complex(float) scale (:108)
+  const float gain = (float)std::pow(10, -RSSI / 10);
+  Queued q;
+  q.time = Time{fn, tn};
+  int rc = modulate(t, bits, tn, &gain, q.samples);
+  if (rc != TRXSIG_OK) return rc;
+  // priority queue, earliest first; equal times keep arrival order
+  size_t pos = t->queue.size();
+  while (pos > 0 && time_less(q.time, t->queue[pos - 1].time)) pos--;
+  t->queue.insert(t->queue.begin() + (long)pos, std::move(q));
+  return TRXSIG_OK;
+}
+
+int trxsig_trx_push_radio_vector(trxsig_trx *t, int tn, int fn, trxsig_c32 *h_out, int *n_out, int *from_queue) {
+  if (!t || !h_out || !n_out || tn < 0 || tn > 7) return fail(t, TRXSIG_EINVAL, "trxsig_trx_push_radio_vector: bad argument");
+  const Time now{fn, tn};
+  // dump stale bursts into the filler table (:142-153)
+  while (!t->queue.empty() && time_less(t->queue.front().time, now)) {
+    const Time nt = t->queue.front().time;
+    const int modFN = nt.fn % t->fillerModulus[nt.tn];
+    t->fillerTable[modFN][nt.tn] = std::move(t->queue.front().samples);
+    t->queue.erase(t->queue.begin());
+  }
+  const int modFN = fn % t->fillerModulus[tn];
+  int fq = 0;
+  if (!t->queue.empty() && time_equal(t->queue.front().time, now)) {       // :159-173
+    t->fillerTable[modFN][tn] = t->queue.front().samples;
+    t->queue.erase(t->queue.begin());
+    fq = 1;
+  }
+  const std::vector<trxsig_c32> &v = t->fillerTable[modFN][tn];             // :175-177 (or the burst just stored)
+  std::memcpy(h_out, v.data(), 8 * v.size());
+  *n_out = (int)v.size();
+  if (from_queue) *from_queue = fq;
+  return TRXSIG_OK;
+}
+
+int trxsig_create_lpf_host(const float *raw, int len, float gainDC, float *out) {
+  if (!raw || !out || len <= 0) return TRXSIG_EINVAL;
+  double sum = 0.0;                                         // sigProcLib.cpp:1119-1139
+  for (int i = 0; i < len; i++) sum += raw[i];
+  const float normFactor = (float)(gainDC / sum);           // :1141
+  for (int i = 0; i < len; i++) out[i] = raw[i] * normFactor;
+  return TRXSIG_OK;
+}
+
+}  // extern "C"
