@@ -21,7 +21,7 @@ class TrxSigError(RuntimeError):
 
 def build(verbose=False):
     """Compile csrc/ into libtrxsig.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    cmd = ["make", "-j8", "-C", os.path.join(_HERE, "csrc")]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)

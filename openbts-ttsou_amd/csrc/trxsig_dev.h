@@ -1,0 +1,123 @@
+// trxsig_dev.h -- device-side helpers shared by every kernel file: Complex<float> arithmetic exactly as the
+// reference's Complex.h does it, the wave-local LDS fence, the reference's table sin/sinc, midamble tap
+// classes (exact-product FMA form), tuning macros.
+//
+// Numerical contract: every float32 operation is the reference's operation, in the reference's
+// order, separately rounded.  All device code is compiled with -ffp-contract=off (no v_fma/v_mac is ever
+// formed from a*b+c) and with hipcc's default correctly-rounded division and square root, so the outputs are
+// bit-identical to Transceiver/sigProcLib.cpp built for x86-64.  Where a sum's order is changed for
+// parallelism the comment says why the result cannot change (only additions of +-0 are skipped or reordered).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "trxsig_tables.h"
+#include "trxsig_launch.h"
+
+#ifndef TRX_CORR_CG
+#define TRX_CORR_CG 3
+#endif
+#ifndef TRX_CORR_WPS
+#define TRX_CORR_WPS 1
+#endif
+#ifndef TRX_CORR_ROUNDS
+#define TRX_CORR_ROUNDS 1
+#endif
+#ifndef TRX_DEMOD_WAVES
+#define TRX_DEMOD_WAVES 4
+#endif
+
+namespace {
+
+typedef trx_c32 cx;
+
+__device__ __forceinline__ cx mk(float r, float i) { cx z; z.r = r; z.i = i; return z; }
+// Complex<float>::operator* (Transceiver/Complex.h:83): (r*a.r - i*a.i, r*a.i + i*a.r)
+__device__ __forceinline__ cx cmul(cx x, cx a) { return mk(x.r * a.r - x.i * a.i, x.r * a.i + x.i * a.r); }
+__device__ __forceinline__ cx cmulr(cx x, float a) { return mk(x.r * a, x.i * a); }       // Complex.h:84
+__device__ __forceinline__ cx cadd(cx x, cx a) { return mk(x.r + a.r, x.i + a.i); }
+__device__ __forceinline__ float norm2(cx x) { return x.i * x.i + x.r * x.r; }            // Complex.h:119
+__device__ __forceinline__ cx cinv(cx x) { float n = norm2(x); return mk(x.r / n, -x.i / n); }  // Complex.h:154-160
+__device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }               // Complex.h:85
+
+struct TapArg { float v[32]; };   // conj'd non-zero midamble taps passed as a kernel argument => SGPRs
+
+// Tap classes.  The GMSK-rotated midamble taps are (+-1, eps) or (eps, +-1): one component is EXACTLY
+// +-1 for most of them (the same ones for every training sequence -- it is a property of the rotation
+// table), so the products with that component are exact and a*b + c with a single rounding (v_fma) is
+// bit-identical to the reference's separately rounded multiply and add.  That saves 2 of the 8
+// operations of a complex multiply-accumulate.  The class of every tap is a template parameter
+// (2 bits per tap: 0 generic, 1 real part exact, 2 imaginary part exact); the host derives it from the
+// actual taps and launches the generic instantiation whenever they do not match the expected pattern.
+// These are the only FMAs outside division/sqrt expansions; tools/asm_stats.py recognises them by the
+// marker comment.
+#define TRX_TAPS_GENERIC 0u
+template <int SPS> struct TapPattern {                     // taps 0,2,4.. real-exact, 1,3,5.. imaginary-exact
+  static constexpr unsigned value = (SPS == 4) ? 0x19999999u : 0x99999999u;   // sps 4: tap 15 is (eps, -0.99999994)
+};
+__device__ __forceinline__ float fma_exact(float a, float b, float c) {       // a*b + c, a*b exact (b = +-1, SGPR)
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fma_exact_subc(float a, float b, float c) {  // a*b - c
+  float r;
+  asm("v_fma_f32 %0, %1, %2, -%3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fma_exact_negab(float a, float b, float c) { // c - a*b
+  float r;
+  asm("v_fma_f32 %0, %1, -%2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+// x * a as Complex<float>::operator* computes it (Complex.h:83), a in SGPRs, CLS = the tap's class
+__device__ __forceinline__ cx cmul_tap(cx x, cx a, int cls) {
+  if (cls == 1) {                                          // a.r = +-1: x.r*a.r and x.i*a.r are exact
+    const float p = x.i * a.i, q = x.r * a.i;
+    return mk(fma_exact_subc(x.r, a.r, p), fma_exact(x.i, a.r, q));
+  }
+  if (cls == 2) {                                          // a.i = +-1: x.i*a.i and x.r*a.i are exact
+    const float p = x.r * a.r, q = x.i * a.r;
+    return mk(fma_exact_negab(x.i, a.i, p), fma_exact(x.r, a.i, q));
+  }
+  return cmul(x, a);
+}
+
+#define TRX_PI_F 3.14159274101257324f             /* (float)M_PI, sigProcLib.cpp:43 */
+#define TRX_2PI_F 6.28318548202514648f            /* (float)(2.0*M_PI), :44 */
+
+// lane i of a 16-lane DPP row reads lane i+N of the same row (row_shl:N)
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {
+  if (N == 0) return v;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from
+  // reordering them across the point where lanes start reading what other lanes wrote.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sinLookup (sigProcLib.cpp:177-188) and sinc (:567-571) against the uploaded trig table
+__device__ __forceinline__ float dev_sin_lookup(const float *__restrict__ sinT, float x) {
+  float arg = x * (1 / TRX_2PI_F);
+  while (arg > 1.0F) arg -= 1.0F;
+  while (arg < 0.0F) arg += 1.0F;
+  const float argT = arg * (float)TRX_TABLESIZE;
+  const int argI = (int)argT;
+  const float delta = argT - argI;
+  const float iDelta = 1.0F - delta;
+  return iDelta * sinT[argI] + delta * sinT[argI + 1];
+}
+__device__ __forceinline__ float dev_sinc(const float *__restrict__ sinT, float x) {
+  if ((x >= 0.01F) || (x <= -0.01F)) return dev_sin_lookup(sinT, x) / x;
+  return 1.0F;
+}
+
+}  // namespace

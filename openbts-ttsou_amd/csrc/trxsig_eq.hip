@@ -1,0 +1,383 @@
+// trxsig_eq.hip -- the equaliser path (sps = 1): channel estimate, designDFE, equalizeBurst.
+// Numerical contract: see trxsig_dev.h / DESIGN.md (every float32 operation is the reference's, in the
+// reference's order; built with -ffp-contract=off).
+#include "trxsig_demod.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Equaliser path (sps = 1; "Assumes symbol-rate sampling", sigProcLib.cpp:1342): the TSC leg of
+// pullRadioVector with a channel estimate and a decision-feedback equaliser
+// (Transceiver.cpp:298-349, 391-396; Transceiver52M/Transceiver.cpp for the windowed variant).
+//
+//   k_eq_detect : one lane per burst.  energyDetect, analyzeTrafficBurst(requestChannel) --
+//                 correlation (full 36-lag window, or the 52M CUSTOM span of 2*maxTOA+1 lags),
+//                 peakDetect, valley test, delayVector on the correlation, 6-tap channel pick --
+//                 then scaleVector(chan, 1/amp), SNR and designDFE(chan, SNR, 7).  Everything here
+//                 is tiny and strictly sequential per burst, so bursts are the parallel axis.
+//   k_demod<1,RAW> : delayVector(burst/amp, -(TOA - chanOffset)), one wave per burst.
+//   k_eq_dfe    : one lane per burst.  7-tap feed-forward FIR + the 156-step decision-feedback
+//                 recursion of equalizeBurst (:1352-1384) and the slicer.
+// ---------------------------------------------------------------------------------------------
+#define EQ_NC 36            /* max correlation lags kept per burst */
+
+// interpolatePoint on a per-lane LDS column of n entries (sigProcLib.cpp:639-659), ix on the 1/512 grid
+__device__ __forceinline__ cx eq_interp(const TrxTables *__restrict__ T, const cx (*col)[64], int lane, int n, float ix) {
+  const float fl = floorf(ix);
+  const int I = (int)fl;
+  const int f = (int)((ix - fl) * 512.0f) & 511;
+  int start = I - 10;
+  if (start < 0) start = 0;
+  int end = I + 11;
+  if ((unsigned)end > (unsigned)(n - 1)) end = n - 1;      // :646 (unsigned compare: negative end -> n-1)
+  const float *row = T->sinc_grid[f];
+  cx p = mk(0, 0);
+  for (int i = start; i < end; i++) p = cadd(p, cmulr(col[i][lane], row[i - I + 10]));
+  return p;
+}
+
+__global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+                                                  const int32_t *__restrict__ offset,
+                                                  const int32_t *__restrict__ length, int B, int tsc,
+                                                  float detect_thresh, float energy_thresh, int variant52m,
+                                                  int max_toa, uint8_t *__restrict__ flags,
+                                                  cx *__restrict__ amp_out, float *__restrict__ toa_out,
+                                                  float *__restrict__ toa_eq, cx *__restrict__ w_out,
+                                                  cx *__restrict__ b_out, float snr_thresh, float snr_value,
+                                                  float *__restrict__ chan_off_out) {
+  // snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
+  // double arithmetic, Transceiver.cpp:340); else snr_thresh >= 0: the threshold that enters
+  // SNR = |amp|^2/(thr^2+1); else energy_thresh.  chan_off_out (optional): chanRespOffset (:343).
+  __shared__ cx corr[EQ_NC][64];
+  __shared__ cx shf[EQ_NC][64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  if (b >= B) return;                                      // no barriers below: each lane owns its columns
+  const int off = offset[b], N = length[b];
+  uint8_t fl = 0;
+  cx amp = mk(0, 0);
+  float toa = 0.0f;
+  const bool good = (off >= 0) && (N >= 92) && (N <= 157);
+  if (!good) {
+    flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
+    return;
+  }
+  const cx *x = samples + off;
+
+  // ---- energyDetect (:916-932; the 52M variant strides by 4, ref52:946-963) ----
+  {
+    float energy = 0.0f;
+    const int step = variant52m ? 4 : 1;
+    for (int i = 0; i < 20; i++) energy += norm2(x[i * step]);
+    const bool ok = energy_thresh < 0.0f || energy / (float)20u > energy_thresh * energy_thresh;
+    if (!ok) { flags[b] = 0; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f; return; }
+    fl = TRXSIG_F_ENERGY;
+  }
+
+  // ---- correlation ----
+  int ncorr, winStart, La, startIndex;
+  unsigned maxTOA = (unsigned)max_toa;
+  if (!variant52m) {
+    ncorr = 36; winStart = 56; La = 36; startIndex = 7;    // NO_DELAY, Lb = 16 (:951-955, 295-300)
+  } else {                                                 // ref52:983-1000
+    if (maxTOA < 3) maxTOA = 3;
+    unsigned spanTOA = maxTOA;
+    if (spanTOA < 5) spanTOA = 5;
+    winStart = (int)(66 - spanTOA);
+    La = (int)(16 + 2 * spanTOA);
+    ncorr = (int)(2 * maxTOA + 1);
+    const unsigned expectedTOAPeak = (unsigned)round((double)((T->mid_toa[tsc] + 5.0f) + (float)(size_t)((16 - 1) / 2)));
+    startIndex = (int)(expectedTOAPeak - maxTOA);
+    if (ncorr > EQ_NC || winStart < 0 || winStart + La > N) {
+      flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
+      return;
+    }
+  }
+  for (int i = 0; i < ncorr; i++) {
+    const int t = startIndex + i;
+    cx sum = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {                         // tmp[j] = conj(mid[15-j]) (:480-498), j ascending
+      const int ai = t - j;
+      if (ai >= 0 && ai < La) sum = cadd(sum, cmul(x[winStart + ai], T->mid_ctap[tsc][15 - j]));
+    }
+    corr[i][lane] = sum;
+  }
+
+  // ---- peakDetect (:663-711) ----
+  float maxP = 0.0f, maxIndex = -1.0f;
+  for (int i = 0; i < ncorr; i++) {
+    const float p = norm2(corr[i][lane]);
+    if (p > maxP) { maxP = p; maxIndex = (float)i; }
+  }
+  float early = maxIndex - 1.0f, late = maxIndex + 1.0f, incr = 0.5f;
+  for (int step = 0; step < 9; step++) {
+    const cx e = eq_interp(T, corr, lane, ncorr, early), l = eq_interp(T, corr, lane, ncorr, late);
+    const float ne = norm2(e), nl = norm2(l);
+    if (ne < nl) early += incr;
+    else if (ne > nl) early -= incr;
+    else break;
+    incr = incr * 0.5f;
+    late = early + 2.0f;
+  }
+  toa = early + 1.0f;
+  amp = eq_interp(T, corr, lane, ncorr, toa);
+
+  // ---- analyzeTrafficBurst tail (:961-1035) ----
+  bool detected = false;
+  float chanOff = 0.0f;
+  cx chan[6];
+  if ((toa < 0.0f) || (toa > (float)ncorr)) {
+    amp = mk(0, 0);
+  } else {
+    const int p = (int)rintf(toa);
+    float valley = 0.0f;
+    int numRms = 0;
+    for (int i = 2; i <= 5; i++) {
+      if (p - i >= 0) { valley += norm2(corr[p - i][lane]); numRms++; }
+      if (p + i < ncorr) { valley += norm2(corr[p + i][lane]); numRms++; }
+    }
+    if (numRms < 2) {
+      amp = mk(0, 0);
+    } else {
+      const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);
+      const float peakToMean = sqrtf(norm2(amp)) / RMS;
+      amp = cdiv(amp, T->mid_gain[tsc]);
+      float TOAoffset;
+      if (!variant52m) {
+        toa = toa - T->mid_toa[tsc];
+        toa = toa - 10.0f;
+        TOAoffset = T->mid_toa[tsc] + 10.0f;
+      } else {
+        toa = toa - (float)maxTOA;
+        TOAoffset = (float)maxTOA;
+      }
+      detected = peakToMean > detect_thresh;
+      if (detected) {
+        // delayVector(corr, -TOA) (:573-616) on the lane's column
+        const float delay = -toa;
+        const int io = (int)floorf(delay);
+        const float frac = delay - (float)io;
+        const cx (*src)[64] = corr;
+        if (fabs((double)frac) > 1e-2) {
+          const float *row = T->sinc_grid[(int)(frac * 512.0f) & 511];
+          for (int t = 0; t < ncorr; t++) {
+            cx sum = mk(0, 0);
+            for (int j = 0; j < 21; j++) {
+              const int ai = t + 10 - j;
+              if (ai >= 0 && ai < ncorr) sum = cadd(sum, cmulr(corr[ai][lane], row[j]));
+            }
+            shf[t][lane] = sum;
+          }
+          src = shf;
+        }
+        // integer shift folded into the reads: w[k] = src[k - io] inside [0,n), else 0
+        auto wv = [&](int k) {
+          const int q = k - io;
+          return (q >= 0 && q < ncorr) ? src[q][lane] : mk(0, 0);
+        };
+        float maxEnergy = -1.0f;
+        int maxI = -1;
+        for (int i = 0; i < 7; i++) {                      // :1012-1021
+          const float st = TOAoffset + (float)(i - 5);
+          if (st + (float)6u > (float)(unsigned)ncorr) continue;
+          if (st < 0.0f) continue;
+          const int s0 = (int)floorf(st);
+          float energy = 0.0f;
+          for (int k = 0; k < 6; k++) energy += norm2(wv(s0 + k));
+          if ((double)energy > 0.95 * (double)maxEnergy) { maxI = i; maxEnergy = energy; }
+        }
+        const int s0 = (int)floorf(TOAoffset + (float)(maxI - 5));
+        const cx ginv = cdiv(mk(1.0f, 0.0f), T->mid_gain[tsc]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) chan[k] = cmul(wv(s0 + k), ginv);   // :1024-1025
+        chanOff = (float)(5 - maxI);                       // :1029
+      }
+    }
+  }
+  fl |= detected ? TRXSIG_F_DETECT : 0;
+  flags[b] = fl;
+  amp_out[b] = amp;
+  toa_out[b] = toa;
+  toa_eq[b] = toa - chanOff;                               // equalizeBurst(..., TOA - chanRespOffset, ...)
+  if (chan_off_out) chan_off_out[b] = chanOff;
+  if (!detected) return;
+
+  // ---- Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7) (:1246-1340) ----
+  const float thr = snr_thresh >= 0.0f ? snr_thresh : (energy_thresh < 0.0f ? 0.0f : energy_thresh);
+  const float snr = snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0));
+  const cx ainv = cdiv(mk(1.0f, 0.0f), amp);
+#pragma unroll
+  for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
+
+  constexpr int Nf = 7, nu = 5;
+  cx G0[Nf], G1[Nf];
+#pragma unroll
+  for (int k = 0; k < Nf; k++) { G0[k] = mk(0, 0); G1[k] = mk(0, 0); }
+  G0[0] = mk((float)(1.0 / (double)sqrtf(snr)), 0.0f);     // :1261
+#pragma unroll
+  for (int j = 0; j <= nu; j++) G1[j] = mk(chan[j].r, -chan[j].i);
+  cx Lu[Nf - 1][Nf - 1];                                   // L[i][j], i < j <= Nf-1, stored at [i][j-i-1]
+  cx Lfb[nu];                                              // L[Nf-1][Nf .. Nf+nu-1]
+  float d = 0.0f;
+#pragma unroll
+  for (int i = 0; i < Nf; i++) {
+    d = norm2(G0[0]) + norm2(G1[0]);                       // :1272
+    const cx g0c = mk(G0[0].r, -G0[0].i), g1c = mk(G1[0].r, -G1[0].i);
+#pragma unroll
+    for (int k = 1; k < Nf; k++) {                         // *Lptr = (G0[k]*conj(G0[0]) + G1[k]*conj(G1[0]))/d (:1277)
+      const int col = i + k;
+      const bool need = (i < Nf - 1) ? (col <= Nf - 1) : (col >= Nf && col < Nf + nu);
+      if (need) {
+        const cx tt = cadd(cmul(G0[k], g0c), cmul(G1[k], g1c));
+        const cx v = mk(tt.r / d, tt.i / d);
+        if (i < Nf - 1) Lu[i][k - 1] = v; else Lfb[col - Nf] = v;
+      }
+    }
+    const cx kk = cdiv(G1[0], G0[0]);                      // :1282
+    if (i != Nf - 1) {
+      cx G0n[Nf], G1n[Nf];
+      const cx kc = mk(kk.r, -kk.i), km = cmulr(kk, -1.0f);
+#pragma unroll
+      for (int q = 0; q < Nf; q++) G0n[q] = cadd(cmul(G1[q], kc), G0[q]);      // :1285-1287
+#pragma unroll
+      for (int q = 0; q < Nf; q++) G1n[q] = cadd(cmul(G0[q], km), G1[q]);      // :1289-1291
+#pragma unroll
+      for (int q = 0; q < Nf - 1; q++) G1n[q] = G1n[q + 1];                     // delayVector(G1new,-1) (:1292)
+      G1n[Nf - 1] = mk(0, 0);
+      const cx sc = mk((float)(1.0 / (double)sqrtf((float)(1.0 + (double)norm2(kk)))), 0.0f);   // :1294-1295
+#pragma unroll
+      for (int q = 0; q < Nf; q++) { G0[q] = cmul(G0n[q], sc); G1[q] = cmul(G1n[q], sc); }
+    }
+  }
+  cx bq[nu];
+#pragma unroll
+  for (int j = 0; j < nu; j++) {                           // :1301-1304: * -1, conj
+    const cx t1 = cmul(Lfb[j], mk(-1.0f, 0.0f));
+    bq[j] = mk(t1.r, -t1.i);
+  }
+  cx v[Nf];
+  v[Nf - 1] = mk(1.0f, 0.0f);
+#pragma unroll
+  for (int k = Nf - 2; k >= 0; k--) {                      // :1310-1319
+    cx vk = mk(0, 0);
+#pragma unroll
+    for (int j = k + 1; j < Nf; j++) {
+      const cx pr = cmul(v[j], Lu[k][j - k - 1]);
+      vk.r -= pr.r; vk.i -= pr.i;
+    }
+    v[k] = vk;
+  }
+#pragma unroll
+  for (int i = 0; i < Nf; i++) {                           // :1323-1335
+    cx wi = mk(0, 0);
+    const int endPt = (nu < (Nf - 1 - i)) ? nu : (Nf - 1 - i);
+#pragma unroll
+    for (int k = 0; k < Nf; k++)
+      if (k < endPt + 1) wi = cadd(wi, cmul(v[i + k < Nf ? i + k : Nf - 1], mk(chan[k < 6 ? k : 5].r, -chan[k < 6 ? k : 5].i)));
+    w_out[(size_t)b * Nf + i] = mk(wi.r / d, wi.i / d);
+  }
+#pragma unroll
+  for (int j = 0; j < nu; j++) b_out[(size_t)b * nu + j] = bq[j];
+}
+
+// equalizeBurst after its delayVector: xd = delayed, scaled burst (B x xstride complex)
+__global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, const cx *__restrict__ xd, int xstride,
+                                               const int32_t *__restrict__ length, int B,
+                                               const uint8_t *__restrict__ flags, const cx *__restrict__ w_in,
+                                               const cx *__restrict__ b_in, float *__restrict__ soft,
+                                               uint8_t *__restrict__ hard, int nsoft, int stride) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float *sb = soft + (size_t)b * stride;
+  uint8_t *hb = hard ? hard + (size_t)b * stride : nullptr;
+  if (!(flags[b] & TRXSIG_F_DETECT)) {
+    for (int m = 0; m < nsoft; m++) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
+    return;
+  }
+  const int N = length[b];
+  const cx *x = xd + (size_t)b * xstride;
+  cx w[7], bq[5], hist[5], win[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) w[j] = w_in[(size_t)b * 7 + j];
+#pragma unroll
+  for (int j = 0; j < 5; j++) { bq[j] = b_in[(size_t)b * 5 + j]; hist[j] = mk(0, 0); }
+  // win[j] = x[k + 6 - j] (zero outside the burst); FULL_SPAN keeps [6, 6+N) (:1352-1356)
+#pragma unroll
+  for (int j = 0; j < 7; j++) win[j] = (6 - j < N) ? x[6 - j] : mk(0, 0);
+  const int nout = nsoft < N ? nsoft : N;
+  for (int k = 0; k < nout; k++) {
+    cx d = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 7; j++) {                          // convolve general branch: sum += a[t-j]*b[j], t = k+6
+      const int ai = k + 6 - j;
+      if (ai >= 0 && ai < N) d = cadd(d, cmul(win[j], w[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++)                            // feedback over past decisions (:1370-1374)
+      if (k - 1 - j >= 0) d = cadd(d, cmul(bq[j], hist[j]));
+    d = cmul(d, T->rev[k]);                                // :1375
+    const float re = d.r;
+    const cx dec = mk((re > 0.0f) ? 1.0f : -1.0f, 0.0f);   // :1378
+    const cx fbv = cmul(dec, T->rot[k]);                   // :1380
+#pragma unroll
+    for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
+    hist[0] = fbv;
+    float sv = (float)(0.5 * (double)(re + 1.0F));         // vectorSlicer (:513-515)
+    if (sv > 1.0f) sv = 1.0f;
+    if (sv < 0.0f) sv = 0.0f;
+    sb[k] = sv;
+    if (hb) hb[k] = sv > 0.5F;
+#pragma unroll
+    for (int j = 6; j > 0; j--) win[j] = win[j - 1];
+    win[0] = (k + 7 < N) ? x[k + 7] : mk(0, 0);
+  }
+  for (int m = nout; m < nsoft; m++) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
+}
+
+
+}  // namespace
+
+hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                               const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
+                               int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
+                               trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
+                               int nsoft, int stride, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
+  k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
+                                                        variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr);
+  k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
+                                                           TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  return hipGetLastError();
+}
+
+
+// the two halves of trx_launch_equalize on their own (the Transceiver facade caches DFE taps per timeslot):
+// channel estimate + designDFE only (energy gate off, explicit SNR threshold) ...
+hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                                   const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
+                                   float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
+                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
+  k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
+                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  return hipGetLastError();
+}
+// ... and scaleVector(burst, 1/amp) + equalizeBurst(burst, toa_eq, w, b) with caller-supplied taps (7 + 5 per burst)
+hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                                    const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
+                                    const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
+                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
+  k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
+      dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  return hipGetLastError();
+}

@@ -11,7 +11,7 @@
 // by memory -- the first version, whose whole-block metric table left 2.5 waves per SIMD, took 217 us.  Per trellis step a lane fetches its two predecessors
 // (survivors s>>1 and 8 + s>>1: ds_bpermute), adds the branch costs and keeps the cheaper one; the
 // first-minimum survivor (bv:382-393) is found with four DPP min exchanges + a ballot and its deferred
-// input bit (24 steps back) is the output.  Numerical contract as in trxsig_kernels.hip: float costs are added
+// input bit (24 steps back) is the output.  Numerical contract as in trxsig_dev.h: float costs are added
 // exactly as the reference adds them (cost + (second-bit cost + first-bit cost), -ffp-contract=off),
 // so survivor selection, ties included, is bit-identical.
 #include <hip/hip_runtime.h>

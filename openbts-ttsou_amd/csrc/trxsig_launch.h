@@ -1,4 +1,6 @@
-// trxsig_launch.h -- internal launcher prototypes (kernels live in trxsig_kernels.hip).
+// trxsig_launch.h -- internal launcher prototypes.  The kernels live in trxsig_normal.hip (default normal-burst
+// path), trxsig_fused.hip (single-launch alternates), trxsig_rach.hip, trxsig_eq.hip, trxsig_tx.hip, trxsig_fec.hip;
+// shared device code in trxsig_dev.h, trxsig_corr.h, trxsig_bisect.h, trxsig_demod.h.
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -78,7 +80,7 @@ hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long
                           int ilv8 = 0 /* mode 1 through the 8-burst TCH deinterleaver (FACCH); mode 3 = TCH: out0 = 33
                                           octets of d[260], out1 = good, out2 = stolen */);
 
-// the halves of trx_launch_equalize (see trxsig_kernels.hip): channel estimate + designDFE with an explicit SNR
+// the halves of trx_launch_equalize (see trxsig_eq.hip): channel estimate + designDFE with an explicit SNR
 // threshold and no energy gate; equalizeBurst with caller-supplied taps (flags: DETECT bit = burst enabled)
 hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,

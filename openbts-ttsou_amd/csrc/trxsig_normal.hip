@@ -1,0 +1,340 @@
+// trxsig_normal.hip -- the default normal-burst path (three launches per batch):
+//   k_tsc_corr   : 16 lanes (one DPP row) per burst, 4 bursts per wave.  Midamble correlation over the
+//                  36-symbol window with the 16 non-zero taps, energy detect, argmax, and a small
+//                  per-burst record of the lags around the peak.
+//   k_tsc_peak   : one LANE per burst.  The serial part of the reference (early-late bisection of
+//                  peakDetect, valley RMS, threshold) has no parallelism inside a burst, so it is run
+//                  for 64 bursts at once from the transposed records.  (k_tsc_peak8: the speculative
+//                  8-lanes-per-burst alternative.)
+//   k_demod      : one wave per burst (trxsig_demod.h).
+// Numerical contract: see trxsig_dev.h / DESIGN.md (every float32 operation is the reference's, in the
+// reference's order; built with -ffp-contract=off).
+#include "trxsig_bisect.h"
+#include "trxsig_corr.h"
+#include "trxsig_demod.h"
+
+namespace {
+
+template <int SPS, unsigned TAPCLS>
+__global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables *__restrict__ T,
+                                                  const cx *__restrict__ samples,
+                                                  const int32_t *__restrict__ offset,
+                                                  const int32_t *__restrict__ length, int B, TapArg taps,
+                                                  cx *__restrict__ rec, int Bpad) {
+  typedef CorrGeom<SPS> G;
+  // one LDS row per burst, owned by the 16 lanes of its DPP row; no workgroup barrier anywhere.
+  // The row first holds the zero-padded window, later (same storage) the correlation.
+  // The row first holds |x[i]|^2 of the energy window, then the zero-padded window, then the correlation.
+  static_assert(8 * G::WPAD >= 4 * G::NE, "the energy norms are staged in the row itself");
+  __shared__ __attribute__((aligned(16))) cx rows[16][G::WPAD];
+  (void)T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 4, r = lane & 15;
+  const int slot = wave * 4 + row;                         // burst slot in this workgroup
+
+  cx tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
+
+  CorrIn<SPS> in[TRX_CORR_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++)
+    corr_issue<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
+#pragma unroll
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
+    int M;
+    float energy;
+    corr_round<SPS, true, true, TAPCLS>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak: one lane per burst.  peakDetect's early-late bisection (sigProcLib.cpp:684-701),
+//   the bogus-TOA check, the valley RMS, the detection threshold, amp = peak/gain and the TOA
+//   bookkeeping of analyzeTrafficBurst (:959-1000, 1035), plus energyDetect's decision (:929-931).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+__global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T,
+                                                 const cx *__restrict__ rec, int Bpad, int B, int tsc,
+                                                 float detect_thresh, float energy_thresh,
+                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                 float *__restrict__ toa_out,
+                                                 float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  __shared__ cx loc[26][64];                               // lags M-12 .. M+11 of each lane's burst; [24],[25] zero
+  __shared__ float pw[G::NS][64];                          // |corr|^2 of lags M-H .. M+H (valley power)
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+
+  // ---- everything this lane will need from the record, loaded up front (coalesced across lanes) ----
+  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+#pragma unroll
+  for (int s = 0; s < G::NS; s++) {
+    const cx v = rec[(size_t)s * Bpad + bb];
+    pw[s][lane] = norm2(v);
+    const int j = s - (G::H - 12);
+    if (j >= 0 && j < 24) {
+      const int lag = M - 12 + j;
+      loc[j][lane] = (lag > G::NL - 2) ? mk(0, 0) : v;     // interpolatePoint never uses the last sample (:646)
+    }
+  }
+  loc[24][lane] = mk(0, 0);
+  loc[25][lane] = mk(0, 0);
+  // (each lane only ever reads its own column: no barrier needed)
+
+  float peakIx;
+  const cx peak = peak_bisect<64>(T->sinc_grid, loc, lane, M, &peakIx);
+
+  // ---- analyzeTrafficBurst tail ----
+  float toa = peakIx;
+  cx amp = peak;
+  bool detected = false;
+  // energy_thresh < 0 disables the gate (trxsig.h)
+  const bool energy_ok = good && (energy_thresh < 0.0f ||
+                                  energy / (float)(unsigned)G::NE > energy_thresh * energy_thresh);
+  if (!(toa < 0.0f) && !(toa > (float)G::NL) && good) {
+    const int p = (int)rintf(toa);
+    float valley = 0.0f;
+    int numRms = 0;
+#pragma unroll
+    for (int i = 2 * SPS; i <= 5 * SPS; i++) {             // :971-980, this order
+      const int lo = p - i, hi = p + i;
+      int slo = lo - M + G::H, shi = hi - M + G::H;        // 0 .. NS-1 because |p - M| <= 1
+      slo = slo < 0 ? 0 : slo; shi = shi > G::NS - 1 ? G::NS - 1 : shi;
+      const float vlo = pw[slo][lane], vhi = pw[shi][lane];
+      if (lo >= 0) { valley += vlo; numRms++; }
+      if (hi < G::NL) { valley += vhi; numRms++; }
+    }
+    if (numRms < 2) {
+      amp = mk(0, 0);
+    } else {
+      const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);   // :989
+      const float peakToMean = sqrtf(norm2(amp)) / RMS;   // Complex::abs() via double sqrt == sqrtf
+      amp = cdiv(amp, T->mid_gain[tsc]);                   // :997
+      toa = toa - T->mid_toa[tsc];                         // :998
+      toa = toa - (float)((66 - 56) * SPS);                // :1000
+      detected = peakToMean > detect_thresh;
+    }
+  } else {
+    amp = mk(0, 0);                                        // "bogus result" (:964-968); TOA left as is
+  }
+  if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
+
+  if (live) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak8: k_tsc_peak's job (peakDetect's bisection + analyzeTrafficBurst's tail from the
+//   detect->peak record) with EIGHT lanes per burst and the bisection speculated two levels at a time
+//   (fused_point / fused_decide, see k_normal_fused): 6 dependent point evaluations instead of 10
+//   dependent steps of two, eight waves per SIMD instead of one.  The sinc rows of the first three
+//   super-steps (nodes on multiples of 16/512) come from an LDS copy; the last three gather from L2.
+//   Measured SLOWER than k_tsc_peak (25 vs 18 us per 64 K bursts): 48 lane-evaluations per burst instead
+//   of 19, each pulling 21 correlation words and a sinc row through the LDS, make it LDS-bandwidth
+//   bound (ablation: neither the L2 gathers nor occupancy matter).  Kept as an A/B option
+//   (TRXSIG_TUNE_SPECULATIVE_PEAK).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+struct Peak8Geom {
+  typedef CorrGeom<SPS> G;
+  static constexpr int NV = 2 * (3 * SPS + 1);
+  static constexpr int O_PW = 26 * 2;                                   // floats: after loc[26]
+  static constexpr int O_V = O_PW + ((G::NS + 3) & ~3);
+  static constexpr int STRIDE = O_V + ((NV + 3) & ~3);                  // floats per burst (multiple of 4)
+};
+
+template <int SPS>
+__global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restrict__ T, const cx *__restrict__ rec, int Bpad,
+                                                   int B, cx gain_inv, float mid_toa, float detect_thresh,
+                                                   float energy_thresh, uint8_t *__restrict__ flags,
+                                                   cx *__restrict__ amp_out, float *__restrict__ toa_out,
+                                                   float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  typedef Peak8Geom<SPS> P8;
+  __shared__ __attribute__((aligned(16))) float stab[32][24];            // sinc rows f = 0, 16, .., 496
+  __shared__ __attribute__((aligned(16))) float scratch[32][P8::STRIDE];
+  {
+    float tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int ix = threadIdx.x * 3 + k; tv[k] = T->sinc_grid[16 * (ix / 24)][ix % 24]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int ix = threadIdx.x * 3 + k; stab[ix / 24][ix % 24] = tv[k]; }
+  }
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 7;
+  const int slot = threadIdx.x >> 3;                       // burst slot in the workgroup
+  const int b = blockIdx.x * 32 + slot;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+  float *S = scratch[slot];
+  cx *loc = reinterpret_cast<cx *>(S);
+  float *pw = S + P8::O_PW, *V = S + P8::O_V;
+
+  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+#pragma unroll
+  for (int s0 = 0; s0 < G::NS; s0 += 8) {
+    const int sl = s0 + r;
+    if (sl < G::NS) {
+      const cx v = rec[(size_t)sl * Bpad + bb];
+      pw[sl] = norm2(v);
+      const int j = sl - (G::H - 12);
+      if (j >= 0 && j < 24) loc[j] = (M - 12 + j > G::NL - 2) ? mk(0, 0) : v;   // never the last sample (:646)
+    }
+  }
+  if (r < 2) loc[24 + r] = mk(0, 0);
+  __syncthreads();                                         // stab complete (the only barrier); also orders the scratch writes
+
+  int e = 0;                                               // early = M-1 + e/512
+  asm volatile("" : "+v"(e));
+  bool active = true;
+  cx peak = mk(0, 0);
+  {
+    const int rel2 = kFusedRel2.v[r], rel1 = kFusedRel1.v[r];
+#pragma unroll
+    for (int st = 0; st < 4; st++) {                       // increments 256,128 | 64,32 | 16,8 | 4,2
+      const int inc_last = 128 >> (2 * st);
+      const int el = e + (rel2 >> 2) * inc_last;
+      float srow[24];
+      if (st < 3) {                                        // nodes on multiples of 16/512: the LDS copy
+        const float4 *rw = reinterpret_cast<const float4 *>(stab[(el & 511) >> 4]);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const float4 t4 = rw[q];
+          srow[4 * q] = t4.x; srow[4 * q + 1] = t4.y; srow[4 * q + 2] = t4.z; srow[4 * q + 3] = t4.w;
+        }
+      } else {
+        fused_row(T, el, srow);
+      }
+      const cx pt = fused_point(loc, el, rel2 & 3, srow);
+      fused_decide<8, 2, false>(pt, lane, 2 * inc_last, e, active, peak);
+    }
+    {                                                      // the ninth step: +-1
+      float srow[24];
+      fused_row(T, e, srow);
+      const cx pt = fused_point(loc, e, rel1 & 3, srow);
+      fused_decide<8, 1, false>(pt, lane, 1, e, active, peak);
+    }
+    float srow[24];                                        // interpolatePoint(early + 1) where the loop stopped (:699-700)
+    fused_row(T, e, srow);
+    peak = fused_point(loc, e, 1, srow);
+    asm volatile("" : "+v"(peak.r), "+v"(peak.i));         // (finished here: not to be interleaved with the tail)
+  }
+  cx amp;
+  float toa;
+  bool detected, energy_ok;
+  fused_tail<SPS, 8>([&](int lag) { const int sl = lag - M + G::H; return (sl < 0 || sl >= G::NS) ? 0.0f : pw[sl]; }, V, r, M, e,
+                     peak, good, energy, gain_inv, mid_toa, detect_thresh, energy_thresh, amp, toa, detected, energy_ok);
+  if (live && r == 0) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int trx_rec_slots(int sps) {
+  switch (sps) {
+    case 1: return CorrGeom<1>::NS + 1;
+    case 2: return CorrGeom<2>::NS + 1;
+    case 4: return CorrGeom<4>::NS + 1;
+  }
+  return 0;
+}
+
+template <int S>
+static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples, const int32_t *off,
+                              const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
+                              trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                              int variant, TrxProfiler *prof) {
+  TapArg ta;
+  for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
+  if (prof) prof->begin(TRXSIG_K_TSC_CORR, st);
+  const dim3 cgrid((B + 16 * TRX_CORR_ROUNDS - 1) / (16 * TRX_CORR_ROUNDS));
+  if (!(variant & 1) && tap_classes(hT, tsc) == TapPattern<S>::value)
+    k_tsc_corr<S, TapPattern<S>::value><<<cgrid, dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
+  else
+    k_tsc_corr<S, TRX_TAPS_GENERIC><<<cgrid, dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
+  if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
+  if (!(variant & 2)) {
+    k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
+                                                            flags, amp, toa, avgpwr);
+  } else {
+    // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
+    const trx_c32 g = hT->mid_gain[tsc];
+    const float n = g.i * g.i + g.r * g.r;
+    trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
+    k_tsc_peak8<S><<<dim3((B + 31) / 32), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
+                                                              energy_thresh, flags, amp, toa, avgpwr);
+  }
+  if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
+}
+
+hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
+                                 const int32_t *off, const int32_t *len, int B, int tsc,
+                                 float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
+                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, int variant,
+                                 TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  switch (sps) {
+    case 1: launch_tsc_detect<1>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
+    case 2: launch_tsc_detect<2>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
+    case 4: launch_tsc_detect<4>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                            const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
+                            const float *toa, const uint8_t *flags, int need_mask, float *soft,
+                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  const dim3 grid((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), block(64 * TRX_DEMOD_WAVES);
+  if (prof) prof->begin(TRXSIG_K_DEMOD, st);
+#define TRX_DEMOD_CASE(S)                                                                                          \
+  case S:                                                                                                          \
+    if (nsoft <= 148)                                                                                              \
+      k_demod<S, false, 148><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, \
+                                                     nsoft, stride);                                              \
+    else                                                                                                           \
+      k_demod<S, false, 157><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, \
+                                                     nsoft, stride);                                              \
+    break;
+  switch (sps) {
+    TRX_DEMOD_CASE(1)
+    TRX_DEMOD_CASE(2)
+    TRX_DEMOD_CASE(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRX_DEMOD_CASE
+  if (prof) prof->end(TRXSIG_K_DEMOD, st);
+  return hipGetLastError();
+}
+

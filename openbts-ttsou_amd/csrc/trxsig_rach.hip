@@ -1,0 +1,629 @@
+// trxsig_rach.hip -- the access-burst path: detectRACHBurst (sigProcLib.cpp:860-914) as k_rach_fast
+// (approximate steering + exact recomputation) or k_rach_corr / k_rach_peak (exact at every lag).
+// Numerical contract: see trxsig_dev.h / DESIGN.md (every float32 operation is the reference's, in the
+// reference's order; built with -ffp-contract=off).
+#include "trxsig_bisect.h"
+#include "trxsig_corr.h"      // energy_chain (the DPP row-shift energy sum)
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// quad_bisect: peakDetect's bisection with FOUR lanes per burst: lanes {0,1,2,3} of a quad own the
+// four independent 21-term chains of a step (early.re, early.im, late.re, late.im); |.|^2 and the
+// early/late comparison are exchanged inside the quad with DPP quad_perm, and the sinc row is shared
+// by the quad (each lane keeps a quarter, taps are broadcast by quad_perm).  Same arithmetic as
+// peak_bisect.  Used where one wave owns one burst (k_rach_fast).
+// ---------------------------------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// A sinc_grid row (24 floats) is shared by the 4 lanes of a quad: lane q keeps float4 #q and #(q+4)
+// (8 floats), tap j is broadcast from lane (j/4)%4 with a DPP quad_perm.
+struct QRow { float4 a, b; };
+
+template <int J>
+__device__ __forceinline__ float qrow_tap(const QRow &w) {
+  constexpr int f4 = J / 4, src = f4 % 4, comp = J % 4;
+  const float4 &v = (f4 < 4) ? w.a : w.b;
+  const float x = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
+  return quad_perm<src * 0x55>(x);                         // quad_perm:[src,src,src,src]
+}
+
+template <bool MASK, int STR, int J>
+__device__ __forceinline__ float qchain(const float *p, int slot0, int zslot, const QRow &w, float acc) {
+  if constexpr (J < 21) {
+    float v = p[J * 2 * STR];
+    if (MASK && slot0 + J > zslot) v = 0.0f;               // interpolatePoint never uses the last sample (:646)
+    acc = acc + v * qrow_tap<J>(w);
+    return qchain<MASK, STR, J + 1>(p, slot0, zslot, w, acc);
+  } else {
+    return acc;
+  }
+}
+
+// HOFF: slot of lag M-12; STR: complex entries per slot row (bursts side by side)
+template <int HOFF, int STR, bool MASK>
+__device__ __forceinline__ void quad_bisect(const TrxTables *__restrict__ T, const float *rcf, int bi, int q, int M,
+                                            int zslot, float *peakIx, float *pk_own, float *pk_partner) {
+  const int c = q & 1, late = q >> 1;
+  auto load_row = [&](int f) {
+    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+    QRow w;
+    w.a = row[q];
+    w.b = (q < 2) ? row[q + 4] : make_float4(0, 0, 0, 0);
+    return w;
+  };
+  // one chain of interpolatePoint: sum_j comp(corr[slot0 + j]) * s[j], j ascending
+  auto chain = [&](int slot0, const QRow &w) {
+    const float *p = rcf + ((size_t)slot0 * STR + bi) * 2 + c;
+    return qchain<MASK, STR, 0>(p, slot0, zslot, w, 0.0f);
+  };
+  auto frac512 = [](float ix) { return (int)((ix - floorf(ix)) * 512.0f); };
+  auto slot_of = [&](float ix) {
+    int base = (int)floorf(ix) - M + 2;                    // 0..3 by construction
+    base = base < 0 ? 0 : (base > 3 ? 3 : base);
+    return base + HOFF;
+  };
+
+  float early = (float)M - 1;
+  float incr = 0.5f;
+  bool active = true;
+  QRow cur = load_row(0);
+#pragma unroll 1
+  for (int step = 0; step < 9; step++) {
+    const QRow up = load_row(frac512(early + incr));
+    const QRow dn = load_row(frac512(early - incr));
+    const float a = chain(slot_of(early) + 2 * late, cur);
+    const float sq = a * a;
+    const float osq = quad_perm<0xB1>(sq);                 // partner component: lanes 0<->1, 2<->3
+    const float nrm = c ? (sq + osq) : (osq + sq);         // i*i + r*r (Complex.h:119)
+    const float onrm = quad_perm<0x4E>(nrm);               // the other point: lanes 0,1 <-> 2,3
+    const float ne = late ? onrm : nrm, nl = late ? nrm : onrm;
+    const bool goUp = ne < nl, goDn = ne > nl;
+    if (active) {
+      if (goUp) early += incr;
+      else if (goDn) early -= incr;
+      else active = false;                                 // "else break" (:695)
+      if (active) incr = incr * 0.5f;
+    }
+    if (active) cur = goUp ? up : dn;                      // the row changes only if the index moved
+  }
+  *peakIx = early + 1.0f;
+  const float a = chain(slot_of(*peakIx), cur);            // every lane: its own component of the peak
+  *pk_own = a;
+  *pk_partner = quad_perm<0xB1>(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rach_corr: detectRACHBurst's correlation (sigProcLib.cpp:867-869) over ALL lags with the dense
+//   41*sps-tap access-burst sequence, energyDetect, argmax and the record for k_rach_peak.
+//   One wave per burst; lane handles lags t = lane + 64*c.
+//
+// corr[t] = sum_j tmp[j]*x[t+s-j], tmp = reverse(conj(rach)), i.e. sum_{m=Lb-1..0} x[t-F+m]*conj(rach[m])
+// with F = Lb/2, accumulated in that order (ascending j) -- every term of the reference, nothing
+// factored or reordered, so corr is bit-identical; out-of-range samples are zeros in the padded LDS
+// copy instead of being skipped (adds +-0).
+//
+// Record per burst (SoA, [slot][Bpad]): complex slots 0..23 = corr[M-12..M+11], slot 24 = {M, energy};
+// then NVAL float slots = |corr|^2 at lags M-1+57*sps .. M+1+107*sps for the valley sum (:888-893).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+struct RachGeom {
+  static constexpr int LB = 41 * SPS;                      // taps
+  static constexpr int F = LB / 2;                         // front pad
+  static constexpr int NMAX = 157 * SPS;
+  static constexpr int NCL = (NMAX + 63) / 64;             // lags per lane
+  static constexpr int XPAD = 64 * NCL + LB;               // padded burst length
+  static constexpr int V0 = 57 * SPS - 1, V1 = 107 * SPS + 1;   // valley lags relative to M
+  static constexpr int NVAL = V1 - V0 + 1;
+  static constexpr int NE = 20 * SPS;
+  static constexpr int NEQ = (NE + 15) / 16;
+  static constexpr int CSLOTS = 25;                        // complex slots
+};
+
+template <int SPS>
+__global__ __launch_bounds__(256) void k_rach_corr(const TrxTables *__restrict__ T,
+                                                   const cx *__restrict__ samples,
+                                                   const int32_t *__restrict__ offset,
+                                                   const int32_t *__restrict__ length, int B,
+                                                   cx *__restrict__ rec, float *__restrict__ recv, int Bpad) {
+  typedef RachGeom<SPS> G;
+  __shared__ cx xs[4][G::XPAD];                            // zero-padded burst, later reused for corr
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int off = offset[b], N = length[b];
+  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
+  const cx *x = samples + (good ? off : 0);
+  cx *X = xs[wave];
+
+  for (int i = lane; i < G::XPAD; i += 64) {
+    const int n = i - G::F;
+    X[i] = (good && n >= 0 && n < N) ? x[n] : mk(0, 0);
+  }
+  // energyDetect on the first 20*sps samples, strictly in order (row 0 of the wave does the chain)
+  float nrm[G::NEQ];
+#pragma unroll
+  for (int q = 0; q < G::NEQ; q++) {
+    const int i = (lane & 15) + 16 * q;
+    cx v = mk(0, 0);
+    if (good && i < G::NE) v = x[i];
+    nrm[q] = norm2(v);
+  }
+  float energy = energy_chain<SPS, 0>(0.0f, nrm);
+  energy = __shfl(energy, 0, 64);
+  wave_lds_fence();
+
+  cx acc[G::NCL];
+#pragma unroll
+  for (int c = 0; c < G::NCL; c++) acc[c] = mk(0, 0);
+  const cx *rseq = T->rach;
+#pragma unroll 4
+  for (int m = G::LB - 1; m >= 0; m--) {
+    const cx rm = rseq[m];
+    const cx tp = mk(rm.r, -rm.i);                         // conj (:487)
+#pragma unroll
+    for (int c = 0; c < G::NCL; c++) acc[c] = cadd(acc[c], cmul(X[lane + 64 * c + m], tp));
+  }
+  wave_lds_fence();                                        // all lanes are done with the samples
+
+  float bestP = 0.0f;
+  int bestT = -1;
+#pragma unroll
+  for (int c = 0; c < G::NCL; c++) {
+    const int t = lane + 64 * c;
+    if (t < N && good) {
+      X[t] = acc[c];
+      const float p = norm2(acc[c]);
+      if (p > bestP) { bestP = p; bestT = t; }             // strict >, first maximum (:675)
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const float oP = __shfl_xor(bestP, m, 64);
+    const int oT = __shfl_xor(bestT, m, 64);
+    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
+    if (take) { bestP = oP; bestT = oT; }
+  }
+  wave_lds_fence();
+
+  const int M = bestT;
+  if (lane < G::CSLOTS) {
+    cx v = mk(0, 0);
+    if (lane < 24) {
+      const int lag = M - 12 + lane;
+      if (good && lag >= 0 && lag < N) v = X[lag];
+    } else {
+      v = mk(__int_as_float(good ? M : -2), energy);
+    }
+    rec[(size_t)lane * Bpad + b] = v;
+  }
+  for (int s = lane; s < G::NVAL; s += 64) {
+    const int lag = M + G::V0 + s;
+    float p = 0.0f;
+    if (good && lag >= 0 && lag < N) p = norm2(X[lag]);
+    recv[(size_t)s * Bpad + b] = p;
+  }
+}
+
+// k_rach_peak: one lane per burst: peakDetect bisection, bogus-TOA check, valley RMS over
+//   peak+57*sps .. peak+107*sps, threshold, amp = peak/gain, TOA bookkeeping (sigProcLib.cpp:873-913).
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ T,
+                                                  const cx *__restrict__ rec, const float *__restrict__ recv,
+                                                  const int32_t *__restrict__ length, int Bpad, int B,
+                                                  float detect_thresh, float energy_thresh,
+                                                  uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                  float *__restrict__ toa_out,
+                                                  float *__restrict__ avgpwr_out) {
+  typedef RachGeom<SPS> G;
+  __shared__ cx loc[26][64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+  const cx meta = rec[(size_t)24 * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+  const int N = length[bb];
+#pragma unroll
+  for (int j = 0; j < 24; j++) {
+    const cx v = rec[(size_t)j * Bpad + bb];
+    const int lag = M - 12 + j;
+    loc[j][lane] = (lag > N - 2) ? mk(0, 0) : v;           // interpolatePoint never uses the last sample (:646)
+  }
+  loc[24][lane] = mk(0, 0);
+  loc[25][lane] = mk(0, 0);
+
+  float peakIx;
+  const cx peak = peak_bisect<64>(T->sinc_grid, loc, lane, M, &peakIx);
+
+  float toa = peakIx;
+  cx amp = mk(0, 0);
+  bool detected = false;
+  const bool energy_ok = good && (energy_thresh < 0.0f ||
+                                  energy / (float)(unsigned)G::NE > energy_thresh * energy_thresh);
+  if (!(toa < 0.0f) && !(toa > (float)N) && good) {        // :878-882
+    const int p = (int)rintf(toa);
+    float valley = 0.0f, numSamples = 0.0f;
+#pragma unroll 4
+    for (int i = 57 * SPS; i <= 107 * SPS; i++) {          // :888-893, this order, stop at the end
+      const int lag = p + i;
+      int sl = lag - M - G::V0;                            // 0 .. NVAL-1 because |p - M| <= 1
+      sl = sl < 0 ? 0 : (sl > G::NVAL - 1 ? G::NVAL - 1 : sl);
+      const float v = recv[(size_t)sl * Bpad + bb];
+      if (lag < N) { valley += v; numSamples += 1.0f; }
+    }
+    if (numSamples >= 2) {
+      const float RMS = (float)((double)sqrtf(valley / numSamples) + 0.00001);      // :901
+      const float peakToMean = sqrtf(norm2(peak)) / RMS;
+      amp = cdiv(peak, T->rach_gain);                      // :905
+      toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
+      detected = peakToMean > detect_thresh;
+    }
+  }
+  if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }
+
+  if (live) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rach_fast: detectRACHBurst (sigProcLib.cpp:860-914) with the SAME results as k_rach_corr +
+//   k_rach_peak at a fraction of the arithmetic.  One wave per burst.
+//
+// Only three things in detectRACHBurst depend on exact correlation values: which lag is the
+// maximum, the 24 lags around it that peakDetect interpolates, and (through one comparison) the
+// valley power.  So:
+//  1. an APPROXIMATE correlation at all lags: the access-burst sequence is GMSK-modulated symbols,
+//     rach[m] = sum_k p[m+sps-sps*k] * c_k, hence corr[t] = sum_k conj(c_k) * z[t-F-sps+sps*k] with
+//     z = x filtered by the (2*sps+1)-tap pulse, minus two edge terms for the pulse tails the
+//     reference's NO_DELAY convolution dropped (sigProcLib.cpp:559); with c_k ~ (+-1)*i^k the 41-tap sum
+//     is additions only.  Measured error of |corr|^2 <= 1.2e-5 of the maximum (tools/).
+//  2. every lag whose approximate power is within RACH_DELTA (4e-3, >300x that error) of the
+//     approximate maximum, plus the 26 lags around the approximate argmax, is recomputed EXACTLY (the
+//     reference's 41*sps-term sum in its order, one lag per lane); the exact first-maximum among them
+//     is the reference's argmax because no other lag can reach it.  If the exact argmax moved by more
+//     than one lag its neighbourhood is recomputed too.
+//  3. peakDetect's bisection runs on the exact neighbourhood (four lanes, quad_bisect).
+//  4. the valley RMS uses the approximate powers; if peak/RMS lands within 1e-3 (relative) of the
+//     threshold -- where a 1e-5 error could matter -- the valley lags are recomputed exactly and summed
+//     in the reference's order, so the detect decision is the reference's in every case.
+// If more far-away candidates turn up than fit in one pass (flat noise, silence) the burst takes
+// the exact route for all lags.
+// ---------------------------------------------------------------------------------------------
+#define RACH_DELTA 4e-3f
+#define RACH_GUARD 1e-3f
+__device__ __constant__ const signed char kRachSym[41] = {           // 2*bit-1 of gRACHSynchSequence (GSM/GSMCommon.cpp:57)
+  -1, 1, -1, -1, 1, -1, 1, 1, -1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, 1, -1, -1, -1, 1, 1, 1, 1, -1,
+  -1, -1 };
+
+template <int SPS>
+struct RachFast {
+  typedef RachGeom<SPS> R;
+  static constexpr int XF = R::F + SPS;                     // X[i] = x[i - XF]
+  static constexpr int XPAD = 64 * R::NCL + R::LB + 4 * SPS + 8;
+  static constexpr int ZPAD = 64 * R::NCL + 40 * SPS + 1;   // Zs[i] = sum_j p[j] X[i+j]
+  static constexpr int NB = 26;                             // lags M~-13 .. M~+12 always recomputed
+};
+
+// exact corr[t] (sigProcLib.cpp:474-503 + 322-366): sum over m = LB-1 .. 0 of x[t-F+m]*conj(rach[m])
+template <int SPS>
+__device__ __forceinline__ cx rach_exact_lag(const cx *X, const cx *__restrict__ rseq, int t) {
+  typedef RachGeom<SPS> R;
+  cx acc = mk(0, 0);
+  const cx *xp = X + t + SPS;                              // X index of x[t-F+m] is t + m + SPS
+#pragma unroll 4
+  for (int m = R::LB - 1; m >= 0; m--) {
+    const cx rm = rseq[m];
+    acc = cadd(acc, cmul(xp[m], mk(rm.r, -rm.i)));
+  }
+  return acc;
+}
+
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+                                                   const int32_t *__restrict__ offset,
+                                                   const int32_t *__restrict__ length, int B,
+                                                   float detect_thresh, float energy_thresh,
+                                                   uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                   float *__restrict__ toa_out, float *__restrict__ avgpwr_out) {
+  typedef RachGeom<SPS> R;
+  typedef RachFast<SPS> Q;
+  __shared__ cx xs[1][Q::XPAD];
+  __shared__ cx zs[1][Q::ZPAD];                             // pulse-filtered burst; later approx powers (float view)
+  __shared__ cx exv[1][64];                                 // exact correlation of the selected lags
+  __shared__ int exl[1][64];                                // ... and which lags they are
+  __shared__ cx nb[1][26];                                  // exact neighbourhood corr[M-12..M+11] (+2 zero slots)
+
+  const int lane = threadIdx.x;
+  constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int off = offset[b], N = length[b];
+  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
+  if (!good) {
+    if (lane == 0) { flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = 0.0f; }
+    return;
+  }
+  const cx *x = samples + off;
+  cx *X = xs[wave];
+  cx *Z = zs[wave];
+  float *PW = reinterpret_cast<float *>(Z);
+  const cx *rseq = T->rach;
+
+  for (int i = lane; i < Q::XPAD; i += 64) {
+    const int n = i - Q::XF;
+    X[i] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
+  }
+  float nrm[R::NEQ];
+#pragma unroll
+  for (int q = 0; q < R::NEQ; q++) {
+    const int i = (lane & 15) + 16 * q;
+    cx v = mk(0, 0);
+    if (i < R::NE) v = x[i];
+    nrm[q] = norm2(v);
+  }
+  float energy = energy_chain<SPS, 0>(0.0f, nrm);
+  energy = __shfl(energy, 0, 64);
+  const bool energy_ok = energy_thresh < 0.0f || energy / (float)(unsigned)R::NE > energy_thresh * energy_thresh;
+  if (!energy_ok) {                                        // Transceiver.cpp:298-306: correlator not run
+    if (lane == 0) { flags[b] = 0; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE; }
+    return;
+  }
+  wave_lds_fence();
+
+  // ---- 1. approximate correlation at all lags (FMA allowed: this pass only steers) ----
+  float pul[2 * SPS + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * SPS + 1; j++) pul[j] = T->pulse[j];
+  for (int i = lane; i < Q::ZPAD; i += 64) {
+    float zr = 0.0f, zi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2 * SPS + 1; j++) {
+      const cx v = X[i + j];
+      zr = __builtin_fmaf(pul[j], v.r, zr); zi = __builtin_fmaf(pul[j], v.i, zi);
+    }
+    Z[i] = mk(zr, zi);
+  }
+  wave_lds_fence();
+  float pw[R::NCL];
+  float bestP = 0.0f;
+  int bestT = -1;
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) {
+    const int t = lane + 64 * c;
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 41; k++) {                         // conj(c_k) z, c_k = sym_k i^k: additions only
+      const cx z = Z[t + SPS * k];
+      const float sg = (float)kRachSym[k];
+      if ((k & 3) == 0) { ar += sg * z.r; ai += sg * z.i; }
+      else if ((k & 3) == 1) { ar += sg * z.i; ai -= sg * z.r; }
+      else if ((k & 3) == 2) { ar -= sg * z.r; ai -= sg * z.i; }
+      else { ar -= sg * z.i; ai += sg * z.r; }
+    }
+    // pulse tails the reference's modulateBurst dropped: before symbol 0 (j < sps) and after symbol 40 (j = 2 sps)
+    float e0r = 0.0f, e0i = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = __builtin_fmaf(pul[j], v.r, e0r); e0i = __builtin_fmaf(pul[j], v.i, e0i); }
+    const float s0 = (float)kRachSym[0], s40 = (float)kRachSym[40];
+    ar -= s0 * e0r; ai -= s0 * e0i;                        // k = 0: conj(c_0) = s0
+    const cx v40 = X[t + 42 * SPS];
+    ar -= s40 * pul[2 * SPS] * v40.r; ai -= s40 * pul[2 * SPS] * v40.i;   // k = 40: i^40 = 1
+    const float p = (t < N) ? ar * ar + ai * ai : -1.0f;
+    pw[c] = p;
+    if (p > bestP) { bestP = p; bestT = t; }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const float oP = __shfl_xor(bestP, m, 64);
+    const int oT = __shfl_xor(bestT, m, 64);
+    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
+    if (take) { bestP = oP; bestT = oT; }
+  }
+  wave_lds_fence();                                        // everybody is done reading Z
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) PW[lane + 64 * c] = pw[c];   // approximate powers (lags >= N hold -1)
+
+  // ---- 2. exact recomputation of the contenders ----
+  const int Ma = bestT;                                    // approximate argmax (-1: silence)
+  const float cut = bestP * (1.0f - RACH_DELTA);
+  const int nb0 = Ma - 13;                                 // neighbourhood lags nb0 .. nb0+25
+  int nfar = 0;
+  int *LG = exl[wave];
+  if (lane < Q::NB) LG[lane] = nb0 + lane;
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) {
+    const int t = lane + 64 * c;
+    const bool far = (t < N) && (pw[c] >= cut) && (t < nb0 || t >= nb0 + Q::NB);
+    const unsigned long long mask = __ballot(far);
+    const int pos = nfar + __popcll(mask & ((1ull << lane) - 1ull));
+    if (far && pos < 64 - Q::NB) LG[Q::NB + pos] = t;
+    nfar += __popcll(mask);
+  }
+  wave_lds_fence();
+  int M;                                                   // exact argmax
+  if (Ma < 0 || nfar > 64 - Q::NB) {
+    // flat or silent burst: exact correlation at every lag (the k_rach_corr route)
+    float bP = 0.0f; int bT = -1;
+    for (int c = 0; c < R::NCL; c++) {
+      const int t = lane + 64 * c;
+      if (t < N) {
+        const cx v = rach_exact_lag<SPS>(X, rseq, t);
+        const float p = norm2(v);
+        if (p > bP) { bP = p; bT = t; }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const float oP = __shfl_xor(bP, m, 64);
+      const int oT = __shfl_xor(bT, m, 64);
+      const bool take = (oP > bP) || (oP == bP && oT >= 0 && (bT < 0 || oT < bT));
+      if (take) { bP = oP; bT = oT; }
+    }
+    M = bT;
+    if (lane < 24) {
+      const int lag = M - 12 + lane;
+      nb[wave][lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
+    }
+  } else {
+    const int nl = Q::NB + nfar;
+    const int t = lane < nl ? LG[lane] : -1;
+    cx v = mk(0, 0);
+    const bool valid = t >= 0 && t < N;
+    if (valid) v = rach_exact_lag<SPS>(X, rseq, t);
+    exv[wave][lane] = v;
+    float bP = valid ? norm2(v) : 0.0f;
+    int bT = (valid && bP > 0.0f) ? t : -1;
+    if (bT < 0) bP = 0.0f;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const float oP = __shfl_xor(bP, m, 64);
+      const int oT = __shfl_xor(bT, m, 64);
+      const bool take = (oP > bP) || (oP == bP && oT >= 0 && (bT < 0 || oT < bT));
+      if (take) { bP = oP; bT = oT; }
+    }
+    M = bT;
+    wave_lds_fence();
+    if (M >= nb0 + 12 && M <= nb0 + 14) {                  // |M - Ma| <= 1: [M-12, M+11] lies inside the recomputed lags
+      if (lane < 24) nb[wave][lane] = exv[wave][M - 12 + lane - nb0];
+    } else if (lane < 24) {
+      const int lag = M - 12 + lane;
+      nb[wave][lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
+    }
+  }
+  if (lane < 24) {                                         // interpolatePoint never uses the last sample (:646)
+    const int lag = M - 12 + lane;
+    if (lag > N - 2 || lag < 0) nb[wave][lane] = mk(0, 0);
+  }
+  if (lane >= 24 && lane < 26) nb[wave][lane] = mk(0, 0);
+  wave_lds_fence();
+
+  // ---- 3. peakDetect's bisection on the exact neighbourhood (lanes 0..3) ----
+  float peakIx, pkOwn, pkOther;
+  quad_bisect<0, 1, false>(T, reinterpret_cast<const float *>(nb[wave]), 0, lane & 3, M, 1 << 30, &peakIx, &pkOwn,
+                           &pkOther);
+  peakIx = __shfl(peakIx, 0, 64); pkOwn = __shfl(pkOwn, 0, 64); pkOther = __shfl(pkOther, 0, 64);
+  const cx peak = mk(pkOwn, pkOther);
+
+  // ---- 4. detectRACHBurst tail (:875-913) ----
+  float toa = peakIx;
+  cx amp = mk(0, 0);
+  bool detected = false;
+  if (!(toa < 0.0f) && !(toa > (float)N)) {
+    const int p = (int)rintf(toa);
+    const int i0 = 57 * SPS, i1 = 107 * SPS;
+    int last = N - 1 - p;                                  // largest i with p + i < N
+    if (last > i1) last = i1;
+    const int cnt = last - i0 + 1;                         // numSamples
+    if (cnt >= 2) {
+      float vs = 0.0f;
+      for (int i = i0 + lane; i <= last; i += 64) vs += PW[p + i];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
+      float RMS = (float)((double)sqrtf(vs / (float)cnt) + 0.00001);
+      float peakToMean = sqrtf(norm2(peak)) / RMS;
+      if (fabsf(peakToMean - detect_thresh) <= RACH_GUARD * fabsf(detect_thresh) || !(vs == vs)) {
+        // too close to call from approximate powers: the reference's valley, exactly (:888-901)
+        float *VX = reinterpret_cast<float *>(exv[wave]);
+        float valley = 0.0f;
+        for (int base = i0; base <= last; base += 64) {
+          const int i = base + lane;
+          float pv = 0.0f;
+          if (i <= last) pv = norm2(rach_exact_lag<SPS>(X, rseq, p + i));
+          wave_lds_fence();
+          VX[lane] = pv;
+          wave_lds_fence();
+          if (lane == 0) {
+            const int n = (last - base + 1) < 64 ? (last - base + 1) : 64;
+            for (int k = 0; k < n; k++) valley += VX[k];
+          }
+        }
+        valley = __shfl(valley, 0, 64);
+        RMS = (float)((double)sqrtf(valley / (float)cnt) + 0.00001);
+        peakToMean = sqrtf(norm2(peak)) / RMS;
+      }
+      amp = cdiv(peak, T->rach_gain);                      // :905
+      toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
+      detected = peakToMean > detect_thresh;
+    }
+  }
+  if (lane == 0) {
+    flags[b] = TRXSIG_F_ENERGY | (detected ? TRXSIG_F_DETECT : 0);
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
+  }
+}
+
+
+}  // namespace
+
+int trx_rach_rec_floats(int sps) {            // floats per burst in the rach record (complex slots + valley)
+  switch (sps) {
+    case 1: return 2 * RachGeom<1>::CSLOTS + RachGeom<1>::NVAL;
+    case 2: return 2 * RachGeom<2>::CSLOTS + RachGeom<2>::NVAL;
+    case 4: return 2 * RachGeom<4>::CSLOTS + RachGeom<4>::NVAL;
+  }
+  return 0;
+}
+
+template <int S>
+static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+                               const int32_t *len, int B, float detect_thresh, float energy_thresh, float *ws,
+                               int Bpad, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                               TrxProfiler *prof) {
+  trx_c32 *rec = (trx_c32 *)ws;
+  float *recv = ws + (size_t)2 * RachGeom<S>::CSLOTS * Bpad;
+  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
+  k_rach_corr<S><<<dim3((B + 3) / 4), dim3(256), 0, st>>>(dT, samples, off, len, B, rec, recv, Bpad);
+  if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
+  k_rach_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, recv, len, Bpad, B, detect_thresh,
+                                                           energy_thresh, flags, amp, toa, avgpwr);
+  if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
+}
+
+hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                                const int32_t *off, const int32_t *len, int B, float detect_thresh,
+                                float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
+                                TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  const dim3 grid(B), block(64);
+  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
+  switch (sps) {
+    case 1: k_rach_fast<1><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    case 2: k_rach_fast<2><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    case 4: k_rach_fast<4><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (prof) prof->end(TRXSIG_K_RACH_CORR, st);
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
+                                  const int32_t *off, const int32_t *len, int B, float detect_thresh,
+                                  float energy_thresh, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp,
+                                  float *toa, float *avgpwr, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  switch (sps) {
+    case 1: launch_rach_detect<1>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 2: launch_rach_detect<2>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
+    case 4: launch_rach_detect<4>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+

@@ -15,10 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_kernels_have_no_contracted_fma():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "openbts-ttsou_amd", "csrc"), "asm"],
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "openbts-ttsou_amd", "csrc"), "asm"],
                           stderr=subprocess.DEVNULL)
     out = ""
-    for f in ("trxsig_kernels.gfx950.s", "trxsig_fec.gfx950.s"):
+    for f in ("trxsig_normal", "trxsig_fused", "trxsig_rach", "trxsig_eq", "trxsig_tx", "trxsig_fec"):
+        f += ".gfx950.s"
         out += subprocess.check_output(["python3", os.path.join(ROOT, "tools", "asm_stats.py"),
                                         os.path.join(ROOT, "openbts-ttsou_amd", "csrc", f)], text=True)
     rows = [l for l in out.splitlines() if "outside a division" in l]

@@ -7,7 +7,7 @@ import re
 import sys
 from collections import Counter
 
-path = sys.argv[1] if len(sys.argv) > 1 else "openbts-ttsou_amd/csrc/trxsig_kernels.gfx950.s"
+path = sys.argv[1] if len(sys.argv) > 1 else "openbts-ttsou_amd/csrc/trxsig_normal.gfx950.s"
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 text = open(path).read()
 for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
