@@ -13,7 +13,7 @@ XCCH_POLY, RACH_POLY = 0x10004820009, 0x06f
 
 class FecOracle:
     def __init__(self):
-        self.lib = L = C.CDLL(os.path.join(_HERE, "libfec_oracle.so"))
+        self.lib = L = C.CDLL(os.environ.get("FEC_ORACLE_LIB", os.path.join(_HERE, "libfec_oracle.so")))   # override: sanitizer builds
         L.fo_encode.argtypes = [u8p, C.c_int, u8p]
         L.fo_viterbi_decode.argtypes = [f32p, C.c_int, u8p, C.c_int]
         for n in ("fo_parity", "fo_syndrome"):

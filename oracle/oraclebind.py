@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsigproc_oracle.so")
+_SO = os.environ.get("SIGPROC_ORACLE_LIB", os.path.join(_HERE, "libsigproc_oracle.so"))   # override: sanitizer builds
 
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
