@@ -208,3 +208,23 @@ def test_tch_facch(t, golden):
         for k in ("tch", "good", "stolen", "facch", "facch_ok"):
             assert np.array_equal(got[k], want[k]), (k, wire)
         assert got["good"][valid].mean() > 0.5
+
+
+def test_argument_checks_and_empty_batches(pkg, t):
+    """Bad arguments are rejected with TRXSIG_EINVAL (no launch); empty batches are no-ops."""
+    import torch
+    L = pkg.lib()
+    soft = torch.rand(8, 148, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    p = lambda x: x.data_ptr()
+    assert L.trxsig_fec_xcch_decode_batch(t.h, p(soft), 148, 0, 1, p(out), p(out)) == 0
+    assert L.trxsig_fec_xcch_decode_batch(t.h, p(soft), 100, 2, 1, p(out), p(out)) != 0          # stride < 148
+    assert L.trxsig_fec_xcch_decode_batch(t.h, None, 148, 2, 1, p(out), p(out)) != 0
+    assert L.trxsig_fec_rach_decode_batch(t.h, p(soft), 148, 0, 1, p(out), p(out), p(out)) == 0
+    assert L.trxsig_fec_rach_decode_batch(t.h, p(soft), 148, 8, 1, None, p(out), p(out)) != 0
+    assert L.trxsig_fec_tch_decode_batch(t.h, p(soft), 148, 7, 1, p(out), p(out), None, None, p(out)) == 0   # < 8 bursts: no block
+    assert L.trxsig_fec_tch_decode_batch(t.h, p(soft), 148, 8, 1, p(out), p(out), p(out), None, p(out)) != 0 # facch without its flag
+    assert L.trxsig_fec_viterbi_batch(t.h, p(soft), 37, 148, 2, p(out), 32) != 0                  # odd length
+    assert L.trxsig_fec_viterbi_batch(t.h, p(soft), 148, 148, 0, p(out), 74) == 0
+    assert b"bad argument" in L.trxsig_last_error(t.h)
+    torch.cuda.synchronize()
