@@ -4,7 +4,7 @@
 // It re-creates the names a Transceiver / RadioInterface translation unit uses -- `complex`,
 // `signalVector`, `BitVector`, `SoftVector`, sigProcLibSetup, generateGSMPulse, modulateBurst,
 // generateMidamble, generateRACHSequence, energyDetect, analyzeTrafficBurst, detectRACHBurst,
-// demodulateBurst, polyphaseResampleVector, createLPF -- with the reference's argument meaning,
+// demodulateBurst, polyphaseResampleVector, createLPF (with setLPFTables) -- with the reference's argument meaning,
 // ownership (functions returning a pointer allocate with `new`, the caller deletes:
 // Transceiver.cpp:112,407,672) and error behaviour (NULL / false, amplitude set to 0 on a "bogus
 // result": sigProcLib.cpp:878-882, 964-968).  Every call that processes samples runs on the GPU
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "trxsig.h"
+#include "trxsig_transceiver.h"   // trxsig_create_lpf_host
 
 namespace trxfacade {
 
@@ -198,11 +199,46 @@ inline SoftVector *demodulateBurst(const signalVector &rxBurst, const signalVect
   return out;
 }
 
+// createLPF (sigProcLib.h:340-343).  The reference ignores the cutoff and loads one of its two coefficient
+// tables (rcvLPF_651.h for filterLen 651, else sendLPF_961.h; sigProcLib.cpp:1119-1139); those tables are
+// reference data, so the caller registers them once (the arrays of the reference's own headers will do).
+inline const float *&lpfTable(int which) { static const float *t[2] = {NULL, NULL}; return t[which]; }
+inline void setLPFTables(const float *rcvLPF_651, const float *sendLPF_961) { lpfTable(0) = rcvLPF_651; lpfTable(1) = sendLPF_961; }
+inline signalVector *createLPF(float /*cutoffFreq*/, int filterLen, float gainDC = 1.0F) {
+  const float *raw = lpfTable(filterLen == 651 ? 0 : 1);
+  const int len = filterLen == 651 ? 651 : 961;
+  if (!raw) return NULL;
+  std::vector<float> taps(len);
+  if (trxsig_create_lpf_host(raw, len, gainDC, taps.data()) != TRXSIG_OK) return NULL;
+  signalVector *lpf = new signalVector(len);
+  for (int k = 0; k < len; k++) (*lpf)[k] = complex(taps[k], 0.0f);
+  lpf->isRealOnly(true);
+  return lpf;
+}
+// polyphaseResampleVector (sigProcLib.h:352-354) with a real-only LPF (the only kind createLPF makes)
+inline signalVector *polyphaseResampleVector(signalVector &wVector, int P, int Q, signalVector *LPF) {
+  State &s = state();
+  if (!s.ctx || !LPF || !LPF->isRealOnly() || wVector.size() == 0) return NULL;
+  std::vector<float> taps(LPF->size());
+  for (size_t k = 0; k < LPF->size(); k++) taps[k] = (*LPF)[k].r;
+  const int nout = trxsig_resample_out_len((int)wVector.size(), P, Q);
+  signalVector *out = new signalVector(nout);
+  if (trxsig_resample_host(s.ctx, (const trxsig_c32 *)wVector.begin(), (int)wVector.size(), P, Q, taps.data(),
+                           (int)taps.size(), (trxsig_c32 *)out->begin(), nout) != nout) {
+    delete out;
+    return NULL;
+  }
+  return out;
+}
+
 }  // namespace trxfacade
 
 #ifndef TRXFACADE_NO_GLOBAL_NAMES   /* the reference's names are namespace-less (sigProcLib.h) */
 using trxfacade::analyzeTrafficBurst;
 using trxfacade::BitVector;
+using trxfacade::createLPF;
+using trxfacade::polyphaseResampleVector;
+using trxfacade::setLPFTables;
 using trxfacade::complex;
 using trxfacade::demodulateBurst;
 using trxfacade::detectRACHBurst;

@@ -193,6 +193,9 @@ int trxsig_resample_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, int n_in, int
                           int S, int P, int Q, const float *d_lpf, int L,
                           trxsig_c32 *d_out, int64_t out_stride);
 int trxsig_resample_out_len(int n_in, int P, int Q);
+/* one stream, host buffers (one PCIe round trip): returns the number of output samples, < 0 on error */
+int trxsig_resample_host(trxsig_ctx *ctx, const trxsig_c32 *h_in, int n_in, int P, int Q, const float *h_lpf, int L,
+                         trxsig_c32 *h_out, int out_capacity);
 
 /* int16 I/Q <-> float: RadioInterface::unUSRPifyVector / USRPifyVector
  *   (radioInterface.cpp:74-116).  swap_iq = 1 reproduces the non-SWLOOPBACK I/Q flip on RX. */

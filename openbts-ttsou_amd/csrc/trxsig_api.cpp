@@ -468,6 +468,29 @@ int trxsig_resample_batch(trxsig_ctx *c, const trxsig_c32 *d_in, int n_in, int64
   return TRXSIG_OK;
 }
 
+int trxsig_resample_host(trxsig_ctx *c, const trxsig_c32 *h_in, int n_in, int P, int Q, const float *h_lpf, int L,
+                         trxsig_c32 *h_out, int out_cap) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n_in <= 0 || P <= 0 || Q <= 0 || L <= 0 || !h_in || !h_lpf || !h_out)
+    return fail(c, TRXSIG_EINVAL, "trxsig_resample_host: bad argument");
+  const int nout = trxsig_resample_out_len(n_in, P, Q);
+  if (nout > out_cap) return fail(c, TRXSIG_EINVAL, "trxsig_resample_host: output buffer too small");
+  DeviceGuard g(c->device);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_in = 0, o_lpf = up(8 * (size_t)n_in), o_out = o_lpf + up(4 * (size_t)L), end = o_out + up(8 * (size_t)nout);
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  HIPCHK(c, hipMemcpyAsync(d + o_in, h_in, 8 * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_lpf, h_lpf, 4 * (size_t)L, hipMemcpyHostToDevice, c->stream));
+  rc = trxsig_resample_batch(c, (const trxsig_c32 *)(d + o_in), n_in, n_in, 1, P, Q, (const float *)(d + o_lpf), L,
+                             (trxsig_c32 *)(d + o_out), nout);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_out, 8 * (size_t)nout, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return nout;
+}
+
 int trxsig_unpack_int16(trxsig_ctx *c, const int16_t *d_iq, int64_t n, int swap_iq, trxsig_c32 *d_out) {
   if (!c) return TRXSIG_EINVAL;
   if (n < 0 || (n > 0 && (!d_iq || !d_out))) return fail(c, TRXSIG_EINVAL, "trxsig_unpack_int16: bad argument");

@@ -3,6 +3,7 @@
 // the RACH leg) written against the reference's own function names.  Exit code 0 = all bits recovered.
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "sigProcLib_trx.h"
 
@@ -55,7 +56,20 @@ int main(int argc, char **argv) {
   }
   std::printf("access burst: %d bit errors\n", rerrs);
 
+  // rate conversion as RadioInterface::pullBuffer does it (radioInterface.cpp:230-246): createLPF + polyphaseResampleVector
+  std::vector<float> raw651(651), raw961(961);
+  for (int k = 0; k < 651; k++) raw651[k] = 0.001f * (float)((k * 37) % 101) - 0.02f;
+  for (int k = 0; k < 961; k++) raw961[k] = 0.001f * (float)((k * 53) % 97) - 0.01f;
+  setLPFTables(raw651.data(), raw961.data());
+  signalVector *lpf = createLPF(1.0f / 96.0f, 961, (float)(65 * sps));
+  signalVector in(192 + 864);
+  for (size_t k = 0; k < in.size(); k++) in[k] = complex((float)((k * 7) % 13) - 6.0f, (float)((k * 11) % 17) - 8.0f);
+  signalVector *res = lpf ? polyphaseResampleVector(in, 65 * sps, 96, lpf) : NULL;
+  std::printf("resampled %d -> %d samples\n", (int)in.size(), res ? (int)res->size() : -1);
+  const bool rs_ok = res && (int)res->size() == (int)((in.size() * 65 * sps + 95) / 96);
+  delete res; delete lpf;
+
   delete soft; delete mod; delete rmod; delete gsmPulse;
   sigProcLibDestroy();
-  return (errs == 0 && rfound && rerrs == 0) ? 0 : 1;
+  return (errs == 0 && rfound && rerrs == 0 && rs_ok) ? 0 : 1;
 }
