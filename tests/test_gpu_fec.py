@@ -228,3 +228,33 @@ def test_argument_checks_and_empty_batches(pkg, t):
     assert L.trxsig_fec_viterbi_batch(t.h, p(soft), 148, 148, 0, p(out), 74) == 0
     assert b"bad argument" in L.trxsig_last_error(t.h)
     torch.cuda.synchronize()
+
+
+def test_end_to_end_access_burst_to_ra(pkg, t):
+    """Access bursts carrying RA + BSIC-masked parity -> modulate -> channel with unknown delay -> detectRACHBurst +
+    demodulateBurst -> RACH FEC: RA and BSIC come back; GPU chain == oracle chain bit for bit."""
+    import torch
+    sps, n = 4, 256
+    o = fecbind.FecOracle(); so = oraclebind.Oracle(sps)
+    rng = np.random.default_rng(77)
+    ra = rng.integers(0, 256, n); bsic = rng.integers(0, 64, n)
+    bits = synth.rach_bits(rng, n)
+    for i in range(n):
+        u = np.zeros(18, np.uint8)
+        u[:8] = o.lsb8msb(np.array([(ra[i] >> (7 - k)) & 1 for k in range(8)], np.uint8))
+        sent = (~(o.parity(fecbind.RACH_POLY, 6, u[:8]) ^ int(bsic[i]))) & 0x3f
+        u[8:14] = [(sent >> (5 - k)) & 1 for k in range(6)]
+        bits[i, 49:85] = o.encode(u)
+    x, off, length, meta = synth.bursts_from_bits(bits, sps, seed=6, sigmas=(0.0, 0.1, 0.2), max_delay=1.5)
+    from util import GpuBatch
+    gb = GpuBatch(x, off, length, nsoft=148, stride=148)
+    t.detect_demod_rach(gb.x, gb.off, gb.len, gb.flags, gb.amp, gb.toa, gb.soft, energy_thresh=-1.0, nsoft=148, soft_stride=148)
+    out = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    t.fec_rach_decode(gb.soft, n, out[0], out[1], out[2], wire=True)
+    torch.cuda.synchronize()
+    got = np.stack([v.cpu().numpy() for v in out], axis=1)
+    ok, amp, toa, soft = so.rach_batch(x, off, length, nsoft=148, nthreads=8)
+    assert np.array_equal(got, o.rach_decode_batch(soft[:, :148], wire=True, nthreads=4))
+    det = (gb.flags.cpu().numpy() & pkg.F_DETECT) != 0
+    good = det & (got[:, 0] == 1) & (got[:, 1] == bsic)
+    assert good.sum() >= 0.85 * n and np.array_equal(got[good, 2], ra[good])
