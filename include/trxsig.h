@@ -298,15 +298,15 @@ const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);
 /* Implementation choice for A/B measurements; results are bit-identical whatever is selected.
- *   TRXSIG_TUNE_NORMAL_PATH: 0 = three kernels (correlate, peak, demodulate), 1 = one fused kernel
- *     with a wave per burst, 2 = fused with two bursts per wave (fused paths need nsoft <= 148,
- *     otherwise the call falls back to 0).  Initial value: env TRXSIG_TSC_VARIANT or the default.
- *   TRXSIG_TUNE_RACH_PATH: 0 = exact correlation at every lag, 1 = approximate-then-exact.
- *     Initial value: env TRXSIG_RACH_VARIANT or the default.
- *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component"
- *     specialisation (which is only taken when the actual taps have that form).  Default 0.
- *     The 3 in TRXSIG_TUNE_NORMAL_PATH selects the fused kernel with four bursts per wave, 4 its
- *     detection half followed by the demodulation kernel.
+ *   TRXSIG_TUNE_NORMAL_PATH (trxsig_detect_demod_normal_batch; initial value: env TRXSIG_TSC_VARIANT, else 0):
+ *     0 = three kernels: correlate, peak, demodulate (the default and the fastest measured);
+ *     1 = one fused kernel, a wave per burst;   2 = fused, two bursts per wave;
+ *     3 = fused, four bursts per wave (k_normal_quad);   4 = k_normal_quad's detection half, then k_demod.
+ *     The fused kernels need nsoft <= 148; otherwise the call takes path 0.
+ *   TRXSIG_TUNE_RACH_PATH (initial value: env TRXSIG_RACH_VARIANT, else 1): 0 = exact correlation at every
+ *     lag, 1 = approximate-then-exact (k_rach_fast).
+ *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component" form (which
+ *     is only taken when the actual taps have that shape).  Default 0.
  *   TRXSIG_TUNE_SPECULATIVE_PEAK: 1 = path 0 runs peakDetect with eight lanes per burst and speculated
  *     bisection (k_tsc_peak8) instead of a lane per burst and the reference's serial loop.  Default 0
  *     (measured slower: 25 vs 18 us per 64 K bursts, LDS bandwidth). */
