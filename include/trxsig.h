@@ -278,6 +278,11 @@ int trxsig_fec_xcch_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_
                                  int wire_quantise, uint8_t *d_frames, uint8_t *d_ok);
 int trxsig_fec_rach_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_bursts,
                                  int wire_quantise, uint8_t *d_tail_ok, uint8_t *d_bsic, uint8_t *d_ra);
+/* XCCH L1 encode, the transmit-side mirror (XCCHL1Encoder::sendFrame/encode/interleave/transmit,
+ * GSML1FEC.cpp:772-845): n_blocks L2 frames of 23 octets -> 4*n_blocks normal bursts of 148 bits, one bit per
+ * byte, ready for trxsig_modulate_batch: e-bits at 3..59 / 88..144, zero tails, both stealing flags set, the
+ * training sequence `tsc` at 61..86. */
+int trxsig_fec_xcch_encode_batch(trxsig_ctx *ctx, const uint8_t *d_frames, int n_blocks, int tsc, uint8_t *d_bits);
 int trxsig_fec_tch_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_stride, int n_bursts,
                                 int wire_quantise, uint8_t *d_tch, uint8_t *d_tch_good, uint8_t *d_facch,
                                 uint8_t *d_facch_ok, uint8_t *d_stolen);

@@ -73,6 +73,7 @@ def lib():
         L.trxsig_pack_int16_scaled.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
         L.trxsig_fec_xcch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.trxsig_fec_rach_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.trxsig_fec_xcch_encode_batch.argtypes = [vp, vp, i32, i32, vp]
         L.trxsig_fec_tch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.trxsig_fec_viterbi_batch.argtypes = [vp, vp, i32, C.c_int64, i32, vp, C.c_int64]
         L.trxsig_timer_start.argtypes = [vp]
@@ -274,6 +275,9 @@ class TrxSig:
         self._chk(self.L.trxsig_fec_rach_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_bursts,
                                                       int(wire), _ptr(tail_ok), _ptr(bsic), _ptr(ra)),
                   "trxsig_fec_rach_decode_batch")
+
+    def fec_xcch_encode(self, frames, n_blocks, tsc, bits):
+        self._chk(self.L.trxsig_fec_xcch_encode_batch(self.h, _ptr(frames), n_blocks, tsc, _ptr(bits)), "trxsig_fec_xcch_encode_batch")
 
     def fec_tch_decode(self, soft, n_bursts, tch, tch_good, stolen, facch=None, facch_ok=None, wire=True, soft_stride=None):
         self._chk(self.L.trxsig_fec_tch_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_bursts, int(wire),

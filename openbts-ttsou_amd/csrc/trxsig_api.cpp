@@ -72,6 +72,7 @@ struct trxsig_ctx {
   int spec_peak = 0;                 // 1: k_tsc_peak8 (8 lanes per burst, speculated bisection) instead of k_tsc_peak
   int generic_taps = 0;              // 1: correlators without the tap-class specialisation (TRXSIG_TUNE_GENERIC_TAPS)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint8_t *d_tsc = nullptr;          // 8 x 26 training-sequence bits (XCCH encoder), uploaded on first use
   std::string err;
 };
 
@@ -213,6 +214,7 @@ void trxsig_destroy(trxsig_ctx *c) {
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_eq) (void)hipFree(c->d_eq);
+    if (c->d_tsc) (void)hipFree(c->d_tsc);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c->prof;
@@ -681,6 +683,22 @@ int trxsig_fec_rach_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_st
     return fail(c, TRXSIG_EINVAL, "trxsig_fec_rach_decode_batch: bad argument");
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_fec(c->stream, 2, d_soft, soft_stride, 36, 18, n_bursts, wire, d_tail_ok, d_bsic, d_ra, 0, c->prof));
+  return TRXSIG_OK;
+}
+int trxsig_fec_xcch_encode_batch(trxsig_ctx *c, const uint8_t *d_frames, int n_blocks, int tsc, uint8_t *d_bits) {
+  if (!c) return TRXSIG_EINVAL;
+  if (n_blocks < 0 || tsc < 0 || tsc > 7 || (n_blocks > 0 && (!d_frames || !d_bits)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_fec_xcch_encode_batch: bad argument");
+  if (n_blocks == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  if (!c->d_tsc) {
+    uint8_t h[8 * 26];
+    for (int t = 0; t < 8; t++)
+      for (int k = 0; k < 26; k++) h[26 * t + k] = trx_training_sequence(t)[k] == '1';
+    HIPCHK(c, hipMalloc((void **)&c->d_tsc, sizeof h));
+    HIPCHK(c, hipMemcpy(c->d_tsc, h, sizeof h, hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, trx_launch_fec_xcch_encode(c->stream, d_frames, n_blocks, c->d_tsc + 26 * tsc, d_bits, c->prof));
   return TRXSIG_OK;
 }
 int trxsig_fec_tch_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_bursts, int wire,

@@ -282,7 +282,84 @@ __global__ __launch_bounds__(64) void k_fec_viterbi(const float *__restrict__ so
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_fec_xcch_encode: XCCHL1Encoder::sendFrame / encode / interleave / transmit (fec:772-845), one wave per L2
+// frame: d[] = the 23 octets LSB first (LSB8MSB, fec:789), 40 parity bits = ~(Fire-code remainder of d[])
+// (writeParityWord, bv:409-416), four zero tail bits, rate-1/2 coder (BitVector::encode, bv:217-239),
+// GSM 05.03 4.1.4 interleaver into the e-bits of four bursts, plus what the encoder's constructor puts in
+// every burst: zero tails, both stealing flags set (fec:713-717) and the training sequence at 61..86.
+// All integer work; the parity word uses the register's GF(2) linearity (XOR of unit responses).
+// ---------------------------------------------------------------------------------------------
+struct XcchPar {                                           // encoderShift response (bh:80-85) to a 1 at position i of 184
+  unsigned long long v[184];
+  constexpr XcchPar() : v() {
+    unsigned long long st = 0x10004820009ULL & ((1ULL << 40) - 1);   // the bit just went in: fb = 1, state = coeff
+    for (int i = 183; i >= 0; i--) {
+      v[i] = st & ((1ULL << 40) - 1);
+      const unsigned long long fb = (st >> 39) & 1ULL;     // one more zero behind it
+      st <<= 1;
+      if (fb) st ^= 0x10004820009ULL;
+    }
+  }
+};
+__device__ __constant__ const XcchPar kXcchPar;
+
+__global__ __launch_bounds__(64) void k_fec_xcch_encode(const uint8_t *__restrict__ frames, int nblk,
+                                                        const uint8_t *__restrict__ tsc_bits /* 26 */, uint8_t *__restrict__ bits) {
+  __shared__ unsigned uw[8];                                // u[228], bit k of word w = u[32w + k]
+  const int lane = threadIdx.x, blk = blockIdx.x;
+  if (blk >= nblk) return;
+  // d[]: octet o contributes u[8o + m] = bit m of the octet (LSB first)
+  unsigned w = 0;
+  if (lane < 6)
+    for (int q = 0; q < 4; q++)
+      if (4 * lane + q < 23) w |= (unsigned)frames[(size_t)blk * 23 + 4 * lane + q] << (8 * q);
+  // parity word of d[0..184): every lane XORs the unit responses of its word's set bits
+  unsigned long long par = 0;
+  if (lane < 6)
+    for (int k = 0; k < 32; k++)
+      if (32 * lane + k < 184 && ((w >> k) & 1u)) par ^= kXcchPar.v[32 * lane + k];
+  unsigned lo = (unsigned)par, hi = (unsigned)(par >> 32);
+  for (int m = 1; m < 8; m <<= 1) { lo ^= __shfl_xor(lo, m, 64); hi ^= __shfl_xor(hi, m, 64); }
+  const unsigned long long pw = ~(((unsigned long long)hi << 32) | lo) & ((1ULL << 40) - 1);   // inverted (bv:413)
+  // u[184 + k] = bit (39 - k) of the word (fillField, MSB first); u[224..227] = 0
+  if (lane == 5) for (int k = 0; k < 8; k++) w |= (unsigned)((pw >> (39 - k)) & 1ULL) << (24 + k);
+  if (lane == 6) { w = 0; for (int k = 0; k < 32; k++) w |= (unsigned)((pw >> (39 - 8 - k)) & 1ULL) << k; }
+  if (lane == 7) w = 0;
+  if (lane < 8) uw[lane] = w;
+  wave_fence();
+  auto ubit = [&](int i) { return i < 0 ? 0u : ((uw[i >> 5] >> (i & 31)) & 1u); };
+  uint8_t *out = bits + (size_t)blk * 4 * 148;
+  // burst skeleton: zeros, stealing flags, training sequence
+  for (int i = lane; i < 4 * 148; i += 64) {
+    const int p = i % 148;
+    uint8_t v = 0;
+    if (p == 60 || p == 87) v = 1;
+    else if (p >= 61 && p < 87) v = tsc_bits[p - 61] & 1u;
+    if (p < 3 || p >= 145 || (p >= 60 && p < 88)) out[i] = v;
+  }
+  // c[2k], c[2k+1] from the 5-bit history ending at u[k]; interleave and place (fec:812-817, 833-836)
+  for (int k = lane; k < 228; k += 64) {
+    const unsigned idx = ubit(k) | (ubit(k - 1) << 1) | (ubit(k - 2) << 2) | (ubit(k - 3) << 3) | (ubit(k - 4) << 4);
+    const unsigned g = (unsigned)(kGen >> (2 * idx)) & 3u;
+    for (int h = 0; h < 2; h++) {
+      const int c = 2 * k + h;
+      const int B = c & 3, j = 2 * ((49 * c) % 57) + ((c % 8) / 4);
+      out[B * 148 + (j < 57 ? 3 + j : 88 + (j - 57))] = (uint8_t)(h == 0 ? (g >> 1) : (g & 1u));
+    }
+  }
+}
+
 }  // namespace
+
+hipError_t trx_launch_fec_xcch_encode(hipStream_t st, const uint8_t *frames, int nblk, const uint8_t *tsc_bits, uint8_t *bits,
+                                      TrxProfiler *prof) {
+  if (nblk <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_FEC, st);
+  k_fec_xcch_encode<<<dim3(nblk), dim3(64), 0, st>>>(frames, nblk, tsc_bits, bits);
+  if (prof) prof->end(TRXSIG_K_FEC, st);
+  return hipGetLastError();
+}
 
 hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long in_stride, int n, int nout, int nblk,
                           int wire, uint8_t *out0, uint8_t *out1, uint8_t *out2, long long out_stride, TrxProfiler *prof,

@@ -90,3 +90,8 @@ hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const t
                                     const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
                                     float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
+
+// XCCH L1 encode: nblk L2 frames (23 octets each) -> 4*nblk bursts of 148 bits (one per byte); tsc_bits: the 26
+// training-sequence bits (device)
+hipError_t trx_launch_fec_xcch_encode(hipStream_t st, const uint8_t *frames, int nblk, const uint8_t *tsc_bits, uint8_t *bits,
+                                      TrxProfiler *prof);

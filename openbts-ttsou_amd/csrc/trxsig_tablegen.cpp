@@ -196,3 +196,6 @@ int trx_build_tables(TrxTables *T, int sps) {
   T->checksum = trx_tables_checksum(T);
   return 0;
 }
+
+// the 26 training-sequence bits of TSC 0..7 as '0'/'1' characters (GSM 05.02 5.2.3; GSM/GSMCommon.cpp:44-53)
+const char *trx_training_sequence(int tsc) { return (tsc >= 0 && tsc < 8) ? kTSC[tsc] : nullptr; }

@@ -176,6 +176,27 @@ int fo_xcch_decode(const float *i4x114, uint8_t *u228, uint8_t *d184, uint64_t *
   return s == 0;
 }
 
+/* XCCHL1Encoder::sendFrame/encode/interleave/transmit (fec:772-845): 23 octets -> four 148-bit bursts (zero tails,
+   stealing flags set fec:713-717, training sequence at 61, e-bits at 3..59 / 88..144) */
+void fo_xcch_encode(const uint8_t *frame23, const uint8_t *tsc26, uint8_t *bursts4x148) {
+  uint8_t u[228], c[456];
+  memset(u, 0, sizeof u);
+  for (int i = 0; i < 184; i++) u[i] = (frame23[i / 8] >> (7 - i % 8)) & 1u;   /* the L2 frame, MSB first */
+  fo_lsb8msb(u, 184);                                                           /* fec:789 */
+  const uint64_t pw = ~fo_parity(0x10004820009ULL, 40, u, 184);                 /* writeParityWord, inverted (bv:409-416) */
+  for (int k = 0; k < 40; k++) u[184 + k] = (uint8_t)((pw >> (39 - k)) & 1u);
+  fo_encode(u, 228, c);
+  memset(bursts4x148, 0, 4 * 148);
+  for (int B = 0; B < 4; B++) {
+    bursts4x148[B * 148 + 60] = 1; bursts4x148[B * 148 + 87] = 1;
+    for (int k = 0; k < 26; k++) bursts4x148[B * 148 + 61 + k] = tsc26[k] & 1u;
+  }
+  for (int k = 0; k < 456; k++) {
+    const int B = k % 4, j = 2 * ((49 * k) % 57) + ((k % 8) / 4);
+    bursts4x148[B * 148 + (j < 57 ? 3 + j : 88 + (j - 57))] = c[k];
+  }
+}
+
 /* RACHL1Decoder::writeLowSide (fec:475-514) */
 int fo_rach_decode(const float *e36, uint8_t *u18, unsigned *bsic, unsigned *ra) {
   uint8_t u[18], d[8];

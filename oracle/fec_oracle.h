@@ -19,6 +19,7 @@ uint64_t fo_syndrome(uint64_t coeff, unsigned psize, const uint8_t *bits, int n)
 void fo_lsb8msb(uint8_t *bits, int n);
 float fo_wire(float v);
 int fo_xcch_decode(const float *i4x114, uint8_t *u228, uint8_t *d184, uint64_t *syn);
+void fo_xcch_encode(const uint8_t *frame23, const uint8_t *tsc26, uint8_t *bursts4x148);
 int fo_rach_decode(const float *e36, uint8_t *u18, unsigned *bsic, unsigned *ra);
 int fo_tch_decode(const float *c456, uint8_t *u189, uint8_t *d260);
 void fo_tch_decode_batch(const float *soft, int stride, int nbursts, int wire, uint8_t *tch, uint8_t *tch_good,

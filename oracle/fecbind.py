@@ -23,6 +23,7 @@ class FecOracle:
         L.fo_wire.argtypes = [C.c_float]; L.fo_wire.restype = C.c_float
         L.fo_xcch_decode.argtypes = [f32p, u8p, u8p, C.POINTER(C.c_uint64)]
         L.fo_rach_decode.argtypes = [f32p, u8p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.fo_xcch_encode.argtypes = [u8p, u8p, u8p]
         L.fo_tch_decode.argtypes = [f32p, u8p, u8p]
         L.fo_tch_decode_batch.argtypes = [f32p, C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, C.c_int]
         L.fo_xcch_decode_batch.argtypes = [f32p, C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_int]
@@ -65,6 +66,11 @@ class FecOracle:
         u = np.zeros(18, np.uint8); bsic = C.c_uint(); ra = C.c_uint()
         t = self.lib.fo_rach_decode(np.ascontiguousarray(e36, np.float32), u, C.byref(bsic), C.byref(ra))
         return dict(tail_ok=bool(t), u=u, bsic=int(bsic.value), ra=int(ra.value))
+
+    def xcch_encode(self, frame23, tsc26):
+        out = np.zeros(4 * 148, np.uint8)
+        self.lib.fo_xcch_encode(np.ascontiguousarray(frame23, np.uint8), np.ascontiguousarray(tsc26, np.uint8), out)
+        return out.reshape(4, 148)
 
     def tch_decode(self, c456):
         u = np.zeros(189, np.uint8); d = np.zeros(260, np.uint8)

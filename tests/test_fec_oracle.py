@@ -144,3 +144,16 @@ def test_random_vs_reference(o):
         assert r.parity(fecbind.XCCH_POLY, 40, 224, bits) == o.parity(fecbind.XCCH_POLY, 40, bits)
         assert r.syndrome(fecbind.RACH_POLY, 6, 8, bits) == o.syndrome(fecbind.RACH_POLY, 6, bits)
         assert np.array_equal(r.lsb8msb(bits), o.lsb8msb(bits))
+
+
+def test_xcch_encode_golden(o, golden):
+    """fo_xcch_encode against the e-bits the reference's encoder steps produced (golden xcch_d -> xcch_hard)."""
+    g = golden("fec.npz")
+    tsc = np.array([int(c) for c in "01001110101100000100111010"], np.uint8)        # TSC 5
+    for i in range(0, len(g["xcch_d"]), 3):
+        frame = np.packbits(g["xcch_d"][i])
+        b = o.xcch_encode(frame, tsc)
+        e = np.concatenate([b[:, 3:60], b[:, 88:145]], axis=1)
+        assert np.array_equal(e, g["xcch_hard"][i]), i
+        assert not b[:, :3].any() and not b[:, 145:].any() and b[:, 60].all() and b[:, 87].all()
+        assert np.array_equal(b[:, 61:87], np.tile(tsc, (4, 1)))

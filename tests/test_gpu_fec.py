@@ -258,3 +258,68 @@ def test_end_to_end_access_burst_to_ra(pkg, t):
     det = (gb.flags.cpu().numpy() & pkg.F_DETECT) != 0
     good = det & (got[:, 0] == 1) & (got[:, 1] == bsic)
     assert good.sum() >= 0.85 * n and np.array_equal(got[good, 2], ra[good])
+
+
+TSCS = ["00100101110000100010010111", "00101101110111100010110111", "01000011101110100100001110", "01000111101101000100011110",
+        "00011010111001000001101011", "01001110101100000100111010", "10100111110110001010011111", "11101111000100101110111100"]
+
+
+def gpu_xcch_encode(t, frames, tsc):
+    import torch
+    nb = len(frames)
+    bits = torch.full((4 * nb, 148), 7, dtype=torch.uint8, device="cuda")
+    t.fec_xcch_encode(dev(frames), nb, tsc, bits)
+    torch.cuda.synchronize()
+    return bits.cpu().numpy()
+
+
+def test_xcch_encode(pkg, t, golden):
+    """XCCH L1 encode (k_fec_xcch_encode): the reference's own e-bits (golden), the oracle on random frames
+    for every TSC, ragged batch sizes, argument checks."""
+    g = golden("fec.npz")
+    frames = np.packbits(g["xcch_d"], axis=1)
+    b = gpu_xcch_encode(t, frames, 5).reshape(-1, 4, 148)
+    e = np.concatenate([b[:, :, 3:60], b[:, :, 88:145]], axis=2)
+    assert np.array_equal(e, g["xcch_hard"])
+    o = fecbind.FecOracle(); rng = np.random.default_rng(77)
+    for tsc, nb in enumerate([1, 2, 3, 63, 64, 65, 257, 1000]):
+        fr = rng.integers(0, 256, (nb, 23)).astype(np.uint8)
+        fr[0] = 0; fr[-1] = 255
+        tb = np.array([int(c) for c in TSCS[tsc]], np.uint8)
+        want = np.concatenate([o.xcch_encode(f, tb) for f in fr])
+        assert np.array_equal(gpu_xcch_encode(t, fr, tsc), want), (tsc, nb)
+    import torch
+    z = torch.zeros(4, 148, dtype=torch.uint8, device="cuda")
+    t.fec_xcch_encode(None, 0, 0, None)
+    for bad in (-1, 8):
+        with pytest.raises(pkg.TrxSigError):
+            t.fec_xcch_encode(z, 1, bad, z)
+    with pytest.raises(pkg.TrxSigError):
+        t.fec_xcch_encode(None, 1, 0, z)
+
+
+def test_closed_loop_l2_to_l2(pkg, t):
+    """L2 frames -> XCCH encode -> GMSK modulate -> noise -> TSC detect + demodulate -> XCCH decode, all on the
+    card through the C-ABI: every frame comes back and the parity check passes."""
+    import torch
+    sps, tsc, nblk = 4, 2, 512
+    B = 4 * nblk
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    frames = torch.randint(0, 256, (nblk, 23), dtype=torch.uint8, device="cuda", generator=g)
+    bits = torch.zeros(B, 148, dtype=torch.uint8, device="cuda")
+    t.fec_xcch_encode(frames, nblk, tsc, bits)
+    guard = torch.full((B,), 8, dtype=torch.int32, device="cuda")
+    n = sps * 156
+    off = (torch.arange(B, dtype=torch.int32, device="cuda") * n).contiguous()
+    length = torch.full((B,), n, dtype=torch.int32, device="cuda")
+    x = torch.zeros(B * n, 2, dtype=torch.float32, device="cuda")
+    t.modulate(bits, guard, x, off)
+    x += 0.15 * torch.randn(x.shape, device="cuda", generator=g)
+    flags = torch.zeros(B, dtype=torch.uint8, device="cuda"); amp = torch.zeros(B, 2, device="cuda"); toa = torch.zeros(B, device="cuda")
+    soft = torch.zeros(B, 148, device="cuda")
+    t.detect_demod_normal(x, off, length, tsc, flags, amp, toa, soft, nsoft=148, soft_stride=148)
+    out = torch.zeros_like(frames); ok = torch.zeros(nblk, dtype=torch.uint8, device="cuda")
+    t.fec_xcch_decode(soft, nblk, out, ok, wire=True)
+    torch.cuda.synchronize()
+    assert bool(((flags & pkg.F_DETECT) != 0).all()) and bool(ok.all())
+    assert torch.equal(out, frames)
