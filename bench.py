@@ -97,7 +97,8 @@ def main():
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3 (side measurement)")
     ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3, 4],
                     help="A/B: normal-burst implementation (trxsig_set_tuning); default = the library's")
-    ap.add_argument("--spec-peak", action="store_true", help="A/B: path 0 with the 8-lanes-per-burst speculative peak kernel")
+    ap.add_argument("--spec-peak", type=int, default=0, choices=[0, 1, 2],
+                    help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
     ap.add_argument("--generic-taps", action="store_true", help="A/B: correlators without the tap-class specialisation")
     args = ap.parse_args()
 
@@ -132,7 +133,7 @@ def main():
     if args.generic_taps:
         ctx.set_tuning(generic_taps=1)
     if args.spec_peak:
-        ctx.set_tuning(spec_peak=1)
+        ctx.set_tuning(spec_peak=args.spec_peak)
 
     B = args.bursts
     rach = args.workload == "rach"

@@ -312,9 +312,11 @@ int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int 
  *     lag, 1 = approximate-then-exact (k_rach_fast).
  *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component" form (which
  *     is only taken when the actual taps have that shape).  Default 0.
- *   TRXSIG_TUNE_SPECULATIVE_PEAK: 1 = path 0 runs peakDetect with eight lanes per burst and speculated
- *     bisection (k_tsc_peak8) instead of a lane per burst and the reference's serial loop.  Default 0
- *     (measured slower: 25 vs 18 us per 64 K bursts, LDS bandwidth). */
+ *   TRXSIG_TUNE_SPECULATIVE_PEAK: path 0's peakDetect kernel.  0 = two lanes per burst (early and late point of
+ *     each bisection step side by side, sinc table in LDS, window in registers; k_tsc_peak2, the default),
+ *     1 = eight lanes per burst with the bisection speculated two levels at a time (k_tsc_peak8; 25 us per
+ *     64 K bursts, LDS bandwidth), 2 = a lane per burst, the reference's serial loop (k_tsc_peak; 18 us,
+ *     k_tsc_peak2 15 us).  All three are bit-identical. */
 enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */

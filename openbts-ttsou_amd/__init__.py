@@ -94,7 +94,8 @@ def tables_dtype():
                      ("pad0", "<u4", 3), ("cosT", "<f4", 1028), ("sinT", "<f4", 1028), ("rot", "<c8", 628),
                      ("rev", "<c8", 628), ("pulse", "<f4", 12), ("mid", "<c8", (8, 64)), ("mid_toa", "<f4", 8),
                      ("mid_gain", "<c8", 8), ("rach", "<c8", 164), ("rach_toa", "<f4"), ("pad1", "<f4"),
-                     ("rach_gain", "<c8"), ("mid_ctap", "<c8", (8, 16)), ("sinc_grid", "<f4", (512, 24))])
+                     ("rach_gain", "<c8"), ("mid_ctap", "<c8", (8, 16)), ("pad2", "<f4", 16),
+                     ("sinc_grid", "<f4", (512, 32))])
 
 
 def build_tables_host(sps):

@@ -69,7 +69,7 @@ struct trxsig_ctx {
   void *d_stage = nullptr;
   int rach_variant = 1;              // 1 = k_rach_fast (approximate-then-exact), 0 = exact at every lag
   int variant = 0;                   // normal-burst path (TRXSIG_TUNE_NORMAL_PATH / env TRXSIG_TSC_VARIANT)
-  int spec_peak = 0;                 // 1: k_tsc_peak8 (8 lanes per burst, speculated bisection) instead of k_tsc_peak
+  int spec_peak = 0;                 // peak kernel of path 0: 0 = k_tsc_peak2 (2 lanes per burst), 1 = k_tsc_peak8 (8, speculated), 2 = k_tsc_peak (1)
   int generic_taps = 0;              // 1: correlators without the tap-class specialisation (TRXSIG_TUNE_GENERIC_TAPS)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint8_t *d_tsc = nullptr;          // 8 x 26 training-sequence bits (XCCH encoder), uploaded on first use
@@ -307,7 +307,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   }
   HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
-                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->generic_taps | (c->spec_peak << 1), c->prof));
+                                  (trx_c32 *)d_amp, d_toa, d_avgpwr, c->generic_taps | (c->spec_peak == 1 ? 2 : 0) | (c->spec_peak == 2 ? 4 : 0), c->prof));
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
@@ -734,7 +734,7 @@ int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 4) { c->variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 1) { c->rach_variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_GENERIC_TAPS && value >= 0 && value <= 1) { c->generic_taps = value; return TRXSIG_OK; }
-  if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 1) { c->spec_peak = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 2) { c->spec_peak = value; return TRXSIG_OK; }
   return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: unknown key or value");
 }
 int trxsig_profile_enable(trxsig_ctx *c, int on) {

@@ -23,7 +23,7 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,
                                  uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                                 int variant /* bit 0: generic taps (no tap-class specialisation); bit 1: 8-lanes-per-burst speculative peak kernel */,
+                                 int variant /* bit 0: generic taps (no tap-class specialisation); bit 1: 8-lanes-per-burst speculative peak kernel; bit 2: lane-per-burst peak kernel (default: 2 lanes per burst) */,
                                  TrxProfiler *prof);
 
 // the whole normal-burst leg in one kernel (k_normal_fused); lanes_per_burst = 64 or 32, nsoft <= 148

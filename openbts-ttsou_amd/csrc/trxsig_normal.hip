@@ -2,10 +2,10 @@
 //   k_tsc_corr   : 16 lanes (one DPP row) per burst, 4 bursts per wave.  Midamble correlation over the
 //                  36-symbol window with the 16 non-zero taps, energy detect, argmax, and a small
 //                  per-burst record of the lags around the peak.
-//   k_tsc_peak   : one LANE per burst.  The serial part of the reference (early-late bisection of
-//                  peakDetect, valley RMS, threshold) has no parallelism inside a burst, so it is run
-//                  for 64 bursts at once from the transposed records.  (k_tsc_peak8: the speculative
-//                  8-lanes-per-burst alternative.)
+//   k_tsc_peak2  : TWO lanes per burst.  The serial part of the reference (early-late bisection of
+//                  peakDetect, valley RMS, threshold): the early and the late point of a step are the
+//                  only work that can run side by side.  (k_tsc_peak: a lane per burst, the reference's
+//                  loop as written; k_tsc_peak8: eight lanes, speculative.  A/B alternatives.)
 //   k_demod      : one wave per burst (trxsig_demod.h).
 // Numerical contract: see trxsig_dev.h / DESIGN.md (every float32 operation is the reference's, in the
 // reference's order; built with -ffp-contract=off).
@@ -254,6 +254,199 @@ __global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restric
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// k_tsc_peak2: k_tsc_peak's job with TWO lanes per burst -- the even lane evaluates the early point of
+//   every bisection step, the odd lane the late one (the two 21-tap sums are the only parallelism the
+//   reference's loop has: each sum must run j = 0..20 in order) -- and two waves per SIMD instead of one.
+//   * the sinc table sits in LDS (48 KB per workgroup): the row of the NEXT step is fetched after the
+//     decision (6 ds_read_b128, ~150 cycles) instead of gathering both candidates from L2 a step ahead
+//     (k_tsc_peak: 12 divergent 16-byte gathers per lane and step, which the CU's vector cache serves one
+//     lane at a time: 1.4 k cycles per step with few distinct rows, 3 k with 256);
+//   * the correlation window lives in REGISTERS: floor(early) is fixed after step 0 (early stays inside
+//     (M-2, M-1) or (M-1, M)), so one select after step 0 makes every later tap index static;
+//   * the valley powers come from registers too (three candidate alignments, selected by rint(toa) - M).
+//   State: early = M-1 + e/512 (all of the reference's +-2^-k steps are exact in float).
+// ---------------------------------------------------------------------------------------------
+template <int SPS>
+__global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec, int Bpad,
+                                                   int B, cx gain_inv, float mid_toa, float detect_thresh,
+                                                   float energy_thresh, uint8_t *__restrict__ flags,
+                                                   cx *__restrict__ amp_out, float *__restrict__ toa_out,
+                                                   float *__restrict__ avgpwr_out) {
+  typedef CorrGeom<SPS> G;
+  constexpr int NL = G::NL, NE = G::NE, NP = 3 * SPS + 3;  // NP: valley powers kept per side
+  __shared__ __attribute__((aligned(16))) float stab[512][24];
+  const int tid = threadIdx.x;
+  const int h = tid & 1;                                   // 0: early point (and the final one), 1: late point
+  const int b = blockIdx.x * 128 + (tid >> 1);
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+#ifdef TRX_PEAK_PROBE                                      // tools/peak_probe.py: clock64() stamps come back through avgpwr
+  long long pt_[16] = {0};
+  int pk_ = 0;
+#define TRX_STAMP() pt_[pk_++] = clock64()
+#else
+#define TRX_STAMP()
+#endif
+  TRX_STAMP();
+
+  // ---- loads first: this thread's 12 float4 of the table, then its part of the detect->peak record ----
+  float4 tv[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const int ix = tid + 256 * k;                          // 3072 float4 = 512 rows x 6
+    tv[k] = *reinterpret_cast<const float4 *>(&T->sinc_grid[ix / 6][4 * (ix % 6)]);
+  }
+  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const bool good = M != -2;
+  // q[k] = corr[M - 12 + k + 2h] with the zeros interpolatePoint implies (it never uses the last sample, :646):
+  // tap j of the early point is q[base + j] on the even lane, of the late point q[base + j] on the odd lane
+  // (base = floor(early) - (M - 2) = 0 or 1), of the final point q[base + 1 + j] on the even lane.
+  cx q[23];
+#pragma unroll
+  for (int k = 0; k < 23; k++) {
+    const int ix = k + 2 * h;
+    const cx v = rec[(size_t)(G::H - 12 + ix) * Bpad + bb];
+    q[k] = (M - 12 + ix > NL - 2) ? mk(0, 0) : v;
+  }
+  // corr at M - (5sps+1) + k and M + (2sps-1) + k, k < NP: every lag the valley can touch (|rint(toa) - M| <= 1);
+  // in flight with the rest, first needed in the tail
+  cx vlo_[NP], vhi_[NP];
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    vlo_[k] = rec[(size_t)(G::H - (5 * SPS + 1) + k) * Bpad + bb];
+    vhi_[k] = rec[(size_t)(G::H + (2 * SPS - 1) + k) * Bpad + bb];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const int ix = tid + 256 * k;
+    *reinterpret_cast<float4 *>(&stab[ix / 6][4 * (ix % 6)]) = tv[k];
+  }
+  TRX_STAMP();
+  __syncthreads();                                         // the only barrier
+  TRX_STAMP();
+
+  auto load_row = [&](int f, float (&s)[24]) {
+    const float4 *rw = reinterpret_cast<const float4 *>(stab[f]);
+#pragma unroll
+    for (int g = 0; g < 6; g++) {
+      const float4 t4 = rw[g];
+      s[4 * g] = t4.x; s[4 * g + 1] = t4.y; s[4 * g + 2] = t4.z; s[4 * g + 3] = t4.w;
+    }
+  };
+  int e = 0;
+  bool active = true;
+  // one early/late decision (:690-697) from this lane's point and its neighbour's
+  auto decide = [&](cx pt, int inc) {
+    const float mine = norm2(pt);
+    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+    const float ne = h ? other : mine, nl = h ? mine : other;
+    if (active) {
+      if (ne < nl) e += inc;
+      else if (ne > nl) e -= inc;
+      else active = false;                                 // "else break" (:695)
+    }
+  };
+  float srow[24];
+  // step 0: early = M-1 is an integer (row 0, base 1)
+  load_row(0, srow);
+  {
+    cx pt = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(q[1 + j], srow[j]));
+    decide(pt, 256);
+  }
+  TRX_STAMP();
+  // floor(early) = M-2 if the first step went down, M-1 otherwise, and stays there
+  cx w[22];
+#pragma unroll
+  for (int k = 0; k < 22; k++) w[k] = (e < 0) ? q[k] : q[k + 1];
+#pragma unroll 1
+  for (int inc = 128; inc >= 1; inc >>= 1) {               // increments 2^-2 .. 2^-9
+    load_row(e & 511, srow);
+    cx pt = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(w[j], srow[j]));
+    decide(pt, inc);
+#ifdef TRX_PEAK_PROBE
+    if (inc == 32 || inc == 4) TRX_STAMP();
+#endif
+  }
+  TRX_STAMP();
+  // the peak itself: interpolatePoint(early + 1), same fractional part (:699-700); the even lane's value counts
+  load_row(e & 511, srow);
+  cx peak = mk(0, 0);
+#pragma unroll
+  for (int j = 0; j < 21; j++) peak = cadd(peak, cmulr(w[j + 1], srow[j]));
+
+  TRX_STAMP();
+  // ---- analyzeTrafficBurst's tail (k_tsc_peak's arithmetic) ----
+  const float early = (float)(M - 1) + (float)e * 0.001953125f;
+  float toa = early + 1.0f;
+  cx amp = peak;
+  bool detected = false;
+  const bool energy_ok = good && (energy_thresh < 0.0f || energy / (float)(unsigned)NE > energy_thresh * energy_thresh);
+  const bool sane = !(toa < 0.0f) && !(toa > (float)NL) && good;
+  if (sane) {
+    const int pk = (int)rintf(toa);
+    const int a = pk - M + 1;                              // 0, 1 or 2
+    // valley in the reference's order (:971-980): i = 2sps..5sps, (peak - i) then (peak + i); the terms the
+    // reference skips (index < 0 or >= n) are +0 in the record, and adding +0 to a sum of non-negative terms
+    // changes nothing; numRms is counted arithmetically.
+    float plo[NP], phi[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) { plo[k] = norm2(vlo_[k]); phi[k] = norm2(vhi_[k]); }
+    float valley = 0.0f;
+#pragma unroll
+    for (int i = 2 * SPS; i <= 5 * SPS; i++) {
+      const int t = 5 * SPS - i, u = i - 2 * SPS;
+      const float vlo = a == 0 ? plo[t] : (a == 1 ? plo[t + 1] : plo[t + 2]);
+      const float vhi = a == 0 ? phi[u] : (a == 1 ? phi[u + 1] : phi[u + 2]);
+      valley = valley + vlo;
+      valley = valley + vhi;
+    }
+    int nlo = (pk < 5 * SPS ? pk : 5 * SPS) - 2 * SPS + 1;           // i <= pk
+    int nhi = (NL - 1 - pk < 5 * SPS ? NL - 1 - pk : 5 * SPS) - 2 * SPS + 1;   // pk + i <= NL-1
+    nlo = nlo < 0 ? 0 : nlo; nhi = nhi < 0 ? 0 : nhi;
+    const int numRms = nlo + nhi;
+    if (numRms < 2) {
+      amp = mk(0, 0);
+    } else {
+      const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);   // :989
+      const float peakToMean = sqrtf(norm2(amp)) / RMS;
+      amp = cmul(amp, gain_inv);                           // amp / gain = amp * gain.inv() (Complex.h:85), :997
+      toa = toa - mid_toa;                                 // :998
+      toa = toa - (float)((66 - 56) * SPS);                // :1000
+      detected = peakToMean > detect_thresh;
+    }
+  } else {
+    amp = mk(0, 0);                                        // "bogus result" (:964-968); TOA left as is
+  }
+  if (!energy_ok) { amp = mk(0, 0); toa = 0.0f; detected = false; }   // Transceiver.cpp:298-306
+
+  if (live && h == 0) {
+    uint8_t fl = 0;
+    if (!good) fl = TRXSIG_F_BADLEN;
+    else fl = (energy_ok ? TRXSIG_F_ENERGY : 0) | (detected ? TRXSIG_F_DETECT : 0);
+    flags[b] = fl;
+    amp_out[b] = amp;
+    toa_out[b] = toa;
+    if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
+  }
+#ifdef TRX_PEAK_PROBE
+  TRX_STAMP();
+  if (live && avgpwr_out) {
+    long long v = 0;
+    for (int k = 1; k < 16; k++) if ((b & 15) == k) v = pt_[k] - pt_[0];
+    if (h == 0) avgpwr_out[b] = (float)v;
+  }
+#endif
+#undef TRX_STAMP
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -282,14 +475,17 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   else
     k_tsc_corr<S, TRX_TAPS_GENERIC><<<cgrid, dim3(256), 0, st>>>(dT, samples, off, len, B, ta, rec, Bpad);
   if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
-  if (!(variant & 2)) {
+  // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
+  const trx_c32 g = hT->mid_gain[tsc];
+  const float n = g.i * g.i + g.r * g.r;
+  trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
+  if (variant & 4) {
     k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
                                                             flags, amp, toa, avgpwr);
+  } else if (!(variant & 2)) {
+    k_tsc_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
+                                                                energy_thresh, flags, amp, toa, avgpwr);
   } else {
-    // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
-    const trx_c32 g = hT->mid_gain[tsc];
-    const float n = g.i * g.i + g.r * g.r;
-    trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
     k_tsc_peak8<S><<<dim3((B + 31) / 32), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
                                                               energy_thresh, flags, amp, toa, avgpwr);
   }

@@ -14,8 +14,8 @@
 #define TRX_MAXSPS 4
 #define TRX_TABLESIZE 1024
 #define TRX_MAGIC 0x54525853u /* "TRXS" */
-#define TRX_BLOB_VERSION 1u
-#define TRX_SINC_ROW 24
+#define TRX_BLOB_VERSION 2u
+#define TRX_SINC_ROW 32   /* one 128-byte line per row */
 
 struct trx_c32 { float r, i; };
 
@@ -34,5 +34,7 @@ struct TrxTables {
   float rach_toa, pad1;
   trx_c32 rach_gain;
   trx_c32 mid_ctap[8][16];                  // conj(mid[t][sps*k]), k = 0..15
-  float sinc_grid[512][TRX_SINC_ROW];       // [f][j], j < 21, rest 0
+  float pad2[16];                           // puts sinc_grid on a 128-byte boundary of the (256-byte aligned) blob
+  float sinc_grid[512][TRX_SINC_ROW];       // [f][j], j < 21, rest 0; a row is exactly one cache line
 };
+static_assert(__builtin_offsetof(TrxTables, sinc_grid) % 128 == 0, "sinc_grid rows are cache lines");

@@ -179,14 +179,20 @@ def test_tap_class_specialisation_is_invisible(pkg, sps, path):
 
 
 @pytest.mark.parametrize("sps", [1, 2, 4])
-def test_speculative_peak_kernel_is_invisible(pkg, sps):
-    """Path 0's k_tsc_peak8 (eight lanes per burst, speculated bisection) against k_tsc_peak (a lane per
-    burst, the reference's serial loop): identical outputs on random, ragged and hostile batches."""
-    a = pkg.TrxSig(sps, 0); a.use_torch_stream(); a.set_tuning(normal_path=0, spec_peak=1)
-    g = pkg.TrxSig(sps, 0); g.use_torch_stream(); g.set_tuning(normal_path=0, spec_peak=0)
+def test_peak_kernels_are_interchangeable(pkg, sps):
+    """Path 0's three peak kernels -- k_tsc_peak2 (two lanes per burst, the default), k_tsc_peak8 (eight lanes,
+    speculated bisection) and k_tsc_peak (a lane per burst, the reference's serial loop as written) --
+    give identical outputs on random, ragged and hostile batches, tie-breaking bisections included."""
+    ctx = []
+    for sp in (2, 0, 1):
+        c = pkg.TrxSig(sps, 0); c.use_torch_stream(); c.set_tuning(normal_path=0, spec_peak=sp); ctx.append(c)
     for tsc in range(8):
         x, off, length, meta = synth.normal_batch(sps, 1031, tsc, seed=900 + tsc)
-        same(run(a, x, off, length, tsc), run(g, x, off, length, tsc), "tsc %d" % tsc)
+        want = run(ctx[0], x, off, length, tsc)
+        for c in ctx[1:]:
+            same(run(c, x, off, length, tsc), want, "tsc %d" % tsc)
         x, off, length = hostile_batch(sps, tsc, seed=950 + tsc)
         for ethr in (-1.0, 5.0):
-            same(run(a, x, off, length, tsc, energy_thresh=ethr), run(g, x, off, length, tsc, energy_thresh=ethr), "hostile")
+            want = run(ctx[0], x, off, length, tsc, energy_thresh=ethr)
+            for c in ctx[1:]:
+                same(run(c, x, off, length, tsc, energy_thresh=ethr), want, "hostile")
