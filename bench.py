@@ -99,6 +99,7 @@ def main():
                     help="A/B: normal-burst implementation (trxsig_set_tuning); default = the library's")
     ap.add_argument("--spec-peak", type=int, default=0, choices=[0, 1, 2],
                     help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
+    ap.add_argument("--no-fresh", action="store_true", help="skip the rotating-inputs side measurement")
     ap.add_argument("--generic-taps", action="store_true", help="A/B: correlators without the tap-class specialisation")
     args = ap.parse_args()
 
@@ -189,6 +190,32 @@ def main():
     prof = ctx.profile_collect()
     ctx.profile_enable(False)
 
+    # ---- side measurement (outside the timed region): the same steps over THREE different input batches in
+    #      rotation (1 GB > the 256 MB memory-side cache), i.e. without the part of the input that a repeated
+    #      batch still finds in that cache from the step before
+    fresh = None
+    if world == 1 and not rach and not args.no_fresh:
+        xs = [xf]
+        for k in (1, 2):
+            xk, offk, lenk, _ = synth.normal_batch_torch(SPS, B, TSC, seed=0xB5E55ED0 + 1000 * k, device=dev)
+            assert torch.equal(offk, off) and torch.equal(lenk, length)
+            xs.append(torch.view_as_real(xk).contiguous())
+        so2 = torch.zeros_like(soft); fl2 = torch.zeros_like(flags); am2 = torch.zeros_like(amp); to2 = torch.zeros_like(toa)
+        def step_k(i):
+            ctx.detect_demod_normal(xs[i % 3], off, length, TSC, fl2, am2, to2, so2, detect_thresh=3.0,
+                                    energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+        kf = min(args.steps, 600)
+        for i in range(60):
+            step_k(i)
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for i in range(kf):
+            step_k(i)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf
+        fresh = {"value": round(B * kf / tf / 1e6, 3), "unit": "Mbursts/s", "inputs_in_rotation": 3, "steps": kf}
+        del xs, so2
+
     # results sanity (outside the timed region): detections and hard bits of the clean bursts
     det = (flags & pkg.F_DETECT) != 0
     clean = det & (meta["sigma"] <= 0.1)
@@ -224,7 +251,7 @@ def main():
                    "bursts_per_gpu": B, "sps": SPS, "parallelism": "burst-sharded x%d (no data-path collective)" % world},
         "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "preheat_steps": n_pre,
         "detected_frac": round(det_frac, 4), "clean_hard_bits_ok": hard_ok,
-        "roofline": roof,
+        "roofline": roof, "fresh_inputs": fresh,
     }
     if not args.no_cpu_baseline and world == 1 and not rach:
         n = min(B, 16384)

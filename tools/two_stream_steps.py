@@ -40,6 +40,7 @@ def run(S, K=1000, W=200, distinct_inputs=False):
         assert torch.equal(o[3], ref)
 
 
-for S in (1, 2, 3, 4):
+for S in (1, 2):
     run(S)
-run(2, distinct_inputs=True)
+for S in (2, 3, 4):
+    run(S, distinct_inputs=True)
