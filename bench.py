@@ -75,10 +75,30 @@ def cpu_baseline(x_host, off, length, sps, tsc, target_seconds=8.0):
     for _ in range(reps):
         o.normal_batch(x_host, off, length, tsc, nthreads=cores)
     tt = time.perf_counter() - t0
-    return {"value": round(B * reps / tt / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
+    port = {"value": round(B * reps / tt / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
             "single_thread_Mbursts_per_s": round(1024 / t1 / 1e6, 6),
             "sample": "%d passes over the first %d bursts of the GPU batch (analyzeTrafficBurst + "
                       "demodulateBurst, oracle/sigproc_oracle.c, %d OpenMP threads, %.1f s)" % (reps, B, cores, tt)}
+    # the real reference, when its in-place build travelled with the snapshot (oracle/_ref/, built by
+    # __graft_entry__.build() where /root/reference exists): timed in a child process that never touches the GPU
+    import refbind
+    if not refbind.available():
+        return port, None
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sample.npz")
+        end = int(off[-1] + length[-1])
+        np_ = __import__("numpy")
+        np_.savez(path, x=x_host[:end], off=off, length=length, sps=sps, tsc=tsc)
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
+                               capture_output=True, text=True, timeout=300)
+            ref = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:                               # the reference leg is optional; the port leg stands
+            sys.stderr.write("reference cpu baseline unavailable: %r\n" % (e,))
+            return port, None
+    return ref, port
 
 
 def main():
@@ -257,7 +277,10 @@ def main():
         n = min(B, 16384)
         end = int(off[n - 1].item() + length[n - 1].item())
         xh = x[:end].cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(xh, off[:n].cpu().numpy(), length[:n].cpu().numpy(), SPS, TSC)
+        main_leg, port_leg = cpu_baseline(xh, off[:n].cpu().numpy(), length[:n].cpu().numpy(), SPS, TSC)
+        out["cpu_baseline"] = main_leg
+        if port_leg is not None:
+            out["cpu_port"] = port_leg                   # the oracle port beside the real reference
         if args.check:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oraclebind
