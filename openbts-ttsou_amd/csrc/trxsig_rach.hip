@@ -304,18 +304,23 @@ __global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ 
 // If more far-away candidates turn up than fit in one pass (flat noise, silence) the burst takes
 // the exact route for all lags.
 // ---------------------------------------------------------------------------------------------
+#ifndef TRX_RACH_EXACT_UNROLL
+#define TRX_RACH_EXACT_UNROLL 4
+#endif
 #define RACH_DELTA 4e-3f
 #define RACH_GUARD 1e-3f
-__device__ __constant__ const signed char kRachSym[41] = {           // 2*bit-1 of gRACHSynchSequence (GSM/GSMCommon.cpp:57)
-  -1, 1, -1, -1, 1, -1, 1, 1, -1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, 1, -1, -1, -1, 1, 1, 1, 1, -1,
-  -1, -1 };
+struct RachSym {                                           // 2*bit-1 of gRACHSynchSequence (GSM/GSMCommon.cpp:57)
+  static constexpr signed char v[41] = {
+    -1, 1, -1, -1, 1, -1, 1, 1, -1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, 1, -1, -1, -1, 1, 1, 1, 1, -1,
+    -1, -1 };
+};
 
 template <int SPS>
 struct RachFast {
   typedef RachGeom<SPS> R;
   static constexpr int XF = R::F + SPS;                     // X[i] = x[i - XF]
   static constexpr int XPAD = 64 * R::NCL + R::LB + 4 * SPS + 8;
-  static constexpr int ZPAD = 64 * R::NCL + 40 * SPS + 1;   // Zs[i] = sum_j p[j] X[i+j]
+  static constexpr int ZPAD = 64 * R::NCL + 40 * SPS + 2;   // Zs[i] = sum_j p[j] X[i+j]; even: written in pairs
   static constexpr int NB = 26;                             // lags M~-13 .. M~+12 always recomputed
 };
 
@@ -325,12 +330,98 @@ __device__ __forceinline__ cx rach_exact_lag(const cx *X, const cx *__restrict__
   typedef RachGeom<SPS> R;
   cx acc = mk(0, 0);
   const cx *xp = X + t + SPS;                              // X index of x[t-F+m] is t + m + SPS
-#pragma unroll 4
-  for (int m = R::LB - 1; m >= 0; m--) {
+  // Software pipelined in groups of four taps: the next group's samples (LDS) and taps (scalar loads) are in flight
+  // while this group's 32 VALU run -- the wave shares its SIMD with only one or two others, so an exposed LDS/scalar
+  // latency per group (the plain loop: 41 x ~250 cycles) is not hidden by anybody else.  Order of the sum unchanged.
+  constexpr int REM = R::LB % 4, NG = R::LB / 4;
+  int m = R::LB - 1;
+#pragma unroll
+  for (int q = 0; q < REM; q++, m--) {
     const cx rm = rseq[m];
     acc = cadd(acc, cmul(xp[m], mk(rm.r, -rm.i)));
   }
+  cx xa[4], ta[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { xa[q] = xp[m - q]; ta[q] = rseq[m - q]; }
+#pragma unroll 2
+  for (int g = 0; g < NG; g++) {
+    cx xb[4], tb[4];
+    const int mn = (g + 1 < NG) ? m - 4 : m;               // (the last iteration re-reads its own group: in range, unused)
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xb[q] = xp[mn - q]; tb[q] = rseq[mn - q]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc = cadd(acc, cmul(xa[q], mk(ta[q].r, -ta[q].i)));
+    asm volatile("" : "+v"(acc.r), "+v"(acc.i));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xa[q] = xb[q]; ta[q] = tb[q]; }
+    m = mn;
+  }
   return acc;
+}
+
+// Approximate correlation, additions only: conj(c_k) z with c_k = sym_k i^k.  Lag t = lane + 64c needs
+// Z[t + sps k] = Z[lane + sps (CJ c + k)], CJ = 64/sps: one read of Z[lane + sps j] serves every (c, k) with CJ c + k = j,
+// and every accumulator still receives its terms k ascending.  (Template recursion: the (j, c) -> k map is resolved at
+// compile time; a 185 x 10 loop nest is beyond what "#pragma unroll" unrolls.)
+template <int SPS, int NCL, int J, int C>
+__device__ __forceinline__ void rach_steer_acc(const cx z, float (&ar)[NCL], float (&ai)[NCL]) {
+  if constexpr (C < NCL) {
+    constexpr int k = J - (64 / SPS) * C;
+    if constexpr (k >= 0 && k <= 40) {
+      constexpr float sg = (float)RachSym::v[k];
+      if constexpr ((k & 3) == 0) { ar[C] += sg * z.r; ai[C] += sg * z.i; }
+      else if constexpr ((k & 3) == 1) { ar[C] += sg * z.i; ai[C] -= sg * z.r; }
+      else if constexpr ((k & 3) == 2) { ar[C] -= sg * z.r; ai[C] -= sg * z.i; }
+      else { ar[C] -= sg * z.i; ai[C] += sg * z.r; }
+    }
+    rach_steer_acc<SPS, NCL, J, C + 1>(z, ar, ai);
+  }
+}
+template <int SPS, int NCL, int J>
+constexpr bool rach_steer_used() {
+  constexpr int CJ = 64 / SPS;
+  for (int c = 0; c < NCL; c++)
+    if (J - CJ * c >= 0 && J - CJ * c <= 40) return true;
+  return false;
+}
+// groups of eight j: the next group's reads are issued before this group's additions (double buffer), the
+// accumulators are pinned after each group (hipcc otherwise sinks the accumulation chains below all 185 reads: 256 VGPRs)
+template <int SPS, int NCL, int J0>
+__device__ __forceinline__ void rach_steer_load(const cx *Zl, cx (&z)[8]) {
+  constexpr int JMAX = (64 / SPS) * (NCL - 1) + 40;
+#pragma unroll
+  for (int q = 0; q < 8; q++) z[q] = mk(0, 0);
+  if constexpr (J0 + 0 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 0>()) z[0] = Zl[SPS * (J0 + 0)]; }
+  if constexpr (J0 + 1 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 1>()) z[1] = Zl[SPS * (J0 + 1)]; }
+  if constexpr (J0 + 2 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 2>()) z[2] = Zl[SPS * (J0 + 2)]; }
+  if constexpr (J0 + 3 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 3>()) z[3] = Zl[SPS * (J0 + 3)]; }
+  if constexpr (J0 + 4 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 4>()) z[4] = Zl[SPS * (J0 + 4)]; }
+  if constexpr (J0 + 5 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 5>()) z[5] = Zl[SPS * (J0 + 5)]; }
+  if constexpr (J0 + 6 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 6>()) z[6] = Zl[SPS * (J0 + 6)]; }
+  if constexpr (J0 + 7 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 7>()) z[7] = Zl[SPS * (J0 + 7)]; }
+}
+template <int SPS, int NCL, int J0, int Q>
+__device__ __forceinline__ void rach_steer_group(const cx (&z)[8], float (&ar)[NCL], float (&ai)[NCL]) {
+  if constexpr (Q < 8) {
+    rach_steer_acc<SPS, NCL, J0 + Q, 0>(z[Q], ar, ai);     // (k outside 0..40 for every c: nothing happens)
+    rach_steer_group<SPS, NCL, J0, Q + 1>(z, ar, ai);
+  }
+}
+template <int SPS, int NCL, int J0>
+__device__ __forceinline__ void rach_steer(const cx *Zl, const cx (&zc)[8], float (&ar)[NCL], float (&ai)[NCL]) {
+  constexpr int JMAX = (64 / SPS) * (NCL - 1) + 40;
+  if constexpr (J0 <= JMAX) {
+    cx zn[8];
+    rach_steer_load<SPS, NCL, J0 + 8>(Zl, zn);
+    __builtin_amdgcn_sched_barrier(0);
+    rach_steer_group<SPS, NCL, J0, 0>(zc, ar, ai);
+#pragma unroll
+    for (int c = 0; c < NCL; c++) { asm volatile("" : "+v"(ar[c])); asm volatile("" : "+v"(ai[c])); }
+    __builtin_amdgcn_sched_barrier(0);
+    rach_steer<SPS, NCL, J0 + 8>(Zl, zn, ar, ai);
+  }
 }
 
 template <int SPS>
@@ -342,8 +433,8 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
                                                    float *__restrict__ toa_out, float *__restrict__ avgpwr_out) {
   typedef RachGeom<SPS> R;
   typedef RachFast<SPS> Q;
-  __shared__ cx xs[1][Q::XPAD];
-  __shared__ cx zs[1][Q::ZPAD];                             // pulse-filtered burst; later approx powers (float view)
+  __shared__ __attribute__((aligned(16))) cx xs[1][Q::XPAD];
+  __shared__ __attribute__((aligned(16))) cx zs[1][Q::ZPAD];                             // pulse-filtered burst; later approx powers (float view)
   __shared__ cx exv[1][64];                                 // exact correlation of the selected lags
   __shared__ int exl[1][64];                                // ... and which lags they are
   __shared__ cx nb[1][26];                                  // exact neighbourhood corr[M-12..M+11] (+2 zero slots)
@@ -352,6 +443,14 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
   const int b = blockIdx.x;
   if (b >= B) return;
+#ifdef TRX_RACH_PROBE                                      // tools/rach_probe.py: clock64() stamps come back through avgpwr
+  long long pt_[16] = {0};
+  int pk_ = 0;
+#define TRX_STAMP() pt_[pk_++] = clock64()
+#else
+#define TRX_STAMP()
+#endif
+  TRX_STAMP();
   const int off = offset[b], N = length[b];
   const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
   if (!good) {
@@ -364,9 +463,19 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   float *PW = reinterpret_cast<float *>(Z);
   const cx *rseq = T->rach;
 
-  for (int i = lane; i < Q::XPAD; i += 64) {
-    const int n = i - Q::XF;
-    X[i] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
+  {                                                        // every load in flight before the first LDS store
+    constexpr int NIT = (Q::XPAD + 63) / 64;
+    cx xv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int n = lane + 64 * it - Q::XF;
+      xv[it] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = lane + 64 * it;
+      if (i < Q::XPAD) X[i] = xv[it];
+    }
   }
   float nrm[R::NEQ];
 #pragma unroll
@@ -384,48 +493,58 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
     return;
   }
   wave_lds_fence();
+  TRX_STAMP();                                             // 1: burst staged, energy done
 
   // ---- 1. approximate correlation at all lags (FMA allowed: this pass only steers) ----
   float pul[2 * SPS + 1];
 #pragma unroll
   for (int j = 0; j < 2 * SPS + 1; j++) pul[j] = T->pulse[j];
-  for (int i = lane; i < Q::ZPAD; i += 64) {
-    float zr = 0.0f, zi = 0.0f;
+  // two consecutive outputs per lane: Z[2g], Z[2g+1] from X[2g .. 2g+2sps+1] (16-byte LDS reads, each sample read once
+  // per pair instead of once per output); per output the taps are still applied j ascending
+  for (int g = lane; 2 * g < Q::ZPAD; g += 64) {
+    cx xv[2 * SPS + 2];
+    const float4 *xp4 = reinterpret_cast<const float4 *>(X + 2 * g);
+#pragma unroll
+    for (int q = 0; q < SPS + 1; q++) {
+      const float4 t4 = xp4[q];
+      xv[2 * q] = mk(t4.x, t4.y); xv[2 * q + 1] = mk(t4.z, t4.w);
+    }
+    float z0r = 0.0f, z0i = 0.0f, z1r = 0.0f, z1i = 0.0f;
 #pragma unroll
     for (int j = 0; j < 2 * SPS + 1; j++) {
-      const cx v = X[i + j];
-      zr = __builtin_fmaf(pul[j], v.r, zr); zi = __builtin_fmaf(pul[j], v.i, zi);
+      z0r = __builtin_fmaf(pul[j], xv[j].r, z0r); z0i = __builtin_fmaf(pul[j], xv[j].i, z0i);
+      z1r = __builtin_fmaf(pul[j], xv[j + 1].r, z1r); z1i = __builtin_fmaf(pul[j], xv[j + 1].i, z1i);
     }
-    Z[i] = mk(zr, zi);
+    *reinterpret_cast<float4 *>(Z + 2 * g) = make_float4(z0r, z0i, z1r, z1i);
   }
   wave_lds_fence();
+  TRX_STAMP();                                             // 2: pulse filter done
   float pw[R::NCL];
   float bestP = 0.0f;
   int bestT = -1;
+  {
+    float ar[R::NCL], ai[R::NCL];
 #pragma unroll
-  for (int c = 0; c < R::NCL; c++) {
-    const int t = lane + 64 * c;
-    float ar = 0.0f, ai = 0.0f;
+    for (int c = 0; c < R::NCL; c++) { ar[c] = 0.0f; ai[c] = 0.0f; }
+    cx z0[8];
+    rach_steer_load<SPS, R::NCL, 0>(Z + lane, z0);
+    rach_steer<SPS, R::NCL, 0>(Z + lane, z0, ar, ai);
 #pragma unroll
-    for (int k = 0; k < 41; k++) {                         // conj(c_k) z, c_k = sym_k i^k: additions only
-      const cx z = Z[t + SPS * k];
-      const float sg = (float)kRachSym[k];
-      if ((k & 3) == 0) { ar += sg * z.r; ai += sg * z.i; }
-      else if ((k & 3) == 1) { ar += sg * z.i; ai -= sg * z.r; }
-      else if ((k & 3) == 2) { ar -= sg * z.r; ai -= sg * z.i; }
-      else { ar -= sg * z.i; ai += sg * z.r; }
+    for (int c = 0; c < R::NCL; c++) {
+      const int t = lane + 64 * c;
+      float a_r = ar[c], a_i = ai[c];
+      // pulse tails the reference's modulateBurst dropped: before symbol 0 (j < sps) and after symbol 40 (j = 2 sps)
+      float e0r = 0.0f, e0i = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = __builtin_fmaf(pul[j], v.r, e0r); e0i = __builtin_fmaf(pul[j], v.i, e0i); }
+      const float s0 = (float)RachSym::v[0], s40 = (float)RachSym::v[40];
+      a_r -= s0 * e0r; a_i -= s0 * e0i;                    // k = 0: conj(c_0) = s0
+      const cx v40 = X[t + 42 * SPS];
+      a_r -= s40 * pul[2 * SPS] * v40.r; a_i -= s40 * pul[2 * SPS] * v40.i;   // k = 40: i^40 = 1
+      const float p = (t < N) ? a_r * a_r + a_i * a_i : -1.0f;
+      pw[c] = p;
+      if (p > bestP) { bestP = p; bestT = t; }
     }
-    // pulse tails the reference's modulateBurst dropped: before symbol 0 (j < sps) and after symbol 40 (j = 2 sps)
-    float e0r = 0.0f, e0i = 0.0f;
-#pragma unroll
-    for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = __builtin_fmaf(pul[j], v.r, e0r); e0i = __builtin_fmaf(pul[j], v.i, e0i); }
-    const float s0 = (float)kRachSym[0], s40 = (float)kRachSym[40];
-    ar -= s0 * e0r; ai -= s0 * e0i;                        // k = 0: conj(c_0) = s0
-    const cx v40 = X[t + 42 * SPS];
-    ar -= s40 * pul[2 * SPS] * v40.r; ai -= s40 * pul[2 * SPS] * v40.i;   // k = 40: i^40 = 1
-    const float p = (t < N) ? ar * ar + ai * ai : -1.0f;
-    pw[c] = p;
-    if (p > bestP) { bestP = p; bestT = t; }
   }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) {
@@ -438,6 +557,7 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
 #pragma unroll
   for (int c = 0; c < R::NCL; c++) PW[lane + 64 * c] = pw[c];   // approximate powers (lags >= N hold -1)
 
+  TRX_STAMP();                                             // 3: approximate correlation + argmax done
   // ---- 2. exact recomputation of the contenders ----
   const int Ma = bestT;                                    // approximate argmax (-1: silence)
   const float cut = bestP * (1.0f - RACH_DELTA);
@@ -512,6 +632,7 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   if (lane >= 24 && lane < 26) nb[wave][lane] = mk(0, 0);
   wave_lds_fence();
 
+  TRX_STAMP();                                             // 4: exact contenders + neighbourhood done
   // ---- 3. peakDetect's bisection on the exact neighbourhood (lanes 0..3) ----
   float peakIx, pkOwn, pkOther;
   quad_bisect<0, 1, false>(T, reinterpret_cast<const float *>(nb[wave]), 0, lane & 3, M, 1 << 30, &peakIx, &pkOwn,
@@ -519,6 +640,7 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   peakIx = __shfl(peakIx, 0, 64); pkOwn = __shfl(pkOwn, 0, 64); pkOther = __shfl(pkOther, 0, 64);
   const cx peak = mk(pkOwn, pkOther);
 
+  TRX_STAMP();                                             // 5: bisection done
   // ---- 4. detectRACHBurst tail (:875-913) ----
   float toa = peakIx;
   cx amp = mk(0, 0);
@@ -567,6 +689,15 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
     toa_out[b] = toa;
     if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
   }
+#ifdef TRX_RACH_PROBE
+  TRX_STAMP();                                             // 6: tail done
+  if (lane == 0 && avgpwr_out) {
+    long long v = 0;
+    for (int k = 1; k < 8; k++) if ((b & 7) == k) v = pt_[k] - pt_[0];
+    avgpwr_out[b] = (float)v;
+  }
+#endif
+#undef TRX_STAMP
 }
 
 
