@@ -308,8 +308,11 @@ int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int 
  *     1 = one fused kernel, a wave per burst;   2 = fused, two bursts per wave;
  *     3 = fused, four bursts per wave (k_normal_quad);   4 = k_normal_quad's detection half, then k_demod.
  *     The fused kernels need nsoft <= 148; otherwise the call takes path 0.
- *   TRXSIG_TUNE_RACH_PATH (initial value: env TRXSIG_RACH_VARIANT, else 1): 0 = exact correlation at every
- *     lag, 1 = approximate-then-exact (k_rach_fast).
+ *   TRXSIG_TUNE_RACH_PATH (initial value: env TRXSIG_RACH_VARIANT, else 2): 0 = exact correlation at every
+ *     lag (k_rach_corr + k_rach_peak), 1 = approximate-then-exact in one kernel, a wave per burst (k_rach_fast),
+ *     2 = the same with peakDetect's bisection and the tail in their own kernel, two lanes per burst
+ *     (k_rach_front + k_rach_peak2; bursts too close to the threshold to call from approximate valley powers
+ *     are handed back to k_rach_fast).  All three give the reference's results.
  *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component" form (which
  *     is only taken when the actual taps have that shape).  Default 0.
  *   TRXSIG_TUNE_SPECULATIVE_PEAK: path 0's peakDetect kernel.  0 = two lanes per burst (early and late point of

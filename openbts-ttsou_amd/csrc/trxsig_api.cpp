@@ -67,7 +67,7 @@ struct trxsig_ctx {
   // staging for the *_host wrappers
   size_t stage_bytes = 0;
   void *d_stage = nullptr;
-  int rach_variant = 1;              // 1 = k_rach_fast (approximate-then-exact), 0 = exact at every lag
+  int rach_variant = 2;              // 2 = k_rach_front + k_rach_peak2 (approximate-then-exact, bisection in its own kernel), 1 = k_rach_fast alone, 0 = exact at every lag
   int variant = 0;                   // normal-burst path (TRXSIG_TUNE_NORMAL_PATH / env TRXSIG_TSC_VARIANT)
   int spec_peak = 0;                 // peak kernel of path 0: 0 = k_tsc_peak2 (2 lanes per burst), 1 = k_tsc_peak8 (8, speculated), 2 = k_tsc_peak (1)
   int generic_taps = 0;              // 1: correlators without the tap-class specialisation (TRXSIG_TUNE_GENERIC_TAPS)
@@ -327,9 +327,10 @@ int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, c
   DeviceGuard g(c->device);
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
-  if (c->rach_variant == 1)
+  if (c->rach_variant >= 1)
     HIPCHK(c, trx_launch_rach_fast(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
-                                   detect_thresh, energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+                                   detect_thresh, energy_thresh, (float *)c->d_rec, c->cap_bursts, c->rach_variant == 2,
+                                   d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   else
     HIPCHK(c, trx_launch_rach_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                      B, detect_thresh, energy_thresh, (float *)c->d_rec, c->cap_bursts, d_flags,
@@ -732,7 +733,7 @@ int trxsig_fec_viterbi_batch(trxsig_ctx *c, const float *d_soft, int n_soft, int
 int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (!c) return TRXSIG_EINVAL;
   if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 4) { c->variant = value; return TRXSIG_OK; }
-  if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 1) { c->rach_variant = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 2) { c->rach_variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_GENERIC_TAPS && value >= 0 && value <= 1) { c->generic_taps = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 2) { c->spec_peak = value; return TRXSIG_OK; }
   return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: unknown key or value");

@@ -76,6 +76,92 @@ __device__ __forceinline__ cx peak_bisect(const TAB &tab, const cx (*loc)[LW], i
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// pair_bisect: peakDetect's bisection with TWO lanes per burst -- the even lane (h = 0) evaluates the early
+// point of every step, the odd lane (h = 1) the late one: the two 21-tap sums are the only parallelism the
+// reference's loop has (each sum must run j = 0..20 in order).  State: early = M-1 + e/512 (all of the
+// reference's +-2^-k steps are exact in float).
+//   stab  the sinc table in LDS (SincLds below); the row of the NEXT step is fetched after the decision
+//         (6 ds_read_b128) instead of gathering both candidates from L2 a step ahead;
+//   q[k]  = corr[M - 12 + k + 2h] with the zeros interpolatePoint implies (lag < 0, lag > n-2, :646), held in
+//         REGISTERS: floor(early) is fixed after step 0 (early stays inside (M-2, M-1) or (M-1, M)), so one
+//         select after step 0 makes every later tap index static.  Tap j of the early point is q[base + j] on the
+//         even lane, of the late point q[base + j] on the odd lane (base = floor(early) - (M - 2) = 0 or 1), of
+//         the final point q[base + 1 + j] on the even lane.
+// Returns interpolatePoint(early + 1) (:699-700) -- the even lane's value counts -- and e.
+// ---------------------------------------------------------------------------------------------
+struct SincLds { float row[512][24]; };                    // 48 KB
+
+// one workgroup of NT threads copies the table: issue the loads early, store when convenient, then __syncthreads()
+template <int NT>
+__device__ __forceinline__ void sinc_lds_issue(const TrxTables *__restrict__ T, int tid, float4 (&tv)[3072 / NT]) {
+#pragma unroll
+  for (int k = 0; k < 3072 / NT; k++) {
+    const int ix = tid + NT * k;                           // 3072 float4 = 512 rows x 6
+    tv[k] = *reinterpret_cast<const float4 *>(&T->sinc_grid[ix / 6][4 * (ix % 6)]);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void sinc_lds_store(SincLds &S, int tid, const float4 (&tv)[3072 / NT]) {
+#pragma unroll
+  for (int k = 0; k < 3072 / NT; k++) {
+    const int ix = tid + NT * k;
+    *reinterpret_cast<float4 *>(&S.row[ix / 6][4 * (ix % 6)]) = tv[k];
+  }
+}
+
+__device__ __forceinline__ cx pair_bisect(const SincLds &S, const cx (&q)[23], int h, int &e_out) {
+  auto load_row = [&](int f, float (&s)[24]) {
+    const float4 *rw = reinterpret_cast<const float4 *>(S.row[f]);
+#pragma unroll
+    for (int g = 0; g < 6; g++) {
+      const float4 t4 = rw[g];
+      s[4 * g] = t4.x; s[4 * g + 1] = t4.y; s[4 * g + 2] = t4.z; s[4 * g + 3] = t4.w;
+    }
+  };
+  int e = 0;
+  bool active = true;
+  // one early/late decision (:690-697) from this lane's point and its neighbour's
+  auto decide = [&](cx pt, int inc) {
+    const float mine = norm2(pt);
+    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+    const float ne = h ? other : mine, nl = h ? mine : other;
+    if (active) {
+      if (ne < nl) e += inc;
+      else if (ne > nl) e -= inc;
+      else active = false;                                 // "else break" (:695)
+    }
+  };
+  float srow[24];
+  // step 0: early = M-1 is an integer (row 0, base 1)
+  load_row(0, srow);
+  {
+    cx pt = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(q[1 + j], srow[j]));
+    decide(pt, 256);
+  }
+  // floor(early) = M-2 if the first step went down, M-1 otherwise, and stays there
+  cx w[22];
+#pragma unroll
+  for (int k = 0; k < 22; k++) w[k] = (e < 0) ? q[k] : q[k + 1];
+#pragma unroll 1
+  for (int inc = 128; inc >= 1; inc >>= 1) {               // increments 2^-2 .. 2^-9
+    load_row(e & 511, srow);
+    cx pt = mk(0, 0);
+#pragma unroll
+    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(w[j], srow[j]));
+    decide(pt, inc);
+  }
+  load_row(e & 511, srow);                                 // early + 1 has the same fractional part
+  cx peak = mk(0, 0);
+#pragma unroll
+  for (int j = 0; j < 21; j++) peak = cadd(peak, cmulr(w[j + 1], srow[j]));
+  e_out = e;
+  return peak;
+}
+
+
 // One super-step of the speculative bisection.  State on entry: early = M-1 + e/512, `active`.  Lane hl
 // evaluates node hp's early (add 0) or late (add 2) point, or (FIN) one of the 2^NLV candidate final
 // points (add 1); the node's index offset, in units of this super-step's smallest increment, and `add`

@@ -43,8 +43,9 @@ hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, 
 // same results, approximate-then-exact single kernel (k_rach_fast)
 hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                                 const int32_t *off, const int32_t *len, int B, float detect_thresh,
-                                float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                                TrxProfiler *prof);
+                                float energy_thresh, float *ws /* trx_rach_rec_floats() floats per burst */, int Bpad,
+                                int split /* 1: k_rach_front + k_rach_peak2 + hand-over, 0: k_rach_fast alone */,
+                                uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof);
 
 // need_mask != 0: burst enabled iff (flags[b] & need_mask) == need_mask; need_mask == 0: iff flags[b] != 0;
 // flags == NULL: every burst enabled.

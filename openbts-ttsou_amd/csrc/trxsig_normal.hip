@@ -256,17 +256,11 @@ __global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restric
 
 
 // ---------------------------------------------------------------------------------------------
-// k_tsc_peak2: k_tsc_peak's job with TWO lanes per burst -- the even lane evaluates the early point of
-//   every bisection step, the odd lane the late one (the two 21-tap sums are the only parallelism the
-//   reference's loop has: each sum must run j = 0..20 in order) -- and two waves per SIMD instead of one.
-//   * the sinc table sits in LDS (48 KB per workgroup): the row of the NEXT step is fetched after the
-//     decision (6 ds_read_b128, ~150 cycles) instead of gathering both candidates from L2 a step ahead
-//     (k_tsc_peak: 12 divergent 16-byte gathers per lane and step, which the CU's vector cache serves one
-//     lane at a time: 1.4 k cycles per step with few distinct rows, 3 k with 256);
-//   * the correlation window lives in REGISTERS: floor(early) is fixed after step 0 (early stays inside
-//     (M-2, M-1) or (M-1, M)), so one select after step 0 makes every later tap index static;
-//   * the valley powers come from registers too (three candidate alignments, selected by rint(toa) - M).
-//   State: early = M-1 + e/512 (all of the reference's +-2^-k steps are exact in float).
+// k_tsc_peak2: k_tsc_peak's job with TWO lanes per burst (pair_bisect, trxsig_bisect.h: early and late point of a
+//   step side by side, sinc table in LDS, correlation window in registers) and two waves per SIMD instead of one.
+//   (k_tsc_peak gathers both candidate rows from L2 a step ahead: 12 divergent 16-byte gathers per lane and step,
+//   which the CU's vector cache serves one lane at a time -- 1.4 k cycles per step with few distinct rows, 3 k with
+//   256.)  The valley powers come from registers too (three candidate alignments, selected by rint(toa) - M).
 // ---------------------------------------------------------------------------------------------
 template <int SPS>
 __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec, int Bpad,
@@ -276,7 +270,7 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
                                                    float *__restrict__ avgpwr_out) {
   typedef CorrGeom<SPS> G;
   constexpr int NL = G::NL, NE = G::NE, NP = 3 * SPS + 3;  // NP: valley powers kept per side
-  __shared__ __attribute__((aligned(16))) float stab[512][24];
+  __shared__ __attribute__((aligned(16))) SincLds stab;
   const int tid = threadIdx.x;
   const int h = tid & 1;                                   // 0: early point (and the final one), 1: late point
   const int b = blockIdx.x * 128 + (tid >> 1);
@@ -293,24 +287,17 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
 
   // ---- loads first: this thread's 12 float4 of the table, then its part of the detect->peak record ----
   float4 tv[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const int ix = tid + 256 * k;                          // 3072 float4 = 512 rows x 6
-    tv[k] = *reinterpret_cast<const float4 *>(&T->sinc_grid[ix / 6][4 * (ix % 6)]);
-  }
+  sinc_lds_issue<256>(T, tid, tv);
   const cx meta = rec[(size_t)G::NS * Bpad + bb];
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
   const bool good = M != -2;
-  // q[k] = corr[M - 12 + k + 2h] with the zeros interpolatePoint implies (it never uses the last sample, :646):
-  // tap j of the early point is q[base + j] on the even lane, of the late point q[base + j] on the odd lane
-  // (base = floor(early) - (M - 2) = 0 or 1), of the final point q[base + 1 + j] on the even lane.
-  cx q[23];
+  cx q[23];                                                // pair_bisect's window: corr[M - 12 + k + 2h]
 #pragma unroll
   for (int k = 0; k < 23; k++) {
     const int ix = k + 2 * h;
     const cx v = rec[(size_t)(G::H - 12 + ix) * Bpad + bb];
-    q[k] = (M - 12 + ix > NL - 2) ? mk(0, 0) : v;
+    q[k] = (M - 12 + ix > NL - 2) ? mk(0, 0) : v;          // interpolatePoint never uses the last sample (:646)
   }
   // corr at M - (5sps+1) + k and M + (2sps-1) + k, k < NP: every lag the valley can touch (|rint(toa) - M| <= 1);
   // in flight with the rest, first needed in the tail
@@ -320,68 +307,13 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
     vlo_[k] = rec[(size_t)(G::H - (5 * SPS + 1) + k) * Bpad + bb];
     vhi_[k] = rec[(size_t)(G::H + (2 * SPS - 1) + k) * Bpad + bb];
   }
-#pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const int ix = tid + 256 * k;
-    *reinterpret_cast<float4 *>(&stab[ix / 6][4 * (ix % 6)]) = tv[k];
-  }
+  sinc_lds_store<256>(stab, tid, tv);
   TRX_STAMP();
   __syncthreads();                                         // the only barrier
   TRX_STAMP();
 
-  auto load_row = [&](int f, float (&s)[24]) {
-    const float4 *rw = reinterpret_cast<const float4 *>(stab[f]);
-#pragma unroll
-    for (int g = 0; g < 6; g++) {
-      const float4 t4 = rw[g];
-      s[4 * g] = t4.x; s[4 * g + 1] = t4.y; s[4 * g + 2] = t4.z; s[4 * g + 3] = t4.w;
-    }
-  };
-  int e = 0;
-  bool active = true;
-  // one early/late decision (:690-697) from this lane's point and its neighbour's
-  auto decide = [&](cx pt, int inc) {
-    const float mine = norm2(pt);
-    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0xB1, 0xf, 0xf, true));   // lane ^ 1
-    const float ne = h ? other : mine, nl = h ? mine : other;
-    if (active) {
-      if (ne < nl) e += inc;
-      else if (ne > nl) e -= inc;
-      else active = false;                                 // "else break" (:695)
-    }
-  };
-  float srow[24];
-  // step 0: early = M-1 is an integer (row 0, base 1)
-  load_row(0, srow);
-  {
-    cx pt = mk(0, 0);
-#pragma unroll
-    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(q[1 + j], srow[j]));
-    decide(pt, 256);
-  }
-  TRX_STAMP();
-  // floor(early) = M-2 if the first step went down, M-1 otherwise, and stays there
-  cx w[22];
-#pragma unroll
-  for (int k = 0; k < 22; k++) w[k] = (e < 0) ? q[k] : q[k + 1];
-#pragma unroll 1
-  for (int inc = 128; inc >= 1; inc >>= 1) {               // increments 2^-2 .. 2^-9
-    load_row(e & 511, srow);
-    cx pt = mk(0, 0);
-#pragma unroll
-    for (int j = 0; j < 21; j++) pt = cadd(pt, cmulr(w[j], srow[j]));
-    decide(pt, inc);
-#ifdef TRX_PEAK_PROBE
-    if (inc == 32 || inc == 4) TRX_STAMP();
-#endif
-  }
-  TRX_STAMP();
-  // the peak itself: interpolatePoint(early + 1), same fractional part (:699-700); the even lane's value counts
-  load_row(e & 511, srow);
-  cx peak = mk(0, 0);
-#pragma unroll
-  for (int j = 0; j < 21; j++) peak = cadd(peak, cmulr(w[j + 1], srow[j]));
-
+  int e;
+  const cx peak = pair_bisect(stab, q, h, e);
   TRX_STAMP();
   // ---- analyzeTrafficBurst's tail (k_tsc_peak's arithmetic) ----
   const float early = (float)(M - 1) + (float)e * 0.001953125f;

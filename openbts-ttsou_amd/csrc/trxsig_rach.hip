@@ -424,13 +424,16 @@ __device__ __forceinline__ void rach_steer(const cx *Zl, const cx (&zc)[8], floa
   }
 }
 
-template <int SPS>
-__global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
-                                                   const int32_t *__restrict__ offset,
-                                                   const int32_t *__restrict__ length, int B,
-                                                   float detect_thresh, float energy_thresh,
-                                                   uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
-                                                   float *__restrict__ toa_out, float *__restrict__ avgpwr_out) {
+#define RACH_SKIP (-1000)                                   // record marker: k_rach_front has already written this burst's outputs
+// SPLIT: stop after step 2 and hand the exact neighbourhood, M, the energy and the three candidate valley sums
+// (rint(toa) = M-1, M, M+1) to k_rach_peak2 through the record (rec: 25 complex slots, vsum: 3 float slots, [slot][Bpad]).
+template <int SPS, bool SPLIT>
+__device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+                                                const int32_t *__restrict__ offset, const int32_t *__restrict__ length,
+                                                float detect_thresh, float energy_thresh,
+                                                uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
+                                                cx *__restrict__ rec, float *__restrict__ vsum, int Bpad) {
   typedef RachGeom<SPS> R;
   typedef RachFast<SPS> Q;
   __shared__ __attribute__((aligned(16))) cx xs[1][Q::XPAD];
@@ -441,8 +444,6 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
 
   const int lane = threadIdx.x;
   constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
-  const int b = blockIdx.x;
-  if (b >= B) return;
 #ifdef TRX_RACH_PROBE                                      // tools/rach_probe.py: clock64() stamps come back through avgpwr
   long long pt_[16] = {0};
   int pk_ = 0;
@@ -454,7 +455,10 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   const int off = offset[b], N = length[b];
   const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
   if (!good) {
-    if (lane == 0) { flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = 0.0f; }
+    if (lane == 0) {
+      flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = 0.0f;
+      if (SPLIT) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(RACH_SKIP), 0.0f);
+    }
     return;
   }
   const cx *x = samples + off;
@@ -489,7 +493,10 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   energy = __shfl(energy, 0, 64);
   const bool energy_ok = energy_thresh < 0.0f || energy / (float)(unsigned)R::NE > energy_thresh * energy_thresh;
   if (!energy_ok) {                                        // Transceiver.cpp:298-306: correlator not run
-    if (lane == 0) { flags[b] = 0; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE; }
+    if (lane == 0) {
+      flags[b] = 0; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
+      if (SPLIT) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(RACH_SKIP), 0.0f);
+    }
     return;
   }
   wave_lds_fence();
@@ -633,6 +640,23 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   wave_lds_fence();
 
   TRX_STAMP();                                             // 4: exact contenders + neighbourhood done
+  if constexpr (SPLIT) {
+    if (lane < 24) rec[(size_t)lane * Bpad + b] = nb[wave][lane];
+    if (lane == 24) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(M), energy);
+    const int i0 = 57 * SPS, i1 = 107 * SPS;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {                          // the approximate valley (step 4) for rint(toa) = M-1+a
+      const int p = M - 1 + a;
+      int last = N - 1 - p;
+      if (last > i1) last = i1;
+      float vs = 0.0f;
+      for (int i = i0 + lane; i <= last; i += 64) vs += PW[p + i];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
+      if (lane == 0) vsum[(size_t)a * Bpad + b] = vs;
+    }
+    return;
+  }
   // ---- 3. peakDetect's bisection on the exact neighbourhood (lanes 0..3) ----
   float peakIx, pkOwn, pkOther;
   quad_bisect<0, 1, false>(T, reinterpret_cast<const float *>(nb[wave]), 0, lane & 3, M, 1 << 30, &peakIx, &pkOwn,
@@ -701,6 +725,116 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
 }
 
 
+// the whole detector in one launch, a wave per burst; with `list` (the hand-over of k_rach_peak2) the workgroups walk
+// the *count listed bursts instead
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+                                                   const int32_t *__restrict__ offset,
+                                                   const int32_t *__restrict__ length, int B,
+                                                   float detect_thresh, float energy_thresh,
+                                                   uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                   float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
+                                                   const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
+  if (!list) {
+    if ((int)blockIdx.x < B)
+      rach_fast_burst<SPS, false>(blockIdx.x, T, samples, offset, length, detect_thresh, energy_thresh, flags, amp_out, toa_out,
+                                  avgpwr_out, nullptr, nullptr, 0);
+    return;
+  }
+  const int n = *count < B ? *count : B;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    rach_fast_burst<SPS, false>(list[i], T, samples, offset, length, detect_thresh, energy_thresh, flags, amp_out, toa_out,
+                                avgpwr_out, nullptr, nullptr, 0);
+    wave_lds_fence();                                      // the next burst reuses the LDS
+  }
+}
+
+// steps 1-2 of k_rach_fast (approximate correlation, exact contenders and neighbourhood) for every burst
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+                                                    const int32_t *__restrict__ offset,
+                                                    const int32_t *__restrict__ length, int B, float energy_thresh,
+                                                    uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                    float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
+                                                    cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
+                                                    int32_t *__restrict__ count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;     // k_rach_peak2's hand-over list starts empty
+  if ((int)blockIdx.x < B)
+    rach_fast_burst<SPS, true>(blockIdx.x, T, samples, offset, length, 0.0f, energy_thresh, flags, amp_out, toa_out, avgpwr_out,
+                               rec, vsum, Bpad);
+}
+
+// steps 3-4 with TWO lanes per burst (pair_bisect): peakDetect's bisection on the exact neighbourhood and
+// detectRACHBurst's tail (:875-913) with the approximate valley.  A burst whose peak/RMS lands within RACH_GUARD of the
+// threshold goes on the hand-over list instead (k_rach_fast in list mode recomputes its valley exactly).
+template <int SPS>
+__global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec,
+                                                    const float *__restrict__ vsum, const int32_t *__restrict__ length,
+                                                    int Bpad, int B, float detect_thresh, uint8_t *__restrict__ flags,
+                                                    cx *__restrict__ amp_out, float *__restrict__ toa_out,
+                                                    float *__restrict__ avgpwr_out, int32_t *__restrict__ list,
+                                                    int32_t *__restrict__ count) {
+  typedef RachGeom<SPS> R;
+  __shared__ __attribute__((aligned(16))) SincLds stab;
+  const int tid = threadIdx.x;
+  const int h = tid & 1;
+  const int b = blockIdx.x * 128 + (tid >> 1);
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;
+  float4 tv[12];
+  sinc_lds_issue<256>(T, tid, tv);
+  const cx meta = rec[(size_t)24 * Bpad + bb];
+  const int M = __float_as_int(meta.r);
+  const float energy = meta.i;
+  const int N = length[bb];
+  cx q[23];                                                // pair_bisect's window: corr[M - 12 + k + 2h] (slots 24, 25: zeros)
+#pragma unroll
+  for (int k = 0; k < 23; k++) {
+    const int ix = k + 2 * h;
+    q[k] = (ix < 24) ? rec[(size_t)(ix < 24 ? ix : 23) * Bpad + bb] : mk(0, 0);
+  }
+  float vs3[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) vs3[a] = vsum[(size_t)a * Bpad + bb];
+  sinc_lds_store<256>(stab, tid, tv);
+  __syncthreads();                                         // the only barrier
+
+  int e;
+  const cx peak = pair_bisect(stab, q, h, e);
+
+  float toa = (float)(M - 1) + (float)e * 0.001953125f + 1.0f;       // peakIx = early + 1 (:699)
+  cx amp = mk(0, 0);
+  bool detected = false, handover = false;
+  if (!(toa < 0.0f) && !(toa > (float)N)) {
+    const int p = (int)rintf(toa);
+    const int a = p - M + 1;                               // 0, 1 or 2
+    const int i0 = 57 * SPS, i1 = 107 * SPS;
+    int last = N - 1 - p;                                  // largest i with p + i < N
+    if (last > i1) last = i1;
+    const int cnt = last - i0 + 1;                         // numSamples
+    if (cnt >= 2) {
+      const float vs = a == 0 ? vs3[0] : (a == 1 ? vs3[1] : vs3[2]);
+      const float RMS = (float)((double)sqrtf(vs / (float)cnt) + 0.00001);
+      const float peakToMean = sqrtf(norm2(peak)) / RMS;
+      handover = fabsf(peakToMean - detect_thresh) <= RACH_GUARD * fabsf(detect_thresh) || !(vs == vs);
+      amp = cdiv(peak, T->rach_gain);                      // :905
+      toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
+      detected = peakToMean > detect_thresh;
+    }
+  }
+  if (live && h == 0 && M != RACH_SKIP) {
+    if (handover) {
+      list[atomicAdd(count, 1)] = b;                       // too close to call from approximate powers
+    } else {
+      flags[b] = TRXSIG_F_ENERGY | (detected ? TRXSIG_F_DETECT : 0);
+      amp_out[b] = amp;
+      toa_out[b] = toa;
+      if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
+    }
+  }
+}
+
+
 }  // namespace
 
 int trx_rach_rec_floats(int sps) {            // floats per burst in the rach record (complex slots + valley)
@@ -727,20 +861,43 @@ static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c3
   if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
 }
 
+template <int S>
+static void launch_rach_fast(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off, const int32_t *len,
+                             int B, float detect_thresh, float energy_thresh, float *ws, int Bpad, int split, uint8_t *flags,
+                             trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof) {
+  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
+  if (!split) {
+    k_rach_fast<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr,
+                                                 nullptr, nullptr);
+    if (prof) prof->end(TRXSIG_K_RACH_CORR, st);
+    return;
+  }
+  // workspace: 25 complex + 3 float record slots, the hand-over list and its counter (all [.][Bpad])
+  trx_c32 *rec = (trx_c32 *)ws;
+  float *vsum = ws + (size_t)2 * 25 * Bpad;
+  int32_t *list = (int32_t *)(vsum + (size_t)3 * Bpad);
+  int32_t *count = list + Bpad;
+  k_rach_front<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, energy_thresh, flags, amp, toa, avgpwr, rec, vsum, Bpad,
+                                                count);
+  if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
+  k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr,
+                                                               list, count);
+  k_rach_fast<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp,
+                                                               toa, avgpwr, list, count);
+  if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
+}
+
 hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                                 const int32_t *off, const int32_t *len, int B, float detect_thresh,
-                                float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                                TrxProfiler *prof) {
+                                float energy_thresh, float *ws, int Bpad, int split, uint8_t *flags, trx_c32 *amp, float *toa,
+                                float *avgpwr, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
-  const dim3 grid(B), block(64);
-  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
   switch (sps) {
-    case 1: k_rach_fast<1><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
-    case 2: k_rach_fast<2><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
-    case 4: k_rach_fast<4><<<grid, block, 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr); break;
+    case 1: launch_rach_fast<1>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
+    case 2: launch_rach_fast<2>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
+    case 4: launch_rach_fast<4>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
     default: return hipErrorInvalidValue;
   }
-  if (prof) prof->end(TRXSIG_K_RACH_CORR, st);
   return hipGetLastError();
 }
 

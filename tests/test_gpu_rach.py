@@ -81,10 +81,11 @@ def test_host_wrappers(pkg, ctx, golden):
     assert_veq(r["soft"][det], g["soft"][sel][det][:, :148])
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 def test_rach_variants_agree_with_oracle(pkg, variant, monkeypatch):
-    """Both RACH kernels (exact-at-every-lag and approximate-then-exact) against the oracle, including
-    noise-only, silent, clipped and late bursts where the approximate pass has to hand over."""
+    """The RACH routes (0: exact at every lag, 1: approximate-then-exact in one kernel, 2: the same with the bisection
+    in its own two-lanes-per-burst kernel and a hand-over list) against the oracle, including noise-only, silent,
+    clipped and late bursts where the approximate pass has to hand over."""
     monkeypatch.setenv("TRXSIG_RACH_VARIANT", variant)
     sps, B = 4, 768
     t = pkg.TrxSig(sps, 0); t.use_torch_stream()

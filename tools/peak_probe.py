@@ -19,8 +19,7 @@ for _ in range(300):
     c.detect_demod_normal(xf, off, length, 2, flags, amp, toa, None, avgpwr=ap, nsoft=0, soft_stride=0)
 torch.cuda.synchronize()
 v = ap.cpu().numpy().reshape(-1, 16).astype(np.float64)
-names = ['start', 'loads landed, table staged', 'barrier passed', 'step 0 done', 'step 3 done', 'step 6 done', 'step 8 done',
-         'final point', 'tail + stores issued']
+names = ['start', 'loads landed, table staged', 'barrier passed', 'bisection + final point', 'tail + stores issued']
 prev = 0
 for k in range(1, len(names)):
     m = v[:, k].mean()
