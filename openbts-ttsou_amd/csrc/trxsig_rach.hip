@@ -448,8 +448,15 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   long long pt_[16] = {0};
   int pk_ = 0;
 #define TRX_STAMP() pt_[pk_++] = clock64()
+#define TRX_STAMP_FLUSH()                                                               \
+  if (lane == 0 && avgpwr_out) {                                                        \
+    long long v_ = 0;                                                                   \
+    for (int k = 1; k < 8; k++) if ((b & 7) == k) v_ = pt_[k] - pt_[0];                 \
+    avgpwr_out[b] = (float)v_;                                                          \
+  }
 #else
 #define TRX_STAMP()
+#define TRX_STAMP_FLUSH()
 #endif
   TRX_STAMP();
   const int off = offset[b], N = length[b];
@@ -655,6 +662,8 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
       if (lane == 0) vsum[(size_t)a * Bpad + b] = vs;
     }
+    TRX_STAMP();                                           // 5: record written
+    TRX_STAMP_FLUSH();
     return;
   }
   // ---- 3. peakDetect's bisection on the exact neighbourhood (lanes 0..3) ----
@@ -713,15 +722,10 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     toa_out[b] = toa;
     if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
   }
-#ifdef TRX_RACH_PROBE
   TRX_STAMP();                                             // 6: tail done
-  if (lane == 0 && avgpwr_out) {
-    long long v = 0;
-    for (int k = 1; k < 8; k++) if ((b & 7) == k) v = pt_[k] - pt_[0];
-    avgpwr_out[b] = (float)v;
-  }
-#endif
+  TRX_STAMP_FLUSH();
 #undef TRX_STAMP
+#undef TRX_STAMP_FLUSH
 }
 
 
@@ -829,7 +833,9 @@ __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict_
       flags[b] = TRXSIG_F_ENERGY | (detected ? TRXSIG_F_DETECT : 0);
       amp_out[b] = amp;
       toa_out[b] = toa;
+#ifndef TRX_RACH_PROBE                                      // (the probe build keeps k_rach_front's stamps in avgpwr)
       if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
+#endif
     }
   }
 }
