@@ -1,6 +1,8 @@
 // trxsig_eq.hip -- the equaliser path (sps = 1): channel estimate, designDFE, equalizeBurst.
 // Numerical contract: see trxsig_dev.h / DESIGN.md (every float32 operation is the reference's, in the
 // reference's order; built with -ffp-contract=off).
+#include <cstdlib>
+
 #include "trxsig_demod.h"
 
 namespace {
@@ -336,6 +338,147 @@ __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// k_eq_dfe2: equalizeBurst (:1352-1384) for 64 bursts per workgroup with TWO waves: lane l of the producer wave and
+//   lane l of the consumer wave share burst l.
+//   * The feed-forward FIR does not depend on the decisions: the PRODUCER computes ff[k] = sum_j x[k+6-j] w[j]
+//     (the reference's terms in the reference's order) a tile of 16 symbols ahead and hands it over through LDS.
+//   * The CONSUMER runs the serial part only: d = ((((ff + b0 h0) + b1 h1) + ...) -- the same accumulator the
+//     reference continues after its feed-forward terms -- reverse rotation, decision, feedback, slicer
+//     (66 instead of 125 VALU per symbol on the critical path).
+//   * Neither touches global memory per symbol: the delayed burst comes in and the soft bits go out tile-wise, with
+//     lanes spread along k (4 rows x 16 symbols per instruction = whole cache lines) instead of 64 rows x one symbol.
+//   (k_eq_dfe: a lane per burst doing everything, one uncoalesced 8-byte load and 4-byte store per symbol with one
+//   step of latency cover: 110 us per 64 K bursts.)
+// ---------------------------------------------------------------------------------------------
+#define EQ_TK 16             /* symbols per tile */
+#define EQ_NT 10             /* tiles: 160 >= 157 symbols */
+__global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T, const cx *__restrict__ xd, int xstride,
+                                                 const int32_t *__restrict__ length, int B,
+                                                 const uint8_t *__restrict__ flags, const cx *__restrict__ w_in,
+                                                 const cx *__restrict__ b_in, float *__restrict__ soft,
+                                                 uint8_t *__restrict__ hard, int nsoft, int stride) {
+  __shared__ cx xt[64][EQ_TK + 1];                          // the producer's own staging of the delayed burst
+  __shared__ cx fft[2][64][EQ_TK + 1];                      // producer -> consumer
+  __shared__ float sft[2][64][EQ_TK + 1];                   // consumer -> producer (soft bits on their way out)
+  const int lane = threadIdx.x & 63;
+  const bool producer = threadIdx.x >= 64;                  // wave-uniform
+  const int b0 = blockIdx.x * 64;
+  const int b = b0 + lane;
+  const int bb = b < B ? b : B - 1;
+  const bool det = b < B && (flags[bb] & TRXSIG_F_DETECT);
+  const int N = length[bb];
+  const int nout = det ? (nsoft < N ? nsoft : N) : 0;       // symbols this burst really produces (zeros beyond)
+  // Barrier u (u = 0..9): ff tile u is ready and soft tile u-1 is complete; barrier 10: soft tile 9 is complete.
+  // Both waves execute exactly eleven barriers.
+  if (producer) {
+    const int kc = lane & 15, r0 = lane >> 4;               // tile traffic: this lane moves column kc of rows r0 + 4 i
+    const cx *x = xd + (size_t)bb * xstride;
+    cx w[7], win[6];
+#pragma unroll
+    for (int j = 0; j < 7; j++) w[j] = w_in[(size_t)bb * 7 + j];
+#pragma unroll
+    for (int m = 0; m < 6; m++) win[m] = (5 - m < N) ? x[5 - m] : mk(0, 0);   // win[m] = x[16 u + 5 - m]
+    // sample tile u: a = 16 u + 6 + c, c = 0..15 (output k = 16 u + i needs x[k + 6 - j]: FULL_SPAN keeps [6, 6+N), :1352-1356)
+    auto load_tile = [&](int u, cx (&v)[16]) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int rb = b0 + r0 + 4 * i, a = EQ_TK * u + 6 + kc;
+        v[i] = (rb < B && a < xstride) ? xd[(size_t)rb * xstride + a] : mk(0, 0);
+      }
+    };
+    auto write_out = [&](int u) {                           // soft tile u, lanes along k
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int r = r0 + 4 * i, k = EQ_TK * u + kc, rb = b0 + r;
+        if (rb < B && k < nsoft) {
+          const float sv = sft[u & 1][r][kc];
+          soft[(size_t)rb * stride + k] = sv;
+          if (hard) hard[(size_t)rb * stride + k] = sv > 0.5F;
+        }
+      }
+    };
+    cx v[16];
+    load_tile(0, v);
+    for (int u = 0; u < EQ_NT; u++) {
+      wave_lds_fence();                                     // everybody has taken its row of the previous tile
+#pragma unroll
+      for (int i = 0; i < 16; i++) xt[r0 + 4 * i][kc] = v[i];
+      wave_lds_fence();
+      if (u + 1 < EQ_NT) load_tile(u + 1, v);               // the next tile's loads fly during this tile's arithmetic
+      cx xa[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) xa[i] = xt[lane][i];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int k = EQ_TK * u + i;
+        cx d = mk(0, 0);
+#pragma unroll
+        for (int j = 0; j < 7; j++) {                       // convolve general branch: sum += a[t-j]*b[j], t = k+6
+          const int ai = k + 6 - j;
+          const cx xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
+          if (ai >= 0 && ai < N) d = cadd(d, cmul(xv, w[j]));
+        }
+        fft[u & 1][lane][i] = d;
+      }
+#pragma unroll
+      for (int m = 0; m < 6; m++) win[m] = xa[15 - m];
+      __syncthreads();                                      // barrier u
+      if (u >= 1) write_out(u - 1);
+    }
+    __syncthreads();                                        // barrier 10
+    write_out(EQ_NT - 1);
+  } else {
+    cx bq[5], hist[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { bq[j] = b_in[(size_t)bb * 5 + j]; hist[j] = mk(0, 0); }
+    for (int u = 0; u < EQ_NT; u++) {
+      __syncthreads();                                      // barrier u
+      // the tile's operands up front: feed-forward sums (LDS), rotation factors (uniform -> scalar loads)
+      cx ffv[EQ_TK], rv[EQ_TK], rt[EQ_TK];
+#pragma unroll
+      for (int i = 0; i < EQ_TK; i++) {
+        ffv[i] = fft[u & 1][lane][i];
+        rv[i] = T->rev[EQ_TK * u + i];                      // (rev/rot hold 157 * 4 entries: in range for k < 160)
+        rt[i] = T->rot[EQ_TK * u + i];
+      }
+#pragma unroll
+      for (int i = 0; i < EQ_TK; i++) {
+        const int k = EQ_TK * u + i;
+        float sv = 0.0f;
+        if (k < nout) {
+          cx d = ffv[i];                                    // the feed-forward terms, already summed in order
+#pragma unroll
+          for (int j = 0; j < 5; j++)                       // feedback over past decisions (:1370-1374)
+            if (k - 1 - j >= 0) d = cadd(d, cmul(bq[j], hist[j]));
+          d = cmul(d, rv[i]);                               // :1375
+          const float re = d.r;
+          const cx dec = mk((re > 0.0f) ? 1.0f : -1.0f, 0.0f);   // :1378
+          const cx fbv = cmul(dec, rt[i]);                  // :1380
+#pragma unroll
+          for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
+          hist[0] = fbv;
+          sv = (float)(0.5 * (double)(re + 1.0F));          // vectorSlicer (:513-515)
+          if (sv > 1.0f) sv = 1.0f;
+          if (sv < 0.0f) sv = 0.0f;
+        }
+        sft[u & 1][lane][i] = sv;
+      }
+    }
+    __syncthreads();                                        // barrier 10
+  }
+}
+
+// TRXSIG_EQ_DFE_VARIANT=1 (environment, A/B): the lane-per-burst k_eq_dfe instead of the producer/consumer k_eq_dfe2
+void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
+                   const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride) {
+  static const bool legacy = std::getenv("TRXSIG_EQ_DFE_VARIANT") && std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) == 1;
+  if (legacy)
+    k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  else
+    k_eq_dfe2<<<dim3((B + 63) / 64), dim3(128), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+}
+
 }  // namespace
 
 hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
@@ -349,7 +492,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
                                                         variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr);
   k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
                                                            TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
-  k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }
@@ -377,7 +520,7 @@ hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const t
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
       dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
-  k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }

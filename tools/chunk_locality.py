@@ -2,7 +2,9 @@
 the memory-side cache when its demodulation re-reads it) pay?  Also: rotating distinct inputs (no cross-step reuse)
 and the demodulation alone.   python tools/chunk_locality.py"""
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import _pkg
 pkg = _pkg.load()

@@ -2,7 +2,9 @@
 (clock64() stamps of every 16th burst's lanes come back through avgpwr):
     make -C openbts-ttsou_amd/csrc probe && TRXSIG_LIB=openbts-ttsou_amd/csrc/build_probe/libtrxsig_probe.so python tools/peak_probe.py"""
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch
 import _pkg

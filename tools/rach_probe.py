@@ -1,7 +1,9 @@
 """Where does k_rach_fast's time go?  Needs the probe build (make -C openbts-ttsou_amd/csrc probe):
     TRXSIG_LIB=openbts-ttsou_amd/csrc/build_probe/libtrxsig_probe.so python tools/rach_probe.py"""
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch
 import _pkg

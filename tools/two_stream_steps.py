@@ -2,7 +2,9 @@
 cross-stream events) -- the latency-bound k_tsc_peak and the VALU-bound k_tsc_corr of one step can share the
 card with the HBM-bound k_demod of another.   python tools/two_stream_steps.py"""
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import _pkg
 pkg = _pkg.load()
