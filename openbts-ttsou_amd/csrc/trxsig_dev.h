@@ -73,6 +73,19 @@ __device__ __forceinline__ float fma_exact_negab(float a, float b, float c) { //
   asm("v_fma_f32 %0, %1, -%2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
   return r;
 }
+// A fused multiply-add in a STEERING pass: an approximate correlation that only decides which lags get recomputed with
+// the reference's exact arithmetic (k_rach_*, the steered midamble correlator); nothing computed with it is ever
+// handed on.  Marked so that tools/asm_stats.py and tests/test_no_fma_contraction.py can tell it from a contraction.
+__device__ __forceinline__ float fma_steer(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 ; steering" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fma_steer_s(float a, float b_sgpr, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 ; steering" : "=v"(r) : "v"(a), "s"(b_sgpr), "v"(c));
+  return r;
+}
 // x * a as Complex<float>::operator* computes it (Complex.h:83), a in SGPRs, CLS = the tap's class
 __device__ __forceinline__ cx cmul_tap(cx x, cx a, int cls) {
   if (cls == 1) {                                          // a.r = +-1: x.r*a.r and x.i*a.r are exact

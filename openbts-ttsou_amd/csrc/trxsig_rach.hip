@@ -526,8 +526,8 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     float z0r = 0.0f, z0i = 0.0f, z1r = 0.0f, z1i = 0.0f;
 #pragma unroll
     for (int j = 0; j < 2 * SPS + 1; j++) {
-      z0r = __builtin_fmaf(pul[j], xv[j].r, z0r); z0i = __builtin_fmaf(pul[j], xv[j].i, z0i);
-      z1r = __builtin_fmaf(pul[j], xv[j + 1].r, z1r); z1i = __builtin_fmaf(pul[j], xv[j + 1].i, z1i);
+      z0r = fma_steer(pul[j], xv[j].r, z0r); z0i = fma_steer(pul[j], xv[j].i, z0i);
+      z1r = fma_steer(pul[j], xv[j + 1].r, z1r); z1i = fma_steer(pul[j], xv[j + 1].i, z1i);
     }
     *reinterpret_cast<float4 *>(Z + 2 * g) = make_float4(z0r, z0i, z1r, z1i);
   }
@@ -550,7 +550,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       // pulse tails the reference's modulateBurst dropped: before symbol 0 (j < sps) and after symbol 40 (j = 2 sps)
       float e0r = 0.0f, e0i = 0.0f;
 #pragma unroll
-      for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = __builtin_fmaf(pul[j], v.r, e0r); e0i = __builtin_fmaf(pul[j], v.i, e0i); }
+      for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = fma_steer(pul[j], v.r, e0r); e0i = fma_steer(pul[j], v.i, e0i); }
       const float s0 = (float)RachSym::v[0], s40 = (float)RachSym::v[40];
       a_r -= s0 * e0r; a_i -= s0 * e0i;                    // k = 0: conj(c_0) = s0
       const cx v40 = X[t + 42 * SPS];
@@ -739,16 +739,10 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
                                                    uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                    float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
                                                    const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
-  if (!list) {
-    if ((int)blockIdx.x < B)
-      rach_fast_burst<SPS, false>(blockIdx.x, T, samples, offset, length, detect_thresh, energy_thresh, flags, amp_out, toa_out,
-                                  avgpwr_out, nullptr, nullptr, 0);
-    return;
-  }
-  const int n = *count < B ? *count : B;
-  for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    rach_fast_burst<SPS, false>(list[i], T, samples, offset, length, detect_thresh, energy_thresh, flags, amp_out, toa_out,
-                                avgpwr_out, nullptr, nullptr, 0);
+  const int n = list ? (*count < B ? *count : B) : B;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {        // (without a list: grid = B, one burst per workgroup)
+    rach_fast_burst<SPS, false>(list ? list[i] : i, T, samples, offset, length, detect_thresh, energy_thresh, flags, amp_out,
+                                toa_out, avgpwr_out, nullptr, nullptr, 0);
     wave_lds_fence();                                      // the next burst reuses the LDS
   }
 }
