@@ -25,7 +25,7 @@ def test_kernels_have_no_contracted_fma():
                                         os.path.join(ROOT, "openbts-ttsou_amd", "csrc", f)], text=True)
     rows = [l for l in out.splitlines() if "outside a division" in l]
     assert len(rows) >= 23 and any("k_fec_viterbi" in l for l in rows)
-    steering_ok = ("k_rach_fast", "k_rach_front", "k_tsc_corr")
+    steering_ok = ("k_rach_fast", "k_rach_front")
     for l in rows:
         n = int(re.search(r"outside a division: (\d+)", l).group(1))
         assert n == 0, l
