@@ -304,8 +304,8 @@ __global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ 
 // If more far-away candidates turn up than fit in one pass (flat noise, silence) the burst takes
 // the exact route for all lags.
 // ---------------------------------------------------------------------------------------------
-#ifndef TRX_RACH_EXACT_UNROLL
-#define TRX_RACH_EXACT_UNROLL 4
+#ifndef TRX_RACH_EXACT_GROUP
+#define TRX_RACH_EXACT_GROUP 4   /* taps per software-pipeline stage of rach_exact_lag */
 #endif
 #define RACH_DELTA 4e-3f
 #define RACH_GUARD 1e-3f
@@ -330,32 +330,32 @@ __device__ __forceinline__ cx rach_exact_lag(const cx *X, const cx *__restrict__
   typedef RachGeom<SPS> R;
   cx acc = mk(0, 0);
   const cx *xp = X + t + SPS;                              // X index of x[t-F+m] is t + m + SPS
-  // Software pipelined in groups of four taps: the next group's samples (LDS) and taps (scalar loads) are in flight
+  // Software pipelined in groups of TRX_RACH_EXACT_GROUP taps: the next group's samples (LDS) and taps (scalar loads) are in flight
   // while this group's 32 VALU run -- the wave shares its SIMD with only one or two others, so an exposed LDS/scalar
   // latency per group (the plain loop: 41 x ~250 cycles) is not hidden by anybody else.  Order of the sum unchanged.
-  constexpr int REM = R::LB % 4, NG = R::LB / 4;
+  constexpr int GS = TRX_RACH_EXACT_GROUP, REM = R::LB % GS, NG = R::LB / GS;
   int m = R::LB - 1;
 #pragma unroll
   for (int q = 0; q < REM; q++, m--) {
     const cx rm = rseq[m];
     acc = cadd(acc, cmul(xp[m], mk(rm.r, -rm.i)));
   }
-  cx xa[4], ta[4];
+  cx xa[GS], ta[GS];
 #pragma unroll
-  for (int q = 0; q < 4; q++) { xa[q] = xp[m - q]; ta[q] = rseq[m - q]; }
+  for (int q = 0; q < GS; q++) { xa[q] = xp[m - q]; ta[q] = rseq[m - q]; }
 #pragma unroll 2
   for (int g = 0; g < NG; g++) {
-    cx xb[4], tb[4];
-    const int mn = (g + 1 < NG) ? m - 4 : m;               // (the last iteration re-reads its own group: in range, unused)
+    cx xb[GS], tb[GS];
+    const int mn = (g + 1 < NG) ? m - GS : m;              // (the last iteration re-reads its own group: in range, unused)
 #pragma unroll
-    for (int q = 0; q < 4; q++) { xb[q] = xp[mn - q]; tb[q] = rseq[mn - q]; }
+    for (int q = 0; q < GS; q++) { xb[q] = xp[mn - q]; tb[q] = rseq[mn - q]; }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc = cadd(acc, cmul(xa[q], mk(ta[q].r, -ta[q].i)));
+    for (int q = 0; q < GS; q++) acc = cadd(acc, cmul(xa[q], mk(ta[q].r, -ta[q].i)));
     asm volatile("" : "+v"(acc.r), "+v"(acc.i));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 4; q++) { xa[q] = xb[q]; ta[q] = tb[q]; }
+    for (int q = 0; q < GS; q++) { xa[q] = xb[q]; ta[q] = tb[q]; }
     m = mn;
   }
   return acc;
@@ -651,17 +651,21 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     if (lane < 24) rec[(size_t)lane * Bpad + b] = nb[wave][lane];
     if (lane == 24) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(M), energy);
     const int i0 = 57 * SPS, i1 = 107 * SPS;
+    float vs[3];                                           // the approximate valley (step 4) for rint(toa) = M-1+a
 #pragma unroll
-    for (int a = 0; a < 3; a++) {                          // the approximate valley (step 4) for rint(toa) = M-1+a
+    for (int a = 0; a < 3; a++) {
       const int p = M - 1 + a;
       int last = N - 1 - p;
       if (last > i1) last = i1;
-      float vs = 0.0f;
-      for (int i = i0 + lane; i <= last; i += 64) vs += PW[p + i];
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
-      if (lane == 0) vsum[(size_t)a * Bpad + b] = vs;
+      vs[a] = 0.0f;
+      for (int i = i0 + lane; i <= last; i += 64) vs[a] += PW[p + i];
     }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {                     // the three reductions side by side
+      const float o0 = __shfl_xor(vs[0], m, 64), o1 = __shfl_xor(vs[1], m, 64), o2 = __shfl_xor(vs[2], m, 64);
+      vs[0] += o0; vs[1] += o1; vs[2] += o2;
+    }
+    if (lane < 3) vsum[(size_t)lane * Bpad + b] = lane == 0 ? vs[0] : (lane == 1 ? vs[1] : vs[2]);
     TRX_STAMP();                                           // 5: record written
     TRX_STAMP_FLUSH();
     return;
