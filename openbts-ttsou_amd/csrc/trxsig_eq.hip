@@ -3,6 +3,7 @@
 // reference's order; built with -ffp-contract=off).
 #include <cstdlib>
 
+#include "trxsig_bisect.h"
 #include "trxsig_demod.h"
 
 namespace {
@@ -22,22 +23,13 @@ namespace {
 //                 recursion of equalizeBurst (:1352-1384) and the slicer.
 // ---------------------------------------------------------------------------------------------
 #define EQ_NC 36            /* max correlation lags kept per burst */
+// two instantiations: the 52M windowed correlation with maxTOA <= 5 (11 lags, 26 window samples: 25 KB of LDS, four
+// workgroups per CU) and everything else (the classic 36-lag window, wide 52M windows)
+#define EQ_DETECT_LAUNCH(...)                                                                          \
+  if (variant52m && max_toa <= 5) k_eq_detect<12, 26><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
+  else k_eq_detect<EQ_NC, 52><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__)
 
-// interpolatePoint on a per-lane LDS column of n entries (sigProcLib.cpp:639-659), ix on the 1/512 grid
-__device__ __forceinline__ cx eq_interp(const TrxTables *__restrict__ T, const cx (*col)[64], int lane, int n, float ix) {
-  const float fl = floorf(ix);
-  const int I = (int)fl;
-  const int f = (int)((ix - fl) * 512.0f) & 511;
-  int start = I - 10;
-  if (start < 0) start = 0;
-  int end = I + 11;
-  if ((unsigned)end > (unsigned)(n - 1)) end = n - 1;      // :646 (unsigned compare: negative end -> n-1)
-  const float *row = T->sinc_grid[f];
-  cx p = mk(0, 0);
-  for (int i = start; i < end; i++) p = cadd(p, cmulr(col[i][lane], row[i - I + 10]));
-  return p;
-}
-
+template <int NCMAX, int NXMAX>                             // correlation lags / window samples kept per burst
 __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                   const int32_t *__restrict__ offset,
                                                   const int32_t *__restrict__ length, int B, int tsc,
@@ -50,11 +42,20 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   // snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
   // double arithmetic, Transceiver.cpp:340); else snr_thresh >= 0: the threshold that enters
   // SNR = |amp|^2/(thr^2+1); else energy_thresh.  chan_off_out (optional): chanRespOffset (:343).
-  __shared__ cx corr[EQ_NC][64];
-  __shared__ cx shf[EQ_NC][64];
+  __shared__ cx corr[NCMAX][64];
+  __shared__ cx shf[NCMAX][64];
+  __shared__ cx xw[NXMAX][64];                              // the correlation window of each lane's burst (column = lane)
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
   if (b >= B) return;                                      // no barriers below: each lane owns its columns
+#ifdef TRX_EQ_PROBE                                        // clock64() stamps come back through toa_out (tools/eq_probe.py)
+  long long pt_[8] = {0};
+  int pk_ = 0;
+#define TRX_STAMP() pt_[pk_++] = clock64()
+#else
+#define TRX_STAMP()
+#endif
+  TRX_STAMP();
   const int off = offset[b], N = length[b];
   uint8_t fl = 0;
   cx amp = mk(0, 0);
@@ -66,21 +67,13 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   }
   const cx *x = samples + off;
 
-  // ---- energyDetect (:916-932; the 52M variant strides by 4, ref52:946-963) ----
-  {
-    float energy = 0.0f;
-    const int step = variant52m ? 4 : 1;
-    for (int i = 0; i < 20; i++) energy += norm2(x[i * step]);
-    const bool ok = energy_thresh < 0.0f || energy / (float)20u > energy_thresh * energy_thresh;
-    if (!ok) { flags[b] = 0; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f; return; }
-    fl = TRXSIG_F_ENERGY;
-  }
-
-  // ---- correlation ----
+  // ---- window geometry (pure arithmetic; needed up front so that the window's loads can fly with the energy's) ----
   int ncorr, winStart, La, startIndex;
   unsigned maxTOA = (unsigned)max_toa;
+  bool winOk;
   if (!variant52m) {
     ncorr = 36; winStart = 56; La = 36; startIndex = 7;    // NO_DELAY, Lb = 16 (:951-955, 295-300)
+    winOk = ncorr <= NCMAX && La <= NXMAX;                 // (the launcher picks an instantiation that fits)
   } else {                                                 // ref52:983-1000
     if (maxTOA < 3) maxTOA = 3;
     unsigned spanTOA = maxTOA;
@@ -90,41 +83,77 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
     ncorr = (int)(2 * maxTOA + 1);
     const unsigned expectedTOAPeak = (unsigned)round((double)((T->mid_toa[tsc] + 5.0f) + (float)(size_t)((16 - 1) / 2)));
     startIndex = (int)(expectedTOAPeak - maxTOA);
-    if (ncorr > EQ_NC || winStart < 0 || winStart + La > N) {
-      flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
-      return;
-    }
+    winOk = !(ncorr > NCMAX || La > NXMAX || winStart < 0 || winStart + La > N);
   }
+
+  // ---- every load of this burst in flight at once: the 20 energy samples and the correlation window (each window
+  //      sample used to be fetched up to 16 times, one uncoalesced 8-byte load per tap and lag) ----
+  cx ev[20], wv[NXMAX];
+  {
+    const int step = variant52m ? 4 : 1;
+#pragma unroll
+    for (int i = 0; i < 20; i++) ev[i] = x[i * step];
+#pragma unroll
+    for (int a = 0; a < NXMAX; a++) wv[a] = (winOk && a < La) ? x[winStart + a] : mk(0, 0);
+  }
+  // ---- energyDetect (:916-932; the 52M variant strides by 4, ref52:946-963) ----
+  {
+    float energy = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 20; i++) energy += norm2(ev[i]);
+    const bool ok = energy_thresh < 0.0f || energy / (float)20u > energy_thresh * energy_thresh;
+    if (!ok) { flags[b] = 0; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f; return; }
+    fl = TRXSIG_F_ENERGY;
+  }
+  TRX_STAMP();                                             // 1: energy
+  // ---- correlation ----
+  if (!winOk) {
+    flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < NXMAX; a++) if (a < La) xw[a][lane] = wv[a];   // the lane's LDS column
+  cx ctap[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) ctap[j] = T->mid_ctap[tsc][15 - j];
   for (int i = 0; i < ncorr; i++) {
     const int t = startIndex + i;
     cx sum = mk(0, 0);
 #pragma unroll
     for (int j = 0; j < 16; j++) {                         // tmp[j] = conj(mid[15-j]) (:480-498), j ascending
       const int ai = t - j;
-      if (ai >= 0 && ai < La) sum = cadd(sum, cmul(x[winStart + ai], T->mid_ctap[tsc][15 - j]));
+      if (ai >= 0 && ai < La) sum = cadd(sum, cmul(xw[ai][lane], ctap[j]));
     }
     corr[i][lane] = sum;
   }
 
+  TRX_STAMP();                                             // 2: correlation
   // ---- peakDetect (:663-711) ----
   float maxP = 0.0f, maxIndex = -1.0f;
   for (int i = 0; i < ncorr; i++) {
     const float p = norm2(corr[i][lane]);
     if (p > maxP) { maxP = p; maxIndex = (float)i; }
   }
-  float early = maxIndex - 1.0f, late = maxIndex + 1.0f, incr = 0.5f;
-  for (int step = 0; step < 9; step++) {
-    const cx e = eq_interp(T, corr, lane, ncorr, early), l = eq_interp(T, corr, lane, ncorr, late);
-    const float ne = norm2(e), nl = norm2(l);
-    if (ne < nl) early += incr;
-    else if (ne > nl) early -= incr;
-    else break;
-    incr = incr * 0.5f;
-    late = early + 2.0f;
+  {
+    // the bisection itself as k_tsc_peak runs it (peak_bisect: both candidate sinc rows of the next step prefetched
+    // with 16-byte loads while this step computes; the eq_interp form made two dependent gather round trips per step).
+    // loc = corr[M-12 .. M+11] with zeros where interpolatePoint skips (lag < 0, lag > n-2); the window's LDS is free now.
+    static_assert(NXMAX >= 26, "loc aliases the correlation window");
+    cx (*loc)[64] = xw;
+    const int M = (int)maxIndex;
+#pragma unroll
+    for (int j = 0; j < 24; j++) {
+      const int lag = M - 12 + j;
+      loc[j][lane] = (lag >= 0 && lag <= ncorr - 2) ? corr[lag < 0 ? 0 : (lag > NCMAX - 1 ? NCMAX - 1 : lag)][lane] : mk(0, 0);
+    }
+    loc[24][lane] = mk(0, 0);
+    loc[25][lane] = mk(0, 0);
+    float peakIx;
+    amp = peak_bisect<64>(T->sinc_grid, loc, lane, M, &peakIx);
+    toa = peakIx;
   }
-  toa = early + 1.0f;
-  amp = eq_interp(T, corr, lane, ncorr, toa);
 
+  TRX_STAMP();                                             // 3: peakDetect
   // ---- analyzeTrafficBurst tail (:961-1035) ----
   bool detected = false;
   float chanOff = 0.0f;
@@ -162,9 +191,15 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
         const float frac = delay - (float)io;
         const cx (*src)[64] = corr;
         if (fabs((double)frac) > 1e-2) {
-          const float *row = T->sinc_grid[(int)(frac * 512.0f) & 511];
+          float row[24];
+          {
+            const float4 *r4 = reinterpret_cast<const float4 *>(T->sinc_grid[(int)(frac * 512.0f) & 511]);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const float4 v4 = r4[q]; row[4 * q] = v4.x; row[4 * q + 1] = v4.y; row[4 * q + 2] = v4.z; row[4 * q + 3] = v4.w; }
+          }
           for (int t = 0; t < ncorr; t++) {
             cx sum = mk(0, 0);
+#pragma unroll
             for (int j = 0; j < 21; j++) {
               const int ai = t + 10 - j;
               if (ai >= 0 && ai < ncorr) sum = cadd(sum, cmulr(corr[ai][lane], row[j]));
@@ -204,6 +239,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   toa_eq[b] = toa - chanOff;                               // equalizeBurst(..., TOA - chanRespOffset, ...)
   if (chan_off_out) chan_off_out[b] = chanOff;
   if (!detected) return;
+  TRX_STAMP();                                             // 4: tail, delayVector, channel pick
 
   // ---- Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7) (:1246-1340) ----
   const float thr = snr_thresh >= 0.0f ? snr_thresh : (energy_thresh < 0.0f ? 0.0f : energy_thresh);
@@ -281,6 +317,15 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   }
 #pragma unroll
   for (int j = 0; j < nu; j++) b_out[(size_t)b * nu + j] = bq[j];
+#ifdef TRX_EQ_PROBE
+  TRX_STAMP();                                             // 5: designDFE + taps
+  {
+    long long v_ = 0;
+    for (int k = 1; k < 8; k++) if ((b & 7) == k) v_ = pt_[k] - pt_[0];
+    toa_out[b] = (float)v_;
+  }
+#endif
+#undef TRX_STAMP
 }
 
 // equalizeBurst after its delayVector: xd = delayed, scaled burst (B x xstride complex)
@@ -488,8 +533,8 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
                                int nsoft, int stride, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
-  k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
-                                                        variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr);
+  EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
+                   variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr);
   k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
                                                            TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
   launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
@@ -506,7 +551,7 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const tr
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
-  k_eq_detect<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
+  EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
                                                         max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();

@@ -1,0 +1,28 @@
+"""Where does k_eq_detect's time go?  Needs trxsig_eq.hip built with -DTRX_EQ_PROBE (clock64() stamps of the detected
+bursts come back through toa):  TRXSIG_LIB=.../libtrxsig_eqprobe.so python tools/eq_probe.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch
+import _pkg
+pkg = _pkg.load()
+from openbts_ttsou_amd import synth
+dev = torch.device('cuda:0')
+B, tsc = 65536, 6
+x, off, length, meta = synth.normal_batch_torch(1, B, tsc, seed=5, device=dev, sigmas=(0.02, 0.1), max_delay=1.0)
+xf = torch.view_as_real(x).contiguous()
+t = pkg.TrxSig(1, 0); t.use_torch_stream(); t.reserve(B)
+d = dict(flags=torch.zeros(B, dtype=torch.uint8, device=dev), amp=torch.zeros(B, 2, device=dev), toa=torch.zeros(B, device=dev),
+         w=torch.zeros(B, 7, 2, device=dev), b=torch.zeros(B, 5, 2, device=dev), soft=torch.zeros(B, 157, device=dev))
+for _ in range(50):
+    t.equalize_normal(xf, off, length, tsc, d['flags'], d['amp'], d['toa'], d['soft'], w=d['w'], b=d['b'], energy_thresh=10.0,
+                      variant52m=True, max_toa=4, nsoft=156, soft_stride=157)
+torch.cuda.synchronize()
+v = d['toa'].cpu().numpy().reshape(-1, 8).astype(np.float64)
+names = ['start', 'energy', 'correlation', 'peakDetect', 'tail + delayVector + channel pick', 'designDFE + taps']
+prev = 0
+for k in range(1, 6):
+    m = v[:, k].mean()
+    print('%-36s %9.0f cycles  (+%7.0f)' % (names[k], m, m - prev))
+    prev = m
