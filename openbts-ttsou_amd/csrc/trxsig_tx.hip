@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_modulate(const TrxTables *__restrict__ 
   cx *o = out + out_off[b];
   const bool scale = gain != nullptr;
   const float gv = scale ? gain[b] : 1.0f;
-  for (int t = threadIdx.x; t < N; t += blockDim.x) {
+  auto sample = [&](int t) {
     cx sum = mk(0, 0);
 #pragma unroll
     for (int q = 0; q < 3; q++) {
@@ -44,7 +44,16 @@ __global__ __launch_bounds__(256) void k_modulate(const TrxTables *__restrict__ 
       }
     }
     if (scale) sum = cmul(sum, mk(gv, 0.0f));              // scaleVector(x, complex(g)) (:719-722)
-    o[t] = sum;
+    return sum;
+  };
+  if ((out_off[b] & 1) == 0) {                             // two samples per lane and one 16-byte store
+    for (int u = threadIdx.x; 2 * u + 1 < N; u += blockDim.x) {
+      const cx s0 = sample(2 * u), s1 = sample(2 * u + 1);
+      *reinterpret_cast<float4 *>(o + 2 * u) = make_float4(s0.r, s0.i, s1.r, s1.i);
+    }
+    if ((N & 1) && threadIdx.x == 0) o[N - 1] = sample(N - 1);
+  } else {
+    for (int t = threadIdx.x; t < N; t += blockDim.x) o[t] = sample(t);
   }
 }
 
