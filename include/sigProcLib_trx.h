@@ -4,12 +4,13 @@
 // It re-creates the names a Transceiver / RadioInterface translation unit uses -- `complex`,
 // `signalVector`, `BitVector`, `SoftVector`, sigProcLibSetup, generateGSMPulse, modulateBurst,
 // generateMidamble, generateRACHSequence, energyDetect, analyzeTrafficBurst, detectRACHBurst,
-// demodulateBurst, polyphaseResampleVector, createLPF (with setLPFTables) -- with the reference's argument meaning,
+// demodulateBurst, scaleVector, designDFE, equalizeBurst, polyphaseResampleVector, createLPF (with setLPFTables) --
+// i.e. every sigProcLib function Transceiver.cpp and radioInterface.cpp call -- with the reference's argument meaning,
 // ownership (functions returning a pointer allocate with `new`, the caller deletes:
 // Transceiver.cpp:112,407,672) and error behaviour (NULL / false, amplitude set to 0 on a "bogus
 // result": sigProcLib.cpp:878-882, 964-968).  Every call that processes samples runs on the GPU
 // through the C-ABI's host-buffer entry points (one PCIe round trip per call); nothing here computes
-// on the CPU.  A real deployment batches instead -- see INTEGRATION.md.
+// on the CPU except scaleVector's element-wise complex multiply.  A real deployment batches instead -- see INTEGRATION.md.
 //
 // Not provided: the free-standing vector primitives (convolve, correlate, delayVector, peakDetect,
 // interpolatePoint, ...).  Transceiver.cpp and radioInterface.cpp never call them (SURVEY 8b lists
@@ -33,6 +34,11 @@ struct complex {
   float real() const { return r; }
   float imag() const { return i; }
   float norm2() const { return i * i + r * r; }
+  complex conj() const { return complex(r, -i); }
+  complex inv() const { const float n = norm2(); return complex(r / n, -i / n); }             // Complex.h:154-160
+  complex operator*(const complex &a) const { return complex(r * a.r - i * a.i, r * a.i + i * a.r); }   // Complex.h:83
+  complex operator*(float a) const { return complex(r * a, i * a); }                           // Complex.h:84
+  complex operator/(const complex &a) const { return (*this) * a.inv(); }                      // Complex.h:85
 };
 
 // Vector<T> subset (CommonLibs/Vector.h:42-252): contiguous, owning.
@@ -168,14 +174,63 @@ inline bool energyDetect(signalVector &rxBurst, unsigned windowLength, float det
   detail::detect(false, rxBurst, 0, 1e30f, detectThreshold, NULL, NULL, avgPwr, &ok);
   return ok;
 }
-// analyzeTrafficBurst (sigProcLib.h:277-285) without channel estimation (requestChannel: use
-// trxsig_equalize_normal_batch, which fuses estimate + designDFE + equalizeBurst)
+// analyzeTrafficBurst (sigProcLib.h:277-285).  requestChannel (symbol-rate samples only, as the reference's equaliser):
+// *channelResponse = new signalVector(6) (caller deletes) and *channelResponseOffset are set when the burst is detected
+// (sigProcLib.cpp:1005-1031).
 inline bool analyzeTrafficBurst(signalVector &rxBurst, unsigned TSC, float detectThreshold, int samplesPerSymbol,
                                 complex *amplitude, float *TOA, bool requestChannel = false,
                                 signalVector **channelResponse = NULL, float *channelResponseOffset = NULL) {
-  (void)channelResponse; (void)channelResponseOffset;
-  if (requestChannel || samplesPerSymbol != state().sps || TSC > 7) return false;
-  return detail::detect(false, rxBurst, TSC, detectThreshold, -1.0f, amplitude, TOA, NULL, NULL);
+  if (samplesPerSymbol != state().sps || TSC > 7) return false;
+  if (!requestChannel) return detail::detect(false, rxBurst, TSC, detectThreshold, -1.0f, amplitude, TOA, NULL, NULL);
+  State &s = state();
+  if (!s.ctx || s.sps != 1 || !channelResponse) return false;
+  uint8_t flags = 0; trxsig_c32 amp = {0, 0}, chan[6]; float toa = 0, choff = 0;
+  if (trxsig_channel_estimate_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), (int)TSC, detectThreshold,
+                                   0, 0, &flags, &amp, &toa, &choff, chan) != TRXSIG_OK)
+    return false;
+  if (amplitude) *amplitude = complex(amp.re, amp.im);
+  if (TOA) *TOA = toa;
+  if (!(flags & TRXSIG_F_DETECT)) return false;
+  *channelResponse = new signalVector(6);
+  for (int k = 0; k < 6; k++) (**channelResponse)[k] = complex(chan[k].re, chan[k].im);
+  if (channelResponseOffset) *channelResponseOffset = choff;
+  return true;
+}
+// scaleVector (sigProcLib.h:182-183): x[k] = x[k] * scale (sigProcLib.cpp:713-723)
+inline void scaleVector(signalVector &x, complex scale) {
+  for (size_t k = 0; k < x.size(); k++) x[k] = x[k] * scale;
+}
+// designDFE (sigProcLib.h:365-369): Nf = 7 and a 6-tap channel, as the Transceiver uses it (Transceiver.cpp:347);
+// *feedForwardFilter (7 taps) and *feedbackFilter (5 taps) are allocated with new (the caller deletes)
+inline bool designDFE(signalVector &channelResponse, float SNRestimate, int Nf, signalVector **feedForwardFilter,
+                      signalVector **feedbackFilter) {
+  State &s = state();
+  if (!s.ctx || Nf != 7 || channelResponse.size() != 6 || !feedForwardFilter || !feedbackFilter) return false;
+  trxsig_c32 chan[6], w[7], b[5];
+  for (int k = 0; k < 6; k++) { chan[k].re = channelResponse[k].r; chan[k].im = channelResponse[k].i; }
+  if (trxsig_design_dfe_host(s.ctx, chan, SNRestimate, w, b) != TRXSIG_OK) return false;
+  *feedForwardFilter = new signalVector(7);
+  *feedbackFilter = new signalVector(5);
+  for (int k = 0; k < 7; k++) (**feedForwardFilter)[k] = complex(w[k].re, w[k].im);
+  for (int k = 0; k < 5; k++) (**feedbackFilter)[k] = complex(b[k].re, b[k].im);
+  return true;
+}
+// equalizeBurst (sigProcLib.h:380-384): the burst is expected scaled by 1/amplitude already (Transceiver.cpp:391);
+// returns one soft bit per sample; caller deletes
+inline SoftVector *equalizeBurst(signalVector &rxBurst, float TOA, int samplesPerSymbol, signalVector &w, signalVector &b) {
+  State &s = state();
+  if (!s.ctx || samplesPerSymbol != 1 || s.sps != 1 || w.size() != 7 || b.size() != 5 || rxBurst.size() > 157) return NULL;
+  trxsig_c32 wt[7], bt[5];
+  for (int k = 0; k < 7; k++) { wt[k].re = w[k].r; wt[k].im = w[k].i; }
+  for (int k = 0; k < 5; k++) { bt[k].re = b[k].r; bt[k].im = b[k].i; }
+  const int ns = (int)rxBurst.size();
+  SoftVector *out = new SoftVector(ns);
+  const trxsig_c32 one = {1.0f, 0.0f};
+  if (trxsig_equalize_taps_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), ns, one, TOA, wt, bt, out->begin(), ns) != TRXSIG_OK) {
+    delete out;
+    return NULL;
+  }
+  return out;
 }
 // detectRACHBurst (sigProcLib.h:263-267)
 inline bool detectRACHBurst(signalVector &rxBurst, float detectThreshold, int samplesPerSymbol, complex *amplitude,
@@ -241,6 +296,9 @@ using trxfacade::polyphaseResampleVector;
 using trxfacade::setLPFTables;
 using trxfacade::complex;
 using trxfacade::demodulateBurst;
+using trxfacade::designDFE;
+using trxfacade::equalizeBurst;
+using trxfacade::scaleVector;
 using trxfacade::detectRACHBurst;
 using trxfacade::energyDetect;
 using trxfacade::generateGSMPulse;

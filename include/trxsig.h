@@ -184,6 +184,28 @@ int trxsig_equalize_taps_batch(trxsig_ctx *ctx, const trxsig_c32 *d_samples, con
                                const int32_t *d_length, int B, const trxsig_c32 *d_amp, const float *d_toa_eq,
                                const uint8_t *d_enable, const trxsig_c32 *d_w, const trxsig_c32 *d_b,
                                float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+/* The same steps as the reference's free functions hand them to each other (sigProcLib.h:277-285, 372-384), for the
+ * source-compatible facade:
+ *   trxsig_channel_estimate_batch: analyzeTrafficBurst(..., requestChannel = true): flags/amp/TOA as the detect calls
+ *     (no energy gate), d_chan_off = channelResponseOffset, d_chan = channelResponse (B x 6 taps, already divided by
+ *     the midamble gain, sigProcLib.cpp:1024-1025; zeros for bursts that were not detected).
+ *   trxsig_design_dfe_batch: designDFE(channelResponse, SNRestimate, Nf = 7, &w, &b) (sigProcLib.cpp:1246-1340) for B
+ *     channel estimates; d_amp != NULL applies scaleVector(channelResponse, 1/amp) first (Transceiver.cpp:346),
+ *     NULL = the caller has done that.  d_w: B x 7, d_b: B x 5. */
+int trxsig_channel_estimate_batch(trxsig_ctx *ctx, const trxsig_c32 *d_samples, const int32_t *d_offset,
+                                  const int32_t *d_length, int B, int tsc, float detect_thresh, int variant52m, int max_toa,
+                                  uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_chan_off, trxsig_c32 *d_chan);
+int trxsig_design_dfe_batch(trxsig_ctx *ctx, const trxsig_c32 *d_chan, const trxsig_c32 *d_amp, const float *d_snr, int B,
+                            trxsig_c32 *d_w, trxsig_c32 *d_b);
+/* single-burst host-buffer forms (one PCIe round trip each; what include/sigProcLib_trx.h calls):
+ * trxsig_equalize_taps_host = scaleVector(burst, 1/amp) + equalizeBurst(burst, toa_eq, 1, w, b) (sigProcLib.h:372-384);
+ * pass amp = {1, 0} for a burst that is scaled already. */
+int trxsig_channel_estimate_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples, int n, int tsc, float detect_thresh,
+                                 int variant52m, int max_toa, uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
+                                 float *h_chan_off, trxsig_c32 h_chan[6]);
+int trxsig_design_dfe_host(trxsig_ctx *ctx, const trxsig_c32 h_chan[6], float snr, trxsig_c32 h_w[7], trxsig_c32 h_b[5]);
+int trxsig_equalize_taps_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples, int n, trxsig_c32 amp, float toa_eq,
+                              const trxsig_c32 h_w[7], const trxsig_c32 h_b[5], float *h_soft, int nsoft);
 
 /* ---- rate conversion: polyphaseResampleVector (sigProcLib.h:352-354) -------------------------
  * S independent streams (one per ARFCN).  Stream s: input d_in + s*in_stride (n_in samples),

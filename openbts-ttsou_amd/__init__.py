@@ -73,6 +73,8 @@ def lib():
         L.trxsig_pack_int16_scaled.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
         L.trxsig_fec_xcch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.trxsig_fec_rach_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.trxsig_channel_estimate_batch.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, i32, i32, vp, vp, vp, vp, vp]
+        L.trxsig_design_dfe_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L.trxsig_fec_xcch_encode_batch.argtypes = [vp, vp, i32, i32, vp]
         L.trxsig_fec_tch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.trxsig_fec_viterbi_batch.argtypes = [vp, vp, i32, C.c_int64, i32, vp, C.c_int64]
@@ -276,6 +278,16 @@ class TrxSig:
         self._chk(self.L.trxsig_fec_rach_decode_batch(self.h, _ptr(soft), soft_stride or soft.shape[-1], n_bursts,
                                                       int(wire), _ptr(tail_ok), _ptr(bsic), _ptr(ra)),
                   "trxsig_fec_rach_decode_batch")
+
+    def channel_estimate(self, samples, offset, length, tsc, flags, amp, toa, chan_off, chan, detect_thresh=3.0, variant52m=False,
+                         max_toa=4):
+        self._chk(self.L.trxsig_channel_estimate_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), offset.numel(), tsc,
+                                                       detect_thresh, int(variant52m), max_toa, _ptr(flags), _ptr(amp), _ptr(toa),
+                                                       _ptr(chan_off), _ptr(chan)), "trxsig_channel_estimate_batch")
+
+    def design_dfe(self, chan, snr, w, b, amp=None):
+        self._chk(self.L.trxsig_design_dfe_batch(self.h, _ptr(chan), _ptr(amp), _ptr(snr), snr.numel(), _ptr(w), _ptr(b)),
+                  "trxsig_design_dfe_batch")
 
     def fec_xcch_encode(self, frames, n_blocks, tsc, bits):
         self._chk(self.L.trxsig_fec_xcch_encode_batch(self.h, _ptr(frames), n_blocks, tsc, _ptr(bits)), "trxsig_fec_xcch_encode_batch")

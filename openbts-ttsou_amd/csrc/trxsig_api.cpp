@@ -385,7 +385,40 @@ int trxsig_estimate_dfe_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const 
   if (rc != TRXSIG_OK) return rc;
   HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
                                     detect_thresh, snr_thresh, snr_value, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
-                                    (float *)c->d_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b, c->prof));
+                                    (float *)c->d_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b, nullptr, c->prof));
+  return TRXSIG_OK;
+}
+
+int trxsig_channel_estimate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
+                                  int B, int tsc, float detect_thresh, int variant52m, int max_toa, uint8_t *d_flags,
+                                  trxsig_c32 *d_amp, float *d_toa, float *d_chan_off, trxsig_c32 *d_chan) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "trxsig_channel_estimate_batch: the channel estimate needs sps == 1");
+  if (bad_batch(d_samples, d_offset, d_length, B) || tsc < 0 || tsc > 7 || max_toa < 0 || max_toa > 17 ||
+      (B > 0 && (!d_flags || !d_amp || !d_toa || !d_chan_off || !d_chan)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_channel_estimate_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_eq(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  // (the kernel also designs a DFE for a nominal SNR into scratch: toa_eq [B], w [7 B], b [5 B] of the equaliser workspace)
+  float *toa_eq = (float *)c->d_eq;
+  trx_c32 *w = (trx_c32 *)(c->d_eq + sizeof(float) * (size_t)c->eq_cap);
+  trx_c32 *bq = w + (size_t)7 * c->eq_cap;
+  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
+                                    detect_thresh, -1.0f, 1.0f, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa, toa_eq,
+                                    d_chan_off, w, bq, (trx_c32 *)d_chan, c->prof));
+  return TRXSIG_OK;
+}
+
+int trxsig_design_dfe_batch(trxsig_ctx *c, const trxsig_c32 *d_chan, const trxsig_c32 *d_amp, const float *d_snr, int B,
+                            trxsig_c32 *d_w, trxsig_c32 *d_b) {
+  if (!c) return TRXSIG_EINVAL;
+  if (B < 0 || (B > 0 && (!d_chan || !d_snr || !d_w || !d_b))) return fail(c, TRXSIG_EINVAL, "trxsig_design_dfe_batch: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_design_dfe(c->stream, (const trx_c32 *)d_chan, (const trx_c32 *)d_amp, d_snr, B, (trx_c32 *)d_w,
+                                  (trx_c32 *)d_b, c->prof));
   return TRXSIG_OK;
 }
 
@@ -641,6 +674,89 @@ int trxsig_demodulate_host(trxsig_ctx *c, const trxsig_c32 *h_samples, int n, tr
   rc = trxsig_demodulate_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), 1,
                                (trxsig_c32 *)(d + o_amp), (float *)(d + o_toa), nullptr, (float *)(d + o_soft),
                                nullptr, nsoft, 160);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_soft, d + o_soft, 4 * (size_t)nsoft, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+// ---- single-burst host forms of the equaliser steps (the source-compatible facade; one PCIe round trip each) ----
+int trxsig_channel_estimate_host(trxsig_ctx *c, const trxsig_c32 *h_samples, int n, int tsc, float detect_thresh, int variant52m,
+                                 int max_toa, uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa, float *h_chan_off,
+                                 trxsig_c32 h_chan[6]) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_samples || n <= 0 || !h_flags || !h_amp || !h_toa || !h_chan_off || !h_chan)
+    return fail(c, TRXSIG_EINVAL, "trxsig_channel_estimate_host: bad argument");
+  DeviceGuard g(c->device);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_s = 0, o_off = up(8 * (size_t)n), o_len = o_off + 256, o_fl = o_len + 256, o_amp = o_fl + 256, o_toa = o_amp + 256,
+               o_co = o_toa + 256, o_ch = o_co + 256, end = o_ch + 256;
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  const int32_t zero = 0, len = n;
+  HIPCHK(c, hipMemcpyAsync(d + o_s, h_samples, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_off, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_len, &len, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));              // the scalars above live on this stack frame
+  rc = trxsig_channel_estimate_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), 1, tsc, detect_thresh,
+                                     variant52m, max_toa, (uint8_t *)(d + o_fl), (trxsig_c32 *)(d + o_amp), (float *)(d + o_toa),
+                                     (float *)(d + o_co), (trxsig_c32 *)(d + o_ch));
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_flags, d + o_fl, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_amp, d + o_amp, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_toa, d + o_toa, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_chan_off, d + o_co, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_chan, d + o_ch, 48, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+int trxsig_design_dfe_host(trxsig_ctx *c, const trxsig_c32 h_chan[6], float snr, trxsig_c32 h_w[7], trxsig_c32 h_b[5]) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_chan || !h_w || !h_b) return fail(c, TRXSIG_EINVAL, "trxsig_design_dfe_host: bad argument");
+  DeviceGuard g(c->device);
+  const size_t o_ch = 0, o_snr = 256, o_w = 512, o_b = 768, end = 1024;
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  HIPCHK(c, hipMemcpyAsync(d + o_ch, h_chan, 48, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_snr, &snr, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_design_dfe_batch(c, (trxsig_c32 *)(d + o_ch), nullptr, (float *)(d + o_snr), 1, (trxsig_c32 *)(d + o_w), (trxsig_c32 *)(d + o_b));
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_w, d + o_w, 56, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_b, d + o_b, 40, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+int trxsig_equalize_taps_host(trxsig_ctx *c, const trxsig_c32 *h_samples, int n, trxsig_c32 amp, float toa_eq,
+                              const trxsig_c32 h_w[7], const trxsig_c32 h_b[5], float *h_soft, int nsoft) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_samples || n <= 0 || !h_w || !h_b || !h_soft || nsoft < 0 || nsoft > 157)
+    return fail(c, TRXSIG_EINVAL, "trxsig_equalize_taps_host: bad argument");
+  DeviceGuard g(c->device);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_s = 0, o_off = up(8 * (size_t)n), o_len = o_off + 256, o_fl = o_len + 256, o_amp = o_fl + 256, o_toa = o_amp + 256,
+               o_w = o_toa + 256, o_b = o_w + 256, o_soft = o_b + 256, end = o_soft + up(4 * 160);
+  int rc = ensure_stage(c, end);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = (char *)c->d_stage;
+  const int32_t zero = 0, len = n;
+  const uint8_t fl = TRXSIG_F_ENERGY | TRXSIG_F_DETECT;
+  HIPCHK(c, hipMemcpyAsync(d + o_s, h_samples, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_off, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_len, &len, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_fl, &fl, 1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_amp, &amp, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_toa, &toa_eq, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_w, h_w, 56, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_b, h_b, 40, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_equalize_taps_batch(c, (trxsig_c32 *)(d + o_s), (int32_t *)(d + o_off), (int32_t *)(d + o_len), 1, (trxsig_c32 *)(d + o_amp),
+                                  (float *)(d + o_toa), (uint8_t *)(d + o_fl), (trxsig_c32 *)(d + o_w), (trxsig_c32 *)(d + o_b),
+                                  (float *)(d + o_soft), nullptr, nsoft, 160);
   if (rc != TRXSIG_OK) return rc;
   HIPCHK(c, hipMemcpyAsync(h_soft, d + o_soft, 4 * (size_t)nsoft, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

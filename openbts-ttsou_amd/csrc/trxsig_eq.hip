@@ -29,6 +29,77 @@ namespace {
   if (variant52m && max_toa <= 5) k_eq_detect<12, 26><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
   else k_eq_detect<EQ_NC, 52><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__)
 
+// designDFE(channelResponse, SNRestimate, Nf = 7, ...) (sigProcLib.cpp:1246-1340), nu = 5: fully unrolled in registers.
+// chan: the six channel taps (already scaled by 1/amp, Transceiver.cpp:346); w: feed-forward, bq: feedback taps.
+__device__ __forceinline__ void design_dfe7(const cx (&chan)[6], float snr, cx (&w)[7], cx (&bq)[5]) {
+  constexpr int Nf = 7, nu = 5;
+  cx G0[Nf], G1[Nf];
+#pragma unroll
+  for (int k = 0; k < Nf; k++) { G0[k] = mk(0, 0); G1[k] = mk(0, 0); }
+  G0[0] = mk((float)(1.0 / (double)sqrtf(snr)), 0.0f);     // :1261
+#pragma unroll
+  for (int j = 0; j <= nu; j++) G1[j] = mk(chan[j].r, -chan[j].i);
+  cx Lu[Nf - 1][Nf - 1];                                   // L[i][j], i < j <= Nf-1, stored at [i][j-i-1]
+  cx Lfb[nu];                                              // L[Nf-1][Nf .. Nf+nu-1]
+  float d = 0.0f;
+#pragma unroll
+  for (int i = 0; i < Nf; i++) {
+    d = norm2(G0[0]) + norm2(G1[0]);                       // :1272
+    const cx g0c = mk(G0[0].r, -G0[0].i), g1c = mk(G1[0].r, -G1[0].i);
+#pragma unroll
+    for (int k = 1; k < Nf; k++) {                         // *Lptr = (G0[k]*conj(G0[0]) + G1[k]*conj(G1[0]))/d (:1277)
+      const int col = i + k;
+      const bool need = (i < Nf - 1) ? (col <= Nf - 1) : (col >= Nf && col < Nf + nu);
+      if (need) {
+        const cx tt = cadd(cmul(G0[k], g0c), cmul(G1[k], g1c));
+        const cx v = mk(tt.r / d, tt.i / d);
+        if (i < Nf - 1) Lu[i][k - 1] = v; else Lfb[col - Nf] = v;
+      }
+    }
+    const cx kk = cdiv(G1[0], G0[0]);                      // :1282
+    if (i != Nf - 1) {
+      cx G0n[Nf], G1n[Nf];
+      const cx kc = mk(kk.r, -kk.i), km = cmulr(kk, -1.0f);
+#pragma unroll
+      for (int q = 0; q < Nf; q++) G0n[q] = cadd(cmul(G1[q], kc), G0[q]);      // :1285-1287
+#pragma unroll
+      for (int q = 0; q < Nf; q++) G1n[q] = cadd(cmul(G0[q], km), G1[q]);      // :1289-1291
+#pragma unroll
+      for (int q = 0; q < Nf - 1; q++) G1n[q] = G1n[q + 1];                     // delayVector(G1new,-1) (:1292)
+      G1n[Nf - 1] = mk(0, 0);
+      const cx sc = mk((float)(1.0 / (double)sqrtf((float)(1.0 + (double)norm2(kk)))), 0.0f);   // :1294-1295
+#pragma unroll
+      for (int q = 0; q < Nf; q++) { G0[q] = cmul(G0n[q], sc); G1[q] = cmul(G1n[q], sc); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < nu; j++) {                           // :1301-1304: * -1, conj
+    const cx t1 = cmul(Lfb[j], mk(-1.0f, 0.0f));
+    bq[j] = mk(t1.r, -t1.i);
+  }
+  cx v[Nf];
+  v[Nf - 1] = mk(1.0f, 0.0f);
+#pragma unroll
+  for (int k = Nf - 2; k >= 0; k--) {                      // :1310-1319
+    cx vk = mk(0, 0);
+#pragma unroll
+    for (int j = k + 1; j < Nf; j++) {
+      const cx pr = cmul(v[j], Lu[k][j - k - 1]);
+      vk.r -= pr.r; vk.i -= pr.i;
+    }
+    v[k] = vk;
+  }
+#pragma unroll
+  for (int i = 0; i < Nf; i++) {                           // :1323-1335
+    cx wi = mk(0, 0);
+    const int endPt = (nu < (Nf - 1 - i)) ? nu : (Nf - 1 - i);
+#pragma unroll
+    for (int k = 0; k < Nf; k++)
+      if (k < endPt + 1) wi = cadd(wi, cmul(v[i + k < Nf ? i + k : Nf - 1], mk(chan[k < 6 ? k : 5].r, -chan[k < 6 ? k : 5].i)));
+    w[i] = mk(wi.r / d, wi.i / d);
+  }
+}
+
 template <int NCMAX, int NXMAX>                             // correlation lags / window samples kept per burst
 __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                   const int32_t *__restrict__ offset,
@@ -38,7 +109,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
                                                   cx *__restrict__ amp_out, float *__restrict__ toa_out,
                                                   float *__restrict__ toa_eq, cx *__restrict__ w_out,
                                                   cx *__restrict__ b_out, float snr_thresh, float snr_value,
-                                                  float *__restrict__ chan_off_out) {
+                                                  float *__restrict__ chan_off_out, cx *__restrict__ chan_out) {
   // snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
   // double arithmetic, Transceiver.cpp:340); else snr_thresh >= 0: the threshold that enters
   // SNR = |amp|^2/(thr^2+1); else energy_thresh.  chan_off_out (optional): chanRespOffset (:343).
@@ -238,6 +309,10 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   toa_out[b] = toa;
   toa_eq[b] = toa - chanOff;                               // equalizeBurst(..., TOA - chanRespOffset, ...)
   if (chan_off_out) chan_off_out[b] = chanOff;
+  if (chan_out) {                                          // analyzeTrafficBurst's channelResponse (:1024-1025), zeros if not detected
+#pragma unroll
+    for (int k = 0; k < 6; k++) chan_out[(size_t)b * 6 + k] = detected ? chan[k] : mk(0, 0);
+  }
   if (!detected) return;
   TRX_STAMP();                                             // 4: tail, delayVector, channel pick
 
@@ -248,73 +323,11 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #pragma unroll
   for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
 
-  constexpr int Nf = 7, nu = 5;
-  cx G0[Nf], G1[Nf];
+  cx w7[7], bq[5];
+  design_dfe7(chan, snr, w7, bq);
 #pragma unroll
-  for (int k = 0; k < Nf; k++) { G0[k] = mk(0, 0); G1[k] = mk(0, 0); }
-  G0[0] = mk((float)(1.0 / (double)sqrtf(snr)), 0.0f);     // :1261
-#pragma unroll
-  for (int j = 0; j <= nu; j++) G1[j] = mk(chan[j].r, -chan[j].i);
-  cx Lu[Nf - 1][Nf - 1];                                   // L[i][j], i < j <= Nf-1, stored at [i][j-i-1]
-  cx Lfb[nu];                                              // L[Nf-1][Nf .. Nf+nu-1]
-  float d = 0.0f;
-#pragma unroll
-  for (int i = 0; i < Nf; i++) {
-    d = norm2(G0[0]) + norm2(G1[0]);                       // :1272
-    const cx g0c = mk(G0[0].r, -G0[0].i), g1c = mk(G1[0].r, -G1[0].i);
-#pragma unroll
-    for (int k = 1; k < Nf; k++) {                         // *Lptr = (G0[k]*conj(G0[0]) + G1[k]*conj(G1[0]))/d (:1277)
-      const int col = i + k;
-      const bool need = (i < Nf - 1) ? (col <= Nf - 1) : (col >= Nf && col < Nf + nu);
-      if (need) {
-        const cx tt = cadd(cmul(G0[k], g0c), cmul(G1[k], g1c));
-        const cx v = mk(tt.r / d, tt.i / d);
-        if (i < Nf - 1) Lu[i][k - 1] = v; else Lfb[col - Nf] = v;
-      }
-    }
-    const cx kk = cdiv(G1[0], G0[0]);                      // :1282
-    if (i != Nf - 1) {
-      cx G0n[Nf], G1n[Nf];
-      const cx kc = mk(kk.r, -kk.i), km = cmulr(kk, -1.0f);
-#pragma unroll
-      for (int q = 0; q < Nf; q++) G0n[q] = cadd(cmul(G1[q], kc), G0[q]);      // :1285-1287
-#pragma unroll
-      for (int q = 0; q < Nf; q++) G1n[q] = cadd(cmul(G0[q], km), G1[q]);      // :1289-1291
-#pragma unroll
-      for (int q = 0; q < Nf - 1; q++) G1n[q] = G1n[q + 1];                     // delayVector(G1new,-1) (:1292)
-      G1n[Nf - 1] = mk(0, 0);
-      const cx sc = mk((float)(1.0 / (double)sqrtf((float)(1.0 + (double)norm2(kk)))), 0.0f);   // :1294-1295
-#pragma unroll
-      for (int q = 0; q < Nf; q++) { G0[q] = cmul(G0n[q], sc); G1[q] = cmul(G1n[q], sc); }
-    }
-  }
-  cx bq[nu];
-#pragma unroll
-  for (int j = 0; j < nu; j++) {                           // :1301-1304: * -1, conj
-    const cx t1 = cmul(Lfb[j], mk(-1.0f, 0.0f));
-    bq[j] = mk(t1.r, -t1.i);
-  }
-  cx v[Nf];
-  v[Nf - 1] = mk(1.0f, 0.0f);
-#pragma unroll
-  for (int k = Nf - 2; k >= 0; k--) {                      // :1310-1319
-    cx vk = mk(0, 0);
-#pragma unroll
-    for (int j = k + 1; j < Nf; j++) {
-      const cx pr = cmul(v[j], Lu[k][j - k - 1]);
-      vk.r -= pr.r; vk.i -= pr.i;
-    }
-    v[k] = vk;
-  }
-#pragma unroll
-  for (int i = 0; i < Nf; i++) {                           // :1323-1335
-    cx wi = mk(0, 0);
-    const int endPt = (nu < (Nf - 1 - i)) ? nu : (Nf - 1 - i);
-#pragma unroll
-    for (int k = 0; k < Nf; k++)
-      if (k < endPt + 1) wi = cadd(wi, cmul(v[i + k < Nf ? i + k : Nf - 1], mk(chan[k < 6 ? k : 5].r, -chan[k < 6 ? k : 5].i)));
-    w_out[(size_t)b * Nf + i] = mk(wi.r / d, wi.i / d);
-  }
+  for (int i = 0; i < 7; i++) w_out[(size_t)b * 7 + i] = w7[i];
+  constexpr int nu = 5;
 #pragma unroll
   for (int j = 0; j < nu; j++) b_out[(size_t)b * nu + j] = bq[j];
 #ifdef TRX_EQ_PROBE
@@ -524,7 +537,37 @@ void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstrid
     k_eq_dfe2<<<dim3((B + 63) / 64), dim3(128), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
 }
 
+// designDFE on its own (a lane per channel estimate): chan B x 6 (as analyzeTrafficBurst returns it, i.e. before the
+// 1/amp scaling -- pass amp = NULL if the caller has scaled it already), snr B floats
+__global__ __launch_bounds__(64) void k_design_dfe(const cx *__restrict__ chan_in, const cx *__restrict__ amp, const float *__restrict__ snr,
+                                                   int B, cx *__restrict__ w_out, cx *__restrict__ b_out) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  cx chan[6], w[7], bq[5];
+#pragma unroll
+  for (int k = 0; k < 6; k++) chan[k] = chan_in[(size_t)b * 6 + k];
+  if (amp) {
+    const cx ainv = cdiv(mk(1.0f, 0.0f), amp[b]);          // scaleVector(chan, 1/amp) (Transceiver.cpp:346)
+#pragma unroll
+    for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
+  }
+  design_dfe7(chan, snr[b], w, bq);
+#pragma unroll
+  for (int i = 0; i < 7; i++) w_out[(size_t)b * 7 + i] = w[i];
+#pragma unroll
+  for (int j = 0; j < 5; j++) b_out[(size_t)b * 5 + j] = bq[j];
+}
+
 }  // namespace
+
+hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
+                                 trx_c32 *bq, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
+  k_design_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(chan, amp, snr, B, w, bq);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  return hipGetLastError();
+}
 
 hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                                const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
@@ -534,7 +577,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
-                   variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr);
+                   variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr);
   k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
                                                            TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
   launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
@@ -548,11 +591,11 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
 hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
-                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, TrxProfiler *prof) {
+                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
-                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off);
+                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }

@@ -86,7 +86,11 @@ hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long
 hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
-                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, TrxProfiler *prof);
+                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan /* B x 6 or NULL */,
+                                   TrxProfiler *prof);
+// designDFE(chan, snr, 7) alone; amp != NULL: scaleVector(chan, 1/amp) first
+hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
+                                 trx_c32 *bq, TrxProfiler *prof);
 hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                                     const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,

@@ -69,7 +69,33 @@ int main(int argc, char **argv) {
   const bool rs_ok = res && (int)res->size() == (int)((in.size() * 65 * sps + 95) / 96);
   delete res; delete lpf;
 
+  // the equaliser leg of Transceiver::pullRadioVector (Transceiver.cpp:317-349, 391-396), symbol-rate samples only:
+  // analyzeTrafficBurst(requestChannel) -> scaleVector(chan, 1/amp) -> designDFE -> scaleVector(burst, 1/amp) -> equalizeBurst
+  int eqerrs = 0;
+  if (sps == 1) {
+    const char *tsc6 = "10100111110110001010011111";
+    char b6[149];
+    std::snprintf(b6, sizeof b6, "%s%s%s", seg, tsc6, seg);
+    BitVector burst6(b6);
+    signalVector *m6 = modulateBurst(burst6, *gsmPulse, 8, sps);
+    if (!m6) return 9;
+    for (size_t k = 0; k < m6->size(); k++) (*m6)[k] = (*m6)[k] * complex(600.0f, 400.0f);
+    for (size_t k = m6->size() - 1; k >= 1; k--) (*m6)[k] = complex((*m6)[k].r + 0.3f * (*m6)[k - 1].r, (*m6)[k].i + 0.3f * (*m6)[k - 1].i);   // a second path
+    complex a6; float t6 = 0, choff = 0;
+    signalVector *chan = NULL, *w = NULL, *b = NULL;
+    const bool f6 = analyzeTrafficBurst(*m6, 6, 3.0, sps, &a6, &t6, true, &chan, &choff);
+    if (!f6 || !chan) return 10;
+    scaleVector(*chan, complex(1.0, 0.0) / a6);
+    if (!designDFE(*chan, 100.0f, 7, &w, &b)) return 11;
+    scaleVector(*m6, complex(1.0, 0.0) / a6);
+    SoftVector *es = equalizeBurst(*m6, t6 - choff, sps, *w, *b);
+    if (!es) return 12;
+    for (int k = 0; k < 148; k++) eqerrs += es->bit(k) != burst6.bit(k);
+    std::printf("equalised burst: channel offset %.1f, |w3| %.4f, %d bit errors\n", choff, (*w)[3].norm2(), eqerrs);
+    delete es; delete w; delete b; delete chan; delete m6;
+  }
+
   delete soft; delete mod; delete rmod; delete gsmPulse;
   sigProcLibDestroy();
-  return (errs == 0 && rfound && rerrs == 0 && rs_ok) ? 0 : 1;
+  return (errs == 0 && rfound && rerrs == 0 && rs_ok && eqerrs == 0) ? 0 : 1;
 }

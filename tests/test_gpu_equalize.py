@@ -136,3 +136,45 @@ def test_config5_fp16_samples(pkg, t1):
             assert r["amp"][i] == a["amp"] and r["toa"][i] == a["toa"]
             ndet += 1
     assert ndet > 10
+
+
+@pytest.mark.parametrize("variant52m", [True, False])
+def test_channel_estimate_and_design_dfe_on_their_own(pkg, t1, variant52m):
+    """analyzeTrafficBurst(requestChannel) and designDFE as separate calls (the facade's route, sigProcLib.h:277-285,
+    365-369): channel response, offset and both filters value-exact against the oracle's."""
+    import torch
+    from openbts_ttsou_amd import synth
+    o = oraclebind.Oracle(1, variant52m=variant52m)
+    B, tsc, mt = 384, 6, 4
+    x, off, length, meta = synth.normal_batch(1, B, tsc, seed=4711 + variant52m, sigmas=(0.02, 0.1, 1.5), max_delay=1.0)
+    for i in range(1, B, 2):
+        s = x[off[i]:off[i] + length[i]]
+        s[1:] = s[1:] + np.complex64(0.4 + 0.2j) * s[:-1].copy()
+    dev = "cuda"
+    dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    doff = torch.from_numpy(off.astype(np.int32)).cuda(); dlen = torch.from_numpy(length.astype(np.int32)).cuda()
+    flags = torch.zeros(B, dtype=torch.uint8, device=dev); amp = torch.zeros(B, 2, device=dev); toa = torch.zeros(B, device=dev)
+    choff = torch.zeros(B, device=dev); chan = torch.zeros(B, 6, 2, device=dev)
+    t1.channel_estimate(dx, doff, dlen, tsc, flags, amp, toa, choff, chan, variant52m=variant52m, max_toa=mt)
+    snr = torch.full((B,), 37.5, device=dev)
+    w = torch.zeros(B, 7, 2, device=dev); b = torch.zeros(B, 5, 2, device=dev)
+    t1.design_dfe(chan, snr, w, b, amp=amp)
+    torch.cuda.synchronize()
+    fl = flags.cpu().numpy(); ch = chan.cpu().numpy().view(np.complex64).reshape(B, 6); co = choff.cpu().numpy()
+    am = amp.cpu().numpy().view(np.complex64).ravel(); wv = w.cpu().numpy().view(np.complex64).reshape(B, 7)
+    bv = b.cpu().numpy().view(np.complex64).reshape(B, 5)
+    ndet = 0
+    for i in range(B):
+        a = o.analyze_traffic(x[off[i]:off[i] + length[i]], tsc, 3.0, req_chan=True, max_toa=mt)
+        assert bool(fl[i] & pkg.F_DETECT) == a["ok"], i
+        assert am[i] == a["amp"] and toa[i].item() == a["toa"], i
+        if not a["ok"]:
+            assert not ch[i].any()
+            continue
+        ndet += 1
+        assert_veq(ch[i], a["chan"], "chan %d" % i); assert co[i] == a["chan_off"]
+        n2 = np.float32(np.float32(a["amp"].imag * a["amp"].imag) + np.float32(a["amp"].real * a["amp"].real))
+        inv = complex(np.float32(a["amp"].real / n2), np.float32(-a["amp"].imag / n2))
+        ow, ob = o.design_dfe(o.scale_vector(a["chan"], inv), 37.5, 7)
+        assert_veq(wv[i], ow, "w %d" % i); assert_veq(bv[i], ob, "b %d" % i)
+    assert ndet > B // 2
