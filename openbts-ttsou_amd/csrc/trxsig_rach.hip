@@ -438,9 +438,11 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   typedef RachFast<SPS> Q;
   __shared__ __attribute__((aligned(16))) cx xs[1][Q::XPAD];
   __shared__ __attribute__((aligned(16))) cx zs[1][Q::ZPAD];                             // pulse-filtered burst; later approx powers (float view)
-  __shared__ cx exv[1][64];                                 // exact correlation of the selected lags
-  __shared__ int exl[1][64];                                // ... and which lags they are
-  __shared__ cx nb[1][26];                                  // exact neighbourhood corr[M-12..M+11] (+2 zero slots)
+  // Three small arrays live in the part of zs that the approximate powers (64*NCL floats) leave free; they are first
+  // written after the approximate pass is done with Z (one LDS allocation less: 12 instead of 11 workgroups per CU at sps 4):
+  //   exv[64] exact correlation of the selected lags, exl[64] which lags they are,
+  //   nb[26]  exact neighbourhood corr[M-12..M+11] (+2 zero slots)
+  static_assert(64 * R::NCL + 2 * 64 + 64 + 2 * 26 <= 2 * Q::ZPAD, "exv/exl/nb fit behind the approximate powers");
 
   const int lane = threadIdx.x;
   constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
@@ -472,6 +474,9 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   cx *X = xs[wave];
   cx *Z = zs[wave];
   float *PW = reinterpret_cast<float *>(Z);
+  cx *const exv_ = reinterpret_cast<cx *>(PW + 64 * R::NCL);
+  int *const exl_ = reinterpret_cast<int *>(PW + 64 * R::NCL + 128);
+  cx *const nb_ = reinterpret_cast<cx *>(PW + 64 * R::NCL + 192);
   const cx *rseq = T->rach;
 
   {                                                        // every load in flight before the first LDS store
@@ -577,7 +582,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   const float cut = bestP * (1.0f - RACH_DELTA);
   const int nb0 = Ma - 13;                                 // neighbourhood lags nb0 .. nb0+25
   int nfar = 0;
-  int *LG = exl[wave];
+  int *LG = exl_;
   if (lane < Q::NB) LG[lane] = nb0 + lane;
 #pragma unroll
   for (int c = 0; c < R::NCL; c++) {
@@ -611,7 +616,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     M = bT;
     if (lane < 24) {
       const int lag = M - 12 + lane;
-      nb[wave][lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
+      nb_[lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
     }
   } else {
     const int nl = Q::NB + nfar;
@@ -619,7 +624,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     cx v = mk(0, 0);
     const bool valid = t >= 0 && t < N;
     if (valid) v = rach_exact_lag<SPS>(X, rseq, t);
-    exv[wave][lane] = v;
+    exv_[lane] = v;
     float bP = valid ? norm2(v) : 0.0f;
     int bT = (valid && bP > 0.0f) ? t : -1;
     if (bT < 0) bP = 0.0f;
@@ -633,22 +638,22 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     M = bT;
     wave_lds_fence();
     if (M >= nb0 + 12 && M <= nb0 + 14) {                  // |M - Ma| <= 1: [M-12, M+11] lies inside the recomputed lags
-      if (lane < 24) nb[wave][lane] = exv[wave][M - 12 + lane - nb0];
+      if (lane < 24) nb_[lane] = exv_[M - 12 + lane - nb0];
     } else if (lane < 24) {
       const int lag = M - 12 + lane;
-      nb[wave][lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
+      nb_[lane] = (lag >= 0 && lag < N) ? rach_exact_lag<SPS>(X, rseq, lag) : mk(0, 0);
     }
   }
   if (lane < 24) {                                         // interpolatePoint never uses the last sample (:646)
     const int lag = M - 12 + lane;
-    if (lag > N - 2 || lag < 0) nb[wave][lane] = mk(0, 0);
+    if (lag > N - 2 || lag < 0) nb_[lane] = mk(0, 0);
   }
-  if (lane >= 24 && lane < 26) nb[wave][lane] = mk(0, 0);
+  if (lane >= 24 && lane < 26) nb_[lane] = mk(0, 0);
   wave_lds_fence();
 
   TRX_STAMP();                                             // 4: exact contenders + neighbourhood done
   if constexpr (SPLIT) {
-    if (lane < 24) rec[(size_t)lane * Bpad + b] = nb[wave][lane];
+    if (lane < 24) rec[(size_t)lane * Bpad + b] = nb_[lane];
     if (lane == 24) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(M), energy);
     const int i0 = 57 * SPS, i1 = 107 * SPS;
     float vs[3];                                           // the approximate valley (step 4) for rint(toa) = M-1+a
@@ -672,7 +677,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   }
   // ---- 3. peakDetect's bisection on the exact neighbourhood (lanes 0..3) ----
   float peakIx, pkOwn, pkOther;
-  quad_bisect<0, 1, false>(T, reinterpret_cast<const float *>(nb[wave]), 0, lane & 3, M, 1 << 30, &peakIx, &pkOwn,
+  quad_bisect<0, 1, false>(T, reinterpret_cast<const float *>(nb_), 0, lane & 3, M, 1 << 30, &peakIx, &pkOwn,
                            &pkOther);
   peakIx = __shfl(peakIx, 0, 64); pkOwn = __shfl(pkOwn, 0, 64); pkOther = __shfl(pkOther, 0, 64);
   const cx peak = mk(pkOwn, pkOther);
@@ -697,7 +702,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       float peakToMean = sqrtf(norm2(peak)) / RMS;
       if (fabsf(peakToMean - detect_thresh) <= RACH_GUARD * fabsf(detect_thresh) || !(vs == vs)) {
         // too close to call from approximate powers: the reference's valley, exactly (:888-901)
-        float *VX = reinterpret_cast<float *>(exv[wave]);
+        float *VX = reinterpret_cast<float *>(exv_);
         float valley = 0.0f;
         for (int base = i0; base <= last; base += 64) {
           const int i = base + lane;
