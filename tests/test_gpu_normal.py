@@ -1,6 +1,8 @@
 """GPU parity, normal (TSC) bursts: libtrxsig's HIP path through the C-ABI against (1) the golden
 vectors captured from the real reference and (2) the CPU oracle on seeded random batches.
 Everything is compared value-exact (IEEE ==): amplitude, TOA, soft bits, hard bits, flags."""
+import os
+
 import numpy as np
 import pytest
 
@@ -138,3 +140,39 @@ def test_demodulate_entry_point(pkg, ctx):
             assert_veq(r["soft"][i], ref, "demod %d" % i)
         else:
             assert not r["soft"][i].any()
+
+
+def test_context_from_broadcast_tables(pkg):
+    """The multi-GPU bench's context creation: the table blob built on the host, placed in device memory the way
+    dist.broadcast_tables hands it over (here a single-rank RCCL group: init, broadcast and MAX all-reduce run, with
+    nobody to talk to), validated, and trxsig_create_from_tables -- results identical to a context that built its
+    own tables; a corrupted blob is refused."""
+    import torch
+    import torch.distributed as tdist
+    from openbts_ttsou_amd import dist as d
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    own = not tdist.is_initialized()
+    if own:
+        tdist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        blob, t = d.broadcast_tables(pkg, 4, device=torch.device("cuda", 0), src=0)
+        assert t.is_cuda and t.numel() == pkg.lib().trxsig_tables_bytes(4)
+        assert d.max_over_ranks(1.25, torch.device("cuda", 0)) == 1.25
+    finally:
+        if own:
+            tdist.destroy_process_group()
+    a = pkg.TrxSig(4, 0, tables_blob=t); a.use_torch_stream()
+    b = pkg.TrxSig(4, 0); b.use_torch_stream()
+    x, off, length, meta = synth.normal_batch(4, 777, 3, seed=99)
+    ra, rb = [], []
+    for c, out in ((a, ra), (b, rb)):
+        gb = GpuBatch(x, off, length)
+        c.detect_demod_normal(gb.x, gb.off, gb.len, 3, gb.flags, gb.amp, gb.toa, gb.soft)
+        out.append(gb.results())
+    for k in ("flags", "amp", "toa", "soft"):
+        assert_veq(ra[0][k], rb[0][k], k)
+    bad = t.clone(); bad[5000] ^= 0x40
+    with pytest.raises(pkg.TrxSigError):
+        pkg.TrxSig(4, 0, tables_blob=bad)
