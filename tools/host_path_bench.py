@@ -31,3 +31,21 @@ out['65536_bursts_per_call'] = {'ms_per_call': round(dt * 1e3, 2), 'Mbursts_per_
                                 'host_to_device_MB': round(xh.nbytes / 1e6), 'device_to_host_MB': round((r['soft'].nbytes + 17 * B) / 1e6),
                                 'note': 'pageable numpy buffers, includes the result allocation'}
 print(json.dumps(out))
+
+# the Transceiver object (include/trxsig_transceiver.h), one burst per call: TSC leg with the DFE cache, sps = 1
+h = pkg.TrxHost(1, 0, start=(100, 0))
+for c in ("CMD POWEROFF", "CMD RXTUNE 890000", "CMD TXTUNE 935000", "CMD SETTSC 6", "CMD SETRXGAIN 10", "CMD SETPOWER 0", "CMD POWERON",
+          "CMD SETSLOT 1 1", "CMD SETSLOT 0 5"):
+    h.control(c)
+xs, offs, lens, _ = synth.normal_batch(1, 64, 6, seed=3, sigmas=(0.02,), max_delay=1.0)
+bursts = [xs[offs[i]:offs[i] + lens[i]].copy() * np.float32(30) for i in range(64)]
+fn = 200
+for i in range(200):
+    fn += 1; h.pull_radio_vector(bursts[i % 64], 1, fn)
+t0 = time.perf_counter()
+K, got = 2000, 0
+for i in range(K):
+    fn += 1
+    got += h.pull_radio_vector(bursts[i % 64], 1, fn) is not None
+dt = (time.perf_counter() - t0) / K
+print(json.dumps({'trx_pull_radio_vector_tsc_leg': {'us_per_call': round(dt * 1e6, 1), 'soft_vectors_returned': got, 'of': K}}))
