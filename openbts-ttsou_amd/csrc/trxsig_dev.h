@@ -88,13 +88,20 @@ __device__ __forceinline__ float fma_steer_s(float a, float b_sgpr, float c) {
 }
 // x * a as Complex<float>::operator* computes it (Complex.h:83), a in SGPRs, CLS = the tap's class
 __device__ __forceinline__ cx cmul_tap(cx x, cx a, int cls) {
+  // (one asm statement for both components: hipcc puts an s_nop behind every inline-asm block)
   if (cls == 1) {                                          // a.r = +-1: x.r*a.r and x.i*a.r are exact
     const float p = x.i * a.i, q = x.r * a.i;
-    return mk(fma_exact_subc(x.r, a.r, p), fma_exact(x.i, a.r, q));
+    cx z;
+    asm("v_fma_f32 %0, %2, %4, -%5 ; exact-product\n\tv_fma_f32 %1, %3, %4, %6 ; exact-product"
+        : "=&v"(z.r), "=v"(z.i) : "v"(x.r), "v"(x.i), "s"(a.r), "v"(p), "v"(q));
+    return z;                                              // (x.r*a.r - p, x.i*a.r + q)
   }
   if (cls == 2) {                                          // a.i = +-1: x.i*a.i and x.r*a.i are exact
     const float p = x.r * a.r, q = x.i * a.r;
-    return mk(fma_exact_negab(x.i, a.i, p), fma_exact(x.r, a.i, q));
+    cx z;
+    asm("v_fma_f32 %0, %3, -%4, %5 ; exact-product\n\tv_fma_f32 %1, %2, %4, %6 ; exact-product"
+        : "=&v"(z.r), "=v"(z.i) : "v"(x.r), "v"(x.i), "s"(a.i), "v"(p), "v"(q));
+    return z;                                              // (p - x.i*a.i, x.r*a.i + q)
   }
   return cmul(x, a);
 }
