@@ -58,21 +58,6 @@ struct TapArg { float v[32]; };   // conj'd non-zero midamble taps passed as a k
 template <int SPS> struct TapPattern {                     // taps 0,2,4.. real-exact, 1,3,5.. imaginary-exact
   static constexpr unsigned value = (SPS == 4) ? 0x19999999u : 0x99999999u;   // sps 4: tap 15 is (eps, -0.99999994)
 };
-__device__ __forceinline__ float fma_exact(float a, float b, float c) {       // a*b + c, a*b exact (b = +-1, SGPR)
-  float r;
-  asm("v_fma_f32 %0, %1, %2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float fma_exact_subc(float a, float b, float c) {  // a*b - c
-  float r;
-  asm("v_fma_f32 %0, %1, %2, -%3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float fma_exact_negab(float a, float b, float c) { // c - a*b
-  float r;
-  asm("v_fma_f32 %0, %1, -%2, %3 ; exact-product" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-  return r;
-}
 // A fused multiply-add in a STEERING pass: an approximate correlation that only decides which lags get recomputed with
 // the reference's exact arithmetic (k_rach_*, the steered midamble correlator); nothing computed with it is ever
 // handed on.  Marked so that tools/asm_stats.py and tests/test_no_fma_contraction.py can tell it from a contraction.
