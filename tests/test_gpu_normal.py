@@ -142,6 +142,7 @@ def test_demodulate_entry_point(pkg, ctx):
             assert not r["soft"][i].any()
 
 
+@pytest.mark.timeout(180)
 def test_context_from_broadcast_tables(pkg):
     """The multi-GPU bench's context creation: the table blob built on the host, placed in device memory the way
     dist.broadcast_tables hands it over (here a single-rank RCCL group: init, broadcast and MAX all-reduce run, with
