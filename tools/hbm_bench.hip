@@ -13,12 +13,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_stream(const float4 *__restrict_
   const float4 *p = in + (size_t)b * stride4;
   float4 v[NLD];
 #pragma unroll
+#ifdef NT_LOAD
+  for (int i = 0; i < NLD; i++) { typedef float f4v __attribute__((ext_vector_type(4))); f4v t = {0, 0, 0, 0}; if (lane + 64 * i < stride4) t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p) + lane + 64 * i); v[i] = make_float4(t.x, t.y, t.z, t.w); }
+#else
   for (int i = 0; i < NLD; i++) v[i] = (lane + 64 * i < stride4) ? p[lane + 64 * i] : make_float4(0, 0, 0, 0);
+#endif
   float s = 0;
 #pragma unroll
   for (int i = 0; i < NLD; i++) s += v[i].x + v[i].y + v[i].z + v[i].w;
   float *o = out + (size_t)b * ostride;
+#ifdef NT_STORE
+  for (int m = lane; m < nout; m += 64) __builtin_nontemporal_store(s + m, o + m);
+#else
   for (int m = lane; m < nout; m += 64) o[m] = s + m;
+#endif
 }
 
 int main() {
