@@ -21,6 +21,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_stream(const float4 *__restrict_
   float s = 0;
 #pragma unroll
   for (int i = 0; i < NLD; i++) s += v[i].x + v[i].y + v[i].z + v[i].w;
+#ifdef EXTRA_VALU                                            // how much arithmetic rides for free under this traffic?
+  {
+    float a0 = s, a1 = s + 1.0f, a2 = s + 2.0f, a3 = s + 3.0f;
+#pragma unroll 16
+    for (int k = 0; k < EXTRA_VALU / 4; k++) {
+      asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(1.0001f));
+    }
+    s = a0 + a1 + a2 + a3;
+  }
+#endif
   float *o = out + (size_t)b * ostride;
 #ifdef NT_STORE
   for (int m = lane; m < nout; m += 64) __builtin_nontemporal_store(s + m, o + m);
