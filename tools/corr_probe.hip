@@ -45,6 +45,38 @@ __global__ __launch_bounds__(PROBE_WG) void k_probe(const cx *__restrict__ sampl
     for (int i = 0; i < g; i++) __builtin_amdgcn_s_sleep(PROBE_STAGGER);
   }
 #endif
+#ifdef PROBE_PIPE
+  // experiment: PROBE_PIPE items per workgroup in sequence, the next item's loads issued before the current item's
+  // arithmetic (a software pipeline), so that one generation of workgroups covers the whole batch
+  {
+    CorrIn<SPS> cur;
+    corr_issue<SPS>(cur, (blockIdx.x * PROBE_PIPE + 0) * (PROBE_WG / 16) + slot, B, r, samples, offset, length);
+    if (STAMPS) { st[1] = wall_clock64(); st[2] = st[1]; }
+#pragma unroll 1
+    for (int k = 0; k < PROBE_PIPE; k++) {
+      CorrIn<SPS> nxt;
+      const int kn = k + 1 < PROBE_PIPE ? k + 1 : k;         // (the last iteration re-loads its own item: in range, unused)
+      corr_issue<SPS>(nxt, (blockIdx.x * PROBE_PIPE + kn) * (PROBE_WG / 16) + slot, B, r, samples, offset, length);
+      __builtin_amdgcn_sched_barrier(0);
+      int M;
+      float energy;
+      corr_round<SPS, true, true, TAPCLS>(cur, rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+    if (STAMPS) {
+      st[3] = wall_clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      st[4] = wall_clock64();
+      st[5] = 0;
+      if (lane == 0) {
+        unsigned long long *d = dbg + (size_t)(blockIdx.x * (PROBE_WG / 64) + wave) * NST;
+        for (int k = 0; k < NST; k++) d[k] = st[k];
+      }
+    }
+    return;
+  }
+#endif
   CorrIn<SPS> in[PROBE_ROUNDS];
 #pragma unroll
   for (int i = 0; i < PROBE_ROUNDS; i++)
@@ -97,12 +129,20 @@ int main(int argc, char **argv) {
   for (auto &v : x) { s = s * 1664525u + 1013904223u; v.r = (float)((int)(s >> 9) % 2001 - 1000); s = s * 1664525u + 1013904223u; v.i = (float)((int)(s >> 9) % 2001 - 1000); }
   cx *dx, *drec; int32_t *doff, *dlen; unsigned long long *ddbg;
   const int Bpad = B, NS1 = CorrGeom<SPS>::NS + 1;
+#ifdef PROBE_PIPE
+  const int nwaves = B / 4 / PROBE_PIPE;
+#else
   const int nwaves = B / 4;
+#endif
   CK(hipMalloc(&dx, tot * sizeof(cx))); CK(hipMalloc(&drec, (size_t)NS1 * Bpad * sizeof(cx)));
   CK(hipMalloc(&doff, B * 4)); CK(hipMalloc(&dlen, B * 4)); CK(hipMalloc(&ddbg, (size_t)nwaves * NST * 8));
   CK(hipMemcpy(dx, x.data(), tot * sizeof(cx), hipMemcpyHostToDevice));
   CK(hipMemcpy(doff, off.data(), B * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dlen, len.data(), B * 4, hipMemcpyHostToDevice));
+#ifdef PROBE_PIPE
+  const dim3 grid(B / ((PROBE_WG / 16) * PROBE_PIPE)), block(PROBE_WG);
+#else
   const dim3 grid(B / ((PROBE_WG / 16) * PROBE_ROUNDS)), block(PROBE_WG);
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < K; i++) k_probe<TapPattern<SPS>::value, false><<<grid, block>>>(dx, doff, dlen, B, ta, drec, Bpad, ddbg);
   CK(hipDeviceSynchronize());
