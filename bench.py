@@ -2,7 +2,9 @@
 """bench.py -- Mbursts/s of the burst detect+demod hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1 without WORLD_SIZE in the environment: this process never touches the GPU; it starts the N ranks itself
+  (a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py`)
+  and exits with the child's code.  Under torchrun (WORLD_SIZE set) it is one of the ranks.
 
 Workload (config.workload): BASELINE config 2 -- 65,536 normal bursts per GPU, 156.25 symbols at
 4 samples/symbol (628/624/624/624 complex float32 samples), one training sequence per batch,
@@ -101,6 +103,65 @@ def cpu_baseline(x_host, off, length, sps, tsc, target_seconds=8.0):
     return ref, port
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as a child
+    torch.distributed.run (one process per GPU, as TRXManager runs one transceiver per ARFCN,
+    TRXManager/TRXManager.cpp:44-54) and exit with its code.  The parent makes no HIP call (counting devices
+    does not initialise the GPU) and never re-execs."""
+    import subprocess
+    if not args.selftest_cpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible -- refusing to run a smaller job under "
+                             "that label\n" % (args.gpus, have))
+            sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def selftest_cpu(args):
+    """The launch path without a GPU (tests/test_bench_spawn.py, gloo): rendezvous, rank 0 builds the table
+    blob, broadcast + checksum on every rank, MAX all-reduce, all-gather of the ranks, one JSON line from
+    rank 0.  No burst is processed and no throughput is reported (`value` null)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import _pkg
+    pkg = _pkg.load()
+    from openbts_ttsou_amd import dist as tdist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    if world > 1:
+        rank, world = tdist.init_from_env("gloo")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    blob, _ = tdist.broadcast_tables(pkg, SPS, device=None, src=0)
+    lo, hi = tdist.shard_range(args.bursts * world, rank, world)
+    tmax = tdist.max_over_ranks(1.0 + rank)
+    seen = tdist.ranks_seen(rank, None)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "value": None, "n_gpus": world, "ranks_seen": seen, "tmax": tmax,
+                          "tables_fnv": int(np.frombuffer(blob.tobytes()[-8:], np.uint64)[0]) if len(blob) >= 8 else 0,
+                          "shard0": [lo, hi]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +182,15 @@ def main():
                     help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
     ap.add_argument("--no-fresh", action="store_true", help="skip the rotating-inputs side measurement")
     ap.add_argument("--generic-taps", action="store_true", help="A/B: correlators without the tap-class specialisation")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="exercise the N-rank launch path on the CPU (gloo): rendezvous, table broadcast, reductions; "
+                         "no bursts are processed and no number is reported")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, sys.argv[1:])                     # does not return
+    if args.selftest_cpu:
+        return selftest_cpu(args)
 
     import numpy as np
     import torch
@@ -138,7 +207,10 @@ def main():
     else:
         rank, local = 0, 0
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d -- refusing to report one under the other's label\n"
+                         % (args.gpus, world))
+        sys.exit(2)
     dev = torch.device("cuda", local)
 
     # constant tables: built once on rank 0, broadcast over RCCL (xGMI), validated, then each rank's
@@ -202,6 +274,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = tdist.max_over_ranks(elapsed, dev)
+    seen = tdist.ranks_seen(rank, dev)
     # ---- per-kernel durations: the same K steps again with every launch bracketed by HIP events
     #      (kept out of the timed region: the extra event records stretch the gaps between kernels)
     ctx.profile_enable(True)
@@ -262,7 +335,7 @@ def main():
                 "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}}
     out = {
         "metric": "Mbursts/s (156.25-sym @ 4 sps) demod+detect", "value": round(value, 3), "unit": "Mbursts/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("config3: %d access bursts/GPU, sps=4, detectRACHBurst over all lags (thr 5.0) + demod "
                                 "to %d soft bits" % (B, NSOFT)) if rach else

@@ -56,3 +56,15 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def ranks_seen(rank, device=None):
+    """All-gather of the rank ids that took part (bench.py reports it next to n_gpus)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [int(rank)]
+    t = torch.tensor([rank], dtype=torch.int64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return sorted(int(o.item()) for o in out)
