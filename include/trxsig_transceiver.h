@@ -61,7 +61,10 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
 /* driveReceiveFIFO's serialisation (:655-674): 158 bytes */
 int trxsig_trx_encode_rx_datagram(int tn, int fn, int rssi, int timing_offset, const float *soft, int n_soft,
                                   uint8_t out[TRXSIG_RX_DATAGRAM_BYTES]);
-/* driveTransmitPriorityQueue's parse (:585-632): 154 bytes in; bits as they arrive (one per byte) */
+/* driveTransmitPriorityQueue's parse (:585-632): 154 bytes in; bits as they arrive (one per byte).
+ * Deviation: a frame number outside [0, gHyperframe = 2048*26*51) is rejected (TRXSIG_EINVAL) -- the reference
+ * accepts any 32-bit value and later indexes its filler table with it.  The entry points below that take (fn, tn)
+ * reject such an fn the same way. */
 int trxsig_trx_decode_tx_datagram(const uint8_t *in, int len, int *tn, int *fn, int *rssi, uint8_t bits[148]);
 
 /* addRadioVector (:100-113): modulate, scale, queue */

@@ -241,7 +241,8 @@ int trxsig_trx_control(trxsig_trx *t, const char *buffer, char *response_out, in
 
 int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n, int tn, int fn, float *h_soft,
                                  int *n_soft, int *rssi_out, int *toa_out) {
-  if (!t || !h_burst || !h_soft || !n_soft || !rssi_out || !toa_out || tn < 0 || tn > 7 || n <= 0 || n > 157 * t->sps)
+  if (!t || !h_burst || !h_soft || !n_soft || !rssi_out || !toa_out || tn < 0 || tn > 7 || n <= 0 || n > 157 * t->sps ||
+      fn < 0 || fn >= kHyperframe)
     return fail(t, TRXSIG_EINVAL, "trxsig_trx_pull_radio_vector: bad argument");
   const Time now{fn, tn};
   const int corrType = expected_corr_type(t, tn, fn);
@@ -384,6 +385,10 @@ int trxsig_trx_decode_tx_datagram(const uint8_t *in, int len, int *tn, int *fn, 
   *tn = (int)(signed char)in[0];
   unsigned long long frameNum = 0;
   for (int i = 0; i < 4; i++) frameNum = (frameNum << 8) | (0x0ff & in[i + 1]);
+  // A frame number lives in [0, gHyperframe) (GSM/GSMCommon.h:306).  The reference takes whatever 32-bit value the
+  // datagram holds (Transceiver.cpp:597-600) and would index its filler table with it; behind a UDP socket that is
+  // an out-of-bounds write, so a datagram with such a value is "badly formatted" here.
+  if (frameNum >= (unsigned long long)kHyperframe) return TRXSIG_EINVAL;
   *fn = (int)frameNum;
   *rssi = (int)(signed char)in[5];                          // (int) buffer[5], char buffer
   std::memcpy(bits, in + 6, 148);
@@ -391,7 +396,8 @@ int trxsig_trx_decode_tx_datagram(const uint8_t *in, int len, int *tn, int *fn, 
 }
 
 int trxsig_trx_add_radio_vector(trxsig_trx *t, const uint8_t *bits, int RSSI, int tn, int fn) {
-  if (!t || !bits || tn < 0 || tn > 7) return fail(t, TRXSIG_EINVAL, "trxsig_trx_add_radio_vector: bad argument");
+  if (!t || !bits || tn < 0 || tn > 7 || fn < 0 || fn >= kHyperframe)
+    return fail(t, TRXSIG_EINVAL, "trxsig_trx_add_radio_vector: bad argument (tn 0..7, fn 0..gHyperframe-1)");
   // scaleVector(*modBurst, pow(10,-RSSI/10)): integer division, double pow, complex(float) scale (:108)
   const float gain = (float)std::pow(10, -RSSI / 10);
   Queued q;
@@ -406,7 +412,8 @@ int trxsig_trx_add_radio_vector(trxsig_trx *t, const uint8_t *bits, int RSSI, in
 }
 
 int trxsig_trx_push_radio_vector(trxsig_trx *t, int tn, int fn, trxsig_c32 *h_out, int *n_out, int *from_queue) {
-  if (!t || !h_out || !n_out || tn < 0 || tn > 7) return fail(t, TRXSIG_EINVAL, "trxsig_trx_push_radio_vector: bad argument");
+  if (!t || !h_out || !n_out || tn < 0 || tn > 7 || fn < 0 || fn >= kHyperframe)
+    return fail(t, TRXSIG_EINVAL, "trxsig_trx_push_radio_vector: bad argument (tn 0..7, fn 0..gHyperframe-1)");
   const Time now{fn, tn};
   // dump stale bursts into the filler table (:142-153)
   while (!t->queue.empty() && time_less(t->queue.front().time, now)) {

@@ -119,6 +119,16 @@ def test_transmit_queue_filler_and_codecs(pkg, golden):
     # a later frame with the same FN modulus replays what was stored in the filler table
     a, _ = h.push_radio_vector(1, 30 + 26 * 5); b, _ = m.push_radio_vector(1, 30 + 26 * 5)
     assert np.array_equal(a, b)
+    # a frame number outside [0, gHyperframe) never reaches the queue or the filler table
+    import pytest
+    bits = np.zeros(148, np.uint8)
+    for bad in (-1, -(2 ** 31), tm.HYPERFRAME):
+        with pytest.raises(pkg.TrxSigError):
+            h.add_radio_vector(bits, 0, 1, bad)
+        with pytest.raises(pkg.TrxSigError):
+            h.push_radio_vector(1, bad)
+    assert h.queue_size() == 0
+    assert h.decode_tx_datagram(bytes([1]) + b"\xff\xff\xff\xff" + bytes(149)) is None
     # createLPF normalisation (a21)
     g = golden("resample.npz")
     assert np.array_equal(h.create_lpf(g["rcvLPF_651_raw"], 96.0), g["lpf651_gain96"])

@@ -33,3 +33,20 @@ def test_schedule_table_and_datagrams():
     assert d[8] == 0 and d[8 + 147] == 255 and d[156:] == b"\x00\x00"
     tx = bytes([3]) + (123456).to_bytes(4, "big") + bytes([0xF6]) + bytes([1, 0] * 74)
     assert m.decode_tx_datagram(tx)[:3] == (3, 123456, -10)
+
+
+def test_tx_datagram_with_out_of_range_frame_number_is_rejected():
+    """A frame number >= gHyperframe (e.g. bytes FF FF FF FF, which an int would read as negative) must not reach the
+    filler table: the C-ABI codec calls it badly formatted.  No GPU needed: the codec is a pure host function."""
+    import ctypes as C
+    import _pkg
+    L = _pkg.load().lib()
+    L.trxsig_trx_decode_tx_datagram.argtypes = [C.c_char_p, C.c_int] + [C.POINTER(C.c_int)] * 3 + [C.c_char_p]
+    tn, fn, rssi = C.c_int(), C.c_int(), C.c_int()
+    bits = C.create_string_buffer(148)
+    ok = bytes([3]) + (tm.HYPERFRAME - 1).to_bytes(4, "big") + bytes([0xF6]) + bytes([1, 0] * 74)
+    assert L.trxsig_trx_decode_tx_datagram(ok, len(ok), C.byref(tn), C.byref(fn), C.byref(rssi), bits) == 0
+    assert (tn.value, fn.value, rssi.value) == (3, tm.HYPERFRAME - 1, -10)
+    for bad_fn in (b"\xff\xff\xff\xff", b"\x80\x00\x00\x00", tm.HYPERFRAME.to_bytes(4, "big")):
+        bad = bytes([3]) + bad_fn + bytes([0xF6]) + bytes([1, 0] * 74)
+        assert L.trxsig_trx_decode_tx_datagram(bad, len(bad), C.byref(tn), C.byref(fn), C.byref(rssi), bits) != 0
