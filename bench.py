@@ -39,7 +39,7 @@ KERNEL_ALG_BYTES = {
     "k_tsc_corr": 8 * 36 * SPS + 8 * 20 * SPS + 8 * 44,     # window + energy window read, record write
     "k_tsc_peak": 8 * 44 + 13 + 4,                          # record read, flags/amp/toa/avgpwr write
     "k_demod": ALG_READ + 13 + 4 * NSOFT,                   # whole burst + amp/toa/flags read, soft write
-    "k_normal_fused": ALG_BYTES,
+    "k_normal_fused": ALG_BYTES, "k_normal_chain": ALG_BYTES,
 }
 
 
@@ -176,7 +176,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--workload", choices=["normal", "rach"], default="normal",
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3 (side measurement)")
-    ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--chain-lag", type=int, default=None, help="A/B: path 5, tiles between detect and demodulate workgroups")
+    ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3, 4, 5],
                     help="A/B: normal-burst implementation (trxsig_set_tuning); default = the library's")
     ap.add_argument("--spec-peak", type=int, default=0, choices=[0, 1, 2],
                     help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
@@ -223,6 +224,8 @@ def main():
     ctx.use_torch_stream()
     if args.path is not None:
         ctx.set_tuning(normal_path=args.path)
+    if args.chain_lag is not None:
+        ctx.set_tuning(chain_lag=args.chain_lag)
     if args.generic_taps:
         ctx.set_tuning(generic_taps=1)
     if args.spec_peak:

@@ -320,7 +320,8 @@ int trxsig_timer_start(trxsig_ctx *ctx);
 int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
 enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_K_RACH_CORR = 3,
        TRXSIG_K_RACH_PEAK = 4, TRXSIG_K_MODULATE = 5, TRXSIG_K_RESAMPLE = 6, TRXSIG_K_EQUALIZE = 7,
-       TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_FEC = 10, TRXSIG_K_COUNT = 11 };
+       TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_FEC = 10, TRXSIG_K_NORMAL_CHAIN = 11,
+       TRXSIG_K_COUNT = 12 };
 const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);
@@ -329,7 +330,13 @@ int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int 
  *     0 = three kernels: correlate, peak, demodulate (the default and the fastest measured);
  *     1 = one fused kernel, a wave per burst;   2 = fused, two bursts per wave;
  *     3 = fused, four bursts per wave (k_normal_quad);   4 = k_normal_quad's detection half, then k_demod.
- *     The fused kernels need nsoft <= 148; otherwise the call takes path 0.
+ *     5 = ONE launch whose detect workgroups hand over to its demodulate workgroups (k_normal_chain,
+ *     trxsig_chain.hip).
+ *     The fused kernels and the chain need nsoft <= 148 (the chain also nsoft > 0); otherwise the call takes path 0.
+ *   TRXSIG_TUNE_CHAIN_LAG: path 5, tiles of 16 bursts (per stream of every 8th tile) between a tile's detect
+ *     workgroup and its demodulate workgroups in launch order.  TRXSIG_TUNE_CHAIN_SPIN: polls before a demodulate
+ *     wave gives up waiting for its burst's detection (then the call is reported as failed at the library's next
+ *     entry and path 0 is used from there on; 0 makes every wait that is not satisfied at once fail -- tests).
  *   TRXSIG_TUNE_RACH_PATH (initial value: env TRXSIG_RACH_VARIANT, else 2): 0 = exact correlation at every
  *     lag (k_rach_corr + k_rach_peak), 1 = approximate-then-exact in one kernel, a wave per burst (k_rach_fast),
  *     2 = the same with peakDetect's bisection and the tail in their own kernel, two lanes per burst
@@ -342,7 +349,8 @@ int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int 
  *     1 = eight lanes per burst with the bisection speculated two levels at a time (k_tsc_peak8; 25 us per
  *     64 K bursts, LDS bandwidth), 2 = a lane per burst, the reference's serial loop (k_tsc_peak; 18 us,
  *     k_tsc_peak2 15 us).  All three are bit-identical. */
-enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3 };
+enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3,
+       TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes);

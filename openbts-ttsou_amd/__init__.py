@@ -310,8 +310,13 @@ class TrxSig:
     def pack_int16(self, x, n, iq):
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
-    def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None):
+    def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None, chain_lag=None,
+                   chain_spin=None):
         """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
+        if chain_lag is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 4, int(chain_lag)), "trxsig_set_tuning")
+        if chain_spin is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 5, int(chain_spin)), "trxsig_set_tuning")
         if spec_peak is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 3, int(spec_peak)), "trxsig_set_tuning")
         if generic_taps is not None:
@@ -326,7 +331,7 @@ class TrxSig:
 
     def profile_collect(self):
         """{kernel name: (total_ms, launches)} since the last collect (synchronises)."""
-        n = 11                                   # TRXSIG_K_COUNT
+        n = 12                                   # TRXSIG_K_COUNT
         ms = (C.c_float * n)(); cnt = (C.c_int * n)()
         self._chk(self.L.trxsig_profile_collect(self.h, ms, cnt), "trxsig_profile_collect")
         return {self.L.trxsig_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}

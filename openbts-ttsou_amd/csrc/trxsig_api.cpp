@@ -73,6 +73,16 @@ struct trxsig_ctx {
   int variant = 0;                   // normal-burst path (TRXSIG_TUNE_NORMAL_PATH / env TRXSIG_TSC_VARIANT)
   int spec_peak = 0;                 // peak kernel of path 0: 0 = k_tsc_peak2 (2 lanes per burst), 1 = k_tsc_peak8 (8, speculated), 2 = k_tsc_peak (1)
   int generic_taps = 0;              // 1: correlators without the tap-class specialisation (TRXSIG_TUNE_GENERIC_TAPS)
+  // single-launch chain (trxsig_chain.hip): per-burst hand-over granules (all tags clear between launches) and a
+  // host-visible word that a demodulator raises when its bounded wait runs out
+  int det_cap = 0;
+  void *d_det = nullptr;
+  unsigned *h_chain_status = nullptr; // pinned, mapped
+  unsigned *d_chain_status = nullptr; // the same word as the device sees it
+  int chain_lag = 48;                 // tiles (per stream) between a tile's detect and demodulate workgroups
+  unsigned chain_spin = 200000;       // polls (x ~0.25 us) before a demodulator gives up
+  int chain_dbg = 0;                  // timing experiments (env TRXSIG_CHAIN_DBG): 1 = no detect role, 2 = no demodulate role
+  bool chain_broken = false;          // a wait ran out once: three launches from then on
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint8_t *d_tsc = nullptr;          // 8 x 26 training-sequence bits (XCCH encoder), uploaded on first use
   std::string err;
@@ -121,6 +131,7 @@ int check_device(int device, std::string &why) {
 int finish_create(trxsig_ctx *c) {
   if (const char *v = std::getenv("TRXSIG_TSC_VARIANT")) c->variant = std::atoi(v);
   if (const char *v = std::getenv("TRXSIG_RACH_VARIANT")) c->rach_variant = std::atoi(v);
+  if (const char *v = std::getenv("TRXSIG_CHAIN_DBG")) c->chain_dbg = std::atoi(v);
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   return TRXSIG_OK;
@@ -136,6 +147,34 @@ int ensure_ws(trxsig_ctx *c, int B) {
   HIPCHK(c, hipMalloc((void **)&c->d_rec, per_burst * cap));
   c->cap_bursts = cap;
   return TRXSIG_OK;
+}
+
+int ensure_chain(trxsig_ctx *c, int B) {
+  if (!c->h_chain_status) {
+    HIPCHK(c, hipHostMalloc((void **)&c->h_chain_status, 64, hipHostMallocMapped));
+    *c->h_chain_status = 0;
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_chain_status, c->h_chain_status, 0));
+  }
+  if (B <= c->det_cap) return TRXSIG_OK;
+  const int cap = (B + 255) & ~255;
+  if (c->d_det) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_det)); c->d_det = nullptr; c->det_cap = 0; }
+  HIPCHK(c, hipMalloc(&c->d_det, trx_chain_ws_bytes(cap)));
+  HIPCHK(c, hipMemsetAsync(c->d_det, 0, trx_chain_ws_bytes(cap), c->stream));
+  c->det_cap = cap;
+  return TRXSIG_OK;
+}
+
+// a demodulator of an earlier chain launch gave up its wait (never observed; HIP does not promise the dispatch
+// order the chain relies on for progress): that call's soft bits are incomplete.  Report it once, clear the
+// hand-over words, and use the three-launch path from here on.
+int chain_check(trxsig_ctx *c) {
+  if (!c->h_chain_status || !*c->h_chain_status) return TRXSIG_OK;
+  (void)hipStreamSynchronize(c->stream);
+  *c->h_chain_status = 0;
+  c->chain_broken = true;
+  if (c->d_det) (void)hipMemsetAsync(c->d_det, 0, trx_chain_ws_bytes(c->det_cap), c->stream);
+  return fail(c, TRXSIG_EHIP, "an earlier trxsig_detect_demod_normal_batch (single-launch path) timed out waiting for its "
+                              "detect workgroups; its soft bits are incomplete.  Falling back to the three-launch path");
 }
 
 int ensure_stage(trxsig_ctx *c, size_t bytes) {
@@ -225,6 +264,8 @@ void trxsig_destroy(trxsig_ctx *c) {
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_eq) (void)hipFree(c->d_eq);
+    if (c->d_det) (void)hipFree(c->d_det);
+    if (c->h_chain_status) (void)hipHostFree(c->h_chain_status);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tsc) (void)hipFree(c->d_tsc);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -243,7 +284,7 @@ int trxsig_get_device(trxsig_ctx *c) { return c ? c->device : -1; }
 int trxsig_synchronize(trxsig_ctx *c) {
   if (!c) return TRXSIG_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return TRXSIG_OK;
+  return chain_check(c);
 }
 const char *trxsig_last_error(const trxsig_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
@@ -296,7 +337,19 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
     return fail(c, TRXSIG_EINVAL, "trxsig_detect_demod_normal_batch: bad argument");
   if (B == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
-  int rc = ensure_ws(c, B);
+  int rc = chain_check(c);
+  if (rc != TRXSIG_OK) return rc;
+  if (c->variant == 5 && !c->chain_broken && nsoft > 0 && nsoft <= 148) {
+    // one launch: detect workgroups hand over to demodulate workgroups inside it (trxsig_chain.hip)
+    rc = ensure_chain(c, B);
+    if (rc != TRXSIG_OK) return rc;
+    HIPCHK(c, trx_launch_normal_chain(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset,
+                                      d_length, B, tsc, detect_thresh, energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa,
+                                      d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->d_det, c->d_chain_status,
+                                      c->chain_lag, c->chain_spin, c->generic_taps, c->prof, c->chain_dbg));
+    return TRXSIG_OK;
+  }
+  rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
   if (c->variant == 4) {
     // detection (correlation + speculative bisection, four bursts per wave) in one kernel, then k_demod
@@ -818,7 +871,8 @@ int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
 
 const char *trxsig_kernel_name(int id) {
   static const char *names[TRXSIG_K_COUNT] = { "k_tsc_corr", "k_tsc_peak", "k_demod", "k_rach_corr", "k_rach_peak",
-                                               "k_modulate", "k_resample", "k_equalize", "k_convert", "k_normal_fused", "k_fec_viterbi" };
+                                               "k_modulate", "k_resample", "k_equalize", "k_convert", "k_normal_fused", "k_fec_viterbi",
+                                               "k_normal_chain" };
   return (id >= 0 && id < TRXSIG_K_COUNT) ? names[id] : "?";
 }
 int trxsig_fec_xcch_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_blocks, int wire,
@@ -885,7 +939,10 @@ int trxsig_fec_viterbi_batch(trxsig_ctx *c, const float *d_soft, int n_soft, int
 
 int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (!c) return TRXSIG_EINVAL;
-  if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 4) { c->variant = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 5) { c->variant = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_CHAIN_LAG && value >= 1) { c->chain_lag = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_CHAIN_SPIN && value >= 0) { c->chain_spin = (unsigned)value; return TRXSIG_OK; }
+  if (key == 6 && value >= 0 && value <= 3) { c->chain_dbg = value; return TRXSIG_OK; }   // timing experiments (tools/chain_roles.py)
   if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 2) { c->rach_variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_GENERIC_TAPS && value >= 0 && value <= 1) { c->generic_taps = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 2) { c->spec_peak = value; return TRXSIG_OK; }

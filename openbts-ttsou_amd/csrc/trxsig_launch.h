@@ -33,6 +33,15 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
                                    float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
                                    int generic_taps /* 1: no tap-class specialisation */, TrxProfiler *prof);
 
+// the whole normal-burst leg in ONE launch with an in-launch hand-over (trxsig_chain.hip); nsoft 1..148; det: 16 bytes
+// per burst, tag words clear on entry (left clear on exit); status: host-visible word raised when a wait runs out
+size_t trx_chain_ws_bytes(int bursts);
+hipError_t trx_launch_normal_chain(hipStream_t st, int sps, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
+                                   const int32_t *off, const int32_t *len, int B, int tsc, float detect_thresh,
+                                   float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, float *soft,
+                                   uint8_t *hard, int nsoft, int stride, void *det, unsigned *status, int lag,
+                                   unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg = 0);
+
 // RACH detect: ws = workspace of trx_rach_rec_floats(sps) * Bpad floats
 int trx_rach_rec_floats(int sps);
 hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,

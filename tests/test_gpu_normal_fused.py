@@ -13,7 +13,7 @@ from util import GpuBatch, assert_veq
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [1, 2, 3, 4]    # 1: a wave per burst, 2: two bursts per wave, 3: four bursts per wave (k_normal_quad), 4: k_normal_quad detection + k_demod
+PATHS = [1, 2, 3, 4, 5]    # 5: k_normal_chain (one launch, in-launch hand-over); 1: a wave per burst, 2: two bursts per wave, 3: four bursts per wave (k_normal_quad), 4: k_normal_quad detection + k_demod
 
 
 @pytest.fixture(scope="module")
@@ -164,7 +164,7 @@ def test_ragged_and_bad_bursts(pkg, ctxs, path):
     ctxs[path, sps].detect_demod_normal(gb.x, gb.off[:0], gb.len[:0], 3, gb.flags, gb.amp, gb.toa, gb.soft)
 
 
-@pytest.mark.parametrize("path", [0, 3])
+@pytest.mark.parametrize("path", [0, 3, 5])
 @pytest.mark.parametrize("sps", [1, 2, 4])
 def test_tap_class_specialisation_is_invisible(pkg, sps, path):
     """The correlators' exact-product FMA form (taps with a component of exactly +-1) against the generic
