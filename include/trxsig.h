@@ -354,6 +354,12 @@ enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENER
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes);
+/* The error bar of the access-burst detector's approximate correlation pass for this table blob (host computation,
+ * no GPU): *bound x sqrt(sum |x[n]|^2 over the burst) bounds |approximate - reference| correlation amplitude at any
+ * lag (derivation: csrc/trxsig_rach.hip); *seq_norm (optional) = the 2-norm of the RACH sequence, for scale.  The
+ * detector only uses the approximate values to decide what to recompute with the reference's arithmetic
+ * (detectRACHBurst, Transceiver/sigProcLib.cpp:860-914), so the bound affects speed, never results. */
+int trxsig_tables_rach_error_bound(const void *h_blob, size_t bytes, float *bound, float *seq_norm);
 
 #ifdef __cplusplus
 }

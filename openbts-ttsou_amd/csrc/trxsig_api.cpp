@@ -81,6 +81,7 @@ struct trxsig_ctx {
   unsigned *d_chain_status = nullptr; // the same word as the device sees it
   int chain_lag = 48;                 // tiles (per stream) between a tile's detect and demodulate workgroups
   unsigned chain_spin = 200000;       // polls (x ~0.25 us) before a demodulator gives up
+  float rach_amp_err = 0.0f;          // trx_rach_amp_err(h_tables): error bar of k_rach_*'s approximate correlation
   int chain_dbg = 0;                  // timing experiments (env TRXSIG_CHAIN_DBG): 1 = no detect role, 2 = no demodulate role
   bool chain_broken = false;          // a wait ran out once: three launches from then on
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -132,6 +133,7 @@ int finish_create(trxsig_ctx *c) {
   if (const char *v = std::getenv("TRXSIG_TSC_VARIANT")) c->variant = std::atoi(v);
   if (const char *v = std::getenv("TRXSIG_RACH_VARIANT")) c->rach_variant = std::atoi(v);
   if (const char *v = std::getenv("TRXSIG_CHAIN_DBG")) c->chain_dbg = std::atoi(v);
+  c->rach_amp_err = trx_rach_amp_err(c->h_tables);
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
   return TRXSIG_OK;
@@ -394,7 +396,7 @@ int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, c
   if (rc != TRXSIG_OK) return rc;
   if (c->rach_variant >= 1)
     HIPCHK(c, trx_launch_rach_fast(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
-                                   detect_thresh, energy_thresh, (float *)c->d_rec, c->cap_bursts, c->rach_variant == 2,
+                                   detect_thresh, energy_thresh, c->rach_amp_err, (float *)c->d_rec, c->cap_bursts, c->rach_variant == 2,
                                    d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   else
     HIPCHK(c, trx_launch_rach_detect(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length,
@@ -966,6 +968,18 @@ int trxsig_profile_collect(trxsig_ctx *c, float total_ms[TRXSIG_K_COUNT], int la
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes) {
   if (!h_blob || bytes != sizeof(TrxTables)) return TRXSIG_EINVAL;
   return trx_tables_valid((const TrxTables *)h_blob) ? TRXSIG_OK : TRXSIG_EINVAL;
+}
+
+int trxsig_tables_rach_error_bound(const void *h_blob, size_t bytes, float *bound, float *seq_norm) {
+  if (!h_blob || bytes != sizeof(TrxTables) || !bound || !trx_tables_valid((const TrxTables *)h_blob)) return TRXSIG_EINVAL;
+  const TrxTables *T = (const TrxTables *)h_blob;
+  *bound = trx_rach_amp_err(T);
+  if (seq_norm) {
+    double n2 = 0.0;
+    for (int m = 0; m < 41 * (int)T->sps; m++) n2 += (double)T->rach[m].r * T->rach[m].r + (double)T->rach[m].i * T->rach[m].i;
+    *seq_norm = (float)std::sqrt(n2);
+  }
+  return TRXSIG_OK;
 }
 
 }  // extern "C"

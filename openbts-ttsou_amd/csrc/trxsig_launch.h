@@ -49,10 +49,13 @@ hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, 
                                   float energy_thresh, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp,
                                   float *toa, float *avgpwr, TrxProfiler *prof);
 
+// bound on |approximate - reference| correlation amplitude per unit of sqrt(burst energy) (error model in trxsig_rach.hip)
+float trx_rach_amp_err(const TrxTables *hT);
 // same results, approximate-then-exact single kernel (k_rach_fast)
 hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                                 const int32_t *off, const int32_t *len, int B, float detect_thresh,
-                                float energy_thresh, float *ws /* trx_rach_rec_floats() floats per burst */, int Bpad,
+                                float energy_thresh, float amp_err /* trx_rach_amp_err(host tables) */,
+                                float *ws /* trx_rach_rec_floats() floats per burst */, int Bpad,
                                 int split /* 1: k_rach_front + k_rach_peak2 + hand-over, 0: k_rach_fast alone */,
                                 uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof);
 

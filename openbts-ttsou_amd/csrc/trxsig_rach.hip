@@ -298,17 +298,52 @@ __global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ 
 //     is the reference's argmax because no other lag can reach it.  If the exact argmax moved by more
 //     than one lag its neighbourhood is recomputed too.
 //  3. peakDetect's bisection runs on the exact neighbourhood (four lanes, quad_bisect).
-//  4. the valley RMS uses the approximate powers; if peak/RMS lands within 1e-3 (relative) of the
-//     threshold -- where a 1e-5 error could matter -- the valley lags are recomputed exactly and summed
-//     in the reference's order, so the detect decision is the reference's in every case.
+//  4. the valley RMS uses the approximate powers with an error bar (rach_decide below); only if the threshold falls
+//     inside the bar are the valley lags recomputed exactly and summed in the reference's order, so the detect
+//     decision is the reference's in every case, for any threshold.
+//
+// Error model (what RACH_DELTA alone and the old fixed 1e-3 guard did not cover: large thresholds, bursts whose
+// correlation maximum is small against their energy).  Let e[t] be the reference's float value of corr[t], a[t] the
+// approximate pass's.  In exact arithmetic a[t] = sum_m conj(bi[m]) x[t-F+m] with the IMPLIED sequence
+// bi[m] = sum_{sps k + j - sps = m} sym_k i^k p[j] (the edge terms remove m < 0 and m >= LB), while the reference
+// uses the table sequence b[m] (rotation table values instead of i^k, float roundings of modulateBurst).  Hence
+//   |a[t] - e[t]| <= |db|_2 |x|_2  +  (ga + ge) sum_m babs[m] |x[t-F+m]|  <=  (|db|_2 + 516 u |babs|_2) sqrt(Ex)  =: D
+// with db = b - bi, babs[m] = sum p[j] >= |b[m]|, |bi[m]| (|babs|_2 <= sqrt2 |b|_2: neighbouring symbols are in
+// quadrature), Ex = sum |x[n]|^2 over the burst, u = 2^-24; ge <= sqrt2 (164 + 2) u bounds the float error of the
+// reference's 164-term sequential sum (two rounded products and a rounded add per term and component), ga <=
+// sqrt2 (9 + 41 + 6) u that of the pulse filter (9 fused steps), the 41 additions and the edge terms; 516 u is more
+// than their sum.  trx_rach_amp_err() evaluates |db|_2 + 516 u |babs|_2 on the host in double from the uploaded
+// tables (so it follows the tables, whatever they are) and the kernels get it as an argument; D = that x sqrt(Ex).
+//   * contenders: lag t can hold the reference's maximum only if sqrt(pw[t]) >= sqrt(pmax) - 2 D (pw: approximate
+//     powers); the cut is the looser of that and RACH_DELTA.  When D is so large that the cut is void every lag
+//     contends and the burst takes the exact route.
+//   * valley: |sum_i pw[p+i] - sum_i |e[p+i]|^2| <= 2 D sqrt(cnt vs) + cnt D^2 (Cauchy-Schwarz), plus 3e-5 (vs + that)
+//     for the float summations on both sides (cnt <= 201 terms) and the rounding of each norm.  peak/RMS is a
+//     monotone function of the valley sum, also in float (division, sqrt, and the additions are monotone when
+//     correctly rounded), so the reference's value lies between the values at vs + E and vs - E: above the threshold
+//     at vs + E means detected, not above it at vs - E means not detected, anything else is recomputed exactly.
 // If more far-away candidates turn up than fit in one pass (flat noise, silence) the burst takes
 // the exact route for all lags.
 // ---------------------------------------------------------------------------------------------
 #ifndef TRX_RACH_EXACT_GROUP
 #define TRX_RACH_EXACT_GROUP 4   /* taps per software-pipeline stage of rach_exact_lag */
 #endif
-#define RACH_DELTA 4e-3f
-#define RACH_GUARD 1e-3f
+#define RACH_DELTA 4e-3f                                    // contenders: at least everything within 0.4 % of the approximate maximum
+
+// detectRACHBurst's decision (sigProcLib.cpp:901-903) from an approximate valley sum vs (cnt terms) whose lags'
+// amplitudes are each within dlt of the reference's: 1 = detected, 0 = not, -1 = cannot be told from vs (see above)
+__device__ __forceinline__ int rach_decide(float peak_abs, float vs, int cnt, float dlt, float thresh) {
+  const float fc = (float)cnt;
+  const float e1 = 2.0f * dlt * sqrtf(fc * vs) + fc * dlt * dlt;
+  const float e = (e1 + 3e-5f * (vs + e1)) * 1.001f;
+  if (!(vs == vs) || !(e == e) || !(vs >= 0.0f)) return -1;
+  const float vhi = vs + e, vlo = vs > e ? vs - e : 0.0f;
+  const float ptm_lo = peak_abs / (float)((double)sqrtf(vhi / fc) + 0.00001);   // :901-902 at the largest valley
+  const float ptm_hi = peak_abs / (float)((double)sqrtf(vlo / fc) + 0.00001);   // ... and at the smallest
+  if (ptm_lo > thresh) return 1;
+  if (!(ptm_hi > thresh)) return 0;
+  return -1;
+}
 struct RachSym {                                           // 2*bit-1 of gRACHSynchSequence (GSM/GSMCommon.cpp:57)
   static constexpr signed char v[41] = {
     -1, 1, -1, -1, 1, -1, 1, 1, -1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, 1, -1, -1, -1, 1, 1, 1, 1, -1,
@@ -430,7 +465,7 @@ __device__ __forceinline__ void rach_steer(const cx *Zl, const cx (&zc)[8], floa
 template <int SPS, bool SPLIT>
 __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                 const int32_t *__restrict__ offset, const int32_t *__restrict__ length,
-                                                float detect_thresh, float energy_thresh,
+                                                float detect_thresh, float energy_thresh, float amp_err,
                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                 float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
                                                 cx *__restrict__ rec, float *__restrict__ vsum, int Bpad) {
@@ -479,6 +514,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   cx *const nb_ = reinterpret_cast<cx *>(PW + 64 * R::NCL + 192);
   const cx *rseq = T->rach;
 
+  float ex = 0.0f;
   {                                                        // every load in flight before the first LDS store
     constexpr int NIT = (Q::XPAD + 63) / 64;
     cx xv[NIT];
@@ -492,7 +528,12 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       const int i = lane + 64 * it;
       if (i < Q::XPAD) X[i] = xv[it];
     }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) ex += norm2(xv[it]);  // burst energy (any order: it only scales an error bound)
   }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) ex += __shfl_xor(ex, m, 64);
+  const float dlt = amp_err * sqrtf(ex) * 1.001f;          // |approximate - reference| correlation amplitude, any lag
   float nrm[R::NEQ];
 #pragma unroll
   for (int q = 0; q < R::NEQ; q++) {
@@ -579,7 +620,12 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   TRX_STAMP();                                             // 3: approximate correlation + argmax done
   // ---- 2. exact recomputation of the contenders ----
   const int Ma = bestT;                                    // approximate argmax (-1: silence)
-  const float cut = bestP * (1.0f - RACH_DELTA);
+  float cut = bestP * (1.0f - RACH_DELTA);
+  {
+    const float ca = sqrtf(bestP) - 2.0f * dlt;            // a lag below this amplitude cannot hold the reference's maximum
+    const float cb = ca > 0.0f ? ca * ca * (1.0f - 1e-6f) : -1.0f;   // (void: every lag contends -> the exact route below)
+    cut = (cb < cut || !(dlt == dlt)) ? cb : cut;
+  }
   const int nb0 = Ma - 13;                                 // neighbourhood lags nb0 .. nb0+25
   int nfar = 0;
   int *LG = exl_;
@@ -670,7 +716,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       const float o0 = __shfl_xor(vs[0], m, 64), o1 = __shfl_xor(vs[1], m, 64), o2 = __shfl_xor(vs[2], m, 64);
       vs[0] += o0; vs[1] += o1; vs[2] += o2;
     }
-    if (lane < 3) vsum[(size_t)lane * Bpad + b] = lane == 0 ? vs[0] : (lane == 1 ? vs[1] : vs[2]);
+    if (lane < 4) vsum[(size_t)lane * Bpad + b] = lane == 0 ? vs[0] : (lane == 1 ? vs[1] : (lane == 2 ? vs[2] : dlt));
     TRX_STAMP();                                           // 5: record written
     TRX_STAMP_FLUSH();
     return;
@@ -698,10 +744,11 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       for (int i = i0 + lane; i <= last; i += 64) vs += PW[p + i];
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
-      float RMS = (float)((double)sqrtf(vs / (float)cnt) + 0.00001);
-      float peakToMean = sqrtf(norm2(peak)) / RMS;
-      if (fabsf(peakToMean - detect_thresh) <= RACH_GUARD * fabsf(detect_thresh) || !(vs == vs)) {
-        // too close to call from approximate powers: the reference's valley, exactly (:888-901)
+      const float peak_abs = sqrtf(norm2(peak));
+      const int dec = rach_decide(peak_abs, vs, cnt, dlt, detect_thresh);
+      detected = dec == 1;
+      if (dec < 0) {
+        // cannot be told from the approximate powers: the reference's valley, exactly (:888-901)
         float *VX = reinterpret_cast<float *>(exv_);
         float valley = 0.0f;
         for (int base = i0; base <= last; base += 64) {
@@ -717,12 +764,11 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
           }
         }
         valley = __shfl(valley, 0, 64);
-        RMS = (float)((double)sqrtf(valley / (float)cnt) + 0.00001);
-        peakToMean = sqrtf(norm2(peak)) / RMS;
+        const float RMS = (float)((double)sqrtf(valley / (float)cnt) + 0.00001);
+        detected = peak_abs / RMS > detect_thresh;
       }
       amp = cdiv(peak, T->rach_gain);                      // :905
       toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
-      detected = peakToMean > detect_thresh;
     }
   }
   if (lane == 0) {
@@ -744,13 +790,13 @@ template <int SPS>
 __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                    const int32_t *__restrict__ offset,
                                                    const int32_t *__restrict__ length, int B,
-                                                   float detect_thresh, float energy_thresh,
+                                                   float detect_thresh, float energy_thresh, float amp_err,
                                                    uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                    float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
                                                    const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
   const int n = list ? (*count < B ? *count : B) : B;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {        // (without a list: grid = B, one burst per workgroup)
-    rach_fast_burst<SPS, false>(list ? list[i] : i, T, samples, offset, length, detect_thresh, energy_thresh, flags, amp_out,
+    rach_fast_burst<SPS, false>(list ? list[i] : i, T, samples, offset, length, detect_thresh, energy_thresh, amp_err, flags, amp_out,
                                 toa_out, avgpwr_out, nullptr, nullptr, 0);
     wave_lds_fence();                                      // the next burst reuses the LDS
   }
@@ -760,20 +806,20 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
 template <int SPS>
 __global__ __launch_bounds__(64) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                     const int32_t *__restrict__ offset,
-                                                    const int32_t *__restrict__ length, int B, float energy_thresh,
+                                                    const int32_t *__restrict__ length, int B, float energy_thresh, float amp_err,
                                                     uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                     float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
                                                     cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
                                                     int32_t *__restrict__ count) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;     // k_rach_peak2's hand-over list starts empty
   if ((int)blockIdx.x < B)
-    rach_fast_burst<SPS, true>(blockIdx.x, T, samples, offset, length, 0.0f, energy_thresh, flags, amp_out, toa_out, avgpwr_out,
+    rach_fast_burst<SPS, true>(blockIdx.x, T, samples, offset, length, 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out, avgpwr_out,
                                rec, vsum, Bpad);
 }
 
 // steps 3-4 with TWO lanes per burst (pair_bisect): peakDetect's bisection on the exact neighbourhood and
-// detectRACHBurst's tail (:875-913) with the approximate valley.  A burst whose peak/RMS lands within RACH_GUARD of the
-// threshold goes on the hand-over list instead (k_rach_fast in list mode recomputes its valley exactly).
+// detectRACHBurst's tail (:875-913) with the approximate valley.  A burst whose threshold lies inside the valley's error
+// bar (rach_decide) goes on the hand-over list instead (k_rach_fast in list mode recomputes its valley exactly).
 template <int SPS>
 __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec,
                                                     const float *__restrict__ vsum, const int32_t *__restrict__ length,
@@ -803,6 +849,7 @@ __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict_
   float vs3[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) vs3[a] = vsum[(size_t)a * Bpad + bb];
+  const float dlt = vsum[(size_t)3 * Bpad + bb];
   sinc_lds_store<256>(stab, tid, tv);
   __syncthreads();                                         // the only barrier
 
@@ -821,12 +868,11 @@ __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict_
     const int cnt = last - i0 + 1;                         // numSamples
     if (cnt >= 2) {
       const float vs = a == 0 ? vs3[0] : (a == 1 ? vs3[1] : vs3[2]);
-      const float RMS = (float)((double)sqrtf(vs / (float)cnt) + 0.00001);
-      const float peakToMean = sqrtf(norm2(peak)) / RMS;
-      handover = fabsf(peakToMean - detect_thresh) <= RACH_GUARD * fabsf(detect_thresh) || !(vs == vs);
+      const int dec = rach_decide(sqrtf(norm2(peak)), vs, cnt, dlt, detect_thresh);
+      handover = dec < 0;
+      detected = dec == 1;
       amp = cdiv(peak, T->rach_gain);                      // :905
       toa = toa - T->rach_toa - (float)(8 * SPS);          // :907
-      detected = peakToMean > detect_thresh;
     }
   }
   if (live && h == 0 && M != RACH_SKIP) {
@@ -845,6 +891,27 @@ __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict_
 
 
 }  // namespace
+
+// |db|_2 + 516 u |babs|_2 of the error model above, from the host copy of the tables, in double
+float trx_rach_amp_err(const TrxTables *hT) {
+  const int sps = (int)hT->sps, LB = 41 * sps;
+  double db2 = 0.0, ba2 = 0.0;
+  for (int m = 0; m < LB; m++) {
+    double br = 0.0, bi = 0.0, ba = 0.0;                   // the implied sequence: sum over sps k + j - sps = m of sym_k i^k p[j]
+    for (int k = 0; k <= 40; k++) {
+      const int j = m + sps - sps * k;
+      if (j < 0 || j > 2 * sps) continue;
+      const double v = (double)RachSym::v[k] * (double)hT->pulse[j];
+      switch (k & 3) { case 0: br += v; break; case 1: bi += v; break; case 2: br -= v; break; default: bi -= v; }
+      ba += (double)hT->pulse[j] < 0 ? -(double)hT->pulse[j] : (double)hT->pulse[j];
+    }
+    const double dr = (double)hT->rach[m].r - br, di = (double)hT->rach[m].i - bi;
+    db2 += dr * dr + di * di;
+    ba2 += ba * ba;
+  }
+  const double u = 5.9604644775390625e-8;
+  return (float)((sqrt(db2) + 516.0 * u * sqrt(ba2)) * 1.0001);
+}
 
 int trx_rach_rec_floats(int sps) {            // floats per burst in the rach record (complex slots + valley)
   switch (sps) {
@@ -872,39 +939,40 @@ static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c3
 
 template <int S>
 static void launch_rach_fast(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off, const int32_t *len,
-                             int B, float detect_thresh, float energy_thresh, float *ws, int Bpad, int split, uint8_t *flags,
-                             trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof) {
+                             int B, float detect_thresh, float energy_thresh, float amp_err, float *ws, int Bpad, int split,
+                             uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, TrxProfiler *prof) {
   if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
   if (!split) {
-    k_rach_fast<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp, toa, avgpwr,
-                                                 nullptr, nullptr);
+    k_rach_fast<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, flags, amp, toa,
+                                                 avgpwr, nullptr, nullptr);
     if (prof) prof->end(TRXSIG_K_RACH_CORR, st);
     return;
   }
-  // workspace: 25 complex + 3 float record slots, the hand-over list and its counter (all [.][Bpad])
+  // workspace: 25 complex + 4 float record slots (three candidate valley sums, the amplitude error bar), the hand-over
+  // list and its counter (all [.][Bpad])
   trx_c32 *rec = (trx_c32 *)ws;
   float *vsum = ws + (size_t)2 * 25 * Bpad;
-  int32_t *list = (int32_t *)(vsum + (size_t)3 * Bpad);
+  int32_t *list = (int32_t *)(vsum + (size_t)4 * Bpad);
   int32_t *count = list + Bpad;
-  k_rach_front<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, energy_thresh, flags, amp, toa, avgpwr, rec, vsum, Bpad,
-                                                count);
+  k_rach_front<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum,
+                                                Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
   k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr,
                                                                list, count);
-  k_rach_fast<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, flags, amp,
-                                                               toa, avgpwr, list, count);
+  k_rach_fast<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, flags,
+                                                               amp, toa, avgpwr, list, count);
   if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
 }
 
 hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                                 const int32_t *off, const int32_t *len, int B, float detect_thresh,
-                                float energy_thresh, float *ws, int Bpad, int split, uint8_t *flags, trx_c32 *amp, float *toa,
-                                float *avgpwr, TrxProfiler *prof) {
+                                float energy_thresh, float amp_err, float *ws, int Bpad, int split, uint8_t *flags, trx_c32 *amp,
+                                float *toa, float *avgpwr, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   switch (sps) {
-    case 1: launch_rach_fast<1>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
-    case 2: launch_rach_fast<2>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
-    case 4: launch_rach_fast<4>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
+    case 1: launch_rach_fast<1>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
+    case 2: launch_rach_fast<2>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
+    case 4: launch_rach_fast<4>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

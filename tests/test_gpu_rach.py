@@ -113,3 +113,58 @@ def test_rach_variants_agree_with_oracle(pkg, variant, monkeypatch):
                                 energy_thresh=-1.0)
             want = o.detect_rach(x[off[i]:off[i] + length[i]], thresh=float(thr))["ok"]
             assert bool(gb1.results()["flags"][0] & pkg.F_DETECT) == want, (i, thr)
+
+
+def _wide_ptm_batch(sps, B, seed):
+    """Access bursts whose peak-to-valley ratio spans 1 .. >1000: the usual noise levels, plus bursts whose samples
+    after the synch sequence are attenuated (clean valley -> large ratio), noise-only, silent and constant bursts."""
+    x, off, length, meta = synth.rach_batch(sps, B, seed=seed, sigmas=(0.0, 0.02, 0.05, 0.1, 0.3, 1.0, 3.0), max_delay_sym=40)
+    rng = np.random.default_rng(seed + 1)
+    for i in range(0, B, 3):                         # quiet tail: everything from 10 symbols after the synch sequence on
+        d = int(meta["delay"][i])
+        k = d + (49 + 10) * sps
+        x[off[i] + k: off[i] + length[i]] *= np.float32(10.0 ** -rng.uniform(0.0, 3.5))
+    for i in range(1, B, 61):                        # noise only
+        x[off[i]:off[i] + length[i]] = (rng.standard_normal(length[i]) + 1j * rng.standard_normal(length[i])) * 40
+    for i in range(2, B, 127):
+        x[off[i]:off[i] + length[i]] = 0
+    for i in range(4, B, 127):                       # flat correlation: small maximum against a large energy
+        x[off[i]:off[i] + length[i]] = 100 + 50j
+    for i in range(6, B, 127):                       # a tone: ditto
+        n = np.arange(length[i]); x[off[i]:off[i] + length[i]] = (700 * np.exp(2j * np.pi * 0.013 * n)).astype(np.complex64)
+    return x, off, length, meta
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_detect_flag_over_thresholds(pkg, variant, monkeypatch):
+    """The approximate-then-exact routes decide from an approximate valley unless the threshold falls inside its error
+    bar (rach_decide, trxsig_rach.hip).  The bar grows with (peak/valley)^2, so sweep the threshold from 1 to 100 over
+    4096 bursts whose ratios cover that whole range: the flag must be the reference's for every burst and threshold
+    (amplitude and TOA do not depend on the threshold and must stay value-exact too)."""
+    monkeypatch.setenv("TRXSIG_RACH_VARIANT", variant)
+    sps, B = 4, 4096
+    t = pkg.TrxSig(sps, 0); t.use_torch_stream()
+    o = oraclebind.Oracle(sps)
+    x, off, length, meta = _wide_ptm_batch(sps, B, seed=31337)
+    gb = GpuBatch(x, off, length)
+    seen = set()
+    for thr in (1.0, 5.0, 13.0, 30.0, 100.0):
+        t.detect_demod_rach(gb.x, gb.off, gb.len, gb.flags, gb.amp, gb.toa, gb.soft, detect_thresh=thr, energy_thresh=-1.0)
+        r = gb.results()
+        ok, amp, toa, soft = o.rach_batch(x, off, length, thresh=thr, nthreads=16)
+        assert_veq((r["flags"] & pkg.F_DETECT) != 0, ok.astype(bool), "detect flags at threshold %g" % thr)
+        assert_veq(r["amp"], amp, "amp"); assert_veq(r["toa"], toa, "toa"); assert_veq(r["soft"], soft, "soft")
+        seen.add(int(ok.sum()))
+    assert len(seen) >= 4, "the batch does not spread over the thresholds: %r" % (seen,)
+    # thresholds placed ON bursts' own ratios (and one ulp either side), 96 bursts across the range
+    ptm = np.array([o.detect_rach(x[off[i]:off[i] + length[i]])["peak_to_mean"] for i in range(0, B, 8)], np.float32)
+    order = np.argsort(ptm)
+    pick = [8 * int(j) for j in order[np.linspace(0, len(order) - 1, 96).astype(int)] if ptm[j] > 0]
+    for i in pick:
+        p = np.float32(ptm[i // 8])
+        for thr in (p, np.nextafter(p, np.float32(0)), np.nextafter(p, np.float32(1e30))):
+            gb1 = GpuBatch(x[off[i]:off[i] + length[i]], [0], [length[i]])
+            t.detect_demod_rach(gb1.x, gb1.off, gb1.len, gb1.flags, gb1.amp, gb1.toa, gb1.soft, detect_thresh=float(thr),
+                                energy_thresh=-1.0)
+            want = o.detect_rach(x[off[i]:off[i] + length[i]], thresh=float(thr))["ok"]
+            assert bool(gb1.results()["flags"][0] & pkg.F_DETECT) == want, (i, float(thr))
