@@ -1,20 +1,27 @@
 // sigProcLib_trx.h -- source-compatible C++ facade over libtrxsig for code written against the
 // reference's Transceiver/sigProcLib.h (OpenBTS).  Header only; link with -ltrxsig.
 //
-// It re-creates the names a Transceiver / RadioInterface translation unit uses -- `complex`,
-// `signalVector`, `BitVector`, `SoftVector`, sigProcLibSetup, generateGSMPulse, modulateBurst,
-// generateMidamble, generateRACHSequence, energyDetect, analyzeTrafficBurst, detectRACHBurst,
-// demodulateBurst, scaleVector, designDFE, equalizeBurst, polyphaseResampleVector, createLPF (with setLPFTables) --
-// i.e. every sigProcLib function Transceiver.cpp and radioInterface.cpp call -- with the reference's argument meaning,
-// ownership (functions returning a pointer allocate with `new`, the caller deletes:
-// Transceiver.cpp:112,407,672) and error behaviour (NULL / false, amplitude set to 0 on a "bogus
-// result": sigProcLib.cpp:878-882, 964-968).  Every call that processes samples runs on the GPU
-// through the C-ABI's host-buffer entry points (one PCIe round trip per call); nothing here computes
-// on the CPU except scaleVector's element-wise complex multiply.  A real deployment batches instead -- see INTEGRATION.md.
+// It re-creates the names of that header -- `complex`, `Vector`, `signalVector` (owning or aliasing, with the
+// concatenating constructor, segment(), copyToSegment(), ...), `BitVector`, `SoftVector`, `Symmetry`, `ConvType`, and the
+// free functions sigProcLibSetup / sigProcLibDestroy, convolve, correlate, generateGSMPulse, vectorSlicer, modulateBurst,
+// delayVector, interpolatePoint, peakDetect, scaleVector, generateMidamble, generateRACHSequence, energyDetect,
+// detectRACHBurst, analyzeTrafficBurst, decimateVector, demodulateBurst, createLPF (with setLPFTables),
+// polyphaseResampleVector, designDFE, equalizeBurst, plus GMSKRotate / GMSKReverseRotate (sigProcLib.cpp:232-264) -- with
+// the reference's argument meaning, ownership (functions returning a pointer allocate with `new`, the caller deletes:
+// Transceiver.cpp:112,407,672) and error behaviour (NULL / false, amplitude set to 0 on a "bogus result":
+// sigProcLib.cpp:878-882, 964-968).  The line cited at each function is its declaration in Transceiver/sigProcLib.h.
+// Define TRXFACADE_52M before including this header for the Transceiver52M/sigProcLib.h signatures instead
+// (analyzeTrafficBurst with maxTOA :295-305, the in-place demodulateBurst :324-328; symbol-rate samples).
 //
-// Not provided: the free-standing vector primitives (convolve, correlate, delayVector, peakDetect,
-// interpolatePoint, ...).  Transceiver.cpp and radioInterface.cpp never call them (SURVEY 8b lists
-// the call sites); inside the library they only exist fused into the burst-level kernels.
+// Every call that processes samples runs on the GPU through the C-ABI's host-buffer entry points (one PCIe round trip
+// per call); nothing here computes on the CPU.  A real deployment batches instead -- see INTEGRATION.md.
+//
+// Not provided (none is called by Transceiver.cpp or radioInterface.cpp): convolve's ABSSYM form (no caller sets a
+// symmetry), frequencyShift, resampleVector, addVector, offsetVector, gaussianNoise, vectorNorm2 / vectorPower, dB / dBinv.
+// Accepted ranges narrower than the reference's: modulateBurst takes 148-bit bursts with guard 0..9 and the library's
+// own pulse; energyDetect's window is 20*sps; designDFE wants Nf = 7 and a 6-tap channel, equalizeBurst 7 + 5 taps;
+// demodulateBurst wants 92..157 symbols (a multiple of sps samples) and |TOA| <= 4096 -- outside them the call returns
+// NULL / false instead of a value.
 #ifndef SIGPROCLIB_TRX_H
 #define SIGPROCLIB_TRX_H
 
@@ -41,40 +48,87 @@ struct complex {
   complex operator/(const complex &a) const { return (*this) * a.inv(); }                      // Complex.h:85
 };
 
-// Vector<T> subset (CommonLibs/Vector.h:42-252): contiguous, owning.
+// Vector<T> (CommonLibs/Vector.h:42-252): a contiguous block that is either owned (freed on destruction) or an alias
+// of somebody else's storage (segment(), the pointer constructors).  As in the reference, copying from a NON-const
+// Vector moves the block (the source becomes an alias of it), copying from a const one clones.
 template <class T>
 class Vector {
  public:
   typedef T *iterator;
   typedef const T *const_iterator;
-  explicit Vector(size_t n = 0) : d_(n) {}
-  size_t size() const { return d_.size(); }
-  T *begin() { return d_.data(); }
-  const T *begin() const { return d_.data(); }
-  T *end() { return d_.data() + d_.size(); }
-  const T *end() const { return d_.data() + d_.size(); }
-  T &operator[](size_t k) { return d_[k]; }
-  const T &operator[](size_t k) const { return d_[k]; }
-  void fill(const T &v) { for (auto &e : d_) e = v; }
- private:
-  std::vector<T> d_;
+  Vector(size_t n = 0) : own_(NULL), b_(NULL), e_(NULL) { resize(n); }
+  Vector(Vector<T> &o) : own_(o.own_), b_(o.b_), e_(o.e_) { o.own_ = NULL; }                 // Vector.h:98-100
+  Vector(const Vector<T> &o) : own_(NULL), b_(NULL), e_(NULL) { clone(o); }                   // :103
+  Vector(T *owned, T *first, T *last) : own_(owned), b_(first), e_(last) {}                   // :106-108
+  Vector(T *first, size_t span) : own_(NULL), b_(first), e_(first + span) {}                  // :111-113 (not deleted)
+  Vector(const Vector<T> &x, const Vector<T> &y) : own_(NULL), b_(NULL), e_(NULL) {           // :116-122 concatenation
+    resize(x.size() + y.size());
+    for (size_t k = 0; k < x.size(); k++) b_[k] = x.b_[k];
+    for (size_t k = 0; k < y.size(); k++) b_[x.size() + k] = y.b_[k];
+  }
+  ~Vector() { clear(); }
+  void operator=(Vector<T> &o) { clear(); own_ = o.own_; b_ = o.b_; e_ = o.e_; o.own_ = NULL; }   // :131-138
+  void operator=(const Vector<T> &o) { clone(o); }                                            // :141
+  size_t size() const { return (size_t)(e_ - b_); }
+  size_t bytes() const { return size() * sizeof(T); }
+  void resize(size_t n) {                                                                      // :66-73 (content discarded)
+    delete[] own_;
+    own_ = n ? new T[n]() : NULL;
+    b_ = own_; e_ = b_ + n;
+  }
+  void clear() { resize(0); }
+  void clone(const Vector<T> &o) { resize(o.size()); for (size_t k = 0; k < o.size(); k++) b_[k] = o.b_[k]; }
+  Vector<T> segment(size_t start, size_t span) { return Vector<T>(NULL, b_ + start, b_ + start + span); }       // :147-153
+  const Vector<T> segment(size_t start, size_t span) const { return Vector<T>(NULL, b_ + start, b_ + start + span); }
+  Vector<T> head(size_t span) { return segment(0, span); }
+  const Vector<T> head(size_t span) const { return segment(0, span); }
+  Vector<T> tail(size_t start) { return segment(start, size() - start); }
+  const Vector<T> tail(size_t start) const { return segment(start, size() - start); }
+  void copyToSegment(Vector<T> &o, size_t start, size_t span) const { for (size_t k = 0; k < span; k++) o.b_[start + k] = b_[k]; }
+  void copyToSegment(Vector<T> &o, size_t start = 0) const { copyToSegment(o, start, size()); }
+  void copyTo(Vector<T> &o) const { copyToSegment(o, 0, size()); }
+  void segmentCopyTo(Vector<T> &o, size_t start, size_t span) const { for (size_t k = 0; k < span; k++) o.b_[k] = b_[start + k]; }
+  void fill(const T &v) { for (T *p = b_; p < e_; p++) *p = v; }
+  void fill(const T &v, unsigned start, unsigned length) { for (unsigned k = 0; k < length; k++) b_[start + k] = v; }
+  T *begin() { return b_; }
+  const T *begin() const { return b_; }
+  T *end() { return e_; }
+  const T *end() const { return e_; }
+  T &operator[](size_t k) { return b_[k]; }
+  const T &operator[](size_t k) const { return b_[k]; }
+ protected:
+  T *own_;   // allocated block, if this Vector owns one
+  T *b_;     // first useful element
+  T *e_;     // one past the last
 };
+
+enum Symmetry { NONE = 0, ABSSYM = 1 };                                                        // sigProcLib.h:34-37
+enum ConvType { FULL_SPAN = 0, OVERLAP_ONLY = 1, START_ONLY = 2, WITH_TAIL = 3, NO_DELAY = 4, UNDEFINED = 255 };   // :41-48
 
 // signalVector (sigProcLib.h:51-99)
 class signalVector : public Vector<complex> {
  public:
-  explicit signalVector(size_t n = 0) : Vector<complex>(n), realOnly_(false) {}
+  signalVector(int dSize = 0, Symmetry wSymmetry = NONE) : Vector<complex>((size_t)dSize), symmetry_(wSymmetry), realOnly_(false) {}
+  signalVector(complex *wData, size_t start, size_t span, Symmetry wSymmetry = NONE)            // :65-71 an alias
+      : Vector<complex>(NULL, wData + start, wData + start + span), symmetry_(wSymmetry), realOnly_(false) {}
+  signalVector(const signalVector &vec1, const signalVector &vec2)                              // :73-79 concatenation
+      : Vector<complex>(vec1, vec2), symmetry_(vec1.symmetry_), realOnly_(false) {}
+  signalVector(const signalVector &wVector)                                                     // :81-88 a copy
+      : Vector<complex>(wVector.size()), symmetry_(wVector.symmetry_), realOnly_(false) { wVector.copyTo(*this); }
+  Symmetry getSymmetry() const { return symmetry_; }
+  void setSymmetry(Symmetry wSymmetry) { symmetry_ = wSymmetry; }
   bool isRealOnly() const { return realOnly_; }
   void isRealOnly(bool v) { realOnly_ = v; }
  private:
+  Symmetry symmetry_;
   bool realOnly_;
 };
 
 // BitVector: one bit per char, consumers mask with 0x01 (CommonLibs/BitVector.cpp:54-63)
 class BitVector : public Vector<char> {
  public:
-  explicit BitVector(size_t n = 0) : Vector<char>(n) {}
-  explicit BitVector(const char *s) : Vector<char>(std::strlen(s)) {
+  BitVector(size_t n = 0) : Vector<char>(n) {}
+  BitVector(const char *s) : Vector<char>(std::strlen(s)) {
     for (size_t k = 0; k < size(); k++) (*this)[k] = (s[k] == '1');
   }
   bool bit(size_t k) const { return (*this)[k] & 0x01; }
@@ -83,7 +137,7 @@ class BitVector : public Vector<char> {
 // SoftVector: float 0..1, bit() = > 0.5F (CommonLibs/BitVector.h:415-420)
 class SoftVector : public Vector<float> {
  public:
-  explicit SoftVector(size_t n = 0) : Vector<float>(n) {}
+  SoftVector(size_t n = 0) : Vector<float>(n) {}
   bool bit(size_t k) const { return (*this)[k] > 0.5F; }
 };
 
@@ -95,20 +149,25 @@ struct State {
 };
 inline State &state() { static State s; return s; }
 
-inline void sigProcLibDestroy(void) {                         // sigProcLib.h:113
+inline void sigProcLibDestroy(void) {                         // sigProcLib.h:117
   State &s = state();
   if (s.ctx) { trxsig_destroy(s.ctx); s.ctx = nullptr; }
 }
-// sigProcLibSetup (sigProcLib.h:110): also builds the pulse, the 8 midambles and the RACH sequence,
-// which the reference creates through separate calls at start-up (Transceiver.cpp:62-64,424,553).
-inline bool sigProcLibSetup(int samplesPerSymbol, int device = 0) {
+// sigProcLibSetup (sigProcLib.h:114; void, as there): also builds the pulse, the 8 midambles and the RACH sequence,
+// which the reference creates through separate calls at start-up (Transceiver.cpp:62-64,424,553).  There is no CPU
+// fallback: without a gfx950 device the library stays unset, sigProcLibReady() says so and every function below
+// returns NULL / false.  sigProcLibSetDevice picks the GPU of the next sigProcLibSetup (default 0).
+inline void sigProcLibSetDevice(int device) { state().device = device; }
+inline void sigProcLibSetup(int samplesPerSymbol) {
   State &s = state();
   sigProcLibDestroy();
-  s.sps = samplesPerSymbol; s.device = device;
-  return trxsig_create(&s.ctx, device, samplesPerSymbol) == TRXSIG_OK;
+  s.sps = samplesPerSymbol;
+  if (trxsig_create(&s.ctx, s.device, samplesPerSymbol) != TRXSIG_OK) s.ctx = nullptr;
 }
+inline bool sigProcLibReady() { return state().ctx != nullptr; }
 
-// generateGSMPulse(2, sps) (sigProcLib.h:137-138): a copy of the table built at set-up
+// generateGSMPulse(2, sps) (sigProcLib.h:137-138; the definition takes (symbolLength, samplesPerSymbol),
+// sigProcLib.cpp:411): a copy of the table built at set-up
 inline signalVector *generateGSMPulse(int symbolLength, int samplesPerSymbol) {
   State &s = state();
   if (!s.ctx || symbolLength != 2 || samplesPerSymbol != s.sps) return NULL;
@@ -119,7 +178,7 @@ inline signalVector *generateGSMPulse(int symbolLength, int samplesPerSymbol) {
   p->isRealOnly(true);
   return p;
 }
-// generateMidamble / generateRACHSequence (sigProcLib.h:227-239): built at set-up; these only check.
+// generateMidamble / generateRACHSequence (sigProcLib.h:235-245): built at set-up; these only check.
 inline bool generateMidamble(signalVector &, int samplesPerSymbol, int TSC) {
   return state().ctx && samplesPerSymbol == state().sps && TSC >= 0 && TSC <= 7;
 }
@@ -166,7 +225,7 @@ inline bool detect(bool rach, signalVector &rxBurst, unsigned TSC, float thresh,
 }
 }  // namespace detail
 
-// energyDetect (sigProcLib.h:246-249); windowLength must be 20*sps, the only value the Transceiver
+// energyDetect (sigProcLib.h:255-258); windowLength must be 20*sps, the only value the Transceiver
 // uses (Transceiver.cpp:298)
 inline bool energyDetect(signalVector &rxBurst, unsigned windowLength, float detectThreshold, float *avgPwr = NULL) {
   if (windowLength != 20u * (unsigned)state().sps) return false;
@@ -174,7 +233,30 @@ inline bool energyDetect(signalVector &rxBurst, unsigned windowLength, float det
   detail::detect(false, rxBurst, 0, 1e30f, detectThreshold, NULL, NULL, avgPwr, &ok);
   return ok;
 }
-// analyzeTrafficBurst (sigProcLib.h:277-285).  requestChannel (symbol-rate samples only, as the reference's equaliser):
+namespace detail {
+// analyzeTrafficBurst with a channel estimate, either variant (trxsig_channel_estimate_host)
+inline bool analyze_chan(signalVector &rxBurst, unsigned TSC, float detectThreshold, int variant52m, int maxTOA, complex *amplitude,
+                         float *TOA, bool wantChannel, signalVector **channelResponse, float *channelResponseOffset) {
+  State &s = state();
+  if (!s.ctx || s.sps != 1 || (wantChannel && !channelResponse)) return false;
+  uint8_t flags = 0; trxsig_c32 amp = {0, 0}, chan[6]; float toa = 0, choff = 0;
+  if (trxsig_channel_estimate_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), (int)TSC, detectThreshold,
+                                   variant52m, maxTOA, &flags, &amp, &toa, &choff, chan) != TRXSIG_OK)
+    return false;
+  if (amplitude) *amplitude = complex(amp.re, amp.im);
+  if (TOA) *TOA = toa;
+  if (!(flags & TRXSIG_F_DETECT)) return false;
+  if (wantChannel) {
+    *channelResponse = new signalVector(6);
+    for (int k = 0; k < 6; k++) (**channelResponse)[k] = complex(chan[k].re, chan[k].im);
+    if (channelResponseOffset) *channelResponseOffset = choff;
+  }
+  return true;
+}
+}  // namespace detail
+
+#ifndef TRXFACADE_52M
+// analyzeTrafficBurst (sigProcLib.h:288-296).  requestChannel (symbol-rate samples only, as the reference's equaliser):
 // *channelResponse = new signalVector(6) (caller deletes) and *channelResponseOffset are set when the burst is detected
 // (sigProcLib.cpp:1005-1031).
 inline bool analyzeTrafficBurst(signalVector &rxBurst, unsigned TSC, float detectThreshold, int samplesPerSymbol,
@@ -182,23 +264,25 @@ inline bool analyzeTrafficBurst(signalVector &rxBurst, unsigned TSC, float detec
                                 signalVector **channelResponse = NULL, float *channelResponseOffset = NULL) {
   if (samplesPerSymbol != state().sps || TSC > 7) return false;
   if (!requestChannel) return detail::detect(false, rxBurst, TSC, detectThreshold, -1.0f, amplitude, TOA, NULL, NULL);
-  State &s = state();
-  if (!s.ctx || s.sps != 1 || !channelResponse) return false;
-  uint8_t flags = 0; trxsig_c32 amp = {0, 0}, chan[6]; float toa = 0, choff = 0;
-  if (trxsig_channel_estimate_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), (int)TSC, detectThreshold,
-                                   0, 0, &flags, &amp, &toa, &choff, chan) != TRXSIG_OK)
-    return false;
-  if (amplitude) *amplitude = complex(amp.re, amp.im);
-  if (TOA) *TOA = toa;
-  if (!(flags & TRXSIG_F_DETECT)) return false;
-  *channelResponse = new signalVector(6);
-  for (int k = 0; k < 6; k++) (**channelResponse)[k] = complex(chan[k].re, chan[k].im);
-  if (channelResponseOffset) *channelResponseOffset = choff;
-  return true;
+  return detail::analyze_chan(rxBurst, TSC, detectThreshold, 0, 0, amplitude, TOA, true, channelResponse, channelResponseOffset);
 }
-// scaleVector (sigProcLib.h:182-183): x[k] = x[k] * scale (sigProcLib.cpp:713-723)
+#else
+// analyzeTrafficBurst of the 52 MHz transceiver (Transceiver52M/sigProcLib.h:295-305): the correlation only covers the
+// 2*maxTOA + 1 lags round the expected peak (Transceiver52M/sigProcLib.cpp:966-1076); symbol-rate samples only.
+inline bool analyzeTrafficBurst(signalVector &rxBurst, unsigned TSC, float detectThreshold, int samplesPerSymbol,
+                                complex *amplitude, float *TOA, unsigned maxTOA, bool requestChannel = false,
+                                signalVector **channelResponse = NULL, float *channelResponseOffset = NULL) {
+  if (samplesPerSymbol != state().sps || TSC > 7) return false;
+  return detail::analyze_chan(rxBurst, TSC, detectThreshold, 1, (int)maxTOA, amplitude, TOA, requestChannel, channelResponse,
+                              channelResponseOffset);
+}
+#endif
+// scaleVector (sigProcLib.h:217-218): x[k] = x[k] * scale, or x[k].real() * scale for a real-only vector (sigProcLib.cpp:713-730)
 inline void scaleVector(signalVector &x, complex scale) {
-  for (size_t k = 0; k < x.size(); k++) x[k] = x[k] * scale;
+  State &s = state();
+  if (!s.ctx || x.size() == 0) return;
+  const trxsig_c32 sc = {scale.r, scale.i};
+  (void)trxsig_elementwise_host(s.ctx, 0, (trxsig_c32 *)x.begin(), (int)x.size(), sc, x.isRealOnly());
 }
 // designDFE (sigProcLib.h:365-369): Nf = 7 and a 6-tap channel, as the Transceiver uses it (Transceiver.cpp:347);
 // *feedForwardFilter (7 taps) and *feedbackFilter (5 taps) are allocated with new (the caller deletes)
@@ -232,15 +316,14 @@ inline SoftVector *equalizeBurst(signalVector &rxBurst, float TOA, int samplesPe
   }
   return out;
 }
-// detectRACHBurst (sigProcLib.h:263-267)
+// detectRACHBurst (sigProcLib.h:269-273)
 inline bool detectRACHBurst(signalVector &rxBurst, float detectThreshold, int samplesPerSymbol, complex *amplitude,
                             float *TOA) {
   if (samplesPerSymbol != state().sps) return false;
   return detail::detect(true, rxBurst, 0, detectThreshold, -1.0f, amplitude, TOA, NULL, NULL);
 }
-// demodulateBurst (sigProcLib.h:316-320): returns N/sps soft bits; caller deletes
-inline SoftVector *demodulateBurst(const signalVector &rxBurst, const signalVector &, int samplesPerSymbol,
-                                   complex channel, float TOA) {
+namespace detail {
+inline SoftVector *demod(const signalVector &rxBurst, int samplesPerSymbol, complex channel, float TOA) {
   State &s = state();
   if (!s.ctx || samplesPerSymbol != s.sps) return NULL;
   const int ns = (int)(rxBurst.size() / (size_t)s.sps);
@@ -253,8 +336,110 @@ inline SoftVector *demodulateBurst(const signalVector &rxBurst, const signalVect
   }
   return out;
 }
+}  // namespace detail
 
-// createLPF (sigProcLib.h:340-343).  The reference ignores the cutoff and loads one of its two coefficient
+// vectorSlicer (sigProcLib.h:168), delayVector (:180-181), GMSKRotate / GMSKReverseRotate (sigProcLib.cpp:232-264): in place
+inline bool vectorSlicer(signalVector *x) {
+  State &s = state();
+  const trxsig_c32 one = {1.0f, 0.0f};
+  return s.ctx && x && x->size() > 0 &&
+         trxsig_elementwise_host(s.ctx, 3, (trxsig_c32 *)x->begin(), (int)x->size(), one, 0) == TRXSIG_OK;
+}
+inline void delayVector(signalVector &wBurst, float delay) {
+  State &s = state();
+  if (s.ctx && wBurst.size() > 0)
+    (void)trxsig_delay_vector_host(s.ctx, (trxsig_c32 *)wBurst.begin(), (int)wBurst.size(), delay, wBurst.isRealOnly());
+}
+inline void GMSKRotate(signalVector &x) {
+  State &s = state();
+  const trxsig_c32 one = {1.0f, 0.0f};
+  if (s.ctx && x.size() > 0) (void)trxsig_elementwise_host(s.ctx, 1, (trxsig_c32 *)x.begin(), (int)x.size(), one, x.isRealOnly());
+}
+inline void GMSKReverseRotate(signalVector &x) {
+  State &s = state();
+  const trxsig_c32 one = {1.0f, 0.0f};
+  if (s.ctx && x.size() > 0) (void)trxsig_elementwise_host(s.ctx, 2, (trxsig_c32 *)x.begin(), (int)x.size(), one, x.isRealOnly());
+}
+
+#ifndef TRXFACADE_52M
+// demodulateBurst (sigProcLib.h:316-320): returns N/sps soft bits; caller deletes
+inline SoftVector *demodulateBurst(const signalVector &rxBurst, const signalVector &, int samplesPerSymbol,
+                                   complex channel, float TOA) {
+  return detail::demod(rxBurst, samplesPerSymbol, channel, TOA);
+}
+#else
+// demodulateBurst of the 52 MHz transceiver (Transceiver52M/sigProcLib.h:324-328): the burst itself is scaled, delayed and
+// de-rotated in place (Transceiver52M/sigProcLib.cpp:1095-1135), and that is what the caller finds in it afterwards
+inline SoftVector *demodulateBurst(signalVector &rxBurst, const signalVector &, int samplesPerSymbol, complex channel,
+                                   float TOA) {
+  SoftVector *out = detail::demod(rxBurst, samplesPerSymbol, channel, TOA);
+  if (!out) return NULL;
+  State &s = state();
+  const complex inv = complex(1.0f, 0.0f) / channel;       // ((complex) 1.0)/channel
+  const trxsig_c32 sc = {inv.r, inv.i};
+  (void)trxsig_elementwise_host(s.ctx, 0, (trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), sc, rxBurst.isRealOnly());
+  delayVector(rxBurst, -TOA);
+  GMSKReverseRotate(rxBurst);
+  return out;
+}
+#endif
+
+// convolve (sigProcLib.h:126-129) and correlate (:162-165): c == NULL allocates the result (caller deletes); a
+// preallocated c must have exactly the output size, else NULL (sigProcLib.cpp:307-310).  Symmetry NONE only.
+namespace detail {
+inline signalVector *conv(const signalVector *a, const signalVector *b, signalVector *c, ConvType spanType, int correlate) {
+  State &s = state();
+  if (!s.ctx || a == NULL || b == NULL || b->getSymmetry() != NONE) return NULL;
+  const int n = trxsig_convolve_out_len((int)a->size(), (int)b->size(), (int)spanType, 0);
+  if (n <= 0 || spanType > NO_DELAY) return NULL;
+  const bool mine = (c == NULL);
+  if (mine) c = new signalVector(n);
+  else if ((int)c->size() != n) return NULL;
+  const int flags = (a->isRealOnly() ? 1 : 0) | (b->isRealOnly() ? 2 : 0);
+  if (trxsig_convolve_host(s.ctx, (const trxsig_c32 *)a->begin(), (int)a->size(), (const trxsig_c32 *)b->begin(), (int)b->size(),
+                           (int)spanType, flags, correlate, 0, 0, (trxsig_c32 *)c->begin(), n) != n) {
+    if (mine) delete c;
+    return NULL;
+  }
+  return c;
+}
+}  // namespace detail
+inline signalVector *convolve(const signalVector *a, const signalVector *b, signalVector *c, ConvType spanType) {
+  return detail::conv(a, b, c, spanType, 0);
+}
+inline signalVector *correlate(signalVector *a, signalVector *b, signalVector *c, ConvType spanType) {
+  return detail::conv(a, b, c, spanType, 1);
+}
+// interpolatePoint (sigProcLib.h:198-199) and peakDetect (:208-210)
+inline complex interpolatePoint(const signalVector &inSig, float ix) {
+  State &s = state();
+  trxsig_c32 r = {0.0f, 0.0f};
+  if (s.ctx && inSig.size() > 0)
+    (void)trxsig_interpolate_point_host(s.ctx, (const trxsig_c32 *)inSig.begin(), (int)inSig.size(), ix, inSig.isRealOnly(), &r);
+  return complex(r.re, r.im);
+}
+inline complex peakDetect(const signalVector &rxBurst, float *peakIndex, float *avgPwr) {
+  State &s = state();
+  trxsig_c32 r = {0.0f, 0.0f};
+  if (s.ctx && rxBurst.size() > 0)
+    (void)trxsig_peak_detect_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), &r, peakIndex, avgPwr);
+  return complex(r.re, r.im);
+}
+// decimateVector (sigProcLib.h:304-305): NULL for a factor <= 1 (sigProcLib.cpp:1043); caller deletes
+inline signalVector *decimateVector(signalVector &wVector, int decimationFactor) {
+  State &s = state();
+  if (!s.ctx || decimationFactor <= 1 || wVector.size() < (size_t)decimationFactor) return NULL;
+  signalVector *d = new signalVector((int)(wVector.size() / (size_t)decimationFactor));
+  d->isRealOnly(wVector.isRealOnly());
+  if (trxsig_decimate_host(s.ctx, (const trxsig_c32 *)wVector.begin(), (int)wVector.size(), decimationFactor,
+                           (trxsig_c32 *)d->begin()) != (int)d->size()) {
+    delete d;
+    return NULL;
+  }
+  return d;
+}
+
+// createLPF (sigProcLib.h:329-331).  The reference ignores the cutoff and loads one of its two coefficient
 // tables (rcvLPF_651.h for filterLen 651, else sendLPF_961.h; sigProcLib.cpp:1119-1139); those tables are
 // reference data, so the caller registers them once (the arrays of the reference's own headers will do).
 inline const float *&lpfTable(int which) { static const float *t[2] = {NULL, NULL}; return t[which]; }
@@ -270,7 +455,7 @@ inline signalVector *createLPF(float /*cutoffFreq*/, int filterLen, float gainDC
   lpf->isRealOnly(true);
   return lpf;
 }
-// polyphaseResampleVector (sigProcLib.h:352-354) with a real-only LPF (the only kind createLPF makes)
+// polyphaseResampleVector (sigProcLib.h:341-343) with a real-only LPF (the only kind createLPF makes)
 inline signalVector *polyphaseResampleVector(signalVector &wVector, int P, int Q, signalVector *LPF) {
   State &s = state();
   if (!s.ctx || !LPF || !LPF->isRealOnly() || wVector.size() == 0) return NULL;
@@ -295,6 +480,28 @@ using trxfacade::createLPF;
 using trxfacade::polyphaseResampleVector;
 using trxfacade::setLPFTables;
 using trxfacade::complex;
+using trxfacade::Vector;
+using trxfacade::Symmetry;
+using trxfacade::NONE;
+using trxfacade::ABSSYM;
+using trxfacade::ConvType;
+using trxfacade::FULL_SPAN;
+using trxfacade::OVERLAP_ONLY;
+using trxfacade::START_ONLY;
+using trxfacade::WITH_TAIL;
+using trxfacade::NO_DELAY;
+using trxfacade::UNDEFINED;
+using trxfacade::convolve;
+using trxfacade::correlate;
+using trxfacade::vectorSlicer;
+using trxfacade::delayVector;
+using trxfacade::GMSKRotate;
+using trxfacade::GMSKReverseRotate;
+using trxfacade::interpolatePoint;
+using trxfacade::peakDetect;
+using trxfacade::decimateVector;
+using trxfacade::sigProcLibReady;
+using trxfacade::sigProcLibSetDevice;
 using trxfacade::demodulateBurst;
 using trxfacade::designDFE;
 using trxfacade::equalizeBurst;

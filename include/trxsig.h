@@ -264,7 +264,9 @@ int trxsig_detect_demod_rach_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples,
                                   float detect_thresh, float energy_thresh,
                                   uint8_t *h_flags, trxsig_c32 *h_amp, float *h_toa,
                                   float *h_avgpwr, float *h_soft, int nsoft, int soft_stride);
-/* one burst, caller-supplied amp/TOA: demodulateBurst (sigProcLib.h:316-320) */
+/* one burst, caller-supplied amp/TOA: demodulateBurst (sigProcLib.h:316-320).  TRXSIG_EINVAL for a burst outside the
+ * accepted geometry (92..157 symbols, a multiple of sps samples) or |TOA| > 4096 / NaN -- the batch form writes zeros for
+ * such a burst, the one-burst form refuses it (the reference itself handles any length). */
 int trxsig_demodulate_host(trxsig_ctx *ctx, const trxsig_c32 *h_samples, int n_samples,
                            trxsig_c32 amp, float toa, float *h_soft, int nsoft);
 int trxsig_modulate_host(trxsig_ctx *ctx, const uint8_t *h_bits, const int32_t *h_guard,
@@ -310,6 +312,54 @@ int trxsig_fec_tch_decode_batch(trxsig_ctx *ctx, const float *d_soft, int soft_s
                                 uint8_t *d_facch_ok, uint8_t *d_stolen);
 int trxsig_fec_viterbi_batch(trxsig_ctx *ctx, const float *d_soft, int n_soft, int64_t in_stride, int n_blocks,
                              uint8_t *d_bits, int64_t out_stride);
+
+/* ---- the free-standing vector primitives of sigProcLib.h (csrc/trxsig_prim.hip) -------------------------------
+ * On the burst path these only run fused into the burst kernels above; the stand-alone forms complete the
+ * sigProcLib.h surface (convolve :126, correlate :162, vectorSlicer :168, delayVector :180, interpolatePoint :198,
+ * peakDetect :208, scaleVector :215, decimateVector :304 of Transceiver/sigProcLib.h; GMSKRotate / GMSKReverseRotate
+ * are sigProcLib.cpp:232-264) and are what config 1's call sequence (Transceiver/sigProcLibTest.cpp) runs through.
+ * Batch forms: B independent vectors packed in one device array (d_off / d_len in samples); max_len = the largest
+ * d_len (sizes the launch).  Values are the reference's, bit for bit: every sum in the reference's order with its
+ * skip / break rules.  Host forms: one vector, pageable host buffers, one PCIe round trip.
+ * Not provided: convolve's ABSSYM symmetry form (sigProcLib.cpp:369-398; no caller in the reference ever sets a symmetry).
+ * span: ConvType of sigProcLib.h:41-48 (+ CUSTOM of Transceiver52M/sigProcLib.h:47 with cust_start / cust_len).
+ * flags: bit 0 = a is real-only, bit 1 = b is real-only (signalVector::isRealOnly: the four arithmetic forms of
+ * sigProcLib.cpp:326-365); correlate != 0: b is used reversed and conjugated (sigProcLib.cpp:474-503). */
+enum { TRXSIG_FULL_SPAN = 0, TRXSIG_OVERLAP_ONLY = 1, TRXSIG_START_ONLY = 2, TRXSIG_WITH_TAIL = 3, TRXSIG_NO_DELAY = 4,
+       TRXSIG_CUSTOM = 5 };
+int trxsig_convolve_out_len(int La, int Lb, int span, int cust_len);   /* < 0: unknown span */
+/* one filter d_b (Lb taps) for all B vectors; out vector i (trxsig_convolve_out_len(d_a_len[i], ...) samples) at d_out_off[i] */
+int trxsig_convolve_batch(trxsig_ctx *ctx, const trxsig_c32 *d_a, const int32_t *d_a_off, const int32_t *d_a_len, int B,
+                          int max_len, const trxsig_c32 *d_b, int Lb, int span, int flags, int correlate, int cust_start,
+                          int cust_len, trxsig_c32 *d_out, const int32_t *d_out_off);
+int trxsig_convolve_host(trxsig_ctx *ctx, const trxsig_c32 *h_a, int La, const trxsig_c32 *h_b, int Lb, int span, int flags,
+                         int correlate, int cust_start, int cust_len, trxsig_c32 *h_out, int out_cap);   /* returns the length */
+/* delayVector(x, delay): d_out has d_in's layout and must not overlap it */
+int trxsig_delay_vector_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                              const float *d_delay, int real_only, trxsig_c32 *d_out);
+int trxsig_delay_vector_host(trxsig_ctx *ctx, trxsig_c32 *h_x /* in place */, int n, float delay, int real_only);
+/* interpolatePoint(x_i, d_ix[i]) -> d_out[i] */
+int trxsig_interpolate_point_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                                   const float *d_ix, int real_only, trxsig_c32 *d_out);
+int trxsig_interpolate_point_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, float ix, int real_only, trxsig_c32 *h_out);
+/* peakDetect(x_i, &d_index[i], &d_avgpwr[i]) -> d_peak[i]; d_index / d_avgpwr may be NULL */
+int trxsig_peak_detect_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                             trxsig_c32 *d_peak, float *d_index, float *d_avgpwr);
+int trxsig_peak_detect_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, trxsig_c32 *h_peak, float *h_index, float *h_avgpwr);
+/* in place: scaleVector(x_i, d_scale[i]); GMSKRotate / GMSKReverseRotate (elements past the 157*sps table entries are
+ * left as they are -- the reference reads past its table there); vectorSlicer */
+int trxsig_scale_vector_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                              const trxsig_c32 *d_scale, int real_only);
+int trxsig_gmsk_rotate_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                             int reverse, int real_only);
+int trxsig_vector_slicer_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len);
+/* decimateVector(x_i, factor): d_len[i] / factor samples at d_out_off[i] (d_len[i] must be a multiple of factor: the
+ * reference writes past its allocation otherwise, sigProcLib.cpp:1045-1050) */
+int trxsig_decimate_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                          int factor, trxsig_c32 *d_out, const int32_t *d_out_off);
+/* one vector, in place on the host buffer; op: 0 scaleVector(scale), 1 GMSKRotate, 2 GMSKReverseRotate, 3 vectorSlicer */
+int trxsig_elementwise_host(trxsig_ctx *ctx, int op, trxsig_c32 *h_x, int n, trxsig_c32 scale, int real_only);
+int trxsig_decimate_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, int factor, trxsig_c32 *h_out);   /* returns n / factor */
 
 /* ---- measurement helpers (HIP events on the context's stream; used by bench.py) ---------------
  * trxsig_timer_*: one start/stop event pair around whatever the caller enqueues in between.

@@ -19,6 +19,11 @@ class TrxSigError(RuntimeError):
     pass
 
 
+class C32(C.Structure):
+    """trxsig_c32 by value."""
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
 def build(verbose=False):
     """Compile csrc/ into libtrxsig.so for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-j8", "-C", os.path.join(_HERE, "csrc")]
@@ -78,6 +83,22 @@ def lib():
         L.trxsig_fec_xcch_encode_batch.argtypes = [vp, vp, i32, i32, vp]
         L.trxsig_fec_tch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.trxsig_fec_viterbi_batch.argtypes = [vp, vp, i32, C.c_int64, i32, vp, C.c_int64]
+        # sigProcLib.h's free-standing primitives
+        L.trxsig_convolve_out_len.argtypes = [i32, i32, i32, i32]
+        L.trxsig_convolve_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.trxsig_convolve_host.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32]
+        L.trxsig_delay_vector_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
+        L.trxsig_delay_vector_host.argtypes = [vp, vp, i32, f32, i32]
+        L.trxsig_interpolate_point_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
+        L.trxsig_interpolate_point_host.argtypes = [vp, vp, i32, f32, i32, vp]
+        L.trxsig_peak_detect_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+        L.trxsig_peak_detect_host.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.trxsig_scale_vector_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32]
+        L.trxsig_gmsk_rotate_batch.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32]
+        L.trxsig_vector_slicer_batch.argtypes = [vp, vp, vp, vp, i32, i32]
+        L.trxsig_decimate_batch.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+        L.trxsig_elementwise_host.argtypes = [vp, i32, vp, i32, C32, i32]
+        L.trxsig_decimate_host.argtypes = [vp, vp, i32, i32, vp]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
@@ -259,6 +280,54 @@ class TrxSig:
                                               None if g is None else g.ctypes.data, B, out.ctypes.data,
                                               off.ctypes.data, out.size), "trxsig_modulate_host")
         return out, off, length
+
+    # ---- sigProcLib.h's free-standing primitives, single-vector host forms (numpy in / out) ----
+    def convolve_host(self, a, b, span, a_real=False, b_real=False, correlate=False, cust_start=0, cust_len=0):
+        import numpy as np
+        a = np.ascontiguousarray(a, np.complex64); b = np.ascontiguousarray(b, np.complex64)
+        n = self.L.trxsig_convolve_out_len(a.size, b.size, span, cust_len)
+        out = np.zeros(max(n, 1), np.complex64)
+        rc = self.L.trxsig_convolve_host(self.h, a.ctypes.data, a.size, b.ctypes.data, b.size, span,
+                                         int(a_real) | (int(b_real) << 1), int(correlate), cust_start, cust_len, out.ctypes.data, out.size)
+        if rc < 0:
+            self._chk(rc, "trxsig_convolve_host")
+        return out[:rc]
+
+    def delay_vector_host(self, x, delay, real_only=False):
+        import numpy as np
+        y = np.array(x, np.complex64, copy=True)
+        self._chk(self.L.trxsig_delay_vector_host(self.h, y.ctypes.data, y.size, float(delay), int(real_only)), "trxsig_delay_vector_host")
+        return y
+
+    def interpolate_point_host(self, x, ix, real_only=False):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); out = np.zeros(1, np.complex64)
+        self._chk(self.L.trxsig_interpolate_point_host(self.h, x.ctypes.data, x.size, float(ix), int(real_only), out.ctypes.data),
+                  "trxsig_interpolate_point_host")
+        return out[0]
+
+    def peak_detect_host(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); pk = np.zeros(1, np.complex64); ix = np.zeros(1, np.float32); av = np.zeros(1, np.float32)
+        self._chk(self.L.trxsig_peak_detect_host(self.h, x.ctypes.data, x.size, pk.ctypes.data, ix.ctypes.data, av.ctypes.data),
+                  "trxsig_peak_detect_host")
+        return pk[0], ix[0], av[0]
+
+    def elementwise_host(self, op, x, scale=1.0, real_only=False):
+        """op: 0 scaleVector, 1 GMSKRotate, 2 GMSKReverseRotate, 3 vectorSlicer."""
+        import numpy as np
+        y = np.array(x, np.complex64, copy=True)
+        sc = C32(float(np.real(scale)), float(np.imag(scale)))
+        self._chk(self.L.trxsig_elementwise_host(self.h, op, y.ctypes.data, y.size, sc, int(real_only)), "trxsig_elementwise_host")
+        return y
+
+    def decimate_host(self, x, factor):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); out = np.zeros(max(x.size // factor, 1), np.complex64)
+        rc = self.L.trxsig_decimate_host(self.h, x.ctypes.data, x.size, factor, out.ctypes.data)
+        if rc < 0:
+            self._chk(rc, "trxsig_decimate_host")
+        return out[:rc]
 
     def resample_out_len(self, n_in, P, Q):
         return self.L.trxsig_resample_out_len(n_in, P, Q)

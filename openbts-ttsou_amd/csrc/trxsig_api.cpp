@@ -749,6 +749,10 @@ int trxsig_demodulate_host(trxsig_ctx *c, const trxsig_c32 *h_samples, int n, tr
   if (!c) return TRXSIG_EINVAL;
   if (!h_samples || !h_soft || n <= 0 || nsoft < 0 || nsoft > 157)
     return fail(c, TRXSIG_EINVAL, "trxsig_demodulate_host: bad argument");
+  // what the kernel would silently answer with all-zero soft bits (trxsig.h: accepted burst geometry) is an error for
+  // the one-burst form: the reference's demodulateBurst has no such limits, so a drop-in caller must hear about it
+  if (n < 92 * c->sps || n > 157 * c->sps || n % c->sps != 0 || !(std::fabs(toa) <= 4096.0f))
+    return fail(c, TRXSIG_EINVAL, "trxsig_demodulate_host: burst must be 92..157 symbols (a multiple of sps samples) and |TOA| <= 4096");
   DeviceGuard g(c->device);
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_s = 0, o_off = up(8 * (size_t)n), o_len = o_off + 256, o_amp = o_len + 256, o_toa = o_amp + 256,
@@ -980,6 +984,244 @@ int trxsig_tables_rach_error_bound(const void *h_blob, size_t bytes, float *boun
     *seq_norm = (float)std::sqrt(n2);
   }
   return TRXSIG_OK;
+}
+
+// ---- the free-standing vector primitives of sigProcLib.h (trxsig_prim.hip) ----------------------------------------
+int trxsig_convolve_out_len(int La, int Lb, int span, int cust_len) {
+  if (La <= 0 || Lb <= 0) return -1;
+  return trx_convolve_out_len(La, Lb, span, cust_len);
+}
+
+int trxsig_convolve_batch(trxsig_ctx *c, const trxsig_c32 *d_a, const int32_t *d_a_off, const int32_t *d_a_len, int B,
+                          int max_len, const trxsig_c32 *d_b, int Lb, int span, int flags, int correlate, int cust_start,
+                          int cust_len, trxsig_c32 *d_out, const int32_t *d_out_off) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_a, d_a_off, d_a_len, B) || max_len <= 0 || !d_b || Lb <= 0 || span < 0 || span > TRXSIG_CUSTOM ||
+      (flags & ~3) || (B > 0 && (!d_out || !d_out_off)) || (span == TRXSIG_CUSTOM && (cust_start < 0 || cust_len <= 0)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_convolve_batch: bad argument");
+  DeviceGuard g(c->device);
+  const int max_out = trx_convolve_out_len(max_len, Lb, span, cust_len);
+  // (OVERLAP_ONLY's length is |La - Lb| + 1: the longest output may belong to the shortest vector)
+  const int grid_out = span == TRXSIG_OVERLAP_ONLY ? (max_len > Lb ? max_len : Lb) + 1 : max_out;
+  HIPCHK(c, trx_launch_convolve(c->stream, (const trx_c32 *)d_a, d_a_off, d_a_len, B, grid_out, (const trx_c32 *)d_b, Lb, span,
+                                flags, correlate != 0, cust_start, cust_len, (trx_c32 *)d_out, d_out_off));
+  return TRXSIG_OK;
+}
+
+namespace {
+// staging-area layout helper for the single-vector host forms: 256-byte aligned regions handed out in order
+struct Stager {
+  trxsig_ctx *c;
+  size_t used = 0;
+  explicit Stager(trxsig_ctx *ctx) : c(ctx) {}
+  size_t take(size_t bytes) { const size_t o = used; used += (bytes + 255) & ~(size_t)255; return o; }
+  char *base() const { return (char *)c->d_stage; }
+};
+}  // namespace
+
+int trxsig_convolve_host(trxsig_ctx *c, const trxsig_c32 *h_a, int La, const trxsig_c32 *h_b, int Lb, int span, int flags,
+                         int correlate, int cust_start, int cust_len, trxsig_c32 *h_out, int out_cap) {
+  if (!c) return TRXSIG_EINVAL;
+  const int nout = (La > 0 && Lb > 0) ? trx_convolve_out_len(La, Lb, span, cust_len) : -1;
+  if (!h_a || !h_b || !h_out || nout <= 0 || out_cap < nout) return fail(c, TRXSIG_EINVAL, "trxsig_convolve_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_a = s.take(8 * (size_t)La), o_b = s.take(8 * (size_t)Lb), o_m = s.take(16), o_out = s.take(8 * (size_t)nout);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  const int32_t meta[3] = {0, La, 0};                      // a_off, a_len, out_off
+  HIPCHK(c, hipMemcpyAsync(d + o_a, h_a, 8 * (size_t)La, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_b, h_b, 8 * (size_t)Lb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));              // meta lives on this stack frame
+  rc = trxsig_convolve_batch(c, (trxsig_c32 *)(d + o_a), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1, La,
+                             (trxsig_c32 *)(d + o_b), Lb, span, flags, correlate, cust_start, cust_len, (trxsig_c32 *)(d + o_out),
+                             (int32_t *)(d + o_m) + 2);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_out, 8 * (size_t)nout, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return nout;
+}
+
+int trxsig_delay_vector_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                              const float *d_delay, int real_only, trxsig_c32 *d_out) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || (B > 0 && (!d_delay || !d_out || d_out == d_in)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_delay_vector_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_delay_vector(c->stream, c->d_tables, (const trx_c32 *)d_in, d_off, d_len, B, d_delay, real_only != 0,
+                                    (trx_c32 *)d_out));
+  return TRXSIG_OK;
+}
+
+int trxsig_delay_vector_host(trxsig_ctx *c, trxsig_c32 *h_x, int n, float delay, int real_only) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0) return fail(c, TRXSIG_EINVAL, "trxsig_delay_vector_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_y = s.take(8 * (size_t)n), o_m = s.take(16);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  int32_t meta[3] = {0, n, 0};
+  std::memcpy(&meta[2], &delay, 4);
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_delay_vector_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1,
+                                 (float *)(d + o_m) + 2, real_only, (trxsig_c32 *)(d + o_y));
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_x, d + o_y, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+int trxsig_interpolate_point_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                                   const float *d_ix, int real_only, trxsig_c32 *d_out) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || (B > 0 && (!d_ix || !d_out)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_interpolate_point_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_interpolate_point(c->stream, c->d_tables, (const trx_c32 *)d_in, d_off, d_len, B, d_ix, real_only != 0,
+                                         (trx_c32 *)d_out));
+  return TRXSIG_OK;
+}
+
+int trxsig_interpolate_point_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, float ix, int real_only, trxsig_c32 *h_out) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0 || !h_out) return fail(c, TRXSIG_EINVAL, "trxsig_interpolate_point_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16), o_out = s.take(8);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  int32_t meta[3] = {0, n, 0};
+  std::memcpy(&meta[2], &ix, 4);
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_interpolate_point_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1,
+                                      (float *)(d + o_m) + 2, real_only, (trxsig_c32 *)(d + o_out));
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_out, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+int trxsig_peak_detect_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                             trxsig_c32 *d_peak, float *d_index, float *d_avgpwr) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || (B > 0 && !d_peak)) return fail(c, TRXSIG_EINVAL, "trxsig_peak_detect_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_peak_detect(c->stream, c->d_tables, (const trx_c32 *)d_in, d_off, d_len, B, (trx_c32 *)d_peak, d_index,
+                                   d_avgpwr));
+  return TRXSIG_OK;
+}
+
+int trxsig_peak_detect_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, trxsig_c32 *h_peak, float *h_index, float *h_avgpwr) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0 || !h_peak) return fail(c, TRXSIG_EINVAL, "trxsig_peak_detect_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16), o_out = s.take(16);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  const int32_t meta[2] = {0, n};
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_peak_detect_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1,
+                                (trxsig_c32 *)(d + o_out), (float *)(d + o_out) + 2, (float *)(d + o_out) + 3);
+  if (rc != TRXSIG_OK) return rc;
+  float res[4];
+  HIPCHK(c, hipMemcpyAsync(res, d + o_out, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  h_peak->re = res[0]; h_peak->im = res[1];
+  if (h_index) *h_index = res[2];
+  if (h_avgpwr) *h_avgpwr = res[3];
+  return TRXSIG_OK;
+}
+
+namespace {
+int elementwise_batch(trxsig_ctx *c, const char *who, int op, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B,
+                      int max_len, const trxsig_c32 *d_scale, int real_only) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_x, d_off, d_len, B) || max_len <= 0 || (op == 0 && B > 0 && !d_scale)) return fail(c, TRXSIG_EINVAL, who);
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_elementwise(c->stream, op, c->d_tables, (trx_c32 *)d_x, d_off, d_len, B, max_len, (const trx_c32 *)d_scale,
+                                   real_only != 0));
+  return TRXSIG_OK;
+}
+}  // namespace
+
+int trxsig_scale_vector_batch(trxsig_ctx *c, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                              const trxsig_c32 *d_scale, int real_only) {
+  return elementwise_batch(c, "trxsig_scale_vector_batch: bad argument", 0, d_x, d_off, d_len, B, max_len, d_scale, real_only);
+}
+int trxsig_gmsk_rotate_batch(trxsig_ctx *c, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                             int reverse, int real_only) {
+  return elementwise_batch(c, "trxsig_gmsk_rotate_batch: bad argument", reverse ? 2 : 1, d_x, d_off, d_len, B, max_len, nullptr,
+                           real_only);
+}
+int trxsig_vector_slicer_batch(trxsig_ctx *c, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len) {
+  return elementwise_batch(c, "trxsig_vector_slicer_batch: bad argument", 3, d_x, d_off, d_len, B, max_len, nullptr, 0);
+}
+
+int trxsig_decimate_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                          int factor, trxsig_c32 *d_out, const int32_t *d_out_off) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || max_len <= 0 || factor <= 1 || (B > 0 && (!d_out || !d_out_off)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_decimate_batch: bad argument (decimateVector returns NULL for a factor <= 1)");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_decimate(c->stream, (const trx_c32 *)d_in, d_off, d_len, B, max_len, factor, (trx_c32 *)d_out, d_out_off));
+  return TRXSIG_OK;
+}
+
+int trxsig_elementwise_host(trxsig_ctx *c, int op, trxsig_c32 *h_x, int n, trxsig_c32 scale, int real_only) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0 || op < 0 || op > 3) return fail(c, TRXSIG_EINVAL, "trxsig_elementwise_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  int32_t meta[4] = {0, n, 0, 0};
+  std::memcpy(&meta[2], &scale, 8);
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 16, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = elementwise_batch(c, "trxsig_elementwise_host: bad argument", op, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m),
+                         (int32_t *)(d + o_m) + 1, 1, n, (trxsig_c32 *)((int32_t *)(d + o_m) + 2), real_only);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_x, d + o_x, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+int trxsig_decimate_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, int factor, trxsig_c32 *h_out) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0 || factor <= 1 || !h_out || n / factor <= 0) return fail(c, TRXSIG_EINVAL, "trxsig_decimate_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const int nout = n / factor;
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16), o_out = s.take(8 * (size_t)nout);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  const int32_t meta[3] = {0, n, 0};
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_decimate_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1, n, factor,
+                             (trxsig_c32 *)(d + o_out), (int32_t *)(d + o_m) + 2);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_out, 8 * (size_t)nout, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return nout;
 }
 
 }  // extern "C"

@@ -42,6 +42,23 @@ hipError_t trx_launch_normal_chain(hipStream_t st, int sps, const TrxTables *dT,
                                    uint8_t *hard, int nsoft, int stride, void *det, unsigned *status, int lag,
                                    unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg = 0);
 
+// free-standing vector primitives of sigProcLib.h (trxsig_prim.hip); op: 0 scaleVector, 1 GMSKRotate, 2 GMSKReverseRotate,
+// 3 vectorSlicer
+int trx_convolve_out_len(int La, int Lb, int span, int cust_len);
+hipError_t trx_launch_convolve(hipStream_t st, const trx_c32 *a, const int32_t *a_off, const int32_t *a_len, int B, int max_out,
+                               const trx_c32 *b, int Lb, int span, int flags, int correlate, int cust_start, int cust_len,
+                               trx_c32 *out, const int32_t *out_off);
+hipError_t trx_launch_delay_vector(hipStream_t st, const TrxTables *dT, const trx_c32 *in, const int32_t *off, const int32_t *len,
+                                   int B, const float *delay, int real_only, trx_c32 *out);
+hipError_t trx_launch_interpolate_point(hipStream_t st, const TrxTables *dT, const trx_c32 *in, const int32_t *off,
+                                        const int32_t *len, int B, const float *ix, int real_only, trx_c32 *out);
+hipError_t trx_launch_peak_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *in, const int32_t *off, const int32_t *len,
+                                  int B, trx_c32 *peak, float *index, float *avgpwr);
+hipError_t trx_launch_elementwise(hipStream_t st, int op, const TrxTables *dT, trx_c32 *x, const int32_t *off, const int32_t *len,
+                                  int B, int max_len, const trx_c32 *scale, int real_only);
+hipError_t trx_launch_decimate(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, int max_len,
+                               int factor, trx_c32 *out, const int32_t *out_off);
+
 // RACH detect: ws = workspace of trx_rach_rec_floats(sps) * Bpad floats
 int trx_rach_rec_floats(int sps);
 hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,

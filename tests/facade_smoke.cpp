@@ -9,7 +9,8 @@
 
 int main(int argc, char **argv) {
   const int sps = argc > 1 ? std::atoi(argv[1]) : 4;
-  if (!sigProcLibSetup(sps)) { std::fprintf(stderr, "sigProcLibSetup failed (no gfx950 device?)\n"); return 2; }
+  sigProcLibSetup(sps);
+  if (!sigProcLibReady()) { std::fprintf(stderr, "sigProcLibSetup failed (no gfx950 device?)\n"); return 2; }
   signalVector *gsmPulse = generateGSMPulse(2, sps);
   if (!gsmPulse) return 3;
   generateRACHSequence(*gsmPulse, sps);

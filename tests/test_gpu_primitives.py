@@ -1,0 +1,147 @@
+"""GPU parity of sigProcLib.h's free-standing vector primitives (csrc/trxsig_prim.hip: convolve / correlate in every span
+type and real/complex form, delayVector, interpolatePoint, peakDetect, scaleVector, GMSKRotate / GMSKReverseRotate,
+vectorSlicer, decimateVector) through the C-ABI: the golden vectors captured from the real reference
+(tests/golden/primitives.npz) and seeded random / ragged / degenerate inputs against the pinned oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+import _pkg
+import oraclebind
+from util import assert_beq, assert_veq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _pkg.load()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = {s: pkg.TrxSig(s, 0) for s in (1, 4)}
+    for v in c.values():
+        v.use_torch_stream()
+    return c
+
+
+def cn(rng, n, scale=1.0):
+    return (scale * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+
+
+def test_golden_primitives(ctx, golden):
+    g = golden("primitives.npz")
+    t = ctx[4]
+    for i in range(int(g["nconv"])):
+        span, ar, br = (int(v) for v in g["conv%d_meta" % i])
+        a, b = g["conv%d_a" % i], g["conv%d_b" % i]
+        assert_beq(t.convolve_host(a, b, span, ar, br), g["conv%d_conv" % i], "convolve %d" % i)
+        assert_beq(t.convolve_host(a, b, span, ar, br, correlate=True), g["conv%d_corr" % i], "correlate %d" % i)
+    pos = 0
+    for k, (off, n) in enumerate(zip(g["delay_off"], g["delay_len"])):
+        x = g["delay_x"][off:off + n]
+        assert_beq(t.delay_vector_host(x, g["delay_d"][k]), g["delay_y"][pos:pos + n], "delayVector %d" % k)
+        pos += n
+        assert t.interpolate_point_host(x, g["interp_ix"][k]) == g["interp_y"][k], k
+        v, ix, avg = t.peak_detect_host(x)
+        assert v == g["peak_val"][k] and ix == g["peak_idx"][k] and avg == g["peak_avg"][k], k
+    v, ix, avg = t.peak_detect_host(np.zeros(40, np.complex64))      # all-zero: maxIndex -1 (sigProcLib.cpp:669)
+    assert_beq(np.array([v.real, v.imag, ix, avg], np.float32), g["peak_zero"])
+
+
+@pytest.mark.parametrize("sps", [1, 4])
+def test_random_primitives_vs_oracle(ctx, sps):
+    o = oraclebind.Oracle(sps)
+    t = ctx[sps]
+    rng = np.random.default_rng(77 + sps)
+    for trial in range(24):
+        na, nb = int(rng.integers(1, 700)), int(rng.integers(1, 170))
+        a, b = cn(rng, na), cn(rng, nb)
+        span = trial % 5
+        ar, br = bool(trial & 1), bool(trial & 2)
+        if ar: a = a.real.astype(np.complex64)
+        if br: b = b.real.astype(np.complex64)
+        assert_beq(t.convolve_host(a, b, span, ar, br), o.convolve(a, b, span, ar, br), "convolve span %d" % span)
+        assert_beq(t.convolve_host(a, b, span, ar, br, correlate=True), o.correlate(a, b, span, ar, br), "correlate span %d" % span)
+    # the windowed CUSTOM span of the 52 MHz variant (Transceiver52M/sigProcLib.cpp:301-304)
+    a, b = cn(rng, 156), cn(rng, 16)
+    assert_beq(t.convolve_host(a, b, 5, cust_start=58, cust_len=9), o.convolve(a, b, 5, start=58, length=9), "CUSTOM span")
+    for trial in range(40):
+        n = int(rng.integers(2, 700))
+        x = cn(rng, n, 100.0)
+        d = np.float32(rng.uniform(-30, 30))
+        if trial % 5 == 0: d = np.float32(np.round(d))                     # integer delay: no filtering (:582)
+        if trial % 5 == 1: d = np.float32(np.round(d) + 0.009)             # |frac| <= 1e-2: still none
+        if trial % 7 == 0: d = np.float32(d * 40)                          # shifted right out of the vector
+        assert_beq(t.delay_vector_host(x, d), o.delay_vector(x, d), "delayVector n %d d %g" % (n, d))
+        ix = np.float32(rng.uniform(-25, n + 25))                          # incl. the ranges the clamps of :643-646 open up
+        assert t.interpolate_point_host(x, ix) == o.interpolate_point(x, ix), (n, ix)
+        if n >= 3:
+            v, i, avg = t.peak_detect_host(x)
+            ov, oi, oavg = o.peak_detect(x)
+            assert v == ov and i == oi and avg == oavg, (n, v, ov, i, oi, avg, oavg)
+        s = np.complex64(complex(rng.normal(), rng.normal()))
+        assert_beq(t.elementwise_host(0, x, s), o.scale_vector(x, s), "scaleVector")
+        m = min(n, 157 * sps)
+        assert_beq(t.elementwise_host(1, x[:m]), o.gmsk_rotate(x[:m]), "GMSKRotate")
+        assert_beq(t.elementwise_host(2, x[:m]), o.gmsk_rotate(x[:m], reverse=True), "GMSKReverseRotate")
+    # peaks at the ends and flat inputs: the bisection's clamped interpolation ranges
+    for x in (np.r_[np.complex64(50), cn(rng, 30)], np.r_[cn(rng, 30), np.complex64(50)], np.full(20, 3 + 4j, np.complex64),
+              np.array([1, 2], np.complex64)):
+        x = np.ascontiguousarray(x, np.complex64)
+        v, i, avg = t.peak_detect_host(x)
+        ov, oi, oavg = o.peak_detect(x)
+        assert v == ov and i == oi and avg == oavg, (x.size, v, ov, i, oi)
+    # vectorSlicer (:507-519) and decimateVector (:1039-1053): closed forms
+    x = cn(rng, 333, 1.5)
+    want = np.clip((0.5 * (x.real.astype(np.float64) + np.float64(np.float32(1.0)))).astype(np.float32), 0, 1)
+    got = t.elementwise_host(3, x)
+    assert_beq(got.real.copy(), want, "vectorSlicer"); assert not got.imag.any()
+    for f in (2, 3, 4):
+        n = 120 * f
+        assert_beq(t.decimate_host(x[:n] if n <= x.size else np.resize(x, n), f), (x[:n] if n <= x.size else np.resize(x, n))[::f], "decimateVector")
+
+
+def test_batch_forms_ragged(pkg, ctx):
+    """The device-pointer batch entry points on ragged batches: same values as vector by vector through the oracle."""
+    import torch
+    t = ctx[4]; o = oraclebind.Oracle(4)
+    rng = np.random.default_rng(5)
+    B = 37
+    lens = rng.integers(1, 640, B).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    x = cn(rng, int(lens.sum()), 10.0)
+    b = cn(rng, 41)
+    dev = torch.device("cuda:0")
+    dx = torch.from_numpy(x.view(np.float32).copy()).to(dev); doff = torch.from_numpy(off).to(dev); dlen = torch.from_numpy(lens).to(dev)
+    db = torch.from_numpy(b.view(np.float32).copy()).to(dev)
+    L = t.L
+    for span in range(5):
+        olen = np.array([L.trxsig_convolve_out_len(int(n), 41, span, 0) for n in lens], np.int32)
+        ooff = np.concatenate([[0], np.cumsum(olen)[:-1]]).astype(np.int32)
+        dout = torch.zeros(int(olen.sum()) * 2, device=dev); dooff = torch.from_numpy(ooff).to(dev)
+        t._chk(L.trxsig_convolve_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, int(lens.max()), db.data_ptr(), 41, span,
+                                       0, 1, 0, 0, dout.data_ptr(), dooff.data_ptr()), "convolve_batch")
+        got = dout.cpu().numpy().view(np.complex64)
+        for i in range(B):
+            assert_beq(got[ooff[i]:ooff[i] + olen[i]], o.correlate(x[off[i]:off[i] + lens[i]], b, span), "span %d vector %d" % (span, i))
+    delay = rng.uniform(-20, 20, B).astype(np.float32)
+    ddelay = torch.from_numpy(delay).to(dev); dy = torch.zeros_like(dx)
+    t._chk(L.trxsig_delay_vector_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, ddelay.data_ptr(), 0, dy.data_ptr()), "delay")
+    pk = torch.zeros(B, 2, device=dev); ix = torch.zeros(B, device=dev); av = torch.zeros(B, device=dev)
+    t._chk(L.trxsig_peak_detect_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, pk.data_ptr(), ix.data_ptr(), av.data_ptr()), "peak")
+    y = dy.cpu().numpy().view(np.complex64); pk = pk.cpu().numpy().view(np.complex64).ravel(); ix = ix.cpu().numpy(); av = av.cpu().numpy()
+    for i in range(B):
+        xi = x[off[i]:off[i] + lens[i]]
+        assert_beq(y[off[i]:off[i] + lens[i]], o.delay_vector(xi, delay[i]), "delay %d" % i)
+        if lens[i] >= 2:
+            ov, oi, oavg = o.peak_detect(xi)
+            assert pk[i] == ov and ix[i] == oi and av[i] == oavg, i
+    # bad arguments are refused, not launched
+    with pytest.raises(pkg.TrxSigError):
+        t._chk(L.trxsig_delay_vector_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, ddelay.data_ptr(), 0, dx.data_ptr()), "in place")
+    with pytest.raises(pkg.TrxSigError):
+        t._chk(L.trxsig_convolve_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, int(lens.max()), db.data_ptr(), 41, 9,
+                                       0, 0, 0, 0, dy.data_ptr(), doff.data_ptr()), "span 9")
