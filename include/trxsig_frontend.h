@@ -1,0 +1,67 @@
+/* trxsig_frontend.h -- the RadioInterface's sample plumbing on the device, in C (C-ABI of libtrxsig):
+ *   trxsig_rxfe   RadioInterface::pullBuffer + driveReceiveRadio (Transceiver/radioInterface.cpp:197-273, 359-401) for S
+ *                 independent ARFCN streams on one GPU: int16 I/Q chunks of OUTCHUNK = 864 samples at 400 kS/s ->
+ *                 unUSRPifyVector (I/Q swapped unless told otherwise, :91-116) -> [192-sample history | chunk] ->
+ *                 polyphaseResampleVector(P = 65*sps, Q = 96, rcvLPF) (:244-246) with the first INHISTORY = 130*sps
+ *                 outputs dropped (:249-252) -> the stream's receive buffer -> bursts of (156 + (TN % 4 == 0)) * sps samples
+ *                 (157-156-156-156, :370-394) handed out as offsets into that buffer, ready for the batch detectors of
+ *                 trxsig.h.  One fused kernel per push (conversion, filter and placement; window and taps staged in LDS).
+ *   trxsig_txbe   RadioInterface::driveTransmitRadio + pushBuffer (:123-194, 337-357): modulated bursts are appended to
+ *                 the stream's send buffer; whenever it holds whole chunks of INCHUNK = 585*sps samples,
+ *                 [INHISTORY history | chunks] -> polyphaseResampleVector(P = 96, Q = 65*sps, sendLPF) (:141-144) ->
+ *                 scaleVector(gain = 13500) (:148) -> USRPifyVector (:74-89), first OUTHISTORY = 192 outputs dropped (:165).
+ *                 One fused kernel per pop (filter, gain, int16 pack).
+ * All buffers are device memory owned by the object (per-stream linear buffers; no reallocation per chunk); sample values
+ * are the reference's bit for bit (tests/test_gpu_config4.py, tests/test_gpu_txchain.py).  The USRP itself (the source /
+ * sink of the int16 samples) and the GSM clock are the caller's (component 5 is out of scope).
+ * Every function returns TRXSIG_OK (0) or a negative TRXSIG_E* code; trxsig_last_error(ctx) has the text. */
+#ifndef TRXSIG_FRONTEND_H
+#define TRXSIG_FRONTEND_H
+
+#include "trxsig.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRXSIG_OUTRATE 96                      /* radioInterface.h:37 */
+#define TRXSIG_OUTCHUNK (9 * TRXSIG_OUTRATE)   /* :41  864 */
+#define TRXSIG_OUTHISTORY (2 * TRXSIG_OUTRATE) /* :39  192 */
+
+typedef struct trxsig_rxfe trxsig_rxfe;
+typedef struct trxsig_txbe trxsig_txbe;
+
+/* h_lpf: the L (normally 961, createLPF(cutoff, 961, 65*sps): radioInterface.cpp:230-234) normalised taps, host memory.
+ * max_chunks: the most chunks one push may carry (sizes the buffers).  start_tn: TN of the first burst cut. */
+int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *ctx, int n_streams, int max_chunks, const float *h_lpf, int L,
+                       int swap_iq, int start_tn);
+void trxsig_rxfe_destroy(trxsig_rxfe *fe);
+/* d_iq: int16 I/Q pairs, [n_streams][n_chunks * 864][2] (device).  Every chunk is filtered behind the 192 samples
+ * that precede it in its stream (the previous push's tail for the first one), exactly as pullBuffer does chunk by chunk.
+ * Bursts handed out by an earlier trxsig_rxfe_pop stay valid until this call. */
+int trxsig_rxfe_push(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks);
+/* Cuts every stream's buffer into as many bursts as it holds ("while (rcvSz > burst size)", :375): *n_bursts per stream,
+ * burst j of stream s is entry s * *n_bursts + j of *d_offset / *d_length (samples, into *d_samples).  h_tn[j] (cap_tn
+ * entries at least *n_bursts; may be NULL) = the burst's TN (the same schedule on every stream).  The pointers belong to
+ * the object and stay valid until the next push. */
+int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t **d_offset, const int32_t **d_length,
+                    int32_t *h_tn, int cap_tn, int *n_bursts);
+int trxsig_rxfe_pending(const trxsig_rxfe *fe);   /* samples per stream not yet cut into bursts */
+
+/* h_lpf: the L (normally 651, createLPF(cutoff, 651, 96): radioInterface.cpp:134-138) normalised taps.  max_bursts: the
+ * most bursts per stream one push may carry. */
+int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *ctx, int n_streams, int max_bursts, const float *h_lpf, int L, float gain);
+void trxsig_txbe_destroy(trxsig_txbe *be);
+/* modulateBurst (+ addRadioVector's power scaling when d_gain != NULL) of n_bursts bursts per stream, appended to the send
+ * buffers: d_bits [n_streams][n_bursts][148] (one bit per byte), h_guard[n_bursts] guard symbols per burst (host; the same
+ * schedule on every stream: 8 + (TN % 4 == 0), Transceiver.cpp:105), d_gain [n_streams][n_bursts] or NULL. */
+int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_t *h_guard, const float *d_gain, int n_bursts);
+/* pushBuffer for every stream: *n_samples int16 I/Q pairs per stream at *d_iq + s * *stream_stride pairs (device; valid
+ * until the next pop), 0 while less than one chunk is buffered. */
+int trxsig_txbe_pop(trxsig_txbe *be, const int16_t **d_iq, int64_t *stream_stride, int *n_samples);
+int trxsig_txbe_pending(const trxsig_txbe *be);   /* modulated samples per stream waiting for a whole chunk */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRXSIG_FRONTEND_H */

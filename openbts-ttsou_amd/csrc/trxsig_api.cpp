@@ -99,6 +99,12 @@ int fail(trxsig_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
   return code;
 }
 
+}  // namespace
+// for the other host translation units of the library (trxsig_frontend.cpp)
+int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e) { return fail(c, code, what, e); }
+TrxProfiler *trx_ctx_profiler(trxsig_ctx *c) { return c ? c->prof : nullptr; }
+namespace {
+
 #define HIPCHK(c, call)                                          \
   do {                                                           \
     hipError_t e_ = (call);                                      \

@@ -1,0 +1,271 @@
+// trxsig_frontend.cpp -- include/trxsig_frontend.h: RadioInterface's receive front end (pullBuffer + driveReceiveRadio)
+// and transmit back end (driveTransmitRadio + pushBuffer) for S independent ARFCN streams, as host objects that own
+// per-stream linear device buffers and enqueue one fused kernel per push / pop (k_resample, trxsig_tx.hip).  The host
+// side only keeps read / write positions and the TN schedule; no sample ever visits the host.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "trxsig_frontend.h"
+#include "trxsig_launch.h"
+
+// context internals (trxsig_api.cpp)
+int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e);
+TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
+
+namespace {
+#define FE_HIP(c, call)                                                        \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) return trx_ctx_fail((c), TRXSIG_EHIP, #call, e_);    \
+  } while (0)
+
+struct Guard {
+  int prev = -1;
+  explicit Guard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+  ~Guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+inline int burst_len(int tn, int sps) { return (156 + ((tn & 3) == 0)) * sps; }   // radioInterface.cpp:370-378
+}  // namespace
+
+struct trxsig_rxfe {
+  trxsig_ctx *c = nullptr;
+  int S = 0, sps = 0, P = 0, L = 0, swap = 1, max_chunks = 0, tn = 0;
+  int n_in = 0, n_out = 0, skip = 0, per_chunk = 0;         // window in, window out, INHISTORY, kept outputs per chunk
+  long long stride = 0;                                     // samples per stream in the receive buffer
+  int rd = 0, wr = 0;                                       // unsliced samples are [rd, wr) of every stream's row
+  trx_c32 *d_rcv = nullptr, *d_tmp = nullptr;
+  short2 *d_hist = nullptr;
+  float *d_lpf = nullptr;
+  int32_t *d_idx = nullptr;                                 // off[S*nb] then len[S*nb]
+  int idx_cap = 0;
+};
+
+struct trxsig_txbe {
+  trxsig_ctx *c = nullptr;
+  int S = 0, sps = 0, Q = 0, L = 0, inchunk = 0, inhist = 0, max_bursts = 0;
+  float gain = 13500.0f;
+  long long stride = 0, iq_stride = 0;
+  int fill = 0;                                             // modulated samples behind the history, per stream
+  int cur = 0;                                              // which of the two send buffers is live
+  trx_c32 *d_send[2] = {nullptr, nullptr};                  // [S][inhist + capacity]: history first
+  float *d_lpf = nullptr;
+  short2 *d_iq = nullptr;
+  int32_t *d_meta = nullptr;                                // guard[S*nb] then off[S*nb]
+};
+
+extern "C" {
+
+int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_chunks, const float *h_lpf, int L, int swap_iq,
+                       int start_tn) {
+  if (!out) return TRXSIG_EINVAL;
+  *out = nullptr;
+  if (!c) return TRXSIG_EINVAL;
+  if (n_streams <= 0 || n_streams > 65535 || max_chunks <= 0 || max_chunks > 65535 || !h_lpf || L <= 0 || start_tn < 0 || start_tn > 7)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create: bad argument", hipSuccess);
+  trxsig_rxfe *fe = new (std::nothrow) trxsig_rxfe;
+  if (!fe) return TRXSIG_ENOMEM;
+  fe->c = c; fe->S = n_streams; fe->sps = trxsig_sps(c); fe->P = 65 * fe->sps; fe->L = L; fe->swap = swap_iq != 0;
+  fe->max_chunks = max_chunks; fe->tn = start_tn;
+  fe->n_in = TRXSIG_OUTHISTORY + TRXSIG_OUTCHUNK;
+  fe->n_out = trxsig_resample_out_len(fe->n_in, fe->P, TRXSIG_OUTRATE);
+  fe->skip = 2 * fe->P;                                     // INHISTORY (radioInterface.h:38)
+  fe->per_chunk = fe->n_out - fe->skip;
+  fe->stride = ((long long)157 * fe->sps + (long long)max_chunks * fe->per_chunk + 63) & ~63LL;
+  Guard g(trxsig_device(c));
+  const size_t rcv_b = sizeof(trx_c32) * (size_t)fe->stride * fe->S, tmp_b = sizeof(trx_c32) * (size_t)157 * fe->sps * fe->S;
+  if (hipMalloc((void **)&fe->d_rcv, rcv_b) != hipSuccess || hipMalloc((void **)&fe->d_tmp, tmp_b) != hipSuccess ||
+      hipMalloc((void **)&fe->d_hist, sizeof(short2) * TRXSIG_OUTHISTORY * (size_t)fe->S) != hipSuccess ||
+      hipMalloc((void **)&fe->d_lpf, sizeof(float) * (size_t)L) != hipSuccess ||
+      hipMemset(fe->d_hist, 0, sizeof(short2) * TRXSIG_OUTHISTORY * (size_t)fe->S) != hipSuccess ||   // rcvHistory->fill(0) (:238-241)
+      hipMemcpy(fe->d_lpf, h_lpf, sizeof(float) * (size_t)L, hipMemcpyHostToDevice) != hipSuccess) {
+    trxsig_rxfe_destroy(fe);
+    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);
+  }
+  *out = fe;
+  return TRXSIG_OK;
+}
+
+void trxsig_rxfe_destroy(trxsig_rxfe *fe) {
+  if (!fe) return;
+  {
+    Guard g(trxsig_device(fe->c));
+    (void)hipFree(fe->d_rcv); (void)hipFree(fe->d_tmp); (void)hipFree(fe->d_hist); (void)hipFree(fe->d_lpf); (void)hipFree(fe->d_idx);
+  }
+  delete fe;
+}
+
+int trxsig_rxfe_pending(const trxsig_rxfe *fe) { return fe ? fe->wr - fe->rd : TRXSIG_EINVAL; }
+
+int trxsig_rxfe_push(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks) {
+  if (!fe) return TRXSIG_EINVAL;
+  trxsig_ctx *c = fe->c;
+  if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: bad argument", hipSuccess);
+  Guard g(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  const int left = fe->wr - fe->rd;
+  if (fe->rd > 0 && left <= 157 * fe->sps) {
+    // the uncut tail (less than a burst after a pop) moves to the front of every row: two small strided copies
+    if (left > 0) {
+      FE_HIP(c, hipMemcpy2DAsync(fe->d_tmp, sizeof(trx_c32) * (size_t)157 * fe->sps, fe->d_rcv + fe->rd, sizeof(trx_c32) * (size_t)fe->stride,
+                                 sizeof(trx_c32) * (size_t)left, fe->S, hipMemcpyDeviceToDevice, st));
+      FE_HIP(c, hipMemcpy2DAsync(fe->d_rcv, sizeof(trx_c32) * (size_t)fe->stride, fe->d_tmp, sizeof(trx_c32) * (size_t)157 * fe->sps,
+                                 sizeof(trx_c32) * (size_t)left, fe->S, hipMemcpyDeviceToDevice, st));
+    }
+    fe->rd = 0; fe->wr = left;
+  }
+  if ((long long)fe->wr + (long long)n_chunks * fe->per_chunk > fe->stride)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: receive buffers full (call trxsig_rxfe_pop first)", hipSuccess);
+  TrxResampleArgs a = {};
+  a.in = d_iq; a.in_stride = (long long)n_chunks * TRXSIG_OUTCHUNK; a.hist = fe->d_hist; a.hist_len = TRXSIG_OUTHISTORY;
+  a.n = fe->n_in; a.win_step = TRXSIG_OUTCHUNK; a.swap = fe->swap;
+  a.lpf = fe->d_lpf; a.L = fe->L; a.P = fe->P; a.Q = TRXSIG_OUTRATE;
+  a.o_skip = fe->skip; a.n_out = fe->n_out;
+  a.out = fe->d_rcv + fe->wr; a.out_stride = fe->stride; a.out_win_step = fe->per_chunk;
+  FE_HIP(c, trx_launch_resample_ex(st, a, fe->S, n_chunks, true, false, trx_ctx_profiler(c)));
+  // rcvHistory = the last OUTHISTORY samples received (:259)
+  const short2 *tail = reinterpret_cast<const short2 *>(d_iq) + ((size_t)n_chunks * TRXSIG_OUTCHUNK - TRXSIG_OUTHISTORY);
+  FE_HIP(c, hipMemcpy2DAsync(fe->d_hist, sizeof(short2) * TRXSIG_OUTHISTORY, tail, sizeof(short2) * (size_t)n_chunks * TRXSIG_OUTCHUNK,
+                             sizeof(short2) * TRXSIG_OUTHISTORY, fe->S, hipMemcpyDeviceToDevice, st));
+  fe->wr += n_chunks * fe->per_chunk;
+  return TRXSIG_OK;
+}
+
+int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t **d_offset, const int32_t **d_length, int32_t *h_tn,
+                    int cap_tn, int *n_bursts) {
+  if (!fe) return TRXSIG_EINVAL;
+  trxsig_ctx *c = fe->c;
+  if (!d_samples || !d_offset || !d_length || !n_bursts) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_pop: bad argument", hipSuccess);
+  int nb = 0, pos = 0, tn = fe->tn;
+  const int avail = fe->wr - fe->rd;
+  while (avail - pos > burst_len(tn, fe->sps)) {            // "while (rcvSz > burst size)" (:375)
+    if (h_tn && nb < cap_tn) h_tn[nb] = tn;
+    pos += burst_len(tn, fe->sps); tn = (tn + 1) & 7; nb++;
+  }
+  if (h_tn && nb > cap_tn) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_pop: h_tn too small", hipSuccess);
+  *n_bursts = nb;
+  *d_samples = (const trxsig_c32 *)fe->d_rcv;
+  if (nb == 0) { *d_offset = *d_length = nullptr; return TRXSIG_OK; }
+  Guard g(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  if (fe->S * nb > fe->idx_cap) {
+    FE_HIP(c, hipStreamSynchronize(st));
+    (void)hipFree(fe->d_idx); fe->d_idx = nullptr; fe->idx_cap = 0;
+    const int cap = fe->S * nb + 1024;
+    FE_HIP(c, hipMalloc((void **)&fe->d_idx, sizeof(int32_t) * 2 * (size_t)cap));
+    fe->idx_cap = cap;
+  }
+  int32_t *off = fe->d_idx, *len = fe->d_idx + fe->idx_cap;
+  FE_HIP(c, trx_launch_burst_index(st, fe->S, nb, fe->stride, fe->rd, fe->tn, fe->sps, off, len));
+  *d_offset = off; *d_length = len;
+  fe->rd += pos; fe->tn = tn;
+  return TRXSIG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *c, int n_streams, int max_bursts, const float *h_lpf, int L, float gain) {
+  if (!out) return TRXSIG_EINVAL;
+  *out = nullptr;
+  if (!c) return TRXSIG_EINVAL;
+  if (n_streams <= 0 || n_streams > 65535 || max_bursts <= 0 || !h_lpf || L <= 0)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_create: bad argument", hipSuccess);
+  trxsig_txbe *be = new (std::nothrow) trxsig_txbe;
+  if (!be) return TRXSIG_ENOMEM;
+  be->c = c; be->S = n_streams; be->sps = trxsig_sps(c); be->Q = 65 * be->sps; be->L = L; be->gain = gain;
+  be->inchunk = 9 * be->Q; be->inhist = 2 * be->Q; be->max_bursts = max_bursts;
+  // room for one chunk of left-over plus one push of the longest bursts
+  const long long cap = (long long)be->inchunk + (long long)max_bursts * 157 * be->sps;
+  be->stride = (be->inhist + cap + 63) & ~63LL;
+  be->iq_stride = ((long long)trxsig_resample_out_len((int)be->stride, TRXSIG_OUTRATE, be->Q) + 63) & ~63LL;
+  Guard g(trxsig_device(c));
+  bool ok = true;
+  for (int k = 0; k < 2 && ok; k++) {
+    ok = hipMalloc((void **)&be->d_send[k], sizeof(trx_c32) * (size_t)be->stride * be->S) == hipSuccess &&
+         hipMemset(be->d_send[k], 0, sizeof(trx_c32) * (size_t)be->stride * be->S) == hipSuccess;   // sendHistory starts as zeros
+  }
+  ok = ok && hipMalloc((void **)&be->d_lpf, sizeof(float) * (size_t)L) == hipSuccess &&
+       hipMemcpy(be->d_lpf, h_lpf, sizeof(float) * (size_t)L, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMalloc((void **)&be->d_iq, sizeof(short2) * (size_t)be->iq_stride * be->S) == hipSuccess &&
+       hipMalloc((void **)&be->d_meta, sizeof(int32_t) * 2 * (size_t)max_bursts * be->S) == hipSuccess;
+  if (!ok) {
+    trxsig_txbe_destroy(be);
+    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_txbe_create: device allocation failed", hipSuccess);
+  }
+  *out = be;
+  return TRXSIG_OK;
+}
+
+void trxsig_txbe_destroy(trxsig_txbe *be) {
+  if (!be) return;
+  {
+    Guard g(trxsig_device(be->c));
+    (void)hipFree(be->d_send[0]); (void)hipFree(be->d_send[1]); (void)hipFree(be->d_lpf); (void)hipFree(be->d_iq); (void)hipFree(be->d_meta);
+  }
+  delete be;
+}
+
+int trxsig_txbe_pending(const trxsig_txbe *be) { return be ? be->fill : TRXSIG_EINVAL; }
+
+int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_t *h_guard, const float *d_gain, int n_bursts) {
+  if (!be) return TRXSIG_EINVAL;
+  trxsig_ctx *c = be->c;
+  if (!d_bits || !h_guard || n_bursts <= 0 || n_bursts > be->max_bursts)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: bad argument", hipSuccess);
+  long long tot = 0;
+  for (int j = 0; j < n_bursts; j++) {
+    if (h_guard[j] < 0 || h_guard[j] > 9) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: guard must be 0..9", hipSuccess);
+    tot += (long long)be->sps * (148 + h_guard[j]);
+  }
+  if (be->inhist + be->fill + tot > be->stride)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: send buffers full (call trxsig_txbe_pop first)", hipSuccess);
+  Guard g(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  const int B = be->S * n_bursts;
+  std::vector<int32_t> meta(2 * (size_t)B);
+  for (int s = 0; s < be->S; s++) {
+    long long pos = (long long)s * be->stride + be->inhist + be->fill;
+    for (int j = 0; j < n_bursts; j++) {
+      meta[(size_t)s * n_bursts + j] = h_guard[j];
+      meta[(size_t)B + (size_t)s * n_bursts + j] = (int32_t)pos;
+      pos += (long long)be->sps * (148 + h_guard[j]);
+    }
+  }
+  FE_HIP(c, hipMemcpyAsync(be->d_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, st));
+  FE_HIP(c, hipStreamSynchronize(st));                      // meta is a local
+  int rc = trxsig_modulate_batch(c, d_bits, be->d_meta, d_gain, B, (trxsig_c32 *)be->d_send[be->cur], be->d_meta + B);
+  if (rc != TRXSIG_OK) return rc;
+  be->fill += (int)tot;
+  return TRXSIG_OK;
+}
+
+int trxsig_txbe_pop(trxsig_txbe *be, const int16_t **d_iq, int64_t *stream_stride, int *n_samples) {
+  if (!be) return TRXSIG_EINVAL;
+  trxsig_ctx *c = be->c;
+  if (!d_iq || !stream_stride || !n_samples) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_pop: bad argument", hipSuccess);
+  *d_iq = (const int16_t *)be->d_iq; *stream_stride = be->iq_stride; *n_samples = 0;
+  const int nch = be->fill / be->inchunk;                   // "if (sendBuffer->size() < INCHUNK) return" (:125-127)
+  if (nch == 0) return TRXSIG_OK;
+  const int ntr = nch * be->inchunk;                        // truncatedBuffer (:131-132)
+  const int n_in = be->inhist + ntr;                        // signalVector(*sendHistory, *truncatedBuffer) (:141)
+  const int n_out = trxsig_resample_out_len(n_in, TRXSIG_OUTRATE, be->Q);
+  Guard g(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  TrxResampleArgs a = {};
+  a.in = be->d_send[be->cur]; a.in_stride = be->stride; a.n = n_in;
+  a.lpf = be->d_lpf; a.L = be->L; a.P = TRXSIG_OUTRATE; a.Q = be->Q;
+  a.o_skip = TRXSIG_OUTHISTORY; a.n_out = n_out;           // writeSamples(resampledVectorShort + OUTHISTORY*2, size - OUTHISTORY) (:165-166)
+  a.out = be->d_iq; a.out_stride = be->iq_stride; a.gain = be->gain;
+  FE_HIP(c, trx_launch_resample_ex(st, a, be->S, 1, false, true, trx_ctx_profiler(c)));
+  // sendHistory = the last INHISTORY samples sent (:183-184), the rest of sendBuffer follows it (:187-191): into the other buffer
+  const int keep = be->inhist + be->fill - ntr;             // history + left-over, contiguous at [ntr, ntr + keep)
+  FE_HIP(c, hipMemcpy2DAsync(be->d_send[be->cur ^ 1], sizeof(trx_c32) * (size_t)be->stride, be->d_send[be->cur] + ntr,
+                             sizeof(trx_c32) * (size_t)be->stride, sizeof(trx_c32) * (size_t)keep, be->S, hipMemcpyDeviceToDevice, st));
+  be->cur ^= 1;
+  be->fill -= ntr;
+  *n_samples = n_out - TRXSIG_OUTHISTORY;
+  return TRXSIG_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 // shared device code in trxsig_dev.h, trxsig_corr.h, trxsig_bisect.h, trxsig_demod.h.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 #include <stdint.h>
 
 #include "trxsig.h"
@@ -88,6 +89,22 @@ hipError_t trx_launch_modulate(hipStream_t st, int sps, const TrxTables *dT, con
 hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long long in_stride, int S, int P, int Q,
                                const float *lpf, int L, trx_c32 *out, long long out_stride, int nout,
                                TrxProfiler *prof);
+// the tiled resampler in full (trxsig_tx.hip): int16 I/Q in with history windows (RadioInterface::pullBuffer) or int16 out
+// with gain (pushBuffer); see k_resample.  OB is filled in by the launcher.
+struct TrxResampleArgs {
+  const void *in; long long in_stride;                     // stream s at in + s*in_stride (elements: trx_c32 or int16 pairs)
+  const short2 *hist; int hist_len;                        // int16 input: the hist_len samples before each stream's start
+  int n, win_step, swap;                                   // samples per window, start-to-start distance of windows, I/Q swap
+  const float *lpf; int L, P, Q;
+  int o_skip, n_out;                                       // outputs [o_skip, n_out) of every window are produced
+  void *out; long long out_stride, out_win_step;           // window w of stream s writes at out + s*out_stride + w*out_win_step
+  float gain;                                              // int16 output
+  int OB;
+};
+hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
+                                  TrxProfiler *prof);
+hipError_t trx_launch_burst_index(hipStream_t st, int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *off,
+                                  int32_t *len);
 // pack: 0 = int16 I/Q -> complex float (swap: I/Q flipped), 1 = complex float -> int16 I/Q, 2 = fp16 I/Q -> complex float
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
                               TrxProfiler *prof, float gain = 1.0f /* pack == 1: scaleVector before the cast */);

@@ -58,27 +58,83 @@ __global__ __launch_bounds__(256) void k_modulate(const TrxTables *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_resample: polyphaseResampleVector (sigProcLib.cpp:1157-1210), S independent streams, one thread
-//   per output sample; the reference's exact index walk and summation order (real LPF branch).
+// k_resample: polyphaseResampleVector (sigProcLib.cpp:1157-1210; real LPF branch) for S independent streams, tiled:
+//   a workgroup produces OB consecutive outputs of one input window.  The input span those outputs can touch and the
+//   LPF taps are staged in LDS with coalesced loads (the span is re-read ~L/P times per sample and the taps are walked
+//   at stride P -- both from LDS, not from HBM); every output is the reference's exact index walk and summation order.
+//   IN_I16:  the input is the radio's int16 I/Q stream and unUSRPifyVector (radioInterface.cpp:91-116) happens on the way
+//            into LDS; the stream is cut into windows of n samples that start win_step apart and reach hist_len samples
+//            back (RadioInterface::pullBuffer's [history | chunk], :244-246), samples before the stream's start come
+//            from `hist`; outputs [o_skip, n_out) of each window are kept (:249-252).
+//   OUT_I16: scaleVector(gain) and USRPifyVector (:148-151, :74-89) on the way out (RadioInterface::pushBuffer).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resample(const cx *__restrict__ in, int n, long long in_stride, int S,
-                                                  int P, int Q, const float *__restrict__ lpf, int L,
-                                                  cx *__restrict__ out, long long out_stride, int nout) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = blockIdx.y;
-  if (o >= nout || s >= S) return;
-  const cx *x = in + (size_t)s * in_stride;
-  const int outputIx = o + (L - 1) / 2 / Q;                // :1177
-  const int branch = (int)(((long long)outputIx * Q) % P);
-  int inOff = (int)(((long long)outputIx * Q - branch) / P);
-  int fi = branch;
-  while (inOff >= n) { inOff--; fi += P; }                 // :1183-1186
-  cx sum = mk(0, 0);
-  while (inOff >= 0 && fi < L) {                           // :1196-1200
-    sum = cadd(sum, cmulr(x[inOff], lpf[fi]));
-    inOff--; fi += P;
+#define TRX_RES_XCAP 4096                                  // staged input samples per workgroup
+#define TRX_RES_LCAP 1024                                  // staged taps
+
+template <bool IN_I16, bool OUT_I16>
+__global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
+  __shared__ __attribute__((aligned(16))) cx X[TRX_RES_XCAP];
+  __shared__ float TP[TRX_RES_LCAP];
+  const int tile = blockIdx.x, w = blockIdx.y, s = blockIdx.z;
+  const int o0 = a.o_skip + tile * a.OB;
+  if (o0 >= a.n_out) return;
+  const int o1 = (o0 + a.OB < a.n_out) ? o0 + a.OB : a.n_out;       // outputs [o0, o1)
+  const int D = (a.L - 1) / 2 / a.Q;                                // :1177
+  long long t0 = ((long long)(o0 + D) * a.Q) / a.P - (a.L + a.P - 1) / a.P;
+  long long t1 = ((long long)(o1 - 1 + D) * a.Q) / a.P;
+  const int lo = t0 < 0 ? 0 : (int)t0;
+  const int hi = t1 > a.n - 1 ? a.n - 1 : (int)t1;                  // staged input samples [lo, hi] of this window
+  const bool taps_lds = a.L <= TRX_RES_LCAP;
+  if (taps_lds) for (int i = threadIdx.x; i < a.L; i += 256) TP[i] = a.lpf[i];
+  if (IN_I16) {
+    const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
+    const short2 *hist = a.hist + (size_t)s * a.hist_len;
+    const long long base = (long long)w * a.win_step - a.hist_len;  // raw index of the window's sample 0
+    for (int i = lo + threadIdx.x; i <= hi; i += 256) {
+      const long long r = base + i;
+      const short2 v = r < 0 ? hist[a.hist_len + r] : raw[r];
+      X[i - lo] = a.swap ? mk((float)v.y, (float)v.x) : mk((float)v.x, (float)v.y);   // unUSRPifyVector (:108-109)
+    }
+  } else {
+    const cx *x = reinterpret_cast<const cx *>(a.in) + (size_t)s * a.in_stride + (size_t)w * a.win_step;
+    for (int i = lo + threadIdx.x; i <= hi; i += 256) X[i - lo] = x[i];
   }
-  out[(size_t)s * out_stride + o] = sum;
+  __syncthreads();
+  for (int o = o0 + threadIdx.x; o < o1; o += 256) {
+    const long long oq = (long long)(o + D) * a.Q;                  // outputIx*Q
+    const int branch = (int)(oq % a.P);                             // :1180
+    int inOff = (int)((oq - branch) / a.P);                         // :1181
+    int fi = branch;
+    while (inOff >= a.n) { inOff--; fi += a.P; }                    // :1183-1186
+    cx sum = mk(0, 0);
+    while (inOff >= 0 && fi < a.L) {                                // :1196-1200
+      sum = cadd(sum, cmulr(X[inOff - lo], taps_lds ? TP[fi] : a.lpf[fi]));
+      inOff--; fi += a.P;
+    }
+    const size_t oi = (size_t)s * a.out_stride + (size_t)w * a.out_win_step + (size_t)(o - a.o_skip);
+    if (OUT_I16) {
+      // scaleVector(resampledVector, 13500.0): the complex (gain, 0) multiplies to (r*gain - i*0, r*0 + i*gain), which for
+      // finite samples is (r*gain, i*gain) up to the sign of a zero, lost in the cast; (short) truncates toward zero
+      short2 q;
+      q.x = (short)(int)(sum.r * a.gain);
+      q.y = (short)(int)(sum.i * a.gain);
+      reinterpret_cast<short2 *>(a.out)[oi] = q;
+    } else {
+      reinterpret_cast<cx *>(a.out)[oi] = sum;
+    }
+  }
+}
+
+// trxsig_rxfe_pop's index arrays: burst j of stream s starts at s*stride + rd + (samples of bursts 0..j-1)
+__global__ __launch_bounds__(256) void k_burst_index(int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *__restrict__ off,
+                                                     int32_t *__restrict__ len) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= S * nb) return;
+  const int s = i / nb, j = i - s * nb;
+  int pos = rd, tn = tn0;
+  for (int k = 0; k < j; k++) { pos += (156 + ((tn & 3) == 0)) * sps; tn = (tn + 1) & 7; }
+  off[i] = (int32_t)((long long)s * stride + pos);
+  len[i] = (156 + ((tn & 3) == 0)) * sps;
 }
 
 // RadioInterface::unUSRPifyVector / USRPifyVector (radioInterface.cpp:74-116)
@@ -129,13 +185,44 @@ hipError_t trx_launch_modulate(hipStream_t st, int sps, const TrxTables *dT, con
   return hipGetLastError();
 }
 
+// outputs per workgroup: as many as keep the staged input span inside TRX_RES_XCAP (and enough workgroups in flight)
+static int resample_tile(const TrxResampleArgs &a) {
+  long long ob = ((long long)(TRX_RES_XCAP - (a.L + a.P - 1) / a.P - 4) * a.P) / a.Q;
+  if (ob > 4096) ob = 4096;
+  if (ob < 64) ob = 64;                                    // (Q/P so large that 64 outputs overflow the span: not a resampler ratio)
+  const int want = a.n_out - a.o_skip;
+  return (int)(ob < want ? ob : want);
+}
+
+hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
+                                  TrxProfiler *prof) {
+  if (S <= 0 || n_windows <= 0 || a.n_out <= a.o_skip) return hipSuccess;
+  a.OB = resample_tile(a);
+  if (((long long)(a.OB - 1) * a.Q) / a.P + (a.L + a.P - 1) / a.P + 3 > TRX_RES_XCAP) return hipErrorInvalidValue;
+  if (S > 65535 || n_windows > 65535) return hipErrorInvalidValue;
+  const dim3 grid((a.n_out - a.o_skip + a.OB - 1) / a.OB, n_windows, S), block(256);
+  if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
+  if (in_i16 && !out_i16) k_resample<true, false><<<grid, block, 0, st>>>(a);
+  else if (!in_i16 && out_i16) k_resample<false, true><<<grid, block, 0, st>>>(a);
+  else if (!in_i16 && !out_i16) k_resample<false, false><<<grid, block, 0, st>>>(a);
+  else return hipErrorInvalidValue;
+  if (prof) prof->end(TRXSIG_K_RESAMPLE, st);
+  return hipGetLastError();
+}
+
 hipError_t trx_launch_resample(hipStream_t st, const trx_c32 *in, int n, long long in_stride, int S, int P, int Q,
                                const float *lpf, int L, trx_c32 *out, long long out_stride, int nout,
                                TrxProfiler *prof) {
-  if (S <= 0 || nout <= 0) return hipSuccess;
-  if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
-  k_resample<<<dim3((nout + 255) / 256, S), dim3(256), 0, st>>>(in, n, in_stride, S, P, Q, lpf, L, out, out_stride, nout);
-  if (prof) prof->end(TRXSIG_K_RESAMPLE, st);
+  TrxResampleArgs a = {};
+  a.in = in; a.in_stride = in_stride; a.n = n; a.lpf = lpf; a.L = L; a.P = P; a.Q = Q; a.n_out = nout; a.out = out;
+  a.out_stride = out_stride;
+  return trx_launch_resample_ex(st, a, S, 1, false, false, prof);
+}
+
+hipError_t trx_launch_burst_index(hipStream_t st, int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *off,
+                                  int32_t *len) {
+  if (S * nb <= 0) return hipSuccess;
+  k_burst_index<<<dim3((S * nb + 255) / 256), dim3(256), 0, st>>>(S, nb, stride, rd, tn0, sps, off, len);
   return hipGetLastError();
 }
 

@@ -1,17 +1,10 @@
-"""Receive front-end orchestration for S independent ARFCN streams (BASELINE config 4): the data
-movement of RadioInterface::pullBuffer + driveReceiveRadio (Transceiver/radioInterface.cpp:197-273,
-359-401) around libtrxsig's kernels.
+"""ctypes view of include/trxsig_frontend.h for tests/ and bench.py: the RadioInterface's receive front end
+(pullBuffer + driveReceiveRadio, Transceiver/radioInterface.cpp:197-273, 359-401) and transmit back end
+(driveTransmitRadio + pushBuffer, :123-194, 337-357) for S independent ARFCN streams (BASELINE config 4 and the TX chain).
+Everything -- buffers, history, 157/156/156/156 slicing, chunking, the fused convert + resample kernels -- lives in
+libtrxsig (csrc/trxsig_frontend.cpp, csrc/trxsig_tx.hip); this module only marshals pointers (torch is plumbing)."""
+import ctypes as C
 
-Per chunk of OUTCHUNK = 864 int16 I/Q samples at 400 kS/s and per stream:
-    unUSRPifyVector (int16 -> float, I/Q swapped)          -> trxsig_unpack_int16
-    [192-sample history | chunk] -> polyphaseResampleVector(P = 65*sps, Q = 96, LPF)
-                                                            -> trxsig_resample_batch
-    drop the first INHISTORY = 130*sps outputs, append to the stream's receive buffer
-then the buffer is cut into bursts of (156 + (TN % 4 == 0)) * sps samples (157-156-156-156).
-Everything numeric runs in the library; this class only concatenates and slices device buffers
-(torch is plumbing).  State per stream = the 192-sample history and the unsliced tail, as in the
-reference.
-"""
 import numpy as np
 
 OUTRATE = 96
@@ -19,122 +12,148 @@ OUTCHUNK = 9 * OUTRATE          # 864
 OUTHISTORY = 2 * OUTRATE        # 192
 
 
+class _DevView:
+    """A device buffer owned by the library, presented to torch (zero copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(data=(int(ptr), False), shape=tuple(shape), typestr=typestr, version=2)
+
+
+def _bind(L):
+    vp, i32 = C.c_void_p, C.c_int
+    if getattr(L, "_frontend_bound", False):
+        return
+    L.trxsig_rxfe_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, i32, i32]
+    L.trxsig_rxfe_destroy.argtypes = [vp]; L.trxsig_rxfe_destroy.restype = None
+    L.trxsig_rxfe_push.argtypes = [vp, vp, i32]
+    L.trxsig_rxfe_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, C.POINTER(i32)]
+    L.trxsig_rxfe_pending.argtypes = [vp]
+    L.trxsig_txbe_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, C.c_float]
+    L.trxsig_txbe_destroy.argtypes = [vp]; L.trxsig_txbe_destroy.restype = None
+    L.trxsig_txbe_push_bursts.argtypes = [vp, vp, vp, vp, i32]
+    L.trxsig_txbe_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(i32)]
+    L.trxsig_txbe_pending.argtypes = [vp]
+    L._frontend_bound = True
+
+
 class RxFrontEnd:
-    def __init__(self, ctx, n_streams, lpf_taps, device="cuda:0", swap_iq=True):
+    def __init__(self, ctx, n_streams, lpf_taps, device="cuda:0", swap_iq=True, max_chunks=1, start_tn=0):
         import torch
         self.torch = torch
         self.ctx = ctx
+        self.L = ctx.L
+        _bind(self.L)
         self.S = n_streams
         self.sps = ctx.sps
-        self.P = 65 * self.sps
-        self.inhistory = 2 * self.P
         self.dev = torch.device(device)
-        self.swap = swap_iq
-        self.lpf = torch.as_tensor(np.ascontiguousarray(lpf_taps, np.float32)).to(self.dev)
-        self.n_in = OUTHISTORY + OUTCHUNK
-        self.n_out = ctx.resample_out_len(self.n_in, self.P, OUTRATE)
-        # [S, history + chunk] complex (float pairs): the history lives in the first 192 entries
-        self.inbuf = torch.zeros(self.S, self.n_in, 2, dtype=torch.float32, device=self.dev)
-        self.outbuf = torch.zeros(self.S, self.n_out, 2, dtype=torch.float32, device=self.dev)
-        self.rcv = torch.zeros(self.S, 0, 2, dtype=torch.float32, device=self.dev)   # unsliced tail per stream
-        self.tn = 0                                                                   # TN of the next burst
+        lpf = np.ascontiguousarray(lpf_taps, np.float32)
+        h = C.c_void_p()
+        ctx._chk(self.L.trxsig_rxfe_create(C.byref(h), ctx.h, n_streams, max_chunks, lpf.ctypes.data, lpf.size, int(swap_iq),
+                                           start_tn), "trxsig_rxfe_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.trxsig_rxfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def push_chunk(self, iq):
-        """iq: int16 tensor [S, 864, 2] (device).  Resamples and appends to the receive buffers."""
+        """iq: int16 tensor [S, K*864, 2] (device), K whole chunks per stream."""
         torch = self.torch
-        assert iq.shape == (self.S, OUTCHUNK, 2) and iq.dtype == torch.int16
-        chunk = torch.empty(self.S, OUTCHUNK, 2, dtype=torch.float32, device=self.dev)
-        self.ctx.unpack_int16(iq.contiguous(), self.S * OUTCHUNK, chunk, swap_iq=self.swap)
-        self.inbuf[:, OUTHISTORY:] = chunk
-        self.ctx.resample(self.inbuf, self.n_in, self.n_in, self.S, self.P, OUTRATE, self.lpf, self.outbuf, self.n_out)
-        self.rcv = torch.cat([self.rcv, self.outbuf[:, self.inhistory:]], dim=1)
-        self.inbuf[:, :OUTHISTORY] = chunk[:, OUTCHUNK - OUTHISTORY:].clone()          # history for the next chunk
+        assert iq.dtype == torch.int16 and iq.shape[0] == self.S and iq.shape[1] % OUTCHUNK == 0 and iq.shape[2] == 2
+        iq = iq.contiguous()
+        self.ctx._chk(self.L.trxsig_rxfe_push(self.h, iq.data_ptr(), iq.shape[1] // OUTCHUNK), "trxsig_rxfe_push")
+        self._keep = iq                                       # the launch reads it asynchronously
+
+    def pop_raw(self, max_bursts=4096):
+        """(samples ptr, offset ptr, length ptr, tn int32 [nb], nb) -- device addresses owned by the library -- or None."""
+        ps, po, pl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nb = C.c_int()
+        tn = np.zeros(max_bursts, np.int32)
+        self.ctx._chk(self.L.trxsig_rxfe_pop(self.h, C.byref(ps), C.byref(po), C.byref(pl), tn.ctypes.data, max_bursts, C.byref(nb)),
+                      "trxsig_rxfe_pop")
+        if nb.value == 0:
+            return None
+        return ps.value, po.value, pl.value, tn[:nb.value].copy(), nb.value
 
     def pop_bursts(self):
-        """Cut every stream's buffer into bursts (same schedule on all streams).  Returns
-        (samples [float pairs, packed], offset int32 [S*nb], length int32 [S*nb], tn int32 [S*nb]) with
-        bursts ordered stream-major, or None when less than one burst is buffered."""
-        torch = self.torch
-        lens, tns = [], []
-        pos, tn, avail = 0, self.tn, self.rcv.shape[1]
-        while True:
-            n = (156 + (tn % 4 == 0)) * self.sps
-            if not (avail - pos > n):                       # "while (rcvSz > burstSize)" (:375)
-                break
-            lens.append(n); tns.append(tn)
-            pos += n; tn = (tn + 1) % 8
-        if not lens:
+        """Cut every stream's buffer into bursts.  Returns (samples float32 [total, 2] view of the library's receive
+        buffers, offset int32 [S*nb], length int32 [S*nb], tn int32 [S*nb]) with bursts ordered stream-major, or None when
+        less than one burst is buffered.  The tensors alias library memory: valid until the next push."""
+        r = self.pop_raw()
+        if r is None:
             return None
-        used = self.rcv[:, :pos].contiguous()               # [S, pos, 2]
-        self.rcv = self.rcv[:, pos:].contiguous()
-        self.tn = tn
-        lens = np.array(lens, np.int32)
-        off1 = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
-        off = (np.arange(self.S)[:, None] * pos + off1[None, :]).astype(np.int32).ravel()
-        length = np.tile(lens, self.S)
-        tnv = np.tile(np.array(tns, np.int32), self.S)
-        return (used.view(-1, 2), torch.from_numpy(off).to(self.dev), torch.from_numpy(length).to(self.dev), tnv)
+        ps, po, pl, tn, nb = r
+        torch = self.torch
+        B = self.S * nb
+        off = torch.as_tensor(_DevView(po, (B,), "<i4"), device=self.dev)
+        length = torch.as_tensor(_DevView(pl, (B,), "<i4"), device=self.dev)
+        torch.cuda.synchronize()
+        end = int((off.to(torch.int64) + length.to(torch.int64)).max().item())
+        x = torch.as_tensor(_DevView(ps, (end, 2), "<f4"), device=self.dev)
+        return x, off, length, np.tile(tn, self.S)
 
-
-INCHUNK_SYM = 65 * 9            # per sps: INCHUNK = INRATE*9 with INRATE = 65*sps (radioInterface.h)
+    def pending(self):
+        return self.L.trxsig_rxfe_pending(self.h)
 
 
 class TxBackEnd:
-    """Transmit back-end for S independent ARFCN streams: the data movement of RadioInterface::pushBuffer
-    (Transceiver/radioInterface.cpp:123-194) around libtrxsig's kernels -- modulated bursts are appended
-    to the send buffer; whenever it holds at least INCHUNK = 585*sps samples, [INHISTORY history | whole
-    chunks] goes through polyphaseResampleVector(P = 96, Q = 65*sps, sendLPF), scaleVector(gain) and
-    USRPifyVector, and the first OUTHISTORY outputs are dropped.  Numerics in the library; this class
-    only concatenates and slices device buffers."""
-
-    def __init__(self, ctx, n_streams, lpf_taps, gain=13500.0, device="cuda:0"):
+    def __init__(self, ctx, n_streams, lpf_taps, gain=13500.0, device="cuda:0", max_bursts=64):
         import torch
         self.torch = torch
         self.ctx = ctx
+        self.L = ctx.L
+        _bind(self.L)
         self.S = n_streams
         self.sps = ctx.sps
-        self.Q = 65 * self.sps
-        self.inchunk = INCHUNK_SYM * self.sps
-        self.inhistory = 2 * self.Q
-        self.gain = float(gain)
         self.dev = torch.device(device)
-        self.lpf = torch.as_tensor(np.ascontiguousarray(lpf_taps, np.float32)).to(self.dev)
-        self.hist = torch.zeros(self.S, self.inhistory, 2, dtype=torch.float32, device=self.dev)
-        self.send = torch.zeros(self.S, 0, 2, dtype=torch.float32, device=self.dev)
+        lpf = np.ascontiguousarray(lpf_taps, np.float32)
+        h = C.c_void_p()
+        ctx._chk(self.L.trxsig_txbe_create(C.byref(h), ctx.h, n_streams, max_bursts, lpf.ctypes.data, lpf.size, float(gain)),
+                 "trxsig_txbe_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.trxsig_txbe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def push_bursts(self, bits, guard, gain=None):
-        """bits: uint8 [S, nb, 148]; guard: int32 [nb] guard symbols per burst (same schedule on every stream);
-        gain: optional float32 [S, nb] (addRadioVector's power scaling).  modulateBurst for all of them."""
+        """bits: uint8 [S, nb, 148] (numpy or device tensor); guard: int32 [nb] guard symbols per burst (same schedule on
+        every stream); gain: optional float32 [S, nb] (addRadioVector's power scaling)."""
         torch = self.torch
-        S, nb = bits.shape[0], bits.shape[1]
-        assert S == self.S
+        d_bits = bits if torch.is_tensor(bits) else torch.as_tensor(np.ascontiguousarray(bits, np.uint8)).to(self.dev)
+        assert d_bits.shape[0] == self.S and d_bits.shape[2] == 148
         guard = np.ascontiguousarray(guard, np.int32)
-        lens = (self.sps * (148 + guard)).astype(np.int64)
-        tot = int(lens.sum())
-        off1 = np.concatenate([[0], np.cumsum(lens)[:-1]])
-        off = (np.arange(S)[:, None] * tot + off1[None, :]).astype(np.int32).ravel()
-        out = torch.zeros(S, tot, 2, dtype=torch.float32, device=self.dev)
-        d_bits = torch.as_tensor(np.ascontiguousarray(bits, np.uint8).reshape(S * nb, 148)).to(self.dev)
-        d_guard = torch.from_numpy(np.tile(guard, S)).to(self.dev)
-        d_gain = None if gain is None else torch.as_tensor(np.ascontiguousarray(gain, np.float32).ravel()).to(self.dev)
-        self.ctx.modulate(d_bits, d_guard, out, torch.from_numpy(off).to(self.dev), gain=d_gain)
-        self.send = torch.cat([self.send, out], dim=1)
+        d_gain = None
+        if gain is not None:
+            d_gain = gain if torch.is_tensor(gain) else torch.as_tensor(np.ascontiguousarray(gain, np.float32)).to(self.dev)
+        self.ctx._chk(self.L.trxsig_txbe_push_bursts(self.h, d_bits.contiguous().data_ptr(), guard.ctypes.data,
+                                                     None if d_gain is None else d_gain.contiguous().data_ptr(), d_bits.shape[1]),
+                      "trxsig_txbe_push_bursts")
+        self._keep = (d_bits, d_gain)
 
     def pop_samples(self):
-        """int16 tensor [S, n, 2] for the radio (96/(65*sps) samples per modulator sample), or None while
-        less than one chunk is buffered."""
-        torch = self.torch
-        nch = self.send.shape[1] // self.inchunk
-        if nch == 0:
+        """int16 tensor [S, n, 2] for the radio (a strided view of the library's output buffer, valid until the next pop),
+        or None while less than one chunk is buffered."""
+        p = C.c_void_p(); stride = C.c_int64(); n = C.c_int()
+        self.ctx._chk(self.L.trxsig_txbe_pop(self.h, C.byref(p), C.byref(stride), C.byref(n)), "trxsig_txbe_pop")
+        if n.value == 0:
             return None
-        ntr = nch * self.inchunk
-        inp = torch.cat([self.hist, self.send[:, :ntr]], dim=1).contiguous()        # [S, INHISTORY + ntr, 2]
-        n_in = inp.shape[1]
-        n_out = self.ctx.resample_out_len(n_in, OUTRATE, self.Q)
-        res = torch.zeros(self.S, n_out, 2, dtype=torch.float32, device=self.dev)
-        self.ctx.resample(inp, n_in, n_in, self.S, OUTRATE, self.Q, self.lpf, res, n_out)
-        iq = torch.zeros(self.S, n_out, 2, dtype=torch.int16, device=self.dev)
-        self.ctx.pack_int16_scaled(res, self.S * n_out, self.gain, iq)
-        self.hist = self.send[:, ntr - self.inhistory:ntr].clone()
-        self.send = self.send[:, ntr:].contiguous()
-        return iq[:, OUTHISTORY:]
+        full = self.torch.as_tensor(_DevView(p.value, (self.S, stride.value, 2), "<i2"), device=self.dev)
+        return full[:, :n.value]
+
+    def pending(self):
+        return self.L.trxsig_txbe_pending(self.h)

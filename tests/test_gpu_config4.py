@@ -74,8 +74,9 @@ def test_config4_pipeline(golden):
         assert off.numel() == S * nb
         # the resampled samples themselves are bit-identical
         xh = x.cpu().numpy().view(np.complex64).ravel()
-        for s in range(S):
-            assert_veq(xh[s * pos:(s + 1) * pos], rcv[s][:pos], "resampled stream %d chunk %d" % (s, c))
+        offh = off.cpu().numpy()
+        for s in range(S):                                        # stream s's bursts are back to back from its first offset on
+            assert_veq(xh[offh[s * nb]:offh[s * nb] + pos], rcv[s][:pos], "resampled stream %d chunk %d" % (s, c))
         B = S * nb
         flags = torch.zeros(B, dtype=torch.uint8, device="cuda"); amp = torch.zeros(B, 2, device="cuda")
         toa = torch.zeros(B, device="cuda"); soft = torch.zeros(B, 148, device="cuda")
@@ -99,3 +100,41 @@ def test_config4_pipeline(golden):
                     total += 1
             rcv[s] = rcv[s][pos:]
     assert total >= S * 20                                       # most complete slots carried a detectable burst
+
+
+def test_multi_chunk_push_equals_chunk_by_chunk(golden):
+    """K chunks in one push (one fused launch, every chunk behind the 192 samples before it) produce the same burst stream
+    as K pushes of one chunk, and the buffers survive pushes without a pop in between up to their capacity."""
+    import torch
+    pkg = _pkg.load()
+    from openbts_ttsou_amd.frontend import RxFrontEnd, OUTCHUNK
+    sps, S, tsc = 4, 5, 1
+    lpf = golden("resample.npz")["lpf961_gain260"]
+    iq, nchunks = make_streams(sps, S, 60, tsc, seed=3)
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    d_iq = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+
+    def run(sizes):
+        fe = RxFrontEnd(ctx, S, lpf, max_chunks=max(sizes), start_tn=3)
+        out, c = [], 0
+        for k in sizes:
+            fe.push_chunk(d_iq[:, c * OUTCHUNK:(c + k) * OUTCHUNK]); c += k
+            got = fe.pop_bursts()
+            if got is None:
+                continue
+            x, off, length, tn = got
+            xh = x.cpu().numpy().view(np.complex64).ravel(); off = off.cpu().numpy(); length = length.cpu().numpy()
+            nb = len(off) // S
+            out.append([(int(tn[j]), [xh[off[s * nb + j]:off[s * nb + j] + length[s * nb + j]].copy() for s in range(S)]) for j in range(nb)])
+        return [b for grp in out for b in grp]
+    one = run([1] * nchunks)
+    many = run([7, 1, 5, nchunks - 13])
+    assert len(one) == len(many) and len(one) > 50
+    for (tn1, b1), (tn2, b2) in zip(one, many):
+        assert tn1 == tn2
+        for s in range(S):
+            assert_veq(b1[s], b2[s], "burst stream %d" % s)
+    fe = RxFrontEnd(ctx, S, lpf, max_chunks=2)
+    fe.push_chunk(d_iq[:, :2 * OUTCHUNK])
+    with pytest.raises(pkg.TrxSigError, match="full"):
+        fe.push_chunk(d_iq[:, 2 * OUTCHUNK:4 * OUTCHUNK])
