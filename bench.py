@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- Mbursts/s of the burst detect+demod hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload normal|rach|config4|config5]
   N>1 without WORLD_SIZE in the environment: this process never touches the GPU; it starts the N ranks itself
   (a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py`)
   and exits with the child's code.  Under torchrun (WORLD_SIZE set) it is one of the ranks.
 
-Workload (config.workload): BASELINE config 2 -- 65,536 normal bursts per GPU, 156.25 symbols at
-4 samples/symbol (628/624/624/624 complex float32 samples), one training sequence per batch,
-synthetic GMSK bursts with random gain, sub-sample delay and AWGN (SNR inf/20/10 dB), resident in
-HBM before the timed region.  A "step" is one pass of trxsig_detect_demod_normal_batch over the
-batch: energy detect + TSC correlate + peak/valley detect + GMSK demodulation to 148 soft bits.
-Multi-GPU: each rank owns an independent batch (weak scaling); the only collective is the
-init-time RCCL broadcast of the constant tables.  `value` is whole-job bursts/s over all ranks,
-timed between barriers, MAX over ranks.
+Workloads (config.workload; the default, `normal`, is the headline):
+  normal   BASELINE config 2 -- 65,536 normal bursts per GPU, 156.25 symbols at 4 samples/symbol (628/624/624/624 complex
+           float32 samples), one training sequence per batch, synthetic GMSK bursts with random gain, sub-sample delay and
+           AWGN (SNR inf/20/10 dB), resident in HBM before the timed region.  A step = one pass of
+           trxsig_detect_demod_normal_batch: energy detect + TSC correlate + peak/valley detect + demodulation to 148 soft bits.
+  rach     config 3 -- 65,536 access bursts per GPU, detectRACHBurst over every lag + demodulation.
+  config4  S ARFCN streams per GPU of int16 I/Q at 400 kS/s, K chunks of 864 samples per step: trxsig_rxfe_push (unUSRPify +
+           polyphase resample 65*sps:96 behind the 192-sample history) + trxsig_rxfe_pop (157/156/156/156 slicing) + the
+           normal-burst detector on every burst cut.  (BASELINE's "8 ARFCN, one per GPU" run is --gpus 8: a stream set per rank.)
+  config5  the Transceiver52M receive leg at one sample per symbol, fp16 sample storage: energy gate, windowed midamble
+           correlation with channel estimate, designDFE (Nf = 7), equalizeBurst.
+Multi-GPU: each rank owns an independent batch / stream set (weak scaling, one engine per ARFCN set as
+TRXManager/TRXManager.cpp:44-54); the only collective is the init-time RCCL broadcast of the constant tables.  `value` is
+whole-job bursts/s over all ranks, timed between barriers, MAX over ranks.
 """
 import argparse
 import json
@@ -25,84 +31,289 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SPS = 4
-TSC = 2
-BURSTS_PER_GPU = 65536
 NSOFT = 148
-# algorithmic bytes per burst: read 8*625 + write 4*148 soft + 16 B metadata
-ALG_READ = 8 * 625
-ALG_WRITE = 4 * NSOFT + 16
-ALG_BYTES = ALG_READ + ALG_WRITE
-# per-kernel algorithmic bytes per burst (DESIGN.md "Kernels"):
-KERNEL_ALG_BYTES = {
-    "k_rach_corr": ALG_READ + 1012, "k_rach_peak": 1012 + 17,
-    "k_tsc_corr": 8 * 36 * SPS + 8 * 20 * SPS + 8 * 44,     # window + energy window read, record write
-    "k_tsc_peak": 8 * 44 + 13 + 4,                          # record read, flags/amp/toa/avgpwr write
-    "k_demod": ALG_READ + 13 + 4 * NSOFT,                   # whole burst + amp/toa/flags read, soft write
-    "k_normal_fused": ALG_BYTES, "k_normal_chain": ALG_BYTES,
-}
 
 
-def measured_traffic(kernel, bursts):
-    """HBM bytes per launch of `kernel` from the committed PMC run (profiles/traffic.json: rocprofv3
-    FETCH_SIZE x2 + WRITE_SIZE, separate passes, same bench command), scaled to this batch size."""
+def measured_traffic(kernel, units, key="bursts_per_launch"):
+    """HBM bytes per launch of `kernel` from the committed PMC run (profiles/traffic.json: rocprofv3 FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes, same bench command), scaled to this launch size."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kernels"][kernel]
-        return int(t["hbm_bytes_per_launch"] * (bursts / float(t["bursts_per_launch"])))
+        return int(t["hbm_bytes_per_launch"] * (units / float(t[key])))
     except Exception:
         return None
 
 
-def cpu_baseline(x_host, off, length, sps, tsc, target_seconds=8.0):
-    """The CPU oracle (a port of the reference's algorithm, oracle/sigproc_oracle.c) timed on this
-    box's host cores over a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oraclebind
-    o = oraclebind.Oracle(sps)
+def host_cores():
     cores = min(os.cpu_count() or 1, 16)
     try:
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    B = len(off)
-    t0 = time.perf_counter()
-    o.normal_batch(x_host, off[:1024], length[:1024], tsc, nthreads=1)
-    t1 = time.perf_counter() - t0
-    o.normal_batch(x_host, off, length, tsc, nthreads=cores)            # warm
-    t0 = time.perf_counter()
-    o.normal_batch(x_host, off, length, tsc, nthreads=cores)
-    tp = time.perf_counter() - t0
-    reps = max(1, int(target_seconds / max(tp, 1e-3)))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        o.normal_batch(x_host, off, length, tsc, nthreads=cores)
-    tt = time.perf_counter() - t0
-    port = {"value": round(B * reps / tt / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
-            "single_thread_Mbursts_per_s": round(1024 / t1 / 1e6, 6),
-            "sample": "%d passes over the first %d bursts of the GPU batch (analyzeTrafficBurst + "
-                      "demodulateBurst, oracle/sigproc_oracle.c, %d OpenMP threads, %.1f s)" % (reps, B, cores, tt)}
-    # the real reference, when its in-place build travelled with the snapshot (oracle/_ref/, built by
-    # __graft_entry__.build() where /root/reference exists): timed in a child process that never touches the GPU
-    import refbind
-    if not refbind.available():
-        return port, None
-    import subprocess
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "sample.npz")
-        end = int(off[-1] + length[-1])
+    return cores
+
+
+# ======================================================================================================================
+class Normal:
+    """BASELINE config 2 (the headline) and, with rach=True, config 3."""
+    sps, tsc = 4, 2
+    dtype = "f32"
+
+    def __init__(self, args, rach=False):
+        self.rach = rach
+        self.B = args.bursts or 65536
+        self.alg_read = 8 * 625                               # SURVEY 8d: 8*N-bar bytes read per burst
+        self.alg_bytes = self.alg_read + 4 * NSOFT + 16       # + 148 soft bits + flag / amp / TOA
+        s = self.sps
+        self.kernel_alg = {                                   # per-kernel algorithmic bytes per burst (DESIGN.md "Kernels")
+            "k_tsc_corr": 8 * 36 * s + 8 * 20 * s + 8 * 44,   # window + energy window read, record write
+            "k_tsc_peak": 8 * 44 + 13 + 4,                    # record read, flags / amp / toa / avgpwr write
+            "k_demod": self.alg_read + 13 + 4 * NSOFT,        # whole burst + amp / toa / flags read, soft write
+            "k_normal_fused": self.alg_bytes, "k_normal_chain": self.alg_bytes,
+            "k_rach_corr": self.alg_read + 8 * 25 + 16 + 17,  # k_rach_front: whole burst read, 25-slot record + 4 floats written
+            "k_rach_peak": 8 * 25 + 16 + 17,
+        }
+        self.kernel_names = {"k_rach_corr": "k_rach_front", "k_rach_peak": "k_rach_peak2+k_rach_fast(list)", "k_tsc_peak": "k_tsc_peak2"}
+
+    def setup(self, pkg, ctx, dev, rank, args):
+        import torch
+        from openbts_ttsou_amd import synth
+        self.pkg, self.ctx, self.dev, self.torch, self.synth = pkg, ctx, dev, torch, synth
+        B = self.B
+        if self.rach:
+            x, off, length, meta = synth.rach_batch_torch(self.sps, B, seed=0xB5E55ED0 + rank, device=dev)
+        else:
+            x, off, length, meta = synth.normal_batch_torch(self.sps, B, self.tsc, seed=0xB5E55ED0 + rank, device=dev)
+        self.x, self.off, self.length, self.meta = x, off, length, meta
+        self.xf = torch.view_as_real(x).contiguous()
+        self.flags = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.amp = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+        self.toa = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.soft = torch.zeros(B, NSOFT, dtype=torch.float32, device=dev)
+        ctx.reserve(B)
+
+    def step(self):
+        if self.rach:
+            self.ctx.detect_demod_rach(self.xf, self.off, self.length, self.flags, self.amp, self.toa, self.soft, detect_thresh=5.0,
+                                       energy_thresh=-1.0, nsoft=NSOFT, soft_stride=NSOFT)
+        else:
+            self.ctx.detect_demod_normal(self.xf, self.off, self.length, self.tsc, self.flags, self.amp, self.toa, self.soft,
+                                         detect_thresh=3.0, energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+
+    def units_per_step(self):
+        return self.B
+
+    def describe(self, world):
+        w = ("config3: %d access bursts/GPU, sps=4, detectRACHBurst over all lags (thr 5.0) + demod to %d soft bits" % (self.B, NSOFT)) \
+            if self.rach else ("config2: %d normal bursts/GPU, sps=4, 628/624/624/624 complex f32 samples, TSC %d, detect (thr 3.0) + "
+                               "demod to %d soft bits" % (self.B, self.tsc, NSOFT))
+        return {"workload": w, "bursts_per_gpu": self.B, "sps": self.sps,
+                "parallelism": "burst-sharded x%d (no data-path collective)" % world}
+
+    def sanity(self):
+        torch = self.torch
+        det = (self.flags & self.pkg.F_DETECT) != 0
+        clean = det & (self.meta["sigma"] <= 0.1)
+        cols = slice(8, 85) if self.rach else slice(0, 148)
+        hard_ok = bool(((self.soft[clean][:, cols] > 0.5).to(torch.uint8) == self.meta["bits"][clean][:, cols]).all().item())
+        return {"detected_frac": round(float(det.float().mean().item()), 4), "clean_hard_bits_ok": hard_ok}
+
+    def fresh_inputs(self, steps):
+        """Side measurement (outside the timed region): the same steps over THREE different input batches in rotation
+        (1 GB > the 256 MB memory-side cache), i.e. without the part of the input a repeated batch still finds in that cache."""
+        if self.rach:
+            return None
+        torch, synth = self.torch, self.synth
+        xs = [self.xf]
+        for k in (1, 2):
+            xk, offk, lenk, _ = synth.normal_batch_torch(self.sps, self.B, self.tsc, seed=0xB5E55ED0 + 1000 * k, device=self.dev)
+            assert torch.equal(offk, self.off) and torch.equal(lenk, self.length)
+            xs.append(torch.view_as_real(xk).contiguous())
+        so2 = torch.zeros_like(self.soft); fl2 = torch.zeros_like(self.flags); am2 = torch.zeros_like(self.amp); to2 = torch.zeros_like(self.toa)
+
+        def step_k(i):
+            self.ctx.detect_demod_normal(xs[i % 3], self.off, self.length, self.tsc, fl2, am2, to2, so2, detect_thresh=3.0,
+                                         energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+        kf = min(steps, 600)
+        for i in range(60):
+            step_k(i)
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        for i in range(kf):
+            step_k(i)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf
+        return {"value": round(self.B * kf / tf / 1e6, 3), "unit": "Mbursts/s", "inputs_in_rotation": 3, "steps": kf}
+
+    def cpu_baseline(self, check):
+        """The real reference (oracle/_ref, when its in-place build travelled with the snapshot) and the oracle port on this
+        box's host cores over a bounded sample of the same workload; optionally the first bursts value-exact vs the oracle."""
         np_ = __import__("numpy")
-        np_.savez(path, x=x_host[:end], off=off, length=length, sps=sps, tsc=tsc)
-        try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
-                               capture_output=True, text=True, timeout=300)
-            ref = json.loads(r.stdout.strip().splitlines()[-1])
-        except Exception as e:                               # the reference leg is optional; the port leg stands
-            sys.stderr.write("reference cpu baseline unavailable: %r\n" % (e,))
-            return port, None
-    return ref, port
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oraclebind
+        n = min(self.B, 16384 if not self.rach else 4096)
+        off = self.off[:n].cpu().numpy(); length = self.length[:n].cpu().numpy()
+        xh = self.x[:int(off[-1] + length[-1])].cpu().numpy()
+        o = oraclebind.Oracle(self.sps)
+        cores = host_cores()
+        run = (lambda nt, cnt=n: o.rach_batch(xh, off[:cnt], length[:cnt], nthreads=nt)) if self.rach else \
+              (lambda nt, cnt=n: o.normal_batch(xh, off[:cnt], length[:cnt], self.tsc, nthreads=nt))
+        n1 = min(n, 1024 if not self.rach else 256)
+        t0 = time.perf_counter(); run(1, n1); t1 = time.perf_counter() - t0
+        run(cores)
+        t0 = time.perf_counter(); run(cores); tp = time.perf_counter() - t0
+        reps = max(1, int(8.0 / max(tp, 1e-3)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = run(cores)
+        tt = time.perf_counter() - t0
+        what = "detectRACHBurst + demodulateBurst" if self.rach else "analyzeTrafficBurst + demodulateBurst"
+        port = {"value": round(n * reps / tt / 1e6, 6), "unit": "Mbursts/s", "cores": cores, "kind": "port",
+                "single_thread_Mbursts_per_s": round(n1 / t1 / 1e6, 6),
+                "sample": "%d passes over the first %d bursts of the GPU batch (%s, oracle/sigproc_oracle.c, %d OpenMP threads, "
+                          "%.1f s)" % (reps, n, what, cores, tt)}
+        out = {"cpu_baseline": port}
+        if check:
+            ok, oamp, otoa, osoft = res
+            det = ((self.flags[:n] & self.pkg.F_DETECT) != 0).cpu().numpy()
+            same = (np_.array_equal(det, ok.astype(bool)) and np_.array_equal(self.soft[:n].cpu().numpy(), osoft) and
+                    np_.array_equal(self.toa[:n].cpu().numpy(), otoa))
+            out["oracle_check_first_%d" % n] = bool(same)
+        import refbind
+        if self.rach or not refbind.available():
+            return out
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sample.npz")
+            np_.savez(path, x=xh, off=off, length=length, sps=self.sps, tsc=self.tsc)
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
+                                   capture_output=True, text=True, timeout=300)
+                out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                out["cpu_port"] = port                      # the oracle port beside the real reference
+            except Exception as e:                          # the reference leg is optional; the port leg stands
+                sys.stderr.write("reference cpu baseline unavailable: %r\n" % (e,))
+        return out
 
 
+# ======================================================================================================================
+class Config4:
+    """S int16 I/Q streams per GPU -> rxfe push (convert + resample) -> pop (slice) -> normal-burst detect + demod."""
+    sps, tsc = 4, 2
+    dtype = "int16 in, f32 arithmetic"
+
+    def __init__(self, args):
+        self.S = args.streams
+        self.K = args.chunks
+        self.per_chunk = 585 * self.sps                      # resampled samples per 864-sample chunk
+        self.alg_bytes = 4 * 625 * 96 // (65 * self.sps) + 4 * NSOFT + 16   # SURVEY 8d config 4: int16 in, soft bits out
+        self.kernel_alg = {"k_resample": None}               # per stream-chunk, see roofline()
+        self.kernel_names = {"k_tsc_peak": "k_tsc_peak2"}
+
+    def setup(self, pkg, ctx, dev, rank, args):
+        import numpy as np
+        import torch
+        from openbts_ttsou_amd import synth
+        from openbts_ttsou_amd.frontend import RxFrontEnd
+        self.pkg, self.ctx, self.dev, self.torch = pkg, ctx, dev, torch
+        S, K, sps = self.S, self.K, self.sps
+        # synthetic radio streams: back-to-back normal bursts (157-156-156-156 symbols) modulated on the device, brought to
+        # 400 kS/s by linear interpolation (the bench needs realistic, detectable content, not a calibrated radio), int16
+        nb = (K * 585 // 156 + 4 + 3) // 4 * 4               # whole 157-156-156-156 groups: every stream the same length
+        gen = torch.Generator(device=dev); gen.manual_seed(0xC0F14 + rank)
+        x, off, length, meta = synth.normal_batch_torch(sps, S * nb, self.tsc, seed=0xC0F14 + rank, device=dev, sigmas=(0.02, 0.05))
+        hi = x.reshape(-1)[: S * (x.numel() // S)].reshape(S, -1)
+        n_lo = K * 864
+        t = torch.arange(n_lo, device=dev, dtype=torch.float64) * (65.0 * sps / 96.0)
+        i0 = t.floor().long().clamp(max=hi.shape[1] - 2); fr = (t - i0).to(torch.float32)
+        lo = hi[:, i0] * (1 - fr) + hi[:, i0 + 1] * fr
+        lo = lo * (8000.0 / lo.abs().amax(dim=1, keepdim=True))
+        iq = torch.stack([lo.imag, lo.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()   # Q first (I/Q flipped)
+        self.iq = iq
+        # createLPF(cutoff, 961, 65*sps) as pullBuffer asks for it -- designed for THIS ratio (synth.design_lpf says why the
+        # reference's fixed table, made for 65:96, is not used at sps 4); the taps are an argument of the library
+        self.lpf = synth.design_lpf(961, 65 * sps)
+        self.fe = RxFrontEnd(ctx, S, self.lpf, max_chunks=K)
+        Bmax = S * (K * self.per_chunk // (156 * sps) + 2)
+        self.flags = torch.zeros(Bmax, dtype=torch.uint8, device=dev)
+        self.amp = torch.zeros(Bmax, 2, dtype=torch.float32, device=dev)
+        self.toa = torch.zeros(Bmax, dtype=torch.float32, device=dev)
+        self.soft = torch.zeros(Bmax, NSOFT, dtype=torch.float32, device=dev)
+        ctx.reserve(Bmax)
+        self.nbursts = 0
+        self.last_nb = 0
+
+    def step(self):
+        self.fe.push_chunk(self.iq)
+        r = self.fe.pop_raw()
+        if r is None:
+            return
+        ps, po, pl, tn, nb = r
+        B = self.S * nb
+        self.ctx._chk(self.ctx.L.trxsig_detect_demod_normal_batch(
+            self.ctx.h, ps, po, pl, B, self.tsc, 3.0, 0.0, self.flags.data_ptr(), self.amp.data_ptr(), self.toa.data_ptr(), None,
+            self.soft.data_ptr(), None, NSOFT, NSOFT), "trxsig_detect_demod_normal_batch")
+        self.nbursts += B
+        self.last_nb = B
+
+    def units_per_step(self):
+        return self.S * self.K * self.per_chunk / (156.25 * self.sps)     # bursts' worth of samples per step
+
+    def describe(self, world):
+        return {"workload": "config4: %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), unUSRPify + "
+                            "polyphase resample 260:96 (961-tap Kaiser LPF) + 157/156/156/156 slicing + TSC %d detect (thr 3.0) + demod to "
+                            "%d soft bits" % (self.S, self.K, self.tsc, NSOFT),
+                "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
+                "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
+
+    def sanity(self):
+        det = (self.flags[:self.last_nb] & self.pkg.F_DETECT) != 0
+        return {"detected_frac": round(float(det.float().mean().item()), 4), "bursts_cut_last_step": int(self.last_nb)}
+
+    def fresh_inputs(self, steps):
+        return None
+
+    def cpu_baseline(self, check):
+        """The oracle's polyphaseResampleVector + analyzeTrafficBurst + demodulateBurst chain on ONE host core over a bounded
+        sample of the streams (chunk by chunk with history, as RadioInterface::pullBuffer)."""
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oraclebind
+        o = oraclebind.Oracle(self.sps)
+        iq = self.iq[0].cpu().numpy()
+        nchunks = min(self.K, 64)
+        t0 = time.perf_counter()
+        hist = np.zeros(192, np.complex64); rcv = []
+        for c in range(nchunks):
+            ch = iq[c * 864:(c + 1) * 864]
+            cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)
+            y = o.polyphase_resample(np.concatenate([hist, cf]), 65 * self.sps, 96, self.lpf)
+            rcv.append(y[2 * 65 * self.sps:]); hist = cf[-192:]
+        x = np.concatenate(rcv)
+        lens = []; pos = 0; tn = 0
+        while x.size - pos > (156 + (tn % 4 == 0)) * self.sps:
+            n = (156 + (tn % 4 == 0)) * self.sps; lens.append(n); pos += n; tn = (tn + 1) % 8
+        lens = np.array(lens, np.int32); off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        ok, amp, toa, soft = o.normal_batch(x, off, lens, self.tsc, nthreads=1)
+        tt = time.perf_counter() - t0
+        out = {"cpu_baseline": {"value": round(len(lens) / tt / 1e6, 6), "unit": "Mbursts/s", "cores": 1, "kind": "port",
+                                "sample": "%d chunks of stream 0 (%d bursts): polyphaseResampleVector chunk by chunk + analyzeTrafficBurst + "
+                                          "demodulateBurst, oracle/sigproc_oracle.c, one thread, %.1f s" % (nchunks, len(lens), tt)}}
+        if check:
+            # the first bursts of stream 0 as the device cut them on the FIRST step are not kept; re-run one step on a fresh front end
+            from openbts_ttsou_amd.frontend import RxFrontEnd
+            fe = RxFrontEnd(self.ctx, self.S, self.lpf, max_chunks=self.K)
+            fe.push_chunk(self.iq)
+            xg, og, lg, tng = fe.pop_bursts()
+            nb = og.numel() // self.S
+            xh = xg.cpu().numpy().view(np.complex64).ravel(); o0 = int(og[0].item())
+            m = min(pos, int(lg[:nb].sum().item()))
+            out["oracle_check_resampled_stream0"] = bool(np.array_equal(xh[o0:o0 + m], x[:m]))
+        return out
+
+
+# ======================================================================================================================
 def _free_port():
     import socket
     s = socket.socket()
@@ -137,7 +348,6 @@ def selftest_cpu(args):
     blob, broadcast + checksum on every rank, MAX all-reduce, all-gather of the ranks, one JSON line from
     rank 0.  No burst is processed and no throughput is reported (`value` null)."""
     import numpy as np
-    import torch
     import torch.distributed as dist
     import _pkg
     pkg = _pkg.load()
@@ -149,8 +359,8 @@ def selftest_cpu(args):
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
-    blob, _ = tdist.broadcast_tables(pkg, SPS, device=None, src=0)
-    lo, hi = tdist.shard_range(args.bursts * world, rank, world)
+    blob, _ = tdist.broadcast_tables(pkg, 4, device=None, src=0)
+    lo, hi = tdist.shard_range((args.bursts or 65536) * world, rank, world)
     tmax = tdist.max_over_ranks(1.0 + rank)
     seen = tdist.ranks_seen(rank, None)
     if world > 1:
@@ -158,6 +368,7 @@ def selftest_cpu(args):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"selftest": True, "value": None, "n_gpus": world, "ranks_seen": seen, "tmax": tmax,
+                          "workload": args.workload,
                           "tables_fnv": int(np.frombuffer(blob.tobytes()[-8:], np.uint64)[0]) if len(blob) >= 8 else 0,
                           "shard0": [lo, hi]}))
 
@@ -165,17 +376,22 @@ def selftest_cpu(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None, help="default: 1000 (normal), 300 (rach), 100 (config4), 500 (config5)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: a tenth of --steps")
     ap.add_argument("--preheat-ms", type=float, default=40.0,
                     help="untimed passes before the warm-up until this much GPU time has gone by: the device needs "
                          "~15-20 ms of load to leave its idle clocks (measured: 496 Mbursts/s over the first 50 "
                          "steps of a cold run, 573 once it has ramped), whatever --warmup/--steps the caller picks")
-    ap.add_argument("--bursts", type=int, default=BURSTS_PER_GPU, help="bursts per GPU")
+    ap.add_argument("--bursts", type=int, default=None, help="bursts per GPU (normal, rach, config5; default 65536)")
+    ap.add_argument("--streams", type=int, default=128, help="config4: ARFCN streams per GPU")
+    ap.add_argument("--chunks", type=int, default=125,
+                    help="config4: 864-sample chunks per stream per step (125 chunks = 117 whole 157-156-156-156 groups: the "
+                         "repeated input stays aligned with the front end's burst schedule from step to step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
-    ap.add_argument("--workload", choices=["normal", "rach"], default="normal",
-                    help="normal = BASELINE config 2 (the headline metric); rach = config 3 (side measurement)")
+    ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
+                    help="normal = BASELINE config 2 (the headline metric); rach = config 3; config4 = resample + slice + detect "
+                         "per ARFCN stream; config5 = 52M equaliser leg, fp16 storage (side measurements)")
     ap.add_argument("--chain-lag", type=int, default=None, help="A/B: path 5, tiles between detect and demodulate workgroups")
     ap.add_argument("--path", type=int, default=None, choices=[0, 1, 2, 3, 4, 5],
                     help="A/B: normal-burst implementation (trxsig_set_tuning); default = the library's")
@@ -192,13 +408,23 @@ def main():
         spawn_ranks(args, sys.argv[1:])                     # does not return
     if args.selftest_cpu:
         return selftest_cpu(args)
+    if args.steps is None:
+        args.steps = {"normal": 1000, "rach": 300, "config4": 100, "config5": 500}[args.workload]
+    if args.warmup is None:
+        args.warmup = max(1, args.steps // 10)
 
-    import numpy as np
     import torch
     import _pkg
     pkg = _pkg.load()
     from openbts_ttsou_amd import dist as tdist
-    from openbts_ttsou_amd import synth
+
+    if args.workload == "config4":
+        wl = Config4(args)
+    elif args.workload == "config5":
+        from bench_config5 import Config5                   # (kept beside bench.py: its data generator is long)
+        wl = Config5(args)
+    else:
+        wl = Normal(args, rach=args.workload == "rach")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -217,10 +443,10 @@ def main():
     # constant tables: built once on rank 0, broadcast over RCCL (xGMI), validated, then each rank's
     # context is created from the received device blob
     if world > 1:
-        _, tbl = tdist.broadcast_tables(pkg, SPS, device=dev, src=0)
-        ctx = pkg.TrxSig(SPS, local, tables_blob=tbl)
+        _, tbl = tdist.broadcast_tables(pkg, wl.sps, device=dev, src=0)
+        ctx = pkg.TrxSig(wl.sps, local, tables_blob=tbl)
     else:
-        ctx = pkg.TrxSig(SPS, local)
+        ctx = pkg.TrxSig(wl.sps, local)
     ctx.use_torch_stream()
     if args.path is not None:
         ctx.set_tuning(normal_path=args.path)
@@ -231,26 +457,8 @@ def main():
     if args.spec_peak:
         ctx.set_tuning(spec_peak=args.spec_peak)
 
-    B = args.bursts
-    rach = args.workload == "rach"
-    if rach:
-        x, off, length, meta = synth.rach_batch_torch(SPS, B, seed=0xB5E55ED0 + rank, device=dev)
-    else:
-        x, off, length, meta = synth.normal_batch_torch(SPS, B, TSC, seed=0xB5E55ED0 + rank, device=dev)
-    xf = torch.view_as_real(x).contiguous()
-    flags = torch.zeros(B, dtype=torch.uint8, device=dev)
-    amp = torch.zeros(B, 2, dtype=torch.float32, device=dev)
-    toa = torch.zeros(B, dtype=torch.float32, device=dev)
-    soft = torch.zeros(B, NSOFT, dtype=torch.float32, device=dev)
-    ctx.reserve(B)
-
-    def step():
-        if rach:
-            ctx.detect_demod_rach(xf, off, length, flags, amp, toa, soft, detect_thresh=5.0, energy_thresh=-1.0,
-                                  nsoft=NSOFT, soft_stride=NSOFT)
-        else:
-            ctx.detect_demod_normal(xf, off, length, TSC, flags, amp, toa, soft, detect_thresh=3.0,
-                                    energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+    wl.setup(pkg, ctx, dev, rank, args)
+    step = wl.step
 
     def barrier():
         if world > 1:
@@ -261,10 +469,10 @@ def main():
     t_pre = time.perf_counter()
     n_pre = 0
     while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-        for _ in range(20):
+        for _ in range(5):
             step()
         torch.cuda.synchronize()
-        n_pre += 20
+        n_pre += 5
     for _ in range(args.warmup):
         step()
     # ---- the timed region: exactly K steps between barriers, nothing else on the stream ----
@@ -278,7 +486,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = tdist.max_over_ranks(elapsed, dev)
     seen = tdist.ranks_seen(rank, dev)
-    # ---- per-kernel durations: the same K steps again with every launch bracketed by HIP events
+    # ---- per-kernel durations: the same steps again with every launch bracketed by HIP events
     #      (kept out of the timed region: the extra event records stretch the gaps between kernels)
     ctx.profile_enable(True)
     for _ in range(min(args.steps, 200)):
@@ -286,85 +494,41 @@ def main():
     prof = ctx.profile_collect()
     ctx.profile_enable(False)
 
-    # ---- side measurement (outside the timed region): the same steps over THREE different input batches in
-    #      rotation (1 GB > the 256 MB memory-side cache), i.e. without the part of the input that a repeated
-    #      batch still finds in that cache from the step before
-    fresh = None
-    if world == 1 and not rach and not args.no_fresh:
-        xs = [xf]
-        for k in (1, 2):
-            xk, offk, lenk, _ = synth.normal_batch_torch(SPS, B, TSC, seed=0xB5E55ED0 + 1000 * k, device=dev)
-            assert torch.equal(offk, off) and torch.equal(lenk, length)
-            xs.append(torch.view_as_real(xk).contiguous())
-        so2 = torch.zeros_like(soft); fl2 = torch.zeros_like(flags); am2 = torch.zeros_like(amp); to2 = torch.zeros_like(toa)
-        def step_k(i):
-            ctx.detect_demod_normal(xs[i % 3], off, length, TSC, fl2, am2, to2, so2, detect_thresh=3.0,
-                                    energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
-        kf = min(args.steps, 600)
-        for i in range(60):
-            step_k(i)
-        torch.cuda.synchronize()
-        tf = time.perf_counter()
-        for i in range(kf):
-            step_k(i)
-        torch.cuda.synchronize()
-        tf = time.perf_counter() - tf
-        fresh = {"value": round(B * kf / tf / 1e6, 3), "unit": "Mbursts/s", "inputs_in_rotation": 3, "steps": kf}
-        del xs, so2
-
-    # results sanity (outside the timed region): detections and hard bits of the clean bursts
-    det = (flags & pkg.F_DETECT) != 0
-    clean = det & (meta["sigma"] <= 0.1)
-    cols = slice(8, 85) if rach else slice(0, 148)
-    hard_ok = bool(((soft[clean][:, cols] > 0.5).to(torch.uint8) == meta["bits"][clean][:, cols]).all().item())
-    det_frac = float(det.float().mean().item())
-
+    fresh = wl.fresh_inputs(args.steps) if (world == 1 and not args.no_fresh) else None
+    sanity = wl.sanity()
     if rank != 0:
         return
-    value = world * B * args.steps / elapsed / 1e6
+    units = wl.units_per_step()
+    value = world * units * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
     roof = None
     if dom[0]:
         avg_ms = dom[1][0] / max(dom[1][1], 1)
-        achieved = KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES) * B / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom[0], B),
-                "alg_bytes_per_launch": KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES) * B,
-                "avg_kernel_ms": round(avg_ms, 4),
-                "alg_bytes_per_burst": KERNEL_ALG_BYTES.get(dom[0], ALG_BYTES),
-                "pipeline_achieved": round(ALG_BYTES * B * args.steps / (ev_ms * 1e-3) / 1e9, 1),
-                "pipeline_frac": round(ALG_BYTES * B * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}}
+        per_unit = wl.kernel_alg.get(dom[0], wl.alg_bytes)
+        launch_units = units
+        if dom[0] == "k_resample" and args.workload == "config4":
+            per_unit, launch_units = 4 * 864 + 8 * wl.per_chunk, wl.S * wl.K     # per stream-chunk: int16 read, c64 written
+        achieved = per_unit * launch_units / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": wl.kernel_names.get(dom[0], dom[0]), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic(wl.kernel_names.get(dom[0], dom[0]), launch_units),
+                "alg_bytes_per_launch": int(per_unit * launch_units), "avg_kernel_ms": round(avg_ms, 4),
+                "alg_bytes_per_unit": per_unit,
+                "pipeline_achieved": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9, 1),
+                "pipeline_frac": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels_ms": {wl.kernel_names.get(k, k): round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}}
     out = {
         "metric": "Mbursts/s (156.25-sym @ 4 sps) demod+detect", "value": round(value, 3), "unit": "Mbursts/s",
         "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("config3: %d access bursts/GPU, sps=4, detectRACHBurst over all lags (thr 5.0) + demod "
-                                "to %d soft bits" % (B, NSOFT)) if rach else
-                               ("config2: %d normal bursts/GPU, sps=4, 628/624/624/624 complex f32 samples, "
-                                "TSC %d, detect (thr 3.0) + demod to %d soft bits" % (B, TSC, NSOFT)),
-                   "bursts_per_gpu": B, "sps": SPS, "parallelism": "burst-sharded x%d (no data-path collective)" % world},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+        "config": wl.describe(world),
         "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "preheat_steps": n_pre,
-        "detected_frac": round(det_frac, 4), "clean_hard_bits_ok": hard_ok,
         "roofline": roof, "fresh_inputs": fresh,
     }
-    if not args.no_cpu_baseline and world == 1 and not rach:
-        n = min(B, 16384)
-        end = int(off[n - 1].item() + length[n - 1].item())
-        xh = x[:end].cpu().numpy()
-        main_leg, port_leg = cpu_baseline(xh, off[:n].cpu().numpy(), length[:n].cpu().numpy(), SPS, TSC)
-        out["cpu_baseline"] = main_leg
-        if port_leg is not None:
-            out["cpu_port"] = port_leg                   # the oracle port beside the real reference
-        if args.check:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oraclebind
-            ok, oamp, otoa, osoft = oraclebind.Oracle(SPS).normal_batch(xh, off[:n].cpu().numpy(),
-                                                                        length[:n].cpu().numpy(), TSC, nthreads=8)
-            same = (np.array_equal(det[:n].cpu().numpy(), ok.astype(bool)) and
-                    np.array_equal(soft[:n].cpu().numpy(), osoft) and np.array_equal(toa[:n].cpu().numpy(), otoa))
-            out["oracle_check_first_%d" % n] = bool(same)
+    out.update(sanity)
+    if not args.no_cpu_baseline and world == 1:
+        out.update(wl.cpu_baseline(args.check))
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -99,7 +99,7 @@ struct TrxResampleArgs {
   int o_skip, n_out;                                       // outputs [o_skip, n_out) of every window are produced
   void *out; long long out_stride, out_win_step;           // window w of stream s writes at out + s*out_stride + w*out_win_step
   float gain;                                              // int16 output
-  int OB;
+  int OB, xcap, taps_lds;                                  // filled in by the launcher
 };
 hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
                                   TrxProfiler *prof);

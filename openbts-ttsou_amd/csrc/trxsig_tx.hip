@@ -69,12 +69,15 @@ __global__ __launch_bounds__(256) void k_modulate(const TrxTables *__restrict__ 
 //   OUT_I16: scaleVector(gain) and USRPifyVector (:148-151, :74-89) on the way out (RadioInterface::pushBuffer).
 // ---------------------------------------------------------------------------------------------
 #define TRX_RES_XCAP 4096                                  // staged input samples per workgroup
-#define TRX_RES_LCAP 1024                                  // staged taps
+#define TRX_RES_LCAP 4096                                  // staged taps
 
 template <bool IN_I16, bool OUT_I16>
 __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
-  __shared__ __attribute__((aligned(16))) cx X[TRX_RES_XCAP];
-  __shared__ float TP[TRX_RES_LCAP];
+  // dynamic LDS, sized by the launcher to what this launch needs (a window of 1056 samples + 961 taps is 12 KB: a dozen
+  // workgroups per CU instead of four): [xcap complex samples][taps]
+  extern __shared__ __attribute__((aligned(16))) char res_lds[];
+  cx *X = reinterpret_cast<cx *>(res_lds);
+  float *TP = reinterpret_cast<float *>(res_lds + sizeof(cx) * (size_t)a.xcap);
   const int tile = blockIdx.x, w = blockIdx.y, s = blockIdx.z;
   const int o0 = a.o_skip + tile * a.OB;
   if (o0 >= a.n_out) return;
@@ -84,26 +87,60 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
   long long t1 = ((long long)(o1 - 1 + D) * a.Q) / a.P;
   const int lo = t0 < 0 ? 0 : (int)t0;
   const int hi = t1 > a.n - 1 ? a.n - 1 : (int)t1;                  // staged input samples [lo, hi] of this window
-  const bool taps_lds = a.L <= TRX_RES_LCAP;
-  if (taps_lds) for (int i = threadIdx.x; i < a.L; i += 256) TP[i] = a.lpf[i];
+  const bool taps_lds = a.taps_lds != 0;
+  // staging: the loads of a round of eight go out together (a plain loop would wait for each load before issuing the next:
+  // five dependent HBM round trips per workgroup was what the first version of this kernel spent its time on)
+  if (taps_lds) {
+    for (int i0 = threadIdx.x; i0 < a.L; i0 += 256 * 4) {
+      float tv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int i = i0 + 256 * q; tv[q] = i < a.L ? a.lpf[i] : 0.0f; }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int i = i0 + 256 * q; if (i < a.L) TP[i] = tv[q]; }
+    }
+  }
   if (IN_I16) {
     const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
     const short2 *hist = a.hist + (size_t)s * a.hist_len;
     const long long base = (long long)w * a.win_step - a.hist_len;  // raw index of the window's sample 0
-    for (int i = lo + threadIdx.x; i <= hi; i += 256) {
-      const long long r = base + i;
-      const short2 v = r < 0 ? hist[a.hist_len + r] : raw[r];
-      X[i - lo] = a.swap ? mk((float)v.y, (float)v.x) : mk((float)v.x, (float)v.y);   // unUSRPifyVector (:108-109)
+    for (int i0 = lo + threadIdx.x; i0 <= hi; i0 += 256 * 8) {
+      short2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + 256 * q;
+        const long long r = base + i;
+        v[q] = i <= hi ? (r < 0 ? hist[a.hist_len + r] : raw[r]) : make_short2(0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + 256 * q;
+        if (i <= hi) X[i - lo] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
+      }
     }
   } else {
     const cx *x = reinterpret_cast<const cx *>(a.in) + (size_t)s * a.in_stride + (size_t)w * a.win_step;
-    for (int i = lo + threadIdx.x; i <= hi; i += 256) X[i - lo] = x[i];
+    for (int i0 = lo + threadIdx.x; i0 <= hi; i0 += 256 * 8) {
+      cx v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const int i = i0 + 256 * q; v[q] = i <= hi ? x[i] : mk(0, 0); }
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const int i = i0 + 256 * q; if (i <= hi) X[i - lo] = v[q]; }
+    }
   }
   __syncthreads();
+  // outputIx*Q = branch + P*inOff is divided once per lane; from one of a lane's outputs to its next it grows by 256*Q
+  int branch0, inOff0;
+  {
+    const long long oq = (long long)(o0 + (int)threadIdx.x + D) * a.Q;
+    if (oq < 0x7fffffffLL) { branch0 = (int)((unsigned)oq % (unsigned)a.P); inOff0 = (int)((unsigned)oq / (unsigned)a.P); }
+    else { branch0 = (int)(oq % a.P); inOff0 = (int)(oq / a.P); }
+  }
+  const int step_b = (int)((256LL * a.Q) % a.P), step_i = (int)((256LL * a.Q) / a.P);
   for (int o = o0 + threadIdx.x; o < o1; o += 256) {
-    const long long oq = (long long)(o + D) * a.Q;                  // outputIx*Q
-    const int branch = (int)(oq % a.P);                             // :1180
-    int inOff = (int)((oq - branch) / a.P);                         // :1181
+    const int branch = branch0;                                     // (outputIx*Q) % P (:1180)
+    int inOff = inOff0;                                             // (outputIx*Q - branch) / P (:1181)
+    branch0 += step_b; inOff0 += step_i;
+    if (branch0 >= a.P) { branch0 -= a.P; inOff0++; }
     int fi = branch;
     while (inOff >= a.n) { inOff--; fi += a.P; }                    // :1183-1186
     cx sum = mk(0, 0);
@@ -198,13 +235,18 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
                                   TrxProfiler *prof) {
   if (S <= 0 || n_windows <= 0 || a.n_out <= a.o_skip) return hipSuccess;
   a.OB = resample_tile(a);
-  if (((long long)(a.OB - 1) * a.Q) / a.P + (a.L + a.P - 1) / a.P + 3 > TRX_RES_XCAP) return hipErrorInvalidValue;
+  long long span = ((long long)(a.OB - 1) * a.Q) / a.P + (a.L + a.P - 1) / a.P + 4;      // staged samples a tile can need
+  if (span > TRX_RES_XCAP) return hipErrorInvalidValue;
+  if (span > a.n) span = a.n;
   if (S > 65535 || n_windows > 65535) return hipErrorInvalidValue;
+  a.xcap = (int)((span + 1) & ~1LL);
+  a.taps_lds = a.L <= TRX_RES_LCAP;
+  const size_t lds = sizeof(trx_c32) * (size_t)a.xcap + (a.taps_lds ? sizeof(float) * (size_t)a.L : 0);
   const dim3 grid((a.n_out - a.o_skip + a.OB - 1) / a.OB, n_windows, S), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
-  if (in_i16 && !out_i16) k_resample<true, false><<<grid, block, 0, st>>>(a);
-  else if (!in_i16 && out_i16) k_resample<false, true><<<grid, block, 0, st>>>(a);
-  else if (!in_i16 && !out_i16) k_resample<false, false><<<grid, block, 0, st>>>(a);
+  if (in_i16 && !out_i16) k_resample<true, false><<<grid, block, lds, st>>>(a);
+  else if (!in_i16 && out_i16) k_resample<false, true><<<grid, block, lds, st>>>(a);
+  else if (!in_i16 && !out_i16) k_resample<false, false><<<grid, block, lds, st>>>(a);
   else return hipErrorInvalidValue;
   if (prof) prof->end(TRXSIG_K_RESAMPLE, st);
   return hipGetLastError();
