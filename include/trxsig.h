@@ -250,6 +250,16 @@ int trxsig_equalize_normal_batch(trxsig_ctx *ctx,
                                  uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
                                  trxsig_c32 *d_w, trxsig_c32 *d_b,
                                  float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+/* The same with the bursts stored as fp16 I/Q pairs (BASELINE config 5): sample_format TRXSIG_SAMPLES_F16 = d_samples is
+ * an array of half-precision {re, im} pairs (4 bytes per sample; d_offset / d_length still count samples),
+ * TRXSIG_SAMPLES_C32 = complex float32 as above.  The kernels read the fp16 words themselves and widen in registers (exact),
+ * so the results equal the float32 call on the same values bit for bit -- there is no float32 copy of the batch in HBM. */
+enum { TRXSIG_SAMPLES_C32 = 0, TRXSIG_SAMPLES_F16 = 1 };
+int trxsig_equalize_normal_batch_fmt(trxsig_ctx *ctx, const void *d_samples, int sample_format, const int32_t *d_offset,
+                                     const int32_t *d_length, int B, int tsc, float detect_thresh, float energy_thresh,
+                                     int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                     trxsig_c32 *d_w, trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
+                                     int soft_stride);
 
 /* ---- convenience: host-buffer single-call wrappers (copy in, run, copy out, synchronise).
  *   These exist so Transceiver::pullRadioVector can keep calling one burst at a time; they are
@@ -371,7 +381,7 @@ int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on 
 enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_K_RACH_CORR = 3,
        TRXSIG_K_RACH_PEAK = 4, TRXSIG_K_MODULATE = 5, TRXSIG_K_RESAMPLE = 6, TRXSIG_K_EQUALIZE = 7,
        TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_FEC = 10, TRXSIG_K_NORMAL_CHAIN = 11,
-       TRXSIG_K_COUNT = 12 };
+       TRXSIG_K_EQ_DELAY = 12, TRXSIG_K_EQ_DFE = 13, TRXSIG_K_COUNT = 14 };   /* TRXSIG_K_EQUALIZE = k_eq_detect / k_design_dfe */
 const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);

@@ -68,6 +68,8 @@ def lib():
         L.trxsig_demodulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32]
         L.trxsig_equalize_normal_batch.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, vp, vp, vp,
                                                    vp, vp, i32, i32]
+        L.trxsig_equalize_normal_batch_fmt.argtypes = [vp, vp, i32, vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, vp, vp, vp,
+                                                       vp, vp, i32, i32]
         L.trxsig_modulate_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L.trxsig_modulate_host.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.c_int64]
         L.trxsig_resample_batch.argtypes = [vp, vp, i32, C.c_int64, i32, i32, i32, vp, i32, vp, C.c_int64]
@@ -255,11 +257,12 @@ class TrxSig:
 
     def equalize_normal(self, samples, offset, length, tsc, flags, amp, toa, soft, w=None, b=None, hard=None,
                         detect_thresh=3.0, energy_thresh=0.0, variant52m=True, max_toa=4, nsoft=148,
-                        soft_stride=None):
+                        soft_stride=None, fp16=False):
+        """fp16=True: `samples` holds half-precision I/Q pairs (read directly by the kernels)."""
         if soft_stride is None:
             soft_stride = soft.shape[-1]
-        self._chk(self.L.trxsig_equalize_normal_batch(
-            self.h, _ptr(samples), _ptr(offset), _ptr(length), offset.numel(), tsc, detect_thresh, energy_thresh,
+        self._chk(self.L.trxsig_equalize_normal_batch_fmt(
+            self.h, _ptr(samples), int(bool(fp16)), _ptr(offset), _ptr(length), offset.numel(), tsc, detect_thresh, energy_thresh,
             int(variant52m), max_toa, _ptr(flags), _ptr(amp), _ptr(toa), _ptr(w), _ptr(b), _ptr(soft), _ptr(hard),
             nsoft, soft_stride), "trxsig_equalize_normal_batch")
 
@@ -400,7 +403,7 @@ class TrxSig:
 
     def profile_collect(self):
         """{kernel name: (total_ms, launches)} since the last collect (synchronises)."""
-        n = 12                                   # TRXSIG_K_COUNT
+        n = 14                                   # TRXSIG_K_COUNT
         ms = (C.c_float * n)(); cnt = (C.c_int * n)()
         self._chk(self.L.trxsig_profile_collect(self.h, ms, cnt), "trxsig_profile_collect")
         return {self.L.trxsig_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
@@ -455,7 +458,7 @@ class TrxHost:
 
     def _chk(self, rc, what):
         if rc < 0:
-            raise RuntimeError("%s: %d (%s)" % (what, rc, self.L.trxsig_trx_last_error(self.h).decode()))
+            raise TrxSigError("%s: %d (%s)" % (what, rc, self.L.trxsig_trx_last_error(self.h).decode()))
         return rc
 
     def control(self, msg):

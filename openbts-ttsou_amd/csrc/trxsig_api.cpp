@@ -456,7 +456,7 @@ int trxsig_estimate_dfe_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const 
   DeviceGuard g(c->device);
   int rc = ensure_eq(c, B);
   if (rc != TRXSIG_OK) return rc;
-  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
+  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc,
                                     detect_thresh, snr_thresh, snr_value, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
                                     (float *)c->d_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b, nullptr, c->prof));
   return TRXSIG_OK;
@@ -478,7 +478,7 @@ int trxsig_channel_estimate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, co
   float *toa_eq = (float *)c->d_eq;
   trx_c32 *w = (trx_c32 *)(c->d_eq + sizeof(float) * (size_t)c->eq_cap);
   trx_c32 *bq = w + (size_t)7 * c->eq_cap;
-  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
+  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc,
                                     detect_thresh, -1.0f, 1.0f, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa, toa_eq,
                                     d_chan_off, w, bq, (trx_c32 *)d_chan, c->prof));
   return TRXSIG_OK;
@@ -509,7 +509,7 @@ int trxsig_equalize_taps_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const
   int rc = ensure_eq(c, B);
   if (rc != TRXSIG_OK) return rc;
   trx_c32 *xd = (trx_c32 *)(c->d_eq + (size_t)c->eq_cap * (4 + 56 + 40));
-  HIPCHK(c, trx_launch_equalize_taps(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+  HIPCHK(c, trx_launch_equalize_taps(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B,
                                      (const trx_c32 *)d_amp, d_toa_eq, d_enable, (const trx_c32 *)d_w, (const trx_c32 *)d_b,
                                      xd, EQ_XS, d_soft, d_hard, nsoft, soft_stride, c->prof));
   return TRXSIG_OK;
@@ -520,8 +520,19 @@ int trxsig_equalize_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, con
                                  int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
                                  trxsig_c32 *d_w, trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
                                  int soft_stride) {
+  return trxsig_equalize_normal_batch_fmt(c, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc, detect_thresh, energy_thresh,
+                                          variant52m, max_toa, d_flags, d_amp, d_toa, d_w, d_b, d_soft, d_hard, nsoft, soft_stride);
+}
+
+int trxsig_equalize_normal_batch_fmt(trxsig_ctx *c, const void *d_samples, int sample_format, const int32_t *d_offset,
+                                     const int32_t *d_length, int B, int tsc, float detect_thresh, float energy_thresh,
+                                     int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                                     trxsig_c32 *d_w, trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
+                                     int soft_stride) {
   if (!c) return TRXSIG_EINVAL;
   if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "trxsig_equalize_normal_batch: equalizeBurst needs sps == 1");
+  if (sample_format != TRXSIG_SAMPLES_C32 && sample_format != TRXSIG_SAMPLES_F16)
+    return fail(c, TRXSIG_EINVAL, "trxsig_equalize_normal_batch_fmt: unknown sample format");
   if (bad_batch(d_samples, d_offset, d_length, B) || tsc < 0 || tsc > 7 || nsoft < 0 || nsoft > 157 ||
       soft_stride < nsoft || max_toa < 0 || max_toa > 17 ||
       (B > 0 && (!d_flags || !d_amp || !d_toa || (nsoft > 0 && !d_soft))))
@@ -538,7 +549,7 @@ int trxsig_equalize_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, con
   trx_c32 *xd = (trx_c32 *)(c->d_eq + cap * (4 + 56 + 40));
   if (d_w) w = (trx_c32 *)d_w;
   if (d_b) bq = (trx_c32 *)d_b;
-  HIPCHK(c, trx_launch_equalize(c->stream, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, tsc,
+  HIPCHK(c, trx_launch_equalize(c->stream, c->d_tables, d_samples, sample_format, d_offset, d_length, B, tsc,
                                 detect_thresh, energy_thresh, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
                                 toa_eq, w, bq, xd, XS, d_soft, d_hard, nsoft, soft_stride, c->prof));
   return TRXSIG_OK;
@@ -883,8 +894,8 @@ int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
 
 const char *trxsig_kernel_name(int id) {
   static const char *names[TRXSIG_K_COUNT] = { "k_tsc_corr", "k_tsc_peak", "k_demod", "k_rach_corr", "k_rach_peak",
-                                               "k_modulate", "k_resample", "k_equalize", "k_convert", "k_normal_fused", "k_fec_viterbi",
-                                               "k_normal_chain" };
+                                               "k_modulate", "k_resample", "k_eq_detect", "k_convert", "k_normal_fused", "k_fec_viterbi",
+                                               "k_normal_chain", "k_eq_delay", "k_eq_dfe" };
   return (id >= 0 && id < TRXSIG_K_COUNT) ? names[id] : "?";
 }
 int trxsig_fec_xcch_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_blocks, int wire,

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, TRX_CHAIN_WPS) void k_normal_chain(
     } else {
       const bool wide = (off & 1) == 0;
       if (wide && (N & 1) == 0) fused_demod<SPS, 64>(T, P, v, N, amp, toa, ln, sb, hb, nsoft, [] {}, nullptr, nullptr);
-      else demod_core<SPS, false, 148>(T, P, samples + off, N, wide, v, amp, toa, ln, sb, hb, nullptr, nsoft);
+      else demod_core<SPS, false, 148>(T, P, samples, off, N, wide, v, amp, toa, ln, sb, hb, nullptr, nsoft);
       wave_lds_fence();                                    // staging reads done before the next burst overwrites it
     }
 #pragma unroll

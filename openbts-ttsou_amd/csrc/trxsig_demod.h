@@ -36,8 +36,8 @@ struct DemodGeom {
 
 // everything of demodulateBurst after the burst's loads have been issued (v[] = the 16-byte loads of
 // the `wide` path, in flight): scale, stage, filter at the decimated instants, rotate, slice, store
-template <int SPS, bool RAW, int NSMAX>
-__device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *P, const cx *xb, int N, bool wide,
+template <int SPS, bool RAW, int NSMAX, typename SMP = SmpC32>
+__device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *P, const void *xbase, long long xoff, int N, bool wide,
                                            const float4 (&v)[(157 * SPS / 2 + 63) / 64], cx amp, float toa, int lane,
                                            float *sb, uint8_t *hb, cx *rawout, int nsoft) {
   typedef DemodGeom<SPS, NSMAX> G;
@@ -94,12 +94,12 @@ __device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *
     }
     if ((N & 1) && lane == 0) {
       const int u0 = N - 1 + lo;
-      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[N - 1], inv);
+      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(SMP::ld(xbase, xoff + N - 1), inv);
     }
   } else {
     for (int n = lane; n < N; n += 64) {
       const int u0 = n + lo;
-      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(xb[n], inv);
+      if (u0 >= 0 && u0 < G::U) P[(u0 % SPS) * G::QLEN + u0 / SPS] = cmul(SMP::ld(xbase, xoff + n), inv);
     }
   }
   wave_lds_fence();
@@ -295,9 +295,9 @@ __device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx 
 }
 
 
-template <int SPS, bool RAW, int NSMAX>
+template <int SPS, bool RAW, int NSMAX, typename SMP = SmpC32>
 __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables *__restrict__ T,
-                                               const cx *__restrict__ samples,
+                                               const void *__restrict__ samples,
                                                const int32_t *__restrict__ offset,
                                                const int32_t *__restrict__ length, int B,
                                                const cx *__restrict__ amp_in,
@@ -327,18 +327,15 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables 
     if (!RAW) for (int m = lane; m < nsoft; m += 64) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
     return;
   }
-  const cx *xb = samples + off;
-
-  // ---- issue the burst's loads first (16-byte path: 2 samples per lane per load) ----
-  constexpr int NLD = (157 * SPS / 2 + 63) / 64;           // float4 loads per lane
+  // ---- issue the burst's loads first (two samples per lane per load: 16 bytes of float32 pairs, 8 of fp16 pairs) ----
+  constexpr int NLD = (157 * SPS / 2 + 63) / 64;           // pair loads per lane
   const bool wide = (off & 1) == 0;
   float4 v[NLD];
   if (wide) {
-    const float4 *xv = reinterpret_cast<const float4 *>(xb);
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const int q = lane + 64 * i;
-      v[i] = (q < N / 2) ? xv[q] : make_float4(0, 0, 0, 0);
+      v[i] = (q < N / 2) ? SMP::ld2(samples, off, q) : make_float4(0, 0, 0, 0);
     }
   }
   // the common case (148 soft bits, even offset and length) goes through fused_demod: same arithmetic,
@@ -348,7 +345,7 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables 
     fused_demod<SPS, 64>(T, ph[wave], v, N, amp, toa, lane, sb, hb, nsoft, [] {}, nullptr, nullptr);
     return;
   }
-  demod_core<SPS, RAW, NSMAX>(T, ph[wave], xb, N, wide, v, amp, toa, lane, sb, hb,
+  demod_core<SPS, RAW, NSMAX, SMP>(T, ph[wave], samples, off, N, wide, v, amp, toa, lane, sb, hb,
                               RAW ? reinterpret_cast<cx *>(soft) + (size_t)b * stride : nullptr, nsoft);
 }
 

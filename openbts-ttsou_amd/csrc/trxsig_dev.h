@@ -43,6 +43,29 @@ __device__ __forceinline__ float norm2(cx x) { return x.i * x.i + x.r * x.r; }  
 __device__ __forceinline__ cx cinv(cx x) { float n = norm2(x); return mk(x.r / n, -x.i / n); }  // Complex.h:154-160
 __device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }               // Complex.h:85
 
+// How a burst's samples are stored in HBM: complex float32 (the reference's Complex<float>, 8 bytes) or fp16 I/Q pairs
+// (4 bytes; BASELINE config 5).  Widening fp16 -> float32 is exact, so every kernel computes in float32 on the same
+// values either way.  ld(): sample i; ld2(): samples 2q, 2q+1 as one float4 (needs the base 16 / 8 byte aligned).
+struct SmpC32 {
+  static constexpr int kBytes = 8;
+  static __device__ __forceinline__ cx ld(const void *base, long long i) { return reinterpret_cast<const cx *>(base)[i]; }
+  static __device__ __forceinline__ float4 ld2(const void *base, long long first, int q) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const cx *>(base) + first)[q];
+  }
+};
+struct SmpF16 {
+  static constexpr int kBytes = 4;
+  static __device__ __forceinline__ cx ld(const void *base, long long i) {
+    const float2 v = __half22float2(reinterpret_cast<const __half2 *>(base)[i]);
+    return mk(v.x, v.y);
+  }
+  static __device__ __forceinline__ float4 ld2(const void *base, long long first, int q) {
+    const uint2 u = reinterpret_cast<const uint2 *>(reinterpret_cast<const __half2 *>(base) + first)[q];
+    const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&u.x)), b = __half22float2(*reinterpret_cast<const __half2 *>(&u.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
+};
+
 struct TapArg { float v[32]; };   // conj'd non-zero midamble taps passed as a kernel argument => SGPRs
 
 // Tap classes.  The GMSK-rotated midamble taps are (+-1, eps) or (eps, +-1): one component is EXACTLY

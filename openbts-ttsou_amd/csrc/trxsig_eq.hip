@@ -25,9 +25,17 @@ namespace {
 #define EQ_NC 36            /* max correlation lags kept per burst */
 // two instantiations: the 52M windowed correlation with maxTOA <= 5 (11 lags, 26 window samples: 25 KB of LDS, four
 // workgroups per CU) and everything else (the classic 36-lag window, wide 52M windows)
-#define EQ_DETECT_LAUNCH(...)                                                                          \
-  if (variant52m && max_toa <= 5) k_eq_detect<12, 26><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
-  else k_eq_detect<EQ_NC, 52><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__)
+#define EQ_DETECT_LAUNCH_T(SMP, ...)                                                                        \
+  if (variant52m && max_toa <= 5) k_eq_detect<12, 26, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
+  else k_eq_detect<EQ_NC, 52, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__)
+#define EQ_DETECT_LAUNCH(...)                                                                               \
+  do { if (fmt == TRXSIG_SAMPLES_F16) { EQ_DETECT_LAUNCH_T(SmpF16, __VA_ARGS__); } else { EQ_DETECT_LAUNCH_T(SmpC32, __VA_ARGS__); } } while (0)
+#define EQ_DELAY_LAUNCH(...)                                                                                \
+  do {                                                                                                      \
+    const dim3 g_((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), b_(64 * TRX_DEMOD_WAVES);                   \
+    if (fmt == TRXSIG_SAMPLES_F16) k_demod<1, true, 157, SmpF16><<<g_, b_, 0, st>>>(__VA_ARGS__);           \
+    else k_demod<1, true, 157, SmpC32><<<g_, b_, 0, st>>>(__VA_ARGS__);                                     \
+  } while (0)
 
 // designDFE(channelResponse, SNRestimate, Nf = 7, ...) (sigProcLib.cpp:1246-1340), nu = 5: fully unrolled in registers.
 // chan: the six channel taps (already scaled by 1/amp, Transceiver.cpp:346); w: feed-forward, bq: feedback taps.
@@ -100,8 +108,8 @@ __device__ __forceinline__ void design_dfe7(const cx (&chan)[6], float snr, cx (
   }
 }
 
-template <int NCMAX, int NXMAX>                             // correlation lags / window samples kept per burst
-__global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+template <int NCMAX, int NXMAX, typename SMP>               // correlation lags / window samples kept per burst; sample storage
+__global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ T, const void *__restrict__ samples,
                                                   const int32_t *__restrict__ offset,
                                                   const int32_t *__restrict__ length, int B, int tsc,
                                                   float detect_thresh, float energy_thresh, int variant52m,
@@ -136,8 +144,6 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
     flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
     return;
   }
-  const cx *x = samples + off;
-
   // ---- window geometry (pure arithmetic; needed up front so that the window's loads can fly with the energy's) ----
   int ncorr, winStart, La, startIndex;
   unsigned maxTOA = (unsigned)max_toa;
@@ -163,9 +169,9 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   {
     const int step = variant52m ? 4 : 1;
 #pragma unroll
-    for (int i = 0; i < 20; i++) ev[i] = x[i * step];
+    for (int i = 0; i < 20; i++) ev[i] = SMP::ld(samples, off + i * step);
 #pragma unroll
-    for (int a = 0; a < NXMAX; a++) wv[a] = (winOk && a < La) ? x[winStart + a] : mk(0, 0);
+    for (int a = 0; a < NXMAX; a++) wv[a] = (winOk && a < La) ? SMP::ld(samples, off + winStart + a) : mk(0, 0);
   }
   // ---- energyDetect (:916-932; the 52M variant strides by 4, ref52:946-963) ----
   {
@@ -569,7 +575,7 @@ hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_
   return hipGetLastError();
 }
 
-hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
                                int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
                                trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
@@ -578,17 +584,18 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c3
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
                    variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr);
-  k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags,
-                                                           TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  if (prof) { prof->end(TRXSIG_K_EQUALIZE, st); prof->begin(TRXSIG_K_EQ_DELAY, st); }
+  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
   launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
-  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
   return hipGetLastError();
 }
 
 
 // the two halves of trx_launch_equalize on their own (the Transceiver facade caches DFE taps per timeslot):
 // channel estimate + designDFE only (energy gate off, explicit SNR threshold) ...
-hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof) {
@@ -600,15 +607,15 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const tr
   return hipGetLastError();
 }
 // ... and scaleVector(burst, 1/amp) + equalizeBurst(burst, toa_eq, w, b) with caller-supplied taps (7 + 5 per burst)
-hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                     const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
                                     float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
-  if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
-  k_demod<1, true, 157><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
-      dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
+  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
   launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
-  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
   return hipGetLastError();
 }

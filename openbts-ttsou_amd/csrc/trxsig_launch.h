@@ -111,7 +111,7 @@ hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long lon
 
 // sps = 1 equaliser path; xd: B x xstride complex scratch (xstride >= 157), toa_eq: B floats scratch,
 // w: B x 7, bq: B x 5 complex
-hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *samples, int fmt /* TRXSIG_SAMPLES_* */, const int32_t *off,
                                const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
                                int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
                                trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
@@ -129,7 +129,7 @@ hipError_t trx_launch_fec(hipStream_t st, int mode, const float *soft, long long
 
 // the halves of trx_launch_equalize (see trxsig_eq.hip): channel estimate + designDFE with an explicit SNR
 // threshold and no energy gate; equalizeBurst with caller-supplied taps (flags: DETECT bit = burst enabled)
-hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan /* B x 6 or NULL */,
@@ -137,7 +137,7 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const tr
 // designDFE(chan, snr, 7) alone; amp != NULL: scaleVector(chan, 1/amp) first
 hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
                                  trx_c32 *bq, TrxProfiler *prof);
-hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
+hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                     const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
                                     float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
