@@ -414,6 +414,15 @@ enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENER
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes);
+/* Multi-GPU set-up for a host that is not Python (one process or thread per GPU): the ONE collective of the
+ * path, an RCCL broadcast of the table blob over xGMI.  Every rank calls it with its ncclComm_t and a device buffer of
+ * trxsig_tables_bytes() bytes -- on `root` that buffer holds the blob (trxsig_tables_device(ctx) of a context made with
+ * trxsig_create, or an upload of trxsig_tables_build_host), on the others it receives it; then the others call
+ * trxsig_create_from_tables, which validates magic / version / checksum.  Equivalent to
+ *   ncclBroadcast(d_blob, d_blob, bytes, ncclUint8, root, comm, stream);
+ * librccl.so is loaded at the first call (libtrxsig does not link it).  Stream-ordered: synchronise `hip_stream` before
+ * trxsig_create_from_tables. */
+int trxsig_tables_broadcast(void *nccl_comm, void *d_blob, size_t bytes, int root, void *hip_stream);
 /* The error bar of the access-burst detector's approximate correlation pass for this table blob (host computation,
  * no GPU): *bound x sqrt(sum |x[n]|^2 over the burst) bounds |approximate - reference| correlation amplitude at any
  * lag (derivation: csrc/trxsig_rach.hip); *seq_norm (optional) = the 2-norm of the RACH sequence, for scale.  The

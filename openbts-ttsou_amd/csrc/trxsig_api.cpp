@@ -3,6 +3,8 @@
 // here except the init-time table construction (trxsig_tablegen.cpp); there is no CPU fallback.
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -989,6 +991,25 @@ int trxsig_profile_collect(trxsig_ctx *c, float total_ms[TRXSIG_K_COUNT], int la
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes) {
   if (!h_blob || bytes != sizeof(TrxTables)) return TRXSIG_EINVAL;
   return trx_tables_valid((const TrxTables *)h_blob) ? TRXSIG_OK : TRXSIG_EINVAL;
+}
+
+// ---- RCCL broadcast of the table blob for hosts that are not Python (the only collective of the path) ----
+// librccl is loaded on first use; libtrxsig does not link it (a single-GPU host never needs it).
+int trxsig_tables_broadcast(void *nccl_comm, void *d_blob, size_t bytes, int root, void *hip_stream) {
+  if (!nccl_comm || !d_blob || bytes != sizeof(TrxTables) || root < 0) return TRXSIG_EINVAL;
+  typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);   // ncclBroadcast (rccl.h:591)
+  static bcast_fn fn = nullptr;
+  if (!fn) {
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { std::fprintf(stderr, "trxsig_tables_broadcast: cannot load librccl.so (%s)\n", dlerror()); return TRXSIG_ENODEV; }
+    fn = (bcast_fn)dlsym(h, "ncclBroadcast");
+    if (!fn) { std::fprintf(stderr, "trxsig_tables_broadcast: librccl.so has no ncclBroadcast\n"); return TRXSIG_ENODEV; }
+  }
+  const int nccl_uint8 = 1;                                 // ncclUint8 (rccl.h:460)
+  const int rc = fn(d_blob, d_blob, bytes, nccl_uint8, root, nccl_comm, (hipStream_t)hip_stream);   // in place on every rank
+  if (rc != 0) { std::fprintf(stderr, "trxsig_tables_broadcast: ncclBroadcast failed (%d)\n", rc); return TRXSIG_EHIP; }
+  return TRXSIG_OK;
 }
 
 int trxsig_tables_rach_error_bound(const void *h_blob, size_t bytes, float *bound, float *seq_norm) {

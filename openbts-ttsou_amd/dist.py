@@ -39,7 +39,7 @@ def broadcast_tables(pkg, sps, device=None, src=0):
         t = torch.zeros(n, dtype=torch.uint8)
     if device is not None:
         t = t.to(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():                               # (a one-rank group still runs the collective: the GPU test relies on it)
         dist.broadcast(t, src=src)
     blob = t.cpu().numpy()
     if not pkg.tables_valid(blob):
@@ -51,7 +51,7 @@ def max_over_ranks(value, device=None):
     """MAX all-reduce of one python float (the bench's step time)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -62,7 +62,7 @@ def ranks_seen(rank, device=None):
     """All-gather of the rank ids that took part (bench.py reports it next to n_gpus)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return [int(rank)]
     t = torch.tensor([rank], dtype=torch.int64, device=device if device is not None else "cpu")
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]

@@ -177,3 +177,19 @@ def test_context_from_broadcast_tables(pkg):
     bad = t.clone(); bad[5000] ^= 0x40
     with pytest.raises(pkg.TrxSigError):
         pkg.TrxSig(4, 0, tables_blob=bad)
+
+
+def test_c_host_rccl_table_broadcast(tmp_path):
+    """trxsig_tables_broadcast from a C++ host with no torch (tests/rccl_broadcast.cpp): a real ncclBroadcast on a one-rank
+    communicator, then trxsig_create_from_tables on the received blob."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "openbts-ttsou_amd")
+    exe = str(tmp_path / "rccl_broadcast")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "rccl_broadcast.cpp"),
+                           "-I", os.path.join(root, "include"), "-I/opt/rocm/include", "-L", lib, "-ltrxsig", "-L/opt/rocm/lib",
+                           "-lrccl", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "broadcast ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
