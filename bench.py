@@ -442,11 +442,12 @@ def main():
 
     # constant tables: built once on rank 0, broadcast over RCCL (xGMI), validated, then each rank's
     # context is created from the received device blob
+    tuning = args.path is not None or args.chain_lag is not None or bool(args.spec_peak)   # A/B flags: libtrxsig_tune.so
     if world > 1:
         _, tbl = tdist.broadcast_tables(pkg, wl.sps, device=dev, src=0)
-        ctx = pkg.TrxSig(wl.sps, local, tables_blob=tbl)
+        ctx = pkg.TrxSig(wl.sps, local, tables_blob=tbl, tuning=tuning)
     else:
-        ctx = pkg.TrxSig(wl.sps, local)
+        ctx = pkg.TrxSig(wl.sps, local, tuning=tuning)
     ctx.use_torch_stream()
     if args.path is not None:
         ctx.set_tuning(normal_path=args.path)

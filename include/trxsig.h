@@ -385,7 +385,8 @@ enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_
 const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);
-/* Implementation choice for A/B measurements; results are bit-identical whatever is selected.
+/* Implementation choice for A/B measurements (tuning build: libtrxsig_tune.so, `make -C csrc tune`); results are bit-identical
+ * whatever is selected.
  *   TRXSIG_TUNE_NORMAL_PATH (trxsig_detect_demod_normal_batch; initial value: env TRXSIG_TSC_VARIANT, else 0):
  *     0 = three kernels: correlate, peak, demodulate (the default and the fastest measured);
  *     1 = one fused kernel, a wave per burst;   2 = fused, two bursts per wave;
@@ -412,6 +413,9 @@ int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int 
 enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3,
        TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
+/* 1 in libtrxsig_tune.so (every implementation above selectable), 0 in the product library libtrxsig.so, which carries the
+ * defaults only (normal path 0 with the two-lane peak kernel, RACH paths 1 and 2) and answers TRXSIG_EINVAL to the rest. */
+int trxsig_tuning_build(void);
 /* validate a host copy of the table blob (magic, version, size, checksum): 0 if valid */
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes);
 /* Multi-GPU set-up for a host that is not Python (one process or thread per GPU): the ONE collective of the

@@ -33,19 +33,44 @@ def build(verbose=False):
     return LIB_PATH
 
 
+TUNE_LIB_PATH = os.path.join(_HERE, "libtrxsig_tune.so")
 _lib = None
+_libs = {}
 
 
-def lib():
+def tune_lib():
+    """libtrxsig_tune.so: the product's code plus the alternates that measured slower (trxsig_set_tuning) -- for A/B
+    measurements and the tests that keep those alternates bit-identical.  Same C-ABI; both libraries can be loaded at once
+    (linked -Bsymbolic)."""
+    return lib(TUNE_LIB_PATH)
+
+
+def lib(path=None):
     """The loaded libtrxsig.so.  torch (if used) must be imported first so that the library binds to
     the HIP runtime torch already loaded (same libamdhip64.so.7 soname) and device pointers are
     shared between the two."""
     global _lib
+    if path is not None:
+        if path not in _libs:
+            saved = _lib
+            _lib = None
+            try:
+                _libs[path] = _load(path)
+            finally:
+                _lib = saved
+        return _libs[path]
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise TrxSigError("libtrxsig.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                              "or `make -C openbts-ttsou_amd/csrc` (there is no CPU fallback)")
-        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(path):
+    global _lib
+    if True:
+        if not os.path.exists(path):
+            raise TrxSigError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C openbts-ttsou_amd/csrc` (there is no CPU fallback)" % os.path.basename(path))
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
         vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
         L.trxsig_abi_version.restype = i32
         L.trxsig_create.argtypes = [C.POINTER(vp), i32, i32]
@@ -108,8 +133,7 @@ def lib():
         L.trxsig_set_tuning.argtypes = [vp, i32, i32]
         L.trxsig_profile_collect.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
         L.trxsig_tables_validate_host.argtypes = [vp, C.c_size_t]
-        _lib = L
-    return _lib
+        return L
 
 
 def tables_dtype():
@@ -151,8 +175,8 @@ def _ptr(t):
 class TrxSig:
     """One library context = one GPU + one stream (trxsig.h)."""
 
-    def __init__(self, sps=4, device=0, tables_blob=None):
-        self.L = lib()
+    def __init__(self, sps=4, device=0, tables_blob=None, tuning=False):
+        self.L = tune_lib() if tuning else lib()
         self.h = C.c_void_p()
         if tables_blob is None:
             rc = self.L.trxsig_create(C.byref(self.h), device, sps)

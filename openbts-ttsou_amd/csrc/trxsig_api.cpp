@@ -138,9 +138,16 @@ int check_device(int device, std::string &why) {
 }
 
 int finish_create(trxsig_ctx *c) {
+#ifdef TRX_TUNING_BUILD
   if (const char *v = std::getenv("TRXSIG_TSC_VARIANT")) c->variant = std::atoi(v);
-  if (const char *v = std::getenv("TRXSIG_RACH_VARIANT")) c->rach_variant = std::atoi(v);
   if (const char *v = std::getenv("TRXSIG_CHAIN_DBG")) c->chain_dbg = std::atoi(v);
+#endif
+  if (const char *v = std::getenv("TRXSIG_RACH_VARIANT")) {
+    c->rach_variant = std::atoi(v);
+#ifndef TRX_TUNING_BUILD
+    if (c->rach_variant < 1 || c->rach_variant > 2) c->rach_variant = 2;
+#endif
+  }
   c->rach_amp_err = trx_rach_amp_err(c->h_tables);
   HIPCHK(c, hipEventCreate(&c->ev0));
   HIPCHK(c, hipEventCreate(&c->ev1));
@@ -159,6 +166,7 @@ int ensure_ws(trxsig_ctx *c, int B) {
   return TRXSIG_OK;
 }
 
+#ifdef TRX_TUNING_BUILD
 int ensure_chain(trxsig_ctx *c, int B) {
   if (!c->h_chain_status) {
     HIPCHK(c, hipHostMalloc((void **)&c->h_chain_status, 64, hipHostMallocMapped));
@@ -177,14 +185,20 @@ int ensure_chain(trxsig_ctx *c, int B) {
 // a demodulator of an earlier chain launch gave up its wait (never observed; HIP does not promise the dispatch
 // order the chain relies on for progress): that call's soft bits are incomplete.  Report it once, clear the
 // hand-over words, and use the three-launch path from here on.
+#endif
+
 int chain_check(trxsig_ctx *c) {
   if (!c->h_chain_status || !*c->h_chain_status) return TRXSIG_OK;
+#ifndef TRX_TUNING_BUILD
+  return TRXSIG_OK;
+#else
   (void)hipStreamSynchronize(c->stream);
   *c->h_chain_status = 0;
   c->chain_broken = true;
   if (c->d_det) (void)hipMemsetAsync(c->d_det, 0, trx_chain_ws_bytes(c->det_cap), c->stream);
   return fail(c, TRXSIG_EHIP, "an earlier trxsig_detect_demod_normal_batch (single-launch path) timed out waiting for its "
                               "detect workgroups; its soft bits are incomplete.  Falling back to the three-launch path");
+#endif
 }
 
 int ensure_stage(trxsig_ctx *c, size_t bytes) {
@@ -349,6 +363,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   DeviceGuard g(c->device);
   int rc = chain_check(c);
   if (rc != TRXSIG_OK) return rc;
+#ifdef TRX_TUNING_BUILD
   if (c->variant == 5 && !c->chain_broken && nsoft > 0 && nsoft <= 148) {
     // one launch: detect workgroups hand over to demodulate workgroups inside it (trxsig_chain.hip)
     rc = ensure_chain(c, B);
@@ -359,8 +374,10 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
                                       c->chain_lag, c->chain_spin, c->generic_taps, c->prof, c->chain_dbg));
     return TRXSIG_OK;
   }
+#endif
   rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
+#ifdef TRX_TUNING_BUILD
   if (c->variant == 4) {
     // detection (correlation + speculative bisection, four bursts per wave) in one kernel, then k_demod
     HIPCHK(c, trx_launch_normal_fused(c->stream, c->sps, 16, c->d_tables, c->h_tables, (const trx_c32 *)d_samples,
@@ -380,6 +397,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
                                       soft_stride, c->generic_taps, c->prof));
     return TRXSIG_OK;
   }
+#endif
   HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
                                   (trx_c32 *)d_amp, d_toa, d_avgpwr, c->generic_taps | (c->spec_peak == 1 ? 2 : 0) | (c->spec_peak == 2 ? 4 : 0), c->prof));
@@ -962,8 +980,23 @@ int trxsig_fec_viterbi_batch(trxsig_ctx *c, const float *d_soft, int n_soft, int
   return TRXSIG_OK;
 }
 
+int trxsig_tuning_build(void) {
+#ifdef TRX_TUNING_BUILD
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (!c) return TRXSIG_EINVAL;
+#ifndef TRX_TUNING_BUILD
+  // the product library carries the default implementations only (normal path 0 with the two-lane peak kernel, RACH paths 1
+  // and 2); the alternates that measured slower live in libtrxsig_tune.so (make -C csrc tune)
+  if ((key == TRXSIG_TUNE_NORMAL_PATH && value != 0) || (key == TRXSIG_TUNE_RACH_PATH && value == 0) ||
+      (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value != 0) || key == TRXSIG_TUNE_CHAIN_LAG || key == TRXSIG_TUNE_CHAIN_SPIN || key == 6)
+    return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: this implementation is only in the tuning build (libtrxsig_tune.so)");
+#endif
   if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 5) { c->variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_CHAIN_LAG && value >= 1) { c->chain_lag = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_CHAIN_SPIN && value >= 0) { c->chain_spin = (unsigned)value; return TRXSIG_OK; }

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
 }
 
 
+#ifdef TRX_TUNING_BUILD   /* k_tsc_peak (a lane per burst) and k_tsc_peak8 (eight lanes, speculative): A/B alternatives, tuning build only */
 // ---------------------------------------------------------------------------------------------
 // k_tsc_peak: one lane per burst.  peakDetect's early-late bisection (sigProcLib.cpp:684-701),
 //   the bogus-TOA check, the valley RMS, the detection threshold, amp = peak/gain and the TOA
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restric
 
 
 
+#endif  // TRX_TUNING_BUILD
+
 // ---------------------------------------------------------------------------------------------
 // k_tsc_peak2: k_tsc_peak's job with TWO lanes per burst (pair_bisect, trxsig_bisect.h: early and late point of a
 //   step side by side, sinc table in LDS, correlation window in registers) and two waves per SIMD instead of one.
@@ -411,15 +414,18 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   const trx_c32 g = hT->mid_gain[tsc];
   const float n = g.i * g.i + g.r * g.r;
   trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
+#ifdef TRX_TUNING_BUILD
   if (variant & 4) {
     k_tsc_peak<S><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, rec, Bpad, B, tsc, detect_thresh, energy_thresh,
                                                             flags, amp, toa, avgpwr);
-  } else if (!(variant & 2)) {
-    k_tsc_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
-                                                                energy_thresh, flags, amp, toa, avgpwr);
-  } else {
+  } else if (variant & 2) {
     k_tsc_peak8<S><<<dim3((B + 31) / 32), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
                                                               energy_thresh, flags, amp, toa, avgpwr);
+  } else
+#endif
+  {
+    k_tsc_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
+                                                                energy_thresh, flags, amp, toa, avgpwr);
   }
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
 }

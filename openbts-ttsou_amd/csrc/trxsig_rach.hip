@@ -124,6 +124,7 @@ struct RachGeom {
   static constexpr int CSLOTS = 25;                        // complex slots
 };
 
+#ifdef TRX_TUNING_BUILD   /* the exact-at-every-lag route (TRXSIG_TUNE_RACH_PATH 0): A/B reference only, not in the product library */
 template <int SPS>
 __global__ __launch_bounds__(256) void k_rach_corr(const TrxTables *__restrict__ T,
                                                    const cx *__restrict__ samples,
@@ -279,6 +280,8 @@ __global__ __launch_bounds__(64) void k_rach_peak(const TrxTables *__restrict__ 
     if (avgpwr_out) avgpwr_out[b] = good ? energy / (float)(unsigned)G::NE : 0.0f;
   }
 }
+
+#endif  // TRX_TUNING_BUILD
 
 // ---------------------------------------------------------------------------------------------
 // k_rach_fast: detectRACHBurst (sigProcLib.cpp:860-914) with the SAME results as k_rach_corr +
@@ -922,6 +925,7 @@ int trx_rach_rec_floats(int sps) {            // floats per burst in the rach re
   return 0;
 }
 
+#ifdef TRX_TUNING_BUILD
 template <int S>
 static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off,
                                const int32_t *len, int B, float detect_thresh, float energy_thresh, float *ws,
@@ -936,6 +940,8 @@ static void launch_rach_detect(hipStream_t st, const TrxTables *dT, const trx_c3
                                                            energy_thresh, flags, amp, toa, avgpwr);
   if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
 }
+
+#endif
 
 template <int S>
 static void launch_rach_fast(hipStream_t st, const TrxTables *dT, const trx_c32 *samples, const int32_t *off, const int32_t *len,
@@ -982,6 +988,11 @@ hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, 
                                   const int32_t *off, const int32_t *len, int B, float detect_thresh,
                                   float energy_thresh, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp,
                                   float *toa, float *avgpwr, TrxProfiler *prof) {
+#ifndef TRX_TUNING_BUILD
+  (void)st; (void)sps; (void)dT; (void)samples; (void)off; (void)len; (void)B; (void)detect_thresh; (void)energy_thresh; (void)ws;
+  (void)Bpad; (void)flags; (void)amp; (void)toa; (void)avgpwr; (void)prof;
+  return hipErrorNotSupported;                             // the exact-at-every-lag route lives in the tuning build only
+#else
   if (B <= 0) return hipSuccess;
   switch (sps) {
     case 1: launch_rach_detect<1>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, ws, Bpad, flags, amp, toa, avgpwr, prof); break;
@@ -990,5 +1001,6 @@ hipError_t trx_launch_rach_detect(hipStream_t st, int sps, const TrxTables *dT, 
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+#endif
 }
 

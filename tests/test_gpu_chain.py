@@ -34,9 +34,10 @@ def same(r, q, what):
 
 
 def ctx(pkg, sps, path, **kw):
-    t = pkg.TrxSig(sps, 0)
+    t = pkg.TrxSig(sps, 0, tuning=(path != 0))               # the chain lives in libtrxsig_tune.so; path 0 is the product library
     t.use_torch_stream()
-    t.set_tuning(normal_path=path, **kw)
+    if path != 0 or kw:
+        t.set_tuning(normal_path=path, **kw)
     return t
 
 

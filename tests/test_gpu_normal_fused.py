@@ -28,9 +28,11 @@ def ctxs(pkg):
     c = {}
     for path in [0] + PATHS:
         for s in (1, 2, 4):
-            t = pkg.TrxSig(s, 0)
+            # the alternates live in libtrxsig_tune.so; path 0 -- what they are compared with -- is the PRODUCT library
+            t = pkg.TrxSig(s, 0, tuning=(path != 0))
             t.use_torch_stream()
-            t.set_tuning(normal_path=path)
+            if path != 0:
+                t.set_tuning(normal_path=path)
             c[path, s] = t
     return c
 
@@ -169,8 +171,8 @@ def test_ragged_and_bad_bursts(pkg, ctxs, path):
 def test_tap_class_specialisation_is_invisible(pkg, sps, path):
     """The correlators' exact-product FMA form (taps with a component of exactly +-1) against the generic
     complex multiply-accumulate: identical outputs, hostile windows included."""
-    a = pkg.TrxSig(sps, 0); a.use_torch_stream(); a.set_tuning(normal_path=path, generic_taps=0)
-    g = pkg.TrxSig(sps, 0); g.use_torch_stream(); g.set_tuning(normal_path=path, generic_taps=1)
+    a = pkg.TrxSig(sps, 0, tuning=True); a.use_torch_stream(); a.set_tuning(normal_path=path, generic_taps=0)
+    g = pkg.TrxSig(sps, 0, tuning=True); g.use_torch_stream(); g.set_tuning(normal_path=path, generic_taps=1)
     for tsc in range(8):
         x, off, length, meta = synth.normal_batch(sps, 515, tsc, seed=700 + tsc)
         same(run(a, x, off, length, tsc), run(g, x, off, length, tsc), "tsc %d" % tsc)
@@ -185,7 +187,7 @@ def test_peak_kernels_are_interchangeable(pkg, sps):
     give identical outputs on random, ragged and hostile batches, tie-breaking bisections included."""
     ctx = []
     for sp in (2, 0, 1):
-        c = pkg.TrxSig(sps, 0); c.use_torch_stream(); c.set_tuning(normal_path=0, spec_peak=sp); ctx.append(c)
+        c = pkg.TrxSig(sps, 0, tuning=True); c.use_torch_stream(); c.set_tuning(normal_path=0, spec_peak=sp); ctx.append(c)
     for tsc in range(8):
         x, off, length, meta = synth.normal_batch(sps, 1031, tsc, seed=900 + tsc)
         want = run(ctx[0], x, off, length, tsc)

@@ -88,7 +88,7 @@ def test_rach_variants_agree_with_oracle(pkg, variant, monkeypatch):
     clipped and late bursts where the approximate pass has to hand over."""
     monkeypatch.setenv("TRXSIG_RACH_VARIANT", variant)
     sps, B = 4, 768
-    t = pkg.TrxSig(sps, 0); t.use_torch_stream()
+    t = pkg.TrxSig(sps, 0, tuning=True); t.use_torch_stream()      # route 0 (exact at every lag) is only in the tuning build
     o = oraclebind.Oracle(sps)
     x, off, length, meta = synth.rach_batch(sps, B, seed=977, sigmas=(0.0, 0.05, 0.3, 1.0, 5.0), max_delay_sym=100)
     rng = np.random.default_rng(3)

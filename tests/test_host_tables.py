@@ -101,3 +101,20 @@ def test_rach_error_bound_is_small_against_the_sequence():
         assert 3.2e-5 < b.value / n.value < 8e-5, (sps, b.value, n.value)
         bad = blob.copy(); bad[100] ^= 1
         assert L.trxsig_tables_rach_error_bound(bad.ctypes.data, bad.size, C.byref(b), C.byref(n)) != 0
+
+
+def test_product_library_carries_the_defaults_only(pkg):
+    """The alternates that measured slower (single-launch normal-burst kernels, the other peak kernels, the exact-at-every-lag
+    RACH route) are compiled into libtrxsig_tune.so only: the product library neither contains their kernels nor lets
+    trxsig_set_tuning select them."""
+    prod = open(pkg.LIB_PATH, "rb").read()
+    tune = open(pkg.TUNE_LIB_PATH, "rb").read()
+    # kernel symbols as the code objects carry them (Itanium names of template instantiations: <len><name>IL...; the plain
+    # strings also appear in the profiler's name table, which both libraries share)
+    for k in (b"14k_normal_fusedIL", b"13k_normal_quadIL", b"14k_normal_chainIL", b"11k_tsc_peak8IL", b"10k_tsc_peakIL", b"11k_rach_corrIL"):
+        assert k not in prod, k
+        assert k in tune, k
+    for k in (b"10k_tsc_corrIL", b"11k_tsc_peak2IL", b"7k_demodIL", b"12k_rach_frontIL", b"12k_rach_peak2IL", b"11k_rach_fastIL", b"10k_resampleIL"):
+        assert k in prod, k
+    assert pkg.lib().trxsig_tuning_build() == 0 and pkg.tune_lib().trxsig_tuning_build() == 1
+    assert pkg.lib().trxsig_abi_version() == pkg.tune_lib().trxsig_abi_version()

@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 
 
 def main(lib):
-    if lib:
-        os.environ["TRXSIG_LIB"] = lib
+    if lib:                                                  # another build of the TUNING library
+        import _pkg as _p
+        _p.load().TUNE_LIB_PATH = lib
     import torch, _pkg
     pkg = _pkg.load()
     from openbts_ttsou_amd import synth
@@ -23,7 +24,7 @@ def main(lib):
         for name, dbg in (("detect only", 2), ("demod only", 1), ("detect only again", 2)):
             t = getattr(main, "ctx", None)
             if t is None:
-                t = main.ctx = pkg.TrxSig(sps, 0); t.use_torch_stream(); t.set_tuning(normal_path=5)
+                t = main.ctx = pkg.TrxSig(sps, 0, tuning=True); t.use_torch_stream(); t.set_tuning(normal_path=5)
             t.set_tuning(chain_lag=lag)
             t._chk(t.L.trxsig_set_tuning(t.h, 6, dbg), "dbg")
             def step():
