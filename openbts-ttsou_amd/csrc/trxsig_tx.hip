@@ -162,14 +162,81 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_rx_resample: k_resample<int16 in> for the receive front end's shape -- one whole window per workgroup, at most four taps
+//   per output (L <= 4 P) -- with the index walk taken out of the inner loop:
+//     * the window sits in LDS between zero pads, so the reference's two edge rules (skip the taps whose sample lies past the
+//       end, :1183-1186; stop at the first sample before the start, :1196) become products with zero samples -- the samples
+//       are int16 values, hence finite, and adding +-0 to the running sum never changes its value;
+//     * the taps are staged branch-major, TPB[branch][k] = lpf[branch + P k] (0 past the end of the filter, the reference
+//       stops there), so an output's taps are ONE 16-byte LDS read instead of four reads P floats apart (the strided walk
+//       cost 7 conflict cycles per LDS instruction);
+//     * outputIx*Q = branch + P*inOff is divided once per lane and then advanced by 256 Q per output.
+//   Same terms in the same order as k_resample: value-identical (tests/test_gpu_config4.py compares both with the oracle).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char res_lds[];
+  // [4 zero samples][n window samples][4 zero samples] then the branch-major taps (P x 4 floats)
+  cx *X = reinterpret_cast<cx *>(res_lds) + 4;
+  float4 *TPB = reinterpret_cast<float4 *>(res_lds + sizeof(cx) * (size_t)(a.n + 8));
+  const int w = blockIdx.y, s = blockIdx.z;
+  const int D = (a.L - 1) / 2 / a.Q;                                // :1177
+  for (int br = threadIdx.x; br < a.P; br += 256) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int fi = br + a.P * k; t[k] = fi < a.L ? a.lpf[fi] : 0.0f; }
+    TPB[br] = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  if (threadIdx.x < 8) X[threadIdx.x < 4 ? (int)threadIdx.x - 4 : a.n + (int)threadIdx.x - 4] = mk(0, 0);
+  {
+    const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
+    const short2 *hist = a.hist + (size_t)s * a.hist_len;
+    const int base = w * a.win_step - a.hist_len;                   // raw index of the window's sample 0
+    for (int i0 = threadIdx.x; i0 < a.n; i0 += 256 * 8) {
+      short2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + 256 * q, r = base + i;
+        v[q] = i < a.n ? (r < 0 ? hist[a.hist_len + r] : raw[r]) : make_short2(0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + 256 * q;
+        if (i < a.n) X[i] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned oq0 = (unsigned)(a.o_skip + (int)threadIdx.x + D) * (unsigned)a.Q;
+  int branch = (int)(oq0 % (unsigned)a.P), inOff = (int)(oq0 / (unsigned)a.P);
+  const int step_b = (256 * a.Q) % a.P, step_i = (256 * a.Q) / a.P;
+  cx *out = reinterpret_cast<cx *>(a.out) + (size_t)s * a.out_stride + (size_t)w * a.out_win_step;
+  for (int o = a.o_skip + threadIdx.x; o < a.n_out; o += 256) {
+    // tap k of the reference's walk (fi = branch + P k) meets sample inOff - k; samples outside [0, n) are the zero pads
+    // (the launcher guarantees 0 <= inOff <= n + 3, so every index lies in [-3, n + 3])
+    const float4 tp = TPB[branch];
+    const cx x0 = X[inOff], x1 = X[inOff - 1], x2 = X[inOff - 2], x3 = X[inOff - 3];
+    cx sum = mk(0, 0);
+    sum = cadd(sum, cmulr(x0, tp.x));
+    sum = cadd(sum, cmulr(x1, tp.y));
+    sum = cadd(sum, cmulr(x2, tp.z));
+    sum = cadd(sum, cmulr(x3, tp.w));
+    out[o - a.o_skip] = sum;
+    branch += step_b; inOff += step_i;
+    if (branch >= a.P) { branch -= a.P; inOff++; }
+  }
+}
+
 // trxsig_rxfe_pop's index arrays: burst j of stream s starts at s*stride + rd + (samples of bursts 0..j-1)
 __global__ __launch_bounds__(256) void k_burst_index(int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *__restrict__ off,
                                                      int32_t *__restrict__ len) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= S * nb) return;
   const int s = i / nb, j = i - s * nb;
-  int pos = rd, tn = tn0;
-  for (int k = 0; k < j; k++) { pos += (156 + ((tn & 3) == 0)) * sps; tn = (tn + 1) & 7; }
+  // bursts tn0 .. tn0+j-1 precede burst j: 156 symbols each, plus one for every TN that is a multiple of 4
+  const int long_before = (tn0 + j + 3) / 4 - (tn0 + 3) / 4;
+  const int pos = rd + (156 * j + long_before) * sps;
+  const int tn = (tn0 + j) & 7;
   off[i] = (int32_t)((long long)s * stride + pos);
   len[i] = (156 + ((tn & 3) == 0)) * sps;
 }
@@ -244,7 +311,14 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
   const size_t lds = sizeof(trx_c32) * (size_t)a.xcap + (a.taps_lds ? sizeof(float) * (size_t)a.L : 0);
   const dim3 grid((a.n_out - a.o_skip + a.OB - 1) / a.OB, n_windows, S), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
-  if (in_i16 && !out_i16) k_resample<true, false><<<grid, block, lds, st>>>(a);
+  // the receive front end's shape (whole window per workgroup, <= 4 taps per output, indices inside 32 bits): k_rx_resample
+  const bool rx_fast = in_i16 && !out_i16 && a.OB == a.n_out - a.o_skip && a.L <= 4 * a.P && a.n <= 4096 && a.P <= 1024 &&
+                       (long long)(a.n_out + (a.L - 1) / 2 / a.Q + 256) * a.Q < 0x7fffffffLL && (long long)n_windows * a.win_step < 0x7fffffffLL &&
+                       ((long long)(a.n_out - 1 + (a.L - 1) / 2 / a.Q) * a.Q) / a.P <= a.n + 3;
+  if (rx_fast) {
+    const size_t lds2 = sizeof(trx_c32) * (size_t)(a.n + 8) + sizeof(float) * 4 * (size_t)a.P;
+    k_rx_resample<<<dim3(1, n_windows, S), block, lds2, st>>>(a);
+  } else if (in_i16 && !out_i16) k_resample<true, false><<<grid, block, lds, st>>>(a);
   else if (!in_i16 && out_i16) k_resample<false, true><<<grid, block, lds, st>>>(a);
   else if (!in_i16 && !out_i16) k_resample<false, false><<<grid, block, lds, st>>>(a);
   else return hipErrorInvalidValue;
