@@ -347,17 +347,25 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #undef TRX_STAMP
 }
 
+// The burst's row of xd was written by k_demod<1,RAW> only if that kernel accepted the burst (k_demod's gate: DETECT flag,
+// 92..157 samples, |TOA| <= 4096 and not NaN).  The equaliser must apply the same gate, or it would equalise whatever an
+// earlier call left in the row and hand back plausible-looking soft bits.
+__device__ __forceinline__ bool eq_enabled(uint8_t fl, int N, float toa_eq) {
+  return (fl & TRXSIG_F_DETECT) && N >= 92 && N <= 157 && (fabsf(toa_eq) <= 4096.0f);
+}
+
 // equalizeBurst after its delayVector: xd = delayed, scaled burst (B x xstride complex)
 __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, const cx *__restrict__ xd, int xstride,
                                                const int32_t *__restrict__ length, int B,
-                                               const uint8_t *__restrict__ flags, const cx *__restrict__ w_in,
+                                               const uint8_t *__restrict__ flags, const float *__restrict__ toa_eq,
+                                               const cx *__restrict__ w_in,
                                                const cx *__restrict__ b_in, float *__restrict__ soft,
                                                uint8_t *__restrict__ hard, int nsoft, int stride) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   float *sb = soft + (size_t)b * stride;
   uint8_t *hb = hard ? hard + (size_t)b * stride : nullptr;
-  if (!(flags[b] & TRXSIG_F_DETECT)) {
+  if (!eq_enabled(flags[b], length[b], toa_eq[b])) {
     for (int m = 0; m < nsoft; m++) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
     return;
   }
@@ -419,7 +427,8 @@ __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, 
 #define EQ_NT 10             /* tiles: 160 >= 157 symbols */
 __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T, const cx *__restrict__ xd, int xstride,
                                                  const int32_t *__restrict__ length, int B,
-                                                 const uint8_t *__restrict__ flags, const cx *__restrict__ w_in,
+                                                 const uint8_t *__restrict__ flags, const float *__restrict__ toa_eq,
+                                                 const cx *__restrict__ w_in,
                                                  const cx *__restrict__ b_in, float *__restrict__ soft,
                                                  uint8_t *__restrict__ hard, int nsoft, int stride) {
   __shared__ cx xt[64][EQ_TK + 1];                          // the producer's own staging of the delayed burst
@@ -430,8 +439,8 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
   const int b0 = blockIdx.x * 64;
   const int b = b0 + lane;
   const int bb = b < B ? b : B - 1;
-  const bool det = b < B && (flags[bb] & TRXSIG_F_DETECT);
   const int N = length[bb];
+  const bool det = b < B && eq_enabled(flags[bb], N, toa_eq[bb]);
   const int nout = det ? (nsoft < N ? nsoft : N) : 0;       // symbols this burst really produces (zeros beyond)
   // Barrier u (u = 0..9): ff tile u is ready and soft tile u-1 is complete; barrier 10: soft tile 9 is complete.
   // Both waves execute exactly eleven barriers.
@@ -535,12 +544,12 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
 
 // TRXSIG_EQ_DFE_VARIANT=1 (environment, A/B): the lane-per-burst k_eq_dfe instead of the producer/consumer k_eq_dfe2
 void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
-                   const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride) {
+                   const float *toa_eq, const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride) {
   static const bool legacy = std::getenv("TRXSIG_EQ_DFE_VARIANT") && std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) == 1;
   if (legacy)
-    k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+    k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
   else
-    k_eq_dfe2<<<dim3((B + 63) / 64), dim3(128), 0, st>>>(dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+    k_eq_dfe2<<<dim3((B + 63) / 64), dim3(128), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
 }
 
 // designDFE on its own (a lane per channel estimate): chan B x 6 (as analyzeTrafficBurst returns it, i.e. before the
@@ -587,7 +596,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
   if (prof) { prof->end(TRXSIG_K_EQUALIZE, st); prof->begin(TRXSIG_K_EQ_DELAY, st); }
   EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
-  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
   return hipGetLastError();
 }
@@ -615,7 +624,7 @@ hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const v
   if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
   EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
-  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, w, bq, soft, hard, nsoft, stride);
+  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
   return hipGetLastError();
 }

@@ -220,3 +220,40 @@ def test_channel_estimate_and_design_dfe_on_their_own(pkg, t1, variant52m):
         ow, ob = o.design_dfe(o.scale_vector(a["chan"], inv), 37.5, 7)
         assert_veq(wv[i], ow, "w %d" % i); assert_veq(bv[i], ob, "b %d" % i)
     assert ndet > B // 2
+
+
+def test_equalize_taps_rejected_burst_is_not_equalised_from_stale_scratch(pkg, t1):
+    """trxsig_equalize_taps_batch with caller-supplied flags: a burst the delay kernel refuses (bad length, |TOA| > 4096 or
+    NaN) must come back as zeros even when its scratch row still holds an earlier call's burst."""
+    import torch
+    from openbts_ttsou_amd import synth
+    B, tsc = 64, 2
+    x, off, length, meta = synth.normal_batch(1, B, tsc, seed=8, sigmas=(0.02,), max_delay=0.5)
+    dev = "cuda"
+    dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    doff = torch.from_numpy(off.astype(np.int32)).cuda(); dlen = torch.from_numpy(length.astype(np.int32)).cuda()
+    amp = torch.ones(B, 2, device=dev); amp[:, 1] = 0
+    w = torch.zeros(B, 7, 2, device=dev); w[:, 0, 0] = 1.0
+    b = torch.zeros(B, 5, 2, device=dev)
+    en = torch.full((B,), pkg.F_DETECT, dtype=torch.uint8, device=dev)
+    soft = torch.full((B, 157), -1.0, device=dev)
+    toa = torch.zeros(B, device=dev)
+    L = t1.L
+    L.trxsig_equalize_taps_batch.argtypes = [__import__("ctypes").c_void_p] * 4 + [__import__("ctypes").c_int] + [__import__("ctypes").c_void_p] * 7 + \
+        [__import__("ctypes").c_int] * 2
+    def call():
+        t1._chk(L.trxsig_equalize_taps_batch(t1.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, amp.data_ptr(), toa.data_ptr(),
+                                             en.data_ptr(), w.data_ptr(), b.data_ptr(), soft.data_ptr(), None, 156, 157), "equalize_taps")
+        torch.cuda.synchronize()
+        return soft.cpu().numpy().copy()
+    first = call()
+    assert (first[:, :148] != 0).any(axis=1).all()                 # every burst produced soft bits; the scratch rows are now warm
+    toa[3] = float("nan"); toa[5] = 5000.0; toa[7] = -1e9
+    dlen2 = dlen.clone(); dlen2[9] = 40
+    dlen, keep = dlen2, dlen
+    soft.fill_(-1.0)
+    second = call()
+    for i in (3, 5, 7, 9):
+        assert not second[i, :156].any(), i
+    ok = [i for i in range(B) if i not in (3, 5, 7, 9)]
+    assert np.array_equal(second[ok], first[ok])
