@@ -19,7 +19,7 @@
 // Not provided (none is called by Transceiver.cpp or radioInterface.cpp): convolve's ABSSYM form (no caller sets a
 // symmetry), frequencyShift, resampleVector, addVector, offsetVector, gaussianNoise, vectorNorm2 / vectorPower, dB / dBinv.
 // Accepted ranges narrower than the reference's: modulateBurst takes 148-bit bursts with guard 0..9 and the library's
-// own pulse; energyDetect's window is 20*sps; designDFE wants Nf = 7 and a 6-tap channel, equalizeBurst 7 + 5 taps;
+// own pulse; designDFE wants Nf = 7 and a 6-tap channel, equalizeBurst 7 + 5 taps;
 // demodulateBurst wants 92..157 symbols (a multiple of sps samples) and |TOA| <= 4096 -- outside them the call returns
 // NULL / false instead of a value.
 #ifndef SIGPROCLIB_TRX_H
@@ -225,13 +225,18 @@ inline bool detect(bool rach, signalVector &rxBurst, unsigned TSC, float thresh,
 }
 }  // namespace detail
 
-// energyDetect (sigProcLib.h:255-258); windowLength must be 20*sps, the only value the Transceiver
-// uses (Transceiver.cpp:298)
+// energyDetect (sigProcLib.h:255-258), any window length; with TRXFACADE_52M the 52 MHz variant's stride of four samples
+// (Transceiver52M/sigProcLib.cpp:946-963)
 inline bool energyDetect(signalVector &rxBurst, unsigned windowLength, float detectThreshold, float *avgPwr = NULL) {
-  if (windowLength != 20u * (unsigned)state().sps) return false;
-  bool ok = false;
-  detail::detect(false, rxBurst, 0, 1e30f, detectThreshold, NULL, NULL, avgPwr, &ok);
-  return ok;
+  State &s = state();
+  if (!s.ctx || rxBurst.size() == 0) return false;
+#ifdef TRXFACADE_52M
+  const int step = 4;
+#else
+  const int step = 1;
+#endif
+  return trxsig_energy_detect_host(s.ctx, (const trxsig_c32 *)rxBurst.begin(), (int)rxBurst.size(), windowLength, step, detectThreshold,
+                                   avgPwr) == 1;
 }
 namespace detail {
 // analyzeTrafficBurst with a channel estimate, either variant (trxsig_channel_estimate_host)

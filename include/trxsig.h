@@ -356,6 +356,12 @@ int trxsig_interpolate_point_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n,
 int trxsig_peak_detect_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
                              trxsig_c32 *d_peak, float *d_index, float *d_avgpwr);
 int trxsig_peak_detect_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, trxsig_c32 *h_peak, float *h_index, float *h_avgpwr);
+/* energyDetect(x_i, window, thresh, &d_avgpwr[i]) -> d_ok[i] (sigProcLib.h:255-258) for any window length; sample_step 1
+ * (Transceiver/) or 4 (the Transceiver52M variant, Transceiver52M/sigProcLib.cpp:946-963).  d_avgpwr / d_ok may be NULL. */
+int trxsig_energy_detect_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                               unsigned window, int sample_step, float thresh, float *d_avgpwr, uint8_t *d_ok);
+int trxsig_energy_detect_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, unsigned window, int sample_step, float thresh,
+                              float *h_avgpwr);   /* returns 1 / 0 (the reference's bool), < 0 on error */
 /* in place: scaleVector(x_i, d_scale[i]); GMSKRotate / GMSKReverseRotate (elements past the 157*sps table entries are
  * left as they are -- the reference reads past its table there); vectorSlicer */
 int trxsig_scale_vector_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,

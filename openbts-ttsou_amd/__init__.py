@@ -126,6 +126,8 @@ def _load(path):
         L.trxsig_decimate_batch.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
         L.trxsig_elementwise_host.argtypes = [vp, i32, vp, i32, C32, i32]
         L.trxsig_decimate_host.argtypes = [vp, vp, i32, i32, vp]
+        L.trxsig_energy_detect_batch.argtypes = [vp, vp, vp, vp, i32, C.c_uint, i32, f32, vp, vp]
+        L.trxsig_energy_detect_host.argtypes = [vp, vp, i32, C.c_uint, i32, f32, vp]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
@@ -347,6 +349,14 @@ class TrxSig:
         sc = C32(float(np.real(scale)), float(np.imag(scale)))
         self._chk(self.L.trxsig_elementwise_host(self.h, op, y.ctypes.data, y.size, sc, int(real_only)), "trxsig_elementwise_host")
         return y
+
+    def energy_detect_host(self, x, window, thresh, step=1):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); av = np.zeros(1, np.float32)
+        rc = self.L.trxsig_energy_detect_host(self.h, x.ctypes.data, x.size, int(window), step, float(thresh), av.ctypes.data)
+        if rc < 0:
+            self._chk(rc, "trxsig_energy_detect_host")
+        return bool(rc), av[0]
 
     def decimate_host(self, x, factor):
         import numpy as np

@@ -1216,6 +1216,40 @@ int trxsig_peak_detect_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, trxsig_
   return TRXSIG_OK;
 }
 
+int trxsig_energy_detect_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                               unsigned window, int sample_step, float thresh, float *d_avgpwr, uint8_t *d_ok) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || (sample_step != 1 && sample_step != 4))
+    return fail(c, TRXSIG_EINVAL, "trxsig_energy_detect_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_energy_detect(c->stream, (const trx_c32 *)d_in, d_off, d_len, B, window, sample_step, thresh, d_avgpwr, d_ok));
+  return TRXSIG_OK;
+}
+
+int trxsig_energy_detect_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, unsigned window, int sample_step, float thresh,
+                              float *h_avgpwr) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0) return fail(c, TRXSIG_EINVAL, "trxsig_energy_detect_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16), o_out = s.take(16);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  const int32_t meta[2] = {0, n};
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_energy_detect_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1, window, sample_step,
+                                  thresh, (float *)(d + o_out), (uint8_t *)(d + o_out) + 8);
+  if (rc != TRXSIG_OK) return rc;
+  unsigned char res[16];
+  HIPCHK(c, hipMemcpyAsync(res, d + o_out, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h_avgpwr) std::memcpy(h_avgpwr, res, 4);
+  return res[8] ? 1 : 0;
+}
+
 namespace {
 int elementwise_batch(trxsig_ctx *c, const char *who, int op, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B,
                       int max_len, const trxsig_c32 *d_scale, int real_only) {

@@ -55,6 +55,8 @@ hipError_t trx_launch_interpolate_point(hipStream_t st, const TrxTables *dT, con
                                         const int32_t *len, int B, const float *ix, int real_only, trx_c32 *out);
 hipError_t trx_launch_peak_detect(hipStream_t st, const TrxTables *dT, const trx_c32 *in, const int32_t *off, const int32_t *len,
                                   int B, trx_c32 *peak, float *index, float *avgpwr);
+hipError_t trx_launch_energy_detect(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, unsigned window,
+                                    int step, float thresh, float *avgpwr, uint8_t *ok);
 hipError_t trx_launch_elementwise(hipStream_t st, int op, const TrxTables *dT, trx_c32 *x, const int32_t *off, const int32_t *len,
                                   int B, int max_len, const trx_c32 *scale, int real_only);
 hipError_t trx_launch_decimate(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, int max_len,

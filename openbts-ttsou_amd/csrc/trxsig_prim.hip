@@ -176,6 +176,34 @@ __global__ __launch_bounds__(64) void k_peak_detect(const TrxTables *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// energyDetect (:916-932; the 52 MHz variant steps four samples at a time, Transceiver52M/sigProcLib.cpp:946-963): the
+// window's powers summed in index order, avgPwr = energy / windowLength, the decision avgPwr > threshold^2.  One wave
+// per vector.  (With step 4 the reference can read past a short vector; such samples count as zero here.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_energy_detect(const cx *__restrict__ in, const int32_t *__restrict__ off,
+                                                      const int32_t *__restrict__ len, unsigned window, int step, float thresh,
+                                                      float *__restrict__ avgpwr_out, uint8_t *__restrict__ ok_out) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int n = len[v];
+  const cx *x = in + off[v];
+  unsigned w = window;
+  if (w > (unsigned)(n < 0 ? 0 : n)) w = (unsigned)(n < 0 ? 0 : n);   // :924
+  float energy = 0.0f;
+  for (unsigned base = 0; base < w; base += 64) {
+    const unsigned i = base + lane;
+    const long long ix = (long long)i * step;
+    const float p = (i < w && ix < n) ? norm2(x[ix]) : 0.0f;
+    const int cnt = w - base < 64 ? (int)(w - base) : 64;
+    for (int q = 0; q < cnt; q++) energy += __shfl(p, q, 64);       // :925-928, index order
+  }
+  if (lane == 0) {
+    const float avg = energy / (float)w;                           // :929 (0/0 for an empty vector, as the reference)
+    if (avgpwr_out) avgpwr_out[v] = avg;
+    if (ok_out) ok_out[v] = avg > thresh * thresh;                 // :931
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // element-wise: scaleVector (:713-730), GMSKRotate / GMSKReverseRotate (:232-264), vectorSlicer (:507-519),
 // decimateVector (:1039-1053)
 // ---------------------------------------------------------------------------------------------
@@ -259,6 +287,13 @@ hipError_t trx_launch_peak_detect(hipStream_t st, const TrxTables *dT, const trx
                                   int B, trx_c32 *peak, float *index, float *avgpwr) {
   if (B <= 0) return hipSuccess;
   k_peak_detect<<<dim3(B), dim3(64), 0, st>>>(dT, in, off, len, peak, index, avgpwr);
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_energy_detect(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, unsigned window,
+                                    int step, float thresh, float *avgpwr, uint8_t *ok) {
+  if (B <= 0) return hipSuccess;
+  k_energy_detect<<<dim3(B), dim3(64), 0, st>>>(in, off, len, window, step, thresh, avgpwr, ok);
   return hipGetLastError();
 }
 

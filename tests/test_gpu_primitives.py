@@ -87,6 +87,18 @@ def test_random_primitives_vs_oracle(ctx, sps):
         m = min(n, 157 * sps)
         assert_beq(t.elementwise_host(1, x[:m]), o.gmsk_rotate(x[:m]), "GMSKRotate")
         assert_beq(t.elementwise_host(2, x[:m]), o.gmsk_rotate(x[:m], reverse=True), "GMSKReverseRotate")
+    # energyDetect: any window, both strides (the 52 MHz variant steps four samples)
+    o52 = oraclebind.Oracle(1, variant52m=True)
+    for n, win in ((628, 80), (157, 20), (50, 200), (300, 1), (97, 64), (130, 65)):
+        x = cn(rng, n, 30.0)
+        for thr in (10.0, 40.0, 80.0):
+            ok, av = t.energy_detect_host(x, win, thr)
+            ook, oav = o.energy_detect(x, win, thr)
+            assert ok == ook and av == oav, (n, win, thr, av, oav)
+            if 4 * min(win, n) <= n:
+                ok, av = t.energy_detect_host(x, win, thr, step=4)
+                ook, oav = o52.energy_detect(x, win, thr)
+                assert ok == ook and av == oav, ("52M", n, win, thr, av, oav)
     # peaks at the ends and flat inputs: the bisection's clamped interpolation ranges
     for x in (np.r_[np.complex64(50), cn(rng, 30)], np.r_[cn(rng, 30), np.complex64(50)], np.full(20, 3 + 4j, np.complex64),
               np.array([1, 2], np.complex64)):
