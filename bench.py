@@ -332,7 +332,7 @@ def spawn_ranks(args, argv):
     if not args.selftest_cpu:
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < (1 if args.rehearse_one_gpu else args.gpus):
             sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible -- refusing to run a smaller job under "
                              "that label\n" % (args.gpus, have))
             sys.exit(2)
@@ -399,6 +399,11 @@ def main():
                     help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
     ap.add_argument("--no-fresh", action="store_true", help="skip the rotating-inputs side measurement")
     ap.add_argument("--generic-taps", action="store_true", help="A/B: correlators without the tap-class specialisation")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank REHEARSAL on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host "
+                         "tensors (RCCL refuses two ranks on one device).  Exercises the whole N-rank flow -- spawn, table broadcast, "
+                         "per-rank workloads, barriers, MAX over ranks, the one line -- but its number is N workloads time-sharing ONE "
+                         "GPU: the line is marked \"rehearsal\" and is not a scaling measurement")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="exercise the N-rank launch path on the CPU (gloo): rendezvous, table broadcast, reductions; "
                          "no bursts are processed and no number is reported")
@@ -428,9 +433,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        rank, world = tdist.init_from_env("nccl")
+        rank, world = tdist.init_from_env("gloo" if args.rehearse_one_gpu else "nccl")
     else:
         rank, local = 0, 0
         torch.cuda.set_device(0)
@@ -439,13 +444,14 @@ def main():
                          % (args.gpus, world))
         sys.exit(2)
     dev = torch.device("cuda", local)
+    cdev = None if args.rehearse_one_gpu else dev           # where the collectives' tensors live
 
     # constant tables: built once on rank 0, broadcast over RCCL (xGMI), validated, then each rank's
     # context is created from the received device blob
     tuning = args.path is not None or args.chain_lag is not None or bool(args.spec_peak)   # A/B flags: libtrxsig_tune.so
     if world > 1:
-        _, tbl = tdist.broadcast_tables(pkg, wl.sps, device=dev, src=0)
-        ctx = pkg.TrxSig(wl.sps, local, tables_blob=tbl, tuning=tuning)
+        _, tbl = tdist.broadcast_tables(pkg, wl.sps, device=cdev, src=0)
+        ctx = pkg.TrxSig(wl.sps, local, tables_blob=tbl.to(dev), tuning=tuning)
     else:
         ctx = pkg.TrxSig(wl.sps, local, tuning=tuning)
     ctx.use_torch_stream()
@@ -485,8 +491,8 @@ def main():
     ev_ms = ctx.timer_stop()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = tdist.max_over_ranks(elapsed, dev)
-    seen = tdist.ranks_seen(rank, dev)
+    elapsed = tdist.max_over_ranks(elapsed, cdev)
+    seen = tdist.ranks_seen(rank, cdev)
     # ---- per-kernel durations: the same steps again with every launch bracketed by HIP events
     #      (kept out of the timed region: the extra event records stretch the gaps between kernels)
     ctx.profile_enable(True)
@@ -528,6 +534,8 @@ def main():
         "roofline": roof, "fresh_inputs": fresh,
     }
     out.update(sanity)
+    if args.rehearse_one_gpu:
+        out["rehearsal"] = "all %d ranks shared cuda:0 (gloo collectives): launch-path check, not a scaling number" % world
     if not args.no_cpu_baseline and world == 1:
         out.update(wl.cpu_baseline(args.check))
     else:

@@ -40,3 +40,20 @@ def test_gpus2_without_two_gpus_fails_loudly():
 def test_world_size_mismatch_fails_loudly():
     r = _run(["--gpus", "4", "--selftest-cpu"], {"WORLD_SIZE": "1"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu():
+    """The whole N-rank bench flow with real GPU work: `bench.py --gpus 2 --rehearse-one-gpu` (both ranks on cuda:0, gloo
+    collectives -- RCCL refuses two ranks on one device): spawn, table broadcast, context from the broadcast blob, per-rank
+    batches, barriers, MAX over ranks, one line with n_gpus == 2.  A launch-path check, not a scaling number."""
+    r = _run(["--gpus", "2", "--rehearse-one-gpu", "--steps", "20", "--bursts", "8192", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == [0, 1] and out["value"] > 0 and "rehearsal" in out
+    assert out["detected_frac"] > 0.99 and out["clean_hard_bits_ok"]
