@@ -220,6 +220,12 @@ class Config4:
         S, K, sps = self.S, self.K, self.sps
         # synthetic radio streams: back-to-back normal bursts (157-156-156-156 symbols) modulated on the device, brought to
         # 400 kS/s by linear interpolation (the bench needs realistic, detectable content, not a calibrated radio), int16
+        # The input must stay aligned with the front end's 157-156-156-156 schedule from step to step: 125 chunks are exactly
+        # 117 groups, so the generated stream is KT = a multiple of 125 chunks long and consecutive steps push consecutive
+        # K-chunk segments of it, wrapping where the stream is aligned again.
+        KT = K * 125 // __import__("math").gcd(K, 125)
+        self.KT, self.seg = KT, 0
+        K = KT
         nb = (K * 585 // 156 + 4 + 3) // 4 * 4               # whole 157-156-156-156 groups: every stream the same length
         gen = torch.Generator(device=dev); gen.manual_seed(0xC0F14 + rank)
         x, off, length, meta = synth.normal_batch_torch(sps, S * nb, self.tsc, seed=0xC0F14 + rank, device=dev, sigmas=(0.02, 0.05))
@@ -230,7 +236,9 @@ class Config4:
         lo = hi[:, i0] * (1 - fr) + hi[:, i0 + 1] * fr
         lo = lo * (8000.0 / lo.abs().amax(dim=1, keepdim=True))
         iq = torch.stack([lo.imag, lo.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()   # Q first (I/Q flipped)
-        self.iq = iq
+        K = self.K
+        self.iq = iq                                          # [S, KT*864, 2]; a step pushes iq[:, seg*K*864 : (seg+1)*K*864]
+        self.segs = [iq[:, i * K * 864:(i + 1) * K * 864].contiguous() for i in range(KT // K)]
         # createLPF(cutoff, 961, 65*sps) as pullBuffer asks for it -- designed for THIS ratio (synth.design_lpf says why the
         # reference's fixed table, made for 65:96, is not used at sps 4); the taps are an argument of the library
         self.lpf = synth.design_lpf(961, 65 * sps)
@@ -245,7 +253,8 @@ class Config4:
         self.last_nb = 0
 
     def step(self):
-        self.fe.push_chunk(self.iq)
+        self.fe.push_chunk(self.segs[self.seg])
+        self.seg = (self.seg + 1) % len(self.segs)
         r = self.fe.pop_raw()
         if r is None:
             return
@@ -282,7 +291,7 @@ class Config4:
         import oraclebind
         o = oraclebind.Oracle(self.sps)
         iq = self.iq[0].cpu().numpy()
-        nchunks = min(self.K, 64)
+        nchunks = min(self.KT, 64)
         t0 = time.perf_counter()
         hist = np.zeros(192, np.complex64); rcv = []
         for c in range(nchunks):
@@ -304,7 +313,7 @@ class Config4:
             # the first bursts of stream 0 as the device cut them on the FIRST step are not kept; re-run one step on a fresh front end
             from openbts_ttsou_amd.frontend import RxFrontEnd
             fe = RxFrontEnd(self.ctx, self.S, self.lpf, max_chunks=self.K)
-            fe.push_chunk(self.iq)
+            fe.push_chunk(self.segs[0])
             xg, og, lg, tng = fe.pop_bursts()
             nb = og.numel() // self.S
             xh = xg.cpu().numpy().view(np.complex64).ravel(); o0 = int(og[0].item())
@@ -385,8 +394,9 @@ def main():
     ap.add_argument("--bursts", type=int, default=None, help="bursts per GPU (normal, rach, config5; default 65536)")
     ap.add_argument("--streams", type=int, default=128, help="config4: ARFCN streams per GPU")
     ap.add_argument("--chunks", type=int, default=125,
-                    help="config4: 864-sample chunks per stream per step (125 chunks = 117 whole 157-156-156-156 groups: the "
-                         "repeated input stays aligned with the front end's burst schedule from step to step)")
+                    help="config4: 864-sample chunks per stream per step.  The generated stream is a multiple of 125 chunks long "
+                         "(125 chunks = 117 whole 157-156-156-156 groups) and consecutive steps push consecutive segments of it, so the "
+                         "input stays aligned with the front end's burst schedule whatever K is")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
