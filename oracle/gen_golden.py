@@ -372,6 +372,30 @@ def gen_config1():
     save("config1_loopback.npz", **kw)
 
 
+def gen_gsm_time():
+    """GSM::Time ordering and arithmetic (GSM/GSMCommon.h:327-455, GSMCommon.cpp:161-176) from the compiled reference: the
+    part of Transceiver's host logic (priority queue order, stale-burst test, frame differences) that CAN be pinned --
+    Transceiver.cpp itself needs the USRP headers and TRXManager.cpp libosip2, neither builds here."""
+    r = refbind.Ref(1)
+    H = 2048 * 26 * 51
+    rng = np.random.default_rng(20261004)
+    edge = [0, 1, 2, H // 2 - 1, H // 2, H // 2 + 1, H - 2, H - 1, 25, 26, 50, 51, 101, 102]
+    fns = np.array(edge + list(rng.integers(0, H, 200)), np.int64)
+    A = [(int(f), int(t)) for f in fns for t in (0, 3, 7)]
+    pairs = [(A[i], A[j]) for i in rng.integers(0, len(A), 1500) for j in [int(rng.integers(0, len(A)))]]
+    pairs += [((f, t), (f2, t2)) for f in edge for f2 in edge for (t, t2) in ((0, 0), (2, 5), (7, 1))]
+    g = lambda op, x, y=(0, 0), s=0: refbind.gsm_time(r.lib, op, x, y, s)
+    steps = rng.integers(0, 9, len(pairs)).astype(np.int32)
+    fsteps = rng.integers(-3000, 3000, len(pairs)).astype(np.int32)
+    save("gsm_time.npz",
+         a=np.array([p[0] for p in pairs], np.int32), b=np.array([p[1] for p in pairs], np.int32),
+         less=np.array([g(0, x, y) for x, y in pairs], np.int32), greater=np.array([g(1, x, y) for x, y in pairs], np.int32),
+         equal=np.array([g(2, x, y) for x, y in pairs], np.int32), minus=np.array([g(3, x, y) for x, y in pairs], np.int32),
+         tn_step=steps, inc_tn=np.array([g(5, x, s=s) for (x, _), s in zip(pairs, steps)], np.int32),
+         dec_tn=np.array([g(6, x, s=s) for (x, _), s in zip(pairs, steps)], np.int32),
+         fn_step=fsteps, add_fn=np.array([g(7, x, s=s) for (x, _), s in zip(pairs, fsteps)], np.int32))
+
+
 BITVECTORTEST_MC = ("000000000000111100000000000001110000011100001101000011000000000000000111000011110000100100001010"
                     "000010100000101000001010000010100000010000000000000000000000000000000000000000000000001100001111"
                     "000000000000000000000000000000000000000000000000000010010000101000001010000010100000101000001010"
@@ -474,4 +498,5 @@ if __name__ == "__main__":
     gen_resample()
     gen_dfe()
     gen_config1()
+    gen_gsm_time()
     gen_fec()

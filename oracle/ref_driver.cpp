@@ -377,4 +377,24 @@ int ref_rach_batch(const float *x, const int *off, const int *len, int B,
   return found;
 }
 
+/* GSM::Time arithmetic and ordering (GSM/GSMCommon.h:327-455, GSMCommon.cpp:161-176): what Transceiver's priority queue,
+ * stale-burst test and frame differences rest on.  op: 0 a < b, 1 a > b, 2 a == b, 3 a - b (frames), 4 FNDelta(fn1, fn2),
+ * 5 a.incTN(step), 6 a.decTN(step), 7 a + step (frames).  Result in *out (ops 0-4) or *out_fn / *out_tn (ops 5-7). */
+int ref_gsm_time(int op, int fn1, int tn1, int fn2, int tn2, int step, int *out, int *out_fn, int *out_tn) {
+  GSM::Time a(fn1, tn1), b(fn2, tn2);
+  switch (op) {
+    case 0: *out = a < b; return 0;
+    case 1: *out = a > b; return 0;
+    case 2: *out = a == b; return 0;
+    case 3: *out = a - b; return 0;
+    case 4: *out = GSM::FNDelta(fn1, fn2); return 0;
+    case 5: a.incTN((unsigned)step); break;
+    case 6: a.decTN((unsigned)step); break;
+    case 7: a += step; break;
+    default: return -1;
+  }
+  *out_fn = a.FN(); *out_tn = (int)a.TN();
+  return 0;
+}
+
 } /* extern "C" */

@@ -30,6 +30,15 @@ def c64(x):
     return np.ascontiguousarray(x, dtype=np.complex64).view(np.float32)
 
 
+def gsm_time(lib, op, a, b=(0, 0), step=0):
+    """GSM::Time of the compiled reference: op 0 a<b, 1 a>b, 2 a==b, 3 a-b, 4 FNDelta(a.fn, b.fn) -> int;
+    op 5 incTN(step), 6 decTN(step), 7 a += step -> (fn, tn)."""
+    out, ofn, otn = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.ref_gsm_time(op, int(a[0]), int(a[1]), int(b[0]), int(b[1]), int(step), C.byref(out), C.byref(ofn), C.byref(otn))
+    assert rc == 0
+    return out.value if op <= 4 else (ofn.value, otn.value)
+
+
 class Ref:
     """One loaded reference library (variant '' = Transceiver/, '52m' = Transceiver52M/).
 
@@ -54,6 +63,8 @@ class Ref:
             getattr(L, n).argtypes = [C.c_float]
             getattr(L, n).restype = C.c_float
         L.ref_expjLookup.argtypes = [C.c_float, f32p]
+        if hasattr(L, "ref_gsm_time"):
+            L.ref_gsm_time.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_int)] * 3
         L.ref_convolve.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, f32p]
         L.ref_correlate.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, f32p]
         L.ref_delay_vector.argtypes = [f32p, C.c_int, C.c_float]

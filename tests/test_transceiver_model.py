@@ -14,6 +14,19 @@ def test_time_arithmetic_wraps_like_gsm_time():
     assert tm.time_less((10, 3), (10, 4)) and not tm.time_less((10, 4), (10, 4))
 
 
+def test_time_arithmetic_matches_the_compiled_reference(golden):
+    """The model's GSM::Time ordering and frame differences against vectors captured from the reference's own GSMCommon
+    (tests/golden/gsm_time.npz, oracle/gen_golden.py:gen_gsm_time): this much of the host orchestration is pinned."""
+    g = golden("gsm_time.npz")
+    for a, b, less, greater, equal, minus in zip(g["a"], g["b"], g["less"], g["greater"], g["equal"], g["minus"]):
+        a, b = (int(a[0]), int(a[1])), (int(b[0]), int(b[1]))
+        assert tm.time_less(a, b) == bool(less), (a, b)
+        assert tm.time_less(b, a) == bool(greater), (a, b)
+        assert (a == b) == bool(equal)
+        assert tm.fn_delta(a[0], b[0]) == int(minus), (a, b)
+    assert int(g["less"].sum()) > 500 and int(g["greater"].sum()) > 500 and int(g["equal"].sum()) > 5
+
+
 def test_schedule_table_and_datagrams():
     m = tm.TransceiverModel(oraclebind.Oracle(1))
     for ts, code in enumerate([tm.I, tm.II, tm.IV, tm.V, tm.VII, tm.LOOPBACK, tm.NONE, tm.VI]):
