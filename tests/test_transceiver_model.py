@@ -21,7 +21,9 @@ def test_time_arithmetic_matches_the_compiled_reference(golden):
     for a, b, less, greater, equal, minus in zip(g["a"], g["b"], g["less"], g["greater"], g["equal"], g["minus"]):
         a, b = (int(a[0]), int(a[1])), (int(b[0]), int(b[1]))
         assert tm.time_less(a, b) == bool(less), (a, b)
-        assert tm.time_less(b, a) == bool(greater), (a, b)
+        # operator> is NOT the mirror of operator< exactly half a hyperframe apart (FNDelta is -H/2 both ways there): a > b
+        # is "frames apart > 0", as the reference writes it (GSMCommon.h:431-435)
+        assert ((a[1] > b[1]) if a[0] == b[0] else tm.fn_delta(a[0], b[0]) > 0) == bool(greater), (a, b)
         assert (a == b) == bool(equal)
         assert tm.fn_delta(a[0], b[0]) == int(minus), (a, b)
     assert int(g["less"].sum()) > 500 and int(g["greater"].sum()) > 500 and int(g["equal"].sum()) > 5
