@@ -1,0 +1,207 @@
+"""BASELINE.json's configurations at their FULL sizes (65,536 bursts per call; 128 ARFCN streams), checked through
+properties that do not need the oracle to process the whole batch:
+  * round trip: the bits that were modulated come back from every clean burst;
+  * order independence: the same bursts handed over in a random order give the same per-burst results, bit for bit
+    (no coupling between the bursts of a launch, whatever wave / workgroup / XCD they land on);
+  * exact scaling: every input sample times two (exact in binary floating point) doubles the amplitude estimate
+    exactly and leaves TOA, flags and soft bits untouched;
+  * a random sample of the batch (1024 bursts) value-exact against the CPU oracle;
+  * stream independence (config 4): a stream's bursts do not depend on how many other streams share the launch."""
+import numpy as np
+import pytest
+
+import _pkg
+import oraclebind
+from util import assert_veq
+
+pytestmark = pytest.mark.gpu
+
+B_FULL = 65536
+NS = 148
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _pkg.load()
+
+
+def _bufs(torch, B, ns, dev):
+    return dict(flags=torch.zeros(B, dtype=torch.uint8, device=dev), amp=torch.zeros(B, 2, device=dev), toa=torch.zeros(B, device=dev),
+                soft=torch.full((B, ns), -1.0, device=dev))
+
+
+def _same(torch, a, b, perm=None):
+    for k in ("flags", "amp", "toa", "soft"):
+        y = b[k]
+        x = a[k] if perm is None else a[k][perm]                # burst i of the permuted call is burst perm[i] of the first
+        # bit patterns, not values: view floats as int32
+        xi = x.view(torch.int32) if x.dtype == torch.float32 else x
+        yi = y.view(torch.int32) if y.dtype == torch.float32 else y
+        assert torch.equal(xi, yi), k
+
+
+def _sample_sub_batch(torch, xf, off, length, pick):
+    """Host copy of the picked bursts as a packed batch."""
+    offs = off[pick].cpu().numpy().astype(np.int64); lens = length[pick].cpu().numpy().astype(np.int64)
+    xs = [xf[o:o + n].cpu().numpy().view(np.complex64).ravel() for o, n in zip(offs, lens)]
+    noff = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    return np.concatenate(xs), noff, lens.astype(np.int32)
+
+
+@pytest.mark.parametrize("rach", [False, True], ids=["config2_normal", "config3_rach"])
+def test_full_batch_properties(pkg, rach):
+    import torch
+    from openbts_ttsou_amd import synth
+    dev = torch.device("cuda:0")
+    sps, tsc, B = 4, 2, B_FULL
+    if rach:
+        x, off, length, meta = synth.rach_batch_torch(sps, B, seed=77, device=dev)
+    else:
+        x, off, length, meta = synth.normal_batch_torch(sps, B, tsc, seed=77, device=dev)
+    xf = torch.view_as_real(x).contiguous()
+    t = pkg.TrxSig(sps, 0); t.use_torch_stream(); t.reserve(B)
+
+    def run(xin, o, n):
+        r = _bufs(torch, B, NS, dev)
+        if rach:
+            t.detect_demod_rach(xin, o, n, r["flags"], r["amp"], r["toa"], r["soft"], detect_thresh=5.0, energy_thresh=-1.0,
+                                nsoft=NS, soft_stride=NS)
+        else:
+            t.detect_demod_normal(xin, o, n, tsc, r["flags"], r["amp"], r["toa"], r["soft"], detect_thresh=3.0, energy_thresh=0.0,
+                                  nsoft=NS, soft_stride=NS)
+        torch.cuda.synchronize()
+        return r
+
+    base = run(xf, off, length)
+    det = (base["flags"] & pkg.F_DETECT) != 0
+    # round trip
+    clean = det & (meta["sigma"] <= 0.1)
+    assert int(clean.sum().item()) > B // 4
+    cols = slice(8, 85) if rach else slice(0, 148)
+    assert bool(((base["soft"][clean][:, cols] > 0.5).to(torch.uint8) == meta["bits"][clean][:, cols]).all().item())
+    assert float(det.float().mean().item()) > (0.6 if rach else 0.95)
+    # the same call again: deterministic to the bit
+    _same(torch, base, run(xf, off, length))
+    # order independence
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    perm = torch.randperm(B, generator=g).to(dev)
+    _same(torch, base, run(xf, off[perm].contiguous(), length[perm].contiguous()), perm)
+    # exact scaling by two
+    twice = run((xf * 2.0).contiguous(), off, length)
+    assert torch.equal(twice["flags"], base["flags"])
+    assert torch.equal(twice["amp"].view(torch.int32), (base["amp"] * 2.0).view(torch.int32))
+    assert torch.equal(twice["toa"].view(torch.int32), base["toa"].view(torch.int32))
+    assert torch.equal(twice["soft"].view(torch.int32), base["soft"].view(torch.int32))
+    # a random sample against the oracle
+    rng = np.random.default_rng(9)
+    pick = torch.from_numpy(np.sort(rng.choice(B, 1024 if not rach else 512, replace=False))).to(dev)
+    xs, so, sl = _sample_sub_batch(torch, xf, off, length, pick)
+    o = oraclebind.Oracle(sps)
+    if rach:
+        ok, amp, toa, soft = o.rach_batch(xs, so, sl, nthreads=8)
+    else:
+        ok, amp, toa, soft = o.normal_batch(xs, so, sl, tsc, nsoft=NS, nthreads=8)
+    assert_veq(det[pick].cpu().numpy(), ok.astype(bool), "detect")
+    assert_veq(base["amp"][pick].cpu().numpy().view(np.complex64).ravel(), amp, "amp")
+    assert_veq(base["toa"][pick].cpu().numpy(), toa, "toa")
+    assert_veq(base["soft"][pick].cpu().numpy(), soft[:, :NS], "soft")
+
+
+def test_config5_full_batch_fp16(pkg):
+    """65,536 one-sample-per-symbol bursts stored as fp16, the 52M equaliser leg: determinism, order independence, and a
+    sample of 768 bursts value-exact against the oracle chain (energyDetect -> analyzeTrafficBurst(requestChannel) ->
+    designDFE -> equalizeBurst)."""
+    import argparse
+    import torch
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_config5 import Config5
+    dev = torch.device("cuda:0")
+    wl = Config5(argparse.Namespace(bursts=B_FULL))
+    t = pkg.TrxSig(1, 0); t.use_torch_stream()
+    wl.setup(pkg, t, dev, 0, None)
+    B = wl.B
+
+    def run(o, n):
+        r = dict(flags=torch.zeros(B, dtype=torch.uint8, device=dev), amp=torch.zeros(B, 2, device=dev), toa=torch.zeros(B, device=dev),
+                 soft=torch.full((B, 157), -1.0, device=dev))
+        t.equalize_normal(wl.half, o, n, wl.tsc, r["flags"], r["amp"], r["toa"], r["soft"], energy_thresh=10.0, variant52m=True,
+                          max_toa=4, nsoft=156, soft_stride=157, fp16=True)
+        torch.cuda.synchronize()
+        return r
+
+    base = run(wl.off, wl.length)
+    det = (base["flags"] & pkg.F_DETECT) != 0
+    assert float(det.float().mean().item()) > 0.95
+    hard = (base["soft"][:, :148] > 0.5).to(torch.uint8)
+    assert float((hard[det] != wl.meta["bits"][det]).float().mean().item()) < 1e-3
+    _same(torch, base, run(wl.off, wl.length))
+    g = torch.Generator(device="cpu"); g.manual_seed(6)
+    perm = torch.randperm(B, generator=g).to(dev)
+    _same(torch, base, run(wl.off[perm].contiguous(), wl.length[perm].contiguous()), perm)
+    # oracle on a sample
+    o = oraclebind.Oracle(1, variant52m=True)
+    rng = np.random.default_rng(10)
+    pick = np.sort(rng.choice(B, 768, replace=False))
+    off = wl.off.cpu().numpy(); length = wl.length.cpu().numpy()
+    fl = base["flags"].cpu().numpy(); soft_d = base["soft"].cpu().numpy()
+    thr = 10.0
+    for i in pick:
+        s = wl.xq[int(off[i]):int(off[i] + length[i])].cpu().numpy().view(np.complex64).ravel()
+        ok_e, _ = o.energy_detect(s, 20, thr)
+        assert bool(fl[i] & pkg.F_ENERGY) == ok_e
+        a = o.analyze_traffic(s, wl.tsc, 3.0, req_chan=True, max_toa=4) if ok_e else None
+        d = bool(a and a["ok"])
+        assert bool(fl[i] & pkg.F_DETECT) == d
+        if d:
+            am = a["amp"]
+            n2 = np.float32(np.float32(am.imag * am.imag) + np.float32(am.real * am.real))
+            inv = complex(np.float32(am.real / n2), np.float32(-am.imag / n2))
+            snr = np.float32(np.float64(n2) / (np.float64(np.float32(thr * thr)) + 1.0))
+            w, b = o.design_dfe(o.scale_vector(a["chan"], inv), float(snr), 7)
+            soft = o.equalize(o.scale_vector(s, inv), np.float32(a["toa"] - a["chan_off"]), w, b)
+            assert np.array_equal(soft_d[i, :156], soft[:156]), i
+
+
+def test_config4_stream_independence(pkg):
+    """128 ARFCN streams through the receive front end in one push: the bursts of streams 0, 77 and 127 are bit for bit
+    what a front end that only carries that one stream cuts from the same samples."""
+    import torch
+    from openbts_ttsou_amd import synth
+    from openbts_ttsou_amd.frontend import RxFrontEnd, _DevView
+    dev = torch.device("cuda:0")
+    S, K = 128, 12
+    t = pkg.TrxSig(4, 0); t.use_torch_stream()
+    lpf = synth.design_lpf(961, 260)
+    g = torch.Generator(device="cpu"); g.manual_seed(12)
+    iq = torch.randint(-2000, 2001, (S, K * 864, 2), generator=g, dtype=torch.int16).to(dev)
+
+    def cut(streams, chunks_per_push):
+        fe = RxFrontEnd(t, len(streams), lpf, max_chunks=K)
+        sub = iq[streams].contiguous()
+        out = []
+        for c0 in range(0, K, chunks_per_push):
+            fe.push_chunk(sub[:, c0 * 864:(c0 + chunks_per_push) * 864].contiguous())
+            r = fe.pop_bursts()
+            if r is None:
+                continue
+            x, off, length, tn = r
+            torch.cuda.synchronize()
+            offh = off.cpu().numpy().astype(np.int64); lenh = length.cpu().numpy()
+            nb = len(offh) // len(streams)
+            for si in range(len(streams)):
+                for j in range(nb):
+                    o_ = offh[si * nb + j]
+                    out.append((si, int(tn[si * nb + j]), x[o_:o_ + lenh[si * nb + j]].clone()))
+        fe.close()
+        return out
+
+    full = cut(list(range(S)), K)
+    for s in (0, 77, 127):
+        one = cut([s], 4)                                      # alone, and in three pushes instead of one
+        mine = [(tn, x) for (si, tn, x) in full if si == s]
+        assert len(one) == len(mine) > 0
+        for (tn_a, xa), (_, tn_b, xb) in zip(mine, one):
+            assert tn_a == tn_b and torch.equal(xa.view(torch.int32), xb.view(torch.int32))
