@@ -49,6 +49,10 @@ __device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }     
 struct SmpC32 {
   static constexpr int kBytes = 8;
   static __device__ __forceinline__ cx ld(const void *base, long long i) { return reinterpret_cast<const cx *>(base)[i]; }
+  typedef cx raw_t;                                        // ldraw(): the stored sample as is (many loads in flight); widen(): to float32
+  static __device__ __forceinline__ raw_t ldraw(const void *base, long long i) { return reinterpret_cast<const cx *>(base)[i]; }
+  static __device__ __forceinline__ raw_t zero() { return mk(0, 0); }
+  static __device__ __forceinline__ cx widen(raw_t r) { return r; }
   static __device__ __forceinline__ float4 ld2(const void *base, long long first, int q) {
     return reinterpret_cast<const float4 *>(reinterpret_cast<const cx *>(base) + first)[q];
   }
@@ -57,6 +61,13 @@ struct SmpF16 {
   static constexpr int kBytes = 4;
   static __device__ __forceinline__ cx ld(const void *base, long long i) {
     const float2 v = __half22float2(reinterpret_cast<const __half2 *>(base)[i]);
+    return mk(v.x, v.y);
+  }
+  typedef unsigned raw_t;
+  static __device__ __forceinline__ raw_t ldraw(const void *base, long long i) { return reinterpret_cast<const unsigned *>(base)[i]; }
+  static __device__ __forceinline__ raw_t zero() { return 0u; }
+  static __device__ __forceinline__ cx widen(raw_t r) {
+    const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r));
     return mk(v.x, v.y);
   }
   static __device__ __forceinline__ float4 ld2(const void *base, long long first, int q) {

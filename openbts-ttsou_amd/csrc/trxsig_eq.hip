@@ -121,12 +121,27 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   // snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
   // double arithmetic, Transceiver.cpp:340); else snr_thresh >= 0: the threshold that enters
   // SNR = |amp|^2/(thr^2+1); else energy_thresh.  chan_off_out (optional): chanRespOffset (:343).
-  __shared__ cx corr[NCMAX][64];
-  __shared__ cx shf[NCMAX][64];
-  __shared__ cx xw[NXMAX][64];                              // the correlation window of each lane's burst (column = lane)
+  // LDS (one wave per workgroup, a column per lane), rows of 64 complex:
+  //   xp  rows [0, XROWS): the correlation window between zero pads (row PADF + a = window sample a; zeros from La on);
+  //   cp  the correlation between zero pads: logical row CPAD + i = lag i.  Its front pad IS xp's last CPAD rows (window
+  //       samples until the correlation is done, zeroed after it; only delayVector reads the pads);
+  //   loc (peakDetect's 26 rows) and, after it, shf (the delayed correlation) reuse xp's first rows.
+  // The pads turn the reference's "skip the taps that fall outside" (:480-498, :584-590) into products with zero samples
+  // (+-0: adding them never changes a value), so the inner loops carry no bounds checks.  The same storage first serves as
+  // the staging area of the burst loads.  29 KB for the 52M window: five workgroups per CU (four would be every one of the
+  // 1024 workgroups of a 65,536-burst launch resident only if the dispatcher balanced them perfectly).
+  constexpr int PADF = 10, XROWS = PADF + NXMAX, CPAD = 10, CROWS = NCMAX + CPAD;    // cp body + back pad
+  constexpr int NSLOT = 20 + NXMAX, PITCH = NSLOT | 1, NPASS = (NSLOT + 63) / 64;
+  static_assert(XROWS - CPAD >= 26 && XROWS - CPAD >= NCMAX, "loc / shf must stay clear of cp's front pad");
+  constexpr size_t kWork = sizeof(cx) * 64 * (XROWS + CROWS), kStage = sizeof(float) * 2 * 64 * PITCH;
+  __shared__ __attribute__((aligned(16))) char lds_raw[kWork > kStage ? kWork : kStage];
+  cx (*xp)[64] = reinterpret_cast<cx (*)[64]>(lds_raw);
+  cx (*cp)[64] = xp + (XROWS - CPAD);
+  cx (*shf)[64] = xp;
+  float *st_re = reinterpret_cast<float *>(lds_raw), *st_im = st_re + 64 * PITCH;
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
-  if (b >= B) return;                                      // no barriers below: each lane owns its columns
+  const bool live = b < B;
 #ifdef TRX_EQ_PROBE                                        // clock64() stamps come back through toa_out (tools/eq_probe.py)
   long long pt_[8] = {0};
   int pk_ = 0;
@@ -135,16 +150,12 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #define TRX_STAMP()
 #endif
   TRX_STAMP();
-  const int off = offset[b], N = length[b];
+  const int off = live ? offset[b] : 0, N = live ? length[b] : 0;
   uint8_t fl = 0;
   cx amp = mk(0, 0);
   float toa = 0.0f;
-  const bool good = (off >= 0) && (N >= 92) && (N <= 157);
-  if (!good) {
-    flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
-    return;
-  }
-  // ---- window geometry (pure arithmetic; needed up front so that the window's loads can fly with the energy's) ----
+  const bool good = live && (off >= 0) && (N >= 92) && (N <= 157);
+  // ---- window geometry (pure arithmetic, the same for every burst but for the length check) ----
   int ncorr, winStart, La, startIndex;
   unsigned maxTOA = (unsigned)max_toa;
   bool winOk;
@@ -163,15 +174,44 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
     winOk = !(ncorr > NCMAX || La > NXMAX || winStart < 0 || winStart + La > N);
   }
 
-  // ---- every load of this burst in flight at once: the 20 energy samples and the correlation window (each window
-  //      sample used to be fetched up to 16 times, one uncoalesced 8-byte load per tap and lag) ----
+  // ---- the burst loads, coalesced: a lane per burst would touch 64 different lines with every load instruction (46
+  //      instructions x 64 lines per wave: 28 % of the kernel went there).  Instead the wave fetches burst k's 20 energy
+  //      samples and its correlation window with ONE instruction (a lane per sample: ~8 lines), all 64 bursts' loads in
+  //      flight together, parks them burst-major in LDS (odd pitch: conflict-free both ways) and every lane then reads
+  //      its own burst's samples back. ----
   cx ev[20], wv[NXMAX];
   {
     const int step = variant52m ? 4 : 1;
+    const unsigned long long goodm = __ballot(good), winm = __ballot(good && winOk);
 #pragma unroll
-    for (int i = 0; i < 20; i++) ev[i] = SMP::ld(samples, off + i * step);
+    for (int p = 0; p < NPASS; p++) {
+      const int slot = lane + 64 * p;
+      const bool is_win = slot >= 20;
+      const bool slot_ok = slot < 20 + La && slot < NSLOT;
+      const int idx = is_win ? winStart + (slot - 20) : slot * step;
+      typename SMP::raw_t v[64];                          // as stored; widened only once every load has been issued
 #pragma unroll
-    for (int a = 0; a < NXMAX; a++) wv[a] = (winOk && a < La) ? SMP::ld(samples, off + winStart + a) : mk(0, 0);
+      for (int k = 0; k < 64; k++) {
+        const int off_k = __builtin_amdgcn_readlane(off, k);
+        const bool ok_k = ((is_win ? winm : goodm) >> k) & 1ull;
+        v[k] = (slot_ok && ok_k) ? SMP::ldraw(samples, (long long)off_k + idx) : SMP::zero();
+      }
+      if (slot < NSLOT) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) { const cx f = SMP::widen(v[k]); st_re[k * PITCH + slot] = f.r; st_im[k * PITCH + slot] = f.i; }
+      }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 20; i++) ev[i] = mk(st_re[lane * PITCH + i], st_im[lane * PITCH + i]);
+#pragma unroll
+    for (int a = 0; a < NXMAX; a++) wv[a] = mk(st_re[lane * PITCH + 20 + a], st_im[lane * PITCH + 20 + a]);   // zeros past La
+    wave_lds_fence();                                      // the staging area is dead: xp / cp take its place
+  }
+  if (!live) return;                                       // no barriers below: each lane owns its columns
+  if (!good) {
+    flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
+    return;
   }
   // ---- energyDetect (:916-932; the 52M variant strides by 4, ref52:946-963) ----
   {
@@ -189,39 +229,56 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
     return;
   }
 #pragma unroll
-  for (int a = 0; a < NXMAX; a++) if (a < La) xw[a][lane] = wv[a];   // the lane's LDS column
+  for (int a = 0; a < PADF; a++) xp[a][lane] = mk(0, 0);
+#pragma unroll
+  for (int a = 0; a < NXMAX; a++) xp[PADF + a][lane] = wv[a];   // the lane's LDS column (zeros from La on)
+#pragma unroll
+  for (int a = 0; a < CPAD; a++) cp[CPAD + ncorr + a][lane] = mk(0, 0);
   cx ctap[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) ctap[j] = T->mid_ctap[tsc][15 - j];
-  for (int i = 0; i < ncorr; i++) {
-    const int t = startIndex + i;
-    cx sum = mk(0, 0);
+  // every tap index t - j of every lag lies in [-PADF, NXMAX): no checks (always so for the geometries above)
+  const bool padded = startIndex - 15 >= -PADF && startIndex + ncorr - 1 < NXMAX;
+  if (padded) {
+    for (int i = 0; i < ncorr; i++) {
+      const cx (*row)[64] = xp + (PADF + startIndex + i);
+      cx sum = mk(0, 0);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {                         // tmp[j] = conj(mid[15-j]) (:480-498), j ascending
-      const int ai = t - j;
-      if (ai >= 0 && ai < La) sum = cadd(sum, cmul(xw[ai][lane], ctap[j]));
+      for (int j = 0; j < 16; j++) sum = cadd(sum, cmul(row[-j][lane], ctap[j]));   // tmp[j] = conj(mid[15-j]) (:480-498), j ascending
+      cp[CPAD + i][lane] = sum;
     }
-    corr[i][lane] = sum;
+  } else {
+    for (int i = 0; i < ncorr; i++) {
+      const int t = startIndex + i;
+      cx sum = mk(0, 0);
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int ai = t - j;
+        if (ai >= 0 && ai < La) sum = cadd(sum, cmul(xp[PADF + ai][lane], ctap[j]));
+      }
+      cp[CPAD + i][lane] = sum;
+    }
   }
+#pragma unroll
+  for (int a = 0; a < CPAD; a++) cp[a][lane] = mk(0, 0);    // the window is dead: its last rows become cp's front pad
 
   TRX_STAMP();                                             // 2: correlation
   // ---- peakDetect (:663-711) ----
   float maxP = 0.0f, maxIndex = -1.0f;
   for (int i = 0; i < ncorr; i++) {
-    const float p = norm2(corr[i][lane]);
+    const float p = norm2(cp[CPAD + i][lane]);
     if (p > maxP) { maxP = p; maxIndex = (float)i; }
   }
   {
     // the bisection itself as k_tsc_peak runs it (peak_bisect: both candidate sinc rows of the next step prefetched
     // with 16-byte loads while this step computes; the eq_interp form made two dependent gather round trips per step).
     // loc = corr[M-12 .. M+11] with zeros where interpolatePoint skips (lag < 0, lag > n-2); the window's LDS is free now.
-    static_assert(NXMAX >= 26, "loc aliases the correlation window");
-    cx (*loc)[64] = xw;
+    cx (*loc)[64] = xp;
     const int M = (int)maxIndex;
 #pragma unroll
     for (int j = 0; j < 24; j++) {
       const int lag = M - 12 + j;
-      loc[j][lane] = (lag >= 0 && lag <= ncorr - 2) ? corr[lag < 0 ? 0 : (lag > NCMAX - 1 ? NCMAX - 1 : lag)][lane] : mk(0, 0);
+      loc[j][lane] = (lag >= 0 && lag <= ncorr - 2) ? cp[CPAD + (lag < 0 ? 0 : (lag > NCMAX - 1 ? NCMAX - 1 : lag))][lane] : mk(0, 0);
     }
     loc[24][lane] = mk(0, 0);
     loc[25][lane] = mk(0, 0);
@@ -242,8 +299,8 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
     float valley = 0.0f;
     int numRms = 0;
     for (int i = 2; i <= 5; i++) {
-      if (p - i >= 0) { valley += norm2(corr[p - i][lane]); numRms++; }
-      if (p + i < ncorr) { valley += norm2(corr[p + i][lane]); numRms++; }
+      if (p - i >= 0) { valley += norm2(cp[CPAD + p - i][lane]); numRms++; }
+      if (p + i < ncorr) { valley += norm2(cp[CPAD + p + i][lane]); numRms++; }
     }
     if (numRms < 2) {
       amp = mk(0, 0);
@@ -266,7 +323,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
         const float delay = -toa;
         const int io = (int)floorf(delay);
         const float frac = delay - (float)io;
-        const cx (*src)[64] = corr;
+        const cx (*src)[64] = cp + CPAD;
         if (fabs((double)frac) > 1e-2) {
           float row[24];
           {
@@ -274,13 +331,11 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #pragma unroll
             for (int q = 0; q < 6; q++) { const float4 v4 = r4[q]; row[4 * q] = v4.x; row[4 * q + 1] = v4.y; row[4 * q + 2] = v4.z; row[4 * q + 3] = v4.w; }
           }
-          for (int t = 0; t < ncorr; t++) {
+          for (int t = 0; t < ncorr; t++) {                // taps t + 10 - j outside [0, ncorr) meet cp's zero pads
+            const cx (*crow)[64] = cp + (CPAD + t + 10);
             cx sum = mk(0, 0);
 #pragma unroll
-            for (int j = 0; j < 21; j++) {
-              const int ai = t + 10 - j;
-              if (ai >= 0 && ai < ncorr) sum = cadd(sum, cmulr(corr[ai][lane], row[j]));
-            }
+            for (int j = 0; j < 21; j++) sum = cadd(sum, cmulr(crow[-j][lane], row[j]));
             shf[t][lane] = sum;
           }
           src = shf;
@@ -341,6 +396,8 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   {
     long long v_ = 0;
     for (int k = 1; k < 8; k++) if ((b & 7) == k) v_ = pt_[k] - pt_[0];
+    if ((b & 7) == 6) v_ = pt_[0] & 0xFFFFFF;              // absolute start / end (24 bits): the launch's spread over time
+    if ((b & 7) == 7) v_ = pt_[5] & 0xFFFFFF;
     toa_out[b] = (float)v_;
   }
 #endif

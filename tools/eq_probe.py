@@ -26,3 +26,20 @@ for k in range(1, 6):
     m = v[:, k].mean()
     print('%-36s %9.0f cycles  (+%7.0f)' % (names[k], m, m - prev))
     prev = m
+
+# absolute stamps (24 bits of clock64): how the launch's waves spread over time
+st = v[:, 6]; en = v[:, 7]
+t0 = st.min()
+st = (st - t0) % (1 << 24); en = (en - t0) % (1 << 24)
+print('wave start: min 0, median %.0f, p90 %.0f, max %.0f cycles after the first' % (np.median(st), np.percentile(st, 90), st.max()))
+print('wave end:   min %.0f, median %.0f, p90 %.0f, max %.0f' % (en.min(), np.median(en), np.percentile(en, 90), en.max()))
+print('wave duration: median %.0f, max %.0f' % (np.median(en - st), (en - st).max()))
+# the counters of the 8 XCDs are not synchronised: look at each cluster of start times on its own
+order = np.argsort(st); ss = st[order]; ee = en[order]
+cuts = np.flatnonzero(np.diff(ss) > 200000)
+lo = 0
+for c in list(cuts) + [len(ss) - 1]:
+    a, e = ss[lo:c + 1], ee[lo:c + 1]
+    print('  cluster of %5d waves: starts spread over %6.0f cycles (median %6.0f), last end %6.0f after the first start' % (
+        len(a), a.max() - a.min(), np.median(a - a.min()), e.max() - a.min()))
+    lo = c + 1
