@@ -32,10 +32,120 @@ namespace {
   do { if (fmt == TRXSIG_SAMPLES_F16) { EQ_DETECT_LAUNCH_T(SmpF16, __VA_ARGS__); } else { EQ_DETECT_LAUNCH_T(SmpC32, __VA_ARGS__); } } while (0)
 #define EQ_DELAY_LAUNCH(...)                                                                                \
   do {                                                                                                      \
-    const dim3 g_((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), b_(64 * TRX_DEMOD_WAVES);                   \
-    if (fmt == TRXSIG_SAMPLES_F16) k_demod<1, true, 157, SmpF16><<<g_, b_, 0, st>>>(__VA_ARGS__);           \
-    else k_demod<1, true, 157, SmpC32><<<g_, b_, 0, st>>>(__VA_ARGS__);                                     \
+    const dim3 g_((B + 15) / 16), b_(256);                                                                  \
+    if (fmt == TRXSIG_SAMPLES_F16) k_eq_delay<SmpF16><<<g_, b_, 0, st>>>(__VA_ARGS__);                      \
+    else k_eq_delay<SmpC32><<<g_, b_, 0, st>>>(__VA_ARGS__);                                                \
   } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// k_eq_delay: equalizeBurst's first step (sigProcLib.cpp:1352-1356 after Transceiver.cpp:346): scaleVector(burst, 1/amp)
+//   then delayVector(-(TOA - chanOffset)) (:573-616) at one sample per symbol, every sample kept (the equaliser wants the
+//   whole burst).  SIXTEEN lanes per burst, four bursts per wave: a wave per burst (k_demod<1,RAW>) spent more
+//   instructions on its bookkeeping than on the 157 x 21 products and kept a third of its lanes idle -- 600 instructions
+//   per burst, issue-bound at 44 us per 65,536 bursts.  Here a lane owns TEN CONSECUTIVE outputs, whose 21-tap windows
+//   overlap: 30 LDS reads feed 210 multiply-adds (the burst sits in LDS, scaled, between zero pads that stand for
+//   "taps outside the vector are skipped", :584-590: +-0 products).  Results go back through LDS so that the stores are
+//   coalesced.  Same terms in the same order as delayVector: j ascending over the 21 real taps; the taps come from the
+//   sinc grid when the fraction lies on it (always after peakDetect), else from the table sinc as the reference computes them.
+// ---------------------------------------------------------------------------------------------
+template <typename SMP>
+__global__ __launch_bounds__(256) void k_eq_delay(const TrxTables *__restrict__ T, const void *__restrict__ samples,
+                                                  const int32_t *__restrict__ offset, const int32_t *__restrict__ length, int B,
+                                                  const cx *__restrict__ amp_in, const float *__restrict__ toa_in,
+                                                  const uint8_t *__restrict__ flags, int need_mask, cx *__restrict__ xd,
+                                                  int xstride) {
+  constexpr int PADL = 16, ROW = 208, OPL = 10;            // 16 lanes x OPL outputs >= 157; windows span [PADL - 10, PADL + 169]
+  static_assert(PADL >= 10 && PADL + 16 * OPL - 1 + 10 < ROW, "every window stays inside the row");
+  __shared__ __attribute__((aligned(16))) cx rows[16][ROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hl = lane & 15, slot = wave * 4 + (lane >> 4);
+  const int b = blockIdx.x * 16 + slot;
+  const bool live = b < B;
+  int off = 0, N = 0;
+  cx amp = mk(1.0f, 0.0f);
+  float toa = 0.0f;
+  uint8_t fl = 0;
+  if (live) { off = offset[b]; N = length[b]; amp = amp_in[b]; toa = toa_in[b]; if (flags) fl = flags[b]; }
+  bool enabled = live && (off >= 0) && (N >= 92) && (N <= 157) && (fabsf(toa) <= 4096.0f);   // k_demod's gate (also rejects NaN/inf)
+  if (flags) enabled = enabled && (need_mask ? ((fl & need_mask) == need_mask) : (fl != 0));
+  if (!enabled) N = 0;
+  cx *S = rows[slot];
+  // ---- the burst's loads first: sample n = hl + 16 i ----
+  typename SMP::raw_t v[OPL];
+#pragma unroll
+  for (int i = 0; i < OPL; i++) {
+    const int n = hl + 16 * i;
+    v[i] = n < N ? SMP::ldraw(samples, (long long)off + n) : SMP::zero();
+  }
+  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (Transceiver.cpp:346 / :1066)
+  const float delay = -toa;                                // delayVector bookkeeping (:577-582)
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  const bool filt = fabs((double)frac) > 1e-2;
+  float tp[21];
+  {
+    const float f512 = frac * 512.0f;
+    const int f = (int)f512;
+    const bool grid = (float)f == f512;
+    const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+    float g[24];
+#pragma unroll
+    for (int q = 0; q < 6; q++) { const float4 r4 = row[q]; g[4 * q] = r4.x; g[4 * q + 1] = r4.y; g[4 * q + 2] = r4.z; g[4 * q + 3] = r4.w; }
+#pragma unroll
+    for (int j = 0; j < 21; j++) tp[j] = g[j];
+    if (__any(!grid)) {
+      // off the grid (never after peakDetect): tap j = sinc(pi*((j - 10) - frac)) (:588), computed by lanes j and j - 16 of the burst
+      const float tv0 = dev_sinc(T->sinT, TRX_PI_F * ((float)(hl - 10) - frac));
+      const float tv1 = dev_sinc(T->sinT, TRX_PI_F * ((float)(hl + 6) - frac));
+      const int first = lane & ~15;
+#pragma unroll
+      for (int j = 0; j < 21; j++) {
+        const float tj = j < 16 ? __shfl(tv0, first + j, 64) : __shfl(tv1, first + j - 16, 64);
+        tp[j] = grid ? g[j] : tj;
+      }
+    }
+  }
+  // ---- the scaled burst between zeros, already moved by the integer delay: sample n at S[PADL + n + io] (what falls
+  //      outside the row lies outside every window below) ----
+#pragma unroll
+  for (int i = 0; i < ROW / 16; i++) S[hl + 16 * i] = mk(0, 0);
+  wave_lds_fence();
+#pragma unroll
+  for (int i = 0; i < OPL; i++) {
+    const int n = hl + 16 * i, p = PADL + n + io;
+    if (n < N && p >= 0 && p < ROW) S[p] = cmul(SMP::widen(v[i]), inv);   // scaleVector (:713-723)
+  }
+  wave_lds_fence();
+  // ---- outputs m = OPL*hl + i: shifted[m] = filtered[m - io] inside [0, N), else 0 (:597-613); tap j of output m meets
+  //      position PADL + m + 10 - j = w[i + 20 - j] ----
+  cx y[OPL];
+  {
+    const cx *W = S + (PADL + OPL * hl - 10);
+    cx w[OPL + 20];
+#pragma unroll
+    for (int k = 0; k < OPL + 20; k++) w[k] = W[k];
+#pragma unroll
+    for (int i = 0; i < OPL; i++) {
+      cx acc = mk(0, 0);
+#pragma unroll
+      for (int j = 0; j < 21; j++) acc = cadd(acc, cmulr(w[i + 20 - j], tp[j]));   // convolve(..., NO_DELAY), j ascending (:590)
+      const int t = OPL * hl + i - io;
+      const cx r = filt ? acc : w[i + 10];
+      y[i] = (t >= 0 && t < N) ? r : mk(0, 0);
+    }
+  }
+  // ---- through LDS again, so that a store instruction writes 16 consecutive samples of each burst ----
+  wave_lds_fence();
+#pragma unroll
+  for (int i = 0; i < OPL; i++) S[OPL * hl + i] = y[i];
+  wave_lds_fence();
+  cx *out = xd + (size_t)(live ? b : 0) * xstride;
+#pragma unroll
+  for (int i = 0; i < OPL; i++) {
+    const int m = hl + 16 * i;
+    if (m < N) out[m] = S[m];
+  }
+}
 
 // designDFE(channelResponse, SNRestimate, Nf = 7, ...) (sigProcLib.cpp:1246-1340), nu = 5: fully unrolled in registers.
 // chan: the six channel taps (already scaled by 1/amp, Transceiver.cpp:346); w: feed-forward, bq: feedback taps.
@@ -588,7 +698,8 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
 #pragma unroll
           for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
           hist[0] = fbv;
-          sv = (float)(0.5 * (double)(re + 1.0F));          // vectorSlicer (:513-515)
+          sv = (re + 1.0F) * 0.5F;                          // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)); re + 1.0F is 0 or
+          //                                                   at least 2^-24 in magnitude, so halving it in float is exact too
           if (sv > 1.0f) sv = 1.0f;
           if (sv < 0.0f) sv = 0.0f;
         }
@@ -651,7 +762,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
                    variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr);
   if (prof) { prof->end(TRXSIG_K_EQUALIZE, st); prof->begin(TRXSIG_K_EQ_DELAY, st); }
-  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
   launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
@@ -679,7 +790,7 @@ hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const v
                                     float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
-  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, (float *)xd, nullptr, 0, xstride);
+  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
   launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
