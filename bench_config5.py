@@ -18,10 +18,10 @@ class Config5:
         self.B = args.bursts or 65536
         self.alg_bytes = 4 * 625 // 4 + 4 * 156 + 16           # 4*156.25 B of fp16 I/Q read; 156 soft bits + flag / amp / TOA written
         # per-kernel algorithmic bytes per burst: k_eq_detect reads the 26-sample window + 20 energy samples (fp16) and writes
-        # flag / amp / TOA / toa_eq + 12 taps; k_demod<1,RAW> reads the burst (fp16) and writes 157 delayed c64; k_eq_dfe2 reads
+        # flag / amp / TOA / toa_eq + 12 taps; k_eq_delay reads the burst (fp16) and writes 157 delayed c64; k_eq_dfe2 reads
         # those + the taps and writes 156 soft bits
         self.kernel_alg = {"k_eq_detect": 4 * 46 + 17 + 4 + 96, "k_eq_delay": 625 + 13 + 8 * 157, "k_eq_dfe": 8 * 157 + 96 + 4 * 156}
-        self.kernel_names = {"k_eq_delay": "k_demod<1,RAW,fp16>", "k_eq_dfe": "k_eq_dfe2"}
+        self.kernel_names = {"k_eq_dfe": "k_eq_dfe2"}
 
     def setup(self, pkg, ctx, dev, rank, args):
         import torch
