@@ -209,7 +209,7 @@ class Config4:
         self.per_chunk = 585 * self.sps                      # resampled samples per 864-sample chunk
         self.alg_bytes = 4 * 625 * 96 // (65 * self.sps) + 4 * NSOFT + 16   # int16 in, soft bits out
         self.kernel_alg = {"k_resample": None}               # per stream-chunk, see roofline()
-        self.kernel_names = {"k_tsc_peak": "k_tsc_peak2"}
+        self.kernel_names = {"k_tsc_peak": "k_tsc_peak2", "k_resample": "k_rx_resample"}
 
     def setup(self, pkg, ctx, dev, rank, args):
         import numpy as np

@@ -18,7 +18,7 @@ namespace {
 //                 peakDetect, valley test, delayVector on the correlation, 6-tap channel pick --
 //                 then scaleVector(chan, 1/amp), SNR and designDFE(chan, SNR, 7).  Everything here
 //                 is tiny and strictly sequential per burst, so bursts are the parallel axis.
-//   k_demod<1,RAW> : delayVector(burst/amp, -(TOA - chanOffset)), one wave per burst.
+//   k_eq_delay  : 16 lanes per burst.  delayVector(burst/amp, -(TOA - chanOffset)).
 //   k_eq_dfe    : one lane per burst.  7-tap feed-forward FIR + the 156-step decision-feedback
 //                 recursion of equalizeBurst (:1352-1384) and the slicer.
 // ---------------------------------------------------------------------------------------------
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #undef TRX_STAMP
 }
 
-// The burst's row of xd was written by k_demod<1,RAW> only if that kernel accepted the burst (k_demod's gate: DETECT flag,
+// The burst's row of xd was written by k_eq_delay only if that kernel accepted the burst (k_demod's gate: DETECT flag,
 // 92..157 samples, |TOA| <= 4096 and not NaN).  The equaliser must apply the same gate, or it would equalise whatever an
 // earlier call left in the row and hand back plausible-looking soft bits.
 __device__ __forceinline__ bool eq_enabled(uint8_t fl, int N, float toa_eq) {

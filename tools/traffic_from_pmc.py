@@ -1,0 +1,56 @@
+"""profiles/traffic.json from the committed counter summaries profiles/r02_pmc_<workload>.txt (tools/pmc.sh via
+tools/r02_profiles.sh): HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE KiB (FETCH_SIZE doubled per the gfx950 correction
+of MI355X_MICROARCH.md).  bench.py reads the file for `roofline.traffic`.
+    python tools/traffic_from_pmc.py"""
+import json, os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+# (file, kernel-name prefix in the summary, key in traffic.json, units per launch, extra fields)
+WANT = [("normal", "k_demod<4", "k_demod", 65536, {}), ("normal", "k_tsc_corr<4", "k_tsc_corr", 65536, {}),
+        ("normal", "k_tsc_peak2<4", "k_tsc_peak2", 65536, {}), ("normal", "k_tsc_peak2<4", "k_tsc_peak", 65536, {}),
+        ("rach", "k_rach_front<4", "k_rach_front", 65536, {}), ("rach", "k_rach_peak2<4", "k_rach_peak2", 65536, {}),
+        ("config5", "k_eq_delay<", "k_eq_delay", 65536, {}), ("config5", "k_eq_detect<", "k_eq_detect", 65536, {}),
+        ("config5", "k_eq_dfe2", "k_eq_dfe2", 65536, {}),
+        ("config4", "k_rx_resample", "k_rx_resample", 128 * 125, {"note": "units = stream-chunks (128 streams x 125 chunks per launch)"}),
+        ("config4", "k_rx_resample", "k_resample", 128 * 125, {"kernel": "k_rx_resample", "note": "units = stream-chunks (128 streams x 125 chunks per launch)"})]
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        if not line.strip():
+            continue
+        if not line.startswith(" "):
+            cur = line.strip(); out.setdefault(cur, {})
+        else:
+            m = re.match(r"\s+(\w+)\s+avg\s+([0-9.]+)", line)
+            if m and cur:
+                out[cur][m.group(1)] = float(m.group(2))
+    return out
+
+
+def main():
+    kernels = {}
+    cache = {}
+    for wl, prefix, key, units, extra in WANT:
+        if wl not in cache:
+            cache[wl] = parse(os.path.join(P, "r02_pmc_%s.txt" % wl))
+        hit = [k for k in cache[wl] if k.startswith(prefix) and "FETCH_SIZE" in cache[wl][k] and "WRITE_SIZE" in cache[wl][k]]
+        if not hit:
+            raise SystemExit("no counters for %s in r02_pmc_%s.txt" % (prefix, wl))
+        c = cache[wl][hit[0]]
+        e = dict(extra)
+        e.update(fetch_kb=round(c["FETCH_SIZE"], 1), write_kb=round(c["WRITE_SIZE"], 1),
+                 hbm_bytes_per_launch=int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)))
+        e["bursts_per_launch"] = units
+        kernels[key] = e
+    doc = {"source": "profiles/r02_pmc_<workload>.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace only, "
+                     "tools/pmc.sh via tools/r02_profiles.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; units KiB); "
+                     "rebuilt by tools/traffic_from_pmc.py", "kernels": kernels}
+    json.dump(doc, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+    for k, v in kernels.items():
+        print("%-14s %6.1f MB per launch" % (k, v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
