@@ -260,6 +260,11 @@ int trxsig_equalize_normal_batch_fmt(trxsig_ctx *ctx, const void *d_samples, int
                                      int variant52m, int max_toa, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
                                      trxsig_c32 *d_w, trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
                                      int soft_stride);
+/* trxsig_equalize_taps_batch (cached DFE taps, Transceiver.cpp:391-396) on either sample storage */
+int trxsig_equalize_taps_batch_fmt(trxsig_ctx *ctx, const void *d_samples, int sample_format, const int32_t *d_offset,
+                                   const int32_t *d_length, int B, const trxsig_c32 *d_amp, const float *d_toa_eq,
+                                   const uint8_t *d_enable, const trxsig_c32 *d_w, const trxsig_c32 *d_b, float *d_soft,
+                                   uint8_t *d_hard, int nsoft, int soft_stride);
 
 /* ---- convenience: host-buffer single-call wrappers (copy in, run, copy out, synchronise).
  *   These exist so Transceiver::pullRadioVector can keep calling one burst at a time; they are

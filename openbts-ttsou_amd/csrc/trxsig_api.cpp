@@ -515,13 +515,14 @@ int trxsig_design_dfe_batch(trxsig_ctx *c, const trxsig_c32 *d_chan, const trxsi
   return TRXSIG_OK;
 }
 
-int trxsig_equalize_taps_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
-                               int B, const trxsig_c32 *d_amp, const float *d_toa_eq, const uint8_t *d_enable,
-                               const trxsig_c32 *d_w, const trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
-                               int soft_stride) {
+int trxsig_equalize_taps_batch_fmt(trxsig_ctx *c, const void *d_samples, int sample_format, const int32_t *d_offset,
+                                   const int32_t *d_length, int B, const trxsig_c32 *d_amp, const float *d_toa_eq,
+                                   const uint8_t *d_enable, const trxsig_c32 *d_w, const trxsig_c32 *d_b, float *d_soft,
+                                   uint8_t *d_hard, int nsoft, int soft_stride) {
   if (!c) return TRXSIG_EINVAL;
   if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "trxsig_equalize_taps_batch: equalizeBurst needs sps == 1");
   if (bad_batch(d_samples, d_offset, d_length, B) || nsoft < 0 || nsoft > 157 || soft_stride < nsoft ||
+      (sample_format != TRXSIG_SAMPLES_C32 && sample_format != TRXSIG_SAMPLES_F16) ||
       (B > 0 && (!d_amp || !d_toa_eq || !d_enable || !d_w || !d_b || (nsoft > 0 && !d_soft))))
     return fail(c, TRXSIG_EINVAL, "trxsig_equalize_taps_batch: bad argument");
   if (B == 0) return TRXSIG_OK;
@@ -529,10 +530,17 @@ int trxsig_equalize_taps_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const
   int rc = ensure_eq(c, B);
   if (rc != TRXSIG_OK) return rc;
   trx_c32 *xd = (trx_c32 *)(c->d_eq + (size_t)c->eq_cap * (4 + 56 + 40));
-  HIPCHK(c, trx_launch_equalize_taps(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B,
+  HIPCHK(c, trx_launch_equalize_taps(c->stream, c->d_tables, d_samples, sample_format, d_offset, d_length, B,
                                      (const trx_c32 *)d_amp, d_toa_eq, d_enable, (const trx_c32 *)d_w, (const trx_c32 *)d_b,
                                      xd, EQ_XS, d_soft, d_hard, nsoft, soft_stride, c->prof));
   return TRXSIG_OK;
+}
+int trxsig_equalize_taps_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
+                               int B, const trxsig_c32 *d_amp, const float *d_toa_eq, const uint8_t *d_enable,
+                               const trxsig_c32 *d_w, const trxsig_c32 *d_b, float *d_soft, uint8_t *d_hard, int nsoft,
+                               int soft_stride) {
+  return trxsig_equalize_taps_batch_fmt(c, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, d_amp, d_toa_eq, d_enable, d_w, d_b,
+                                        d_soft, d_hard, nsoft, soft_stride);
 }
 
 int trxsig_equalize_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,

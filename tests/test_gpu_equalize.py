@@ -257,3 +257,63 @@ def test_equalize_taps_rejected_burst_is_not_equalised_from_stale_scratch(pkg, t
         assert not second[i, :156].any(), i
     ok = [i for i in range(B) if i not in (3, 5, 7, 9)]
     assert np.array_equal(second[ok], first[ok])
+
+
+def test_delay_and_equalize_with_arbitrary_toa_lengths_and_taps(pkg, t1):
+    """k_eq_delay + k_eq_dfe2 through trxsig_equalize_taps_batch on inputs analyzeTrafficBurst would never produce: every
+    length from 92 to 157 at ragged odd offsets, TOAs on the 1/512 grid, off it (table sinc computed in the kernel), within
+    1e-2 of an integer (delayVector's copy branch), integer shifts of tens and hundreds of samples in both directions (the
+    burst leaves the staging row partly or wholly), random amplitudes and random feed-forward / feedback taps; float32 and
+    fp16 storage.  Every soft bit value-exact against scaleVector + equalizeBurst of the oracle."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(2024)
+    o = oraclebind.Oracle(1)
+    B = 528
+    lens = np.concatenate([np.arange(92, 158), rng.integers(92, 158, B - 66)]).astype(np.int32)
+    gaps = rng.integers(0, 4, B)
+    off = np.zeros(B, np.int32)
+    pos = 1
+    for i in range(B):
+        off[i] = pos; pos += int(lens[i]) + int(gaps[i])
+    xq = rng.integers(-1500, 1501, (pos + 8, 2)).astype(np.float32)          # fp16-exact integers: both storages see the same values
+    toa = np.empty(B, np.float32)
+    kinds = rng.integers(0, 6, B)
+    for i in range(B):
+        k = kinds[i]
+        if k == 0: toa[i] = rng.integers(-8 * 512, 8 * 512) / 512.0                       # on the grid
+        elif k == 1: toa[i] = np.float32(rng.uniform(-9, 9))                             # off the grid
+        elif k == 2: toa[i] = np.float32(rng.integers(-6, 7) + rng.choice([-1, 1]) * rng.uniform(0, 9e-3))   # copy branch
+        elif k == 3: toa[i] = np.float32(rng.integers(-40, 41) + rng.integers(0, 512) / 512.0)             # tens of samples
+        elif k == 4: toa[i] = np.float32(rng.choice([-300.25, -157.0, -100.5, 99.75, 156.5, 2000.125, 4096.0, -4096.0]))
+        else: toa[i] = 0.0
+    amp = (rng.uniform(0.2, 40, B) * np.exp(2j * np.pi * rng.uniform(0, 1, B))).astype(np.complex64)
+    w = (rng.normal(0, 0.4, (B, 7)) + 1j * rng.normal(0, 0.4, (B, 7))).astype(np.complex64)
+    b = (rng.normal(0, 0.2, (B, 5)) + 1j * rng.normal(0, 0.2, (B, 5))).astype(np.complex64)
+    dev = "cuda"
+    doff = torch.from_numpy(off).cuda(); dlen = torch.from_numpy(lens).cuda()
+    damp = torch.from_numpy(amp.view(np.float32).reshape(B, 2)).cuda(); dtoa = torch.from_numpy(toa).cuda()
+    dw = torch.from_numpy(w.view(np.float32).reshape(B, 7, 2)).cuda(); db = torch.from_numpy(b.view(np.float32).reshape(B, 5, 2)).cuda()
+    en = torch.full((B,), pkg.F_DETECT, dtype=torch.uint8, device=dev)
+    L = t1.L
+    vp, i32 = C.c_void_p, C.c_int
+    L.trxsig_equalize_taps_batch_fmt.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32]
+    want = np.zeros((B, 157), np.float32)
+    xc = xq.view(np.complex64).ravel()
+    for i in range(B):
+        s = xc[off[i]:off[i] + lens[i]]
+        a = amp[i]
+        n2 = np.float32(np.float32(a.imag * a.imag) + np.float32(a.real * a.real))
+        inv = complex(np.float32(a.real / n2), np.float32(-a.imag / n2))
+        soft = o.equalize(o.scale_vector(s, inv), np.float32(toa[i]), w[i], b[i])
+        want[i, :min(156, len(soft))] = soft[:156]
+    for fmt, dx in ((0, torch.from_numpy(xq).cuda()), (1, torch.from_numpy(xq).to(torch.float16).cuda())):
+        soft = torch.full((B, 157), -1.0, device=dev)
+        t1._chk(L.trxsig_equalize_taps_batch_fmt(t1.h, dx.data_ptr(), fmt, doff.data_ptr(), dlen.data_ptr(), B, damp.data_ptr(),
+                                                 dtoa.data_ptr(), en.data_ptr(), dw.data_ptr(), db.data_ptr(), soft.data_ptr(), None,
+                                                 156, 157), "equalize_taps_fmt")
+        torch.cuda.synchronize()
+        got = soft.cpu().numpy()
+        for i in range(B):
+            n = min(156, int(lens[i]))
+            assert np.array_equal(got[i, :n], want[i, :n]), (fmt, i, int(lens[i]), float(toa[i]), int(kinds[i]))

@@ -40,4 +40,38 @@ for sps in (1, 2, 4):
     total += N // 2
     print("sps %d: 8 TSC x %d normal bursts (x2 energy gates) + %d access bursts identical  [%.0f s]" % (sps, N, N // 2, time.time() - t0),
           flush=True)
+# the equaliser leg at one sample per symbol, classic and 52M windows, half of the bursts through a two-path channel
+t = pkg.TrxSig(1, 0); t.use_torch_stream()
+for variant52m in (False, True):
+    o = oraclebind.Oracle(1, variant52m=variant52m)
+    tsc, thr, Ne = 6, 10.0, max(N // 4, 256)
+    x, off, length, meta = synth.normal_batch(1, Ne, tsc, seed=777 + variant52m, sigmas=(0.02, 0.1, 0.4, 1.5), max_delay=2.0)
+    x = (x * np.float32(200)).astype(np.complex64)
+    for i in range(1, Ne, 2):
+        s = x[off[i]:off[i] + length[i]]
+        s[1:] = s[1:] + np.complex64(0.4 + 0.2j) * s[:-1].copy()
+    dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    doff = torch.from_numpy(off.astype(np.int32)).cuda(); dlen = torch.from_numpy(length.astype(np.int32)).cuda()
+    fl = torch.zeros(Ne, dtype=torch.uint8, device="cuda"); am = torch.zeros(Ne, 2, device="cuda"); to = torch.zeros(Ne, device="cuda")
+    so = torch.zeros(Ne, 157, device="cuda")
+    t.equalize_normal(dx, doff, dlen, tsc, fl, am, to, so, energy_thresh=thr, variant52m=variant52m, max_toa=4, nsoft=156, soft_stride=157)
+    torch.cuda.synchronize()
+    flh = fl.cpu().numpy(); soh = so.cpu().numpy()
+    for i in range(Ne):
+        s = x[off[i]:off[i] + length[i]]
+        ok_e, _ = o.energy_detect(s, 20, thr)
+        assert bool(flh[i] & pkg.F_ENERGY) == ok_e, i
+        a = o.analyze_traffic(s, tsc, 3.0, req_chan=True, max_toa=4) if ok_e else None
+        det = bool(a and a["ok"])
+        assert bool(flh[i] & pkg.F_DETECT) == det, i
+        if det:
+            amv = a["amp"]
+            n2 = np.float32(np.float32(amv.imag * amv.imag) + np.float32(amv.real * amv.real))
+            inv = complex(np.float32(amv.real / n2), np.float32(-amv.imag / n2))
+            snr = np.float32(np.float64(n2) / (np.float64(np.float32(thr * thr)) + 1.0))
+            w, b = o.design_dfe(o.scale_vector(a["chan"], inv), float(snr), 7)
+            soft = o.equalize(o.scale_vector(s, inv), np.float32(a["toa"] - a["chan_off"]), w, b)
+            assert np.array_equal(soh[i, :156], soft[:156]), i
+    total += Ne
+    print("equaliser leg (%s window): %d bursts identical  [%.0f s]" % ("52M" if variant52m else "classic", Ne, time.time() - t0), flush=True)
 print("parity campaign: %d bursts, every output value-exact" % total)
