@@ -47,6 +47,18 @@ int trxsig_rxfe_push(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks);
 int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t **d_offset, const int32_t **d_length,
                     int32_t *h_tn, int cap_tn, int *n_bursts);
 int trxsig_rxfe_pending(const trxsig_rxfe *fe);   /* samples per stream not yet cut into bursts */
+/* trxsig_rxfe_push + trxsig_rxfe_pop + trxsig_detect_demod_normal_batch in one call, with the resampled stream never written to
+ * memory: the detect and demodulate kernels compute the samples of their bursts from the int16 chunks (four multiply-adds
+ * each; the unfused chain writes 300 MB of complex float32 per 61 K bursts and reads it back 1.4 times).  Same results bit
+ * for bit.  Needs sps == 4, a filter of at most 4*260 taps and nsoft <= 148; a front end is used either through this call or
+ * through push / pop, not both.  *n_bursts per stream are completed by this push; burst j of stream s is entry
+ * s * *n_bursts + j of every output array (which must hold n_streams * bursts_upper_bound entries, the bound being
+ * (628 + n_chunks * 2340) / 624); h_tn as in trxsig_rxfe_pop.  d_iq is read by kernels on the context's stream: keep it
+ * unchanged until they have run. */
+int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int tsc, float detect_thresh,
+                                         float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr,
+                                         float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride, int32_t *h_tn, int cap_tn,
+                                         int *n_bursts);
 
 /* h_lpf: the L (normally 651, createLPF(cutoff, 651, 96): radioInterface.cpp:134-138) normalised taps.  max_bursts: the
  * most bursts per stream one push may carry. */

@@ -105,6 +105,8 @@ int fail(trxsig_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 // for the other host translation units of the library (trxsig_frontend.cpp)
 int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e) { return fail(c, code, what, e); }
 TrxProfiler *trx_ctx_profiler(trxsig_ctx *c) { return c ? c->prof : nullptr; }
+int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
+                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 namespace {
 
 #define HIPCHK(c, call)                                          \
@@ -407,6 +409,26 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
                                soft_stride, c->prof));
   return TRXSIG_OK;
 }
+
+}  // extern "C"
+// the normal-burst leg on bursts that are computed from the raw int16 stream (trxsig_rxfe_push_detect_demod_normal,
+// trxsig_frontend.cpp): same kernels, same scratch, no complex float32 stream in HBM
+int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
+                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
+  if (tsc < 0 || tsc > 7 || nsoft < 0 || nsoft > 148 || soft_stride < nsoft || B < 0 ||
+      (B > 0 && (!d_flags || !d_amp || !d_toa || (nsoft > 0 && !d_soft))))
+    return fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_ws(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, trx_launch_rx_normal(c->stream, c->d_tables, c->h_tables, gen, B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts,
+                                 d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->generic_taps, c->prof));
+  return TRXSIG_OK;
+}
+extern "C" {
 
 int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
                                    const int32_t *d_length, int B, float detect_thresh, float energy_thresh,

@@ -14,6 +14,8 @@
 // context internals (trxsig_api.cpp)
 int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e);
 TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
+int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
+                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
 namespace {
 #define FE_HIP(c, call)                                                        \
@@ -41,6 +43,11 @@ struct trxsig_rxfe {
   float *d_lpf = nullptr;
   int32_t *d_idx = nullptr;                                 // off[S*nb] then len[S*nb]
   int idx_cap = 0;
+  // fused mode (trxsig_rxfe_push_detect_demod_normal): no receive buffer; what is kept between calls is raw
+  int mode = 0;                                             // 0 undecided, 1 push / pop, 2 fused
+  short2 *d_keep = nullptr;                                 // [S][n_in]: the window (history + chunk) of the last chunk received
+  float4 *d_tpb = nullptr;                                  // [P] branch-major taps
+  int tail = 0;                                             // resampled samples of earlier pushes not yet cut into bursts
 };
 
 struct trxsig_txbe {
@@ -84,6 +91,18 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
     trxsig_rxfe_destroy(fe);
     return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);
   }
+  if (fe->sps == 4 && L <= 4 * fe->P) {                     // the fused call's tables (sps 4, at most four taps per output)
+    std::vector<float> tpb(4 * (size_t)fe->P, 0.0f);
+    for (int br = 0; br < fe->P; br++)
+      for (int k = 0; k < 4; k++) if (br + fe->P * k < L) tpb[4 * br + k] = h_lpf[br + fe->P * k];
+    if (hipMalloc((void **)&fe->d_tpb, sizeof(float4) * (size_t)fe->P) != hipSuccess ||
+        hipMemcpy(fe->d_tpb, tpb.data(), sizeof(float4) * (size_t)fe->P, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&fe->d_keep, sizeof(short2) * (size_t)fe->n_in * fe->S) != hipSuccess ||
+        hipMemset(fe->d_keep, 0, sizeof(short2) * (size_t)fe->n_in * fe->S) != hipSuccess) {
+      trxsig_rxfe_destroy(fe);
+      return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);
+    }
+  }
   *out = fe;
   return TRXSIG_OK;
 }
@@ -93,16 +112,19 @@ void trxsig_rxfe_destroy(trxsig_rxfe *fe) {
   {
     Guard g(trxsig_device(fe->c));
     (void)hipFree(fe->d_rcv); (void)hipFree(fe->d_tmp); (void)hipFree(fe->d_hist); (void)hipFree(fe->d_lpf); (void)hipFree(fe->d_idx);
+    (void)hipFree(fe->d_keep); (void)hipFree(fe->d_tpb);
   }
   delete fe;
 }
 
-int trxsig_rxfe_pending(const trxsig_rxfe *fe) { return fe ? fe->wr - fe->rd : TRXSIG_EINVAL; }
+int trxsig_rxfe_pending(const trxsig_rxfe *fe) { return fe ? (fe->mode == 2 ? fe->tail : fe->wr - fe->rd) : TRXSIG_EINVAL; }
 
 int trxsig_rxfe_push(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks) {
   if (!fe) return TRXSIG_EINVAL;
   trxsig_ctx *c = fe->c;
   if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: bad argument", hipSuccess);
+  if (fe->mode == 2) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: this front end is used through the fused call", hipSuccess);
+  fe->mode = 1;
   Guard g(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   const int left = fe->wr - fe->rd;
@@ -138,6 +160,7 @@ int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t
   if (!fe) return TRXSIG_EINVAL;
   trxsig_ctx *c = fe->c;
   if (!d_samples || !d_offset || !d_length || !n_bursts) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_pop: bad argument", hipSuccess);
+  if (fe->mode == 2) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_pop: this front end is used through the fused call", hipSuccess);
   int nb = 0, pos = 0, tn = fe->tn;
   const int avail = fe->wr - fe->rd;
   while (avail - pos > burst_len(tn, fe->sps)) {            // "while (rcvSz > burst size)" (:375)
@@ -161,6 +184,51 @@ int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t
   FE_HIP(c, trx_launch_burst_index(st, fe->S, nb, fe->stride, fe->rd, fe->tn, fe->sps, off, len));
   *d_offset = off; *d_length = len;
   fe->rd += pos; fe->tn = tn;
+  return TRXSIG_OK;
+}
+
+int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int tsc, float detect_thresh,
+                                         float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr,
+                                         float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride, int32_t *h_tn, int cap_tn,
+                                         int *n_bursts) {
+  if (!fe) return TRXSIG_EINVAL;
+  trxsig_ctx *c = fe->c;
+  if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks || !n_bursts)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: bad argument", hipSuccess);
+  if (!fe->d_tpb) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: needs sps == 4 and a filter of at most 4*260 taps", hipSuccess);
+  if (fe->mode == 1) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: this front end is used through push / pop", hipSuccess);
+  fe->mode = 2;
+  // the bursts this push completes: "while (rcvSz > burst size)" (:375) over the uncut tail plus the new samples
+  const int avail = fe->tail + n_chunks * fe->per_chunk;
+  int nb = 0, pos = 0, tn = fe->tn;
+  while (avail - pos > burst_len(tn, fe->sps)) {
+    if (h_tn && nb < cap_tn) h_tn[nb] = tn;
+    pos += burst_len(tn, fe->sps); tn = (tn + 1) & 7; nb++;
+  }
+  if (h_tn && nb > cap_tn) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: h_tn too small", hipSuccess);
+  *n_bursts = nb;
+  Guard g(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  if (nb > 0) {
+    TrxRxGen gen = {};
+    gen.raw = reinterpret_cast<const short2 *>(d_iq); gen.raw_stride = (long long)n_chunks * TRXSIG_OUTCHUNK;
+    gen.keep = fe->d_keep; gen.tpb = fe->d_tpb; gen.K = n_chunks; gen.swap = fe->swap;
+    gen.skipD = fe->skip + (fe->L - 1) / 2 / TRXSIG_OUTRATE;
+    gen.tail = fe->tail; gen.tn0 = fe->tn; gen.nb = nb;
+    const int rc = trx_ctx_rx_normal(c, gen, fe->S * nb, tsc, detect_thresh, energy_thresh, d_flags, d_amp, d_toa, d_avgpwr, d_soft,
+                                     d_hard, nsoft, soft_stride);
+    if (rc != TRXSIG_OK) return rc;
+  }
+  // keep the window of the last chunk: [its 192-sample history | the chunk] (stream-ordered behind the kernels that read d_keep)
+  const size_t kb = sizeof(short2) * (size_t)fe->n_in, rowb = sizeof(short2) * (size_t)n_chunks * TRXSIG_OUTCHUNK;
+  const short2 *raw = reinterpret_cast<const short2 *>(d_iq);
+  if (n_chunks >= 2) {
+    FE_HIP(c, hipMemcpy2DAsync(fe->d_keep, kb, raw + ((size_t)n_chunks * TRXSIG_OUTCHUNK - fe->n_in), rowb, kb, fe->S, hipMemcpyDeviceToDevice, st));
+  } else {
+    FE_HIP(c, hipMemcpy2DAsync(fe->d_keep, kb, fe->d_keep + TRXSIG_OUTCHUNK, kb, sizeof(short2) * TRXSIG_OUTHISTORY, fe->S, hipMemcpyDeviceToDevice, st));
+    FE_HIP(c, hipMemcpy2DAsync(fe->d_keep + TRXSIG_OUTHISTORY, kb, raw, rowb, sizeof(short2) * TRXSIG_OUTCHUNK, fe->S, hipMemcpyDeviceToDevice, st));
+  }
+  fe->tail = avail - pos; fe->tn = tn;
   return TRXSIG_OK;
 }
 

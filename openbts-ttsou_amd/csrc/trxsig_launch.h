@@ -107,6 +107,20 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
                                   TrxProfiler *prof);
 hipError_t trx_launch_burst_index(hipStream_t st, int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *off,
                                   int32_t *len);
+// The receive front end fused into the normal-burst detectors (trxsig_rxgen.h, sps = 4, 65*4 : 96 with at most four taps per
+// output): the bursts are described by where they start in the stream of resampled samples, and the kernels compute those
+// samples from the raw int16 stream as they need them.
+struct TrxRxGen {
+  const short2 *raw; long long raw_stride;                 // this push: stream s at raw + s*raw_stride, K*864 samples each
+  const short2 *keep;                                      // [S][1056]: history + last chunk of the previous push (its window)
+  const float4 *tpb;                                       // [260] taps, branch-major: tpb[br] = lpf[br + 260 k], k = 0..3
+  int K, swap, skipD;                                      // chunks in this push; I/Q swap; INHISTORY outputs skipped + (L-1)/2/Q
+  int tail, tn0, nb;                                       // uncut resampled samples before this push; TN of burst 0; bursts per stream
+};
+hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const TrxRxGen &gen, int B, int tsc,
+                                float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp,
+                                float *toa, float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps,
+                                TrxProfiler *prof);
 // pack: 0 = int16 I/Q -> complex float (swap: I/Q flipped), 1 = complex float -> int16 I/Q, 2 = fp16 I/Q -> complex float
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
                               TrxProfiler *prof, float gain = 1.0f /* pack == 1: scaleVector before the cast */);

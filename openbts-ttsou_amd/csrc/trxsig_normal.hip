@@ -12,6 +12,7 @@
 #include "trxsig_bisect.h"
 #include "trxsig_corr.h"
 #include "trxsig_demod.h"
+#include "trxsig_rxgen.h"
 
 namespace {
 
@@ -382,6 +383,112 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
 #undef TRX_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// The receive front end fused in (trxsig_rxgen.h; sps = 4): k_tsc_corr_rx / k_demod_rx are k_tsc_corr / k_demod with the
+// burst's samples computed from the raw int16 stream instead of loaded: the wave first parks the stretch of raw samples
+// its burst depends on (140 for the correlator's two windows, 236 for the whole burst) in LDS as floats, then every lane
+// produces the samples it would have loaded -- four multiply-adds each -- and the kernel carries on unchanged.
+// ---------------------------------------------------------------------------------------------
+template <int SPS, unsigned TAPCLS>
+__global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr_rx(TrxRxGen a, int B, TapArg taps, cx *__restrict__ rec, int Bpad) {
+  static_assert(SPS == 4, "the fused front end is the 260 : 96 resampler");
+  typedef CorrGeom<SPS> G;
+  constexpr int XCAP = 160;                                // raw samples behind resampled samples [0, 92*SPS) of a burst: <= 140
+  static_assert(G::WPAD >= XCAP, "the raw stretch is parked in the burst's own row");
+  __shared__ __attribute__((aligned(16))) cx rows[16][G::WPAD];
+  __shared__ float4 tpb_s[RXG_P];
+  for (int i = threadIdx.x; i < RXG_P; i += 256) tpb_s[i] = a.tpb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 4, r = lane & 15;
+  const int slot = wave * 4 + row;
+  cx tap[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
+  const int b = blockIdx.x * 16 + slot;
+  CorrIn<SPS> in;
+  in.b = b; in.live = b < B; in.good = in.live;
+  const RxBurst u = rx_burst(a, in.live ? b : 0);
+  const int jlo = rx_index(u.g0, a.skipD).j0 - 3;
+  cx *X = rows[slot];
+  {
+    cx v[XCAP / 16];
+#pragma unroll
+    for (int i = 0; i < XCAP / 16; i++) v[i] = in.live ? rx_raw(a, u.s, jlo + r + 16 * i) : mk(0, 0);
+#pragma unroll
+    for (int i = 0; i < XCAP / 16; i++) X[r + 16 * i] = v[i];
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int i = 0; i < CorrIn<SPS>::NW; i++) {
+    const int q = r + 16 * i;
+    in.w[i] = (in.good && q < G::NL) ? rx_sample(X, tpb_s, jlo, rx_index(u.g0 + 56 * SPS + q, a.skipD)) : mk(0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < G::NEQ; q++) {
+    const int i = r + 16 * q;
+    in.e[q] = (in.good && i < G::NE) ? rx_sample(X, tpb_s, jlo, rx_index(u.g0 + i, a.skipD)) : mk(0, 0);
+  }
+  wave_lds_fence();                                        // the raw stretch is dead: the row becomes corr_round's
+  int M;
+  float energy;
+  corr_round<SPS, true, true, TAPCLS>(in, rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+}
+
+template <int SPS>
+__global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B,
+                                                                  const cx *__restrict__ amp_in, const float *__restrict__ toa_in,
+                                                                  const uint8_t *__restrict__ flags, int need_mask,
+                                                                  float *__restrict__ soft, uint8_t *__restrict__ hard, int nsoft,
+                                                                  int stride) {
+  static_assert(SPS == 4, "the fused front end is the 260 : 96 resampler");
+  typedef DemodGeom<SPS, 148> G;
+  constexpr int XCAP = 256;                                // raw samples behind one burst: <= 236
+  static_assert(G::U >= XCAP, "the raw stretch is parked in the burst's staging area");
+  __shared__ cx ph[TRX_DEMOD_WAVES][G::U];
+  __shared__ float4 tpb_s[RXG_P];
+  for (int i = threadIdx.x; i < RXG_P; i += 64 * TRX_DEMOD_WAVES) tpb_s[i] = a.tpb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * TRX_DEMOD_WAVES + wave;       // wave-uniform
+  if (b >= B) return;
+  float *sb = soft + (size_t)b * stride;
+  uint8_t *hb = hard ? hard + (size_t)b * stride : nullptr;
+  const cx amp = amp_in[b];
+  const float toa = toa_in[b];
+  bool enabled = fabsf(toa) <= 4096.0f;                    // also rejects NaN/inf TOA
+  if (flags) enabled = enabled && (need_mask ? ((flags[b] & need_mask) == need_mask) : (flags[b] != 0));
+  if (!enabled) {
+    for (int m = lane; m < nsoft; m += 64) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
+    return;
+  }
+  const RxBurst u = rx_burst(a, b);
+  const int jlo = rx_index(u.g0, a.skipD).j0 - 3;
+  cx *X = ph[wave];
+  {
+    cx v[XCAP / 64];
+#pragma unroll
+    for (int i = 0; i < XCAP / 64; i++) v[i] = rx_raw(a, u.s, jlo + lane + 64 * i);
+#pragma unroll
+    for (int i = 0; i < XCAP / 64; i++) X[lane + 64 * i] = v[i];
+  }
+  wave_lds_fence();
+  constexpr int NLD = (157 * SPS / 2 + 63) / 64;           // sample pairs per lane, as k_demod loads them
+  float4 v[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; i++) {
+    const int q = lane + 64 * i;
+    v[i] = make_float4(0, 0, 0, 0);
+    if (2 * q < u.N) {
+      const cx s0 = rx_sample(X, tpb_s, jlo, rx_index(u.g0 + 2 * q, a.skipD));
+      const cx s1 = rx_sample(X, tpb_s, jlo, rx_index(u.g0 + 2 * q + 1, a.skipD));
+      v[i] = make_float4(s0.r, s0.i, s1.r, s1.i);
+    }
+  }
+  fused_demod<SPS, 64>(T, ph[wave], v, u.N, amp, toa, lane, sb, hb, nsoft, [] {}, nullptr, nullptr);   // (starts with an LDS fence)
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -441,6 +548,37 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
     case 2: launch_tsc_detect<2>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
     case 4: launch_tsc_detect<4>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, rec, Bpad, flags, amp, toa, avgpwr, variant, prof); break;
     default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const TrxRxGen &gen, int B, int tsc,
+                                float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp,
+                                float *toa, float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps,
+                                TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  if (nsoft > 148 || gen.nb <= 0) return hipErrorInvalidValue;
+  constexpr int S = 4;
+  TapArg ta;
+  for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
+  if (prof) prof->begin(TRXSIG_K_TSC_CORR, st);
+  const dim3 cgrid((B + 15) / 16);
+  if (!generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value)
+    k_tsc_corr_rx<S, TapPattern<S>::value><<<cgrid, dim3(256), 0, st>>>(gen, B, ta, rec, Bpad);
+  else
+    k_tsc_corr_rx<S, TRX_TAPS_GENERIC><<<cgrid, dim3(256), 0, st>>>(gen, B, ta, rec, Bpad);
+  if (prof) { prof->end(TRXSIG_K_TSC_CORR, st); prof->begin(TRXSIG_K_TSC_PEAK, st); }
+  const trx_c32 g = hT->mid_gain[tsc];                     // gain.inv() (Complex.h:154-160), as launch_tsc_detect
+  const float n = g.i * g.i + g.r * g.r;
+  trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
+  k_tsc_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh,
+                                                              flags, amp, toa, avgpwr);
+  if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
+  if (nsoft > 0) {
+    if (prof) prof->begin(TRXSIG_K_DEMOD, st);
+    k_demod_rx<S><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
+        dT, gen, B, amp, toa, flags, TRXSIG_F_DETECT, soft, hard, nsoft, stride);
+    if (prof) prof->end(TRXSIG_K_DEMOD, st);
   }
   return hipGetLastError();
 }

@@ -28,6 +28,8 @@ def _bind(L):
     L.trxsig_rxfe_push.argtypes = [vp, vp, i32]
     L.trxsig_rxfe_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, C.POINTER(i32)]
     L.trxsig_rxfe_pending.argtypes = [vp]
+    L.trxsig_rxfe_push_detect_demod_normal.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32,
+                                                       C.POINTER(i32)]
     L.trxsig_txbe_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, C.c_float]
     L.trxsig_txbe_destroy.argtypes = [vp]; L.trxsig_txbe_destroy.restype = None
     L.trxsig_txbe_push_bursts.argtypes = [vp, vp, vp, vp, i32]
@@ -98,6 +100,25 @@ class RxFrontEnd:
         end = int((off.to(torch.int64) + length.to(torch.int64)).max().item())
         x = torch.as_tensor(_DevView(ps, (end, 2), "<f4"), device=self.dev)
         return x, off, length, np.tile(tn, self.S)
+
+    def push_detect_demod(self, iq, tsc, flags, amp, toa, soft, avgpwr=None, hard=None, detect_thresh=3.0, energy_thresh=0.0, nsoft=148,
+                          soft_stride=None, max_bursts=4096):
+        """The fused call: iq int16 [S, K*864, 2] (device); outputs are device tensors with room for S * bursts entries
+        (burst j of stream s at s*nb + j).  Returns (nb bursts per stream, tn int32 [nb])."""
+        torch = self.torch
+        assert iq.dtype == torch.int16 and iq.shape[0] == self.S and iq.shape[1] % OUTCHUNK == 0 and iq.shape[2] == 2
+        iq = iq.contiguous()
+        if soft_stride is None:
+            soft_stride = soft.shape[-1]
+        nb = C.c_int()
+        tn = np.zeros(max_bursts, np.int32)
+        p = lambda t: None if t is None else t.data_ptr()
+        self.ctx._chk(self.L.trxsig_rxfe_push_detect_demod_normal(self.h, iq.data_ptr(), iq.shape[1] // OUTCHUNK, tsc, detect_thresh,
+                                                                  energy_thresh, p(flags), p(amp), p(toa), p(avgpwr), p(soft), p(hard),
+                                                                  nsoft, soft_stride, tn.ctypes.data, max_bursts, C.byref(nb)),
+                      "trxsig_rxfe_push_detect_demod_normal")
+        self._keep = iq
+        return nb.value, tn[:nb.value].copy()
 
     def pending(self):
         return self.L.trxsig_rxfe_pending(self.h)

@@ -138,3 +138,76 @@ def test_multi_chunk_push_equals_chunk_by_chunk(golden):
     fe.push_chunk(d_iq[:, :2 * OUTCHUNK])
     with pytest.raises(pkg.TrxSigError, match="full"):
         fe.push_chunk(d_iq[:, 2 * OUTCHUNK:4 * OUTCHUNK])
+
+
+@pytest.mark.parametrize("lpf_kind", ["reference_table", "designed"])
+def test_fused_front_end_equals_push_pop_detect(golden, lpf_kind):
+    """trxsig_rxfe_push_detect_demod_normal (the detectors compute their samples from the int16 chunks; no resampled stream
+    in memory) against push + pop + trxsig_detect_demod_normal_batch on the same streams: pushes of 1, 2, 7, ... chunks, a
+    start TN of 3, bursts straddling pushes.  Flags, amplitude, TOA, average power, soft and hard bits identical bit for bit."""
+    import torch
+    pkg = _pkg.load()
+    from openbts_ttsou_amd import synth
+    from openbts_ttsou_amd.frontend import RxFrontEnd, OUTCHUNK
+    sps, S, tsc = 4, 6, 1
+    lpf = golden("resample.npz")["lpf961_gain260"] if lpf_kind == "reference_table" else synth.design_lpf(961, 260)
+    iq, nchunks = make_streams(sps, S, 130, tsc, seed=5)
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    d_iq = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+    sizes = [1, 1, 2, 7, 1, 5, 3]
+    assert nchunks > sum(sizes) + 1
+    sizes.append(nchunks - sum(sizes))
+    dev = "cuda"
+
+    def bufs(n):
+        return dict(flags=torch.zeros(n, dtype=torch.uint8, device=dev), amp=torch.zeros(n, 2, device=dev), toa=torch.zeros(n, device=dev),
+                    pwr=torch.zeros(n, device=dev), soft=torch.full((n, 148), -1.0, device=dev),
+                    hard=torch.full((n, 148), 255, dtype=torch.uint8, device=dev))
+
+    def unfused():
+        fe = RxFrontEnd(ctx, S, lpf, max_chunks=max(sizes), start_tn=3)
+        out, c = [], 0
+        for k in sizes:
+            fe.push_chunk(d_iq[:, c * OUTCHUNK:(c + k) * OUTCHUNK]); c += k
+            r = fe.pop_raw()
+            if r is None:
+                out.append(None); continue
+            ps, po, pl, tn, nb = r
+            o = bufs(S * nb)
+            ctx._chk(ctx.L.trxsig_detect_demod_normal_batch(ctx.h, ps, po, pl, S * nb, tsc, 3.0, 0.0, o["flags"].data_ptr(), o["amp"].data_ptr(),
+                                                            o["toa"].data_ptr(), o["pwr"].data_ptr(), o["soft"].data_ptr(), o["hard"].data_ptr(),
+                                                            148, 148), "detect_demod")
+            torch.cuda.synchronize()
+            out.append((tn, {k2: v.cpu().numpy() for k2, v in o.items()}))
+        return out
+
+    def fused():
+        fe = RxFrontEnd(ctx, S, lpf, max_chunks=max(sizes), start_tn=3)
+        out, c = [], 0
+        for k in sizes:
+            o = bufs(S * (2 + k * 4))
+            nb, tn = fe.push_detect_demod(d_iq[:, c * OUTCHUNK:(c + k) * OUTCHUNK], tsc, o["flags"], o["amp"], o["toa"], o["soft"],
+                                          avgpwr=o["pwr"], hard=o["hard"], nsoft=148, soft_stride=148)
+            c += k
+            torch.cuda.synchronize()
+            out.append(None if nb == 0 else (tn, {k2: v.cpu().numpy()[:S * nb] for k2, v in o.items()}))
+        return out
+
+    a, b = unfused(), fused()
+    ndet = ntot = 0
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        assert (ra is None) == (rb is None), i
+        if ra is None:
+            continue
+        assert np.array_equal(ra[0], rb[0]), ("tn", i)
+        for k2 in ("flags", "amp", "toa", "pwr", "soft", "hard"):
+            x, y = ra[1][k2], rb[1][k2]
+            assert x.shape == y.shape and x.tobytes() == y.tobytes(), (k2, "push", i, sizes[i])
+        ndet += int(((ra[1]["flags"] & pkg.F_DETECT) != 0).sum()); ntot += len(ra[1]["flags"])
+    assert ntot > S * 100 and (lpf_kind == "reference_table" or ndet > ntot // 2)
+    # a front end serves one of the two call styles
+    fe = RxFrontEnd(ctx, S, lpf, max_chunks=2)
+    fe.push_chunk(d_iq[:, :OUTCHUNK])
+    o = bufs(S * 8)
+    with pytest.raises(pkg.TrxSigError, match="push / pop"):
+        fe.push_detect_demod(d_iq[:, OUTCHUNK:2 * OUTCHUNK], tsc, o["flags"], o["amp"], o["toa"], o["soft"])
