@@ -210,6 +210,9 @@ class Config4:
         self.alg_bytes = 4 * 625 * 96 // (65 * self.sps) + 4 * NSOFT + 16   # int16 in, soft bits out
         self.kernel_alg = {"k_resample": None}               # per stream-chunk, see roofline()
         self.kernel_names = {"k_tsc_peak": "k_tsc_peak2", "k_resample": "k_rx_resample"}
+        self.fused = bool(getattr(args, "fused_frontend", False))   # the detectors compute their samples from the int16 chunks
+        if self.fused:
+            self.kernel_names.update({"k_demod": "k_demod_rx", "k_tsc_corr": "k_tsc_corr_rx"})
 
     def setup(self, pkg, ctx, dev, rank, args):
         import numpy as np
@@ -253,6 +256,13 @@ class Config4:
         self.last_nb = 0
 
     def step(self):
+        if self.fused:
+            nb, _ = self.fe.push_detect_demod(self.segs[self.seg], self.tsc, self.flags, self.amp, self.toa, self.soft, detect_thresh=3.0,
+                                              energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+            self.seg = (self.seg + 1) % len(self.segs)
+            self.nbursts += self.S * nb
+            self.last_nb = self.S * nb
+            return
         self.fe.push_chunk(self.segs[self.seg])
         self.seg = (self.seg + 1) % len(self.segs)
         r = self.fe.pop_raw()
@@ -399,6 +409,7 @@ def main():
                          "input stays aligned with the front end's burst schedule whatever K is")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
+    ap.add_argument("--fused-frontend", action="store_true", help="config4: trxsig_rxfe_push_detect_demod_normal (no resampled stream in HBM) instead of push + pop + detect")
     ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3; config4 = resample + slice + detect "
                          "per ARFCN stream; config5 = 52M equaliser leg, fp16 storage (side measurements)")

@@ -171,10 +171,12 @@ struct FusedGeom {
 // burst's loads there, into the same registers).
 // tp_pre / rv_pre (optional): the 21 delay-filter taps for this TOA and the lane's OPL reverse-rotation
 // values, when the caller has fetched them ahead of time.
-template <int SPS, int LPB, typename HOOK>
-__device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + LPB - 1) / LPB],
-                                            int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft, HOOK staged,
-                                            const float *tp_pre, const cx *rv_pre) {
+// fused_demod_ex: the same with the staging step handed in -- stage(P, inv, lo) writes sample n, scaled by inv, to position
+// u = n + lo (entry (u % SPS) * QLEN + u / SPS) for every n in [0, N) whose position lies in [0, U); the positions outside
+// [lo, lo + N) have been zeroed.  fused_demod (below) stages from the 16-byte loads; k_demod_rx from samples it computes.
+template <int SPS, int LPB, typename STAGE, typename HOOK>
+__device__ __forceinline__ void fused_demod_ex(const TrxTables *__restrict__ T, cx *P, int N, cx amp, float toa, int hl, float *sb,
+                                               uint8_t *hbp, int nsoft, STAGE stage, HOOK staged, const float *tp_pre, const cx *rv_pre) {
   typedef FusedGeom<SPS, LPB> G;
   typedef typename G::D D;
   const bool lane_owner = G::OPL * hl < 148;
@@ -218,28 +220,7 @@ __device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx 
   const int lo = io + D::C, hi = N + io + D::C;            // samples occupy positions [lo, hi)
   for (int u = hl; u < lo && u < D::U; u += LPB) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
   for (int u = (hi > 0 ? hi : 0) + hl; u < D::U; u += LPB) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
-  if (lo >= 0 && (N & 1) == 0 && (2 * LPB) % SPS == 0) {
-    // common case: nothing falls off the front, pairs are whole.  Pair q = hl + LPB*i sits at positions
-    // u = 2q + lo, u + 1; successive i move both by 2*LPB positions = 2*LPB/SPS entries of the same phase.
-    const int ua = 2 * hl + lo, ub = ua + 1;
-    cx *pa = P + (ua % SPS) * D::QLEN + ua / SPS;
-    cx *pb = P + (ub % SPS) * D::QLEN + ub / SPS;
-#pragma unroll
-    for (int i = 0; i < G::NLD; i++) {
-      if (2 * (hl + LPB * i) < N) {
-        if (ua + 2 * LPB * i < D::U) pa[i * (2 * LPB / SPS)] = cmul(mk(v[i].x, v[i].y), inv);   // scaleVector (:713-723)
-        if (ub + 2 * LPB * i < D::U) pb[i * (2 * LPB / SPS)] = cmul(mk(v[i].z, v[i].w), inv);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < G::NLD; i++) {
-      const int n0 = 2 * (hl + LPB * i);
-      const int u0 = n0 + lo, u1 = u0 + 1;
-      if (n0 < N && u0 >= 0 && u0 < D::U) P[(u0 % SPS) * D::QLEN + u0 / SPS] = cmul(mk(v[i].x, v[i].y), inv);
-      if (n0 + 1 < N && u1 >= 0 && u1 < D::U) P[(u1 % SPS) * D::QLEN + u1 / SPS] = cmul(mk(v[i].z, v[i].w), inv);
-    }
-  }
+  stage(P, inv, lo);
   wave_lds_fence();
   staged();
 
@@ -292,6 +273,40 @@ __device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx 
       if (hbp) hbp[m] = sv > 0.5F;                         // SoftVector::bit (BitVector.h:415-420)
     }
   }
+}
+
+
+template <int SPS, int LPB, typename HOOK>
+__device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + LPB - 1) / LPB],
+                                            int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft, HOOK staged,
+                                            const float *tp_pre, const cx *rv_pre) {
+  typedef FusedGeom<SPS, LPB> G;
+  typedef typename G::D D;
+  auto stage = [&](cx *P_, cx inv, int lo) {
+  if (lo >= 0 && (N & 1) == 0 && (2 * LPB) % SPS == 0) {
+    // common case: nothing falls off the front, pairs are whole.  Pair q = hl + LPB*i sits at positions
+    // u = 2q + lo, u + 1; successive i move both by 2*LPB positions = 2*LPB/SPS entries of the same phase.
+    const int ua = 2 * hl + lo, ub = ua + 1;
+    cx *pa = P_ + (ua % SPS) * D::QLEN + ua / SPS;
+    cx *pb = P_ + (ub % SPS) * D::QLEN + ub / SPS;
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      if (2 * (hl + LPB * i) < N) {
+        if (ua + 2 * LPB * i < D::U) pa[i * (2 * LPB / SPS)] = cmul(mk(v[i].x, v[i].y), inv);   // scaleVector (:713-723)
+        if (ub + 2 * LPB * i < D::U) pb[i * (2 * LPB / SPS)] = cmul(mk(v[i].z, v[i].w), inv);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      const int n0 = 2 * (hl + LPB * i);
+      const int u0 = n0 + lo, u1 = u0 + 1;
+      if (n0 < N && u0 >= 0 && u0 < D::U) P_[(u0 % SPS) * D::QLEN + u0 / SPS] = cmul(mk(v[i].x, v[i].y), inv);
+      if (n0 + 1 < N && u1 >= 0 && u1 < D::U) P_[(u1 % SPS) * D::QLEN + u1 / SPS] = cmul(mk(v[i].z, v[i].w), inv);
+    }
+  }
+  };
+  fused_demod_ex<SPS, LPB>(T, P, N, amp, toa, hl, sb, hbp, nsoft, stage, staged, tp_pre, rv_pre);
 }
 
 

@@ -92,11 +92,14 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
     return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);
   }
   if (fe->sps == 4 && L <= 4 * fe->P) {                     // the fused call's tables (sps 4, at most four taps per output)
-    std::vector<float> tpb(4 * (size_t)fe->P, 0.0f);
-    for (int br = 0; br < fe->P; br++)
-      for (int k = 0; k < 4; k++) if (br + fe->P * k < L) tpb[4 * br + k] = h_lpf[br + fe->P * k];
-    if (hipMalloc((void **)&fe->d_tpb, sizeof(float4) * (size_t)fe->P) != hipSuccess ||
-        hipMemcpy(fe->d_tpb, tpb.data(), sizeof(float4) * (size_t)fe->P, hipMemcpyHostToDevice) != hipSuccess ||
+    // only the 65 branches 4 m occur (96 = 4*24, 260 = 4*65); slot n holds branch 4*(24 n mod 65) (trxsig_rxgen.h)
+    std::vector<float> tpb(4 * 65, 0.0f);
+    for (int n = 0; n < 65; n++) {
+      const int br = 4 * ((24 * n) % 65);
+      for (int k = 0; k < 4; k++) if (br + fe->P * k < L) tpb[4 * n + k] = h_lpf[br + fe->P * k];
+    }
+    if (hipMalloc((void **)&fe->d_tpb, sizeof(float4) * 65) != hipSuccess ||
+        hipMemcpy(fe->d_tpb, tpb.data(), sizeof(float4) * 65, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&fe->d_keep, sizeof(short2) * (size_t)fe->n_in * fe->S) != hipSuccess ||
         hipMemset(fe->d_keep, 0, sizeof(short2) * (size_t)fe->n_in * fe->S) != hipSuccess) {
       trxsig_rxfe_destroy(fe);
@@ -214,6 +217,11 @@ int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, i
     gen.raw = reinterpret_cast<const short2 *>(d_iq); gen.raw_stride = (long long)n_chunks * TRXSIG_OUTCHUNK;
     gen.keep = fe->d_keep; gen.tpb = fe->d_tpb; gen.K = n_chunks; gen.swap = fe->swap;
     gen.skipD = fe->skip + (fe->L - 1) / 2 / TRXSIG_OUTRATE;
+    // inOff = (skipD + r)*96/260 reaches the window's end (n_in) at r = rl0 and n_in + 1 at r = rl1
+    const int rl0 = (fe->n_in * fe->P + TRXSIG_OUTRATE - 1) / TRXSIG_OUTRATE - gen.skipD;
+    const int rl1 = ((fe->n_in + 1) * fe->P + TRXSIG_OUTRATE - 1) / TRXSIG_OUTRATE - gen.skipD;
+    gen.w0 = fe->per_chunk - rl0 > 0 ? fe->per_chunk - rl0 : 0;
+    gen.w1 = fe->per_chunk - rl1 > 0 ? fe->per_chunk - rl1 : 0;
     gen.tail = fe->tail; gen.tn0 = fe->tn; gen.nb = nb;
     const int rc = trx_ctx_rx_normal(c, gen, fe->S * nb, tsc, detect_thresh, energy_thresh, d_flags, d_amp, d_toa, d_avgpwr, d_soft,
                                      d_hard, nsoft, soft_stride);

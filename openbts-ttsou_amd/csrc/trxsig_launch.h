@@ -113,8 +113,9 @@ hipError_t trx_launch_burst_index(hipStream_t st, int S, int nb, long long strid
 struct TrxRxGen {
   const short2 *raw; long long raw_stride;                 // this push: stream s at raw + s*raw_stride, K*864 samples each
   const short2 *keep;                                      // [S][1056]: history + last chunk of the previous push (its window)
-  const float4 *tpb;                                       // [260] taps, branch-major: tpb[br] = lpf[br + 260 k], k = 0..3
+  const float4 *tpb;                                       // [65] taps of branch 4*(24 n mod 65) in slot n: lpf[br + 260 k], k = 0..3
   int K, swap, skipD;                                      // chunks in this push; I/Q swap; INHISTORY outputs skipped + (L-1)/2/Q
+  int w0, w1;                                              // the last w0 (w1) outputs of a chunk have tap 0 (tap 1) beyond the window's end
   int tail, tn0, nb;                                       // uncut resampled samples before this push; TN of burst 0; bursts per stream
 };
 hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const TrxRxGen &gen, int B, int tsc,

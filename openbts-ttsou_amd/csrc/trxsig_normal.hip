@@ -14,6 +14,13 @@
 #include "trxsig_demod.h"
 #include "trxsig_rxgen.h"
 
+#ifndef TRX_RXC_WPS
+#define TRX_RXC_WPS 1
+#endif
+#ifndef TRX_RXD_WPS
+#define TRX_RXD_WPS 1
+#endif
+
 namespace {
 
 template <int SPS, unsigned TAPCLS>
@@ -390,14 +397,14 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
 // produces the samples it would have loaded -- four multiply-adds each -- and the kernel carries on unchanged.
 // ---------------------------------------------------------------------------------------------
 template <int SPS, unsigned TAPCLS>
-__global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr_rx(TrxRxGen a, int B, TapArg taps, cx *__restrict__ rec, int Bpad) {
+__global__ __launch_bounds__(256, TRX_RXC_WPS) void k_tsc_corr_rx(TrxRxGen a, int B, TapArg taps, cx *__restrict__ rec, int Bpad) {
   static_assert(SPS == 4, "the fused front end is the 260 : 96 resampler");
   typedef CorrGeom<SPS> G;
   constexpr int XCAP = 160;                                // raw samples behind resampled samples [0, 92*SPS) of a burst: <= 140
   static_assert(G::WPAD >= XCAP, "the raw stretch is parked in the burst's own row");
   __shared__ __attribute__((aligned(16))) cx rows[16][G::WPAD];
-  __shared__ float4 tpb_s[RXG_P];
-  for (int i = threadIdx.x; i < RXG_P; i += 256) tpb_s[i] = a.tpb[i];
+  __shared__ float4 tpb_s[RXG_NT];
+  if (threadIdx.x < RXG_NT) tpb_s[threadIdx.x] = a.tpb[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane >> 4, r = lane & 15;
@@ -412,22 +419,30 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr_rx(TrxRxGen a, i
   const int jlo = rx_index(u.g0, a.skipD).j0 - 3;
   cx *X = rows[slot];
   {
-    cx v[XCAP / 16];
+    short2 v[XCAP / 16];
 #pragma unroll
-    for (int i = 0; i < XCAP / 16; i++) v[i] = in.live ? rx_raw(a, u.s, jlo + r + 16 * i) : mk(0, 0);
+    for (int i = 0; i < XCAP / 16; i++) v[i] = rx_raw(a, u.s, jlo + r + 16 * i);   // (a dead row reads burst 0's stretch)
 #pragma unroll
-    for (int i = 0; i < XCAP / 16; i++) X[r + 16 * i] = v[i];
+    for (int i = 0; i < XCAP / 16; i++) X[r + 16 * i] = rx_widen(a, v[i]);
   }
   wave_lds_fence();
+  {
+    static_assert(G::NL % 16 == 0 && G::NE % 16 == 0, "every lane owns a sample in every round");
+    const int nb = rx_boundary(u.g0);                      // samples from the burst's start to the next chunk boundary
+    RxIdx ix = rx_index(u.g0 + 56 * SPS + r, a.skipD);     // window sample q = r + 16 i
 #pragma unroll
-  for (int i = 0; i < CorrIn<SPS>::NW; i++) {
-    const int q = r + 16 * i;
-    in.w[i] = (in.good && q < G::NL) ? rx_sample(X, tpb_s, jlo, rx_index(u.g0 + 56 * SPS + q, a.skipD)) : mk(0, 0);
-  }
+    for (int i = 0; i < CorrIn<SPS>::NW; i++) {
+      in.w[i] = rx_sample(X, tpb_s, jlo, ix, nb - (56 * SPS + r + 16 * i), a.w0, a.w1);
+      ix = rx_step<16>(ix);
+      if (i % 3 == 2) asm volatile("" ::: "memory");            // (keeps hipcc from hoisting every sample's LDS reads: 141 VGPRs)
+    }
+    ix = rx_index(u.g0 + r, a.skipD);                      // energy-window sample i = r + 16 q
 #pragma unroll
-  for (int q = 0; q < G::NEQ; q++) {
-    const int i = r + 16 * q;
-    in.e[q] = (in.good && i < G::NE) ? rx_sample(X, tpb_s, jlo, rx_index(u.g0 + i, a.skipD)) : mk(0, 0);
+    for (int q = 0; q < G::NEQ; q++) {
+      in.e[q] = rx_sample(X, tpb_s, jlo, ix, nb - (r + 16 * q), a.w0, a.w1);
+      ix = rx_step<16>(ix);
+      if (q % 3 == 2) asm volatile("" ::: "memory");
+    }
   }
   wave_lds_fence();                                        // the raw stretch is dead: the row becomes corr_round's
   int M;
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr_rx(TrxRxGen a, i
 }
 
 template <int SPS>
-__global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B,
+__global__ __launch_bounds__(64 * TRX_DEMOD_WAVES, TRX_RXD_WPS) void k_demod_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B,
                                                                   const cx *__restrict__ amp_in, const float *__restrict__ toa_in,
                                                                   const uint8_t *__restrict__ flags, int need_mask,
                                                                   float *__restrict__ soft, uint8_t *__restrict__ hard, int nsoft,
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod_rx(const TrxTabl
   constexpr int XCAP = 256;                                // raw samples behind one burst: <= 236
   static_assert(G::U >= XCAP, "the raw stretch is parked in the burst's staging area");
   __shared__ cx ph[TRX_DEMOD_WAVES][G::U];
-  __shared__ float4 tpb_s[RXG_P];
-  for (int i = threadIdx.x; i < RXG_P; i += 64 * TRX_DEMOD_WAVES) tpb_s[i] = a.tpb[i];
+  __shared__ float4 tpb_s[RXG_NT];
+  if (threadIdx.x < RXG_NT) tpb_s[threadIdx.x] = a.tpb[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -467,26 +482,45 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod_rx(const TrxTabl
   const int jlo = rx_index(u.g0, a.skipD).j0 - 3;
   cx *X = ph[wave];
   {
-    cx v[XCAP / 64];
+    short2 v[XCAP / 64];
 #pragma unroll
     for (int i = 0; i < XCAP / 64; i++) v[i] = rx_raw(a, u.s, jlo + lane + 64 * i);
 #pragma unroll
-    for (int i = 0; i < XCAP / 64; i++) X[lane + 64 * i] = v[i];
+    for (int i = 0; i < XCAP / 64; i++) X[lane + 64 * i] = rx_widen(a, v[i]);
   }
   wave_lds_fence();
-  constexpr int NLD = (157 * SPS / 2 + 63) / 64;           // sample pairs per lane, as k_demod loads them
-  float4 v[NLD];
+  // sample n = lane + 64 i of the burst (consecutive lanes = consecutive samples: consecutive tap slots, neighbouring raw samples)
+  constexpr int NSL = (157 * SPS + 63) / 64;
+  cx sv[NSL];
+  {
+    const int nb = rx_boundary(u.g0);
+    RxIdx ix = rx_index(u.g0 + lane, a.skipD);
 #pragma unroll
-  for (int i = 0; i < NLD; i++) {
-    const int q = lane + 64 * i;
-    v[i] = make_float4(0, 0, 0, 0);
-    if (2 * q < u.N) {
-      const cx s0 = rx_sample(X, tpb_s, jlo, rx_index(u.g0 + 2 * q, a.skipD));
-      const cx s1 = rx_sample(X, tpb_s, jlo, rx_index(u.g0 + 2 * q + 1, a.skipD));
-      v[i] = make_float4(s0.r, s0.i, s1.r, s1.i);
+    for (int i = 0; i < NSL; i++) {
+      // (samples past the burst's end -- last round only -- read staged or stale LDS inside this wave's area and are not staged)
+      sv[i] = rx_sample(X, tpb_s, jlo, ix, nb - (lane + 64 * i), a.w0, a.w1);
+      ix = rx_step<64>(ix);
+      if (i % 3 == 2) asm volatile("" ::: "memory");            // (keeps hipcc from hoisting every sample's LDS reads: 152 VGPRs)
     }
   }
-  fused_demod<SPS, 64>(T, ph[wave], v, u.N, amp, toa, lane, sb, hb, nsoft, [] {}, nullptr, nullptr);   // (starts with an LDS fence)
+  const int N = u.N;
+  auto stage = [&](cx *P, cx inv, int lo) {                // scaleVector (:713-723) into the polyphase staging area
+    typedef DemodGeom<SPS, 148> D;
+    const int u0 = lane + lo;                              // sample n = lane + 64 i sits at position u0 + 64 i: same phase, 16 entries on
+    if (u0 >= 0) {
+      cx *p0 = P + (u0 % SPS) * D::QLEN + u0 / SPS;
+#pragma unroll
+      for (int i = 0; i < NSL; i++)
+        if (lane + 64 * i < N && u0 + 64 * i < D::U) p0[i * (64 / SPS)] = cmul(sv[i], inv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSL; i++) {
+        const int uu = u0 + 64 * i;
+        if (lane + 64 * i < N && uu >= 0 && uu < D::U) P[(uu % SPS) * D::QLEN + uu / SPS] = cmul(sv[i], inv);
+      }
+    }
+  };
+  fused_demod_ex<SPS, 64>(T, ph[wave], N, amp, toa, lane, sb, hb, nsoft, stage, [] {}, nullptr, nullptr);   // (starts with an LDS fence)
 }
 
 }  // namespace

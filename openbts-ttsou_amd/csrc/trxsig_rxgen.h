@@ -28,37 +28,73 @@ __device__ __forceinline__ RxBurst rx_burst(const TrxRxGen &a, int b) {
   return u;
 }
 
-struct RxIdx { int j0, br, io; };                          // raw index of tap 0, branch, window-relative index of tap 0
+// Where resampled sample g comes from: j0 = raw index of tap 0's sample, br = branch, n = the branch's slot in the tap table.
+// 2340 outputs advance the walk by exactly 864 inputs (2340*96 = 864*260), so j0 and br run on across chunk boundaries and
+// a fixed step of d samples is a fixed (d*96 % 260, d*96 / 260) step with a carry.
+// Tap table: 96 = 4*24 and 260 = 4*65, so only the 65 branches 4 m ever occur and consecutive outputs visit m, m + 24,
+// m + 48, ... (mod 65).  The table is stored in THAT order -- slot n holds branch 4*(24 n mod 65), i.e. n = 19 m mod 65 --
+// so that consecutive outputs (consecutive lanes) read consecutive 16-byte slots: conflict-free, where indexing by branch
+// put every lane of a wave on the same four LDS banks (96*4 dwords = 0 mod 64).
+constexpr int RXG_NT = 65;
+struct RxIdx { int j0, br, n; };
 __device__ __forceinline__ RxIdx rx_index(int g, int skipD) {
   const unsigned u = (unsigned)(g + RXG_PC);               // g >= -2340
   const unsigned cq = u / RXG_PC, r = u - cq * RXG_PC;
   const unsigned oq = ((unsigned)skipD + r) * RXG_Q;
+  const unsigned io = oq / RXG_P;
   RxIdx x;
-  x.io = (int)(oq / RXG_P);
-  x.br = (int)(oq - (unsigned)x.io * RXG_P);
-  x.j0 = RXG_CH * ((int)cq - 1) - RXG_HIST + x.io;
+  x.br = (int)(oq - io * RXG_P);
+  x.j0 = RXG_CH * ((int)cq - 1) - RXG_HIST + (int)io;
+  x.n = (int)((19u * ((unsigned)x.br >> 2)) % RXG_NT);
   return x;
 }
+template <int D>                                           // D samples further on, 0 < D < 2340
+__device__ __forceinline__ RxIdx rx_step(RxIdx x) {
+  constexpr int DB = (D * RXG_Q) % RXG_P, DI = (D * RXG_Q) / RXG_P, DN = D % RXG_NT;
+  x.br += DB;
+  const bool carry = x.br >= RXG_P;
+  x.br -= carry ? RXG_P : 0;
+  x.j0 += DI + (carry ? 1 : 0);
+  x.n += DN;
+  x.n -= x.n >= RXG_NT ? RXG_NT : 0;
+  return x;
+}
+// The end-of-window rule (:1183-1186: a tap whose sample lies at or beyond the window's end is skipped) only concerns the
+// last few outputs of a chunk: tap 0 for the w0 = 2340 - rl0 outputs before a chunk boundary, tap 1 for the last w1.  A
+// burst holds at most one boundary; rx_boundary = how many samples after g0 it comes (1..2340).
+__device__ __forceinline__ int rx_boundary(int g0) {
+  const unsigned u = (unsigned)(g0 + RXG_PC);
+  return RXG_PC - (int)(u % RXG_PC);
+}
 
-// raw sample j of stream s as the float pair unUSRPifyVector makes of it (radioInterface.cpp:91-116)
-__device__ __forceinline__ cx rx_raw(const TrxRxGen &a, int s, int j) {
-  short2 v = make_short2(0, 0);
-  if (j < 0) v = a.keep[(size_t)s * RXG_NIN + (RXG_NIN + j)];
-  else if (j < a.K * RXG_CH) v = a.raw[(size_t)s * a.raw_stride + j];
+// raw sample j of stream s (j >= -1056): one unconditional load -- the previous push's kept window for j < 0, this push
+// otherwise; an index past the push's last sample is clamped (such a sample only ever meets a tap the end-of-window rule
+// has zeroed, and it is a finite int16 value either way).  rx_widen: the float pair unUSRPifyVector makes of it
+// (radioInterface.cpp:91-116), applied once all of a wave's loads are in flight.
+__device__ __forceinline__ short2 rx_raw(const TrxRxGen &a, int s, int j) {
+  const int top = a.K * RXG_CH - 1;
+  const int jc = j > top ? top : j;
+  const short2 *p = jc < 0 ? a.keep + ((size_t)s * RXG_NIN + (RXG_NIN + jc)) : a.raw + ((size_t)s * a.raw_stride + jc);
+  return *p;
+}
+__device__ __forceinline__ cx rx_widen(const TrxRxGen &a, short2 v) {
   return a.swap ? mk((float)v.y, (float)v.x) : mk((float)v.x, (float)v.y);
 }
 
-// X[t] = raw sample jlo + t (LDS, staged by the caller), TPB = the branch-major taps (LDS)
-__device__ __forceinline__ cx rx_sample(const cx *X, const float4 *TPB, int jlo, RxIdx ix) {
-  const int t = ix.j0 - jlo;
-  const float4 tp = TPB[ix.br];
-  const cx z = mk(0, 0);
-  const cx x0 = ix.io < RXG_NIN ? X[t] : z, x1 = ix.io - 1 < RXG_NIN ? X[t - 1] : z, x2 = X[t - 2], x3 = X[t - 3];
+// X[t] = raw sample jlo + t (LDS, staged by the caller), TPB = the tap table (LDS, slot order); d = samples from this one to
+// the next chunk boundary.  The reference skips a tap whose sample lies at or beyond the window's end; here that tap is made
+// zero instead, the product is +-0, and since the sum starts at +0 and +0 + (+-0) = +0 the running sum is the reference's
+// bit for bit (the sample read in its place is a finite int16 value).  No branch, no conditional load.
+__device__ __forceinline__ cx rx_sample(const cx *X, const float4 *TPB, int jlo, RxIdx ix, int d, int w0, int w1) {
+  const cx *x = X + (ix.j0 - jlo);
+  float4 tp = TPB[ix.n];
+  tp.x = (unsigned)(d - 1) < (unsigned)w0 ? 0.0f : tp.x;
+  tp.y = (unsigned)(d - 1) < (unsigned)w1 ? 0.0f : tp.y;
   cx sum = mk(0, 0);
-  sum = cadd(sum, cmulr(x0, tp.x));
-  sum = cadd(sum, cmulr(x1, tp.y));
-  sum = cadd(sum, cmulr(x2, tp.z));
-  sum = cadd(sum, cmulr(x3, tp.w));
+  sum = cadd(sum, cmulr(x[0], tp.x));
+  sum = cadd(sum, cmulr(x[-1], tp.y));
+  sum = cadd(sum, cmulr(x[-2], tp.z));
+  sum = cadd(sum, cmulr(x[-3], tp.w));
   return sum;
 }
 
