@@ -434,14 +434,14 @@ __global__ __launch_bounds__(256, TRX_RXC_WPS) void k_tsc_corr_rx(TrxRxGen a, in
     for (int i = 0; i < CorrIn<SPS>::NW; i++) {
       in.w[i] = rx_sample(X, tpb_s, jlo, ix, nb - (56 * SPS + r + 16 * i), a.w0, a.w1);
       ix = rx_step<16>(ix);
-      if (i % 3 == 2) asm volatile("" ::: "memory");            // (keeps hipcc from hoisting every sample's LDS reads: 141 VGPRs)
+      if (i % 3 == 2) asm volatile("" : "+v"(in.w[i].r), "+v"(in.w[i].i), "+v"(in.w[i - 1].r), "+v"(in.w[i - 1].i), "+v"(in.w[i - 2].r), "+v"(in.w[i - 2].i) : : "memory");   // (see k_demod_rx)
     }
     ix = rx_index(u.g0 + r, a.skipD);                      // energy-window sample i = r + 16 q
 #pragma unroll
     for (int q = 0; q < G::NEQ; q++) {
       in.e[q] = rx_sample(X, tpb_s, jlo, ix, nb - (r + 16 * q), a.w0, a.w1);
       ix = rx_step<16>(ix);
-      if (q % 3 == 2) asm volatile("" ::: "memory");
+      if (q % 3 == 2) asm volatile("" : "+v"(in.e[q].r), "+v"(in.e[q].i), "+v"(in.e[q - 1].r), "+v"(in.e[q - 1].i), "+v"(in.e[q - 2].r), "+v"(in.e[q - 2].i) : : "memory");
     }
   }
   wave_lds_fence();                                        // the raw stretch is dead: the row becomes corr_round's
@@ -500,7 +500,8 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES, TRX_RXD_WPS) void k_demod_rx(
       // (samples past the burst's end -- last round only -- read staged or stale LDS inside this wave's area and are not staged)
       sv[i] = rx_sample(X, tpb_s, jlo, ix, nb - (lane + 64 * i), a.w0, a.w1);
       ix = rx_step<64>(ix);
-      if (i % 3 == 2) asm volatile("" ::: "memory");            // (keeps hipcc from hoisting every sample's LDS reads: 152 VGPRs)
+      // (pins the sample before the next ones' LDS reads are issued: hipcc otherwise issues all thirty reads first -- 152 VGPRs)
+      if (i % 2 == 1) asm volatile("" : "+v"(sv[i].r), "+v"(sv[i].i), "+v"(sv[i - 1].r), "+v"(sv[i - 1].i) : : "memory");
     }
   }
   const int N = u.N;
