@@ -210,9 +210,13 @@ class Config4:
         self.alg_bytes = 4 * 625 * 96 // (65 * self.sps) + 4 * NSOFT + 16   # int16 in, soft bits out
         self.kernel_alg = {"k_resample": None}               # per stream-chunk, see roofline()
         self.kernel_names = {"k_tsc_peak": "k_tsc_peak2", "k_resample": "k_rx_resample"}
-        self.fused = bool(getattr(args, "fused_frontend", False))   # the detectors compute their samples from the int16 chunks
+        # default: trxsig_rxfe_push_detect_demod_normal (the detectors compute their samples from the int16 chunks, no resampled
+        # stream in HBM); --unfused-frontend: push + pop + trxsig_detect_demod_normal_batch through the complex float32 stream
+        self.fused = not bool(getattr(args, "unfused_frontend", False))
         if self.fused:
             self.kernel_names.update({"k_demod": "k_demod_rx", "k_tsc_corr": "k_tsc_corr_rx"})
+            # per burst: the raw stretch behind the burst (236 int16 pairs) / behind its two windows (140) read, soft bits / record written
+            self.kernel_alg.update({"k_demod": 4 * 236 + 13 + 4 * NSOFT, "k_tsc_corr": 4 * 140 + 8 * 44, "k_tsc_peak": 8 * 44 + 13 + 4})
 
     def setup(self, pkg, ctx, dev, rank, args):
         import numpy as np
@@ -282,7 +286,8 @@ class Config4:
     def describe(self, world):
         return {"workload": "config4: %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), unUSRPify + "
                             "polyphase resample 260:96 (961-tap Kaiser LPF) + 157/156/156/156 slicing + TSC %d detect (thr 3.0) + demod to "
-                            "%d soft bits" % (self.S, self.K, self.tsc, NSOFT),
+                            "%d soft bits; %s" % (self.S, self.K, self.tsc, NSOFT, "one fused call, the resampled stream never written to HBM"
+                                                  if self.fused else "through the resampled complex float32 stream (push + pop + detect)"),
                 "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                 "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
 
@@ -329,6 +334,17 @@ class Config4:
             xh = xg.cpu().numpy().view(np.complex64).ravel(); o0 = int(og[0].item())
             m = min(pos, int(lg[:nb].sum().item()))
             out["oracle_check_resampled_stream0"] = bool(np.array_equal(xh[o0:o0 + m], x[:m]))
+            # and the fused call's results for the same bursts against the oracle's analyzeTrafficBurst + demodulateBurst
+            torch = self.torch
+            fe2 = RxFrontEnd(self.ctx, self.S, self.lpf, max_chunks=self.K)
+            nb2, _ = fe2.push_detect_demod(self.segs[0], self.tsc, self.flags, self.amp, self.toa, self.soft, detect_thresh=3.0,
+                                           energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
+            torch.cuda.synchronize()
+            k = min(nb2, len(lens))
+            det = ((self.flags[:k] & self.pkg.F_DETECT) != 0).cpu().numpy()
+            same = np.array_equal(det, ok[:k].astype(bool)) and np.array_equal(self.toa[:k].cpu().numpy(), toa[:k]) and \
+                np.array_equal(self.soft[:k].cpu().numpy()[det], soft[:k, :NSOFT][det])
+            out["oracle_check_fused_stream0_first_%d" % k] = bool(same)
         return out
 
 
@@ -409,7 +425,7 @@ def main():
                          "input stays aligned with the front end's burst schedule whatever K is")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
-    ap.add_argument("--fused-frontend", action="store_true", help="config4: trxsig_rxfe_push_detect_demod_normal (no resampled stream in HBM) instead of push + pop + detect")
+    ap.add_argument("--unfused-frontend", action="store_true", help="config4: push + pop + detect through the resampled complex float32 stream instead of trxsig_rxfe_push_detect_demod_normal")
     ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3; config4 = resample + slice + detect "
                          "per ARFCN stream; config5 = 52M equaliser leg, fp16 storage (side measurements)")

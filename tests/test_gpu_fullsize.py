@@ -205,3 +205,75 @@ def test_config4_stream_independence(pkg):
         assert len(one) == len(mine) > 0
         for (tn_a, xa), (_, tn_b, xb) in zip(mine, one):
             assert tn_a == tn_b and torch.equal(xa.view(torch.int32), xb.view(torch.int32))
+
+
+def test_config4_fused_stream_independence_and_equivalence(pkg):
+    """The fused front end (trxsig_rxfe_push_detect_demod_normal) on 128 ARFCN streams x 12 chunks in one call: every burst's
+    flags / amplitude / TOA / soft bits equal (bit for bit) what the unfused chain gives, and what a front end carrying only
+    that stream gives in three calls of four chunks."""
+    import torch
+    from openbts_ttsou_amd import synth
+    from openbts_ttsou_amd.frontend import RxFrontEnd
+    dev = torch.device("cuda:0")
+    S, K, tsc = 128, 12, 2
+    t = pkg.TrxSig(4, 0); t.use_torch_stream()
+    lpf = synth.design_lpf(961, 260)
+    # detectable content: modulated bursts brought to 400 kS/s by linear interpolation (as bench.py's config 4)
+    nb0 = (K * 585 // 156 + 8) // 4 * 4
+    x, off, length, meta = synth.normal_batch_torch(4, S * nb0, tsc, seed=21, device=dev, sigmas=(0.02, 0.05))
+    hi = x.reshape(-1)[: S * (x.numel() // S)].reshape(S, -1)
+    tt = torch.arange(K * 864, device=dev, dtype=torch.float64) * (260.0 / 96.0)
+    i0 = tt.floor().long().clamp(max=hi.shape[1] - 2); fr = (tt - i0).to(torch.float32)
+    lo = hi[:, i0] * (1 - fr) + hi[:, i0 + 1] * fr
+    lo = lo * (8000.0 / lo.abs().amax(dim=1, keepdim=True))
+    iq = torch.stack([lo.imag, lo.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()
+
+    def bufs(n):
+        return dict(flags=torch.zeros(n, dtype=torch.uint8, device=dev), amp=torch.zeros(n, 2, device=dev), toa=torch.zeros(n, device=dev),
+                    soft=torch.full((n, NS), -1.0, device=dev))
+
+    def fused(streams, per_push):
+        fe = RxFrontEnd(t, len(streams), lpf, max_chunks=K)
+        sub = iq[streams].contiguous()
+        per_stream = [[] for _ in streams]
+        for c0 in range(0, K, per_push):
+            o = bufs(len(streams) * (2 + 4 * per_push))
+            nb, tn = fe.push_detect_demod(sub[:, c0 * 864:(c0 + per_push) * 864].contiguous(), tsc, o["flags"], o["amp"], o["toa"], o["soft"],
+                                          nsoft=NS, soft_stride=NS)
+            torch.cuda.synchronize()
+            for si in range(len(streams)):
+                for j in range(nb):
+                    e = si * nb + j
+                    per_stream[si].append((int(tn[j]), int(o["flags"][e]), o["amp"][e].clone(), o["toa"][e].clone(), o["soft"][e].clone()))
+        fe.close()
+        return per_stream
+
+    def unfused(streams):
+        fe = RxFrontEnd(t, len(streams), lpf, max_chunks=K)
+        fe.push_chunk(iq[streams].contiguous())
+        ps, po, pl, tn, nb = fe.pop_raw()
+        o = bufs(len(streams) * nb)
+        t._chk(t.L.trxsig_detect_demod_normal_batch(t.h, ps, po, pl, len(streams) * nb, tsc, 3.0, 0.0, o["flags"].data_ptr(), o["amp"].data_ptr(),
+                                                    o["toa"].data_ptr(), None, o["soft"].data_ptr(), None, NS, NS), "detect_demod")
+        torch.cuda.synchronize()
+        out = [[(int(tn[j]), int(o["flags"][si * nb + j]), o["amp"][si * nb + j].clone(), o["toa"][si * nb + j].clone(),
+                 o["soft"][si * nb + j].clone()) for j in range(nb)] for si in range(len(streams))]
+        fe.close()
+        return out
+
+    def same(a, b):
+        assert len(a) == len(b) > 0
+        for x_, y_ in zip(a, b):
+            assert x_[0] == y_[0] and x_[1] == y_[1]
+            for k in (2, 3, 4):
+                assert torch.equal(x_[k].view(torch.int32), y_[k].view(torch.int32))
+
+    full = fused(list(range(S)), K)
+    ref = unfused(list(range(S)))
+    ndet = 0
+    for s in range(S):
+        same(full[s], ref[s])
+        ndet += sum(1 for e in full[s] if e[1] & pkg.F_DETECT)
+    assert ndet > S * len(full[0]) * 0.9
+    for s in (0, 77, 127):
+        same(full[s], fused([s], 4)[0])
