@@ -49,7 +49,7 @@ int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t
 int trxsig_rxfe_pending(const trxsig_rxfe *fe);   /* samples per stream not yet cut into bursts */
 /* trxsig_rxfe_push + trxsig_rxfe_pop + trxsig_detect_demod_normal_batch in one call, with the resampled stream never written to
  * memory: the detect and demodulate kernels compute the samples of their bursts from the int16 chunks (four multiply-adds
- * each; the unfused chain writes 300 MB of complex float32 per 61 K bursts and reads it back 1.4 times).  Same results bit
+ * each; the unfused chain writes 300 MB of complex float32 per 60 K bursts and reads it back 1.4 times).  Same results bit
  * for bit.  Needs sps == 4, a filter of at most 4*260 taps and nsoft <= 148; a front end is used either through this call or
  * through push / pop, not both.  *n_bursts per stream are completed by this push; burst j of stream s is entry
  * s * *n_bursts + j of every output array (which must hold n_streams * bursts_upper_bound entries, the bound being

@@ -1,6 +1,6 @@
 // trxsig_rxgen.h -- RadioInterface::pullBuffer's resampler (radioInterface.cpp:244-252: polyphaseResampleVector(65*sps : 96)
 // of [192-sample history | 864-sample chunk], first 130*sps outputs dropped) evaluated ON DEMAND inside the burst kernels:
-// a resampled sample is four multiply-adds on raw int16 samples, so the complex float32 stream (300 MB per 61 K bursts,
+// a resampled sample is four multiply-adds on raw int16 samples, so the complex float32 stream (300 MB per 60 K bursts,
 // written once and read back 1.4 times by the unfused chain) never exists in HBM.  sps = 4 only (P = 260, L <= 4 P).
 //
 // Resampled sample g (counted from the first sample this push produces; g < 0 = the previous push's last chunk):

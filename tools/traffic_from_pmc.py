@@ -11,8 +11,9 @@ WANT = [("normal", "k_demod<4", "k_demod", 65536, {}), ("normal", "k_tsc_corr<4"
         ("rach", "k_rach_front<4", "k_rach_front", 65536, {}), ("rach", "k_rach_peak2<4", "k_rach_peak2", 65536, {}),
         ("config5", "k_eq_delay<", "k_eq_delay", 65536, {}), ("config5", "k_eq_detect<", "k_eq_detect", 65536, {}),
         ("config5", "k_eq_dfe2", "k_eq_dfe2", 65536, {}),
-        ("config4", "k_rx_resample", "k_rx_resample", 128 * 125, {"note": "units = stream-chunks (128 streams x 125 chunks per launch)"}),
-        ("config4", "k_rx_resample", "k_resample", 128 * 125, {"kernel": "k_rx_resample", "note": "units = stream-chunks (128 streams x 125 chunks per launch)"})]
+        ("config4", "k_demod_rx<4", "k_demod_rx", 59904, {}), ("config4", "k_tsc_corr_rx<4", "k_tsc_corr_rx", 59904, {}),
+        ("config4_unfused", "k_rx_resample", "k_rx_resample", 128 * 125, {"note": "units = stream-chunks (128 streams x 125 chunks per launch)"}),
+        ("config4_unfused", "k_rx_resample", "k_resample", 128 * 125, {"kernel": "k_rx_resample", "note": "units = stream-chunks (128 streams x 125 chunks per launch)"})]
 
 
 def parse(path):
