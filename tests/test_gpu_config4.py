@@ -211,3 +211,31 @@ def test_fused_front_end_equals_push_pop_detect(golden, lpf_kind):
     o = bufs(S * 8)
     with pytest.raises(pkg.TrxSigError, match="push / pop"):
         fe.push_detect_demod(d_iq[:, OUTCHUNK:2 * OUTCHUNK], tsc, o["flags"], o["amp"], o["toa"], o["soft"])
+
+
+def test_fused_front_end_argument_checks(golden):
+    """The fused call refuses what it cannot do instead of computing something else: a context at one sample per symbol,
+    more than 148 soft bits, more chunks than the object was sized for."""
+    import torch
+    pkg = _pkg.load()
+    from openbts_ttsou_amd import synth
+    from openbts_ttsou_amd.frontend import RxFrontEnd, OUTCHUNK
+    lpf = synth.design_lpf(961, 260)
+    iq = torch.zeros(2, 3 * OUTCHUNK, 2, dtype=torch.int16, device="cuda")
+    n = 2 * 16
+    o = dict(flags=torch.zeros(n, dtype=torch.uint8, device="cuda"), amp=torch.zeros(n, 2, device="cuda"), toa=torch.zeros(n, device="cuda"),
+             soft=torch.zeros(n, 157, device="cuda"))
+    ctx1 = pkg.TrxSig(1, 0); ctx1.use_torch_stream()
+    fe1 = RxFrontEnd(ctx1, 2, synth.design_lpf(961, 65), max_chunks=3)
+    with pytest.raises(pkg.TrxSigError, match="sps == 4"):
+        fe1.push_detect_demod(iq, 0, o["flags"], o["amp"], o["toa"], o["soft"])
+    ctx4 = pkg.TrxSig(4, 0); ctx4.use_torch_stream()
+    fe4 = RxFrontEnd(ctx4, 2, lpf, max_chunks=2)
+    with pytest.raises(pkg.TrxSigError, match="bad argument"):
+        fe4.push_detect_demod(iq, 0, o["flags"], o["amp"], o["toa"], o["soft"])          # 3 chunks > max_chunks
+    with pytest.raises(pkg.TrxSigError, match="bad argument"):
+        fe4.push_detect_demod(iq[:, :OUTCHUNK], 0, o["flags"], o["amp"], o["toa"], o["soft"], nsoft=156, soft_stride=157)
+    # silence in, nothing detected out, and the object keeps working
+    nb, tn = fe4.push_detect_demod(iq[:, :2 * OUTCHUNK], 0, o["flags"], o["amp"], o["toa"], o["soft"], nsoft=148, soft_stride=157)
+    torch.cuda.synchronize()
+    assert nb == 7 and list(tn) == [0, 1, 2, 3, 4, 5, 6] and not (o["flags"][:2 * nb] & pkg.F_DETECT).any()
