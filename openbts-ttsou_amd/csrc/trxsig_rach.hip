@@ -474,14 +474,16 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
                                                 cx *__restrict__ rec, float *__restrict__ vsum, int Bpad) {
   typedef RachGeom<SPS> R;
   typedef RachFast<SPS> Q;
+  // LDS, 8.4 KB per wave (19 waves per CU; the kernel gains from every wave it can get: 366 us at 12 per CU, 415 at 9):
+  //   A   the zero-padded burst X -- then, IN PLACE, its pulse-filtered copy Z for the steering pass -- then X again,
+  //       re-staged from global memory (L2) for the tail corrections and the exact sums.  (X and Z side by side were 13 KB.)
+  //   PWw the approximate powers the valley can read: lags M - 1 + 57 sps .. M + 1 + 107 sps, written once M is known;
+  //   exv[64] exact correlation of the selected lags, exl[64] which lags they are, nb[26] exact neighbourhood
+  //       corr[M-12..M+11] (+2 zero slots).
+  constexpr int PWN = 50 * SPS + 8;                        // 107 sps - 57 sps + 1 terms, three candidate peaks
+  static_assert(Q::ZPAD <= Q::XPAD, "Z is written over X");
   __shared__ __attribute__((aligned(16))) cx xs[1][Q::XPAD];
-  __shared__ __attribute__((aligned(16))) cx zs[1][Q::ZPAD];                             // pulse-filtered burst; later approx powers (float view)
-  // Three small arrays live in the part of zs that the approximate powers (64*NCL floats) leave free; they are first
-  // written after the approximate pass is done with Z (one LDS allocation less: 12 instead of 11 workgroups per CU at sps 4):
-  //   exv[64] exact correlation of the selected lags, exl[64] which lags they are,
-  //   nb[26]  exact neighbourhood corr[M-12..M+11] (+2 zero slots)
-  static_assert(64 * R::NCL + 2 * 64 + 64 + 2 * 26 <= 2 * Q::ZPAD, "exv/exl/nb fit behind the approximate powers");
-
+  __shared__ __attribute__((aligned(16))) float side[PWN + 2 * 64 + 64 + 2 * 26];
   const int lane = threadIdx.x;
   constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
 #ifdef TRX_RACH_PROBE                                      // tools/rach_probe.py: clock64() stamps come back through avgpwr
@@ -510,11 +512,11 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   }
   const cx *x = samples + off;
   cx *X = xs[wave];
-  cx *Z = zs[wave];
-  float *PW = reinterpret_cast<float *>(Z);
-  cx *const exv_ = reinterpret_cast<cx *>(PW + 64 * R::NCL);
-  int *const exl_ = reinterpret_cast<int *>(PW + 64 * R::NCL + 128);
-  cx *const nb_ = reinterpret_cast<cx *>(PW + 64 * R::NCL + 192);
+  cx *Z = xs[wave];                                        // the same storage, at different times
+  float *PWw = side;
+  cx *const exv_ = reinterpret_cast<cx *>(side + PWN);
+  int *const exl_ = reinterpret_cast<int *>(side + PWN + 128);
+  cx *const nb_ = reinterpret_cast<cx *>(side + PWN + 192);
   const cx *rseq = T->rach;
 
   float ex = 0.0f;
@@ -563,7 +565,10 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
 #pragma unroll
   for (int j = 0; j < 2 * SPS + 1; j++) pul[j] = T->pulse[j];
   // two consecutive outputs per lane: Z[2g], Z[2g+1] from X[2g .. 2g+2sps+1] (16-byte LDS reads, each sample read once
-  // per pair instead of once per output); per output the taps are still applied j ascending
+  // per pair instead of once per output); per output the taps are still applied j ascending.
+  // IN PLACE: an iteration's 64 lanes read positions 128 i .. 128 i + 135 and then write 128 i .. 128 i + 127; the LDS
+  // executes a wave's instructions in order, so every lane has its samples before any lane's store lands, and the next
+  // iteration only reads from 128 (i + 1) on -- which this one has not written.
   for (int g = lane; 2 * g < Q::ZPAD; g += 64) {
     cx xv[2 * SPS + 2];
     const float4 *xp4 = reinterpret_cast<const float4 *>(X + 2 * g);
@@ -578,7 +583,9 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       z0r = fma_steer(pul[j], xv[j].r, z0r); z0i = fma_steer(pul[j], xv[j].i, z0i);
       z1r = fma_steer(pul[j], xv[j + 1].r, z1r); z1i = fma_steer(pul[j], xv[j + 1].i, z1i);
     }
+    wave_lds_fence();                                      // (the loads above stay above the store)
     *reinterpret_cast<float4 *>(Z + 2 * g) = make_float4(z0r, z0i, z1r, z1i);
+    wave_lds_fence();
   }
   wave_lds_fence();
   TRX_STAMP();                                             // 2: pulse filter done
@@ -592,6 +599,23 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     cx z0[8];
     rach_steer_load<SPS, R::NCL, 0>(Z + lane, z0);
     rach_steer<SPS, R::NCL, 0>(Z + lane, z0, ar, ai);
+    // ---- the burst again (L2 by now) over its filtered copy: everything below works on X ----
+    wave_lds_fence();                                      // everybody is done reading Z
+    {
+      constexpr int NIT = (Q::XPAD + 63) / 64;
+      cx xv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int n = lane + 64 * it - Q::XF;
+        xv[it] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int i = lane + 64 * it;
+        if (i < Q::XPAD) X[i] = xv[it];
+      }
+    }
+    wave_lds_fence();
 #pragma unroll
     for (int c = 0; c < R::NCL; c++) {
       const int t = lane + 64 * c;
@@ -616,9 +640,6 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
     if (take) { bestP = oP; bestT = oT; }
   }
-  wave_lds_fence();                                        // everybody is done reading Z
-#pragma unroll
-  for (int c = 0; c < R::NCL; c++) PW[lane + 64 * c] = pw[c];   // approximate powers (lags >= N hold -1)
 
   TRX_STAMP();                                             // 3: approximate correlation + argmax done
   // ---- 2. exact recomputation of the contenders ----
@@ -698,6 +719,13 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     if (lag > N - 2 || lag < 0) nb_[lane] = mk(0, 0);
   }
   if (lane >= 24 && lane < 26) nb_[lane] = mk(0, 0);
+  // the approximate powers the valley can touch: lag M - 1 + 57 sps + w at PWw[w] (lags >= N hold -1 and are never read)
+  const int pw0 = M - 1 + 57 * SPS;
+#pragma unroll
+  for (int c = 0; c < R::NCL; c++) {
+    const int w = lane + 64 * c - pw0;
+    if (w >= 0 && w < PWN) PWw[w] = pw[c];
+  }
   wave_lds_fence();
 
   TRX_STAMP();                                             // 4: exact contenders + neighbourhood done
@@ -712,7 +740,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       int last = N - 1 - p;
       if (last > i1) last = i1;
       vs[a] = 0.0f;
-      for (int i = i0 + lane; i <= last; i += 64) vs[a] += PW[p + i];
+      for (int i = i0 + lane; i <= last; i += 64) vs[a] += PWw[p + i - pw0];
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {                     // the three reductions side by side
@@ -744,7 +772,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     const int cnt = last - i0 + 1;                         // numSamples
     if (cnt >= 2) {
       float vs = 0.0f;
-      for (int i = i0 + lane; i <= last; i += 64) vs += PW[p + i];
+      for (int i = i0 + lane; i <= last; i += 64) vs += PWw[p + i - pw0];
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) vs += __shfl_xor(vs, m, 64);
       const float peak_abs = sqrtf(norm2(peak));
