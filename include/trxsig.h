@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define TRXSIG_ABI_VERSION 1
+/* 2: TRXSIG_K_COUNT grew (trxsig_profile_collect writes TRXSIG_K_COUNT entries: a host built against an older header must
+ * not be run against this library -- compare trxsig_abi_version() with TRXSIG_ABI_VERSION at start-up, or use
+ * trxsig_profile_collect_n, which takes the caller's capacity). */
+#define TRXSIG_ABI_VERSION 2
 
 typedef struct trxsig_ctx trxsig_ctx;
 typedef struct { float re, im; } trxsig_c32;
@@ -392,10 +395,15 @@ int trxsig_timer_stop(trxsig_ctx *ctx, float *elapsed_ms);   /* synchronises on 
 enum { TRXSIG_K_TSC_CORR = 0, TRXSIG_K_TSC_PEAK = 1, TRXSIG_K_DEMOD = 2, TRXSIG_K_RACH_CORR = 3,
        TRXSIG_K_RACH_PEAK = 4, TRXSIG_K_MODULATE = 5, TRXSIG_K_RESAMPLE = 6, TRXSIG_K_EQUALIZE = 7,
        TRXSIG_K_CONVERT = 8, TRXSIG_K_NORMAL_FUSED = 9, TRXSIG_K_FEC = 10, TRXSIG_K_NORMAL_CHAIN = 11,
-       TRXSIG_K_EQ_DELAY = 12, TRXSIG_K_EQ_DFE = 13, TRXSIG_K_COUNT = 14 };   /* TRXSIG_K_EQUALIZE = k_eq_detect / k_design_dfe */
+       TRXSIG_K_EQ_DELAY = 12, TRXSIG_K_EQ_DFE = 13, TRXSIG_K_GROUP = 14, TRXSIG_K_COUNT = 15 };
+/* TRXSIG_K_EQUALIZE = k_eq_detect / k_design_dfe; TRXSIG_K_GROUP = the Transceiver group's replay (trxsig_trxgroup.h) */
 const char *trxsig_kernel_name(int kernel_id);
 int trxsig_profile_enable(trxsig_ctx *ctx, int on);
 int trxsig_profile_collect(trxsig_ctx *ctx, float total_ms[TRXSIG_K_COUNT], int launches[TRXSIG_K_COUNT]);
+/* the same for a caller that states how many entries its arrays hold (at most `cap` are written); returns the library's
+ * kernel count, so a caller built against another header version can tell */
+int trxsig_profile_collect_n(trxsig_ctx *ctx, int cap, float *total_ms, int *launches);
+int trxsig_kernel_count(void);
 /* Implementation choice for A/B measurements (tuning build: libtrxsig_tune.so, `make -C csrc tune`); results are bit-identical
  * whatever is selected.
  *   TRXSIG_TUNE_NORMAL_PATH (trxsig_detect_demod_normal_batch; initial value: env TRXSIG_TSC_VARIANT, else 0):

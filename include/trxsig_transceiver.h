@@ -40,6 +40,14 @@ enum { TRXSIG_CHAN_NONE = 0, TRXSIG_CHAN_I, TRXSIG_CHAN_II, TRXSIG_CHAN_III, TRX
 /* Transceiver::Transceiver (:40-92): samples per symbol, start time.  The TSC leg equalises
  * (equalizeBurst "assumes symbol-rate sampling"), so it needs sps == 1; RACH and TX work at any sps. */
 int trxsig_trx_create(trxsig_trx **out, int device, int sps, int start_fn, int start_tn);
+/* How the TSC leg of pullRadioVector ends.  TRXSIG_TSCLEG_EQUALIZE (the default): Transceiver/Transceiver.cpp:313-349,
+ * 391-396 -- per-timeslot channel estimate + designDFE, every detected burst through equalizeBurst (sps == 1).
+ * TRXSIG_TSCLEG_DEMOD: analyzeTrafficBurst + demodulateBurst and no channel cache, which is what
+ * Transceiver52M/Transceiver.cpp:272, 322, 382 does while its mMaxExpectedDelay <= 1 ("needDFE" false); any sps.  The
+ * sigProcLib calls are Transceiver/sigProcLib.cpp's in both (full-window analyzeTrafficBurst, energyDetect over 20*sps
+ * consecutive samples) and so is the slot schedule (expectedCorrType :207-269). */
+enum { TRXSIG_TSCLEG_EQUALIZE = 0, TRXSIG_TSCLEG_DEMOD = 1 };
+int trxsig_trx_set_tsc_leg(trxsig_trx *t, int leg);
 void trxsig_trx_destroy(trxsig_trx *t);
 const char *trxsig_trx_last_error(const trxsig_trx *t);
 trxsig_ctx *trxsig_trx_context(trxsig_trx *t);          /* the underlying library context */

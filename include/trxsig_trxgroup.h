@@ -1,0 +1,93 @@
+/* trxsig_trxgroup.h -- S `Transceiver` objects (one per ARFCN: TRXManager/TRXManager.cpp:44-54 makes one per carrier,
+ * apps/OpenBTS.cpp:66) served by ONE GPU context at batch speed: the receive side of Transceiver/Transceiver.cpp:207-410
+ * (expectedCorrType + pullRadioVector) for n_slots consecutive timeslots x S ARFCNs per call.
+ *
+ * Why it exists: include/trxsig_transceiver.h answers pullRadioVector one burst per call (a PCIe round trip and three to
+ * six tiny launches each: 38-94 us, slower than the reference on one CPU core).  The batch detectors of trxsig.h are
+ * fast but stateless, while pullRadioVector is not: mEnergyThreshold, prevFalseDetectionTime and the per-timeslot
+ * channel / DFE cache carry from burst to burst of an ARFCN (SURVEY 8a' item 14).  The group keeps that state ON THE
+ * DEVICE and replays it there:
+ *
+ *   1. the host classifies every (slot, ARFCN) with expectedCorrType (:207-269) and groups the bursts that reach a
+ *      correlator into rows by class -- training sequence 0..7 (each ARFCN has its own mTSC) and access bursts;
+ *   2. one stateless detector launch per class in use, energy gate off: energyDetect's avgPwr, analyzeTrafficBurst /
+ *      detectRACHBurst's (detected, amplitude, TOA) for every row;
+ *   3. k_group_replay, a lane per ARFCN walking its bursts in time order: energyDetect's decision against the adaptive
+ *      threshold (:298-306), the threshold updates (:303, 338-339, 355-356, 367-375, in the reference's double
+ *      arithmetic; exp() from a table filled by the host's libm), the channel cache's "estimate now?" (:313-325), which
+ *      taps equalise which burst, SNRestimate (:340);
+ *   4. channel estimate + designDFE for the rows the replay marked (:341-349), equalizeBurst with the slot's taps
+ *      (:391-396) or demodulateBurst (:385-388) for every row that comes back as a SoftVector;
+ *   5. the slots' cache entries are refreshed from this call's estimates.
+ *   Everything is enqueued on the context's stream; nothing synchronises until the caller collects.
+ *
+ * Results equal S independent trxsig_trx objects fed the same bursts one by one, and oracle/transceiver_model.py
+ * (tests/test_gpu_trxgroup.py): soft bits, RSSI, timing offset and the threshold after every burst (exact double).
+ * Thread safety: one caller at a time per group (the reference serialises a Transceiver with mLock); the context's
+ * other entry points may be used between calls.
+ */
+#ifndef TRXSIG_TRXGROUP_H
+#define TRXSIG_TRXGROUP_H
+
+#include "trxsig_transceiver.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trxsig_trxgroup trxsig_trxgroup;
+
+/* n_arfcn Transceivers on `ctx` (which the group borrows: destroy the group first).  tsc_leg: TRXSIG_TSCLEG_EQUALIZE
+ * (Transceiver/Transceiver.cpp as written; needs a context with sps == 1) or TRXSIG_TSCLEG_DEMOD (see
+ * trxsig_trx_set_tsc_leg; any sps).  Every ARFCN starts as Transceiver::Transceiver leaves it (:58-92): all slots
+ * NONE, TSC 0, threshold 250.0, prevFalseDetectionTime = channelEstimateTime[] = (start_fn, start_tn). */
+int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *ctx, int n_arfcn, int tsc_leg, int start_fn, int start_tn);
+void trxsig_trxgroup_destroy(trxsig_trxgroup *g);
+int trxsig_trxgroup_arfcns(const trxsig_trxgroup *g);
+
+/* driveControl (:439-580) of ARFCN `arfcn`: as trxsig_trx_control.  SETSLOT / SETTSC take effect at the next pull. */
+int trxsig_trxgroup_control(trxsig_trxgroup *g, int arfcn, const char *command, char *response, int response_cap);
+int trxsig_trxgroup_expected_corr_type(const trxsig_trxgroup *g, int arfcn, int tn, int fn);
+
+/* What one pull leaves behind, device resident, owned by the group, valid until its next pull.  A "row" is a burst that
+ * reached a correlator; rows are grouped by class (TSC 0..7 in turn, then access bursts), in (slot, ARFCN) order inside
+ * a class. */
+typedef struct {
+  int n_slots, n_arfcn, n_rows;
+  const int32_t *d_row;        /* [n_slots][n_arfcn]: the burst's row, -1 where the slot is OFF / IDLE (NULL comes back)  */
+  const uint8_t *d_valid;      /* [n_rows] TRXSIG_F_DETECT where pullRadioVector returns a SoftVector, else 0              */
+  const uint8_t *d_flags;      /* [n_rows] the stateless detector's TRXSIG_F_* (energy gate off)                           */
+  const trxsig_c32 *d_amp;     /* [n_rows] amplitude                                                                        */
+  const float *d_toa;          /* [n_rows] TOA in samples                                                                   */
+  const float *d_avgpwr;       /* [n_rows] energyDetect's avgPwr                                                            */
+  const double *d_threshold;   /* [n_rows] mEnergyThreshold after the burst                                                 */
+  const float *d_soft;         /* [n_rows][soft_stride]: the SoftVector's first 148 values; zeros where d_valid is 0        */
+  int soft_stride;
+} trxsig_trxgroup_result;
+
+/* pullRadioVector for n_slots consecutive timeslots starting at (fn, tn), every ARFCN: the burst of slot t (time
+ * (fn, tn) + t timeslots) and ARFCN a starts at d_samples + t*slot_stride + a*arfcn_stride (complex samples, device)
+ * and has (156 + (TN % 4 == 0)) * sps samples (radioInterface.cpp:370-378), or burst_len samples if burst_len > 0.
+ * Offsets must stay below 2^31 samples.  Asynchronous: d_samples must stay unchanged until the stream has run. */
+int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_t slot_stride, int64_t arfcn_stride,
+                         int burst_len, int fn, int tn, int n_slots, trxsig_trxgroup_result *res);
+
+/* What the caller of pullRadioVector sees, on the host, for the last pull (synchronises the stream): entry t*n_arfcn + a
+ *   h_valid   1 where a SoftVector came back
+ *   h_soft    [n_slots*n_arfcn][148] its soft bits (untouched where h_valid is 0); may be NULL
+ *   h_rssi    (int) floor(20 log10(9450 / |amp|))   (:400)        h_timing  (int) round(TOA * 256 / sps)   (:402)
+ *   h_threshold  mEnergyThreshold after the burst (NaN where no correlator ran); may be NULL */
+int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft, int *h_rssi, int *h_timing, double *h_threshold);
+
+/* trxsig_trxgroup_pull on host samples (copied to a device buffer of the group first; PCIe-inclusive), same layout;
+ * h_samples holds (n_slots-1)*slot_stride + (n_arfcn-1)*arfcn_stride + (burst_len ? burst_len : 157*sps) samples. */
+int trxsig_trxgroup_pull_host(trxsig_trxgroup *g, const trxsig_c32 *h_samples, int64_t slot_stride, int64_t arfcn_stride,
+                              int burst_len, int fn, int tn, int n_slots);
+
+/* mEnergyThreshold of one ARFCN now (synchronises) */
+int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRXSIG_TRXGROUP_H */

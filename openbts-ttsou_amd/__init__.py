@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRXSIG_LIB", os.path.join(_HERE, "libtrxsig.so"))   # TRXSIG_LIB: tuning builds
 
 F_ENERGY, F_DETECT, F_BADLEN = 1, 2, 128
+ABI_VERSION = 2                                  # TRXSIG_ABI_VERSION of include/trxsig.h
 
 
 class TrxSigError(RuntimeError):
@@ -134,6 +135,10 @@ def _load(path):
         L.trxsig_profile_enable.argtypes = [vp, i32]
         L.trxsig_set_tuning.argtypes = [vp, i32, i32]
         L.trxsig_profile_collect.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+        L.trxsig_profile_collect_n.argtypes = [vp, i32, C.POINTER(f32), C.POINTER(i32)]
+        L.trxsig_kernel_count.restype = i32
+        if L.trxsig_abi_version() != ABI_VERSION:
+            raise TrxSigError("%s speaks ABI %d, this binding was written for %d" % (path, L.trxsig_abi_version(), ABI_VERSION))
         L.trxsig_tables_validate_host.argtypes = [vp, C.c_size_t]
         return L
 
@@ -437,9 +442,10 @@ class TrxSig:
 
     def profile_collect(self):
         """{kernel name: (total_ms, launches)} since the last collect (synchronises)."""
-        n = 14                                   # TRXSIG_K_COUNT
+        n = self.L.trxsig_kernel_count()
         ms = (C.c_float * n)(); cnt = (C.c_int * n)()
-        self._chk(self.L.trxsig_profile_collect(self.h, ms, cnt), "trxsig_profile_collect")
+        if self.L.trxsig_profile_collect_n(self.h, n, ms, cnt) < 0:
+            self._chk(-1, "trxsig_profile_collect_n")
         return {self.L.trxsig_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
     def timer_start(self):
@@ -455,7 +461,7 @@ class TrxHost:
     """ctypes view of include/trxsig_transceiver.h: the per-ARFCN Transceiver orchestration (pullRadioVector,
     addRadioVector / pushRadioVector, control commands, UDP datagram codecs) on top of the GPU library."""
 
-    def __init__(self, sps, device=0, start=(0, 0)):
+    def __init__(self, sps, device=0, start=(0, 0), tsc_leg=0):
         import numpy as np
         self.np = np
         self.L = L = lib()
@@ -474,11 +480,14 @@ class TrxHost:
         L.trxsig_trx_filler_modulus.argtypes = [vp, i32]
         L.trxsig_trx_queue_size.argtypes = [vp]
         L.trxsig_create_lpf_host.argtypes = [vp, i32, C.c_float, vp]
+        L.trxsig_trx_set_tsc_leg.argtypes = [vp, i32]
         self.sps = sps
         self.h = vp()
         rc = L.trxsig_trx_create(C.byref(self.h), device, sps, start[0], start[1])
         if rc != 0:
             raise RuntimeError("trxsig_trx_create failed: %d" % rc)
+        if tsc_leg:
+            self._chk(L.trxsig_trx_set_tsc_leg(self.h, tsc_leg), "trxsig_trx_set_tsc_leg")
 
     def close(self):
         if self.h:
@@ -559,3 +568,93 @@ class TrxHost:
         out = np.zeros(len(raw), np.float32)
         self._chk(self.L.trxsig_create_lpf_host(raw.ctypes.data, len(raw), float(gain), out.ctypes.data), "create_lpf")
         return out
+
+
+TSCLEG_EQUALIZE, TSCLEG_DEMOD = 0, 1
+
+
+class TrxGroupResult(C.Structure):
+    """trxsig_trxgroup_result"""
+    _fields_ = [("n_slots", C.c_int), ("n_arfcn", C.c_int), ("n_rows", C.c_int), ("d_row", C.c_void_p), ("d_valid", C.c_void_p),
+                ("d_flags", C.c_void_p), ("d_amp", C.c_void_p), ("d_toa", C.c_void_p), ("d_avgpwr", C.c_void_p),
+                ("d_threshold", C.c_void_p), ("d_soft", C.c_void_p), ("soft_stride", C.c_int)]
+
+
+class TrxGroup:
+    """ctypes view of include/trxsig_trxgroup.h: S Transceivers' pullRadioVector per call, state machine on the device."""
+
+    def __init__(self, ctx, n_arfcn, tsc_leg=TSCLEG_EQUALIZE, start=(0, 0)):
+        import numpy as np
+        self.np = np
+        self.ctx = ctx
+        self.L = L = ctx.L
+        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+        L.trxsig_trxgroup_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32, i32]
+        L.trxsig_trxgroup_destroy.argtypes = [vp]; L.trxsig_trxgroup_destroy.restype = None
+        L.trxsig_trxgroup_control.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32]
+        L.trxsig_trxgroup_expected_corr_type.argtypes = [vp, i32, i32, i32]
+        L.trxsig_trxgroup_pull.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, C.POINTER(TrxGroupResult)]
+        L.trxsig_trxgroup_pull_host.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32]
+        L.trxsig_trxgroup_collect.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
+        self.S = n_arfcn
+        self.h = vp()
+        rc = L.trxsig_trxgroup_create(C.byref(self.h), ctx.h, n_arfcn, tsc_leg, start[0], start[1])
+        if rc != 0:
+            raise TrxSigError("trxsig_trxgroup_create failed (%d): %s" % (rc, L.trxsig_last_error(ctx.h).decode()))
+        self.n_slots = 0
+
+    def close(self):
+        if self.h:
+            self.L.trxsig_trxgroup_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise TrxSigError("%s: %d (%s)" % (what, rc, self.L.trxsig_last_error(self.ctx.h).decode()))
+        return rc
+
+    def control(self, arfcn, msg):
+        buf = C.create_string_buffer(128)
+        self._chk(self.L.trxsig_trxgroup_control(self.h, arfcn, msg.encode(), buf, 128), "trxsig_trxgroup_control")
+        return buf.value.decode()
+
+    def expected_corr_type(self, arfcn, tn, fn):
+        return self.L.trxsig_trxgroup_expected_corr_type(self.h, arfcn, tn, fn)
+
+    def pull(self, samples, slot_stride, arfcn_stride, fn, tn, n_slots, burst_len=0):
+        """samples: torch complex64-as-float32 device tensor (or a device address)."""
+        res = TrxGroupResult()
+        self._chk(self.L.trxsig_trxgroup_pull(self.h, _ptr(samples), slot_stride, arfcn_stride, burst_len, fn, tn, n_slots, C.byref(res)),
+                  "trxsig_trxgroup_pull")
+        self.n_slots = n_slots
+        return res
+
+    def pull_host(self, x, slot_stride, arfcn_stride, fn, tn, n_slots, burst_len=0):
+        np = self.np
+        x = np.ascontiguousarray(x, np.complex64)
+        self._chk(self.L.trxsig_trxgroup_pull_host(self.h, x.ctypes.data, slot_stride, arfcn_stride, burst_len, fn, tn, n_slots),
+                  "trxsig_trxgroup_pull_host")
+        self.n_slots = n_slots
+
+    def collect(self, soft=True):
+        """dict of host arrays indexed [slot][arfcn]: valid, soft (x148), rssi, timing, threshold."""
+        np = self.np
+        n = self.n_slots * self.S
+        valid = np.zeros(n, np.uint8); rssi = np.zeros(n, np.int32); timing = np.zeros(n, np.int32); thr = np.zeros(n, np.float64)
+        sb = np.zeros((n, 148), np.float32) if soft else None
+        self._chk(self.L.trxsig_trxgroup_collect(self.h, valid.ctypes.data, sb.ctypes.data if soft else None, rssi.ctypes.data,
+                                                 timing.ctypes.data, thr.ctypes.data), "trxsig_trxgroup_collect")
+        sh = (self.n_slots, self.S)
+        return dict(valid=valid.reshape(sh).astype(bool), soft=None if sb is None else sb.reshape(sh + (148,)), rssi=rssi.reshape(sh),
+                    timing=timing.reshape(sh), threshold=thr.reshape(sh))
+
+    def energy_threshold(self, arfcn):
+        v = C.c_double()
+        self._chk(self.L.trxsig_trxgroup_energy_threshold(self.h, arfcn, C.byref(v)), "trxsig_trxgroup_energy_threshold")
+        return v.value

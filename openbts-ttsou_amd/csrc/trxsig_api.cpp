@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "trxsig.h"
+#include "trxsig_ctx.h"
 #include "trxsig_launch.h"
 #include "trxsig_tablegen.h"
 
@@ -105,8 +106,6 @@ int fail(trxsig_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 // for the other host translation units of the library (trxsig_frontend.cpp)
 int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e) { return fail(c, code, what, e); }
 TrxProfiler *trx_ctx_profiler(trxsig_ctx *c) { return c ? c->prof : nullptr; }
-int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
-                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 namespace {
 
 #define HIPCHK(c, call)                                          \
@@ -605,6 +604,37 @@ int trxsig_equalize_normal_batch_fmt(trxsig_ctx *c, const void *d_samples, int s
   return TRXSIG_OK;
 }
 
+}  // extern "C"
+// the equalising TSC leg of the Transceiver group (trxsig_ctx.h)
+int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B, int tsc,
+                           const uint8_t *d_enable, const float *d_snr, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                           float *d_toa_eq, float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "the channel estimate / DFE path needs sps == 1");
+  if (B <= 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc, 3.0f, -1.0f, 1.0f,
+                                    0, 0, d_flags, (trx_c32 *)d_amp, d_toa, d_toa_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b,
+                                    nullptr, c->prof, d_enable, d_snr));
+  return TRXSIG_OK;
+}
+int trx_ctx_group_equalize(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,
+                           const trxsig_c32 *d_amp, const float *d_toa_eq, const uint8_t *d_gate, const trxsig_c32 *d_w_tab,
+                           const trxsig_c32 *d_b_tab, const int32_t *d_tap_ix, float *d_soft, int nsoft, int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "equalizeBurst needs sps == 1");
+  if (B <= 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_eq(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  trx_c32 *xd = (trx_c32 *)(c->d_eq + (size_t)c->eq_cap * (4 + 56 + 40));
+  HIPCHK(c, trx_launch_equalize_taps(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, (const trx_c32 *)d_amp,
+                                     d_toa_eq, d_gate, (const trx_c32 *)d_w_tab, (const trx_c32 *)d_b_tab, xd, EQ_XS, d_soft, nullptr,
+                                     nsoft, soft_stride, c->prof, d_tap_ix));
+  return TRXSIG_OK;
+}
+extern "C" {
+
 // ---- TX path, rate conversion, sample format ---------------------------------------------------------
 int trxsig_modulate_batch(trxsig_ctx *c, const uint8_t *d_bits, const int32_t *d_guard, const float *d_gain, int B,
                           trxsig_c32 *d_out, const int32_t *d_out_offset) {
@@ -945,7 +975,7 @@ int trxsig_timer_stop(trxsig_ctx *c, float *ms) {
 const char *trxsig_kernel_name(int id) {
   static const char *names[TRXSIG_K_COUNT] = { "k_tsc_corr", "k_tsc_peak", "k_demod", "k_rach_corr", "k_rach_peak",
                                                "k_modulate", "k_resample", "k_eq_detect", "k_convert", "k_normal_fused", "k_fec_viterbi",
-                                               "k_normal_chain", "k_eq_delay", "k_eq_dfe" };
+                                               "k_normal_chain", "k_eq_delay", "k_eq_dfe", "k_group_replay" };
   return (id >= 0 && id < TRXSIG_K_COUNT) ? names[id] : "?";
 }
 int trxsig_fec_xcch_decode_batch(trxsig_ctx *c, const float *d_soft, int soft_stride, int n_blocks, int wire,
@@ -1050,6 +1080,15 @@ int trxsig_profile_collect(trxsig_ctx *c, float total_ms[TRXSIG_K_COUNT], int la
   DeviceGuard g(c->device);
   c->prof->collect(total_ms, launches);
   return TRXSIG_OK;
+}
+int trxsig_kernel_count(void) { return TRXSIG_K_COUNT; }
+int trxsig_profile_collect_n(trxsig_ctx *c, int cap, float *total_ms, int *launches) {
+  if (!c || cap < 0 || (cap > 0 && (!total_ms || !launches))) return TRXSIG_EINVAL;
+  float ms[TRXSIG_K_COUNT]; int n[TRXSIG_K_COUNT];
+  const int rc = trxsig_profile_collect(c, ms, n);
+  if (rc != TRXSIG_OK) return rc;
+  for (int i = 0; i < cap && i < TRXSIG_K_COUNT; i++) { total_ms[i] = ms[i]; launches[i] = n[i]; }
+  return TRXSIG_K_COUNT;
 }
 int trxsig_tables_validate_host(const void *h_blob, size_t bytes) {
   if (!h_blob || bytes != sizeof(TrxTables)) return TRXSIG_EINVAL;

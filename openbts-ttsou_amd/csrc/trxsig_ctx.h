@@ -1,0 +1,22 @@
+// trxsig_ctx.h -- internal: what the other host translation units of the library (trxsig_frontend.cpp, trxsig_trxgroup.cpp)
+// may ask of a context (trxsig_api.cpp owns struct trxsig_ctx).
+#pragma once
+#include "trxsig.h"
+#include "trxsig_launch.h"
+
+int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e);
+TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
+// the normal-burst leg on bursts computed from the raw int16 stream (trxsig_rxfe_push_detect_demod_normal)
+int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
+                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+// Transceiver group (trxsig_trxgroup.cpp), equalising TSC leg (sps = 1):
+//   estimate: analyzeTrafficBurst(requestChannel) + scaleVector(chan, 1/amp) + designDFE(chan, d_snr[b], 7) for the bursts with
+//     d_enable[b] != 0 only (Transceiver.cpp:341-349); nothing is written for the others.  Detection threshold 3.0 (:331).
+//   equalize: scaleVector(burst, 1/amp) + equalizeBurst(burst, d_toa_eq[b], w, b) (:391-396) for the bursts whose d_gate has
+//     TRXSIG_F_DETECT, burst b with the taps at entry d_tap_ix[b] of the tap table.
+int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B, int tsc,
+                           const uint8_t *d_enable, const float *d_snr, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
+                           float *d_toa_eq, float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b);
+int trx_ctx_group_equalize(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,
+                           const trxsig_c32 *d_amp, const float *d_toa_eq, const uint8_t *d_gate, const trxsig_c32 *d_w_tab,
+                           const trxsig_c32 *d_b_tab, const int32_t *d_tap_ix, float *d_soft, int nsoft, int soft_stride);

@@ -227,8 +227,11 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
                                                   cx *__restrict__ amp_out, float *__restrict__ toa_out,
                                                   float *__restrict__ toa_eq, cx *__restrict__ w_out,
                                                   cx *__restrict__ b_out, float snr_thresh, float snr_value,
-                                                  float *__restrict__ chan_off_out, cx *__restrict__ chan_out) {
-  // snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
+                                                  float *__restrict__ chan_off_out, cx *__restrict__ chan_out,
+                                                  const uint8_t *__restrict__ enable, const float *__restrict__ snr_in) {
+  // enable (optional): only bursts with enable[b] != 0 are processed, nothing is written for the others (the Transceiver
+  // group estimates the channel of the few bursts its replay marks, trxsig_group.hip); snr_in (optional): the SNR
+  // estimate per burst.  snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
   // double arithmetic, Transceiver.cpp:340); else snr_thresh >= 0: the threshold that enters
   // SNR = |amp|^2/(thr^2+1); else energy_thresh.  chan_off_out (optional): chanRespOffset (:343).
   // LDS (one wave per workgroup, a column per lane), rows of 64 complex:
@@ -251,7 +254,8 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   float *st_re = reinterpret_cast<float *>(lds_raw), *st_im = st_re + 64 * PITCH;
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
-  const bool live = b < B;
+  const bool live = b < B && (!enable || enable[b < B ? b : 0] != 0);
+  if (enable && !__any(live)) return;                      // (wave-uniform: the workgroup is one wave)
 #ifdef TRX_EQ_PROBE                                        // clock64() stamps come back through toa_out (tools/eq_probe.py)
   long long pt_[8] = {0};
   int pk_ = 0;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 
   // ---- Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7) (:1246-1340) ----
   const float thr = snr_thresh >= 0.0f ? snr_thresh : (energy_thresh < 0.0f ? 0.0f : energy_thresh);
-  const float snr = snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0));
+  const float snr = snr_in ? snr_in[b] : (snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0)));
   const cx ainv = cdiv(mk(1.0f, 0.0f), amp);
 #pragma unroll
   for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
@@ -527,7 +531,8 @@ __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, 
                                                const uint8_t *__restrict__ flags, const float *__restrict__ toa_eq,
                                                const cx *__restrict__ w_in,
                                                const cx *__restrict__ b_in, float *__restrict__ soft,
-                                               uint8_t *__restrict__ hard, int nsoft, int stride) {
+                                               uint8_t *__restrict__ hard, int nsoft, int stride,
+                                               const int32_t *__restrict__ tap_ix) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   float *sb = soft + (size_t)b * stride;
@@ -538,11 +543,12 @@ __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, 
   }
   const int N = length[b];
   const cx *x = xd + (size_t)b * xstride;
+  const size_t tb = tap_ix ? (size_t)tap_ix[b] : (size_t)b;
   cx w[7], bq[5], hist[5], win[7];
 #pragma unroll
-  for (int j = 0; j < 7; j++) w[j] = w_in[(size_t)b * 7 + j];
+  for (int j = 0; j < 7; j++) w[j] = w_in[tb * 7 + j];
 #pragma unroll
-  for (int j = 0; j < 5; j++) { bq[j] = b_in[(size_t)b * 5 + j]; hist[j] = mk(0, 0); }
+  for (int j = 0; j < 5; j++) { bq[j] = b_in[tb * 5 + j]; hist[j] = mk(0, 0); }
   // win[j] = x[k + 6 - j] (zero outside the burst); FULL_SPAN keeps [6, 6+N) (:1352-1356)
 #pragma unroll
   for (int j = 0; j < 7; j++) win[j] = (6 - j < N) ? x[6 - j] : mk(0, 0);
@@ -597,7 +603,10 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
                                                  const uint8_t *__restrict__ flags, const float *__restrict__ toa_eq,
                                                  const cx *__restrict__ w_in,
                                                  const cx *__restrict__ b_in, float *__restrict__ soft,
-                                                 uint8_t *__restrict__ hard, int nsoft, int stride) {
+                                                 uint8_t *__restrict__ hard, int nsoft, int stride,
+                                                 const int32_t *__restrict__ tap_ix) {
+  // tap_ix (optional): burst b is equalised with the taps at w_in + 7 tap_ix[b], b_in + 5 tap_ix[b] (the per-timeslot cache
+  // of Transceiver.cpp:317-349: many bursts share one estimate); NULL = its own taps at index b.
   __shared__ cx xt[64][EQ_TK + 1];                          // the producer's own staging of the delayed burst
   __shared__ cx fft[2][64][EQ_TK + 1];                      // producer -> consumer
   __shared__ float sft[2][64][EQ_TK + 1];                   // consumer -> producer (soft bits on their way out)
@@ -609,6 +618,7 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
   const int N = length[bb];
   const bool det = b < B && eq_enabled(flags[bb], N, toa_eq[bb]);
   const int nout = det ? (nsoft < N ? nsoft : N) : 0;       // symbols this burst really produces (zeros beyond)
+  const size_t tb = (tap_ix && det) ? (size_t)tap_ix[bb] : (tap_ix ? (size_t)0 : (size_t)bb);
   // Barrier u (u = 0..9): ff tile u is ready and soft tile u-1 is complete; barrier 10: soft tile 9 is complete.
   // Both waves execute exactly eleven barriers.
   if (producer) {
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
     const cx *x = xd + (size_t)bb * xstride;
     cx w[7], win[6];
 #pragma unroll
-    for (int j = 0; j < 7; j++) w[j] = w_in[(size_t)bb * 7 + j];
+    for (int j = 0; j < 7; j++) w[j] = w_in[tb * 7 + j];
 #pragma unroll
     for (int m = 0; m < 6; m++) win[m] = (5 - m < N) ? x[5 - m] : mk(0, 0);   // win[m] = x[16 u + 5 - m]
     // sample tile u: a = 16 u + 6 + c, c = 0..15 (output k = 16 u + i needs x[k + 6 - j]: FULL_SPAN keeps [6, 6+N), :1352-1356)
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
   } else {
     cx bq[5], hist[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { bq[j] = b_in[(size_t)bb * 5 + j]; hist[j] = mk(0, 0); }
+    for (int j = 0; j < 5; j++) { bq[j] = b_in[tb * 5 + j]; hist[j] = mk(0, 0); }
     for (int u = 0; u < EQ_NT; u++) {
       __syncthreads();                                      // barrier u
       // the tile's operands up front: feed-forward sums (LDS), rotation factors (uniform -> scalar loads)
@@ -712,12 +722,13 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
 
 // TRXSIG_EQ_DFE_VARIANT=1 (environment, A/B): the lane-per-burst k_eq_dfe instead of the producer/consumer k_eq_dfe2
 void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
-                   const float *toa_eq, const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride) {
+                   const float *toa_eq, const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride,
+                   const int32_t *tap_ix = nullptr) {
   static const bool legacy = std::getenv("TRXSIG_EQ_DFE_VARIANT") && std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) == 1;
   if (legacy)
-    k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
+    k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
   else
-    k_eq_dfe2<<<dim3((B + 63) / 64), dim3(128), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
+    k_eq_dfe2<<<dim3((B + 63) / 64), dim3(128), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
 }
 
 // designDFE on its own (a lane per channel estimate): chan B x 6 (as analyzeTrafficBurst returns it, i.e. before the
@@ -760,7 +771,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
-                   variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr);
+                   variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr, nullptr, nullptr);
   if (prof) { prof->end(TRXSIG_K_EQUALIZE, st); prof->begin(TRXSIG_K_EQ_DELAY, st); }
   EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
@@ -775,11 +786,13 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
 hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
-                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof) {
+                                   float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof,
+                                   const uint8_t *enable, const float *snr_in) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
-                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan);
+                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan,
+                                                        enable, snr_in);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }
@@ -787,12 +800,12 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
 hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                     const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
-                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof, const int32_t *tap_ix) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
   EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
-  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
+  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
   if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
   return hipGetLastError();
 }

@@ -8,14 +8,9 @@
 #include <new>
 #include <vector>
 
+#include "trxsig_ctx.h"
 #include "trxsig_frontend.h"
 #include "trxsig_launch.h"
-
-// context internals (trxsig_api.cpp)
-int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e);
-TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
-int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
-                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
 namespace {
 #define FE_HIP(c, call)                                                        \

@@ -1,0 +1,64 @@
+// trxsig_group.h -- internal: what the host side of the Transceiver group (trxsig_trxgroup.cpp) and its kernels
+// (trxsig_group.hip) share.  The group is S `Transceiver` objects (Transceiver/Transceiver.cpp, one per ARFCN) whose
+// per-burst state machine -- mEnergyThreshold, prevFalseDetectionTime, the per-timeslot channel / DFE cache -- is
+// replayed ON THE DEVICE, a lane per ARFCN in burst order, between the stateless batch detectors and the batch
+// demodulator / equaliser, so that one call serves n_slots x S bursts without a host round trip in the middle.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
+
+#include "trxsig_launch.h"
+
+// Per-ARFCN receive state of class Transceiver (Transceiver.h:95-116), device resident.
+struct TrxGroupArfcn {
+  double thr;                // mEnergyThreshold (Transceiver.cpp:88: 250.0)
+  int32_t prev_false_fn;     // prevFalseDetectionTime.FN() (only the frame number enters Time::operator-, GSMCommon.h:414-417)
+  int32_t pad;
+  int32_t est_fn[8];         // channelEstimateTime[ts].FN()
+  int32_t tap_src[8];        // -1: channelResponse[ts] == NULL; else the entry of the tap table that holds DFEForward[ts],
+                             // DFEFeedback[ts] and chanRespOffset[ts]
+};
+
+// exp(-k) for the integer frame differences Transceiver.cpp:355,374 can form, tabulated on the host with the host's libm
+// (the function the reference calls): entry k + TRXG_EXP_LO, k clipped to [-TRXG_EXP_LO, TRXG_EXP_HI].  exp(710) = +inf
+// and exp(-746) = 0 in double, so the clipped ends are the values of everything beyond them.
+#define TRXG_EXP_LO 710
+#define TRXG_EXP_HI 746
+#define TRXG_EXP_N (TRXG_EXP_LO + TRXG_EXP_HI + 1)
+
+// Row classes: rows (bursts that reach a correlator) are grouped by class, class k = TSC k for k < 8, 8 = RACH.
+#define TRXG_NCLASS 9
+#define TRXG_CLASS_RACH 8
+
+struct TrxGroupExpand {
+  int S, n_slots, tn0, sps, fixed_len, G;                  // G: segment columns per slot
+  long long slot_stride, arfcn_stride, base;               // burst (t, a) starts at sample base + t*slot_stride + a*arfcn_stride
+  const uint16_t *gid;                                     // [8][S]: which segment column ARFCN a belongs to on timeslot tn
+  const int32_t *pos;                                      // [8][S]: its place inside that segment
+  const int32_t *seg_base;                                 // [n_slots][G]: first row of the segment, -1 = no correlator (OFF / IDLE)
+  int32_t *rowmap;                                         // [n_slots][S] -> row or -1
+  int32_t *off, *len;                                      // [rows]
+};
+hipError_t trx_launch_group_expand(hipStream_t st, const TrxGroupExpand &a);
+
+struct TrxGroupReplay {
+  int S, n_slots, fn0, tn0, equalize, n_tsc_rows;          // rows < n_tsc_rows are normal bursts, the rest access bursts
+  const int32_t *rowmap;
+  const uint8_t *flags; const trx_c32 *amp; const float *avgpwr;   // the stateless detectors' answers (energy gate off)
+  const double *exp_tab;
+  TrxGroupArfcn *state;
+  uint8_t *gate;                                           // TRXSIG_F_DETECT where pullRadioVector returns a SoftVector
+  uint8_t *ev;                                             // 1 where the burst's channel is estimated (Transceiver.cpp:341-349)
+  int32_t *tap_ix;                                         // tap-table entry the burst is equalised with
+  float *snr;                                              // SNRestimate[ts] (:340) of an estimating burst
+  double *thr_after;                                       // mEnergyThreshold after the burst
+};
+// packed: scratch of n_slots * S float4 (the detectors' answers in (slot, ARFCN) order)
+hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, float4 *packed, TrxProfiler *prof);
+
+// toa_eq[row] = TOA - chanRespOffset[ts] (Transceiver.cpp:393) for the gated normal-burst rows
+hipError_t trx_launch_group_toa_eq(hipStream_t st, int n_rows, const uint8_t *gate, const float *toa, const int32_t *tap_ix,
+                                   const float *chan_off_tab, float *toa_eq);
+// end of a call: the taps estimated in this batch that are still a slot's current ones move into the slot's cache entry
+hipError_t trx_launch_group_commit(hipStream_t st, int S, TrxGroupArfcn *state, trx_c32 *w_tab, trx_c32 *b_tab, float *chan_off_tab);

@@ -150,14 +150,16 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan /* B x 6 or NULL */,
-                                   TrxProfiler *prof);
+                                   TrxProfiler *prof, const uint8_t *enable = nullptr /* only bursts with enable[b] != 0; nothing
+                                   is written for the others */, const float *snr_in = nullptr /* SNR estimate per burst */);
 // designDFE(chan, snr, 7) alone; amp != NULL: scaleVector(chan, 1/amp) first
 hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
                                  trx_c32 *bq, TrxProfiler *prof);
 hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off,
                                     const int32_t *len, int B, const trx_c32 *amp, const float *toa_eq,
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
-                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
+                                    float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof,
+                                    const int32_t *tap_ix = nullptr /* burst b uses the taps at index tap_ix[b] */);
 
 // XCCH L1 encode: nblk L2 frames (23 octets each) -> 4*nblk bursts of 148 bits (one per byte); tsc_bits: the 26
 // training-sequence bits (device)

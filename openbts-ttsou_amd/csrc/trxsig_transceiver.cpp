@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "trxsig_transceiver.h"
+#include "trxsig_trxstate.h"
 
 namespace {
 
@@ -49,12 +50,8 @@ struct trxsig_trx {
   trxsig_ctx *ctx = nullptr;
   int sps = 1;
   std::string err;
-  // control state (:83-91, 439-580)
-  bool on = false;
-  double txFreq = 0.0, rxFreq = 0.0;
-  int power = -10;
-  unsigned tsc = 0;
-  int chanType[8];
+  TrxControl ctl;                                           // control state (:83-91, 439-580)
+  int tscLeg = TRXSIG_TSCLEG_EQUALIZE;                      // how the TSC leg ends (trxsig_trx_set_tsc_leg)
   // receive state
   double energyThreshold = 250.0;                           // :88
   Time prevFalseDetectionTime;
@@ -63,8 +60,7 @@ struct trxsig_trx {
   float SNRestimate[8];
   Time channelEstimateTime[8];
   trxsig_c32 dfeW[8][7], dfeB[8][5];
-  // transmit state
-  int fillerModulus[8];
+  // transmit state (fillerModulus lives in ctl)
   std::vector<trxsig_c32> fillerTable[102][8];
   std::vector<Queued> queue;                                // earliest time first (VectorQueue)
   // device scratch for the single-burst calls
@@ -90,18 +86,29 @@ int fail(trxsig_trx *t, int code, const std::string &what) {
     if (rc_ != TRXSIG_OK) return fail(t, rc_, std::string(#call) + ": " + trxsig_last_error((t)->ctx)); \
   } while (0)
 
-void set_modulus(trxsig_trx *t, int ts) {                   // setModulus (:183-204)
-  switch (t->chanType[ts]) {
-    case TRXSIG_CHAN_NONE: case TRXSIG_CHAN_I: case TRXSIG_CHAN_II: case TRXSIG_CHAN_III: t->fillerModulus[ts] = 26; break;
-    case TRXSIG_CHAN_IV: case TRXSIG_CHAN_VI: case TRXSIG_CHAN_V: t->fillerModulus[ts] = 51; break;
-    case TRXSIG_CHAN_VII: t->fillerModulus[ts] = 102; break;
+// modulateBurst(bits, pulse, 8 + (TN % 4 == 0), sps) [+ scaleVector(gain)] on the GPU
+int modulate(trxsig_trx *t, const uint8_t *bits, int tn, const float *gain, std::vector<trxsig_c32> &out) {
+  const int32_t guard = 8 + ((tn % 4) == 0), off = 0;
+  out.assign((size_t)t->sps * (148 + guard), trxsig_c32{0.0f, 0.0f});
+  TRX_LIB(t, trxsig_modulate_host(t->ctx, bits, &guard, gain, 1, out.data(), &off, (int64_t)out.size()));
+  return TRXSIG_OK;
+}
+
+}  // namespace
+
+// ---- TrxControl (trxsig_trxstate.h) ----
+void TrxControl::setModulus(int ts) {                       // setModulus (:183-204)
+  switch (chanType[ts]) {
+    case TRXSIG_CHAN_NONE: case TRXSIG_CHAN_I: case TRXSIG_CHAN_II: case TRXSIG_CHAN_III: fillerModulus[ts] = 26; break;
+    case TRXSIG_CHAN_IV: case TRXSIG_CHAN_VI: case TRXSIG_CHAN_V: fillerModulus[ts] = 51; break;
+    case TRXSIG_CHAN_VII: fillerModulus[ts] = 102; break;
     default: break;
   }
 }
 
-int expected_corr_type(const trxsig_trx *t, int tn, int fn) {       // :207-269
+int TrxControl::corrType(int chanType, int fn) {            // expectedCorrType (:207-269)
   const unsigned burstFN = (unsigned)fn;
-  switch (t->chanType[tn & 7]) {
+  switch (chanType) {
     case TRXSIG_CHAN_NONE: return TRXSIG_CORR_OFF;
     case TRXSIG_CHAN_I: return TRXSIG_CORR_TSC;
     case TRXSIG_CHAN_II: return (burstFN % 2 == 1) ? TRXSIG_CORR_IDLE : TRXSIG_CORR_TSC;
@@ -123,16 +130,57 @@ int expected_corr_type(const trxsig_trx *t, int tn, int fn) {       // :207-269
     default: return TRXSIG_CORR_OFF;
   }
 }
+int TrxControl::expectedCorrType(int tn, int fn) const { return corrType(chanType[tn & 7], fn); }
 
-// modulateBurst(bits, pulse, 8 + (TN % 4 == 0), sps) [+ scaleVector(gain)] on the GPU
-int modulate(trxsig_trx *t, const uint8_t *bits, int tn, const float *gain, std::vector<trxsig_c32> &out) {
-  const int32_t guard = 8 + ((tn % 4) == 0), off = 0;
-  out.assign((size_t)t->sps * (148 + guard), trxsig_c32{0.0f, 0.0f});
-  TRX_LIB(t, trxsig_modulate_host(t->ctx, bits, &guard, gain, 1, out.data(), &off, (int64_t)out.size()));
-  return TRXSIG_OK;
+int TrxControl::command(const char *buffer, char *response) {   // driveControl (:439-580)
+  char cmdcheck[4] = {0}, command[100] = {0};
+  response[0] = 0;
+  std::sscanf(buffer, "%3s %99s", cmdcheck, command);
+  if (std::strcmp(cmdcheck, "CMD") != 0) return 0;            // "bogus message": no response (:466-470)
+  if (std::strcmp(command, "POWEROFF") == 0) {
+    std::sprintf(response, "RSP POWEROFF 0");
+  } else if (std::strcmp(command, "POWERON") == 0) {
+    if (!txFreq || !rxFreq) std::sprintf(response, "RSP POWERON 1");
+    else {
+      std::sprintf(response, "RSP POWERON 0");
+      if (!on) { power = -20; on = true; }
+    }
+  } else if (std::strcmp(command, "SETPOWER") == 0) {
+    int dbPwr = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbPwr);
+    if (!on) std::sprintf(response, "RSP SETPOWER 1 %d", dbPwr);
+    else { power = dbPwr; std::sprintf(response, "RSP SETPOWER 0 %d", dbPwr); }
+  } else if (std::strcmp(command, "ADJPOWER") == 0) {
+    int dbStep = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbStep);
+    if (!on) std::sprintf(response, "RSP ADJPOWER 1 %d", power);
+    else { power += dbStep; std::sprintf(response, "RSP ADJPOWER 0 %d", power); }
+  } else if (std::strcmp(command, "RXTUNE") == 0) {
+    int freqKhz = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
+    if (on) std::sprintf(response, "RSP RXTUNE 1 %d", freqKhz);
+    else { rxFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP RXTUNE 0 %d", freqKhz); }
+  } else if (std::strcmp(command, "TXTUNE") == 0) {
+    int freqKhz = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
+    if (on) std::sprintf(response, "RSP TXTUNE 1 %d", freqKhz);
+    else { txFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP TXTUNE 0 %d", freqKhz); }
+  } else if (std::strcmp(command, "SETTSC") == 0) {
+    int TSC = 0;
+    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &TSC);
+    if (on || TSC < 0 || TSC > 7) std::sprintf(response, "RSP SETTSC 1 %d", TSC);   // (the reference does not range-check)
+    else { tsc = (unsigned)TSC; epoch++; std::sprintf(response, "RSP SETTSC 0 %d", TSC); }
+  } else if (std::strcmp(command, "SETSLOT") == 0) {
+    int corrCode = 0, timeslot = 0;
+    std::sscanf(buffer, "%3s %99s %d %d", cmdcheck, command, &timeslot, &corrCode);
+    if (timeslot < 0 || timeslot > 7) return 0;               // returns without responding (:556-561)
+    chanType[timeslot] = corrCode;
+    setModulus(timeslot);
+    epoch++;
+    std::sprintf(response, "RSP SETSLOT 0 %d %d", timeslot, corrCode);
+  }                                                          // unknown command: empty response buffer is sent (:571-575)
+  return 1;
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -151,9 +199,9 @@ int trxsig_trx_create(trxsig_trx **out, int device, int sps, int start_fn, int s
     std::vector<trxsig_c32> mod;
     rc = modulate(t, dummy, i, nullptr, mod);
     if (rc != TRXSIG_OK) { trxsig_destroy(t->ctx); delete t; return rc; }
-    t->fillerModulus[i] = 26;
+    t->ctl.fillerModulus[i] = 26;
     for (int j = 0; j < 102; j++) t->fillerTable[j][i] = mod;
-    t->chanType[i] = TRXSIG_CHAN_NONE;
+    t->ctl.chanType[i] = TRXSIG_CHAN_NONE;
     t->haveChan[i] = false;
     t->chanRespOffset[i] = 0.0f;
     t->SNRestimate[i] = 0.0f;
@@ -180,63 +228,27 @@ void trxsig_trx_destroy(trxsig_trx *t) {
 const char *trxsig_trx_last_error(const trxsig_trx *t) { return t ? t->err.c_str() : "null transceiver"; }
 trxsig_ctx *trxsig_trx_context(trxsig_trx *t) { return t ? t->ctx : nullptr; }
 double trxsig_trx_energy_threshold(const trxsig_trx *t) { return t ? t->energyThreshold : 0.0; }
-int trxsig_trx_filler_modulus(const trxsig_trx *t, int tn) { return (t && tn >= 0 && tn < 8) ? t->fillerModulus[tn] : -1; }
+int trxsig_trx_filler_modulus(const trxsig_trx *t, int tn) { return (t && tn >= 0 && tn < 8) ? t->ctl.fillerModulus[tn] : -1; }
 int trxsig_trx_queue_size(const trxsig_trx *t) { return t ? (int)t->queue.size() : -1; }
 int trxsig_trx_expected_corr_type(const trxsig_trx *t, int tn, int fn) {
-  return (t && tn >= 0 && tn < 8) ? expected_corr_type(t, tn, fn) : TRXSIG_CORR_OFF;
+  return (t && tn >= 0 && tn < 8) ? t->ctl.expectedCorrType(tn, fn) : TRXSIG_CORR_OFF;
 }
 
 int trxsig_trx_control(trxsig_trx *t, const char *buffer, char *response_out, int cap) {
   if (!t || !buffer || !response_out || cap < 1) return TRXSIG_EINVAL;
-  char cmdcheck[4] = {0}, command[100] = {0}, response[100] = {0};
+  char response[100] = {0};
   if (std::strlen(buffer) >= 100) return fail(t, TRXSIG_EINVAL, "control message longer than MAX_PACKET_LENGTH");
-  std::sscanf(buffer, "%3s %99s", cmdcheck, command);
-  if (std::strcmp(cmdcheck, "CMD") != 0) { response_out[0] = 0; return 0; }       // "bogus message": no response (:466-470)
-  if (std::strcmp(command, "POWEROFF") == 0) {
-    std::sprintf(response, "RSP POWEROFF 0");
-  } else if (std::strcmp(command, "POWERON") == 0) {
-    if (!t->txFreq || !t->rxFreq) std::sprintf(response, "RSP POWERON 1");
-    else {
-      std::sprintf(response, "RSP POWERON 0");
-      if (!t->on) { t->power = -20; t->on = true; }
-    }
-  } else if (std::strcmp(command, "SETPOWER") == 0) {
-    int dbPwr = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbPwr);
-    if (!t->on) std::sprintf(response, "RSP SETPOWER 1 %d", dbPwr);
-    else { t->power = dbPwr; std::sprintf(response, "RSP SETPOWER 0 %d", dbPwr); }
-  } else if (std::strcmp(command, "ADJPOWER") == 0) {
-    int dbStep = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbStep);
-    if (!t->on) std::sprintf(response, "RSP ADJPOWER 1 %d", t->power);
-    else { t->power += dbStep; std::sprintf(response, "RSP ADJPOWER 0 %d", t->power); }
-  } else if (std::strcmp(command, "RXTUNE") == 0) {
-    int freqKhz = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
-    if (t->on) std::sprintf(response, "RSP RXTUNE 1 %d", freqKhz);
-    else { t->rxFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP RXTUNE 0 %d", freqKhz); }
-  } else if (std::strcmp(command, "TXTUNE") == 0) {
-    int freqKhz = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
-    if (t->on) std::sprintf(response, "RSP TXTUNE 1 %d", freqKhz);
-    else { t->txFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP TXTUNE 0 %d", freqKhz); }
-  } else if (std::strcmp(command, "SETTSC") == 0) {
-    int TSC = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &TSC);
-    if (t->on || TSC < 0 || TSC > 7) std::sprintf(response, "RSP SETTSC 1 %d", TSC);   // (the reference does not range-check)
-    else { t->tsc = (unsigned)TSC; std::sprintf(response, "RSP SETTSC 0 %d", TSC); }
-  } else if (std::strcmp(command, "SETSLOT") == 0) {
-    int corrCode = 0, timeslot = 0;
-    std::sscanf(buffer, "%3s %99s %d %d", cmdcheck, command, &timeslot, &corrCode);
-    if (timeslot < 0 || timeslot > 7) { response_out[0] = 0; return 0; }           // returns without responding (:556-561)
-    t->chanType[timeslot] = corrCode;
-    set_modulus(t, timeslot);
-    std::sprintf(response, "RSP SETSLOT 0 %d %d", timeslot, corrCode);
-  }                                                          // unknown command: empty response buffer is sent (:571-575)
+  if (!t->ctl.command(buffer, response)) { response_out[0] = 0; return 0; }
   const int n = (int)std::strlen(response);
   if (n + 1 > cap) return fail(t, TRXSIG_EINVAL, "response buffer too small");
   std::memcpy(response_out, response, (size_t)n + 1);
   return n;
+}
+
+int trxsig_trx_set_tsc_leg(trxsig_trx *t, int leg) {
+  if (!t || (leg != TRXSIG_TSCLEG_EQUALIZE && leg != TRXSIG_TSCLEG_DEMOD)) return TRXSIG_EINVAL;
+  t->tscLeg = leg;
+  return TRXSIG_OK;
 }
 
 int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n, int tn, int fn, float *h_soft,
@@ -245,10 +257,13 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
       fn < 0 || fn >= kHyperframe)
     return fail(t, TRXSIG_EINVAL, "trxsig_trx_pull_radio_vector: bad argument");
   const Time now{fn, tn};
-  const int corrType = expected_corr_type(t, tn, fn);
+  const int corrType = t->ctl.expectedCorrType(tn, fn);
   if (corrType == TRXSIG_CORR_OFF || corrType == TRXSIG_CORR_IDLE) return 0;      // :288-291
-  if (corrType == TRXSIG_CORR_TSC && t->sps != 1)
-    return fail(t, TRXSIG_EINVAL, "the TSC leg equalises (Transceiver.cpp:391-396) and needs sps == 1");
+  // TRXSIG_TSCLEG_DEMOD: the TSC leg ends in demodulateBurst and keeps no channel cache, as Transceiver52M/Transceiver.cpp
+  // does while mMaxExpectedDelay <= 1 (needDFE false: :272, 322, 382)
+  const bool needDFE = t->tscLeg == TRXSIG_TSCLEG_EQUALIZE;
+  if (corrType == TRXSIG_CORR_TSC && needDFE && t->sps != 1)
+    return fail(t, TRXSIG_EINVAL, "the equalising TSC leg (Transceiver.cpp:391-396) needs sps == 1 (see trxsig_trx_set_tsc_leg)");
 
   // ---- the burst's detection numbers from the GPU: avgPwr of energyDetect, and analyzeTrafficBurst /
   //      detectRACHBurst (stateless, so running them ahead of the energy decision changes nothing) ----
@@ -257,9 +272,12 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
   trxsig_c32 amplitude{0.0f, 0.0f};
   float TOA = 0.0f, avgPwr = 0.0f;
   const int nsoft = n / t->sps;
-  if (corrType == TRXSIG_CORR_TSC)
-    TRX_LIB(t, trxsig_detect_demod_normal_host(t->ctx, h_burst, &off, &len, 1, (int)t->tsc, 3.0f, -1.0f, &flags, &amplitude,
+  if (corrType == TRXSIG_CORR_TSC && needDFE)
+    TRX_LIB(t, trxsig_detect_demod_normal_host(t->ctx, h_burst, &off, &len, 1, (int)t->ctl.tsc, 3.0f, -1.0f, &flags, &amplitude,
                                                &TOA, &avgPwr, nullptr, 0, 0));
+  else if (corrType == TRXSIG_CORR_TSC)
+    TRX_LIB(t, trxsig_detect_demod_normal_host(t->ctx, h_burst, &off, &len, 1, (int)t->ctl.tsc, 3.0f, -1.0f, &flags, &amplitude,
+                                               &TOA, &avgPwr, h_soft, nsoft, nsoft));     // demodulateBurst(amp, TOA) rides along
   else
     TRX_LIB(t, trxsig_detect_demod_rach_host(t->ctx, h_burst, &off, &len, 1, 5.0f, -1.0f, &flags, &amplitude, &TOA, &avgPwr,
                                              h_soft, nsoft, nsoft));     // demodulateBurst(amp, TOA) rides along
@@ -279,6 +297,7 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
     const double sinceEstimate = time_minus(now, t->channelEstimateTime[tn]);
     bool estimateChannel = false;
     if (sinceEstimate > 50 || !t->haveChan[tn]) { t->haveChan[tn] = false; estimateChannel = true; }
+    if (!needDFE) estimateChannel = false;                 // Transceiver52M/Transceiver.cpp:322
     if (success) {
       t->energyThreshold -= 1.0F;                          // :338-339
       if (t->energyThreshold < 0.0) t->energyThreshold = 0.0;
@@ -299,7 +318,7 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
         // the SNR estimate goes in as formed above (the reference squares its DOUBLE threshold; the batch
         // kernel's own formula squares a float one)
         if (!(t->SNRestimate[tn] > 0.0f)) return fail(t, TRXSIG_EINVAL, "SNR estimate is not positive");
-        TRX_LIB(t, trxsig_estimate_dfe_batch(t->ctx, d_x, d_off, d_len, 1, (int)t->tsc, 3.0f, -1.0f, t->SNRestimate[tn], 0, 0,
+        TRX_LIB(t, trxsig_estimate_dfe_batch(t->ctx, d_x, d_off, d_len, 1, (int)t->ctl.tsc, 3.0f, -1.0f, t->SNRestimate[tn], 0, 0,
                                              d_fl, d_amp, d_toa, d_co, d_w, d_b));
         uint8_t efl = 0;
         TRX_HIP(t, hipMemcpyAsync(&efl, d_fl, 1, hipMemcpyDeviceToHost, st));
@@ -330,7 +349,7 @@ int trxsig_trx_pull_radio_vector(trxsig_trx *t, const trxsig_c32 *h_burst, int n
   }
   if (!success) return 0;
 
-  if (corrType == TRXSIG_CORR_TSC) {
+  if (corrType == TRXSIG_CORR_TSC && needDFE) {
     // scaleVector(burst, 1/amp); equalizeBurst(burst, TOA - chanRespOffset[ts], sps, w[ts], b[ts]) (:391-396)
     char *d = t->d;
     hipStream_t st = (hipStream_t)trxsig_get_stream(t->ctx);
@@ -418,11 +437,11 @@ int trxsig_trx_push_radio_vector(trxsig_trx *t, int tn, int fn, trxsig_c32 *h_ou
   // dump stale bursts into the filler table (:142-153)
   while (!t->queue.empty() && time_less(t->queue.front().time, now)) {
     const Time nt = t->queue.front().time;
-    const int modFN = nt.fn % t->fillerModulus[nt.tn];
+    const int modFN = nt.fn % t->ctl.fillerModulus[nt.tn];
     t->fillerTable[modFN][nt.tn] = std::move(t->queue.front().samples);
     t->queue.erase(t->queue.begin());
   }
-  const int modFN = fn % t->fillerModulus[tn];
+  const int modFN = fn % t->ctl.fillerModulus[tn];
   int fq = 0;
   if (!t->queue.empty() && time_equal(t->queue.front().time, now)) {       // :159-173
     t->fillerTable[modFN][tn] = t->queue.front().samples;

@@ -1,0 +1,385 @@
+// trxsig_trxgroup.cpp -- include/trxsig_trxgroup.h: S Transceivers' receive side (Transceiver/Transceiver.cpp:207-410) per
+// call for n_slots timeslots, the per-ARFCN state machine replayed on the device (trxsig_group.hip).  The host only
+// classifies slots (expectedCorrType) and enqueues; line references: Transceiver/Transceiver.cpp unless a file is named.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "trxsig_ctx.h"
+#include "trxsig_group.h"
+#include "trxsig_trxgroup.h"
+#include "trxsig_trxstate.h"
+
+namespace {
+constexpr int kHyperframe = 2048 * 26 * 51;                 // GSM/GSMCommon.h:306
+constexpr int kSoft = 148;                                  // soft values kept per burst (gSlotLen: what the datagram carries, :658-672)
+
+struct Guard {
+  int prev = -1;
+  explicit Guard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+  ~Guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// one column of a timeslot's segment table: the ARFCNs that share (channel combination, TSC) on that timeslot take the
+// same path at every frame number
+struct Column { int chanType, tsc, count; };
+
+template <typename T>
+struct DevBuf {                                             // grow-only device array
+  T *p = nullptr;
+  size_t cap = 0;
+  // keep: leading elements to carry over a reallocation; st: the stream whose queued work may still use the old array
+  hipError_t need(size_t n, hipStream_t st, size_t keep = 0) {
+    if (n <= cap) return hipSuccess;
+    const size_t ncap = n + n / 4 + 256;
+    T *q = nullptr;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    e = hipMalloc((void **)&q, sizeof(T) * ncap);
+    if (e != hipSuccess) return e;
+    if (p && keep) e = hipMemcpy(q, p, sizeof(T) * (keep < cap ? keep : cap), hipMemcpyDeviceToDevice);
+    if (p) (void)hipFree(p);
+    p = q; cap = ncap;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+}  // namespace
+
+struct trxsig_trxgroup {
+  trxsig_ctx *c = nullptr;
+  int S = 0, sps = 1, leg = TRXSIG_TSCLEG_EQUALIZE;
+  std::vector<TrxControl> ctl;
+  // segment tables, re-derived when a SETSLOT / SETTSC changed something
+  bool dirty = true;
+  unsigned epoch_sum = 0;
+  std::vector<Column> cols[8];
+  int G = 1;
+  uint16_t *d_gid = nullptr;                                // [8][S]
+  int32_t *d_pos = nullptr;                                 // [8][S]
+  TrxGroupArfcn *d_state = nullptr;
+  double *d_exp = nullptr;
+  // per-call workspace
+  DevBuf<int32_t> rowmap, seg, off, len, tap_ix;
+  DevBuf<float4> packed;
+  DevBuf<uint8_t> flags, gate, ev, ev_flags;
+  DevBuf<trx_c32> amp, ev_amp, w_tab, b_tab, in;
+  DevBuf<float> toa, avgpwr, toa_eq, snr, ev_toa, ev_toaeq, soft, chan_off;
+  DevBuf<double> thr_after;
+  std::vector<int32_t> h_seg;
+  // the last pull
+  int n_slots = 0, n_rows = 0, n_tsc_rows = 0;
+  bool have = false;
+};
+
+namespace {
+#define G_HIP(g, call)                                                          \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) return trx_ctx_fail((g)->c, TRXSIG_EHIP, #call, e_);  \
+  } while (0)
+#define G_LIB(call)                       \
+  do {                                    \
+    int rc_ = (call);                     \
+    if (rc_ != TRXSIG_OK) return rc_;     \
+  } while (0)
+
+// which ARFCNs travel together on each timeslot
+int derive_tables(trxsig_trxgroup *g) {
+  const int S = g->S;
+  std::vector<uint16_t> gid((size_t)8 * S);
+  std::vector<int32_t> pos((size_t)8 * S);
+  int G = 1;
+  for (int tn = 0; tn < 8; tn++) {
+    std::vector<Column> &cs = g->cols[tn];
+    cs.clear();
+    for (int a = 0; a < S; a++) {
+      const int ct = g->ctl[a].chanType[tn], tsc = (int)g->ctl[a].tsc;
+      size_t k = 0;
+      while (k < cs.size() && !(cs[k].chanType == ct && cs[k].tsc == tsc)) k++;
+      if (k == cs.size()) cs.push_back(Column{ct, tsc, 0});
+      gid[(size_t)tn * S + a] = (uint16_t)k;
+      pos[(size_t)tn * S + a] = cs[k].count++;
+    }
+    if ((int)cs.size() > G) G = (int)cs.size();
+  }
+  g->G = G;
+  G_HIP(g, hipMemcpy(g->d_gid, gid.data(), sizeof(uint16_t) * gid.size(), hipMemcpyHostToDevice));
+  G_HIP(g, hipMemcpy(g->d_pos, pos.data(), sizeof(int32_t) * pos.size(), hipMemcpyHostToDevice));
+  g->dirty = false;
+  return TRXSIG_OK;
+}
+
+inline int row_class(const Column &c, int fn) {             // -1: OFF / IDLE (pullRadioVector returns NULL at once, :288-291)
+  const int t = TrxControl::corrType(c.chanType, fn);
+  return t == TRXSIG_CORR_TSC ? c.tsc : (t == TRXSIG_CORR_RACH ? TRXG_CLASS_RACH : -1);
+}
+}  // namespace
+
+extern "C" {
+
+int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, int tsc_leg, int start_fn, int start_tn) {
+  if (!out) return TRXSIG_EINVAL;
+  *out = nullptr;
+  if (!c) return TRXSIG_EINVAL;
+  if (n_arfcn <= 0 || n_arfcn > 65535 || (tsc_leg != TRXSIG_TSCLEG_EQUALIZE && tsc_leg != TRXSIG_TSCLEG_DEMOD) || start_fn < 0 ||
+      start_fn >= kHyperframe || start_tn < 0 || start_tn > 7)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_create: bad argument", hipSuccess);
+  if (tsc_leg == TRXSIG_TSCLEG_EQUALIZE && trxsig_sps(c) != 1)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_create: the equalising TSC leg (Transceiver.cpp:391-396) needs sps == 1", hipSuccess);
+  trxsig_trxgroup *g = new (std::nothrow) trxsig_trxgroup;
+  if (!g) return TRXSIG_ENOMEM;
+  g->c = c; g->S = n_arfcn; g->sps = trxsig_sps(c); g->leg = tsc_leg;
+  g->ctl.resize((size_t)n_arfcn);
+  Guard gd(trxsig_device(c));
+  const int S = n_arfcn;
+  std::vector<TrxGroupArfcn> st((size_t)S);
+  for (TrxGroupArfcn &a : st) {                             // Transceiver::Transceiver (:58-92)
+    a.thr = 250.0; a.prev_false_fn = start_fn; a.pad = 0;
+    for (int k = 0; k < 8; k++) { a.est_fn[k] = start_fn; a.tap_src[k] = -1; }
+  }
+  std::vector<double> ex(TRXG_EXP_N);
+  for (int k = -TRXG_EXP_LO; k <= TRXG_EXP_HI; k++) ex[(size_t)(k + TRXG_EXP_LO)] = std::exp(-(double)k);   // exp(-framesElapsed) (:355)
+  const size_t S8 = (size_t)S * 8;
+  if (hipMalloc((void **)&g->d_gid, sizeof(uint16_t) * S8) != hipSuccess || hipMalloc((void **)&g->d_pos, sizeof(int32_t) * S8) != hipSuccess ||
+      hipMalloc((void **)&g->d_state, sizeof(TrxGroupArfcn) * (size_t)S) != hipSuccess ||
+      hipMalloc((void **)&g->d_exp, sizeof(double) * TRXG_EXP_N) != hipSuccess ||
+      hipMemcpy(g->d_state, st.data(), sizeof(TrxGroupArfcn) * (size_t)S, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(g->d_exp, ex.data(), sizeof(double) * TRXG_EXP_N, hipMemcpyHostToDevice) != hipSuccess ||
+      g->w_tab.need(S8 * 7, nullptr) != hipSuccess || g->b_tab.need(S8 * 5, nullptr) != hipSuccess || g->chan_off.need(S8, nullptr) != hipSuccess) {
+    trxsig_trxgroup_destroy(g);
+    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);
+  }
+  *out = g;
+  return TRXSIG_OK;
+}
+
+void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
+  if (!g) return;
+  {
+    Guard gd(trxsig_device(g->c));
+    (void)hipStreamSynchronize((hipStream_t)trxsig_get_stream(g->c));
+    (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
+    g->rowmap.release(); g->seg.release(); g->off.release(); g->len.release(); g->tap_ix.release(); g->packed.release();
+    g->flags.release(); g->gate.release(); g->ev.release(); g->ev_flags.release(); g->amp.release(); g->ev_amp.release();
+    g->w_tab.release(); g->b_tab.release(); g->in.release(); g->toa.release(); g->avgpwr.release(); g->toa_eq.release();
+    g->snr.release(); g->ev_toa.release(); g->ev_toaeq.release(); g->soft.release(); g->chan_off.release(); g->thr_after.release();
+  }
+  delete g;
+}
+
+int trxsig_trxgroup_arfcns(const trxsig_trxgroup *g) { return g ? g->S : TRXSIG_EINVAL; }
+
+int trxsig_trxgroup_control(trxsig_trxgroup *g, int arfcn, const char *command, char *response_out, int cap) {
+  if (!g) return TRXSIG_EINVAL;
+  if (arfcn < 0 || arfcn >= g->S || !command || !response_out || cap < 1 || std::strlen(command) >= 100)
+    return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_control: bad argument", hipSuccess);
+  char response[100] = {0};
+  TrxControl &ctl = g->ctl[(size_t)arfcn];
+  const unsigned before = ctl.epoch;
+  const int answered = ctl.command(command, response);
+  if (ctl.epoch != before) g->dirty = true;
+  if (!answered) { response_out[0] = 0; return 0; }
+  const int n = (int)std::strlen(response);
+  if (n + 1 > cap) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_control: response buffer too small", hipSuccess);
+  std::memcpy(response_out, response, (size_t)n + 1);
+  return n;
+}
+
+int trxsig_trxgroup_expected_corr_type(const trxsig_trxgroup *g, int arfcn, int tn, int fn) {
+  return (g && arfcn >= 0 && arfcn < g->S && tn >= 0 && tn < 8) ? g->ctl[(size_t)arfcn].expectedCorrType(tn, fn) : TRXSIG_CORR_OFF;
+}
+
+int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_t slot_stride, int64_t arfcn_stride, int burst_len,
+                         int fn, int tn, int n_slots, trxsig_trxgroup_result *res) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  const int S = g->S, sps = g->sps;
+  if (!d_samples || n_slots <= 0 || fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7 || slot_stride < 0 || arfcn_stride < 0 || burst_len < 0 ||
+      (burst_len > 0 && (burst_len % sps != 0 || burst_len < 92 * sps || burst_len > 157 * sps)))
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: bad argument", hipSuccess);
+  const long long cells = (long long)n_slots * S;
+  const long long last = (long long)(n_slots - 1) * slot_stride + (long long)(S - 1) * arfcn_stride + 157LL * sps;
+  if (cells > std::numeric_limits<int32_t>::max() / 2 || last > std::numeric_limits<int32_t>::max())
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: the batch's sample offsets must stay below 2^31 (split the call)", hipSuccess);
+  Guard gd(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  g->have = false;
+  if (g->dirty) G_LIB(derive_tables(g));
+
+  // ---- expectedCorrType for every (slot, column): rows by class ----
+  const int G = g->G;
+  g->h_seg.assign((size_t)n_slots * G, -1);
+  int count[TRXG_NCLASS] = {0}, base[TRXG_NCLASS + 1] = {0};
+  {
+    int t_tn = tn, t_fn = fn;
+    for (int t = 0; t < n_slots; t++) {
+      const std::vector<Column> &cs = g->cols[t_tn];
+      for (size_t k = 0; k < cs.size(); k++) {
+        const int cl = row_class(cs[k], t_fn);
+        if (cl >= 0) count[cl] += cs[k].count;
+      }
+      if (++t_tn == 8) { t_tn = 0; if (++t_fn == kHyperframe) t_fn = 0; }
+    }
+    for (int k = 0; k < TRXG_NCLASS; k++) base[k + 1] = base[k] + count[k];
+    int run[TRXG_NCLASS];
+    for (int k = 0; k < TRXG_NCLASS; k++) run[k] = base[k];
+    t_tn = tn; t_fn = fn;
+    for (int t = 0; t < n_slots; t++) {
+      const std::vector<Column> &cs = g->cols[t_tn];
+      for (size_t k = 0; k < cs.size(); k++) {
+        const int cl = row_class(cs[k], t_fn);
+        if (cl >= 0) { g->h_seg[(size_t)t * G + k] = run[cl]; run[cl] += cs[k].count; }
+      }
+      if (++t_tn == 8) { t_tn = 0; if (++t_fn == kHyperframe) t_fn = 0; }
+    }
+  }
+  const int n_rows = base[TRXG_NCLASS], n_tsc = base[TRXG_CLASS_RACH];
+  const size_t R = (size_t)(n_rows > 0 ? n_rows : 1), S8 = (size_t)S * 8;
+
+  // ---- workspace (grow-only; an array that grows waits for the stream first) ----
+  G_HIP(g, g->rowmap.need((size_t)cells, st)); G_HIP(g, g->packed.need((size_t)cells, st)); G_HIP(g, g->seg.need((size_t)n_slots * G, st));
+  G_HIP(g, g->off.need(R, st)); G_HIP(g, g->len.need(R, st)); G_HIP(g, g->tap_ix.need(R, st));
+  G_HIP(g, g->flags.need(R, st)); G_HIP(g, g->gate.need(R, st)); G_HIP(g, g->ev.need(R, st)); G_HIP(g, g->ev_flags.need(R, st));
+  G_HIP(g, g->amp.need(R, st)); G_HIP(g, g->ev_amp.need(R, st));
+  G_HIP(g, g->toa.need(R, st)); G_HIP(g, g->avgpwr.need(R, st)); G_HIP(g, g->toa_eq.need(R, st)); G_HIP(g, g->snr.need(R, st));
+  G_HIP(g, g->ev_toa.need(R, st)); G_HIP(g, g->ev_toaeq.need(R, st)); G_HIP(g, g->thr_after.need(R, st));
+  G_HIP(g, g->soft.need(R * kSoft, st));
+  G_HIP(g, g->w_tab.need((S8 + R) * 7, st, S8 * 7)); G_HIP(g, g->b_tab.need((S8 + R) * 5, st, S8 * 5));
+  G_HIP(g, g->chan_off.need(S8 + R, st, S8));
+
+  // (pageable source: the copy has consumed h_seg when the call returns)
+  G_HIP(g, hipMemcpyAsync(g->seg.p, g->h_seg.data(), sizeof(int32_t) * g->h_seg.size(), hipMemcpyHostToDevice, st));
+  TrxGroupExpand ex = {};
+  ex.S = S; ex.n_slots = n_slots; ex.tn0 = tn; ex.sps = sps; ex.fixed_len = burst_len; ex.G = G;
+  ex.slot_stride = slot_stride; ex.arfcn_stride = arfcn_stride; ex.base = 0;
+  ex.gid = g->d_gid; ex.pos = g->d_pos; ex.seg_base = g->seg.p; ex.rowmap = g->rowmap.p; ex.off = g->off.p; ex.len = g->len.p;
+  G_HIP(g, trx_launch_group_expand(st, ex));
+
+  // ---- the stateless detectors, a launch per class in use; thresholds 3.0 / 5.0 (:331, 363), energy gate off ----
+  for (int k = 0; k < TRXG_NCLASS; k++) {
+    if (!count[k]) continue;
+    const int b0 = base[k];
+    if (k < TRXG_CLASS_RACH)
+      G_LIB(trxsig_detect_demod_normal_batch(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], k, 3.0f, -1.0f, g->flags.p + b0,
+                                             (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0, g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
+    else
+      G_LIB(trxsig_detect_demod_rach_batch(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], 5.0f, -1.0f, g->flags.p + b0,
+                                           (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0, g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
+  }
+
+  // ---- the state machine, a lane per ARFCN ----
+  const bool equalize = g->leg == TRXSIG_TSCLEG_EQUALIZE;
+  TrxGroupReplay rp = {};
+  rp.S = S; rp.n_slots = n_slots; rp.fn0 = fn; rp.tn0 = tn; rp.equalize = equalize; rp.n_tsc_rows = n_tsc;
+  rp.rowmap = g->rowmap.p; rp.flags = g->flags.p; rp.amp = g->amp.p; rp.avgpwr = g->avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
+  rp.gate = g->gate.p; rp.ev = g->ev.p; rp.tap_ix = g->tap_ix.p; rp.snr = g->snr.p; rp.thr_after = g->thr_after.p;
+  G_HIP(g, trx_launch_group_replay(st, rp, g->packed.p, trx_ctx_profiler(c)));
+
+  // ---- what comes back as a SoftVector ----
+  if (n_tsc > 0) {
+    if (equalize) {
+      for (int k = 0; k < TRXG_CLASS_RACH; k++) {           // :341-349 for the rows the replay marked
+        if (!count[k]) continue;
+        const int b0 = base[k];
+        G_LIB(trx_ctx_group_estimate(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], k, g->ev.p + b0, g->snr.p + b0, g->ev_flags.p + b0,
+                                     (trxsig_c32 *)g->ev_amp.p + b0, g->ev_toa.p + b0, g->ev_toaeq.p + b0, g->chan_off.p + S8 + b0,
+                                     (trxsig_c32 *)g->w_tab.p + (S8 + b0) * 7, (trxsig_c32 *)g->b_tab.p + (S8 + b0) * 5));
+      }
+      G_HIP(g, trx_launch_group_toa_eq(st, n_tsc, g->gate.p, g->toa.p, g->tap_ix.p, g->chan_off.p, g->toa_eq.p));
+      G_LIB(trx_ctx_group_equalize(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa_eq.p, g->gate.p,
+                                   (const trxsig_c32 *)g->w_tab.p, (const trxsig_c32 *)g->b_tab.p, g->tap_ix.p, g->soft.p, kSoft, kSoft));
+    } else {
+      G_LIB(trxsig_demodulate_batch(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa.p, g->gate.p, g->soft.p,
+                                    nullptr, kSoft, kSoft));
+    }
+  }
+  if (n_rows > n_tsc)                                       // :385-388
+    G_LIB(trxsig_demodulate_batch(c, d_samples, g->off.p + n_tsc, g->len.p + n_tsc, n_rows - n_tsc, (const trxsig_c32 *)g->amp.p + n_tsc,
+                                  g->toa.p + n_tsc, g->gate.p + n_tsc, g->soft.p + (size_t)n_tsc * kSoft, nullptr, kSoft, kSoft));
+  if (equalize) G_HIP(g, trx_launch_group_commit(st, S, g->d_state, g->w_tab.p, g->b_tab.p, g->chan_off.p));
+
+  g->n_slots = n_slots; g->n_rows = n_rows; g->n_tsc_rows = n_tsc; g->have = true;
+  if (res) {
+    res->n_slots = n_slots; res->n_arfcn = S; res->n_rows = n_rows;
+    res->d_row = g->rowmap.p; res->d_valid = g->gate.p; res->d_flags = g->flags.p; res->d_amp = (const trxsig_c32 *)g->amp.p;
+    res->d_toa = g->toa.p; res->d_avgpwr = g->avgpwr.p; res->d_threshold = g->thr_after.p; res->d_soft = g->soft.p; res->soft_stride = kSoft;
+  }
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft, int *h_rssi, int *h_timing, double *h_threshold) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  if (!g->have) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_collect: no pull to collect", hipSuccess);
+  if (!h_valid || !h_rssi || !h_timing) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_collect: bad argument", hipSuccess);
+  Guard gd(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  const size_t cells = (size_t)g->n_slots * g->S, R = (size_t)g->n_rows;
+  std::vector<int32_t> row(cells);
+  std::vector<uint8_t> gate(R);
+  std::vector<trx_c32> amp(R);
+  std::vector<float> toa(R), soft(h_soft ? R * kSoft : 0);
+  std::vector<double> thr(h_threshold ? R : 0);
+  G_HIP(g, hipMemcpyAsync(row.data(), g->rowmap.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, st));
+  if (R) {
+    G_HIP(g, hipMemcpyAsync(gate.data(), g->gate.p, R, hipMemcpyDeviceToHost, st));
+    G_HIP(g, hipMemcpyAsync(amp.data(), g->amp.p, sizeof(trx_c32) * R, hipMemcpyDeviceToHost, st));
+    G_HIP(g, hipMemcpyAsync(toa.data(), g->toa.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+    if (h_soft) G_HIP(g, hipMemcpyAsync(soft.data(), g->soft.p, sizeof(float) * R * kSoft, hipMemcpyDeviceToHost, st));
+    if (h_threshold) G_HIP(g, hipMemcpyAsync(thr.data(), g->thr_after.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+  }
+  G_HIP(g, hipStreamSynchronize(st));
+  for (size_t i = 0; i < cells; i++) {
+    const int r = row[i];
+    const bool ok = r >= 0 && (gate[(size_t)r] & TRXSIG_F_DETECT);
+    h_valid[i] = ok ? 1 : 0;
+    h_rssi[i] = 0; h_timing[i] = 0;
+    if (h_threshold) h_threshold[i] = r >= 0 ? thr[(size_t)r] : std::numeric_limits<double>::quiet_NaN();
+    if (!ok) continue;
+    // :400-402 -- Complex::abs() is (float)sqrt((double)norm2) (Complex.h:131); round() = half away from zero
+    const trx_c32 a = amp[(size_t)r];
+    const float n2 = a.i * a.i + a.r * a.r;
+    const float absA = (float)std::sqrt((double)n2);
+    h_rssi[i] = (int)std::floor(20.0 * std::log10(9450.0 / absA));
+    h_timing[i] = (int)std::round(toa[(size_t)r] * 256.0 / g->sps);
+    if (h_soft) std::memcpy(h_soft + i * kSoft, soft.data() + (size_t)r * kSoft, sizeof(float) * kSoft);
+  }
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_pull_host(trxsig_trxgroup *g, const trxsig_c32 *h_samples, int64_t slot_stride, int64_t arfcn_stride, int burst_len,
+                              int fn, int tn, int n_slots) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  if (!h_samples || n_slots <= 0 || slot_stride < 0 || arfcn_stride < 0)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_host: bad argument", hipSuccess);
+  const long long span = (long long)(n_slots - 1) * slot_stride + (long long)(g->S - 1) * arfcn_stride +
+                         (burst_len > 0 ? burst_len : 157LL * g->sps);
+  if (span > std::numeric_limits<int32_t>::max())
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_host: the batch's sample offsets must stay below 2^31", hipSuccess);
+  Guard gd(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  G_HIP(g, g->in.need((size_t)span, st));
+  G_HIP(g, hipMemcpyAsync(g->in.p, h_samples, sizeof(trx_c32) * (size_t)span, hipMemcpyHostToDevice, st));
+  return trxsig_trxgroup_pull(g, (const trxsig_c32 *)g->in.p, slot_stride, arfcn_stride, burst_len, fn, tn, n_slots, nullptr);
+}
+
+int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr) {
+  if (!g) return TRXSIG_EINVAL;
+  if (arfcn < 0 || arfcn >= g->S || !thr) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_energy_threshold: bad argument", hipSuccess);
+  Guard gd(trxsig_device(g->c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(g->c);
+  TrxGroupArfcn a;
+  G_HIP(g, hipMemcpyAsync(&a, g->d_state + arfcn, sizeof a, hipMemcpyDeviceToHost, st));
+  G_HIP(g, hipStreamSynchronize(st));
+  *thr = a.thr;
+  return TRXSIG_OK;
+}
+
+}  // extern "C"

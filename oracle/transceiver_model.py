@@ -34,7 +34,11 @@ def time_less(a, b):                        # GSM::Time::operator< (GSMCommon.h:
 
 
 class TransceiverModel:
-    def __init__(self, oracle, start=(0, 0)):
+    def __init__(self, oracle, start=(0, 0), need_dfe=True):
+        """need_dfe=False: the TSC leg as Transceiver52M/Transceiver.cpp runs it while mMaxExpectedDelay <= 1
+        (:272 needDFE false -> :322 no channel estimate, :382 demodulateBurst instead of equalizeBurst); the sigProcLib
+        calls stay Transceiver/sigProcLib.cpp's and so does the slot schedule."""
+        self.need_dfe = need_dfe
         self.o = oracle
         self.sps = oracle.sps
         self.on = False; self.tx_freq = 0.0; self.rx_freq = 0.0; self.power = -10; self.tsc = 0
@@ -135,6 +139,8 @@ class TransceiverModel:
             estimate = float(fn_delta(fn, self.est_time[tn][0])) > 50 or self.chan[tn] is None
             if estimate:
                 self.chan[tn] = None
+            if not self.need_dfe:
+                estimate = False                                                 # Transceiver52M/Transceiver.cpp:322
             a = self.o.analyze_traffic(x, self.tsc, 3.0, req_chan=estimate)
             success = a["ok"]
             amp, toa = a["amp"], a["toa"]
@@ -167,7 +173,7 @@ class TransceiverModel:
                 self.prev_false = now
         if not success:
             return None
-        if ct == RACH:
+        if ct == RACH or not self.need_dfe:
             soft = self.o.demodulate(x, amp, toa)
         else:
             w, b, co = self.chan[tn]

@@ -1,0 +1,225 @@
+"""The Transceiver group (include/trxsig_trxgroup.h): pullRadioVector for S ARFCNs x n_slots timeslots per call, the
+per-ARFCN state machine (adaptive energy threshold, false-detection clock, per-timeslot channel / DFE cache) replayed on
+the device.  Checked against (1) S independent single-burst objects (include/trxsig_transceiver.h) fed the same bursts
+one at a time and (2) oracle/transceiver_model.py on the CPU oracle: what comes back, its 148 soft bits, RSSI, timing
+offset and the threshold after every burst (exact double equality).  S = 128 ARFCNs, 200 frames, channel combinations
+I / II / IV / V / VII / NONE, four training sequences, clean bursts, two-path channels, loud noise (false detections raise
+the threshold), silence (the threshold decays), bursts of the wrong kind; the frames arrive in calls of 1 ... 400 slots
+that start on any timeslot."""
+import numpy as np
+import pytest
+
+import _pkg
+import oraclebind
+import synth
+import transceiver_model as tm
+
+pytestmark = pytest.mark.gpu
+
+CELL_SYM = 160                                   # samples per (slot, ARFCN) cell, in symbols (bursts are 156 / 157)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _pkg.load()
+
+
+def slot_config(a):
+    """(tsc, {tn: combination}) of ARFCN a: the C0-like carriers carry the common channels, the rest traffic."""
+    tsc = (2, 5, 0, 7)[a % 4]
+    kind = a % 8
+    if kind == 0:
+        return tsc, {0: tm.V, 1: tm.VII, 2: tm.I, 3: tm.IV, 5: tm.II}
+    if kind == 1:
+        return tsc, {0: tm.IV, 2: tm.I, 4: tm.I, 6: tm.VII}
+    if kind == 2:
+        return tsc, {t: tm.I for t in range(8)}
+    if kind == 3:
+        return tsc, {1: tm.I, 2: tm.II, 3: tm.I, 7: tm.VI}
+    if kind == 4:
+        return tsc, {0: tm.V, 4: tm.I}
+    if kind == 5:
+        return tsc, {t: tm.I for t in (1, 3, 5, 7)}
+    if kind == 6:
+        return tsc, {0: tm.VII, 1: tm.VII, 2: tm.I}
+    return tsc, {2: tm.I, 3: tm.I, 4: tm.V}
+
+
+def configure(ctl, a):
+    tsc, slots = slot_config(a)
+    r = [ctl("CMD RXTUNE 890000"), ctl("CMD TXTUNE 935000"), ctl("CMD SETTSC %d" % tsc)]
+    r += [ctl("CMD SETSLOT %d %d" % (tn, c)) for tn, c in sorted(slots.items())]
+    r.append(ctl("CMD POWERON"))
+    return r
+
+
+def build_cells(sps, S, n_slots, fn0, tn0, seed):
+    """The received bursts, [n_slots][S][CELL] complex64, and each cell's expected correlation type."""
+    rng = np.random.default_rng(seed)
+    cell = CELL_SYM * sps
+    x = np.zeros((n_slots, S, cell), np.complex64)
+    pool_n, pool_r = 1536, 768
+    pools = {}
+    for tsc in (2, 5, 0, 7):
+        xs, offs, lens, _ = synth.normal_batch(sps, pool_n, tsc, seed=seed + tsc, sigmas=(0.0, 0.05, 0.2, 0.5), max_delay=1.2)
+        for i in range(0, pool_n, 3):                                    # a two-path channel on a third of them
+            s = xs[offs[i]:offs[i] + lens[i]]
+            s[sps:] = s[sps:] + np.complex64(0.35 - 0.2j) * s[:-sps].copy()
+        pools[tsc] = (xs, offs, lens)
+    pools["rach"] = synth.rach_batch(sps, pool_r, seed=seed + 11, sigmas=(0.0, 0.1, 0.3), max_delay_sym=20)[:3]
+    ctype = np.zeros((n_slots, S), np.int8)
+    chan = np.zeros((S, 8), np.int64)
+    tscs = np.zeros(S, np.int64)
+    for a in range(S):
+        tscs[a], slots = slot_config(a)
+        for tn, c in slots.items():
+            chan[a, tn] = c
+    m = tm.TransceiverModel.__new__(tm.TransceiverModel)
+    for t in range(n_slots):
+        tn = (tn0 + t) % 8
+        fn = (fn0 + (tn0 + t) // 8) % tm.HYPERFRAME
+        n = (156 + (tn % 4 == 0)) * sps
+        quiet = 700 <= t < 1200                                          # > 50 frames of silence: the thresholds decay
+        for a in range(S):
+            m.chan_type = chan[a]
+            ct = m.expected_corr_type(tn, fn)
+            ctype[t, a] = ct
+            kind = rng.integers(0, 12)
+            if quiet or kind == 0 or (ct in (tm.OFF, tm.IDLE) and kind < 8):
+                v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.5
+            elif kind <= 2:
+                v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * rng.uniform(300, 2500)     # loud noise
+            else:
+                want_rach = (ct == tm.RACH) != (kind == 3)               # kind 3: a burst of the other sort
+                xs, offs, lens = pools["rach"] if want_rach else pools[int(tscs[a])]
+                i = rng.integers(0, len(offs))
+                v = xs[offs[i]:offs[i] + lens[i]][:n]
+                if len(v) < n:
+                    v = np.concatenate([v, np.zeros(n - len(v), np.complex64)])
+            x[t, a, :n] = v
+    return x, ctype
+
+
+def run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls):
+    import torch
+    ctx = pkg.TrxSig(sps, 0)
+    ctx.use_torch_stream()
+    g = pkg.TrxGroup(ctx, S, tsc_leg=leg, start=(fn0, tn0))
+    cell = x.shape[2]
+    out = dict(valid=np.zeros((n_slots, S), bool), soft=np.zeros((n_slots, S, 148), np.float32), rssi=np.zeros((n_slots, S), np.int32),
+               timing=np.zeros((n_slots, S), np.int32), threshold=np.zeros((n_slots, S)))
+    responses = [configure(lambda c, a=a: g.control(a, c), a) for a in range(S)]
+    dx = torch.from_numpy(x.view(np.float32).reshape(-1)).to("cuda:0")
+    t = 0
+    k = 0
+    while t < n_slots:
+        n = min(calls[k % len(calls)], n_slots - t)
+        k += 1
+        tn = (tn0 + t) % 8
+        fn = (fn0 + (tn0 + t) // 8) % tm.HYPERFRAME
+        res = g.pull(dx.data_ptr() + 8 * t * S * cell, S * cell, cell, fn, tn, n)
+        assert res.n_slots == n and res.n_arfcn == S
+        r = g.collect()
+        for key in out:
+            out[key][t:t + n] = r[key]
+        t += n
+    final_thr = np.array([g.energy_threshold(a) for a in range(S)])
+    g.close(); ctx.close()
+    return out, responses, final_thr
+
+
+def check_against(name, pull, ctype, x, sps, out, arfcns, fn0, tn0, thr_of):
+    """pull(a, burst, tn, fn) -> None | (soft, rssi, timing); thr_of(a) -> the threshold after the burst."""
+    n_slots = x.shape[0]
+    seen = {"none": 0, "tsc": 0, "rach": 0}
+    for a in arfcns:
+        for t in range(n_slots):
+            ct = ctype[t, a]
+            if ct in (tm.OFF, tm.IDLE):
+                assert not out["valid"][t, a] and np.isnan(out["threshold"][t, a])
+                continue
+            tn = (tn0 + t) % 8
+            fn = (fn0 + (tn0 + t) // 8) % tm.HYPERFRAME
+            n = (156 + (tn % 4 == 0)) * sps
+            r = pull(a, x[t, a, :n], tn, fn)
+            assert out["threshold"][t, a] == thr_of(a), (name, a, t, out["threshold"][t, a], thr_of(a))
+            assert (r is not None) == bool(out["valid"][t, a]), (name, a, t, ct)
+            if r is None:
+                seen["none"] += 1
+                continue
+            seen["tsc" if ct == tm.TSC else "rach"] += 1
+            assert r[1] == out["rssi"][t, a] and r[2] == out["timing"][t, a], (name, a, t, r[1:], out["rssi"][t, a], out["timing"][t, a])
+            assert np.array_equal(np.asarray(r[0][:148], np.float32), out["soft"][t, a]), (name, a, t, ct)
+    return seen
+
+
+@pytest.mark.parametrize("sps,leg,frames", [(1, 0, 200), (4, 1, 60)])
+def test_group_equals_single_objects_and_model(pkg, sps, leg, frames):
+    S, fn0, tn0 = 128, 1000, 3
+    n_slots = 8 * frames
+    x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=100 + sps)
+    out, responses, final_thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=(1, 7, 8, 64, 400, 3, 123, 16))
+    thr = out["threshold"][~np.isnan(out["threshold"])]
+    assert thr.min() < 200 and thr.max() > 255                           # the thresholds really moved both ways
+    assert out["valid"].sum() > 0.2 * (ctype == tm.TSC).sum()
+
+    # (1) S independent single-burst objects, the drop-in form of pullRadioVector
+    objs = [pkg.TrxHost(sps, 0, start=(fn0, tn0), tsc_leg=leg) for _ in range(S)]
+    for a in range(S):
+        assert configure(objs[a].control, a) == responses[a]
+    seen = check_against("single", lambda a, b, tn, fn: objs[a].pull_radio_vector(b, tn, fn), ctype, x, sps, out, range(S), fn0, tn0,
+                         lambda a: objs[a].energy_threshold)
+    assert seen["tsc"] > 5000 and seen["rach"] > 300 and seen["none"] > 5000, seen
+    assert np.array_equal(final_thr, np.array([o.energy_threshold for o in objs]))
+    for o in objs:
+        o.close()
+
+    # (2) the restatement of Transceiver.cpp on the CPU oracle
+    o = oraclebind.Oracle(sps)
+    models = {}
+    arfcns = range(S) if sps == 1 else range(0, S, 4)
+    for a in arfcns:
+        models[a] = tm.TransceiverModel(o, start=(fn0, tn0), need_dfe=(leg == 0))
+        assert configure(models[a].control, a) == responses[a]
+    seen = check_against("model", lambda a, b, tn, fn: models[a].pull_radio_vector(b, tn, fn), ctype, x, sps, out, arfcns, fn0, tn0,
+                         lambda a: models[a].energy_threshold)
+    assert seen["tsc"] > 1000 and seen["rach"] > 100, seen
+
+
+def test_reconfiguration_and_limits(pkg):
+    """SETSLOT between pulls re-derives the row classes; arguments that cannot be honoured are refused."""
+    import torch
+    sps, S = 4, 5
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+    cell = CELL_SYM * sps
+    xs, offs, lens, meta = synth.normal_batch(sps, 8 * S, 3, seed=5, sigmas=(0.0,), max_delay=0.5)
+    x = np.zeros((8, S, cell), np.complex64)
+    for t in range(8):
+        for a in range(S):
+            i = t * S + a
+            n = (156 + (t % 4 == 0)) * sps
+            x[t, a, :min(n, lens[i])] = xs[offs[i]:offs[i] + lens[i]][:n]
+    dx = torch.from_numpy(x.view(np.float32).reshape(-1)).to("cuda:0")
+    res = g.pull(dx, S * cell, cell, 10, 0, 8)
+    assert res.n_rows == 0 and not g.collect()["valid"].any()          # every slot NONE: nothing reaches a correlator
+    for a in range(S):
+        assert g.control(a, "CMD SETTSC 3") == "RSP SETTSC 0 3"
+        assert g.control(a, "CMD SETSLOT %d 1" % a) == "RSP SETSLOT 0 %d 1" % a
+    res = g.pull(dx, S * cell, cell, 10, 0, 8)
+    r = g.collect()
+    assert res.n_rows == S
+    for a in range(S):
+        assert r["valid"][a, a] and r["valid"].sum() == S
+        bits = (r["soft"][a, a] > 0.5).astype(np.uint8)
+        assert np.array_equal(bits, meta["bits"][a * S + a])
+        assert g.energy_threshold(a) == 249.0
+    with pytest.raises(pkg.TrxSigError):
+        g.pull(dx, 1 << 30, cell, 10, 0, 8)                             # offsets beyond 2^31 samples
+    with pytest.raises(pkg.TrxSigError):
+        g.pull(dx, S * cell, cell, 10, 8, 8)                            # TN out of range
+    with pytest.raises(pkg.TrxSigError):
+        pkg.TrxGroup(ctx, 4, tsc_leg=pkg.TSCLEG_EQUALIZE)                # the equalising leg needs sps == 1
+    g.close(); ctx.close()

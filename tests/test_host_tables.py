@@ -22,14 +22,14 @@ def pkg():
 
 
 def test_exports_every_declared_symbol(pkg):
-    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("trxsig.h", "trxsig_transceiver.h", "trxsig_frontend.h"))
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("trxsig.h", "trxsig_transceiver.h", "trxsig_frontend.h", "trxsig_trxgroup.h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(trxsig_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 90 and "trxsig_rxfe_push" in names and "trxsig_convolve_batch" in names and "trxsig_trx_pull_radio_vector" in names and "trxsig_fec_tch_decode_batch" in names
+    assert len(names) >= 90 and "trxsig_rxfe_push" in names and "trxsig_convolve_batch" in names and "trxsig_trx_pull_radio_vector" in names and "trxsig_fec_tch_decode_batch" in names and "trxsig_trxgroup_pull" in names
     L = pkg.lib()
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
-    assert L.trxsig_abi_version() == 1
+    assert L.trxsig_abi_version() == pkg.ABI_VERSION == 2
 
 
 def test_no_cpu_fallback(pkg):
