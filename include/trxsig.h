@@ -339,10 +339,9 @@ int trxsig_fec_viterbi_batch(trxsig_ctx *ctx, const float *d_soft, int n_soft, i
  * Batch forms: B independent vectors packed in one device array (d_off / d_len in samples); max_len = the largest
  * d_len (sizes the launch).  Values are the reference's, bit for bit: every sum in the reference's order with its
  * skip / break rules.  Host forms: one vector, pageable host buffers, one PCIe round trip.
- * Not provided: convolve's ABSSYM symmetry form (sigProcLib.cpp:369-398; no caller in the reference ever sets a symmetry).
  * span: ConvType of sigProcLib.h:41-48 (+ CUSTOM of Transceiver52M/sigProcLib.h:47 with cust_start / cust_len).
  * flags: bit 0 = a is real-only, bit 1 = b is real-only (signalVector::isRealOnly: the four arithmetic forms of
- * sigProcLib.cpp:326-365); correlate != 0: b is used reversed and conjugated (sigProcLib.cpp:474-503). */
+ * sigProcLib.cpp:326-365), bit 2 = b has ABSSYM symmetry (:369-398; convolve only); correlate != 0: b is used reversed and conjugated (sigProcLib.cpp:474-503). */
 enum { TRXSIG_FULL_SPAN = 0, TRXSIG_OVERLAP_ONLY = 1, TRXSIG_START_ONLY = 2, TRXSIG_WITH_TAIL = 3, TRXSIG_NO_DELAY = 4,
        TRXSIG_CUSTOM = 5 };
 int trxsig_convolve_out_len(int La, int Lb, int span, int cust_len);   /* < 0: unknown span */
@@ -381,7 +380,48 @@ int trxsig_vector_slicer_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *
  * reference writes past its allocation otherwise, sigProcLib.cpp:1045-1050) */
 int trxsig_decimate_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
                           int factor, trxsig_c32 *d_out, const int32_t *d_out_off);
-/* one vector, in place on the host buffer; op: 0 scaleVector(scale), 1 GMSKRotate, 2 GMSKReverseRotate, 3 vectorSlicer */
+/* ---- the rest of sigProcLib.h: the functions no caller on the burst path uses, for a complete surface -------------------
+ * dB (sigProcLib.h:102; sigProcLib.cpp:88-114) and dBinv (:105; :117-144): the reference's piecewise-linear float
+ *   approximations, on the host (scalar functions of one float).  sinc (:177; :567-571) against the context's trig table.
+ * gaussianNoise (:188-190; :618-637): Box-Muller on the C library's rand(), two draws per sample in the reference's
+ *   order (more after a zero draw) -- the caller's srand() seed decides the values, as with the reference.  Host.
+ * vectorNorm2 / vectorPower (:108, 111; :146-160): the powers summed in index order; d_norm2 / d_power may be NULL.
+ * frequencyShift (:149-153; :432-471): y[k] = x[k] * expjLookup(phase_k) (real-only x: expjLookup(phase_k) * x[k].real()),
+ *   phase_0 = start_phase, phase_{k+1} = phase_k + freq in float; d_final_phase[i] (optional) = the phase after the last
+ *   sample.  d_out may be d_in.  The reference's range reduction is a subtract-one loop that never ends for a float too large
+ *   to change by 1: phases beyond +-25000 rad (|start| + n |freq|) are refused by the host forms (TRXSIG_EINVAL); the batch
+ *   form bounds the loop instead and its values beyond that range are unspecified.
+ * addVector (:184-185; :746-758): x[k] += y[k] over the shorter of the two, in place.
+ * offsetVector (:225-226; :760-777): x[k] += offset (real-only x: x[k] = offset + x[k].real()), in place.
+ * resampleVector (:352-354; :1213-1243) AS THE REFERENCE BEHAVES: its loop never advances the output iterator, so every
+ *   interpolated value lands in element 0 and the other ceil(n * exp_factor) - 1 elements stay zero.  exp_factor >= 1 (NULL in
+ *   the reference otherwise: TRXSIG_EINVAL); out vector i at d_out_off[i], trxsig_resample_linear_out_len(n, f) samples.
+ * convolve's ABSSYM form (:369-398): trxsig_convolve_batch / _host with flags bit 2 set (b is an ABSSYM filter: half its
+ *   taps are used, each on a[t-j] and on a[t-Lb+j]); the reference's reads beyond a's end (its fourth arm has no upper
+ *   bound) count as zero. */
+float trxsig_db(float x);
+float trxsig_dbinv(float x);
+int trxsig_sinc_host(const trxsig_ctx *ctx, float x, float *out);
+int trxsig_gaussian_noise_host(int length, float variance, trxsig_c32 mean, trxsig_c32 *h_out);
+int trxsig_vector_norm2_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B, float *d_norm2,
+                              float *d_power);
+int trxsig_vector_norm2_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, float *norm2, float *power);
+int trxsig_frequency_shift_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                                 const float *d_freq, const float *d_start_phase, int real_only, trxsig_c32 *d_out, float *d_final_phase);
+int trxsig_frequency_shift_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, float freq, float start_phase, int real_only,
+                                trxsig_c32 *h_out, float *final_phase);
+int trxsig_add_vector_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *d_xoff, const int32_t *d_xlen, const trxsig_c32 *d_y,
+                            const int32_t *d_yoff, const int32_t *d_ylen, int B, int max_len);
+int trxsig_add_vector_host(trxsig_ctx *ctx, trxsig_c32 *h_x, int nx, const trxsig_c32 *h_y, int ny);
+int trxsig_offset_vector_batch(trxsig_ctx *ctx, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                               const trxsig_c32 *d_offset, int real_only);
+int trxsig_resample_linear_out_len(int n, float exp_factor);   /* < 0: exp_factor < 1 */
+int trxsig_resample_linear_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                                 float exp_factor, const trxsig_c32 *d_end_point, trxsig_c32 *d_out, const int32_t *d_out_off);
+int trxsig_resample_linear_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, float exp_factor, trxsig_c32 end_point, trxsig_c32 *h_out,
+                                int out_cap);   /* returns the length */
+/* one vector, in place on the host buffer; op: 0 scaleVector(scale), 1 GMSKRotate, 2 GMSKReverseRotate, 3 vectorSlicer,
+ * 4 offsetVector(scale = the offset) */
 int trxsig_elementwise_host(trxsig_ctx *ctx, int op, trxsig_c32 *h_x, int n, trxsig_c32 scale, int real_only);
 int trxsig_decimate_host(trxsig_ctx *ctx, const trxsig_c32 *h_x, int n, int factor, trxsig_c32 *h_out);   /* returns n / factor */
 

@@ -32,7 +32,9 @@ typedef struct trxsig_rxfe trxsig_rxfe;
 typedef struct trxsig_txbe trxsig_txbe;
 
 /* h_lpf: the L (normally 961, createLPF(cutoff, 961, 65*sps): radioInterface.cpp:230-234) normalised taps, host memory.
- * max_chunks: the most chunks one push may carry (sizes the buffers).  start_tn: TN of the first burst cut. */
+ * max_chunks: the most chunks one push may carry (sizes the buffers).  start_tn: TN of the first burst cut.
+ * Burst offsets are 32-bit: n_streams * (157*sps + max_chunks * 585*sps) samples must stay below 2^31 (TRXSIG_EINVAL
+ * otherwise -- use several front ends). */
 int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *ctx, int n_streams, int max_chunks, const float *h_lpf, int L,
                        int swap_iq, int start_tn);
 void trxsig_rxfe_destroy(trxsig_rxfe *fe);
@@ -52,9 +54,10 @@ int trxsig_rxfe_pending(const trxsig_rxfe *fe);   /* samples per stream not yet 
  * each; the unfused chain writes 300 MB of complex float32 per 60 K bursts and reads it back 1.4 times).  Same results bit
  * for bit.  Needs sps == 4, a filter of at most 4*260 taps and nsoft <= 148; a front end is used either through this call or
  * through push / pop, not both.  *n_bursts per stream are completed by this push; burst j of stream s is entry
- * s * *n_bursts + j of every output array (which must hold n_streams * bursts_upper_bound entries, the bound being
- * (628 + n_chunks * 2340) / 624); h_tn as in trxsig_rxfe_pop.  d_iq is read by kernels on the context's stream: keep it
- * unchanged until they have run. */
+ * s * *n_bursts + j of every output array.  cap_tn = the bursts per stream the output arrays (and h_tn, if given) have room
+ * for, i.e. they hold n_streams * cap_tn entries; (628 + n_chunks * 2340) / 624 always suffices.  A push that completes more
+ * is refused with TRXSIG_EINVAL before anything is launched or the front end's state changes.  d_iq is read by kernels on the
+ * context's stream: keep it unchanged until they have run. */
 int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int tsc, float detect_thresh,
                                          float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr,
                                          float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride, int32_t *h_tn, int cap_tn,

@@ -29,6 +29,7 @@
 #ifndef TRXSIG_TRXGROUP_H
 #define TRXSIG_TRXGROUP_H
 
+#include "trxsig_frontend.h"
 #include "trxsig_transceiver.h"
 
 #ifdef __cplusplus
@@ -71,6 +72,16 @@ typedef struct {
  * Offsets must stay below 2^31 samples.  Asynchronous: d_samples must stay unchanged until the stream has run. */
 int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_t slot_stride, int64_t arfcn_stride,
                          int burst_len, int fn, int tn, int n_slots, trxsig_trxgroup_result *res);
+
+/* The same with the bursts coming straight from the radio: RadioInterface::pullBuffer + driveReceiveRadio
+ * (radioInterface.cpp:197-273, 359-401) + pullRadioVector in one call.  `fe` is a receive front end with one stream per
+ * ARFCN on the group's context (trxsig_frontend.h; sps 4, used through its fused calls only); d_iq / n_chunks as
+ * trxsig_rxfe_push_detect_demod_normal.  The detectors -- midamble and access-burst alike, by each slot's expectedCorrType --
+ * compute their samples from the int16 chunks; the resampled stream never exists in memory.  The push completes *n_slots
+ * timeslots (possibly 0); the first one is at time (fn, the front end's current TN) -- the GSM clock is the caller's
+ * (radioInterface.cpp:364-366).  Needs the TRXSIG_TSCLEG_DEMOD leg. */
+int trxsig_trxgroup_pull_rxfe(trxsig_trxgroup *g, trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int fn, int *n_slots,
+                              trxsig_trxgroup_result *res);
 
 /* What the caller of pullRadioVector sees, on the host, for the last pull (synchronises the stream): entry t*n_arfcn + a
  *   h_valid   1 where a SoftVector came back

@@ -595,6 +595,7 @@ class TrxGroup:
         L.trxsig_trxgroup_expected_corr_type.argtypes = [vp, i32, i32, i32]
         L.trxsig_trxgroup_pull.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, C.POINTER(TrxGroupResult)]
         L.trxsig_trxgroup_pull_host.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32]
+        L.trxsig_trxgroup_pull_rxfe.argtypes = [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(TrxGroupResult)]
         L.trxsig_trxgroup_collect.argtypes = [vp, vp, vp, vp, vp, vp]
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
         self.S = n_arfcn
@@ -634,6 +635,17 @@ class TrxGroup:
                   "trxsig_trxgroup_pull")
         self.n_slots = n_slots
         return res
+
+    def pull_rxfe(self, fe, iq, fn):
+        """fe: frontend.RxFrontEnd on the same context; iq: int16 device tensor [S, K*864, 2].  Returns (slots completed, result)."""
+        iq = iq.contiguous()
+        res = TrxGroupResult()
+        n = C.c_int()
+        self._chk(self.L.trxsig_trxgroup_pull_rxfe(self.h, fe.h, iq.data_ptr(), iq.shape[1] // 864, fn, C.byref(n), C.byref(res)),
+                  "trxsig_trxgroup_pull_rxfe")
+        fe._keep = iq
+        self.n_slots = n.value
+        return n.value, res
 
     def pull_host(self, x, slot_stride, arfcn_stride, fn, tn, n_slots, burst_len=0):
         np = self.np

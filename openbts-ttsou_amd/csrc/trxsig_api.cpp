@@ -427,6 +427,31 @@ int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float 
                                  d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->generic_taps, c->prof));
   return TRXSIG_OK;
 }
+int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
+                    uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
+  if (B < 0 || (B > 0 && (!d_len || !d_flags || !d_amp || !d_toa))) return fail(c, TRXSIG_EINVAL, "trx_ctx_rx_rach: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  int rc = ensure_ws(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, trx_launch_rx_rach(c->stream, c->d_tables, gen, d_len, B, detect_thresh, energy_thresh, c->rach_amp_err, (float *)c->d_rec,
+                               c->cap_bursts, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+  return TRXSIG_OK;
+}
+int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
+                     float *d_soft, int nsoft, int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
+  if (B < 0 || nsoft < 0 || nsoft > 148 || soft_stride < nsoft || (B > 0 && (!d_amp || !d_toa || (nsoft > 0 && !d_soft))))
+    return fail(c, TRXSIG_EINVAL, "trx_ctx_rx_demod: bad argument");
+  if (B == 0 || nsoft == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_rx_demod(c->stream, c->d_tables, gen, B, (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, nullptr, nsoft,
+                                soft_stride, c->prof));
+  return TRXSIG_OK;
+}
 extern "C" {
 
 int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset,
@@ -1137,7 +1162,7 @@ int trxsig_convolve_batch(trxsig_ctx *c, const trxsig_c32 *d_a, const int32_t *d
                           int cust_len, trxsig_c32 *d_out, const int32_t *d_out_off) {
   if (!c) return TRXSIG_EINVAL;
   if (bad_batch(d_a, d_a_off, d_a_len, B) || max_len <= 0 || !d_b || Lb <= 0 || span < 0 || span > TRXSIG_CUSTOM ||
-      (flags & ~3) || (B > 0 && (!d_out || !d_out_off)) || (span == TRXSIG_CUSTOM && (cust_start < 0 || cust_len <= 0)))
+      (flags & ~7) || ((flags & 4) && correlate) || (B > 0 && (!d_out || !d_out_off)) || (span == TRXSIG_CUSTOM && (cust_start < 0 || cust_len <= 0)))
     return fail(c, TRXSIG_EINVAL, "trxsig_convolve_batch: bad argument");
   DeviceGuard g(c->device);
   const int max_out = trx_convolve_out_len(max_len, Lb, span, cust_len);
@@ -1344,6 +1369,216 @@ int trxsig_vector_slicer_batch(trxsig_ctx *c, trxsig_c32 *d_x, const int32_t *d_
   return elementwise_batch(c, "trxsig_vector_slicer_batch: bad argument", 3, d_x, d_off, d_len, B, max_len, nullptr, 0);
 }
 
+int trxsig_offset_vector_batch(trxsig_ctx *c, trxsig_c32 *d_x, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
+                               const trxsig_c32 *d_offset, int real_only) {
+  if (c && B > 0 && !d_offset) return fail(c, TRXSIG_EINVAL, "trxsig_offset_vector_batch: bad argument");
+  return elementwise_batch(c, "trxsig_offset_vector_batch: bad argument", 4, d_x, d_off, d_len, B, max_len, d_offset, real_only);
+}
+
+// ---- the rest of sigProcLib.h (host scalars in the reference's float arithmetic; this file is built with -ffp-contract=off) ----
+float trxsig_db(float x) {                                 // sigProcLib.cpp:88-114
+  float arg = 1.0F, dB = 0.0F;
+  if (x >= 1.0F) return 0.0F;
+  if (x <= 0.0F) return -200.0F;
+  float prevArg = arg, prevdB = dB, stepSize = 16.0F, dBstepSize = 12.0F;
+  while (stepSize > 1.0F) {
+    do {
+      prevArg = arg; prevdB = dB;
+      arg /= stepSize; dB -= dBstepSize;
+    } while (arg > x);
+    arg = prevArg; dB = prevdB;
+    stepSize *= 0.5F; dBstepSize -= 3.0F;
+  }
+  return ((arg - x) * (dB - 3.0F) + (x - arg * 0.5F) * dB) / (arg - arg * 0.5F);
+}
+float trxsig_dbinv(float x) {                              // sigProcLib.cpp:117-144
+  float arg = 1.0F, dB = 0.0F;
+  if (x >= 0.0F) return 1.0F;
+  if (x <= -200.0F) return 0.0F;
+  float prevArg = arg, prevdB = dB, stepSize = 16.0F, dBstepSize = 12.0F;
+  while (stepSize > 1.0F) {
+    do {
+      prevArg = arg; prevdB = dB;
+      arg /= stepSize; dB -= dBstepSize;
+    } while (dB > x);
+    arg = prevArg; dB = prevdB;
+    stepSize *= 0.5F; dBstepSize -= 3.0F;
+  }
+  return ((dB - x) * (arg * 0.5F) + (x - (dB - 3.0F)) * (arg)) / 3.0F;
+}
+int trxsig_sinc_host(const trxsig_ctx *c, float x, float *out) {   // sinc (:567-571) on sinLookup (:177-188)
+  if (!c || !out) return TRXSIG_EINVAL;
+  if (!((x >= 0.01F) || (x <= -0.01F))) { *out = 1.0F; return TRXSIG_OK; }
+  if (!(std::fabs(x) <= 1.0e7f)) return TRXSIG_EINVAL;     // (the reference's subtract-one range reduction would not end)
+  const float M_1_2PI_F = 1 / 6.28318548202514648f;
+  float arg = x * M_1_2PI_F;
+  while (arg > 1.0F) arg -= 1.0F;
+  while (arg < 0.0F) arg += 1.0F;
+  const float argT = arg * ((float)TRX_TABLESIZE);
+  const int argI = (int)argT;
+  const float delta = argT - argI;
+  const float iDelta = 1.0F - delta;
+  const float sn = iDelta * c->h_tables->sinT[argI] + delta * c->h_tables->sinT[argI + 1];
+  *out = sn / x;
+  return TRXSIG_OK;
+}
+int trxsig_gaussian_noise_host(int length, float variance, trxsig_c32 mean, trxsig_c32 *h_out) {   // :618-637
+  if (length < 0 || (length > 0 && !h_out)) return TRXSIG_EINVAL;
+  const float stddev = sqrtf(variance);
+  for (int k = 0; k < length; k++) {
+    float u1 = (float)rand() / (float)RAND_MAX;
+    while (u1 == 0.0) u1 = (float)rand() / (float)RAND_MAX;
+    const float u2 = (float)rand() / (float)RAND_MAX;
+    const float arg = 2.0 * M_PI * u2;
+    // mean + stddev*complex(cos(arg),sin(arg))*sqrtf(-2.0*log(u1)): cos / sin / log of a float are the float overloads;
+    // Real * Complex scales both parts (Complex.h:226-229), Complex * Real likewise (:84), then the complex sum
+    const float er = std::cos(arg) * stddev, ei = std::sin(arg) * stddev;
+    const float m = sqrtf(-2.0 * std::log(u1));
+    h_out[k].re = mean.re + er * m;
+    h_out[k].im = mean.im + ei * m;
+  }
+  return TRXSIG_OK;
+}
+
+int trxsig_vector_norm2_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B, float *d_norm2,
+                              float *d_power) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B)) return fail(c, TRXSIG_EINVAL, "trxsig_vector_norm2_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_vector_norm2(c->stream, (const trx_c32 *)d_in, d_off, d_len, B, d_norm2, d_power));
+  return TRXSIG_OK;
+}
+int trxsig_vector_norm2_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, float *norm2, float *power) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0) return fail(c, TRXSIG_EINVAL, "trxsig_vector_norm2_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16), o_out = s.take(16);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  const int32_t meta[2] = {0, n};
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_vector_norm2_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1, (float *)(d + o_out),
+                                 (float *)(d + o_out) + 1);
+  if (rc != TRXSIG_OK) return rc;
+  float res[2];
+  HIPCHK(c, hipMemcpyAsync(res, d + o_out, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (norm2) *norm2 = res[0];
+  if (power) *power = res[1];
+  return TRXSIG_OK;
+}
+
+int trxsig_frequency_shift_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                                 const float *d_freq, const float *d_start_phase, int real_only, trxsig_c32 *d_out, float *d_final_phase) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || (B > 0 && (!d_freq || !d_start_phase || !d_out)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_frequency_shift_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_frequency_shift(c->stream, c->d_tables, (const trx_c32 *)d_in, d_off, d_len, B, d_freq, d_start_phase, real_only != 0,
+                                       (trx_c32 *)d_out, d_final_phase));
+  return TRXSIG_OK;
+}
+int trxsig_frequency_shift_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, float freq, float start_phase, int real_only,
+                                trxsig_c32 *h_out, float *final_phase) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || n <= 0 || !h_out) return fail(c, TRXSIG_EINVAL, "trxsig_frequency_shift_host: bad argument");
+  if (!(std::fabs((double)start_phase) + (double)n * std::fabs((double)freq) <= (double)trx_frequency_shift_max_phase()))
+    return fail(c, TRXSIG_EINVAL, "trxsig_frequency_shift_host: phase beyond +-25000 rad (the reference's range reduction would not return)");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(32);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  int32_t meta[5] = {0, n, 0, 0, 0};
+  std::memcpy(&meta[2], &freq, 4); std::memcpy(&meta[3], &start_phase, 4);
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 20, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_frequency_shift_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1, (float *)(d + o_m) + 2,
+                                    (float *)(d + o_m) + 3, real_only, (trxsig_c32 *)(d + o_x), (float *)(d + o_m) + 4);
+  if (rc != TRXSIG_OK) return rc;
+  float fin = 0.0f;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_x, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&fin, (float *)(d + o_m) + 4, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (final_phase) *final_phase = fin;
+  return TRXSIG_OK;
+}
+
+int trxsig_add_vector_batch(trxsig_ctx *c, trxsig_c32 *d_x, const int32_t *d_xoff, const int32_t *d_xlen, const trxsig_c32 *d_y,
+                            const int32_t *d_yoff, const int32_t *d_ylen, int B, int max_len) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_x, d_xoff, d_xlen, B) || bad_batch(d_y, d_yoff, d_ylen, B) || max_len <= 0)
+    return fail(c, TRXSIG_EINVAL, "trxsig_add_vector_batch: bad argument");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_add_vector(c->stream, (trx_c32 *)d_x, d_xoff, d_xlen, (const trx_c32 *)d_y, d_yoff, d_ylen, B, max_len));
+  return TRXSIG_OK;
+}
+int trxsig_add_vector_host(trxsig_ctx *c, trxsig_c32 *h_x, int nx, const trxsig_c32 *h_y, int ny) {
+  if (!c) return TRXSIG_EINVAL;
+  if (!h_x || !h_y || nx <= 0 || ny <= 0) return fail(c, TRXSIG_EINVAL, "trxsig_add_vector_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)nx), o_y = s.take(8 * (size_t)ny), o_m = s.take(16);
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  const int32_t meta[3] = {0, nx, ny};
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)nx, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_y, h_y, 8 * (size_t)ny, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_add_vector_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, (trxsig_c32 *)(d + o_y),
+                               (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 2, 1, nx < ny ? nx : ny);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_x, d + o_x, 8 * (size_t)nx, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TRXSIG_OK;
+}
+
+int trxsig_resample_linear_out_len(int n, float exp_factor) {
+  if (n < 0 || !(exp_factor >= 1.0f)) return -1;
+  return (int)std::ceil((float)(size_t)n * exp_factor);    // (int) ceil(wVector.size()*expFactor) (:1222)
+}
+int trxsig_resample_linear_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
+                                 float exp_factor, const trxsig_c32 *d_end_point, trxsig_c32 *d_out, const int32_t *d_out_off) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_in, d_off, d_len, B) || !(exp_factor >= 1.0f) || !(exp_factor <= 65536.0f) || (B > 0 && (!d_end_point || !d_out || !d_out_off)))
+    return fail(c, TRXSIG_EINVAL, "trxsig_resample_linear_batch: bad argument (resampleVector returns NULL for expFactor < 1)");
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_resample_linear(c->stream, (const trx_c32 *)d_in, d_off, d_len, B, exp_factor, (const trx_c32 *)d_end_point,
+                                       (trx_c32 *)d_out, d_out_off));
+  return TRXSIG_OK;
+}
+int trxsig_resample_linear_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, float exp_factor, trxsig_c32 end_point, trxsig_c32 *h_out,
+                                int out_cap) {
+  if (!c) return TRXSIG_EINVAL;
+  const int nout = trxsig_resample_linear_out_len(n, exp_factor);
+  if (!h_x || n <= 0 || !h_out || nout < 0 || nout > out_cap) return fail(c, TRXSIG_EINVAL, "trxsig_resample_linear_host: bad argument");
+  DeviceGuard g(c->device);
+  Stager s(c);
+  const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(32), o_out = s.take(8 * (size_t)(nout > 0 ? nout : 1));
+  int rc = ensure_stage(c, s.used);
+  if (rc != TRXSIG_OK) return rc;
+  char *d = s.base();
+  int32_t meta[6] = {0, n, 0, 0, 0, 0};
+  std::memcpy(&meta[4], &end_point, 8);
+  HIPCHK(c, hipMemcpyAsync(d + o_x, h_x, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + o_m, meta, 24, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = trxsig_resample_linear_batch(c, (trxsig_c32 *)(d + o_x), (int32_t *)(d + o_m), (int32_t *)(d + o_m) + 1, 1, exp_factor,
+                                    (trxsig_c32 *)((int32_t *)(d + o_m) + 4), (trxsig_c32 *)(d + o_out), (int32_t *)(d + o_m) + 2);
+  if (rc != TRXSIG_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(h_out, d + o_out, 8 * (size_t)nout, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return nout;
+}
+
 int trxsig_decimate_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B, int max_len,
                           int factor, trxsig_c32 *d_out, const int32_t *d_out_off) {
   if (!c) return TRXSIG_EINVAL;
@@ -1356,7 +1591,7 @@ int trxsig_decimate_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32_t *
 
 int trxsig_elementwise_host(trxsig_ctx *c, int op, trxsig_c32 *h_x, int n, trxsig_c32 scale, int real_only) {
   if (!c) return TRXSIG_EINVAL;
-  if (!h_x || n <= 0 || op < 0 || op > 3) return fail(c, TRXSIG_EINVAL, "trxsig_elementwise_host: bad argument");
+  if (!h_x || n <= 0 || op < 0 || op > 4) return fail(c, TRXSIG_EINVAL, "trxsig_elementwise_host: bad argument");
   DeviceGuard g(c->device);
   Stager s(c);
   const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16);

@@ -9,6 +9,19 @@ TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
 // the normal-burst leg on bursts computed from the raw int16 stream (trxsig_rxfe_push_detect_demod_normal)
 int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
                       trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+// ... detectRACHBurst (d_len[b] = the burst's length as the front end cuts it) and demodulateBurst with caller-supplied
+// amplitude / TOA for the bursts whose d_enable[b] != 0, on such bursts
+int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
+                    uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr);
+int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
+                     float *d_soft, int nsoft, int soft_stride);
+// the receive front end's side of a fused push (trxsig_frontend.cpp): which bursts this push completes and how the kernels
+// find their samples (begin), and the window / clock bookkeeping once the kernels are enqueued (end)
+struct trxsig_rxfe;
+struct TrxRxfePush { TrxRxGen gen; int nb, tn0, n_streams; };
+int trx_rxfe_fused_begin(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, TrxRxfePush *out);
+int trx_rxfe_fused_end(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, const TrxRxfePush &p);
+trxsig_ctx *trx_rxfe_ctx(trxsig_rxfe *fe);
 // Transceiver group (trxsig_trxgroup.cpp), equalising TSC leg (sps = 1):
 //   estimate: analyzeTrafficBurst(requestChannel) + scaleVector(chan, 1/amp) + designDFE(chan, d_snr[b], 7) for the bursts with
 //     d_enable[b] != 0 only (Transceiver.cpp:341-349); nothing is written for the others.  Detection threshold 3.0 (:331).

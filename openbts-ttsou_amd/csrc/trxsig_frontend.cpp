@@ -76,6 +76,11 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
   fe->skip = 2 * fe->P;                                     // INHISTORY (radioInterface.h:38)
   fe->per_chunk = fe->n_out - fe->skip;
   fe->stride = ((long long)157 * fe->sps + (long long)max_chunks * fe->per_chunk + 63) & ~63LL;
+  // burst offsets (k_burst_index) and burst counts (S * bursts per push) are 32-bit
+  if (fe->stride * fe->S > 0x7fffffffLL || ((long long)max_chunks * fe->per_chunk / (156 * fe->sps) + 2) * fe->S > 0x7fffffffLL) {
+    delete fe;
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create: n_streams x max_chunks exceeds 2^31 samples (32-bit burst offsets): use several front ends", hipSuccess);
+  }
   Guard g(trxsig_device(c));
   const size_t rcv_b = sizeof(trx_c32) * (size_t)fe->stride * fe->S, tmp_b = sizeof(trx_c32) * (size_t)157 * fe->sps * fe->S;
   if (hipMalloc((void **)&fe->d_rcv, rcv_b) != hipSuccess || hipMalloc((void **)&fe->d_tmp, tmp_b) != hipSuccess ||
@@ -185,44 +190,43 @@ int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t
   return TRXSIG_OK;
 }
 
-int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int tsc, float detect_thresh,
-                                         float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr,
-                                         float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride, int32_t *h_tn, int cap_tn,
-                                         int *n_bursts) {
+}  // extern "C"
+
+trxsig_ctx *trx_rxfe_ctx(trxsig_rxfe *fe) { return fe ? fe->c : nullptr; }
+
+// the bursts a fused push completes and where the kernels find their samples
+int trx_rxfe_fused_begin(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, TrxRxfePush *out) {
   if (!fe) return TRXSIG_EINVAL;
   trxsig_ctx *c = fe->c;
-  if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks || !n_bursts)
-    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: bad argument", hipSuccess);
-  if (!fe->d_tpb) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: needs sps == 4 and a filter of at most 4*260 taps", hipSuccess);
-  if (fe->mode == 1) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: this front end is used through push / pop", hipSuccess);
-  fe->mode = 2;
-  // the bursts this push completes: "while (rcvSz > burst size)" (:375) over the uncut tail plus the new samples
+  if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks || !out)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "fused receive front end: bad argument", hipSuccess);
+  if (!fe->d_tpb) return trx_ctx_fail(c, TRXSIG_EINVAL, "fused receive front end: needs sps == 4 and a filter of at most 4*260 taps", hipSuccess);
+  if (fe->mode == 1) return trx_ctx_fail(c, TRXSIG_EINVAL, "fused receive front end: this front end is used through push / pop", hipSuccess);
+  // "while (rcvSz > burst size)" (:375) over the uncut tail plus the new samples
   const int avail = fe->tail + n_chunks * fe->per_chunk;
   int nb = 0, pos = 0, tn = fe->tn;
-  while (avail - pos > burst_len(tn, fe->sps)) {
-    if (h_tn && nb < cap_tn) h_tn[nb] = tn;
-    pos += burst_len(tn, fe->sps); tn = (tn + 1) & 7; nb++;
-  }
-  if (h_tn && nb > cap_tn) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: h_tn too small", hipSuccess);
-  *n_bursts = nb;
+  while (avail - pos > burst_len(tn, fe->sps)) { pos += burst_len(tn, fe->sps); tn = (tn + 1) & 7; nb++; }
+  TrxRxGen gen = {};
+  gen.raw = reinterpret_cast<const short2 *>(d_iq); gen.raw_stride = (long long)n_chunks * TRXSIG_OUTCHUNK;
+  gen.keep = fe->d_keep; gen.tpb = fe->d_tpb; gen.K = n_chunks; gen.swap = fe->swap;
+  gen.skipD = fe->skip + (fe->L - 1) / 2 / TRXSIG_OUTRATE;
+  // inOff = (skipD + r)*96/260 reaches the window's end (n_in) at r = rl0 and n_in + 1 at r = rl1
+  const int rl0 = (fe->n_in * fe->P + TRXSIG_OUTRATE - 1) / TRXSIG_OUTRATE - gen.skipD;
+  const int rl1 = ((fe->n_in + 1) * fe->P + TRXSIG_OUTRATE - 1) / TRXSIG_OUTRATE - gen.skipD;
+  gen.w0 = fe->per_chunk - rl0 > 0 ? fe->per_chunk - rl0 : 0;
+  gen.w1 = fe->per_chunk - rl1 > 0 ? fe->per_chunk - rl1 : 0;
+  gen.tail = fe->tail; gen.tn0 = fe->tn; gen.nb = nb; gen.sel = nullptr;
+  out->gen = gen; out->nb = nb; out->tn0 = fe->tn; out->n_streams = fe->S;
+  return TRXSIG_OK;
+}
+
+// once the kernels that read d_iq / the kept window are enqueued: keep the window of the last chunk, advance the clock
+int trx_rxfe_fused_end(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, const TrxRxfePush &p) {
+  trxsig_ctx *c = fe->c;
+  fe->mode = 2;
   Guard g(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
-  if (nb > 0) {
-    TrxRxGen gen = {};
-    gen.raw = reinterpret_cast<const short2 *>(d_iq); gen.raw_stride = (long long)n_chunks * TRXSIG_OUTCHUNK;
-    gen.keep = fe->d_keep; gen.tpb = fe->d_tpb; gen.K = n_chunks; gen.swap = fe->swap;
-    gen.skipD = fe->skip + (fe->L - 1) / 2 / TRXSIG_OUTRATE;
-    // inOff = (skipD + r)*96/260 reaches the window's end (n_in) at r = rl0 and n_in + 1 at r = rl1
-    const int rl0 = (fe->n_in * fe->P + TRXSIG_OUTRATE - 1) / TRXSIG_OUTRATE - gen.skipD;
-    const int rl1 = ((fe->n_in + 1) * fe->P + TRXSIG_OUTRATE - 1) / TRXSIG_OUTRATE - gen.skipD;
-    gen.w0 = fe->per_chunk - rl0 > 0 ? fe->per_chunk - rl0 : 0;
-    gen.w1 = fe->per_chunk - rl1 > 0 ? fe->per_chunk - rl1 : 0;
-    gen.tail = fe->tail; gen.tn0 = fe->tn; gen.nb = nb;
-    const int rc = trx_ctx_rx_normal(c, gen, fe->S * nb, tsc, detect_thresh, energy_thresh, d_flags, d_amp, d_toa, d_avgpwr, d_soft,
-                                     d_hard, nsoft, soft_stride);
-    if (rc != TRXSIG_OK) return rc;
-  }
-  // keep the window of the last chunk: [its 192-sample history | the chunk] (stream-ordered behind the kernels that read d_keep)
+  // [its 192-sample history | the chunk] (stream-ordered behind the kernels that read d_keep)
   const size_t kb = sizeof(short2) * (size_t)fe->n_in, rowb = sizeof(short2) * (size_t)n_chunks * TRXSIG_OUTCHUNK;
   const short2 *raw = reinterpret_cast<const short2 *>(d_iq);
   if (n_chunks >= 2) {
@@ -231,8 +235,35 @@ int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, i
     FE_HIP(c, hipMemcpy2DAsync(fe->d_keep, kb, fe->d_keep + TRXSIG_OUTCHUNK, kb, sizeof(short2) * TRXSIG_OUTHISTORY, fe->S, hipMemcpyDeviceToDevice, st));
     FE_HIP(c, hipMemcpy2DAsync(fe->d_keep + TRXSIG_OUTHISTORY, kb, raw, rowb, sizeof(short2) * TRXSIG_OUTCHUNK, fe->S, hipMemcpyDeviceToDevice, st));
   }
-  fe->tail = avail - pos; fe->tn = tn;
+  int pos = 0, tn = p.tn0;
+  for (int j = 0; j < p.nb; j++) { pos += burst_len(tn, fe->sps); tn = (tn + 1) & 7; }
+  fe->tail = fe->tail + n_chunks * fe->per_chunk - pos;
+  fe->tn = tn;
   return TRXSIG_OK;
+}
+
+extern "C" {
+
+int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int tsc, float detect_thresh,
+                                         float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr,
+                                         float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride, int32_t *h_tn, int cap_tn,
+                                         int *n_bursts) {
+  if (!fe) return TRXSIG_EINVAL;
+  trxsig_ctx *c = fe->c;
+  if (!n_bursts) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: bad argument", hipSuccess);
+  TrxRxfePush p;
+  int rc = trx_rxfe_fused_begin(fe, d_iq, n_chunks, &p);
+  if (rc != TRXSIG_OK) return rc;
+  // nothing of the front end's state has changed yet: a refused call leaves it as it was
+  if (p.nb > cap_tn) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_detect_demod_normal: cap_tn is smaller than the bursts this push completes (the output arrays hold n_streams * cap_tn entries)", hipSuccess);
+  if (h_tn) for (int j = 0; j < p.nb; j++) h_tn[j] = (p.tn0 + j) & 7;
+  *n_bursts = p.nb;
+  if (p.nb > 0) {
+    rc = trx_ctx_rx_normal(c, p.gen, fe->S * p.nb, tsc, detect_thresh, energy_thresh, d_flags, d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft,
+                           soft_stride);
+    if (rc != TRXSIG_OK) return rc;
+  }
+  return trx_rxfe_fused_end(fe, d_iq, n_chunks, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

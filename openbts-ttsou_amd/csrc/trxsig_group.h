@@ -34,6 +34,8 @@ struct TrxGroupArfcn {
 struct TrxGroupExpand {
   int S, n_slots, tn0, sps, fixed_len, G;                  // G: segment columns per slot
   long long slot_stride, arfcn_stride, base;               // burst (t, a) starts at sample base + t*slot_stride + a*arfcn_stride
+  int rx_nb;                                               // > 0: the bursts are a receive front end's (trxsig_rxgen.h); `off` gets
+                                                           // the row's burst index there, a*rx_nb + t, instead of a sample offset
   const uint16_t *gid;                                     // [8][S]: which segment column ARFCN a belongs to on timeslot tn
   const int32_t *pos;                                      // [8][S]: its place inside that segment
   const int32_t *seg_base;                                 // [n_slots][G]: first row of the segment, -1 = no correlator (OFF / IDLE)

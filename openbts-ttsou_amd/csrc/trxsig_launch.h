@@ -44,7 +44,7 @@ hipError_t trx_launch_normal_chain(hipStream_t st, int sps, const TrxTables *dT,
                                    unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg = 0);
 
 // free-standing vector primitives of sigProcLib.h (trxsig_prim.hip); op: 0 scaleVector, 1 GMSKRotate, 2 GMSKReverseRotate,
-// 3 vectorSlicer
+// 3 vectorSlicer, 4 offsetVector (scale[v] = the offset)
 int trx_convolve_out_len(int La, int Lb, int span, int cust_len);
 hipError_t trx_launch_convolve(hipStream_t st, const trx_c32 *a, const int32_t *a_off, const int32_t *a_len, int B, int max_out,
                                const trx_c32 *b, int Lb, int span, int flags, int correlate, int cust_start, int cust_len,
@@ -61,6 +61,17 @@ hipError_t trx_launch_elementwise(hipStream_t st, int op, const TrxTables *dT, t
                                   int B, int max_len, const trx_c32 *scale, int real_only);
 hipError_t trx_launch_decimate(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, int max_len,
                                int factor, trx_c32 *out, const int32_t *out_off);
+
+// the rest of sigProcLib.h's surface (trxsig_prim.hip): vectorNorm2 / vectorPower, frequencyShift, addVector, resampleVector
+hipError_t trx_launch_vector_norm2(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, float *norm2_out,
+                                   float *power_out);
+float trx_frequency_shift_max_phase(void);
+hipError_t trx_launch_frequency_shift(hipStream_t st, const TrxTables *dT, const trx_c32 *in, const int32_t *off, const int32_t *len,
+                                      int B, const float *freq, const float *start, int real_only, trx_c32 *out, float *final_phase);
+hipError_t trx_launch_add_vector(hipStream_t st, trx_c32 *x, const int32_t *xoff, const int32_t *xlen, const trx_c32 *y,
+                                 const int32_t *yoff, const int32_t *ylen, int B, int max_len);
+hipError_t trx_launch_resample_linear(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, float exp_factor,
+                                      const trx_c32 *end_point, trx_c32 *out, const int32_t *out_off);
 
 // RACH detect: ws = workspace of trx_rach_rec_floats(sps) * Bpad floats
 int trx_rach_rec_floats(int sps);
@@ -117,11 +128,20 @@ struct TrxRxGen {
   int K, swap, skipD;                                      // chunks in this push; I/Q swap; INHISTORY outputs skipped + (L-1)/2/Q
   int w0, w1;                                              // the last w0 (w1) outputs of a chunk have tap 0 (tap 1) beyond the window's end
   int tail, tn0, nb;                                       // uncut resampled samples before this push; TN of burst 0; bursts per stream
+  const int32_t *sel;                                      // optional: launch index b stands for burst sel[b] (= s*nb + j); NULL: b itself
 };
 hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const TrxRxGen &gen, int B, int tsc,
                                 float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp,
                                 float *toa, float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps,
                                 TrxProfiler *prof);
+// the other legs on bursts computed from the raw stream (the Transceiver group's fused front end): detectRACHBurst
+// (k_rach_front_rx + k_rach_peak2 + the hand-over in k_rach_fast_rx; ws as trx_launch_rach_fast) and demodulateBurst alone
+// with caller-supplied amplitude / TOA / enable flags (k_demod_rx)
+hipError_t trx_launch_rx_rach(hipStream_t st, const TrxTables *dT, const TrxRxGen &gen, const int32_t *len /* samples per burst */, int B,
+                              float detect_thresh, float energy_thresh, float amp_err, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp,
+                              float *toa, float *avgpwr, TrxProfiler *prof);
+hipError_t trx_launch_rx_demod(hipStream_t st, const TrxTables *dT, const TrxRxGen &gen, int B, const trx_c32 *amp, const float *toa,
+                               const uint8_t *flags, int need_mask, float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
 // pack: 0 = int16 I/Q -> complex float (swap: I/Q flipped), 1 = complex float -> int16 I/Q, 2 = fp16 I/Q -> complex float
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
                               TrxProfiler *prof, float gain = 1.0f /* pack == 1: scaleVector before the cast */);

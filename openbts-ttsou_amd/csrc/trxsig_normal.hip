@@ -618,6 +618,17 @@ hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTa
   return hipGetLastError();
 }
 
+hipError_t trx_launch_rx_demod(hipStream_t st, const TrxTables *dT, const TrxRxGen &gen, int B, const trx_c32 *amp, const float *toa,
+                               const uint8_t *flags, int need_mask, float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+  if (B <= 0 || nsoft <= 0) return hipSuccess;
+  if (nsoft > 148 || gen.nb <= 0) return hipErrorInvalidValue;
+  if (prof) prof->begin(TRXSIG_K_DEMOD, st);
+  k_demod_rx<4><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, gen, B, amp, toa, flags, need_mask,
+                                                                                                          soft, hard, nsoft, stride);
+  if (prof) prof->end(TRXSIG_K_DEMOD, st);
+  return hipGetLastError();
+}
+
 hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,

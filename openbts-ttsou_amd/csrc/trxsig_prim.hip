@@ -39,6 +39,24 @@ __global__ __launch_bounds__(256) void k_convolve(const cx *__restrict__ a, cons
   const bool ar = flags & 1, br = flags & 2;
   cx sum = mk(0, 0);
   float fsum = 0.0f;
+  if (!CORR && (flags & 4)) {
+    // b->getSymmetry() == ABSSYM (:369-398): half the taps, each applied to a[t-j] and to its partner a[t-Lb+j] (one
+    // sample further than the mirror image, as the reference has it); complex arithmetic whatever the real-only marks
+    // say.  The reference reads the partner without an upper bound in its fourth arm: a partner at or beyond a's end counts
+    // as zero here.
+    const int half = (Lb & 1) ? (Lb + 1) / 2 : Lb / 2;
+    for (int j = 0; j < half; j++) {
+      const int ia = t - j, is = t - Lb + j;
+      if (ia < 0) break;
+      const cx sv = (is >= 0 && is < La) ? av[is] : mk(0, 0);
+      if (ia == is) sum = cadd(sum, cmul(av[ia], b[j]));
+      else if (ia < La && is >= 0) sum = cadd(sum, cmul(cadd(av[ia], sv), b[j]));
+      else if (ia < La) sum = cadd(sum, cmul(av[ia], b[j]));
+      else if (is >= 0) sum = cadd(sum, cmul(sv, b[j]));
+    }
+    out[out_off[v] + o] = sum;
+    return;
+  }
   for (int j = 0; j < Lb; j++) {
     const int ia = t - j;
     if (ia < 0) break;                                     // :327 "if (aP < aStart) break"
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(64) void k_energy_detect(const cx *__restrict__ in,
 // element-wise: scaleVector (:713-730), GMSKRotate / GMSKReverseRotate (:232-264), vectorSlicer (:507-519),
 // decimateVector (:1039-1053)
 // ---------------------------------------------------------------------------------------------
-enum { EW_SCALE = 0, EW_ROTATE = 1, EW_REVROT = 2, EW_SLICE = 3 };
+enum { EW_SCALE = 0, EW_ROTATE = 1, EW_REVROT = 2, EW_SLICE = 3, EW_OFFSET = 4 };
 template <int OP>
 __global__ __launch_bounds__(256) void k_elementwise(const TrxTables *__restrict__ T, cx *__restrict__ x, const int32_t *__restrict__ off,
                                                      const int32_t *__restrict__ len, const cx *__restrict__ scale, int real_only) {
@@ -221,6 +239,9 @@ __global__ __launch_bounds__(256) void k_elementwise(const TrxTables *__restrict
   if (OP == EW_SCALE) {
     const cx s = scale[v];
     r = real_only ? cmulr(s, xv.r) : cmul(xv, s);          // :725 xP->real()*scale -> Complex*Real; :719 *xP * scale
+  } else if (OP == EW_OFFSET) {
+    const cx o = scale[v];                                 // offsetVector (:760-777): *xP += offset / xP->real() + offset
+    r = real_only ? mk(o.r + xv.r, o.i) : cadd(xv, o);
   } else if (OP == EW_ROTATE || OP == EW_REVROT) {
     if (k >= 157 * (int)T->sps) return;                    // the tables hold 157*sps entries (:215-216)
     const cx rt = OP == EW_ROTATE ? T->rot[k] : T->rev[k];
@@ -233,6 +254,114 @@ __global__ __launch_bounds__(256) void k_elementwise(const TrxTables *__restrict
     r = mk(sv, 0.0f);
   }
   *p = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The part of sigProcLib.h the burst path never calls (sigProcLib.h:108-111, 149-153, 184-185, 352-354).
+// vectorNorm2 / vectorPower (:146-160): the powers summed in index order.  One wave per vector.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_vector_norm2(const cx *__restrict__ in, const int32_t *__restrict__ off,
+                                                     const int32_t *__restrict__ len, float *__restrict__ norm2_out,
+                                                     float *__restrict__ power_out) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int n = len[v] < 0 ? 0 : len[v];
+  const cx *x = in + off[v];
+  float energy = 0.0f;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const float p = i < n ? norm2(x[i]) : 0.0f;
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int q = 0; q < cnt; q++) energy += __shfl(p, q, 64);
+  }
+  if (lane == 0) {
+    if (norm2_out) norm2_out[v] = energy;
+    if (power_out) power_out[v] = energy / (float)(size_t)n;          // vectorNorm2(x)/x.size()
+  }
+}
+
+// expjLookup (:192-204) with its subtract-one range reduction bounded: the host entry points refuse phases beyond
+// TRX_FSHIFT_MAXPHASE, for which the reference's loop would run for ever (a float that large no longer changes by 1) or for
+// a very long time
+#define TRX_FSHIFT_MAXPHASE 25000.0f
+__device__ __forceinline__ cx dev_expj_lookup(const TrxTables *__restrict__ T, float x) {
+  float arg = x * (1 / TRX_2PI_F);
+  for (int it = 0; it < 8192 && arg > 1.0F; it++) arg -= 1.0F;
+  for (int it = 0; it < 8192 && arg < 0.0F; it++) arg += 1.0F;
+  const float argT = arg * (float)TRX_TABLESIZE;
+  int argI = (int)argT;
+  argI = argI < 0 ? 0 : (argI > TRX_TABLESIZE ? TRX_TABLESIZE : argI);   // (only a phase the host refused could get here)
+  const float delta = argT - argI;
+  const float iDelta = 1.0F - delta;
+  return mk(iDelta * T->cosT[argI] + delta * T->cosT[argI + 1], iDelta * T->sinT[argI] + delta * T->sinT[argI + 1]);
+}
+// frequencyShift (:432-471): y[k] = x[k] * expjLookup(phase_k), phase_k = startPhase + freq + ... + freq (k sequential float
+// additions).  One wave per vector; every lane runs the whole chain of additions and keeps the phases of its own elements.
+__global__ __launch_bounds__(64) void k_frequency_shift(const TrxTables *__restrict__ T, const cx *__restrict__ in,
+                                                        const int32_t *__restrict__ off, const int32_t *__restrict__ len,
+                                                        const float *__restrict__ freq, const float *__restrict__ start,
+                                                        int real_only, cx *__restrict__ out, float *__restrict__ final_phase) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int n = len[v] < 0 ? 0 : len[v];
+  const cx *x = in + off[v];
+  cx *y = out + off[v];
+  const float f = freq[v];
+  float phase = start[v];
+  for (int base = 0; base < n; base += 64) {
+    float mine = phase;
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int q = 0; q < cnt; q++) {
+      mine = q == lane ? phase : mine;
+      phase += f;                                          // :454, :460
+    }
+    const int i = base + lane;
+    if (i < n) {
+      const cx e = dev_expj_lookup(T, mine);
+      const cx xv = x[i];
+      y[i] = real_only ? cmulr(e, xv.r) : cmul(xv, e);     // :453 expjLookup(phase)*real(); :459 (*xP)*expjLookup(phase)
+    }
+  }
+  if (lane == 0 && final_phase) final_phase[v] = phase;
+}
+
+// addVector (:746-758): x[k] = x[k] + y[k] over the shorter of the two
+__global__ __launch_bounds__(256) void k_add_vector(cx *__restrict__ x, const int32_t *__restrict__ xoff, const int32_t *__restrict__ xlen,
+                                                    const cx *__restrict__ y, const int32_t *__restrict__ yoff,
+                                                    const int32_t *__restrict__ ylen) {
+  const int v = blockIdx.y;
+  const int n = xlen[v] < ylen[v] ? xlen[v] : ylen[v];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  cx *p = x + xoff[v] + k;
+  *p = cadd(*p, y[yoff[v] + k]);
+}
+
+// resampleVector (:1213-1243) AS IT BEHAVES: the loop never advances its output iterator, so every interpolated value is
+// written to element 0 and the rest of the freshly allocated (zeroed) vector stays zero.  A lane per vector.
+__global__ __launch_bounds__(64) void k_resample_linear(const cx *__restrict__ in, const int32_t *__restrict__ off,
+                                                        const int32_t *__restrict__ len, int B, float expFactor,
+                                                        const cx *__restrict__ end_point, cx *__restrict__ out,
+                                                        const int32_t *__restrict__ out_off) {
+  const int v = blockIdx.x * 64 + threadIdx.x;
+  if (v >= B) return;
+  const int n = len[v] < 0 ? 0 : len[v];
+  const cx *x = in + off[v];
+  cx *y = out + out_off[v];
+  const int nout = (int)ceilf((float)(size_t)n * expFactor);
+  for (int k = 0; k < nout; k++) y[k] = mk(0, 0);
+  const cx endPoint = end_point[v];
+  float t = 0.0f;
+  while (nout > 0) {
+    const unsigned tLow = (unsigned)floorf(t);
+    const unsigned tHigh = tLow + 1;
+    if (tLow > (unsigned)n - 1) break;
+    if (tHigh > (unsigned)n) break;
+    const cx lowPoint = x[tLow];
+    const cx highPoint = (tHigh == (unsigned)n) ? endPoint : x[tHigh];
+    const cx a = mk((float)tHigh - t, 0.0f);               // complex a = (tHigh-t)
+    const cx b = mk(t - (float)tLow, 0.0f);
+    y[0] = cadd(cmul(a, lowPoint), cmul(b, highPoint));
+    t = (float)((double)t + 1.0 / (double)expFactor);      // t += 1.0/expFactor
+  }
 }
 
 __global__ __launch_bounds__(256) void k_decimate(const cx *__restrict__ in, const int32_t *__restrict__ off,
@@ -306,6 +435,7 @@ hipError_t trx_launch_elementwise(hipStream_t st, int op, const TrxTables *dT, t
     case EW_ROTATE: k_elementwise<EW_ROTATE><<<grid, block, 0, st>>>(dT, x, off, len, scale, real_only); break;
     case EW_REVROT: k_elementwise<EW_REVROT><<<grid, block, 0, st>>>(dT, x, off, len, scale, real_only); break;
     case EW_SLICE: k_elementwise<EW_SLICE><<<grid, block, 0, st>>>(dT, x, off, len, scale, real_only); break;
+    case EW_OFFSET: k_elementwise<EW_OFFSET><<<grid, block, 0, st>>>(dT, x, off, len, scale, real_only); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -315,5 +445,31 @@ hipError_t trx_launch_decimate(hipStream_t st, const trx_c32 *in, const int32_t 
                                int factor, trx_c32 *out, const int32_t *out_off) {
   if (B <= 0 || max_len <= 0) return hipSuccess;
   k_decimate<<<dim3((max_len / factor + 255) / 256 + 1, B), dim3(256), 0, st>>>(in, off, len, factor, out, out_off);
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_vector_norm2(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, float *norm2_out,
+                                   float *power_out) {
+  if (B <= 0) return hipSuccess;
+  k_vector_norm2<<<dim3(B), dim3(64), 0, st>>>(in, off, len, norm2_out, power_out);
+  return hipGetLastError();
+}
+float trx_frequency_shift_max_phase(void) { return TRX_FSHIFT_MAXPHASE; }
+hipError_t trx_launch_frequency_shift(hipStream_t st, const TrxTables *dT, const trx_c32 *in, const int32_t *off, const int32_t *len,
+                                      int B, const float *freq, const float *start, int real_only, trx_c32 *out, float *final_phase) {
+  if (B <= 0) return hipSuccess;
+  k_frequency_shift<<<dim3(B), dim3(64), 0, st>>>(dT, in, off, len, freq, start, real_only, out, final_phase);
+  return hipGetLastError();
+}
+hipError_t trx_launch_add_vector(hipStream_t st, trx_c32 *x, const int32_t *xoff, const int32_t *xlen, const trx_c32 *y,
+                                 const int32_t *yoff, const int32_t *ylen, int B, int max_len) {
+  if (B <= 0 || max_len <= 0) return hipSuccess;
+  k_add_vector<<<dim3((max_len + 255) / 256, B), dim3(256), 0, st>>>(x, xoff, xlen, y, yoff, ylen);
+  return hipGetLastError();
+}
+hipError_t trx_launch_resample_linear(hipStream_t st, const trx_c32 *in, const int32_t *off, const int32_t *len, int B, float exp_factor,
+                                      const trx_c32 *end_point, trx_c32 *out, const int32_t *out_off) {
+  if (B <= 0) return hipSuccess;
+  k_resample_linear<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(in, off, len, B, exp_factor, end_point, out, out_off);
   return hipGetLastError();
 }

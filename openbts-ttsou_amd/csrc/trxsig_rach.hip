@@ -4,6 +4,7 @@
 // reference's order; built with -ffp-contract=off).
 #include "trxsig_bisect.h"
 #include "trxsig_corr.h"      // energy_chain (the DPP row-shift energy sum)
+#include "trxsig_rxgen.h"     // bursts computed from the raw int16 stream (k_rach_front_rx)
 
 namespace {
 
@@ -462,12 +463,54 @@ __device__ __forceinline__ void rach_steer(const cx *Zl, const cx (&zc)[8], floa
   }
 }
 
+// Where a burst's samples come from: packed complex float32 in memory, or (RachRxSrc) computed from the raw int16 stream
+// of the receive front end, four multiply-adds per sample (trxsig_rxgen.h) -- the detector stages its burst twice and
+// reads the energy window, that is all it ever asks of the samples.
+//   stage<NIT, XF>(lane, xv): xv[it] = sample lane + 64 it - XF, zero outside [0, N)
+struct RachMemSrc {
+  const cx *x;
+  int N;
+  bool good;
+  __device__ __forceinline__ RachMemSrc(const cx *samples, const int32_t *offset, const int32_t *length, int b, int sps) {
+    const int off = offset[b];
+    N = length[b];
+    good = (off >= 0) && (N >= 92 * sps) && (N <= 157 * sps) && (N % sps == 0);
+    x = samples + (good ? off : 0);
+  }
+  template <int NIT, int XF>
+  __device__ __forceinline__ void stage(int lane, cx (&xv)[NIT]) const {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int n = lane + 64 * it - XF;
+      xv[it] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
+    }
+  }
+  __device__ __forceinline__ cx at(int n) const { return x[n]; }
+};
+struct RachRxSrc {
+  RxGlobalSrc g;
+  int N;
+  bool good;
+  __device__ __forceinline__ RachRxSrc(const TrxRxGen &gen, int b) : g(gen, b), N(g.u.N), good(true) {}
+  template <int NIT, int XF>
+  __device__ __forceinline__ void stage(int lane, cx (&xv)[NIT]) const {
+    static_assert(XF < 3 * 64 - 63, "every lane is inside the burst from the third round on");
+    RxIdx ix = g.index(0);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int n = lane + 64 * it - XF;
+      if (it < 3) ix = g.index(n >= 0 ? n : 0); else ix = rx_step<64>(ix);
+      xv[it] = (n >= 0 && n < N) ? g.at(ix, n) : mk(0, 0);
+    }
+  }
+  __device__ __forceinline__ cx at(int n) const { return g.at(g.index(n), n); }
+};
+
 #define RACH_SKIP (-1000)                                   // record marker: k_rach_front has already written this burst's outputs
 // SPLIT: stop after step 2 and hand the exact neighbourhood, M, the energy and the three candidate valley sums
 // (rint(toa) = M-1, M, M+1) to k_rach_peak2 through the record (rec: 25 complex slots, vsum: 3 float slots, [slot][Bpad]).
-template <int SPS, bool SPLIT>
-__device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__restrict__ T, const cx *__restrict__ samples,
-                                                const int32_t *__restrict__ offset, const int32_t *__restrict__ length,
+template <int SPS, bool SPLIT, typename SRC>
+__device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__restrict__ T, const SRC &src,
                                                 float detect_thresh, float energy_thresh, float amp_err,
                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                 float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
@@ -501,16 +544,14 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
 #define TRX_STAMP_FLUSH()
 #endif
   TRX_STAMP();
-  const int off = offset[b], N = length[b];
-  const bool good = (off >= 0) && (N >= 92 * SPS) && (N <= 157 * SPS) && (N % SPS == 0);
-  if (!good) {
+  const int N = src.N;
+  if (!src.good) {
     if (lane == 0) {
       flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = 0.0f;
       if (SPLIT) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(RACH_SKIP), 0.0f);
     }
     return;
   }
-  const cx *x = samples + off;
   cx *X = xs[wave];
   cx *Z = xs[wave];                                        // the same storage, at different times
   float *PWw = side;
@@ -523,11 +564,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   {                                                        // every load in flight before the first LDS store
     constexpr int NIT = (Q::XPAD + 63) / 64;
     cx xv[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int n = lane + 64 * it - Q::XF;
-      xv[it] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
-    }
+    src.template stage<NIT, Q::XF>(lane, xv);
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int i = lane + 64 * it;
@@ -544,7 +581,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   for (int q = 0; q < R::NEQ; q++) {
     const int i = (lane & 15) + 16 * q;
     cx v = mk(0, 0);
-    if (i < R::NE) v = x[i];
+    if (i < R::NE) v = src.at(i);
     nrm[q] = norm2(v);
   }
   float energy = energy_chain<SPS, 0>(0.0f, nrm);
@@ -604,11 +641,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     {
       constexpr int NIT = (Q::XPAD + 63) / 64;
       cx xv[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int n = lane + 64 * it - Q::XF;
-        xv[it] = (n >= 0 && n < N) ? x[n] : mk(0, 0);
-      }
+      src.template stage<NIT, Q::XF>(lane, xv);
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int i = lane + 64 * it;
@@ -827,9 +860,25 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
                                                    const int32_t *__restrict__ list, const int32_t *__restrict__ count) {
   const int n = list ? (*count < B ? *count : B) : B;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {        // (without a list: grid = B, one burst per workgroup)
-    rach_fast_burst<SPS, false>(list ? list[i] : i, T, samples, offset, length, detect_thresh, energy_thresh, amp_err, flags, amp_out,
+    const int b = list ? list[i] : i;
+    rach_fast_burst<SPS, false>(b, T, RachMemSrc(samples, offset, length, b, SPS), detect_thresh, energy_thresh, amp_err, flags, amp_out,
                                 toa_out, avgpwr_out, nullptr, nullptr, 0);
     wave_lds_fence();                                      // the next burst reuses the LDS
+  }
+}
+// the same on bursts computed from the raw stream (hand-over list only)
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_fast_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B, float detect_thresh,
+                                                      float energy_thresh, float amp_err, uint8_t *__restrict__ flags,
+                                                      cx *__restrict__ amp_out, float *__restrict__ toa_out,
+                                                      float *__restrict__ avgpwr_out, const int32_t *__restrict__ list,
+                                                      const int32_t *__restrict__ count) {
+  const int n = *count < B ? *count : B;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int b = list[i];
+    rach_fast_burst<SPS, false>(b, T, RachRxSrc(a, b), detect_thresh, energy_thresh, amp_err, flags, amp_out, toa_out, avgpwr_out,
+                                nullptr, nullptr, 0);
+    wave_lds_fence();
   }
 }
 
@@ -844,8 +893,21 @@ __global__ __launch_bounds__(64) void k_rach_front(const TrxTables *__restrict__
                                                     int32_t *__restrict__ count) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;     // k_rach_peak2's hand-over list starts empty
   if ((int)blockIdx.x < B)
-    rach_fast_burst<SPS, true>(blockIdx.x, T, samples, offset, length, 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out, avgpwr_out,
-                               rec, vsum, Bpad);
+    rach_fast_burst<SPS, true>(blockIdx.x, T, RachMemSrc(samples, offset, length, blockIdx.x, SPS), 0.0f, energy_thresh, amp_err, flags,
+                               amp_out, toa_out, avgpwr_out, rec, vsum, Bpad);
+}
+// ... on bursts computed from the raw int16 stream of the receive front end (no resampled stream in memory)
+template <int SPS>
+__global__ __launch_bounds__(64) void k_rach_front_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B, float energy_thresh,
+                                                       float amp_err, uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                       float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
+                                                       cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
+                                                       int32_t *__restrict__ count) {
+  static_assert(SPS == 4, "the fused front end is the 260 : 96 resampler");
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;
+  if ((int)blockIdx.x < B)
+    rach_fast_burst<SPS, true>(blockIdx.x, T, RachRxSrc(a, blockIdx.x), 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out,
+                               avgpwr_out, rec, vsum, Bpad);
 }
 
 // steps 3-4 with TWO lanes per burst (pair_bisect): peakDetect's bisection on the exact neighbourhood and
@@ -1009,6 +1071,27 @@ hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, co
     case 4: launch_rach_fast<4>(st, dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, ws, Bpad, split, flags, amp, toa, avgpwr, prof); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// detectRACHBurst on bursts computed from the raw int16 stream (sps 4): k_rach_front_rx + k_rach_peak2 + hand-over; len[b] =
+// the burst's length in samples (the slot schedule, as the front end cuts it)
+hipError_t trx_launch_rx_rach(hipStream_t st, const TrxTables *dT, const TrxRxGen &gen, const int32_t *len, int B, float detect_thresh,
+                              float energy_thresh, float amp_err, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp, float *toa,
+                              float *avgpwr, TrxProfiler *prof) {
+  if (B <= 0) return hipSuccess;
+  constexpr int S = 4;
+  trx_c32 *rec = (trx_c32 *)ws;
+  float *vsum = ws + (size_t)2 * 25 * Bpad;
+  int32_t *list = (int32_t *)(vsum + (size_t)4 * Bpad);
+  int32_t *count = list + Bpad;
+  if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
+  k_rach_front_rx<S><<<dim3(B), dim3(64), 0, st>>>(dT, gen, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum, Bpad, count);
+  if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
+  k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr, list, count);
+  k_rach_fast_rx<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, gen, B, detect_thresh, energy_thresh, amp_err, flags, amp, toa, avgpwr,
+                                                                  list, count);
+  if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
   return hipGetLastError();
 }
 

@@ -17,11 +17,13 @@ namespace {
 constexpr int RXG_PC = 2340, RXG_P = 260, RXG_Q = 96, RXG_NIN = 1056, RXG_CH = 864, RXG_HIST = 192;
 
 struct RxBurst { int s, g0, N; };
-// burst b = s*nb + j of this call: 156 symbols, 157 when TN % 4 == 0 (radioInterface.cpp:370-378)
+// burst s*nb + j of this call (launch index b itself, or a.sel[b] when a selection is given): 156 symbols, 157 when
+// TN % 4 == 0 (radioInterface.cpp:370-378)
 __device__ __forceinline__ RxBurst rx_burst(const TrxRxGen &a, int b) {
   RxBurst u;
-  u.s = b / a.nb;
-  const int j = b - u.s * a.nb, tn = a.tn0 + j;
+  const int cell = a.sel ? a.sel[b] : b;
+  u.s = cell / a.nb;
+  const int j = cell - u.s * a.nb, tn = a.tn0 + j;
   const int long_before = (tn + 3) / 4 - (a.tn0 + 3) / 4;
   u.g0 = (156 * j + long_before) * 4 - a.tail;
   u.N = (156 + ((tn & 3) == 0)) * 4;
@@ -97,5 +99,28 @@ __device__ __forceinline__ cx rx_sample(const cx *X, const float4 *TPB, int jlo,
   sum = cadd(sum, cmulr(x[-3], tp.w));
   return sum;
 }
+
+// Resampled sample n of a burst straight from global memory (no staged stretch): four 4-byte loads that neighbouring lanes
+// share through the vector cache.  For kernels whose LDS is spoken for (the access-burst detector).
+struct RxGlobalSrc {
+  TrxRxGen a;
+  RxBurst u;
+  int nb;                                                  // samples from the burst's start to the next chunk boundary
+  __device__ __forceinline__ RxGlobalSrc(const TrxRxGen &gen, int b) : a(gen), u(rx_burst(gen, b)), nb(rx_boundary(u.g0)) {}
+  __device__ __forceinline__ cx at(RxIdx ix, int n) const {
+    float4 tp = a.tpb[ix.n];
+    const int d = nb - n;
+    tp.x = (unsigned)(d - 1) < (unsigned)a.w0 ? 0.0f : tp.x;
+    tp.y = (unsigned)(d - 1) < (unsigned)a.w1 ? 0.0f : tp.y;
+    const short2 r0 = rx_raw(a, u.s, ix.j0), r1 = rx_raw(a, u.s, ix.j0 - 1), r2 = rx_raw(a, u.s, ix.j0 - 2), r3 = rx_raw(a, u.s, ix.j0 - 3);
+    cx sum = mk(0, 0);
+    sum = cadd(sum, cmulr(rx_widen(a, r0), tp.x));
+    sum = cadd(sum, cmulr(rx_widen(a, r1), tp.y));
+    sum = cadd(sum, cmulr(rx_widen(a, r2), tp.z));
+    sum = cadd(sum, cmulr(rx_widen(a, r3), tp.w));
+    return sum;
+  }
+  __device__ __forceinline__ RxIdx index(int n) const { return rx_index(u.g0 + n, a.skipD); }
+};
 
 }  // namespace

@@ -195,18 +195,26 @@ int trxsig_trxgroup_expected_corr_type(const trxsig_trxgroup *g, int arfcn, int 
   return (g && arfcn >= 0 && arfcn < g->S && tn >= 0 && tn < 8) ? g->ctl[(size_t)arfcn].expectedCorrType(tn, fn) : TRXSIG_CORR_OFF;
 }
 
-int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_t slot_stride, int64_t arfcn_stride, int burst_len,
-                         int fn, int tn, int n_slots, trxsig_trxgroup_result *res) {
-  if (!g) return TRXSIG_EINVAL;
+}  // extern "C"
+
+namespace {
+// where a pull's bursts are: packed complex float32 in device memory (burst (t, a) at t*slot_stride + a*arfcn_stride), or
+// computed by the detectors from the raw int16 stream of a receive front end (gen != NULL; burst (t, a) = its a*nb + t)
+struct PullSource {
+  const trxsig_c32 *d_samples = nullptr;
+  int64_t slot_stride = 0, arfcn_stride = 0;
+  int burst_len = 0;
+  const TrxRxGen *gen = nullptr;
+};
+
+int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_slots, trxsig_trxgroup_result *res) {
   trxsig_ctx *c = g->c;
   const int S = g->S, sps = g->sps;
-  if (!d_samples || n_slots <= 0 || fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7 || slot_stride < 0 || arfcn_stride < 0 || burst_len < 0 ||
-      (burst_len > 0 && (burst_len % sps != 0 || burst_len < 92 * sps || burst_len > 157 * sps)))
-    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: bad argument", hipSuccess);
+  const trxsig_c32 *d_samples = src.d_samples;
+  const int burst_len = src.burst_len;
   const long long cells = (long long)n_slots * S;
-  const long long last = (long long)(n_slots - 1) * slot_stride + (long long)(S - 1) * arfcn_stride + 157LL * sps;
-  if (cells > std::numeric_limits<int32_t>::max() / 2 || last > std::numeric_limits<int32_t>::max())
-    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: the batch's sample offsets must stay below 2^31 (split the call)", hipSuccess);
+  if (cells > std::numeric_limits<int32_t>::max() / 2)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: too many bursts in one call (split it)", hipSuccess);
   Guard gd(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   g->have = false;
@@ -257,7 +265,7 @@ int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_
   G_HIP(g, hipMemcpyAsync(g->seg.p, g->h_seg.data(), sizeof(int32_t) * g->h_seg.size(), hipMemcpyHostToDevice, st));
   TrxGroupExpand ex = {};
   ex.S = S; ex.n_slots = n_slots; ex.tn0 = tn; ex.sps = sps; ex.fixed_len = burst_len; ex.G = G;
-  ex.slot_stride = slot_stride; ex.arfcn_stride = arfcn_stride; ex.base = 0;
+  ex.slot_stride = src.slot_stride; ex.arfcn_stride = src.arfcn_stride; ex.base = 0; ex.rx_nb = src.gen ? src.gen->nb : 0;
   ex.gid = g->d_gid; ex.pos = g->d_pos; ex.seg_base = g->seg.p; ex.rowmap = g->rowmap.p; ex.off = g->off.p; ex.len = g->len.p;
   G_HIP(g, trx_launch_group_expand(st, ex));
 
@@ -265,7 +273,16 @@ int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_
   for (int k = 0; k < TRXG_NCLASS; k++) {
     if (!count[k]) continue;
     const int b0 = base[k];
-    if (k < TRXG_CLASS_RACH)
+    if (src.gen) {                                          // the detectors compute their samples from the raw stream; off = the selection
+      TrxRxGen gen = *src.gen;
+      gen.sel = g->off.p + b0;
+      if (k < TRXG_CLASS_RACH)
+        G_LIB(trx_ctx_rx_normal(c, gen, count[k], k, 3.0f, -1.0f, g->flags.p + b0, (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0,
+                                g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
+      else
+        G_LIB(trx_ctx_rx_rach(c, gen, g->len.p + b0, count[k], 5.0f, -1.0f, g->flags.p + b0, (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0,
+                              g->avgpwr.p + b0));
+    } else if (k < TRXG_CLASS_RACH)
       G_LIB(trxsig_detect_demod_normal_batch(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], k, 3.0f, -1.0f, g->flags.p + b0,
                                              (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0, g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
     else
@@ -294,12 +311,16 @@ int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_
       G_HIP(g, trx_launch_group_toa_eq(st, n_tsc, g->gate.p, g->toa.p, g->tap_ix.p, g->chan_off.p, g->toa_eq.p));
       G_LIB(trx_ctx_group_equalize(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa_eq.p, g->gate.p,
                                    (const trxsig_c32 *)g->w_tab.p, (const trxsig_c32 *)g->b_tab.p, g->tap_ix.p, g->soft.p, kSoft, kSoft));
-    } else {
+    } else if (!src.gen) {
       G_LIB(trxsig_demodulate_batch(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa.p, g->gate.p, g->soft.p,
                                     nullptr, kSoft, kSoft));
     }
   }
-  if (n_rows > n_tsc)                                       // :385-388
+  if (src.gen) {                                            // normal and access bursts alike: demodulateBurst on every gated row
+    TrxRxGen gen = *src.gen;
+    gen.sel = g->off.p;
+    G_LIB(trx_ctx_rx_demod(c, gen, n_rows, (const trxsig_c32 *)g->amp.p, g->toa.p, g->gate.p, g->soft.p, kSoft, kSoft));
+  } else if (n_rows > n_tsc)                                // :385-388
     G_LIB(trxsig_demodulate_batch(c, d_samples, g->off.p + n_tsc, g->len.p + n_tsc, n_rows - n_tsc, (const trxsig_c32 *)g->amp.p + n_tsc,
                                   g->toa.p + n_tsc, g->gate.p + n_tsc, g->soft.p + (size_t)n_tsc * kSoft, nullptr, kSoft, kSoft));
   if (equalize) G_HIP(g, trx_launch_group_commit(st, S, g->d_state, g->w_tab.p, g->b_tab.p, g->chan_off.p));
@@ -311,6 +332,48 @@ int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_
     res->d_toa = g->toa.p; res->d_avgpwr = g->avgpwr.p; res->d_threshold = g->thr_after.p; res->d_soft = g->soft.p; res->soft_stride = kSoft;
   }
   return TRXSIG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_t slot_stride, int64_t arfcn_stride, int burst_len,
+                         int fn, int tn, int n_slots, trxsig_trxgroup_result *res) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  const int S = g->S, sps = g->sps;
+  if (!d_samples || n_slots <= 0 || fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7 || slot_stride < 0 || arfcn_stride < 0 || burst_len < 0 ||
+      (burst_len > 0 && (burst_len % sps != 0 || burst_len < 92 * sps || burst_len > 157 * sps)))
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: bad argument", hipSuccess);
+  const long long last = (long long)(n_slots - 1) * slot_stride + (long long)(S - 1) * arfcn_stride + 157LL * sps;
+  if (last > std::numeric_limits<int32_t>::max())
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull: the batch's sample offsets must stay below 2^31 (split the call)", hipSuccess);
+  PullSource src;
+  src.d_samples = d_samples; src.slot_stride = slot_stride; src.arfcn_stride = arfcn_stride; src.burst_len = burst_len;
+  return pull_core(g, src, fn, tn, n_slots, res);
+}
+
+int trxsig_trxgroup_pull_rxfe(trxsig_trxgroup *g, trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int fn, int *n_slots,
+                              trxsig_trxgroup_result *res) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  if (!fe || !n_slots || fn < 0 || fn >= kHyperframe) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: bad argument", hipSuccess);
+  if (trx_rxfe_ctx(fe) != c) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: the front end lives on another context", hipSuccess);
+  if (g->leg != TRXSIG_TSCLEG_DEMOD || g->sps != 4)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: the fused front end needs sps == 4 and the demodulating TSC leg", hipSuccess);
+  TrxRxfePush p;
+  G_LIB(trx_rxfe_fused_begin(fe, d_iq, n_chunks, &p));
+  if (p.n_streams != g->S) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: one stream per ARFCN, please", hipSuccess);
+  *n_slots = p.nb;
+  if (p.nb > 0) {
+    PullSource src;
+    src.gen = &p.gen;
+    G_LIB(pull_core(g, src, fn, p.tn0, p.nb, res));
+  } else {
+    g->have = false;
+    if (res) std::memset(res, 0, sizeof *res);
+  }
+  return trx_rxfe_fused_end(fe, d_iq, n_chunks, p);
 }
 
 int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft, int *h_rssi, int *h_timing, double *h_threshold) {

@@ -111,7 +111,8 @@ class RxFrontEnd:
         if soft_stride is None:
             soft_stride = soft.shape[-1]
         nb = C.c_int()
-        tn = np.zeros(max_bursts, np.int32)
+        max_bursts = min(max_bursts, flags.numel() // self.S)    # cap_tn: what the output arrays hold, in bursts per stream
+        tn = np.zeros(max(max_bursts, 1), np.int32)
         p = lambda t: None if t is None else t.data_ptr()
         self.ctx._chk(self.L.trxsig_rxfe_push_detect_demod_normal(self.h, iq.data_ptr(), iq.shape[1] // OUTCHUNK, tsc, detect_thresh,
                                                                   energy_thresh, p(flags), p(amp), p(toa), p(avgpwr), p(soft), p(hard),

@@ -236,6 +236,68 @@ def gen_primitives():
     save("primitives.npz", **kw)
 
 
+def gen_extras():
+    """The part of sigProcLib.h the burst path never calls (dB, dBinv, vectorNorm2 / vectorPower, frequencyShift, sinc,
+    addVector, offsetVector, gaussianNoise with a fixed srand seed, resampleVector, convolve's ABSSYM form), from the
+    compiled reference."""
+    rng = np.random.default_rng(700)
+    r = refbind.Ref(1)
+
+    def cn(n, scale=1.0):
+        return (scale * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    kw = {}
+    xs = np.concatenate([np.float32([0.0, -1.0, 1.0, 1.5, 0.5, 0.25, 1e-3, 3e-7, 1e-19, 0.99999994, 0.1]),
+                         (10.0 ** rng.uniform(-20, 0.2, 40)).astype(np.float32)])
+    kw["db_x"] = xs; kw["db_y"] = np.array([r.dB(v) for v in xs], np.float32)
+    xi = np.concatenate([np.float32([0.0, 1.0, -200.0, -250.0, -3.0, -0.5, -10.7, -199.5, -12.0, -24.0]),
+                         rng.uniform(-210, 2, 40).astype(np.float32)])
+    kw["dbinv_x"] = xi; kw["dbinv_y"] = np.array([r.dBinv(v) for v in xi], np.float32)
+    sx = np.concatenate([np.float32([0.0, 0.01, -0.01, 0.0099, 3.1415927, -3.1415927, 40.0, -77.7]),
+                         rng.uniform(-35, 35, 60).astype(np.float32)])
+    kw["sinc_x"] = sx; kw["sinc_y"] = np.array([r.sinc(v) for v in sx], np.float32)
+    vec = [cn(n, 100.0) for n in (1, 2, 63, 64, 65, 157, 628, 1056)]
+    x, off, lens = pack(vec)
+    kw.update(vec_x=x, vec_off=off, vec_len=lens, vec_norm2=np.array([r.vector_norm2(v) for v in vec], np.float32),
+              vec_power=np.array([r.vector_power(v) for v in vec], np.float32))
+    # frequencyShift: complex and real-only inputs, phases that wrap both ways
+    fs = []
+    for k, v in enumerate(vec):
+        freq = np.float32([0.0, 0.48 * np.pi, -0.3, 2.5, -6.9, 0.013, 1.0, -0.77][k])
+        start = np.float32([0.0, 1.0, -2.0, 12.5, -40.0, 0.5, 3.1415927, 100.0][k])
+        ro = k % 3 == 2
+        vv = v.real.astype(np.complex64) if ro else v
+        y, fin = r.frequency_shift(vv, freq, start, ro)
+        fs.append((vv, freq, start, ro, y, fin))
+    kw.update(fshift_x=np.concatenate([f[0] for f in fs]), fshift_freq=np.array([f[1] for f in fs], np.float32),
+              fshift_start=np.array([f[2] for f in fs], np.float32), fshift_real=np.array([f[3] for f in fs], np.uint8),
+              fshift_y=np.concatenate([f[4] for f in fs]), fshift_final=np.array([f[5] for f in fs], np.float32))
+    # addVector: the shorter operand bounds the sum
+    a = cn(157, 50.0); b1 = cn(157, 50.0); b2 = cn(40, 50.0); b3 = cn(300, 50.0)
+    kw.update(add_x=a, add_y1=b1, add_y2=b2, add_y3=b3, add_r1=r.add_vector(a, b1), add_r2=r.add_vector(a, b2), add_r3=r.add_vector(a, b3))
+    o = np.complex64(3.25 - 1.5j)
+    ar = a.real.astype(np.complex64)
+    kw.update(offset=o, offset_c=r.offset_vector(a, o, False), offset_xr=ar, offset_r=r.offset_vector(ar, o, True))
+    # gaussianNoise after srand(seed): the reference's rand() draw order (two draws per sample, more after a zero)
+    for seed, n, var, mean in ((1, 149, 0.001 / np.sqrt(np.float32(2)), 0j), (12345, 64, 2.5, 1.0 - 2.0j)):
+        kw["noise%d" % seed] = r.gaussian_noise(seed, n, var, mean)
+        kw["noise%d_arg" % seed] = np.array([n, var, mean.real, mean.imag], np.float64)
+    # resampleVector as it behaves: every interpolated value lands in element 0
+    rs = cn(50, 10.0)
+    for k, ef in enumerate((1.0, 1.5, 2.37, 4.0)):
+        kw["rsv%d" % k] = r.resample_vector(rs, ef, 7 + 1j)
+    kw.update(rsv_x=rs, rsv_factor=np.float32([1.0, 1.5, 2.37, 4.0]), rsv_end=np.complex64(7 + 1j))
+    # convolve with an ABSSYM filter (START_ONLY / NO_DELAY: the spans on which the reference stays inside its operands)
+    i = 0
+    for span in (refbind.START_ONLY, refbind.NO_DELAY):
+        for nb in (4, 5, 8, 9, 21):
+            aa = cn(60); bb = cn(nb)
+            kw["sym%d_a" % i] = aa; kw["sym%d_b" % i] = bb; kw["sym%d_span" % i] = np.int32(span)
+            kw["sym%d_y" % i] = r.convolve(aa, bb, span, abssym=True)
+            i += 1
+    kw["nsym"] = np.int32(i)
+    save("extras.npz", **kw)
+
+
 def gen_resample():
     rng = np.random.default_rng(400)
     r = refbind.Ref(4)
@@ -495,6 +557,7 @@ if __name__ == "__main__":
     gen_rach(4, 48, "rach_sps4.npz")
     gen_rach(1, 32, "rach_sps1.npz")
     gen_primitives()
+    gen_extras()
     gen_resample()
     gen_dfe()
     gen_config1()

@@ -55,6 +55,15 @@ def lib():
         L.so_convolve.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.so_correlate.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int]
         L.so_scale_vector.argtypes = [f32p, C.c_int, c32, C.c_int]
+        for n in ("so_dB", "so_dBinv"):
+            getattr(L, n).argtypes = [C.c_float]; getattr(L, n).restype = C.c_float
+        for n in ("so_vector_norm2", "so_vector_power"):
+            getattr(L, n).argtypes = [f32p, C.c_int]; getattr(L, n).restype = C.c_float
+        L.so_frequency_shift.argtypes = [vp, f32p, C.c_int, C.c_float, C.c_float, C.c_int, f32p]; L.so_frequency_shift.restype = C.c_float
+        L.so_add_vector.argtypes = [f32p, C.c_int, f32p, C.c_int]
+        L.so_offset_vector.argtypes = [f32p, C.c_int, c32, C.c_int]
+        L.so_resample_vector.argtypes = [f32p, C.c_int, C.c_float, c32, f32p]
+        L.so_gaussian_noise.argtypes = [C.c_int, C.c_float, c32, f32p]
         L.so_gmsk_rotate.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int]
         L.so_delay_vector.argtypes = [vp, f32p, C.c_int, C.c_float]
         L.so_interpolate_point.argtypes = [vp, f32p, C.c_int, C.c_float, C.c_int]; L.so_interpolate_point.restype = c32
@@ -126,12 +135,50 @@ class Oracle:
         z = self.L.so_expjLookup(self.ctx, np.float32(x))
         return complex(z.r, z.i)
 
+    def dB(self, x): return self.L.so_dB(np.float32(x))
+    def dBinv(self, x): return self.L.so_dBinv(np.float32(x))
+
+    # the rest of sigProcLib.h's surface
+    def vector_norm2(self, x):
+        x = c64(x); return np.float32(self.L.so_vector_norm2(x, x.size // 2))
+
+    def vector_power(self, x):
+        x = c64(x); return np.float32(self.L.so_vector_power(x, x.size // 2))
+
+    def frequency_shift(self, x, freq, start_phase=0.0, real_only=False):
+        x = c64(x); y = np.zeros_like(x)
+        fin = self.L.so_frequency_shift(self.ctx, x, x.size // 2, np.float32(freq), np.float32(start_phase), int(real_only), y)
+        return y.view(np.complex64), np.float32(fin)
+
+    def add_vector(self, x, y):
+        x = c64(x).copy(); y = c64(y)
+        self.L.so_add_vector(x, x.size // 2, y, y.size // 2)
+        return x.view(np.complex64)
+
+    def offset_vector(self, x, offset, real_only=False):
+        x = c64(x).copy()
+        self.L.so_offset_vector(x, x.size // 2, _cx(offset), int(real_only))
+        return x.view(np.complex64)
+
+    def resample_vector(self, x, exp_factor, end_point=0j):
+        x = c64(x)
+        out = np.zeros(2 * (int(np.ceil(x.size // 2 * float(exp_factor))) + 4), np.float32)
+        n = self.L.so_resample_vector(x, x.size // 2, np.float32(exp_factor), _cx(end_point), out)
+        return None if n < 0 else out.view(np.complex64)[:n].copy()
+
+    def gaussian_noise(self, seed, length, variance=1.0, mean=0j):
+        """srand(seed) in this process's C library, then the reference's draw order."""
+        C.CDLL(None).srand(int(seed))
+        out = np.zeros(2 * length, np.float32)
+        self.L.so_gaussian_noise(length, np.float32(variance), _cx(mean), out)
+        return out.view(np.complex64)
+
     # primitives
-    def convolve(self, a, b, span=NO_DELAY, a_real=False, b_real=False, start=0, length=0):
+    def convolve(self, a, b, span=NO_DELAY, a_real=False, b_real=False, start=0, length=0, abssym=False):
         a = c64(a); b = c64(b)
         na, nb = a.size // 2, b.size // 2
         out = np.zeros(2 * (na + nb + 2 + length), np.float32)
-        n = self.L.so_convolve(a, na, b, nb, out, span, (1 if a_real else 0) | (2 if b_real else 0), start, length)
+        n = self.L.so_convolve(a, na, b, nb, out, span, (1 if a_real else 0) | (2 if b_real else 0) | (4 if abssym else 0), start, length)
         return None if n < 0 else out.view(np.complex64)[:n].copy()
 
     def correlate(self, a, b, span=NO_DELAY, a_real=False, b_real=False):

@@ -156,6 +156,7 @@ int ref_convolve(const float *a, int na, const float *b, int nb, int span,
 {
   signalVector *A = mk(a, na), *B = mk(b, nb);
   A->isRealOnly(flags & 1); B->isRealOnly(flags & 2);
+  if (flags & 4) B->setSymmetry(ABSSYM);
   signalVector *c = convolve(A, B, NULL, (ConvType)span);
   int n = -1;
   if (c) { n = c->size(); put(c, out); delete c; }
@@ -380,6 +381,53 @@ int ref_rach_batch(const float *x, const int *off, const int *len, int B,
 /* GSM::Time arithmetic and ordering (GSM/GSMCommon.h:327-455, GSMCommon.cpp:161-176): what Transceiver's priority queue,
  * stale-burst test and frame differences rest on.  op: 0 a < b, 1 a > b, 2 a == b, 3 a - b (frames), 4 FNDelta(fn1, fn2),
  * 5 a.incTN(step), 6 a.decTN(step), 7 a + step (frames).  Result in *out (ops 0-4) or *out_fn / *out_tn (ops 5-7). */
+/* --- the rest of sigProcLib.h's surface (sigProcLib.h:101-111, 149-153, 177, 184-190, 225-226, 352-354) --------- */
+float ref_dB(float x) { return dB(x); }
+float ref_dBinv(float x) { return dBinv(x); }
+float ref_vector_norm2(const float *x, int n) { signalVector *X = mk(x, n); float e = vectorNorm2(*X); delete X; return e; }
+float ref_vector_power(const float *x, int n) { signalVector *X = mk(x, n); float e = vectorPower(*X); delete X; return e; }
+float ref_frequency_shift(const float *x, int n, float freq, float startPhase, int real_only, float *y)
+{
+  signalVector *X = mk(x, n);
+  X->isRealOnly(real_only);
+  float fin = 0;
+  signalVector *Y = frequencyShift(NULL, X, freq, startPhase, &fin);
+  put(Y, y);
+  delete X; delete Y;
+  return fin;
+}
+void ref_add_vector(float *x, int nx, const float *y, int ny)
+{
+  signalVector *X = mk(x, nx), *Y = mk(y, ny);
+  addVector(*X, *Y);
+  put(X, x);
+  delete X; delete Y;
+}
+void ref_offset_vector(float *x, int n, float orr, float oi, int real_only)
+{
+  signalVector *X = mk(x, n);
+  X->isRealOnly(real_only);
+  offsetVector(*X, complex(orr, oi));
+  put(X, x);
+  delete X;
+}
+int ref_resample_vector(const float *x, int n, float expFactor, float er, float ei, float *out)
+{
+  signalVector *X = mk(x, n);
+  signalVector *Y = resampleVector(*X, expFactor, complex(er, ei));
+  int m = -1;
+  if (Y) { m = Y->size(); put(Y, out); delete Y; }
+  delete X;
+  return m;
+}
+void ref_gaussian_noise(unsigned seed, int length, float variance, float mr, float mi, float *out)
+{
+  srand(seed);
+  signalVector *N = gaussianNoise(length, variance, complex(mr, mi));
+  put(N, out);
+  delete N;
+}
+
 int ref_gsm_time(int op, int fn1, int tn1, int fn2, int tn2, int step, int *out, int *out_fn, int *out_tn) {
   GSM::Time a(fn1, tn1), b(fn2, tn2);
   switch (op) {

@@ -84,6 +84,16 @@ class Ref:
         L.ref_equalize.argtypes = [f32p, C.c_int, C.c_float, f32p, C.c_int, f32p, C.c_int, f32p]
         L.ref_normal_batch.argtypes = [f32p, i32p, i32p, C.c_int, C.c_uint, C.c_float, u8p, f32p, f32p, f32p]
         L.ref_rach_batch.argtypes = [f32p, i32p, i32p, C.c_int, C.c_float, u8p, f32p, f32p, f32p]
+        if hasattr(L, "ref_dB"):                              # the rest of sigProcLib.h's surface
+            for n in ("ref_dB", "ref_dBinv"):
+                getattr(L, n).argtypes = [C.c_float]; getattr(L, n).restype = C.c_float
+            for n in ("ref_vector_norm2", "ref_vector_power"):
+                getattr(L, n).argtypes = [f32p, C.c_int]; getattr(L, n).restype = C.c_float
+            L.ref_frequency_shift.argtypes = [f32p, C.c_int, C.c_float, C.c_float, C.c_int, f32p]; L.ref_frequency_shift.restype = C.c_float
+            L.ref_add_vector.argtypes = [f32p, C.c_int, f32p, C.c_int]
+            L.ref_offset_vector.argtypes = [f32p, C.c_int, C.c_float, C.c_float, C.c_int]
+            L.ref_resample_vector.argtypes = [f32p, C.c_int, C.c_float, C.c_float, C.c_float, f32p]
+            L.ref_gaussian_noise.argtypes = [C.c_uint, C.c_int, C.c_float, C.c_float, C.c_float, f32p]
         if L.ref_setup(sps) != 0:
             raise RuntimeError("ref_setup failed")
 
@@ -136,18 +146,54 @@ class Ref:
         self.lib.ref_expjLookup(np.float32(x), o)
         return complex(o[0], o[1])
 
+    def dB(self, x): return self.lib.ref_dB(np.float32(x))
+    def dBinv(self, x): return self.lib.ref_dBinv(np.float32(x))
+
+    # ---- the rest of sigProcLib.h's surface ----
+    def vector_norm2(self, x):
+        x = c64(x); return np.float32(self.lib.ref_vector_norm2(x, x.size // 2))
+
+    def vector_power(self, x):
+        x = c64(x); return np.float32(self.lib.ref_vector_power(x, x.size // 2))
+
+    def frequency_shift(self, x, freq, start_phase=0.0, real_only=False):
+        x = c64(x); y = np.zeros_like(x)
+        fin = self.lib.ref_frequency_shift(x, x.size // 2, np.float32(freq), np.float32(start_phase), int(real_only), y)
+        return y.view(np.complex64), np.float32(fin)
+
+    def add_vector(self, x, y):
+        x = c64(x).copy(); y = c64(y)
+        self.lib.ref_add_vector(x, x.size // 2, y, y.size // 2)
+        return x.view(np.complex64)
+
+    def offset_vector(self, x, offset, real_only=False):
+        x = c64(x).copy(); o = complex(offset)
+        self.lib.ref_offset_vector(x, x.size // 2, np.float32(o.real), np.float32(o.imag), int(real_only))
+        return x.view(np.complex64)
+
+    def resample_vector(self, x, exp_factor, end_point=0j):
+        x = c64(x); e = complex(end_point)
+        out = np.zeros(2 * (int(np.ceil(x.size // 2 * float(exp_factor))) + 4), np.float32)
+        n = self.lib.ref_resample_vector(x, x.size // 2, np.float32(exp_factor), np.float32(e.real), np.float32(e.imag), out)
+        return None if n < 0 else out.view(np.complex64)[:n].copy()
+
+    def gaussian_noise(self, seed, length, variance=1.0, mean=0j):
+        m = complex(mean); out = np.zeros(2 * length, np.float32)
+        self.lib.ref_gaussian_noise(int(seed), length, np.float32(variance), np.float32(m.real), np.float32(m.imag), out)
+        return out.view(np.complex64)
+
     # ---- primitives ----
-    def _conv(self, fn, a, b, span, a_real, b_real):
+    def _conv(self, fn, a, b, span, a_real, b_real, abssym=False):
         a = c64(a); b = c64(b)
         na, nb = a.size // 2, b.size // 2
         out = np.zeros(2 * (na + nb + 2), np.float32)
-        n = fn(a, na, b, nb, span, (1 if a_real else 0) | (2 if b_real else 0), out)
+        n = fn(a, na, b, nb, span, (1 if a_real else 0) | (2 if b_real else 0) | (4 if abssym else 0), out)
         if n < 0:
             return None
         return out.view(np.complex64)[:n].copy()
 
-    def convolve(self, a, b, span=NO_DELAY, a_real=False, b_real=False):
-        return self._conv(self.lib.ref_convolve, a, b, span, a_real, b_real)
+    def convolve(self, a, b, span=NO_DELAY, a_real=False, b_real=False, abssym=False):
+        return self._conv(self.lib.ref_convolve, a, b, span, a_real, b_real, abssym)
 
     def correlate(self, a, b, span=NO_DELAY, a_real=False, b_real=False):
         return self._conv(self.lib.ref_correlate, a, b, span, a_real, b_real)

@@ -130,6 +130,25 @@ int so_convolve(const so_c32 *a, int La, const so_c32 *b, int Lb, so_c32 *out,
   const int aReal = flags & 1, bReal = flags & 2;
   int stop = startIndex + (int)outSize;
   so_c32 *cp = out;
+  if (flags & 4) {                                            /* b->getSymmetry() == ABSSYM: ref:369-398 */
+    /* (the reference pairs a[t-j] with a[t-Lb+j] -- one sample further than the mirror image -- and reads the partner
+       without an upper bound check in its fourth arm; partners at or beyond a's end count as zero here) */
+    const int half = (Lb % 2) ? (Lb + 1) / 2 : Lb / 2;
+    for (int t = startIndex; t < stop; t++) {
+      so_c32 sum = C(0, 0);
+      int ai = t, as = t - Lb;
+      for (int j = 0; j < half; j++, ai--, as++) {
+        if (ai < 0) break;
+        const so_c32 sv = (as >= 0 && as < La) ? a[as >= 0 && as < La ? as : 0] : C(0, 0);
+        if (ai == as) sum = cadd(sum, cmul(a[ai], b[j]));
+        else if (ai < La && as >= 0) sum = cadd(sum, cmul(cadd(a[ai], sv), b[j]));
+        else if (ai < La) sum = cadd(sum, cmul(a[ai], b[j]));
+        else if (as >= 0) sum = cadd(sum, cmul(sv, b[j]));
+      }
+      *cp++ = sum;
+    }
+    return (int)outSize;
+  }
   for (int t = startIndex; t < stop; t++) {                   /* ref:322-366 */
     int ai = t;
     if (aReal && bReal) {
@@ -187,6 +206,105 @@ static float vector_norm2(const so_c32 *x, int n)             /* ref:146-154 */
   float e = 0.0;
   for (int k = 0; k < n; k++) e += norm2(x[k]);
   return e;
+}
+float so_vector_norm2(const so_c32 *x, int n) { return vector_norm2(x, n); }
+float so_vector_power(const so_c32 *x, int n) { return vector_norm2(x, n) / (float)(size_t)n; }   /* ref:157-160 */
+
+float so_dB(float x)                                          /* ref:88-114 */
+{
+  float arg = 1.0F, dB = 0.0F;
+  if (x >= 1.0F) return 0.0F;
+  if (x <= 0.0F) return -200.0F;
+  float prevArg = arg, prevdB = dB, stepSize = 16.0F, dBstepSize = 12.0F;
+  while (stepSize > 1.0F) {
+    do {
+      prevArg = arg; prevdB = dB;
+      arg /= stepSize; dB -= dBstepSize;
+    } while (arg > x);
+    arg = prevArg; dB = prevdB;
+    stepSize *= 0.5F; dBstepSize -= 3.0F;
+  }
+  return ((arg - x) * (dB - 3.0F) + (x - arg * 0.5F) * dB) / (arg - arg * 0.5F);
+}
+
+float so_dBinv(float x)                                       /* ref:117-144 */
+{
+  float arg = 1.0F, dB = 0.0F;
+  if (x >= 0.0F) return 1.0F;
+  if (x <= -200.0F) return 0.0F;
+  float prevArg = arg, prevdB = dB, stepSize = 16.0F, dBstepSize = 12.0F;
+  while (stepSize > 1.0F) {
+    do {
+      prevArg = arg; prevdB = dB;
+      arg /= stepSize; dB -= dBstepSize;
+    } while (dB > x);
+    arg = prevArg; dB = prevdB;
+    stepSize *= 0.5F; dBstepSize -= 3.0F;
+  }
+  return ((dB - x) * (arg * 0.5F) + (x - (dB - 3.0F)) * (arg)) / 3.0F;
+}
+
+/* frequencyShift(y, x, freq, startPhase, &finalPhase): ref:432-471; y may be x */
+float so_frequency_shift(const so_ctx *c, const so_c32 *x, int n, float freq, float startPhase, int real_only, so_c32 *y)
+{
+  float phase = startPhase;
+  for (int k = 0; k < n; k++) {
+    const so_c32 e = so_expjLookup(c, phase);
+    y[k] = real_only ? cmulr(e, x[k].r) : cmul(x[k], e);      /* expjLookup(phase)*real() / (*xP)*expjLookup(phase) */
+    phase += freq;
+  }
+  return phase;
+}
+
+void so_add_vector(so_c32 *x, int nx, const so_c32 *y, int ny) /* ref:746-758 */
+{
+  for (int k = 0; k < nx && k < ny; k++) x[k] = cadd(x[k], y[k]);
+}
+
+void so_offset_vector(so_c32 *x, int n, so_c32 offset, int real_only) /* ref:760-777 */
+{
+  if (!real_only) for (int k = 0; k < n; k++) x[k] = cadd(x[k], offset);          /* *xP += offset */
+  else            for (int k = 0; k < n; k++) x[k] = C(offset.r + x[k].r, offset.i); /* xP->real() + offset (Complex.h:233-236) */
+}
+
+/* resampleVector(wVector, expFactor, endPoint): ref:1213-1243 AS IT BEHAVES -- the loop never advances its output
+   iterator, so every interpolated value lands in element 0 and the rest of the (zero-initialised) vector stays zero.
+   Returns the output length, -1 for expFactor < 1 (NULL in the reference). */
+int so_resample_vector(const so_c32 *x, int n, float expFactor, so_c32 endPoint, so_c32 *out)
+{
+  if (expFactor < 1.0) return -1;
+  const int nout = (int)ceilf((float)(size_t)n * expFactor);
+  for (int k = 0; k < nout; k++) out[k] = C(0, 0);
+  float t = 0.0;
+  while (nout > 0) {
+    const unsigned tLow = (unsigned)floorf(t);
+    const unsigned tHigh = tLow + 1;
+    if (tLow > (unsigned)n - 1) break;
+    if (tHigh > (unsigned)n) break;
+    const so_c32 lowPoint = x[tLow];
+    const so_c32 highPoint = (tHigh == (unsigned)n) ? endPoint : x[tHigh];
+    const so_c32 a = C((float)tHigh - t, 0.0f);
+    const so_c32 b = C(t - (float)tLow, 0.0f);
+    out[0] = cadd(cmul(a, lowPoint), cmul(b, highPoint));
+    t = (float)((double)t + 1.0 / (double)expFactor);
+  }
+  return nout;
+}
+
+/* gaussianNoise(length, variance, mean): ref:618-637; draws from the C library's rand() as the reference does */
+void so_gaussian_noise(int length, float variance, so_c32 mean, so_c32 *out)
+{
+  const float stddev = sqrtf(variance);
+  for (int k = 0; k < length; k++) {
+    float u1 = (float)rand() / (float)RAND_MAX;
+    while (u1 == 0.0) u1 = (float)rand() / (float)RAND_MAX;
+    const float u2 = (float)rand() / (float)RAND_MAX;
+    const float arg = (float)(2.0 * M_PI * (double)u2);
+    /* C++ overload resolution in the reference: cos / sin / log of a float are the float functions */
+    const so_c32 e = C(cosf(arg), sinf(arg));
+    const so_c32 v = cmulr(C(e.r * stddev, e.i * stddev), sqrtf((float)(-2.0 * (double)logf(u1))));
+    out[k] = cadd(mean, v);
+  }
 }
 
 /* ---- generateGSMPulse(symbolLength=2, sps): ref:411-430 ------------------------ */

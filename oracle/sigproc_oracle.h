@@ -65,6 +65,18 @@ float so_sinLookup(const so_ctx *c, float x);
 float so_cosLookup(const so_ctx *c, float x);
 so_c32 so_expjLookup(const so_ctx *c, float x);
 float so_sinc(const so_ctx *c, float x);
+/* the rest of sigProcLib.h's surface: dB / dBinv (ref:88-144), vectorNorm2 / vectorPower (:146-160), frequencyShift
+   (:432-471; returns the final phase), addVector (:746-758), offsetVector (:760-777), resampleVector (:1213-1243, as it
+   behaves: see the .c), gaussianNoise (:618-637, rand()) */
+float so_dB(float x);
+float so_dBinv(float x);
+float so_vector_norm2(const so_c32 *x, int n);
+float so_vector_power(const so_c32 *x, int n);
+float so_frequency_shift(const so_ctx *c, const so_c32 *x, int n, float freq, float startPhase, int real_only, so_c32 *y);
+void so_add_vector(so_c32 *x, int nx, const so_c32 *y, int ny);
+void so_offset_vector(so_c32 *x, int n, so_c32 offset, int real_only);
+int so_resample_vector(const so_c32 *x, int n, float expFactor, so_c32 endPoint, so_c32 *out);
+void so_gaussian_noise(int length, float variance, so_c32 mean, so_c32 *out);
 
 /* flags: bit0 = a realOnly, bit1 = b realOnly.  Returns output length or -1.
    start/len only used for SO_CUSTOM. */
