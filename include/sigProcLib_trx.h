@@ -16,8 +16,9 @@
 // Every call that processes samples runs on the GPU through the C-ABI's host-buffer entry points (one PCIe round trip
 // per call); nothing here computes on the CPU.  A real deployment batches instead -- see INTEGRATION.md.
 //
-// Not provided (none is called by Transceiver.cpp or radioInterface.cpp): convolve's ABSSYM form (no caller sets a
-// symmetry), frequencyShift, resampleVector, addVector, offsetVector, gaussianNoise, vectorNorm2 / vectorPower, dB / dBinv.
+// The functions no caller on the path uses are here too, for a complete surface: dB, dBinv, vectorNorm2, vectorPower,
+// frequencyShift, sinc, addVector, gaussianNoise (the C library's rand(), in the reference's draw order), offsetVector,
+// resampleVector (as the reference behaves) and convolve with an ABSSYM filter.
 // Accepted ranges narrower than the reference's: modulateBurst takes 148-bit bursts with guard 0..9 and the library's
 // own pulse; designDFE wants Nf = 7 and a 6-tap channel, equalizeBurst 7 + 5 taps;
 // demodulateBurst wants 92..157 symbols (a multiple of sps samples) and |TOA| <= 4096 -- outside them the call returns
@@ -46,6 +47,9 @@ struct complex {
   complex operator*(const complex &a) const { return complex(r * a.r - i * a.i, r * a.i + i * a.r); }   // Complex.h:83
   complex operator*(float a) const { return complex(r * a, i * a); }                           // Complex.h:84
   complex operator/(const complex &a) const { return (*this) * a.inv(); }                      // Complex.h:85
+  complex operator+(const complex &a) const { return complex(r + a.r, i + a.i); }              // Complex.h:79
+  complex operator-(const complex &a) const { return complex(r - a.r, i - a.i); }              // Complex.h:81
+  complex &operator+=(const complex &a) { r += a.r; i += a.i; return *this; }                  // Complex.h:162-167
 };
 
 // Vector<T> (CommonLibs/Vector.h:42-252): a contiguous block that is either owned (freed on destruction) or an alias
@@ -162,6 +166,7 @@ inline void sigProcLibSetup(int samplesPerSymbol) {
   State &s = state();
   sigProcLibDestroy();
   s.sps = samplesPerSymbol;
+  if (trxsig_abi_version() != TRXSIG_ABI_VERSION) { s.ctx = nullptr; return; }   // header and library must agree (trxsig.h)
   if (trxsig_create(&s.ctx, s.device, samplesPerSymbol) != TRXSIG_OK) s.ctx = nullptr;
 }
 inline bool sigProcLibReady() { return state().ctx != nullptr; }
@@ -390,17 +395,19 @@ inline SoftVector *demodulateBurst(signalVector &rxBurst, const signalVector &, 
 #endif
 
 // convolve (sigProcLib.h:126-129) and correlate (:162-165): c == NULL allocates the result (caller deletes); a
-// preallocated c must have exactly the output size, else NULL (sigProcLib.cpp:307-310).  Symmetry NONE only.
+// preallocated c must have exactly the output size, else NULL (sigProcLib.cpp:307-310).  b->getSymmetry() == ABSSYM takes
+// convolve's symmetric-filter branch (:369-398).
 namespace detail {
 inline signalVector *conv(const signalVector *a, const signalVector *b, signalVector *c, ConvType spanType, int correlate) {
   State &s = state();
-  if (!s.ctx || a == NULL || b == NULL || b->getSymmetry() != NONE) return NULL;
+  if (!s.ctx || a == NULL || b == NULL) return NULL;
   const int n = trxsig_convolve_out_len((int)a->size(), (int)b->size(), (int)spanType, 0);
   if (n <= 0 || spanType > NO_DELAY) return NULL;
   const bool mine = (c == NULL);
   if (mine) c = new signalVector(n);
   else if ((int)c->size() != n) return NULL;
-  const int flags = (a->isRealOnly() ? 1 : 0) | (b->isRealOnly() ? 2 : 0);
+  // (correlate's reversed copy of b never carries a symmetry, sigProcLib.cpp:480-481)
+  const int flags = (a->isRealOnly() ? 1 : 0) | (b->isRealOnly() ? 2 : 0) | ((!correlate && b->getSymmetry() == ABSSYM) ? 4 : 0);
   if (trxsig_convolve_host(s.ctx, (const trxsig_c32 *)a->begin(), (int)a->size(), (const trxsig_c32 *)b->begin(), (int)b->size(),
                            (int)spanType, flags, correlate, 0, 0, (trxsig_c32 *)c->begin(), n) != n) {
     if (mine) delete c;
@@ -444,6 +451,78 @@ inline signalVector *decimateVector(signalVector &wVector, int decimationFactor)
   return d;
 }
 
+// ---- the functions no caller on the burst path uses (sigProcLib.h:101-111, 149-153, 177, 184-190, 225-226, 352-354) ----
+inline float dB(float x) { return trxsig_db(x); }                                              // :102
+inline float dBinv(float x) { return trxsig_dbinv(x); }                                        // :105
+inline float vectorNorm2(const signalVector &x) {                                              // :108
+  State &s = state();
+  float e = 0.0f;
+  if (s.ctx && x.size() > 0) (void)trxsig_vector_norm2_host(s.ctx, (const trxsig_c32 *)x.begin(), (int)x.size(), &e, NULL);
+  return e;
+}
+inline float vectorPower(const signalVector &x) {                                              // :111
+  State &s = state();
+  float p = 0.0f;
+  if (s.ctx && x.size() > 0) (void)trxsig_vector_norm2_host(s.ctx, (const trxsig_c32 *)x.begin(), (int)x.size(), NULL, &p);
+  return p;
+}
+// frequencyShift (:149-153): y == NULL allocates the result (caller deletes); y may be x; NULL if y is shorter than x
+inline signalVector *frequencyShift(signalVector *y, signalVector *x, float freq = 0.0, float startPhase = 0.0, float *finalPhase = NULL) {
+  State &s = state();
+  if (!s.ctx || !x) return NULL;
+  const bool mine = (y == NULL);
+  if (mine) { y = new signalVector((int)x->size()); y->isRealOnly(x->isRealOnly()); }
+  if (y->size() < x->size()) return NULL;
+  float fin = startPhase;
+  if (x->size() > 0 && trxsig_frequency_shift_host(s.ctx, (const trxsig_c32 *)x->begin(), (int)x->size(), freq, startPhase, x->isRealOnly(),
+                                                   (trxsig_c32 *)y->begin(), &fin) != TRXSIG_OK) {
+    if (mine) delete y;
+    return NULL;
+  }
+  if (finalPhase) *finalPhase = fin;
+  return y;
+}
+inline float sinc(float x) {                                                                   // :177
+  float v = 1.0f;
+  if (state().ctx) (void)trxsig_sinc_host(state().ctx, x, &v);
+  return v;
+}
+inline bool addVector(signalVector &x, signalVector &y) {                                      // :184-185, in place on x
+  State &s = state();
+  if (!s.ctx) return false;
+  if (x.size() == 0 || y.size() == 0) return true;
+  return trxsig_add_vector_host(s.ctx, (trxsig_c32 *)x.begin(), (int)x.size(), (const trxsig_c32 *)y.begin(), (int)y.size()) == TRXSIG_OK;
+}
+// gaussianNoise (:188-190): the C library's rand() in the reference's draw order -- seed it with srand(); caller deletes
+inline signalVector *gaussianNoise(int length, float variance = 1.0, complex mean = complex(0.0)) {
+  if (length < 0) return NULL;
+  signalVector *noise = new signalVector(length);
+  const trxsig_c32 m = {mean.r, mean.i};
+  if (trxsig_gaussian_noise_host(length, variance, m, (trxsig_c32 *)noise->begin()) != TRXSIG_OK) { delete noise; return NULL; }
+  return noise;
+}
+inline void offsetVector(signalVector &x, complex offset) {                                    // :225-226
+  State &s = state();
+  if (!s.ctx || x.size() == 0) return;
+  const trxsig_c32 o = {offset.r, offset.i};
+  (void)trxsig_elementwise_host(s.ctx, 4, (trxsig_c32 *)x.begin(), (int)x.size(), o, x.isRealOnly());
+}
+// resampleVector (:352-354) as the reference behaves (its loop never advances the output iterator: element 0 takes every
+// interpolated value, the rest stays zero); NULL for expFactor < 1; caller deletes
+inline signalVector *resampleVector(signalVector &wVector, float expFactor, complex endPoint) {
+  State &s = state();
+  const int n = trxsig_resample_linear_out_len((int)wVector.size(), expFactor);
+  if (!s.ctx || n < 0) return NULL;
+  signalVector *out = new signalVector(n);
+  const trxsig_c32 e = {endPoint.r, endPoint.i};
+  if (wVector.size() > 0 && trxsig_resample_linear_host(s.ctx, (const trxsig_c32 *)wVector.begin(), (int)wVector.size(), expFactor, e,
+                                                        (trxsig_c32 *)out->begin(), n) != n) {
+    delete out;
+    return NULL;
+  }
+  return out;
+}
+
 // createLPF (sigProcLib.h:329-331).  The reference ignores the cutoff and loads one of its two coefficient
 // tables (rcvLPF_651.h for filterLen 651, else sendLPF_961.h; sigProcLib.cpp:1119-1139); those tables are
 // reference data, so the caller registers them once (the arrays of the reference's own headers will do).
@@ -480,6 +559,16 @@ inline signalVector *polyphaseResampleVector(signalVector &wVector, int P, int Q
 
 #ifndef TRXFACADE_NO_GLOBAL_NAMES   /* the reference's names are namespace-less (sigProcLib.h) */
 using trxfacade::analyzeTrafficBurst;
+using trxfacade::dB;
+using trxfacade::dBinv;
+using trxfacade::vectorNorm2;
+using trxfacade::vectorPower;
+using trxfacade::frequencyShift;
+using trxfacade::sinc;
+using trxfacade::addVector;
+using trxfacade::gaussianNoise;
+using trxfacade::offsetVector;
+using trxfacade::resampleVector;
 using trxfacade::BitVector;
 using trxfacade::createLPF;
 using trxfacade::polyphaseResampleVector;

@@ -129,6 +129,20 @@ def _load(path):
         L.trxsig_decimate_host.argtypes = [vp, vp, i32, i32, vp]
         L.trxsig_energy_detect_batch.argtypes = [vp, vp, vp, vp, i32, C.c_uint, i32, f32, vp, vp]
         L.trxsig_energy_detect_host.argtypes = [vp, vp, i32, C.c_uint, i32, f32, vp]
+        L.trxsig_db.argtypes = [f32]; L.trxsig_db.restype = f32
+        L.trxsig_dbinv.argtypes = [f32]; L.trxsig_dbinv.restype = f32
+        L.trxsig_sinc_host.argtypes = [vp, f32, C.POINTER(f32)]
+        L.trxsig_gaussian_noise_host.argtypes = [i32, f32, C32, vp]
+        L.trxsig_vector_norm2_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+        L.trxsig_vector_norm2_host.argtypes = [vp, vp, i32, C.POINTER(f32), C.POINTER(f32)]
+        L.trxsig_frequency_shift_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp]
+        L.trxsig_frequency_shift_host.argtypes = [vp, vp, i32, f32, f32, i32, vp, C.POINTER(f32)]
+        L.trxsig_add_vector_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32]
+        L.trxsig_add_vector_host.argtypes = [vp, vp, i32, vp, i32]
+        L.trxsig_offset_vector_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32]
+        L.trxsig_resample_linear_out_len.argtypes = [i32, f32]
+        L.trxsig_resample_linear_batch.argtypes = [vp, vp, vp, vp, i32, f32, vp, vp, vp]
+        L.trxsig_resample_linear_host.argtypes = [vp, vp, i32, f32, C32, vp, i32]
         L.trxsig_timer_start.argtypes = [vp]
         L.trxsig_timer_stop.argtypes = [vp, C.POINTER(f32)]
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
@@ -316,13 +330,62 @@ class TrxSig:
         return out, off, length
 
     # ---- sigProcLib.h's free-standing primitives, single-vector host forms (numpy in / out) ----
-    def convolve_host(self, a, b, span, a_real=False, b_real=False, correlate=False, cust_start=0, cust_len=0):
+    # ---- the rest of sigProcLib.h (host forms) ----
+    def db(self, x): return self.L.trxsig_db(float(x))
+    def dbinv(self, x): return self.L.trxsig_dbinv(float(x))
+
+    def sinc_host(self, x):
+        v = C.c_float()
+        self._chk(self.L.trxsig_sinc_host(self.h, float(x), C.byref(v)), "trxsig_sinc_host")
+        return v.value
+
+    def gaussian_noise_host(self, seed, length, variance=1.0, mean=0j):
+        import numpy as np
+        C.CDLL(None).srand(int(seed))
+        out = np.zeros(length, np.complex64)
+        self._chk(self.L.trxsig_gaussian_noise_host(length, float(variance), C32(float(np.real(mean)), float(np.imag(mean))), out.ctypes.data),
+                  "trxsig_gaussian_noise_host")
+        return out
+
+    def vector_norm2_host(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); e = C.c_float(); p = C.c_float()
+        self._chk(self.L.trxsig_vector_norm2_host(self.h, x.ctypes.data, x.size, C.byref(e), C.byref(p)), "trxsig_vector_norm2_host")
+        return np.float32(e.value), np.float32(p.value)
+
+    def frequency_shift_host(self, x, freq, start_phase=0.0, real_only=False):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64); y = np.zeros_like(x); fin = C.c_float()
+        self._chk(self.L.trxsig_frequency_shift_host(self.h, x.ctypes.data, x.size, float(freq), float(start_phase), int(real_only),
+                                                     y.ctypes.data, C.byref(fin)), "trxsig_frequency_shift_host")
+        return y, np.float32(fin.value)
+
+    def add_vector_host(self, x, y):
+        import numpy as np
+        x = np.array(x, np.complex64, copy=True); y = np.ascontiguousarray(y, np.complex64)
+        self._chk(self.L.trxsig_add_vector_host(self.h, x.ctypes.data, x.size, y.ctypes.data, y.size), "trxsig_add_vector_host")
+        return x
+
+    def resample_linear_host(self, x, exp_factor, end_point=0j):
+        import numpy as np
+        x = np.ascontiguousarray(x, np.complex64)
+        n = self.L.trxsig_resample_linear_out_len(x.size, float(exp_factor))
+        if n < 0:
+            return None
+        out = np.zeros(max(n, 1), np.complex64)
+        rc = self.L.trxsig_resample_linear_host(self.h, x.ctypes.data, x.size, float(exp_factor),
+                                                C32(float(np.real(end_point)), float(np.imag(end_point))), out.ctypes.data, out.size)
+        if rc < 0:
+            self._chk(rc, "trxsig_resample_linear_host")
+        return out[:rc]
+
+    def convolve_host(self, a, b, span, a_real=False, b_real=False, correlate=False, cust_start=0, cust_len=0, abssym=False):
         import numpy as np
         a = np.ascontiguousarray(a, np.complex64); b = np.ascontiguousarray(b, np.complex64)
         n = self.L.trxsig_convolve_out_len(a.size, b.size, span, cust_len)
         out = np.zeros(max(n, 1), np.complex64)
         rc = self.L.trxsig_convolve_host(self.h, a.ctypes.data, a.size, b.ctypes.data, b.size, span,
-                                         int(a_real) | (int(b_real) << 1), int(correlate), cust_start, cust_len, out.ctypes.data, out.size)
+                                         int(a_real) | (int(b_real) << 1) | (int(abssym) << 2), int(correlate), cust_start, cust_len, out.ctypes.data, out.size)
         if rc < 0:
             self._chk(rc, "trxsig_convolve_host")
         return out[:rc]

@@ -417,8 +417,10 @@ def gen_config1():
     ch = np.array([9000.0, np.float32(0.4) * np.float32(9000.0), 0, np.float32(-1.2) * 0], np.complex64)  # :133-137
     rx = r.convolve(dl, ch, refbind.NO_DELAY)                   # :139
     ra = r.analyze_traffic(rx, 0, 8.0, req_chan=True)           # :146 (before the noise is added)
-    noise_pwr = 0.001 / np.float32(np.sqrt(np.float32(2)))      # :143
-    rxn = (rx + awgn(rng, rx.size, float(np.sqrt(2 * noise_pwr)))).astype(np.complex64)   # :147
+    noise_pwr = 0.001 / float(np.sqrt(np.float32(2)))           # :143 double noisePwr = 0.001/sqrtf(2)
+    noise = r.gaussian_noise(1, rx.size, np.float32(noise_pwr))  # :144 after srand(1), the seed a C program starts with
+    rxn = r.add_vector(rx, noise)                               # :147
+    kw.update(autocorr=r.correlate(dn, xr, refbind.NO_DELAY), energy=r.vector_norm2(up), noise=noise)   # :118, :122
     soft = r.demodulate(rxn, ra["amp"], ra["toa"])              # :152
     kw.update(bits=bits, mod=x, up=up, dn=dn, delayed=dl, rx=rx, rx_noisy=rxn, ok=np.uint8(ra["ok"]),
               amp=ra["amp"], toa=ra["toa"], chan=ra.get("chan", np.zeros(0, np.complex64)),

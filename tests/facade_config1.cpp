@@ -1,8 +1,11 @@
 // BASELINE config 1 through the product: the call sequence of the reference's Transceiver/sigProcLibTest.cpp:29-181 (sps 1,
 // TSC 0; CommSig -> BitVector, SoftSig -> SoftVector as SURVEY section 4 describes) written against the reference's own
-// function names and run through include/sigProcLib_trx.h, i.e. on the GPU.  Inputs come from <dir>/in.bin (written by
-// tests/test_facade.py from tests/golden/: the two bit patterns, the raw LPF tables, the noisy burst), every intermediate
-// goes to <dir>/<name>.bin as raw float32 for the test to compare with tests/golden/config1_loopback.npz.
+// function names and run through include/sigProcLib_trx.h, i.e. on the GPU -- every call of the reference's main(), in its
+// order: :118 correlate, :122 vectorNorm2, :141-144 noisePwr / gaussianNoise (after srand(1), the C library's default
+// seed, so the draws are the ones the reference's program makes) and :147 addVector included.  Inputs come from <dir>/in.bin
+// (written by tests/test_facade.py from tests/golden/: the two bit patterns and the raw LPF tables -- reference data),
+// every intermediate goes to <dir>/<name>.bin as raw float32 for the test to compare with tests/golden/config1_loopback.npz.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -22,14 +25,12 @@ int main(int argc, char **argv) {
   if (argc < 2) return 19;
   dir = argv[1];
   char bits[149] = {0}, rbits[149] = {0};
-  std::vector<float> raw651(651), raw961(961), noisy(2 * 149);
-  float snr = 0;
+  std::vector<float> raw651(651), raw961(961);
   {
     FILE *f = std::fopen((dir + "/in.bin").c_str(), "rb");
     if (!f) return 18;
     bool ok = std::fread(bits, 1, 148, f) == 148 && std::fread(rbits, 1, 148, f) == 148 &&
-              std::fread(raw651.data(), 4, 651, f) == 651 && std::fread(raw961.data(), 4, 961, f) == 961 &&
-              std::fread(noisy.data(), 4, 298, f) == 298 && std::fread(&snr, 4, 1, f) == 1;
+              std::fread(raw651.data(), 4, 651, f) == 651 && std::fread(raw961.data(), 4, 961, f) == 961;
     std::fclose(f);
     if (!ok) return 17;
   }
@@ -67,6 +68,10 @@ int main(int argc, char **argv) {
   signalVector *dn = polyphaseResampleVector(*up, 65, 96, lpfRx);                        // :112-113
   if (!dn) return 8;
   dump("dn", *dn);
+  signalVector *autocorr = correlate(dn, rmod, NULL, NO_DELAY);                          // :118
+  if (!autocorr) return 14;
+  dump("autocorr", *autocorr);
+  { const float e = vectorNorm2(*up); dump("energy", &e, 1); }                           // :122
   delayVector(*dn, 6.932);                                                               // :125
   dump("delayed", *dn);
   signalVector channelResponse(4);                                                       // :133-137
@@ -79,12 +84,19 @@ int main(int argc, char **argv) {
   dump("rx", *rx);
   complex amp; float TOA = 0, chanOffset = 0;
   signalVector *chanResp = NULL;
+  double noisePwr = 0.001 / sqrtf(2);                                                    // :143
+  srand(1);                                                                              // (the seed a C program starts with)
+  signalVector *noise = gaussianNoise((int)rx->size(), noisePwr);                        // :144
+  if (!noise) return 15;
+  dump("noise", *noise);
   const bool found = analyzeTrafficBurst(*rx, 0, 8.0, sps, &amp, &TOA, true, &chanResp, &chanOffset);   // :146
   { const float r[5] = {found ? 1.0f : 0.0f, amp.r, amp.i, TOA, chanOffset}; dump("det", r, 5); }
   if (!found || !chanResp) return 10;
   dump("chan", *chanResp);
-  signalVector rxNoisy((int)noisy.size() / 2);                                           // :147 (the noise is an input here)
-  for (size_t k = 0; k < rxNoisy.size(); k++) rxNoisy[k] = complex(noisy[2 * k], noisy[2 * k + 1]);
+  if (!addVector(*rx, *noise)) return 16;                                                // :147
+  dump("rx_noisy", *rx);
+  signalVector &rxNoisy = *rx;
+  const float snr = 1.0 / noisePwr;                                                      // :159 (designDFE's float parameter)
   SoftVector *soft = demodulateBurst(rxNoisy, *gsmPulse, sps, amp, TOA);                 // :152
   if (!soft) return 11;
   dump("soft", soft->begin(), soft->size());
@@ -98,6 +110,7 @@ int main(int argc, char **argv) {
   for (int k = 0; k < 148; k++) { errs += soft->bit(k) != normalBurst.bit(k); eqerrs += eq->bit(k) != normalBurst.bit(k); }
   std::printf("config 1: RACH found %d; TSC found %d, TOA %.4f; slicer bit errors %d, DFE bit errors %d\n", rfound, found, TOA, errs, eqerrs);
   delete eq; delete w; delete b; delete soft; delete chanResp; delete rx; delete dn; delete up; delete lpfTx; delete lpfRx;
+  delete autocorr; delete noise;
   delete mod; delete rmod; delete gsmPulse;
   sigProcLibDestroy();
   return rfound ? 0 : 1;       // (the bit-error counts are the reference's own: the test compares them with the golden run)

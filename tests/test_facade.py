@@ -75,7 +75,6 @@ def test_config1_call_sequence_through_the_facade(tmp_path, golden):
     with open(d / "in.bin", "wb") as f:
         f.write(g["bits"].astype(np.int8).tobytes()); f.write(g["rach_bits"].astype(np.int8).tobytes())
         f.write(lp["rcvLPF_651_raw"].astype(np.float32).tobytes()); f.write(lp["sendLPF_961_raw"].astype(np.float32).tobytes())
-        f.write(g["rx_noisy"].astype(np.complex64).tobytes()); f.write(np.float32(g["dfe_snr"]).tobytes())
     r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=120)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
@@ -86,7 +85,8 @@ def test_config1_call_sequence_through_the_facade(tmp_path, golden):
     def rd(name, cplx=True):
         a = np.fromfile(d / (name + ".bin"), np.float32)
         return a.view(np.complex64) if cplx else a
-    for name in ("mod", "up", "dn", "delayed", "rx", "chan", "dfe_w", "dfe_b"):
+    assert rd("energy", False)[0] == g["energy"]
+    for name in ("mod", "up", "dn", "autocorr", "delayed", "rx", "noise", "rx_noisy", "chan", "dfe_w", "dfe_b"):
         got, want = rd(name), g[name]
         assert got.shape == want.shape and np.array_equal(got, want), name
     for name in ("soft", "eq_soft", "lpf_tx", "lpf_rx"):

@@ -157,3 +157,54 @@ def test_batch_forms_ragged(pkg, ctx):
     with pytest.raises(pkg.TrxSigError):
         t._chk(L.trxsig_convolve_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, int(lens.max()), db.data_ptr(), 41, 9,
                                        0, 0, 0, 0, dy.data_ptr(), doff.data_ptr()), "span 9")
+
+
+def test_rest_of_the_sigproclib_surface(ctx, golden):
+    """dB / dBinv, sinc, vectorNorm2 / vectorPower, frequencyShift, addVector, offsetVector, gaussianNoise (fixed srand seed),
+    resampleVector and convolve's ABSSYM form through the C-ABI against tests/golden/extras.npz (captured from the compiled
+    reference) and, on random inputs, the oracle.  Bit-exact."""
+    g = golden("extras.npz")
+    t = ctx[1]
+    o = oraclebind.Oracle(1)
+    assert_beq(np.array([t.db(v) for v in g["db_x"]], np.float32), g["db_y"], "dB")
+    assert_beq(np.array([t.dbinv(v) for v in g["dbinv_x"]], np.float32), g["dbinv_y"], "dBinv")
+    assert_beq(np.array([t.sinc_host(v) for v in g["sinc_x"]], np.float32), g["sinc_y"], "sinc")
+    pos = 0
+    for k, (off, n) in enumerate(zip(g["vec_off"], g["vec_len"])):
+        v = g["vec_x"][off:off + n]
+        e, p = t.vector_norm2_host(v)
+        assert e == g["vec_norm2"][k] and p == g["vec_power"][k], k
+        x = g["fshift_x"][pos:pos + n]
+        y, fin = t.frequency_shift_host(x, g["fshift_freq"][k], g["fshift_start"][k], bool(g["fshift_real"][k]))
+        assert_beq(y, g["fshift_y"][pos:pos + n], "frequencyShift %d" % k)
+        assert fin == g["fshift_final"][k]
+        pos += n
+    for k in (1, 2, 3):
+        assert_beq(t.add_vector_host(g["add_x"], g["add_y%d" % k]), g["add_r%d" % k], "addVector %d" % k)
+    assert_beq(t.elementwise_host(4, g["add_x"], complex(g["offset"]), False), g["offset_c"], "offsetVector")
+    assert_beq(t.elementwise_host(4, g["offset_xr"], complex(g["offset"]), True), g["offset_r"], "offsetVector real")
+    for seed in (1, 12345):
+        n, var, mr, mi = g["noise%d_arg" % seed]
+        assert_beq(t.gaussian_noise_host(seed, int(n), np.float32(var), complex(mr, mi)), g["noise%d" % seed], "gaussianNoise %d" % seed)
+    for k, ef in enumerate(g["rsv_factor"]):
+        assert_beq(t.resample_linear_host(g["rsv_x"], ef, complex(g["rsv_end"])), g["rsv%d" % k], "resampleVector %d" % k)
+    assert t.resample_linear_host(g["rsv_x"], 0.5) is None
+    for i in range(int(g["nsym"])):
+        assert_beq(t.convolve_host(g["sym%d_a" % i], g["sym%d_b" % i], int(g["sym%d_span" % i]), abssym=True), g["sym%d_y" % i], "ABSSYM %d" % i)
+    # random inputs against the oracle, incl. every span of the ABSSYM form and phases that wrap many times
+    rng = np.random.default_rng(5)
+    for trial in range(16):
+        n = int(rng.integers(1, 900))
+        x = cn(rng, n, 100.0)
+        assert t.vector_norm2_host(x) == (o.vector_norm2(x), o.vector_power(x))
+        f, s0, ro = np.float32(rng.uniform(-7, 7)), np.float32(rng.uniform(-50, 50)), bool(trial & 1)
+        xx = x.real.astype(np.complex64) if ro else x
+        y, fin = t.frequency_shift_host(xx, f, s0, ro); yo, fo = o.frequency_shift(xx, f, s0, ro)
+        assert_beq(y, yo, "frequencyShift random %d" % trial); assert fin == fo
+        b = cn(rng, int(rng.integers(1, 30)))
+        for span in range(5):
+            assert_beq(t.convolve_host(x, b, span, abssym=True), o.convolve(x, b, span, abssym=True), "ABSSYM span %d" % span)
+        ef = np.float32(rng.uniform(1, 5))
+        assert_beq(t.resample_linear_host(x, ef, 1 - 2j), o.resample_vector(x, ef, 1 - 2j), "resampleVector random")
+    with pytest.raises(Exception):
+        t.frequency_shift_host(np.ones(100, np.complex64), 1000.0, 0.0)      # beyond +-25000 rad: the reference would not return

@@ -118,3 +118,31 @@ def test_product_library_carries_the_defaults_only(pkg):
         assert k in prod, k
     assert pkg.lib().trxsig_tuning_build() == 0 and pkg.tune_lib().trxsig_tuning_build() == 1
     assert pkg.lib().trxsig_abi_version() == pkg.tune_lib().trxsig_abi_version()
+
+
+SIGPROCLIB_H_FUNCTIONS = (   # every free function Transceiver/sigProcLib.h:101-384 declares (33 names)
+    "dB", "dBinv", "vectorNorm2", "vectorPower", "sigProcLibSetup", "sigProcLibDestroy", "convolve", "generateGSMPulse",
+    "frequencyShift", "correlate", "vectorSlicer", "modulateBurst", "sinc", "delayVector", "addVector", "gaussianNoise",
+    "interpolatePoint", "peakDetect", "scaleVector", "offsetVector", "generateMidamble", "generateRACHSequence", "energyDetect",
+    "detectRACHBurst", "analyzeTrafficBurst", "decimateVector", "demodulateBurst", "createLPF", "polyphaseResampleVector",
+    "resampleVector", "designDFE", "equalizeBurst")
+
+
+def test_facade_covers_the_whole_sigproclib_header(tmp_path):
+    """include/sigProcLib_trx.h defines every free function of the reference's sigProcLib.h under its own name, in the
+    global namespace (a translation unit that takes the address of each one compiles), and the header's own list of names
+    is the one above -- checked against the reference header where it is present (build container)."""
+    import subprocess
+    assert len(SIGPROCLIB_H_FUNCTIONS) == 32 and len(set(SIGPROCLIB_H_FUNCTIONS)) == 32      # + the `complex` typedef = 33 names
+    ref = "/root/reference/Transceiver/sigProcLib.h"
+    if os.path.exists(ref):
+        text = "".join(open(ref).read().splitlines(True)[100:384])
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)) - {"complex"}
+        assert declared == set(SIGPROCLIB_H_FUNCTIONS), declared ^ set(SIGPROCLIB_H_FUNCTIONS)
+    src = tmp_path / "names.cpp"
+    uses = "\n".join("  (void)sizeof(&%s);" % n if n not in ("convolve", "analyzeTrafficBurst", "demodulateBurst") else "" for n in SIGPROCLIB_H_FUNCTIONS)
+    src.write_text('#include "sigProcLib_trx.h"\nint main() {\n%s\n  signalVector a(4), b(2);\n  b.setSymmetry(ABSSYM);\n'
+                   '  (void)sizeof(convolve(&a, &b, NULL, NO_DELAY)); complex z; float t;\n'
+                   '  (void)sizeof(analyzeTrafficBurst(a, 0, 3.0f, 1, &z, &t)); (void)sizeof(demodulateBurst(a, b, 1, z, t));\n  return 0;\n}\n' % uses)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
