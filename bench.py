@@ -12,9 +12,14 @@ Workloads (config.workload; the default, `normal`, is the headline):
            AWGN (SNR inf/20/10 dB), resident in HBM before the timed region.  A step = one pass of
            trxsig_detect_demod_normal_batch: energy detect + TSC correlate + peak/valley detect + demodulation to 148 soft bits.
   rach     config 3 -- 65,536 access bursts per GPU, detectRACHBurst over every lag + demodulation.
-  config4  S ARFCN streams per GPU of int16 I/Q at 400 kS/s, K chunks of 864 samples per step: trxsig_rxfe_push (unUSRPify +
-           polyphase resample 65*sps:96 behind the 192-sample history) + trxsig_rxfe_pop (157/156/156/156 slicing) + the
-           normal-burst detector on every burst cut.  (BASELINE's "8 ARFCN, one per GPU" run is --gpus 8: a stream set per rank.)
+  config4  S ARFCN streams per GPU of int16 I/Q at 400 kS/s, K chunks of 864 samples per step, through the Transceiver group on
+           the fused receive front end (trxsig_trxgroup_pull_rxfe): unUSRPify + polyphase resample 65*sps:96 behind the 192-sample
+           history + 157/156/156/156 slicing + per-slot expectedCorrType (every eighth ARFCN carries channel combination V on
+           timeslot 0, i.e. access-burst slots; all other slots combination I) + midamble / access-burst detection + the
+           per-ARFCN energy-threshold state machine + demodulation, the detectors computing their samples from the int16 chunks.
+           --stateless-frontend: the same without schedule or state (trxsig_rxfe_push_detect_demod_normal, TSC on every slot,
+           fixed thresholds); --unfused-frontend: through the resampled stream (push + pop + detect).
+           (BASELINE's "8 ARFCN, one per GPU" run is --gpus 8: a stream set per rank.)
   config5  the Transceiver52M receive leg at one sample per symbol, fp16 sample storage: energy gate, windowed midamble
            correlation with channel estimate, designDFE (Nf = 7), equalizeBurst.
 Multi-GPU: each rank owns an independent batch / stream set (weak scaling, one engine per ARFCN set as
@@ -143,7 +148,12 @@ class Normal:
             step_k(i)
         torch.cuda.synchronize()
         tf = time.perf_counter() - tf
-        return {"value": round(self.B * kf / tf / 1e6, 3), "unit": "Mbursts/s", "inputs_in_rotation": 3, "steps": kf}
+        self.ctx.profile_enable(True)                       # the same rotation with every launch bracketed by HIP events
+        for i in range(min(kf, 150)):
+            step_k(i)
+        pf = self.ctx.profile_collect()
+        self.ctx.profile_enable(False)
+        return {"value": round(self.B * kf / tf / 1e6, 3), "unit": "Mbursts/s", "inputs_in_rotation": 3, "steps": kf, "prof": pf}
 
     def cpu_baseline(self, check):
         """The real reference (oracle/_ref, when its in-place build travelled with the snapshot) and the oracle port on this
@@ -210,9 +220,15 @@ class Config4:
         self.alg_bytes = 4 * 625 * 96 // (65 * self.sps) + 4 * NSOFT + 16   # int16 in, soft bits out
         self.kernel_alg = {"k_resample": None}               # per stream-chunk, see roofline()
         self.kernel_names = {"k_tsc_peak": "k_tsc_peak2", "k_resample": "k_rx_resample"}
-        # default: trxsig_rxfe_push_detect_demod_normal (the detectors compute their samples from the int16 chunks, no resampled
-        # stream in HBM); --unfused-frontend: push + pop + trxsig_detect_demod_normal_batch through the complex float32 stream
+        # default: the Transceiver group on the fused front end (schedule + per-ARFCN state machine);
+        # --stateless-frontend: trxsig_rxfe_push_detect_demod_normal (no schedule, no state; the detectors compute their samples
+        # from the int16 chunks, no resampled stream in HBM);
+        # --unfused-frontend: push + pop + trxsig_detect_demod_normal_batch through the complex float32 stream
         self.fused = not bool(getattr(args, "unfused_frontend", False))
+        self.group = self.fused and not bool(getattr(args, "stateless_frontend", False))
+        if self.group:
+            self.kernel_names.update({"k_rach_corr": "k_rach_front_rx", "k_rach_peak": "k_rach_peak2+k_rach_fast_rx(list)"})
+            self.kernel_alg.update({"k_rach_corr": 4 * 236 + 8 * 25 + 16 + 17, "k_rach_peak": 8 * 25 + 16 + 17, "k_group_replay": 16 + 4 + 1 + 8})
         if self.fused:
             self.kernel_names.update({"k_demod": "k_demod_rx", "k_tsc_corr": "k_tsc_corr_rx"})
             # per burst: the raw stretch behind the burst (236 int16 pairs) / behind its two windows (140) read, soft bits / record written
@@ -250,6 +266,13 @@ class Config4:
         # reference's fixed table, made for 65:96, is not used at sps 4); the taps are an argument of the library
         self.lpf = synth.design_lpf(961, 65 * sps)
         self.fe = RxFrontEnd(ctx, S, self.lpf, max_chunks=K)
+        if self.group:
+            self.grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
+            for a in range(S):
+                self.grp.control(a, "CMD SETTSC %d" % self.tsc)
+                for tn in range(8):
+                    self.grp.control(a, "CMD SETSLOT %d %d" % (tn, 5 if (tn == 0 and a % 8 == 0) else 1))
+            self.slots_done = 0
         Bmax = S * (K * self.per_chunk // (156 * sps) + 2)
         self.flags = torch.zeros(Bmax, dtype=torch.uint8, device=dev)
         self.amp = torch.zeros(Bmax, 2, dtype=torch.float32, device=dev)
@@ -260,6 +283,15 @@ class Config4:
         self.last_nb = 0
 
     def step(self):
+        if self.group:
+            fn = (self.slots_done // 8) % (2048 * 26 * 51)
+            ns, res = self.grp.pull_rxfe(self.fe, self.segs[self.seg], fn)
+            self.seg = (self.seg + 1) % len(self.segs)
+            self.slots_done += ns
+            self.nbursts += self.S * ns
+            self.last_nb = res.n_rows
+            self.last_res = res
+            return
         if self.fused:
             nb, _ = self.fe.push_detect_demod(self.segs[self.seg], self.tsc, self.flags, self.amp, self.toa, self.soft, detect_thresh=3.0,
                                               energy_thresh=0.0, nsoft=NSOFT, soft_stride=NSOFT)
@@ -286,12 +318,22 @@ class Config4:
     def describe(self, world):
         return {"workload": "config4: %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), unUSRPify + "
                             "polyphase resample 260:96 (961-tap Kaiser LPF) + 157/156/156/156 slicing + TSC %d detect (thr 3.0) + demod to "
-                            "%d soft bits; %s" % (self.S, self.K, self.tsc, NSOFT, "one fused call, the resampled stream never written to HBM"
-                                                  if self.fused else "through the resampled complex float32 stream (push + pop + detect)"),
+                            "%d soft bits; %s" % (self.S, self.K, self.tsc, NSOFT,
+                                                  "Transceiver group on the fused front end: expectedCorrType per (ARFCN, slot) -- combination V on "
+                                                  "TN 0 of every 8th ARFCN (access-burst slots), combination I elsewhere --, adaptive energy threshold "
+                                                  "per ARFCN replayed on the device, the resampled stream never written to HBM" if self.group else
+                                                  ("one fused call, the resampled stream never written to HBM, TSC on every slot, fixed thresholds"
+                                                   if self.fused else "through the resampled complex float32 stream (push + pop + detect)")),
                 "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                 "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
 
     def sanity(self):
+        if self.group:
+            r = self.grp.collect(soft=False)
+            thr = r["threshold"]
+            return {"softvectors_returned_frac_last_step": round(float(r["valid"].mean()), 4), "rows_last_step": int(self.last_nb),
+                    "slots_last_step": int(r["valid"].shape[0]), "energy_threshold_min_max": [float(__import__("numpy").nanmin(thr)),
+                                                                                            float(__import__("numpy").nanmax(thr))]}
         det = (self.flags[:self.last_nb] & self.pkg.F_DETECT) != 0
         return {"detected_frac": round(float(det.float().mean().item()), 4), "bursts_cut_last_step": int(self.last_nb)}
 
@@ -305,25 +347,34 @@ class Config4:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oraclebind
         o = oraclebind.Oracle(self.sps)
-        iq = self.iq[0].cpu().numpy()
-        nchunks = min(self.KT, 64)
+        nchunks = min(self.KT, 125)
+        n_bursts = 0
         t0 = time.perf_counter()
-        hist = np.zeros(192, np.complex64); rcv = []
-        for c in range(nchunks):
-            ch = iq[c * 864:(c + 1) * 864]
-            cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)
-            y = o.polyphase_resample(np.concatenate([hist, cf]), 65 * self.sps, 96, self.lpf)
-            rcv.append(y[2 * 65 * self.sps:]); hist = cf[-192:]
-        x = np.concatenate(rcv)
-        lens = []; pos = 0; tn = 0
-        while x.size - pos > (156 + (tn % 4 == 0)) * self.sps:
-            n = (156 + (tn % 4 == 0)) * self.sps; lens.append(n); pos += n; tn = (tn + 1) % 8
-        lens = np.array(lens, np.int32); off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
-        ok, amp, toa, soft = o.normal_batch(x, off, lens, self.tsc, nthreads=1)
+        for s in range(self.S):                               # one stream after the other until ~10 s of CPU work are done
+            iq = self.iq[s].cpu().numpy()
+            hist = np.zeros(192, np.complex64); rcv = []
+            for c in range(nchunks):
+                ch = iq[c * 864:(c + 1) * 864]
+                cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)
+                y = o.polyphase_resample(np.concatenate([hist, cf]), 65 * self.sps, 96, self.lpf)
+                rcv.append(y[2 * 65 * self.sps:]); hist = cf[-192:]
+            xs = np.concatenate(rcv)
+            lens = []; pos = 0; tn = 0
+            while xs.size - pos > (156 + (tn % 4 == 0)) * self.sps:
+                n = (156 + (tn % 4 == 0)) * self.sps; lens.append(n); pos += n; tn = (tn + 1) % 8
+            lens = np.array(lens, np.int32); off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+            r = o.normal_batch(xs, off, lens, self.tsc, nthreads=1)
+            n_bursts += len(lens)
+            if s == 0:
+                x, ok, amp, toa, soft, lens0, pos0 = xs, r[0], r[1], r[2], r[3], lens, pos
+            if time.perf_counter() - t0 > 10.0:
+                break
         tt = time.perf_counter() - t0
-        out = {"cpu_baseline": {"value": round(len(lens) / tt / 1e6, 6), "unit": "Mbursts/s", "cores": 1, "kind": "port",
-                                "sample": "%d chunks of stream 0 (%d bursts): polyphaseResampleVector chunk by chunk + analyzeTrafficBurst + "
-                                          "demodulateBurst, oracle/sigproc_oracle.c, one thread, %.1f s" % (nchunks, len(lens), tt)}}
+        lens, pos = lens0, pos0
+        out = {"cpu_baseline": {"value": round(n_bursts / tt / 1e6, 6), "unit": "Mbursts/s", "cores": 1, "kind": "port",
+                                "sample": "%d chunks each of the first %d streams (%d bursts): polyphaseResampleVector chunk by chunk + "
+                                          "analyzeTrafficBurst + demodulateBurst, oracle/sigproc_oracle.c, one thread, %.1f s"
+                                          % (nchunks, s + 1, n_bursts, tt)}}
         if check:
             # the first bursts of stream 0 as the device cut them on the FIRST step are not kept; re-run one step on a fresh front end
             from openbts_ttsou_amd.frontend import RxFrontEnd
@@ -425,7 +476,9 @@ def main():
                          "input stays aligned with the front end's burst schedule whatever K is")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
-    ap.add_argument("--unfused-frontend", action="store_true", help="config4: push + pop + detect through the resampled complex float32 stream instead of trxsig_rxfe_push_detect_demod_normal")
+    ap.add_argument("--unfused-frontend", action="store_true", help="config4: push + pop + detect through the resampled complex float32 stream instead of the fused front end")
+    ap.add_argument("--stateless-frontend", action="store_true", help="config4: trxsig_rxfe_push_detect_demod_normal (TSC on every slot, fixed thresholds) instead of the Transceiver group")
+    ap.add_argument("--repeats", type=int, default=None, help="extra timed repetitions of the K steps after the official one (min / median are reported beside `value`); default 4 when --steps < 100, else 0")
     ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
                     help="normal = BASELINE config 2 (the headline metric); rach = config 3; config4 = resample + slice + detect "
                          "per ARFCN stream; config5 = 52M equaliser leg, fp16 storage (side measurements)")
@@ -527,9 +580,20 @@ def main():
         step()
     ev_ms = ctx.timer_stop()
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = tdist.max_over_ranks(elapsed, cdev)
+    elapsed_own = time.perf_counter() - t0
+    elapsed = tdist.max_over_ranks(elapsed_own, cdev)
     seen = tdist.ranks_seen(rank, cdev)
+    per_rank = tdist.gather_floats(elapsed_own, cdev)       # every rank's own time for the same K steps (a straggler shows here)
+    # ---- more repetitions of the same K steps (outside `value`): the spread of a short run
+    n_rep = args.repeats if args.repeats is not None else (4 if args.steps < 100 else 0)
+    rep_ms = [elapsed / args.steps * 1e3]
+    for _ in range(n_rep):
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        rep_ms.append(tdist.max_over_ranks(time.perf_counter() - tr, cdev) / args.steps * 1e3)
     # ---- per-kernel durations: the same steps again with every launch bracketed by HIP events
     #      (kept out of the timed region: the extra event records stretch the gaps between kernels)
     ctx.profile_enable(True)
@@ -539,6 +603,9 @@ def main():
     ctx.profile_enable(False)
 
     fresh = wl.fresh_inputs(args.steps) if (world == 1 and not args.no_fresh) else None
+    prof_fresh = None
+    if fresh is not None and "prof" in fresh:
+        prof_fresh = fresh.pop("prof")
     sanity = wl.sanity()
     if rank != 0:
         return
@@ -562,13 +629,30 @@ def main():
                 "pipeline_achieved": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9, 1),
                 "pipeline_frac": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernels_ms": {wl.kernel_names.get(k, k): round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}}
+    roof_fresh = None
+    if prof_fresh and dom[0] in prof_fresh:
+        # the same kernel on inputs it has not seen a step ago (three batches in rotation, 1 GB > the 256 MB memory-side cache)
+        f_ms = prof_fresh[dom[0]][0] / max(prof_fresh[dom[0]][1], 1)
+        per_unit = wl.kernel_alg.get(dom[0], wl.alg_bytes)
+        ach = per_unit * units / (f_ms * 1e-3) / 1e9
+        roof_fresh = {"bound": "hbm", "kernel": wl.kernel_names.get(dom[0], dom[0]), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(f_ms, 4),
+                      "alg_bytes_per_launch": int(per_unit * units), "inputs_in_rotation": 3,
+                      "pipeline_frac": round(wl.alg_bytes * fresh["value"] * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
+                      "kernels_ms": {wl.kernel_names.get(k, k): round(v[0] / max(v[1], 1), 4) for k, v in prof_fresh.items()}}
     out = {
         "metric": "Mbursts/s (156.25-sym @ 4 sps) demod+detect", "value": round(value, 3), "unit": "Mbursts/s",
         "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
         "config": wl.describe(world),
         "hip_event_ms_per_step": round(ev_ms / args.steps, 4), "preheat_steps": n_pre,
-        "roofline": roof, "fresh_inputs": fresh,
+        "roofline": roof, "fresh_inputs": fresh, "roofline_fresh": roof_fresh,
+        "per_rank": [{"rank": i, "value": round(units * args.steps / t / 1e6, 3), "ms_per_step": round(t / args.steps * 1e3, 4)}
+                     for i, t in enumerate(per_rank)],
+        "repetitions": {"n": len(rep_ms), "ms_per_step": [round(v, 4) for v in rep_ms], "min_ms_per_step": round(min(rep_ms), 4),
+                        "median_ms_per_step": round(sorted(rep_ms)[len(rep_ms) // 2], 4),
+                        "median_value": round(world * units / (sorted(rep_ms)[len(rep_ms) // 2] * 1e-3) / 1e6, 3),
+                        "note": "`value` is the first repetition (the contract's K steps); the others follow it back to back"},
     }
     out.update(sanity)
     if args.rehearse_one_gpu:

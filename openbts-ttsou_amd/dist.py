@@ -68,3 +68,15 @@ def ranks_seen(rank, device=None):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return sorted(int(o.item()) for o in out)
+
+
+def gather_floats(value, device=None):
+    """All-gather of one python float per rank, in rank order (bench.py: every rank's own step time)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
