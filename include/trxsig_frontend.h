@@ -10,7 +10,7 @@
  *                 the stream's send buffer; whenever it holds whole chunks of INCHUNK = 585*sps samples,
  *                 [INHISTORY history | chunks] -> polyphaseResampleVector(P = 96, Q = 65*sps, sendLPF) (:141-144) ->
  *                 scaleVector(gain = 13500) (:148) -> USRPifyVector (:74-89), first OUTHISTORY = 192 outputs dropped (:165).
- *                 One fused kernel per pop (filter, gain, int16 pack).
+ *                 One kernel per pop that modulates from the queued bits, filters, scales and packs int16 (trxsig_txbe_set_fused).
  * All buffers are device memory owned by the object (per-stream linear buffers; no reallocation per chunk); sample values
  * are the reference's bit for bit (tests/test_gpu_config4.py, tests/test_gpu_txchain.py).  The USRP itself (the source /
  * sink of the int16 samples) and the GSM clock are the caller's (component 5 is out of scope).
@@ -66,6 +66,13 @@ int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, i
 /* h_lpf: the L (normally 651, createLPF(cutoff, 651, 96): radioInterface.cpp:134-138) normalised taps.  max_bursts: the
  * most bursts per stream one push may carry. */
 int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *ctx, int n_streams, int max_bursts, const float *h_lpf, int L, float gain);
+/* How the back end works inside (before the first push; results are the same int16 values either way).  1, the default:
+ * FUSED -- a pushed burst leaves only its 148 bits and its gain in a ring; trxsig_txbe_pop runs ONE kernel that computes the
+ * modulated samples its filter taps meet from those bits (modulateBurst's three non-zero terms, addRadioVector's scaling),
+ * resamples, applies the 13500 gain and packs int16: the complex float32 send buffer of radioInterface.cpp:123-194 never
+ * exists in memory.  0: modulate into a send buffer at push, resample it at pop (two kernels, 5 KB per burst written and
+ * read back). */
+int trxsig_txbe_set_fused(trxsig_txbe *be, int fused);
 void trxsig_txbe_destroy(trxsig_txbe *be);
 /* modulateBurst (+ addRadioVector's power scaling when d_gain != NULL) of n_bursts bursts per stream, appended to the send
  * buffers: d_bits [n_streams][n_bursts][148] (one bit per byte), h_guard[n_bursts] guard symbols per burst (host; the same

@@ -45,10 +45,23 @@ struct trxsig_rxfe {
   int tail = 0;                                             // resampled samples of earlier pushes not yet cut into bursts
 };
 
+// a burst whose samples (partly) lie in the send buffer: fused mode keeps its bits, not its samples
+struct TxBurst { long long start; int len, slot, guard, has_gain; };
+
 struct trxsig_txbe {
   trxsig_ctx *c = nullptr;
   int S = 0, sps = 0, Q = 0, L = 0, inchunk = 0, inhist = 0, max_bursts = 0;
   float gain = 13500.0f;
+  // fused mode (the default): modulate -> resample -> gain -> int16 in ONE kernel per pop, straight from the bursts' bits; the
+  // complex float32 send buffer does not exist.  The ring keeps the bits / gains of every burst that still has samples in
+  // [history | pending], the host keeps where each of them starts (window coordinates: sample 0 = first history sample).
+  int fused = 1, started = 0;
+  int ring_cap = 0, ring_head = 0;
+  uint8_t *d_ring = nullptr;                                // [S][ring_cap][148]
+  float *d_rgain = nullptr;                                 // [S][ring_cap]
+  int32_t *d_tab = nullptr;                                 // start[tab_cap] then meta[tab_cap]
+  int tab_cap = 0;
+  std::vector<TxBurst> live;
   long long stride = 0, iq_stride = 0;
   int fill = 0;                                             // modulated samples behind the history, per stream
   int cur = 0;                                              // which of the two send buffers is live
@@ -287,10 +300,16 @@ int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *c, int n_streams, int max_
     ok = hipMalloc((void **)&be->d_send[k], sizeof(trx_c32) * (size_t)be->stride * be->S) == hipSuccess &&
          hipMemset(be->d_send[k], 0, sizeof(trx_c32) * (size_t)be->stride * be->S) == hipSuccess;   // sendHistory starts as zeros
   }
+  // the ring holds what one push can add plus whatever can still be pending or in the history (less than a chunk + the history)
+  be->ring_cap = max_bursts + (be->inchunk + be->inhist) / (148 * be->sps) + 4;
+  be->tab_cap = be->ring_cap + 2;
   ok = ok && hipMalloc((void **)&be->d_lpf, sizeof(float) * (size_t)L) == hipSuccess &&
        hipMemcpy(be->d_lpf, h_lpf, sizeof(float) * (size_t)L, hipMemcpyHostToDevice) == hipSuccess &&
        hipMalloc((void **)&be->d_iq, sizeof(short2) * (size_t)be->iq_stride * be->S) == hipSuccess &&
-       hipMalloc((void **)&be->d_meta, sizeof(int32_t) * 2 * (size_t)max_bursts * be->S) == hipSuccess;
+       hipMalloc((void **)&be->d_meta, sizeof(int32_t) * 2 * (size_t)max_bursts * be->S) == hipSuccess &&
+       hipMalloc((void **)&be->d_ring, (size_t)148 * be->ring_cap * be->S) == hipSuccess &&
+       hipMalloc((void **)&be->d_rgain, sizeof(float) * (size_t)be->ring_cap * be->S) == hipSuccess &&
+       hipMalloc((void **)&be->d_tab, sizeof(int32_t) * 2 * (size_t)be->tab_cap) == hipSuccess && be->ring_cap < 65536;
   if (!ok) {
     trxsig_txbe_destroy(be);
     return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_txbe_create: device allocation failed", hipSuccess);
@@ -304,11 +323,19 @@ void trxsig_txbe_destroy(trxsig_txbe *be) {
   {
     Guard g(trxsig_device(be->c));
     (void)hipFree(be->d_send[0]); (void)hipFree(be->d_send[1]); (void)hipFree(be->d_lpf); (void)hipFree(be->d_iq); (void)hipFree(be->d_meta);
+    (void)hipFree(be->d_ring); (void)hipFree(be->d_rgain); (void)hipFree(be->d_tab);
   }
   delete be;
 }
 
 int trxsig_txbe_pending(const trxsig_txbe *be) { return be ? be->fill : TRXSIG_EINVAL; }
+
+int trxsig_txbe_set_fused(trxsig_txbe *be, int fused) {
+  if (!be) return TRXSIG_EINVAL;
+  if (be->started) return trx_ctx_fail(be->c, TRXSIG_EINVAL, "trxsig_txbe_set_fused: the back end is in use", hipSuccess);
+  be->fused = fused != 0;
+  return TRXSIG_OK;
+}
 
 int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_t *h_guard, const float *d_gain, int n_bursts) {
   if (!be) return TRXSIG_EINVAL;
@@ -324,6 +351,24 @@ int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: send buffers full (call trxsig_txbe_pop first)", hipSuccess);
   Guard g(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  be->started = 1;
+  if (be->fused) {
+    // only the bits travel: burst j of this push takes ring slot head + j and starts where the pending samples end
+    if ((int)be->live.size() + n_bursts > be->ring_cap)
+      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: burst ring full (call trxsig_txbe_pop first)", hipSuccess);
+    FE_HIP(c, trx_launch_tx_ring_store(st, d_bits, d_gain, be->S, n_bursts, be->ring_head, be->ring_cap, be->d_ring, be->d_rgain));
+    long long pos = (long long)be->inhist + be->fill;
+    for (int j = 0; j < n_bursts; j++) {
+      TxBurst b;
+      b.start = pos; b.len = be->sps * (148 + h_guard[j]); b.slot = (be->ring_head + j) % be->ring_cap; b.guard = h_guard[j];
+      b.has_gain = d_gain != nullptr;
+      be->live.push_back(b);
+      pos += b.len;
+    }
+    be->ring_head = (be->ring_head + n_bursts) % be->ring_cap;
+    be->fill += (int)tot;
+    return TRXSIG_OK;
+  }
   const int B = be->S * n_bursts;
   std::vector<int32_t> meta(2 * (size_t)B);
   for (int s = 0; s < be->S; s++) {
@@ -359,6 +404,35 @@ int trxsig_txbe_pop(trxsig_txbe *be, const int16_t **d_iq, int64_t *stream_strid
   a.lpf = be->d_lpf; a.L = be->L; a.P = TRXSIG_OUTRATE; a.Q = be->Q;
   a.o_skip = TRXSIG_OUTHISTORY; a.n_out = n_out;           // writeSamples(resampledVectorShort + OUTHISTORY*2, size - OUTHISTORY) (:165-166)
   a.out = be->d_iq; a.out_stride = be->iq_stride; a.gain = be->gain;
+  if (be->fused) {
+    // the window [history | whole chunks] as a list of bursts: where each starts, its ring slot, guard and gain flag
+    const int M = (int)be->live.size();
+    std::vector<int32_t> tab(2 * (size_t)be->tab_cap, 0);
+    int m_used = 0;
+    for (int m = 0; m < M && m_used < be->tab_cap; m++) {
+      const TxBurst &b = be->live[(size_t)m];
+      if (b.start >= n_in) break;                           // lies entirely in the left-over
+      tab[(size_t)m_used] = (int32_t)b.start;
+      tab[(size_t)be->tab_cap + m_used] = b.slot | (b.guard << 16) | (b.has_gain << 20);
+      m_used++;
+    }
+    FE_HIP(c, hipMemcpyAsync(be->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, st));   // (pageable source: consumed at return)
+    a.in = be->d_ring; a.in_stride = be->ring_cap;
+    a.tx_tables = (const TrxTables *)trxsig_tables_device(c); a.tx_gain = be->d_rgain; a.tx_start = be->d_tab; a.tx_meta = be->d_tab + be->tab_cap;
+    a.tx_n = m_used; a.tx_sps = be->sps;
+    FE_HIP(c, trx_launch_resample_ex(st, a, be->S, 1, false, true, trx_ctx_profiler(c), true));
+    // sendHistory = the last INHISTORY samples sent, the rest of sendBuffer follows it (:183-191): the window's origin moves on
+    // by ntr samples; bursts that end before it are done
+    size_t keep_from = 0;
+    for (size_t m = 0; m < be->live.size(); m++) {
+      be->live[m].start -= ntr;
+      if (be->live[m].start + be->live[m].len <= 0) keep_from = m + 1;
+    }
+    be->live.erase(be->live.begin(), be->live.begin() + (long)keep_from);
+    be->fill -= ntr;
+    *n_samples = n_out - TRXSIG_OUTHISTORY;
+    return TRXSIG_OK;
+  }
   FE_HIP(c, trx_launch_resample_ex(st, a, be->S, 1, false, true, trx_ctx_profiler(c)));
   // sendHistory = the last INHISTORY samples sent (:183-184), the rest of sendBuffer follows it (:187-191): into the other buffer
   const int keep = be->inhist + be->fill - ntr;             // history + left-over, contiguous at [ntr, ntr + keep)

@@ -113,9 +113,15 @@ struct TrxResampleArgs {
   void *out; long long out_stride, out_win_step;           // window w of stream s writes at out + s*out_stride + w*out_win_step
   float gain;                                              // int16 output
   int OB, xcap, taps_lds;                                  // filled in by the launcher
+  // input computed from burst bits (the fused transmit back end): in = the bit ring [S][in_stride slots][148], tx_gain the gains
+  // [S][in_stride]; tx_start[m] / tx_meta[m] (m < tx_n, device, ascending): where burst m starts in the window and
+  // slot | guard << 16 | has_gain << 20
+  const TrxTables *tx_tables; const float *tx_gain; const int32_t *tx_start, *tx_meta; int tx_n, tx_sps;
 };
 hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
-                                  TrxProfiler *prof);
+                                  TrxProfiler *prof, bool in_bits = false);
+hipError_t trx_launch_tx_ring_store(hipStream_t st, const uint8_t *bits, const float *gain, int S, int nb, int head, int cap, uint8_t *ring,
+                                    float *gring);
 hipError_t trx_launch_burst_index(hipStream_t st, int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *off,
                                   int32_t *len);
 // The receive front end fused into the normal-burst detectors (trxsig_rxgen.h, sps = 4, 65*4 : 96 with at most four taps per

@@ -71,8 +71,60 @@ __global__ __launch_bounds__(256) void k_modulate(const TrxTables *__restrict__ 
 #define TRX_RES_XCAP 4096                                  // staged input samples per workgroup
 #define TRX_RES_LCAP 4096                                  // staged taps
 
-template <bool IN_I16, bool OUT_I16>
+//   IN_BITS: (the transmit back end, fused) there is no input stream at all: the window is the concatenation of modulated
+//            bursts, and a staged sample is computed from the burst's 148 bits -- modulateBurst's at most three non-zero
+//            terms (k_modulate's arithmetic) and addRadioVector's gain -- so the complex float32 send buffer never exists.
+//            a.tx: the bursts that overlap the window (start position, ring slot, guard, gain flag), a.in: the bit ring.
+// Window samples [lo, hi] that bursts cover, computed from the bursts' bits: burst by burst, a thread per symbol period.
+// Sample t = SPS u + r of a burst is modulateBurst's sum over j ascending of a[t + SPS - j] p[j] where only j = r, r + SPS
+// (and r + 2 SPS for r = 0) meet a non-zero a[n] = rot[n] * (2 bit - 1), n = SPS (u + 1 - q) (k_modulate's arithmetic): the
+// three symbols u + 1, u, u - 1 serve the period's SPS samples.
+template <int SPS>
+__device__ __forceinline__ void tx_stage_tile(const TrxTables *__restrict__ T, const uint8_t *__restrict__ ring, const float *__restrict__ gring,
+                                              const int *tb_start, const int *tb_meta, int M, int lo, int hi, cx *X) {
+  float pul[2 * SPS + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * SPS + 1; j++) pul[j] = T->pulse[j];
+  for (int m = 0; m < M; m++) {                            // (uniform: every thread walks the tile's bursts)
+    const int start = tb_start[m];
+    if (start > hi) break;
+    const int meta = tb_meta[m], slot = meta & 0xffff, guard = (meta >> 16) & 0xf;
+    const bool scale = (meta >> 20) & 1;
+    const int nsym = 148 + guard;
+    if (start + SPS * nsym <= lo) continue;
+    const float gv = scale ? gring[slot] : 1.0f;
+    const uint8_t *bits = ring + (size_t)slot * 148;
+    const int u0 = start < lo ? (lo - start) / SPS : 0;
+    const int u1 = (hi - start) / SPS < nsym - 1 ? (hi - start) / SPS : nsym - 1;
+    for (int u = u0 + (int)threadIdx.x; u <= u1; u += 256) {
+      cx av[3];                                            // a[SPS (u + 1 - q)], q = 0, 1, 2; valid: the symbol exists
+      bool ok[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int k = u + 1 - q;
+        ok[q] = k >= 0 && k < 148;
+        const int kc = ok[q] ? k : 0;
+        const float sym = (float)(2.0 * (bits[kc] & 0x01) - 1.0);
+        av[q] = cmulr(T->rot[SPS * kc], sym);              // GMSKRotate, realOnly (:235-239)
+      }
+#pragma unroll
+      for (int r = 0; r < SPS; r++) {
+        const int i = start + SPS * u + r;
+        cx sum = mk(0, 0);
+        if (ok[0]) sum = cadd(sum, cmulr(av[0], pul[r]));              // j = r
+        if (ok[1]) sum = cadd(sum, cmulr(av[1], pul[r + SPS]));        // j = r + SPS   (convolve, b real: :345-353)
+        if (r == 0 && ok[2]) sum = cadd(sum, cmulr(av[2], pul[2 * SPS]));   // j = 2 SPS
+        if (scale) sum = cmul(sum, mk(gv, 0.0f));                      // scaleVector(x, complex(g)) (:719-722)
+        if (i >= lo && i <= hi) X[i - lo] = sum;
+      }
+    }
+  }
+}
+
+enum { RES_IN_F32 = 0, RES_IN_I16 = 1, RES_IN_BITS = 2 };
+template <int INKIND, bool OUT_I16>
 __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
+  constexpr bool IN_I16 = INKIND == RES_IN_I16;
   // dynamic LDS, sized by the launcher to what this launch needs (a window of 1056 samples + 961 taps is 12 KB: a dozen
   // workgroups per CU instead of four): [xcap complex samples][taps]
   extern __shared__ __attribute__((aligned(16))) char res_lds[];
@@ -117,6 +169,29 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
         if (i <= hi) X[i - lo] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
       }
     }
+  } else if (INKIND == RES_IN_BITS) {
+    // the bursts behind this tile's samples: [start, start + len) in window coordinates, back to back
+    // (a tile's span is at most TRX_RES_XCAP samples = 28 of the shortest bursts: 64 table entries from the one that
+    // holds sample `lo` cover it)
+    __shared__ int tb_start[64], tb_meta[64], tb_first;
+    if (threadIdx.x == 0) {
+      int a0 = 0, b0 = a.tx_n - 1;                         // last burst that starts at or before lo (0 if none does)
+      while (a0 < b0) { const int mid = (a0 + b0 + 1) >> 1; if (a.tx_start[mid] <= lo) a0 = mid; else b0 = mid - 1; }
+      tb_first = a0 < 0 ? 0 : a0;
+    }
+    __syncthreads();
+    const int m_first = tb_first;
+    const int M = a.tx_n - m_first < 64 ? a.tx_n - m_first : 64;
+    if ((int)threadIdx.x < M) { tb_start[threadIdx.x] = a.tx_start[m_first + threadIdx.x]; tb_meta[threadIdx.x] = a.tx_meta[m_first + threadIdx.x]; }
+    __syncthreads();
+    const uint8_t *ring = reinterpret_cast<const uint8_t *>(a.in) + (size_t)s * a.in_stride * 148;
+    const float *gring = a.tx_gain + (size_t)s * a.in_stride;
+    // history before the first burst ever pushed (sendHistory starts as zeros) and anything no burst covers
+    for (int i = lo + threadIdx.x; i <= hi; i += 256) X[i - lo] = mk(0, 0);
+    __syncthreads();
+    if (a.tx_sps == 4) tx_stage_tile<4>(a.tx_tables, ring, gring, tb_start, tb_meta, M, lo, hi, X);
+    else if (a.tx_sps == 2) tx_stage_tile<2>(a.tx_tables, ring, gring, tb_start, tb_meta, M, lo, hi, X);
+    else tx_stage_tile<1>(a.tx_tables, ring, gring, tb_start, tb_meta, M, lo, hi, X);
   } else {
     const cx *x = reinterpret_cast<const cx *>(a.in) + (size_t)s * a.in_stride + (size_t)w * a.win_step;
     for (int i0 = lo + threadIdx.x; i0 <= hi; i0 += 256 * 8) {
@@ -227,6 +302,16 @@ __global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a) {
   }
 }
 
+// trxsig_txbe_push_bursts, fused mode: the bits (and gains) of the pushed bursts go into the per-stream burst ring
+__global__ __launch_bounds__(256) void k_tx_ring_store(const uint8_t *__restrict__ bits, const float *__restrict__ gain, int S, int nb,
+                                                       int head, int cap, uint8_t *__restrict__ ring, float *__restrict__ gring) {
+  const int i = blockIdx.x;                                // (stream, burst)
+  const int s = i / nb, j = i - s * nb;
+  const int slot = (head + j) % cap;
+  if (threadIdx.x < 148) ring[((size_t)s * cap + slot) * 148 + threadIdx.x] = bits[(size_t)i * 148 + threadIdx.x];
+  if (threadIdx.x == 0) gring[(size_t)s * cap + slot] = gain ? gain[i] : 1.0f;
+}
+
 // trxsig_rxfe_pop's index arrays: burst j of stream s starts at s*stride + rd + (samples of bursts 0..j-1)
 __global__ __launch_bounds__(256) void k_burst_index(int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *__restrict__ off,
                                                      int32_t *__restrict__ len) {
@@ -299,7 +384,7 @@ static int resample_tile(const TrxResampleArgs &a) {
 }
 
 hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
-                                  TrxProfiler *prof) {
+                                  TrxProfiler *prof, bool in_bits) {
   if (S <= 0 || n_windows <= 0 || a.n_out <= a.o_skip) return hipSuccess;
   a.OB = resample_tile(a);
   long long span = ((long long)(a.OB - 1) * a.Q) / a.P + (a.L + a.P - 1) / a.P + 4;      // staged samples a tile can need
@@ -318,9 +403,11 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
   if (rx_fast) {
     const size_t lds2 = sizeof(trx_c32) * (size_t)(a.n + 8) + sizeof(float) * 4 * (size_t)a.P;
     k_rx_resample<<<dim3(1, n_windows, S), block, lds2, st>>>(a);
-  } else if (in_i16 && !out_i16) k_resample<true, false><<<grid, block, lds, st>>>(a);
-  else if (!in_i16 && out_i16) k_resample<false, true><<<grid, block, lds, st>>>(a);
-  else if (!in_i16 && !out_i16) k_resample<false, false><<<grid, block, lds, st>>>(a);
+  } else if (in_bits && out_i16 && !in_i16) k_resample<RES_IN_BITS, true><<<grid, block, lds, st>>>(a);
+  else if (in_bits) return hipErrorInvalidValue;
+  else if (in_i16 && !out_i16) k_resample<RES_IN_I16, false><<<grid, block, lds, st>>>(a);
+  else if (!in_i16 && out_i16) k_resample<RES_IN_F32, true><<<grid, block, lds, st>>>(a);
+  else if (!in_i16 && !out_i16) k_resample<RES_IN_F32, false><<<grid, block, lds, st>>>(a);
   else return hipErrorInvalidValue;
   if (prof) prof->end(TRXSIG_K_RESAMPLE, st);
   return hipGetLastError();
@@ -355,3 +442,10 @@ hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long lon
   return hipGetLastError();
 }
 
+
+hipError_t trx_launch_tx_ring_store(hipStream_t st, const uint8_t *bits, const float *gain, int S, int nb, int head, int cap, uint8_t *ring,
+                                    float *gring) {
+  if (S * nb <= 0) return hipSuccess;
+  k_tx_ring_store<<<dim3(S * nb), dim3(256), 0, st>>>(bits, gain, S, nb, head, cap, ring, gring);
+  return hipGetLastError();
+}

@@ -35,6 +35,7 @@ def _bind(L):
     L.trxsig_txbe_push_bursts.argtypes = [vp, vp, vp, vp, i32]
     L.trxsig_txbe_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(i32)]
     L.trxsig_txbe_pending.argtypes = [vp]
+    L.trxsig_txbe_set_fused.argtypes = [vp, i32]
     L._frontend_bound = True
 
 
@@ -126,7 +127,7 @@ class RxFrontEnd:
 
 
 class TxBackEnd:
-    def __init__(self, ctx, n_streams, lpf_taps, gain=13500.0, device="cuda:0", max_bursts=64):
+    def __init__(self, ctx, n_streams, lpf_taps, gain=13500.0, device="cuda:0", max_bursts=64, fused=True):
         import torch
         self.torch = torch
         self.ctx = ctx
@@ -140,6 +141,7 @@ class TxBackEnd:
         ctx._chk(self.L.trxsig_txbe_create(C.byref(h), ctx.h, n_streams, max_bursts, lpf.ctypes.data, lpf.size, float(gain)),
                  "trxsig_txbe_create")
         self.h = h
+        ctx._chk(self.L.trxsig_txbe_set_fused(h, int(fused)), "trxsig_txbe_set_fused")
 
     def close(self):
         if self.h:

@@ -1,6 +1,7 @@
 """TX chain end to end on the GPU (pushRadioVector side): bursts -> modulateBurst ->
 send buffer with history -> polyphaseResampleVector(96 : 65*sps, sendLPF) -> scaleVector(13500) ->
-USRPifyVector int16, against the same chain built from the CPU oracle.  Value-exact."""
+USRPifyVector int16, against the same chain built from the CPU oracle.  Value-exact, in both forms of the back end: fused
+(one kernel per pop that modulates from the queued bits; the complex float32 send buffer never exists) and unfused."""
 import numpy as np
 import pytest
 
@@ -10,8 +11,9 @@ import oraclebind
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("sps", [1, 4])
-def test_tx_chain(golden, sps):
+def test_tx_chain(golden, sps, fused):
     import torch
     assert torch.cuda.is_available()
     pkg = _pkg.load()
@@ -21,7 +23,7 @@ def test_tx_chain(golden, sps):
     g = golden("resample.npz")
     lpf = g["lpf651_gain96"]                                    # createLPF(1/260, 651, P=96) as pushBuffer builds it
     ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
-    be = TxBackEnd(ctx, S, lpf)
+    be = TxBackEnd(ctx, S, lpf, fused=fused)      # fused: modulate -> resample -> int16 in one kernel, no complex float32 send buffer
     o = oraclebind.Oracle(sps)
     rng = np.random.default_rng(31 + sps)
     hist = [np.zeros(2 * 65 * sps, np.complex64) for _ in range(S)]
@@ -29,8 +31,8 @@ def test_tx_chain(golden, sps):
     inchunk = 65 * 9 * sps
     tn = 0
     nout = 0
-    for it in range(12):
-        nb = int(rng.integers(1, 6))
+    for it in range(14):
+        nb = int(rng.integers(1, 6)) if it != 9 else 40       # (one push of many bursts: several chunks in one pop)
         guard = np.array([8 + ((tn + k) % 4 == 0) for k in range(nb)], np.int32); tn = (tn + nb) % 8
         bits = np.stack([synth.normal_bits(rng, nb, int(rng.integers(0, 8))) for _ in range(S)])    # [S, nb, 148]
         gain = rng.uniform(0.1, 1.0, (S, nb)).astype(np.float32) if it % 2 else None
