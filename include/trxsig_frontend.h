@@ -63,6 +63,28 @@ int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, i
                                          float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride, int32_t *h_tn, int cap_tn,
                                          int *n_bursts);
 
+/* ---- multi-ARFCN channeliser (no such component exists in the reference, which runs one radio and one
+ * Transceiver per ARFCN) ----------------------------------------------------------------------------------------------------
+ * One WIDEBAND int16 stream at rate_factor x 400 kS/s carries n_carriers ARFCNs.  For every carrier the stream is mixed to
+ * baseband with the reference's frequencyShift (sigProcLib.h:149-153: z[n] = x[n] * expjLookup(phase), table trig) and brought
+ * to sps samples per symbol by its polyphaseResampleVector(P = 65*sps, Q = 96*rate_factor, h_lpf) behind a history of
+ * 192*rate_factor samples, exactly as RadioInterface::pullBuffer does for one carrier (radioInterface.cpp:230-259) -- fused in
+ * one kernel: the wideband window is staged once per (carrier, tile), mixed on the way into LDS, filtered from there.  The
+ * result lands in the receive buffers of an ordinary front end with n_wide_streams * n_carriers streams (stream w*n_carriers
+ * + k = carrier k of wideband stream w): trxsig_rxfe_pop and the batch detectors / the Transceiver group take it from there.
+ * Mixer phase: frequencyShift's `phase += freq` chain is restarted every 64 wideband samples; block b (raw samples 64 b ..
+ * 64 b + 63 of the stream, counted from its first sample) starts at (float) fmod(b * 64 * (double) freq, 2 pi), i.e. the
+ * caller-supplied startPhase of that call.  With that convention the output equals the reference's two primitives applied
+ * per carrier bit for bit (tests/test_gpu_channeliser.py); parity is pinned on the reference's primitives, there is no
+ * reference component to compare the whole with.
+ * h_carrier_freq[k]: radians per wideband sample (negative of the carrier's offset from the stream's centre, to bring it to 0).
+ * h_lpf: L taps of a low-pass at the P-times-interpolated rate (DC gain P), e.g. a Kaiser design with its cutoff at the
+ * 200 kHz channel edge. */
+int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *ctx, int n_wide_streams, int n_carriers, const float *h_carrier_freq,
+                                int rate_factor, int max_chunks, const float *h_lpf, int L, int swap_iq, int start_tn);
+/* d_iq: int16 I/Q pairs [n_wide_streams][n_chunks * 864 * rate_factor][2] (device): n_chunks chunks of 2.16 ms each */
+int trxsig_rxfe_push_wideband(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks);
+
 /* h_lpf: the L (normally 651, createLPF(cutoff, 651, 96): radioInterface.cpp:134-138) normalised taps.  max_bursts: the
  * most bursts per stream one push may carry. */
 int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *ctx, int n_streams, int max_bursts, const float *h_lpf, int L, float gain);

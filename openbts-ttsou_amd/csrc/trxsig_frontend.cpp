@@ -43,6 +43,11 @@ struct trxsig_rxfe {
   short2 *d_keep = nullptr;                                 // [S][n_in]: the window (history + chunk) of the last chunk received
   float4 *d_tpb = nullptr;                                  // [P] branch-major taps
   int tail = 0;                                             // resampled samples of earlier pushes not yet cut into bursts
+  // wideband input (the channeliser, trxsig_rxfe_create_wideband): Sw raw streams at Cw x 400 kS/s, C carriers each;
+  // output stream s = carrier s % C of raw stream s / C
+  int Cw = 0, C = 0, Sw = 0;
+  float *d_freq = nullptr;
+  long long n_total = 0;                                    // raw samples (per wideband stream) received so far, offset by the history
 };
 
 // a burst whose samples (partly) lie in the send buffer: fused mode keeps its bits, not its samples
@@ -123,10 +128,84 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
   return TRXSIG_OK;
 }
 
+int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *c, int n_wide_streams, int n_carriers, const float *h_carrier_freq,
+                                int rate_factor, int max_chunks, const float *h_lpf, int L, int swap_iq, int start_tn) {
+  if (!out) return TRXSIG_EINVAL;
+  *out = nullptr;
+  if (!c) return TRXSIG_EINVAL;
+  if (n_wide_streams <= 0 || n_carriers <= 0 || n_carriers > 64 || rate_factor <= 0 || rate_factor > 64 || !h_carrier_freq ||
+      (long long)n_wide_streams * n_carriers > 65535)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create_wideband: bad argument", hipSuccess);
+  for (int k = 0; k < n_carriers; k++)
+    if (!(h_carrier_freq[k] >= -3.2f && h_carrier_freq[k] <= 3.2f))
+      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create_wideband: carrier frequencies are radians per wideband sample, |f| <= pi", hipSuccess);
+  int rc = trxsig_rxfe_create(out, c, n_wide_streams * n_carriers, max_chunks, h_lpf, L, swap_iq, start_tn);
+  if (rc != TRXSIG_OK) return rc;
+  trxsig_rxfe *fe = *out;
+  fe->Cw = rate_factor; fe->C = n_carriers; fe->Sw = n_wide_streams;
+  if (trxsig_resample_out_len(fe->n_in * rate_factor, fe->P, TRXSIG_OUTRATE * rate_factor) != fe->n_out) {
+    trxsig_rxfe_destroy(fe);
+    *out = nullptr;
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create_wideband: this rate factor changes the resampler's output length", hipSuccess);
+  }
+  fe->n_total = (long long)TRXSIG_OUTHISTORY * rate_factor;   // (a multiple of 64: the first history sample is raw sample 0 of block 0)
+  Guard g(trxsig_device(c));
+  // the history is per wideband stream and rate_factor times longer; the fused (narrowband) tables are not used
+  (void)hipFree(fe->d_hist); fe->d_hist = nullptr;
+  (void)hipFree(fe->d_keep); fe->d_keep = nullptr; (void)hipFree(fe->d_tpb); fe->d_tpb = nullptr;
+  const size_t hb = sizeof(short2) * (size_t)TRXSIG_OUTHISTORY * rate_factor * n_wide_streams;
+  if (hipMalloc((void **)&fe->d_hist, hb) != hipSuccess || hipMemset(fe->d_hist, 0, hb) != hipSuccess ||
+      hipMalloc((void **)&fe->d_freq, sizeof(float) * (size_t)n_carriers) != hipSuccess ||
+      hipMemcpy(fe->d_freq, h_carrier_freq, sizeof(float) * (size_t)n_carriers, hipMemcpyHostToDevice) != hipSuccess) {
+    trxsig_rxfe_destroy(fe);
+    *out = nullptr;
+    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create_wideband: device allocation failed", hipSuccess);
+  }
+  return TRXSIG_OK;
+}
+
+int trxsig_rxfe_push_wideband(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks) {
+  if (!fe) return TRXSIG_EINVAL;
+  trxsig_ctx *c = fe->c;
+  if (!fe->Cw) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_wideband: not a wideband front end", hipSuccess);
+  if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_wideband: bad argument", hipSuccess);
+  fe->mode = 1;
+  Guard g(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  const int left = fe->wr - fe->rd;
+  if (fe->rd > 0 && left <= 157 * fe->sps) {                // the uncut tail moves to the front of every row (as trxsig_rxfe_push)
+    if (left > 0) {
+      FE_HIP(c, hipMemcpy2DAsync(fe->d_tmp, sizeof(trx_c32) * (size_t)157 * fe->sps, fe->d_rcv + fe->rd, sizeof(trx_c32) * (size_t)fe->stride,
+                                 sizeof(trx_c32) * (size_t)left, fe->S, hipMemcpyDeviceToDevice, st));
+      FE_HIP(c, hipMemcpy2DAsync(fe->d_rcv, sizeof(trx_c32) * (size_t)fe->stride, fe->d_tmp, sizeof(trx_c32) * (size_t)157 * fe->sps,
+                                 sizeof(trx_c32) * (size_t)left, fe->S, hipMemcpyDeviceToDevice, st));
+    }
+    fe->rd = 0; fe->wr = left;
+  }
+  if ((long long)fe->wr + (long long)n_chunks * fe->per_chunk > fe->stride)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push_wideband: receive buffers full (call trxsig_rxfe_pop first)", hipSuccess);
+  const int Cw = fe->Cw, chunk = TRXSIG_OUTCHUNK * Cw, hist = TRXSIG_OUTHISTORY * Cw;
+  TrxResampleArgs a = {};
+  a.in = d_iq; a.in_stride = (long long)n_chunks * chunk; a.hist = fe->d_hist; a.hist_len = hist;
+  a.n = hist + chunk; a.win_step = chunk; a.swap = fe->swap;
+  a.lpf = fe->d_lpf; a.L = fe->L; a.P = fe->P; a.Q = TRXSIG_OUTRATE * Cw;
+  a.o_skip = fe->skip; a.n_out = fe->n_out;
+  a.out = fe->d_rcv + fe->wr; a.out_stride = fe->stride; a.out_win_step = fe->per_chunk;
+  a.mix_freq = fe->d_freq; a.mix_carriers = fe->C; a.mix_n0 = fe->n_total; a.mix_tables = (const TrxTables *)trxsig_tables_device(c);
+  FE_HIP(c, trx_launch_resample_ex(st, a, fe->S, n_chunks, true, false, trx_ctx_profiler(c)));
+  const short2 *tail = reinterpret_cast<const short2 *>(d_iq) + ((size_t)n_chunks * chunk - hist);
+  FE_HIP(c, hipMemcpy2DAsync(fe->d_hist, sizeof(short2) * (size_t)hist, tail, sizeof(short2) * (size_t)n_chunks * chunk,
+                             sizeof(short2) * (size_t)hist, fe->Sw, hipMemcpyDeviceToDevice, st));
+  fe->wr += n_chunks * fe->per_chunk;
+  fe->n_total += (long long)n_chunks * chunk;
+  return TRXSIG_OK;
+}
+
 void trxsig_rxfe_destroy(trxsig_rxfe *fe) {
   if (!fe) return;
   {
     Guard g(trxsig_device(fe->c));
+    (void)hipFree(fe->d_freq);
     (void)hipFree(fe->d_rcv); (void)hipFree(fe->d_tmp); (void)hipFree(fe->d_hist); (void)hipFree(fe->d_lpf); (void)hipFree(fe->d_idx);
     (void)hipFree(fe->d_keep); (void)hipFree(fe->d_tpb);
   }
@@ -140,6 +219,7 @@ int trxsig_rxfe_push(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks) {
   trxsig_ctx *c = fe->c;
   if (!d_iq || n_chunks <= 0 || n_chunks > fe->max_chunks) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: bad argument", hipSuccess);
   if (fe->mode == 2) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: this front end is used through the fused call", hipSuccess);
+  if (fe->Cw) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_push: a wideband front end takes trxsig_rxfe_push_wideband", hipSuccess);
   fe->mode = 1;
   Guard g(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);

@@ -279,21 +279,6 @@ __global__ __launch_bounds__(64) void k_vector_norm2(const cx *__restrict__ in, 
   }
 }
 
-// expjLookup (:192-204) with its subtract-one range reduction bounded: the host entry points refuse phases beyond
-// TRX_FSHIFT_MAXPHASE, for which the reference's loop would run for ever (a float that large no longer changes by 1) or for
-// a very long time
-#define TRX_FSHIFT_MAXPHASE 25000.0f
-__device__ __forceinline__ cx dev_expj_lookup(const TrxTables *__restrict__ T, float x) {
-  float arg = x * (1 / TRX_2PI_F);
-  for (int it = 0; it < 8192 && arg > 1.0F; it++) arg -= 1.0F;
-  for (int it = 0; it < 8192 && arg < 0.0F; it++) arg += 1.0F;
-  const float argT = arg * (float)TRX_TABLESIZE;
-  int argI = (int)argT;
-  argI = argI < 0 ? 0 : (argI > TRX_TABLESIZE ? TRX_TABLESIZE : argI);   // (only a phase the host refused could get here)
-  const float delta = argT - argI;
-  const float iDelta = 1.0F - delta;
-  return mk(iDelta * T->cosT[argI] + delta * T->cosT[argI + 1], iDelta * T->sinT[argI] + delta * T->sinT[argI + 1]);
-}
 // frequencyShift (:432-471): y[k] = x[k] * expjLookup(phase_k), phase_k = startPhase + freq + ... + freq (k sequential float
 // additions).  One wave per vector; every lane runs the whole chain of additions and keeps the phases of its own elements.
 __global__ __launch_bounds__(64) void k_frequency_shift(const TrxTables *__restrict__ T, const cx *__restrict__ in,

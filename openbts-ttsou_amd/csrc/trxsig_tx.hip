@@ -152,9 +152,12 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
     }
   }
   if (IN_I16) {
-    const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
-    const short2 *hist = a.hist + (size_t)s * a.hist_len;
+    const bool mix = a.mix_carriers > 0;
+    const int s_raw = mix ? s / a.mix_carriers : s;         // the channeliser: carrier s % C of wideband stream s / C
+    const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s_raw * a.in_stride;
+    const short2 *hist = a.hist + (size_t)s_raw * a.hist_len;
     const long long base = (long long)w * a.win_step - a.hist_len;  // raw index of the window's sample 0
+    const float mfreq = mix ? a.mix_freq[s - s_raw * a.mix_carriers] : 0.0f;
     for (int i0 = lo + threadIdx.x; i0 <= hi; i0 += 256 * 8) {
       short2 v[8];
 #pragma unroll
@@ -166,7 +169,22 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int i = i0 + 256 * q;
-        if (i <= hi) X[i - lo] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
+        cx xv = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
+        if (mix) {
+          // frequencyShift (:459-460) with the phase chain restarted every 64 raw samples (see TrxResampleArgs): the wave's 64
+          // consecutive samples lie in at most two blocks, whose start phases are formed once per wave in double
+          const long long n = a.mix_n0 + base + (i <= hi ? i : hi);
+          const long long n_first = a.mix_n0 + base + (i0 - (int)(threadIdx.x & 63)) + 256 * q;   // lane 0's sample
+          const long long b0 = n_first >> 6;               // (the same value on every lane of the wave)
+          const double step = 64.0 * (double)mfreq;
+          const float ph0 = (float)fmod((double)b0 * step, 6.283185307179586);
+          const float ph1 = (float)fmod((double)(b0 + 1) * step, 6.283185307179586);
+          float phase = (n >> 6) == b0 ? ph0 : ph1;
+          const int rr = (int)(n & 63);
+          for (int k = 0; k < rr; k++) phase += mfreq;     // phase += freq, sample by sample (:460)
+          xv = cmul(xv, dev_expj_lookup(a.mix_tables, phase));   // (*xP)*expjLookup(phase) (:459)
+        }
+        if (i <= hi) X[i - lo] = xv;
       }
     }
   } else if (INKIND == RES_IN_BITS) {

@@ -30,6 +30,8 @@ def _bind(L):
     L.trxsig_rxfe_pending.argtypes = [vp]
     L.trxsig_rxfe_push_detect_demod_normal.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32,
                                                        C.POINTER(i32)]
+    L.trxsig_rxfe_create_wideband.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, i32, vp, i32, i32, i32]
+    L.trxsig_rxfe_push_wideband.argtypes = [vp, vp, i32]
     L.trxsig_txbe_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, C.c_float]
     L.trxsig_txbe_destroy.argtypes = [vp]; L.trxsig_txbe_destroy.restype = None
     L.trxsig_txbe_push_bursts.argtypes = [vp, vp, vp, vp, i32]
@@ -40,20 +42,39 @@ def _bind(L):
 
 
 class RxFrontEnd:
-    def __init__(self, ctx, n_streams, lpf_taps, device="cuda:0", swap_iq=True, max_chunks=1, start_tn=0):
+    def __init__(self, ctx, n_streams, lpf_taps, device="cuda:0", swap_iq=True, max_chunks=1, start_tn=0, carrier_freq=None, rate_factor=0):
+        """carrier_freq (radians per wideband sample, one per carrier) + rate_factor: the channeliser -- n_streams WIDEBAND
+        streams at rate_factor x 400 kS/s, len(carrier_freq) ARFCNs each; bursts come out per (stream, carrier)."""
         import torch
         self.torch = torch
         self.ctx = ctx
         self.L = ctx.L
         _bind(self.L)
-        self.S = n_streams
         self.sps = ctx.sps
         self.dev = torch.device(device)
         lpf = np.ascontiguousarray(lpf_taps, np.float32)
         h = C.c_void_p()
-        ctx._chk(self.L.trxsig_rxfe_create(C.byref(h), ctx.h, n_streams, max_chunks, lpf.ctypes.data, lpf.size, int(swap_iq),
-                                           start_tn), "trxsig_rxfe_create")
+        self.rate_factor = rate_factor
+        if carrier_freq is not None:
+            fr = np.ascontiguousarray(carrier_freq, np.float32)
+            ctx._chk(self.L.trxsig_rxfe_create_wideband(C.byref(h), ctx.h, n_streams, fr.size, fr.ctypes.data, rate_factor, max_chunks,
+                                                        lpf.ctypes.data, lpf.size, int(swap_iq), start_tn), "trxsig_rxfe_create_wideband")
+            self.S = n_streams * fr.size
+            self.Sw = n_streams
+        else:
+            ctx._chk(self.L.trxsig_rxfe_create(C.byref(h), ctx.h, n_streams, max_chunks, lpf.ctypes.data, lpf.size, int(swap_iq),
+                                               start_tn), "trxsig_rxfe_create")
+            self.S = n_streams
         self.h = h
+
+    def push_wideband(self, iq):
+        """iq: int16 tensor [Sw, K*864*rate_factor, 2] (device), K whole chunks per wideband stream."""
+        torch = self.torch
+        n = OUTCHUNK * self.rate_factor
+        assert iq.dtype == torch.int16 and iq.shape[0] == self.Sw and iq.shape[1] % n == 0 and iq.shape[2] == 2
+        iq = iq.contiguous()
+        self.ctx._chk(self.L.trxsig_rxfe_push_wideband(self.h, iq.data_ptr(), iq.shape[1] // n), "trxsig_rxfe_push_wideband")
+        self._keep = iq
 
     def close(self):
         if self.h:
