@@ -224,8 +224,13 @@ class Config4:
         # --stateless-frontend: trxsig_rxfe_push_detect_demod_normal (no schedule, no state; the detectors compute their samples
         # from the int16 chunks, no resampled stream in HBM);
         # --unfused-frontend: push + pop + trxsig_detect_demod_normal_batch through the complex float32 stream
-        self.fused = not bool(getattr(args, "unfused_frontend", False))
+        # --wideband C: the channeliser -- S / C wideband streams at 8 x 400 kS/s with C carriers each, mixed down and resampled per
+        # carrier in one kernel into the receive buffers, then pop + the normal-burst detector (through the resampled stream)
+        self.wide = int(getattr(args, "wideband", 0) or 0)
+        self.fused = not bool(getattr(args, "unfused_frontend", False)) and not self.wide
         self.group = self.fused and not bool(getattr(args, "stateless_frontend", False))
+        if self.wide:
+            self.kernel_names["k_resample"] = "k_resample<int16 wideband, mix>"
         if self.group:
             self.kernel_names.update({"k_rach_corr": "k_rach_front_rx", "k_rach_peak": "k_rach_peak2+k_rach_fast_rx(list)"})
             self.kernel_alg.update({"k_rach_corr": 4 * 236 + 8 * 25 + 16 + 17, "k_rach_peak": 8 * 25 + 16 + 17, "k_group_replay": 16 + 4 + 1 + 8})
@@ -265,7 +270,31 @@ class Config4:
         # createLPF(cutoff, 961, 65*sps) as pullBuffer asks for it -- designed for THIS ratio (synth.design_lpf says why the
         # reference's fixed table, made for 65:96, is not used at sps 4); the taps are an argument of the library
         self.lpf = synth.design_lpf(961, 65 * sps)
-        self.fe = RxFrontEnd(ctx, S, self.lpf, max_chunks=K)
+        if self.wide:
+            # carriers 400 kHz apart round the centre of a 3.2 MS/s stream; each narrowband stream is brought to the wideband rate
+            # by linear interpolation, shifted to its carrier and summed (content for a throughput run, not a calibrated radio)
+            C, CW = self.wide, 8
+            assert S % C == 0 and C <= 8
+            offs = (torch.arange(C, device=dev, dtype=torch.float64) - (C - 1) / 2.0) * 400e3
+            self.freqs = (-2.0 * np.pi * offs / (400e3 * CW)).to(torch.float32).cpu().numpy()
+            self.lpf = synth.design_lpf(8001, 65 * sps, beta=6.0, cutoff=0.09)
+            nw = KT * 864 * CW
+            tw = torch.arange(nw, device=dev, dtype=torch.float64) / CW
+            i0 = tw.floor().long().clamp(max=KT * 864 - 2); fr = (tw - i0).to(torch.float32)
+            lo_c = (iq[:, :, 1].to(torch.float32) + 1j * iq[:, :, 0].to(torch.float32))          # [S, KT*864] complex
+            wide = torch.zeros(S // C, nw, dtype=torch.complex64, device=dev)
+            ph = torch.arange(nw, device=dev, dtype=torch.float64)
+            for k in range(C):
+                rot = torch.exp(1j * (2.0 * np.pi * float(offs[k]) / (400e3 * CW)) * ph).to(torch.complex64)
+                xk = lo_c[k::C]
+                wide += (xk[:, i0] * (1 - fr) + xk[:, i0 + 1] * fr) * rot
+            wide = wide * (8000.0 / wide.abs().amax(dim=1, keepdim=True))
+            wiq = torch.stack([wide.imag, wide.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()
+            self.segs = [wiq[:, i * K * 864 * CW:(i + 1) * K * 864 * CW].contiguous() for i in range(KT // K)]
+            self.fe = RxFrontEnd(ctx, S // C, self.lpf, max_chunks=K, carrier_freq=self.freqs, rate_factor=CW)
+            del wide, lo_c
+        else:
+            self.fe = RxFrontEnd(ctx, S, self.lpf, max_chunks=K)
         if self.group:
             self.grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
             for a in range(S):
@@ -299,7 +328,10 @@ class Config4:
             self.nbursts += self.S * nb
             self.last_nb = self.S * nb
             return
-        self.fe.push_chunk(self.segs[self.seg])
+        if self.wide:
+            self.fe.push_wideband(self.segs[self.seg])
+        else:
+            self.fe.push_chunk(self.segs[self.seg])
         self.seg = (self.seg + 1) % len(self.segs)
         r = self.fe.pop_raw()
         if r is None:
@@ -323,7 +355,10 @@ class Config4:
                                                   "TN 0 of every 8th ARFCN (access-burst slots), combination I elsewhere --, adaptive energy threshold "
                                                   "per ARFCN replayed on the device, the resampled stream never written to HBM" if self.group else
                                                   ("one fused call, the resampled stream never written to HBM, TSC on every slot, fixed thresholds"
-                                                   if self.fused else "through the resampled complex float32 stream (push + pop + detect)")),
+                                                   if self.fused else ("CHANNELISER: %d wideband streams at 3.2 MS/s x %d carriers, frequencyShift + "
+                                                                       "polyphase 260:768 (8001-tap LPF) per carrier in one kernel, then pop + detect"
+                                                                       % (self.S // self.wide, self.wide) if self.wide else
+                                                                       "through the resampled complex float32 stream (push + pop + detect)"))),
                 "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                 "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
 
@@ -477,6 +512,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--unfused-frontend", action="store_true", help="config4: push + pop + detect through the resampled complex float32 stream instead of the fused front end")
+    ap.add_argument("--wideband", type=int, default=0, help="config4: the channeliser -- streams / N wideband streams at 3.2 MS/s carrying N ARFCNs each (N <= 8)")
     ap.add_argument("--stateless-frontend", action="store_true", help="config4: trxsig_rxfe_push_detect_demod_normal (TSC on every slot, fixed thresholds) instead of the Transceiver group")
     ap.add_argument("--repeats", type=int, default=None, help="extra timed repetitions of the K steps after the official one (min / median are reported beside `value`); default 4 when --steps < 100, else 0")
     ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
@@ -620,6 +656,8 @@ def main():
         launch_units = units
         if dom[0] == "k_resample" and args.workload == "config4":
             per_unit, launch_units = 4 * 864 + 8 * wl.per_chunk, wl.S * wl.K     # per stream-chunk: int16 read, c64 written
+            if getattr(wl, "wide", 0):
+                per_unit = 4 * 864 * 8 // wl.wide + 8 * wl.per_chunk             # the wideband chunk is read once for its carriers
         achieved = per_unit * launch_units / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": wl.kernel_names.get(dom[0], dom[0]), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -72,10 +72,14 @@ int trxsig_rxfe_push_detect_demod_normal(trxsig_rxfe *fe, const int16_t *d_iq, i
  * one kernel: the wideband window is staged once per (carrier, tile), mixed on the way into LDS, filtered from there.  The
  * result lands in the receive buffers of an ordinary front end with n_wide_streams * n_carriers streams (stream w*n_carriers
  * + k = carrier k of wideband stream w): trxsig_rxfe_pop and the batch detectors / the Transceiver group take it from there.
- * Mixer phase: frequencyShift's `phase += freq` chain is restarted every 64 wideband samples; block b (raw samples 64 b ..
- * 64 b + 63 of the stream, counted from its first sample) starts at (float) fmod(b * 64 * (double) freq, 2 pi), i.e. the
- * caller-supplied startPhase of that call.  With that convention the output equals the reference's two primitives applied
- * per carrier bit for bit (tests/test_gpu_channeliser.py); parity is pinned on the reference's primitives, there is no
+ * Mixer phase: the reference's frequencyShift forms the phase of sample n as a running float sum (`phase += freq` n times),
+ * which is sequential over the whole stream and loses a ulp of an ever larger number at every step (after one 2.16 ms chunk
+ * at 3.2 MS/s the sum is ~2,700 rad and has drifted by milliradians).  The channeliser keeps frequencyShift's arithmetic --
+ * z[n] = x[n] * expjLookup(phase[n]) with the reference's table trig -- and forms the phase of raw sample n (counted from the
+ * stream's first sample) directly: phase[n] = (float)(t - 2 pi floor(t / 2 pi)), t = (double) n * (double) freq, every step an
+ * IEEE operation; that is frequencyShift called on the one-sample vector {x[n]} with startPhase = phase[n].  With that
+ * convention the output equals the reference's two primitives applied per carrier bit for bit (tests/test_gpu_channeliser.py,
+ * which also measures the distance to the running-sum form); parity is pinned on the reference's primitives, there is no
  * reference component to compare the whole with.
  * h_carrier_freq[k]: radians per wideband sample (negative of the carrier's offset from the stream's centre, to bring it to 0).
  * h_lpf: L taps of a low-pass at the P-times-interpolated rate (DC gain P), e.g. a Kaiser design with its cutoff at the

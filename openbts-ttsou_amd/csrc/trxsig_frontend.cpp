@@ -148,7 +148,7 @@ int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *c, int n_wide_str
     *out = nullptr;
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create_wideband: this rate factor changes the resampler's output length", hipSuccess);
   }
-  fe->n_total = (long long)TRXSIG_OUTHISTORY * rate_factor;   // (a multiple of 64: the first history sample is raw sample 0 of block 0)
+  fe->n_total = (long long)TRXSIG_OUTHISTORY * rate_factor;   // (the zero history in front of the stream holds raw samples 0 .. hist - 1)
   Guard g(trxsig_device(c));
   // the history is per wideband stream and rate_factor times longer; the fused (narrowband) tables are not used
   (void)hipFree(fe->d_hist); fe->d_hist = nullptr;

@@ -112,12 +112,13 @@ struct TrxResampleArgs {
   int o_skip, n_out;                                       // outputs [o_skip, n_out) of every window are produced
   void *out; long long out_stride, out_win_step;           // window w of stream s writes at out + s*out_stride + w*out_win_step
   float gain;                                              // int16 output
-  int OB, xcap, taps_lds;                                  // filled in by the launcher
+  int OB, xcap, taps_lds, tap_pitch, tap_g;                // filled in by the launcher
   // int16 input, wideband (the channeliser): output stream s is carrier s % mix_carriers of raw stream s / mix_carriers, mixed down
-  // on the way into LDS: z[n] = x[n] * expjLookup(phase[n]) (frequencyShift, sigProcLib.cpp:459) with the phase of raw sample n
-  // restarted every 64 samples: block b = n / 64 starts at (float) fmod(b * 64 * (double) freq, 2 pi) and adds freq per sample.
-  // mix_freq: [mix_carriers] floats (device); mix_n0: global index of raw sample 0 of this launch's `in` (a multiple of 64 ahead
-  // of the history); mix_tables: the context's tables (trig lookup)
+  // on the way into LDS: z[n] = x[n] * expjLookup(phase[n]) (frequencyShift's arithmetic, sigProcLib.cpp:459) with the phase of
+  // raw sample n formed directly, phase[n] = (float)(t - 2 pi floor(t / 2 pi)), t = (double) n * (double) freq, instead of by
+  // the reference's running float sum (trxsig_frontend.h says why).
+  // mix_freq: [mix_carriers] floats (device); mix_n0: global index of raw sample 0 of this launch's `in`; mix_tables: the
+  // context's tables (trig lookup)
   const float *mix_freq; int mix_carriers; long long mix_n0; const TrxTables *mix_tables;
   // input computed from burst bits (the fused transmit back end): in = the bit ring [S][in_stride slots][148], tx_gain the gains
   // [S][in_stride]; tx_start[m] / tx_meta[m] (m < tx_n, device, ascending): where burst m starts in the window and

@@ -140,9 +140,22 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
   const int lo = t0 < 0 ? 0 : (int)t0;
   const int hi = t1 > a.n - 1 ? a.n - 1 : (int)t1;                  // staged input samples [lo, hi] of this window
   const bool taps_lds = a.taps_lds != 0;
+  // taps_lds == 2: BRANCH-MAJOR, TP[branch * pitch + k] = lpf[branch + P k] (pitch odd): an output walks its own row, so the
+  // lanes of a wave -- whose branches differ by multiples of Q mod P -- stay on different banks; the linear layout walked at
+  // stride P puts them on a handful of banks (96:260 and 260:768 both: 16-way conflicts)
+  // Only the branches that are multiples of g = gcd(P, Q) ever occur (outputIx*Q mod P): the table holds P / g rows.
+  const bool taps_bm = a.taps_lds == 2;
+  const int pitch = a.tap_pitch, tg = a.tap_g;
   // staging: the loads of a round of eight go out together (a plain loop would wait for each load before issuing the next:
   // five dependent HBM round trips per workgroup was what the first version of this kernel spent its time on)
-  if (taps_lds) {
+  if (taps_bm) {
+    const int KT = (a.L + a.P - 1) / a.P, rows = a.P / tg;
+    for (int e = threadIdx.x; e < rows * KT; e += 256) {
+      const int row = e % rows, k = e / rows;
+      const int fi = row * tg + a.P * k;
+      TP[row * pitch + k] = fi < a.L ? a.lpf[fi] : 0.0f;
+    }
+  } else if (taps_lds) {
     for (int i0 = threadIdx.x; i0 < a.L; i0 += 256 * 4) {
       float tv[4];
 #pragma unroll
@@ -171,18 +184,13 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
         const int i = i0 + 256 * q;
         cx xv = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
         if (mix) {
-          // frequencyShift (:459-460) with the phase chain restarted every 64 raw samples (see TrxResampleArgs): the wave's 64
-          // consecutive samples lie in at most two blocks, whose start phases are formed once per wave in double
+          // frequencyShift's arithmetic (:459): z[n] = x[n] * expjLookup(phase[n]), the phase of raw sample n formed directly
+          // (see TrxResampleArgs) -- every operation below is an IEEE double / float operation, the same on host and device
           const long long n = a.mix_n0 + base + (i <= hi ? i : hi);
-          const long long n_first = a.mix_n0 + base + (i0 - (int)(threadIdx.x & 63)) + 256 * q;   // lane 0's sample
-          const long long b0 = n_first >> 6;               // (the same value on every lane of the wave)
-          const double step = 64.0 * (double)mfreq;
-          const float ph0 = (float)fmod((double)b0 * step, 6.283185307179586);
-          const float ph1 = (float)fmod((double)(b0 + 1) * step, 6.283185307179586);
-          float phase = (n >> 6) == b0 ? ph0 : ph1;
-          const int rr = (int)(n & 63);
-          for (int k = 0; k < rr; k++) phase += mfreq;     // phase += freq, sample by sample (:460)
-          xv = cmul(xv, dev_expj_lookup(a.mix_tables, phase));   // (*xP)*expjLookup(phase) (:459)
+          const double xr = (double)n * (double)mfreq;
+          const double kk = floor(xr * 0.15915494309189535);
+          const float phase = (float)(xr - kk * 6.283185307179586);
+          xv = cmul(xv, dev_expj_lookup(a.mix_tables, phase));
         }
         if (i <= hi) X[i - lo] = xv;
       }
@@ -237,9 +245,17 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
     int fi = branch;
     while (inOff >= a.n) { inOff--; fi += a.P; }                    // :1183-1186
     cx sum = mk(0, 0);
-    while (inOff >= 0 && fi < a.L) {                                // :1196-1200
-      sum = cadd(sum, cmulr(X[inOff - lo], taps_lds ? TP[fi] : a.lpf[fi]));
-      inOff--; fi += a.P;
+    if (taps_bm) {
+      const float *row = TP + (branch / tg) * pitch + (fi - branch) / a.P;
+      while (inOff >= 0 && fi < a.L) {                              // :1196-1200
+        sum = cadd(sum, cmulr(X[inOff - lo], *row++));
+        inOff--; fi += a.P;
+      }
+    } else {
+      while (inOff >= 0 && fi < a.L) {                              // :1196-1200
+        sum = cadd(sum, cmulr(X[inOff - lo], taps_lds ? TP[fi] : a.lpf[fi]));
+        inOff--; fi += a.P;
+      }
     }
     const size_t oi = (size_t)s * a.out_stride + (size_t)w * a.out_win_step + (size_t)(o - a.o_skip);
     if (OUT_I16) {
@@ -393,8 +409,8 @@ hipError_t trx_launch_modulate(hipStream_t st, int sps, const TrxTables *dT, con
 }
 
 // outputs per workgroup: as many as keep the staged input span inside TRX_RES_XCAP (and enough workgroups in flight)
-static int resample_tile(const TrxResampleArgs &a) {
-  long long ob = ((long long)(TRX_RES_XCAP - (a.L + a.P - 1) / a.P - 4) * a.P) / a.Q;
+static int resample_tile(const TrxResampleArgs &a, int xcap_limit) {
+  long long ob = ((long long)(xcap_limit - (a.L + a.P - 1) / a.P - 4) * a.P) / a.Q;
   if (ob > 4096) ob = 4096;
   if (ob < 64) ob = 64;                                    // (Q/P so large that 64 outputs overflow the span: not a resampler ratio)
   const int want = a.n_out - a.o_skip;
@@ -404,14 +420,26 @@ static int resample_tile(const TrxResampleArgs &a) {
 hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
                                   TrxProfiler *prof, bool in_bits) {
   if (S <= 0 || n_windows <= 0 || a.n_out <= a.o_skip) return hipSuccess;
-  a.OB = resample_tile(a);
+  // the channeliser's tiles are smaller: its staging is arithmetic (the mixer), not copying, and wants more waves in flight
+  a.OB = resample_tile(a, a.mix_carriers > 0 ? 2048 : TRX_RES_XCAP);
   long long span = ((long long)(a.OB - 1) * a.Q) / a.P + (a.L + a.P - 1) / a.P + 4;      // staged samples a tile can need
   if (span > TRX_RES_XCAP) return hipErrorInvalidValue;
   if (span > a.n) span = a.n;
   if (S > 65535 || n_windows > 65535) return hipErrorInvalidValue;
   a.xcap = (int)((span + 1) & ~1LL);
   a.taps_lds = a.L <= TRX_RES_LCAP;
-  const size_t lds = sizeof(trx_c32) * (size_t)a.xcap + (a.taps_lds ? sizeof(float) * (size_t)a.L : 0);
+  size_t tap_bytes = a.taps_lds ? sizeof(float) * (size_t)a.L : 0;
+  {
+    const int KT = (a.L + a.P - 1) / a.P;
+    const int pitch = KT | 1;
+    int g = a.P, r = a.Q % a.P;
+    while (r) { const int t = g % r; g = r; r = t; }        // gcd(P, Q)
+    if (KT >= 3 && sizeof(float) * (size_t)(a.P / g) * pitch <= 40 * 1024) {   // branch-major taps (see k_resample)
+      a.taps_lds = 2; a.tap_pitch = pitch; a.tap_g = g;
+      tap_bytes = sizeof(float) * (size_t)(a.P / g) * pitch;
+    }
+  }
+  const size_t lds = sizeof(trx_c32) * (size_t)a.xcap + tap_bytes;
   const dim3 grid((a.n_out - a.o_skip + a.OB - 1) / a.OB, n_windows, S), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
   // the receive front end's shape (whole window per workgroup, <= 4 taps per output, indices inside 32 bits): k_rx_resample

@@ -4,6 +4,7 @@ The CPU restatement of the reference sigProcLib (oracle/sigproc_oracle.c).
 Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -61,6 +62,7 @@ def lib():
             getattr(L, n).argtypes = [f32p, C.c_int]; getattr(L, n).restype = C.c_float
         L.so_frequency_shift.argtypes = [vp, f32p, C.c_int, C.c_float, C.c_float, C.c_int, f32p]; L.so_frequency_shift.restype = C.c_float
         L.so_add_vector.argtypes = [f32p, C.c_int, f32p, C.c_int]
+        L.so_mix_down.argtypes = [vp, f32p, C.c_int, C.c_longlong, C.c_float, f32p]
         L.so_offset_vector.argtypes = [f32p, C.c_int, c32, C.c_int]
         L.so_resample_vector.argtypes = [f32p, C.c_int, C.c_float, c32, f32p]
         L.so_gaussian_noise.argtypes = [C.c_int, C.c_float, c32, f32p]
@@ -154,6 +156,17 @@ class Oracle:
         x = c64(x).copy(); y = c64(y)
         self.L.so_add_vector(x, x.size // 2, y, y.size // 2)
         return x.view(np.complex64)
+
+    def mix_down(self, x, n0, freq):
+        """The channeliser's mixer: frequencyShift sample by sample, the phase of raw sample n0 + k formed directly."""
+        x = c64(x); y = np.zeros_like(x)
+        self.L.so_mix_down(self.ctx, x, x.size // 2, int(n0), np.float32(freq), y)
+        return y.view(np.complex64)
+
+    @staticmethod
+    def mix_phase(n, freq):
+        t = float(n) * float(np.float32(freq))
+        return np.float32(t - math.floor(t * 0.15915494309189535) * 6.283185307179586)
 
     def offset_vector(self, x, offset, real_only=False):
         x = c64(x).copy()

@@ -256,6 +256,20 @@ float so_frequency_shift(const so_ctx *c, const so_c32 *x, int n, float freq, fl
   return phase;
 }
 
+/* The channeliser's mixer (include/trxsig_frontend.h): frequencyShift's arithmetic, y[k] = x[k] * expjLookup(phase), with the
+   phase of raw sample n = n0 + k formed directly, (float)(t - 2 pi floor(t / 2 pi)), t = (double) n * (double) freq -- i.e.
+   frequencyShift (ref:432-471) on the one-sample vector {x[k]} with that startPhase (tests/test_oracle_golden.py checks the
+   identity).  Not a function of the reference: a convention of this build, restated here for the checker. */
+void so_mix_down(const so_ctx *c, const so_c32 *x, int n, long long n0, float freq, so_c32 *y)
+{
+  for (int k = 0; k < n; k++) {
+    const double t = (double)(n0 + k) * (double)freq;
+    const double kk = floor(t * 0.15915494309189535);
+    const float phase = (float)(t - kk * 6.283185307179586);
+    y[k] = cmul(x[k], so_expjLookup(c, phase));
+  }
+}
+
 void so_add_vector(so_c32 *x, int nx, const so_c32 *y, int ny) /* ref:746-758 */
 {
   for (int k = 0; k < nx && k < ny; k++) x[k] = cadd(x[k], y[k]);

@@ -74,6 +74,8 @@ float so_vector_norm2(const so_c32 *x, int n);
 float so_vector_power(const so_c32 *x, int n);
 float so_frequency_shift(const so_ctx *c, const so_c32 *x, int n, float freq, float startPhase, int real_only, so_c32 *y);
 void so_add_vector(so_c32 *x, int nx, const so_c32 *y, int ny);
+/* the channeliser's mixer convention (see the .c): frequencyShift sample by sample with directly formed phases */
+void so_mix_down(const so_ctx *c, const so_c32 *x, int n, long long n0, float freq, so_c32 *y);
 void so_offset_vector(so_c32 *x, int n, so_c32 offset, int real_only);
 int so_resample_vector(const so_c32 *x, int n, float expFactor, so_c32 endPoint, so_c32 *out);
 void so_gaussian_noise(int length, float variance, so_c32 mean, so_c32 *out);
