@@ -52,7 +52,9 @@ __device__ __forceinline__ void demod_core(const TrxTables *__restrict__ T, cx *
   {
     const float f512 = frac * 512.0f;
     const int f = (int)f512;
-    if ((float)f == f512) {                                // on the 1/512 grid: sinc_grid[f][j] (uniform -> s_load)
+    // (frac = delay - floor(delay) can round to exactly 1.0 for a tiny negative delay: f = 512 is off the grid, the table
+    // sinc below then forms sinc(pi (j - 10 - 1.0)) as the reference does)
+    if (f < 512 && (float)f == f512) {                     // on the 1/512 grid: sinc_grid[f][j] (uniform -> s_load)
 #pragma unroll
       for (int j = 0; j < 21; j++) tp[j] = T->sinc_grid[f][j];
     } else {
@@ -194,7 +196,7 @@ __device__ __forceinline__ void fused_demod_ex(const TrxTables *__restrict__ T, 
   } else {
     const float f512 = frac * 512.0f;
     int f = (int)f512;
-    if ((float)f == f512) {                                // on the 1/512 grid (always, after peakDetect)
+    if (f < 512 && (float)f == f512) {                     // on the 1/512 grid (always, after peakDetect; f = 512: see demod_core)
       if (LPB == 64) {                                     // wave-uniform: the row comes in by s_load
         f = __builtin_amdgcn_readfirstlane(f);
 #pragma unroll

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_eq_delay(const TrxTables *__restrict__ 
   {
     const float f512 = frac * 512.0f;
     const int f = (int)f512;
-    const bool grid = (float)f == f512;
+    const bool grid = f < 512 && (float)f == f512;          // (frac can round to exactly 1.0 for a tiny negative delay: off the grid)
     const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
     float g[24];
 #pragma unroll

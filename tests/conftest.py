@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    # pytest-timeout (in this image) enforces the limit; registered here too so that the marker is known where the plugin is absent
+    config.addinivalue_line("markers", "timeout(seconds): fail the test if it runs longer (pytest-timeout)")
 
 
 @pytest.fixture(scope="session")

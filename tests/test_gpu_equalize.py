@@ -287,6 +287,7 @@ def test_delay_and_equalize_with_arbitrary_toa_lengths_and_taps(pkg, t1):
         elif k == 3: toa[i] = np.float32(rng.integers(-40, 41) + rng.integers(0, 512) / 512.0)             # tens of samples
         elif k == 4: toa[i] = np.float32(rng.choice([-300.25, -157.0, -100.5, 99.75, 156.5, 2000.125, 4096.0, -4096.0]))
         else: toa[i] = 0.0
+    toa[5:9] = np.float32([1e-9, 3e-8, -1e-9, 2.0 + 1e-7])   # tiny positive TOA: the delay's fraction rounds to exactly 1.0
     amp = (rng.uniform(0.2, 40, B) * np.exp(2j * np.pi * rng.uniform(0, 1, B))).astype(np.complex64)
     w = (rng.normal(0, 0.4, (B, 7)) + 1j * rng.normal(0, 0.4, (B, 7))).astype(np.complex64)
     b = (rng.normal(0, 0.2, (B, 5)) + 1j * rng.normal(0, 0.2, (B, 5))).astype(np.complex64)

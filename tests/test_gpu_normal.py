@@ -127,6 +127,8 @@ def test_demodulate_entry_point(pkg, ctx):
     toa = rng.uniform(-3, 3, 64).astype(np.float32)
     toa[:8] = np.round(toa[:8])                   # integer delays: no fractional filter
     toa[8:12] = np.float32(0.005)                 # |frac| below the 1e-2 gate
+    toa[12:14] = np.float32(1e-9)                 # delay = -1e-9: floor gives -1 and the fraction rounds to exactly 1.0
+    toa[14] = np.float32(-1e-9)
     en = np.ones(64, np.uint8); en[20] = 0
     import torch
     gb = GpuBatch(x, off, length, nsoft=156, stride=156)
