@@ -43,6 +43,25 @@ __device__ __forceinline__ float norm2(cx x) { return x.i * x.i + x.r * x.r; }  
 __device__ __forceinline__ cx cinv(cx x) { float n = norm2(x); return mk(x.r / n, -x.i / n); }  // Complex.h:154-160
 __device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }               // Complex.h:85
 
+// Packed float32 pairs (v_pk_mul_f32 / v_pk_add_f32: both halves are separate IEEE operations, nothing is fused).  Worth it
+// only where ONE wave's instruction count is the limit (the decision-feedback recursion: a single wave per 64 bursts issues
+// an instruction every ~5 cycles whatever it is); throughput-bound kernels gain nothing (4.3 cycles per packed instruction).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk(cx z) { v2f v = {z.r, z.i}; return v; }
+// Complex<float>::operator* (Complex.h:83): (x.r*a.r - x.i*a.i, x.r*a.i + x.i*a.r), every product and sum rounded separately
+__device__ __forceinline__ v2f pk_cmul(v2f x, v2f a) {
+  v2f p, q, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(x), "v"(a));                  // (x.r*a.r, x.r*a.i)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(x), "v"(a));     // (x.i*a.i, x.i*a.r)
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                     // (p.lo - q.lo, p.hi + q.hi)
+  return r;
+}
+__device__ __forceinline__ v2f pk_cadd(v2f x, v2f a) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a));
+  return r;
+}
+
 // How a burst's samples are stored in HBM: complex float32 (the reference's Complex<float>, 8 bytes) or fp16 I/Q pairs
 // (4 bytes; BASELINE config 5).  Widening fp16 -> float32 is exact, so every kernel computes in float32 on the same
 // values either way.  ld(): sample i; ld2(): samples 2q, 2q+1 as one float4 (needs the base 16 / 8 byte aligned).

@@ -596,6 +596,33 @@ __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, 
 //   (k_eq_dfe: a lane per burst doing everything, one uncoalesced 8-byte load and 4-byte store per symbol with one
 //   step of latency cover: 110 us per 64 K bursts.)
 // ---------------------------------------------------------------------------------------------
+// One symbol of equalizeBurst's decision-feedback loop (:1370-1384) on the feed-forward sum ff: the feedback terms continue the
+// same accumulator in the reference's order, reverse rotation, decision, the rotated decision goes into the history, slicer.
+// (Round 3 also ran this step on packed float32 pairs -- pk_cmul / pk_cadd of trxsig_dev.h, 31 instead of 66 instructions, the
+// same values: k_eq_dfe2 57.2 -> 60.1 us.  The recursion is bound by the latency of its dependent chain, not by the
+// consumer wave's instruction count.)
+__device__ __forceinline__ float dfe_step(int k, int nout, cx ff, cx rv, cx rt, const cx (&bq)[5], cx (&hist)[5]) {
+  float sv = 0.0f;
+  if (k < nout) {
+    cx d = ff;                                              // the feed-forward terms, already summed in order
+#pragma unroll
+    for (int j = 0; j < 5; j++)                             // feedback over past decisions (:1370-1374)
+      if (k - 1 - j >= 0) d = cadd(d, cmul(bq[j], hist[j]));
+    d = cmul(d, rv);                                        // :1375
+    const float re = d.r;
+    const cx dec = mk((re > 0.0f) ? 1.0f : -1.0f, 0.0f);    // :1378
+    const cx fbv = cmul(dec, rt);                           // :1380
+#pragma unroll
+    for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
+    hist[0] = fbv;
+    sv = (re + 1.0F) * 0.5F;                                // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)); re + 1.0F is 0 or
+    //                                                         at least 2^-24 in magnitude, so halving it in float is exact too
+    if (sv > 1.0f) sv = 1.0f;
+    if (sv < 0.0f) sv = 0.0f;
+  }
+  return sv;
+}
+
 #define EQ_TK 16             /* symbols per tile */
 #define EQ_NT 10             /* tiles: 160 >= 157 symbols */
 __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T, const cx *__restrict__ xd, int xstride,
@@ -693,38 +720,214 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
         rt[i] = T->rot[EQ_TK * u + i];
       }
 #pragma unroll
-      for (int i = 0; i < EQ_TK; i++) {
-        const int k = EQ_TK * u + i;
-        float sv = 0.0f;
-        if (k < nout) {
-          cx d = ffv[i];                                    // the feed-forward terms, already summed in order
-#pragma unroll
-          for (int j = 0; j < 5; j++)                       // feedback over past decisions (:1370-1374)
-            if (k - 1 - j >= 0) d = cadd(d, cmul(bq[j], hist[j]));
-          d = cmul(d, rv[i]);                               // :1375
-          const float re = d.r;
-          const cx dec = mk((re > 0.0f) ? 1.0f : -1.0f, 0.0f);   // :1378
-          const cx fbv = cmul(dec, rt[i]);                  // :1380
-#pragma unroll
-          for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
-          hist[0] = fbv;
-          sv = (re + 1.0F) * 0.5F;                          // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)); re + 1.0F is 0 or
-          //                                                   at least 2^-24 in magnitude, so halving it in float is exact too
-          if (sv > 1.0f) sv = 1.0f;
-          if (sv < 0.0f) sv = 0.0f;
-        }
-        sft[u & 1][lane][i] = sv;
-      }
+      for (int i = 0; i < EQ_TK; i++) sft[u & 1][lane][i] = dfe_step(EQ_TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
     }
     __syncthreads();                                        // barrier 10
   }
 }
 
+#ifdef TRX_TUNING_BUILD   /* k_eq_dfe3: the single-kernel equaliser tail, measured slower; tuning library only */
+// ---------------------------------------------------------------------------------------------
+// k_eq_dfe3 (round 3, A/B only): scaleVector + equalizeBurst in ONE kernel -- k_eq_delay's job done inside k_eq_dfe2's workgroup, so
+//   the delayed burst (82 MB written and 108 MB read back per 65,536 bursts) never visits HBM.  64 bursts per workgroup,
+//   FOUR waves, lane l of every wave belongs to burst l; time runs in tiles of 16 symbols and the roles are pipelined:
+//     wave 2, loader    raw samples of tile s+2, lanes along k (a row's 16 samples are one 32/64-byte piece), widened, scaled by
+//                       1/amp (scaleVector) and parked in a 64-entry ring per burst ALREADY SHIFTED by the burst's integer
+//                       delay: sample a sits at position p = a + floor(delay), so no address below depends on the TOA and
+//                       any TOA is served (samples outside the burst are zeros: "taps outside the vector are skipped");
+//     waves 0, 1        delayVector's 21-tap fractional filter (k_eq_delay's arithmetic: j ascending, real taps from the sinc
+//                       grid or the table sinc) for tile s, eight outputs each per burst, from the ring to a tile buffer;
+//     wave 2            the feed-forward FIR of tile s-1 (k_eq_dfe2's producer) from that buffer;
+//     wave 3            the decision-feedback recursion of tile s-2 (k_eq_dfe2's consumer);
+//     wave 2            soft bits of tile s-3 out, lanes along k.
+//   One workgroup barrier per step, 14 steps.  Same terms in the same order as k_eq_delay + k_eq_dfe2: value-identical
+//   (TRXSIG_EQ_DFE_VARIANT=3 selects it: tests/test_gpu_equalize.py passes with it; measured slower than the two kernels,
+//   see launch_eq_tail).
+//   Delayed sample m of tile u sits at tile index m - (16 u + 6): the feed-forward sum of output k = 16 u + i meets delayed
+//   samples k .. k + 6 (FULL_SPAN keeps [6, 6 + N), :1352-1356), i.e. tile u's entries i .. and the previous tile's last six.
+// ---------------------------------------------------------------------------------------------
+#define EQ3_RING 64
+template <typename SMP>
+__global__ __launch_bounds__(256) void k_eq_dfe3(const TrxTables *__restrict__ T, const void *__restrict__ samples,
+                                                 const int32_t *__restrict__ offset, const int32_t *__restrict__ length, int B,
+                                                 const cx *__restrict__ amp_in, const float *__restrict__ toa_eq,
+                                                 const uint8_t *__restrict__ flags, const cx *__restrict__ w_in,
+                                                 const cx *__restrict__ b_in, const int32_t *__restrict__ tap_ix,
+                                                 float *__restrict__ soft, uint8_t *__restrict__ hard, int nsoft, int stride) {
+  __shared__ cx ring[64][EQ3_RING + 1];                     // [burst][p & 63] (odd pitch: a lane per burst reads conflict-free)
+  __shared__ cx dl[2][64][EQ_TK + 1];                       // delay waves -> feed-forward wave
+  __shared__ cx fft[2][64][EQ_TK + 1];                      // feed-forward wave -> consumer
+  __shared__ float sft[2][64][EQ_TK + 1];                   // consumer -> feed-forward wave (soft bits on their way out)
+  __shared__ int r_off[64], r_n[64], r_io[64];
+  __shared__ cx r_inv[64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int b0 = blockIdx.x * 64;
+  const int b = b0 + lane;
+  const int bb = b < B ? b : B - 1;
+  const int N = length[bb];
+  const int off = offset[bb];
+  const float te = toa_eq[bb];
+  const bool det = b < B && off >= 0 && eq_enabled(flags[bb], N, te);
+  const int nout = det ? (nsoft < N ? nsoft : N) : 0;       // symbols this burst really produces (zeros beyond)
+  const size_t tb = (tap_ix && det) ? (size_t)tap_ix[bb] : (tap_ix ? (size_t)0 : (size_t)bb);
+  // delayVector bookkeeping (:577-582).  A burst that is not equalised (flag, length, |TOA| > 4096, NaN) gets delay 0: its TOA may
+  // be anything, and the table sinc's subtract-one range reduction does not come back from a huge argument
+  const float delay = det ? -te : 0.0f;
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  if (wave == 2) {                                          // what the loader needs per row
+    r_off[lane] = off; r_n[lane] = det ? N : 0; r_io[lane] = io;
+    r_inv[lane] = cdiv(mk(1.0f, 0.0f), amp_in[bb]);         // ((complex)1.0)/amp (Transceiver.cpp:391)
+  }
+  const int kc = lane & 15, r0 = lane >> 4;                 // tile traffic: this lane moves column kc of rows r0 + 4 i
+  // raw tile v: positions p = 16 v + kc, i.e. samples a = p - io of each row
+  auto load_raw = [&](int v, typename SMP::raw_t (&rv)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r = r0 + 4 * i;
+      const int a = EQ_TK * v + kc - r_io[r];
+      rv[i] = (a >= 0 && a < r_n[r]) ? SMP::ldraw(samples, (long long)r_off[r] + a) : SMP::zero();
+    }
+  };
+  auto park_raw = [&](int v, const typename SMP::raw_t (&rv)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r = r0 + 4 * i;
+      ring[r][(EQ_TK * v + kc) & (EQ3_RING - 1)] = cmul(SMP::widen(rv[i]), r_inv[r]);   // scaleVector (:713-723)
+    }
+  };
+  if (wave == 2) {
+    wave_lds_fence();                                       // the row tables are this wave's own writes
+    typename SMP::raw_t rv[16];
+    load_raw(-1, rv); park_raw(-1, rv);
+    load_raw(0, rv); park_raw(0, rv);
+  }
+  __syncthreads();
+
+  if (wave < 2) {
+    // ---- delayVector (:573-616), eight outputs of every tile per wave ----
+    const bool filt = fabs((double)frac) > 1e-2;
+    float tp[21];
+    {
+      const float f512 = frac * 512.0f;
+      const int f = (int)f512;
+      const bool grid = f < 512 && (float)f == f512;
+      const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+      float g[24];
+#pragma unroll
+      for (int q = 0; q < 6; q++) { const float4 r4 = row[q]; g[4 * q] = r4.x; g[4 * q + 1] = r4.y; g[4 * q + 2] = r4.z; g[4 * q + 3] = r4.w; }
+#pragma unroll
+      for (int j = 0; j < 21; j++) tp[j] = g[j];
+      if (__any(!grid)) {                                   // off the grid (never after peakDetect): sinc(pi*((j - 10) - frac)) (:588)
+#pragma unroll
+        for (int j = 0; j < 21; j++) {
+          const float tj = dev_sinc(T->sinT, TRX_PI_F * ((float)(j - 10) - frac));
+          tp[j] = grid ? g[j] : tj;
+        }
+      }
+    }
+    const int h8 = 8 * wave;
+    for (int s = -1; s <= EQ_NT + 2; s++) {
+      if (s <= EQ_NT - 1) {
+        const int m0 = EQ_TK * s + 6 + h8;                  // first delayed sample of this wave's half tile
+        cx w[28];
+#pragma unroll
+        for (int q = 0; q < 28; q++) w[q] = ring[lane][(m0 - 10 + q) & (EQ3_RING - 1)];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          cx acc = mk(0, 0);
+#pragma unroll
+          for (int j = 0; j < 21; j++) acc = cadd(acc, cmulr(w[i + 20 - j], tp[j]));   // convolve(..., NO_DELAY), j ascending (:590)
+          const int t = m0 + i - io;
+          const cx r = filt ? acc : w[i + 10];
+          dl[s & 1][lane][h8 + i] = (t >= 0 && t < N && det) ? r : mk(0, 0);           // shifted[m] inside [0, N), else 0 (:597-613)
+        }
+      }
+      __syncthreads();
+    }
+  } else if (wave == 2) {
+    // ---- loader, feed-forward FIR, soft bits out ----
+    cx w[7], win[6];
+#pragma unroll
+    for (int j = 0; j < 7; j++) w[j] = w_in[tb * 7 + j];
+#pragma unroll
+    for (int m = 0; m < 6; m++) win[m] = mk(0, 0);
+    auto write_out = [&](int u) {                           // soft tile u, lanes along k
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int r = r0 + 4 * i, k = EQ_TK * u + kc, rb = b0 + r;
+        if (rb < B && k < nsoft) {
+          const float sv = sft[u & 1][r][kc];
+          soft[(size_t)rb * stride + k] = sv;
+          if (hard) hard[(size_t)rb * stride + k] = sv > 0.5F;
+        }
+      }
+    };
+    for (int s = -1; s <= EQ_NT + 2; s++) {
+      typename SMP::raw_t rv[16];
+      const bool do_load = s + 2 <= EQ_NT + 1;              // (ring tiles up to NT + 1: the last delay step reads into it)
+      if (do_load) load_raw(s + 2, rv);                     // in flight under the arithmetic below
+      else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) rv[i] = SMP::zero();
+      }
+      const int u = s - 1;
+      if (u >= -1 && u <= EQ_NT - 1) {
+        cx xa[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) xa[i] = dl[u & 1][lane][i];
+        if (u >= 0) {
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int k = EQ_TK * u + i;
+            cx d = mk(0, 0);
+#pragma unroll
+            for (int j = 0; j < 7; j++) {                   // convolve general branch: sum += a[t-j]*b[j], t = k+6
+              const int ai = k + 6 - j;
+              const cx xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
+              if (ai >= 0 && ai < N) d = cadd(d, cmul(xv, w[j]));
+            }
+            fft[u & 1][lane][i] = d;
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 6; m++) win[m] = xa[15 - m];    // delayed samples 16 u + 21 - m: the next tile's x[k + 6 - j], j > i
+      }
+      if (do_load) park_raw(s + 2, rv);
+      if (s - 3 >= 0 && s - 3 <= EQ_NT - 1) write_out(s - 3);
+      __syncthreads();
+    }
+  } else {
+    // ---- the decision-feedback recursion (k_eq_dfe2's consumer) ----
+    cx bq[5], hist[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { bq[j] = b_in[tb * 5 + j]; hist[j] = mk(0, 0); }
+    for (int s = -1; s <= EQ_NT + 2; s++) {
+      const int u = s - 2;
+      if (u >= 0 && u <= EQ_NT - 1) {
+        cx ffv[EQ_TK], rv[EQ_TK], rt[EQ_TK];
+#pragma unroll
+        for (int i = 0; i < EQ_TK; i++) {
+          ffv[i] = fft[u & 1][lane][i];
+          rv[i] = T->rev[EQ_TK * u + i];                    // (rev/rot hold 157 * 4 entries: in range for k < 160)
+          rt[i] = T->rot[EQ_TK * u + i];
+        }
+#pragma unroll
+        for (int i = 0; i < EQ_TK; i++) sft[u & 1][lane][i] = dfe_step(EQ_TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+#endif  // TRX_TUNING_BUILD
+
 // TRXSIG_EQ_DFE_VARIANT=1 (environment, A/B): the lane-per-burst k_eq_dfe instead of the producer/consumer k_eq_dfe2
 void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
                    const float *toa_eq, const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride,
                    const int32_t *tap_ix = nullptr) {
-  static const bool legacy = std::getenv("TRXSIG_EQ_DFE_VARIANT") && std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) == 1;
+  static const bool legacy = std::getenv("TRXSIG_EQ_DFE_VARIANT") && std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) == 1;   // (2: k_eq_dfe2)
   if (legacy)
     k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
   else
@@ -754,6 +957,38 @@ __global__ __launch_bounds__(64) void k_design_dfe(const cx *__restrict__ chan_i
 
 }  // namespace
 
+// scaleVector + equalizeBurst: k_eq_delay + k_eq_dfe2 through the xd scratch (default; TRXSIG_EQ_DFE_VARIANT=1: the lane-per-burst
+// k_eq_dfe) or, TRXSIG_EQ_DFE_VARIANT=3 in the tuning library, the single fused kernel k_eq_dfe3 -- value-identical and, as measured, slower: 160 us
+// against 37 + 57 per 65,536 bursts.  Its 78 KB of LDS leave two workgroups per CU, so the 1,024 workgroups run in two
+// generations, and each generation lasts as long as the decision-feedback recursion of its 157 symbols (a latency chain,
+// ~0.33 us per symbol) however well the other roles hide under it; the two-kernel form has all 1,024 consumer waves in flight
+// at once.
+#ifdef TRX_TUNING_BUILD
+static int eq_dfe_variant() {
+  static const int v = std::getenv("TRXSIG_EQ_DFE_VARIANT") ? std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) : 0;
+  return v;
+}
+#endif
+static void launch_eq_tail(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off, const int32_t *len, int B,
+                           const trx_c32 *amp, const float *toa_eq, const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd,
+                           int xstride, float *soft, uint8_t *hard, int nsoft, int stride, const int32_t *tap_ix, TrxProfiler *prof) {
+#ifdef TRX_TUNING_BUILD
+  if (eq_dfe_variant() == 3) {
+    if (prof) prof->begin(TRXSIG_K_EQ_DFE, st);
+    const dim3 g((B + 63) / 64), blk(256);
+    if (fmt == TRXSIG_SAMPLES_F16) k_eq_dfe3<SmpF16><<<g, blk, 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags, w, bq, tap_ix, soft, hard, nsoft, stride);
+    else k_eq_dfe3<SmpC32><<<g, blk, 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags, w, bq, tap_ix, soft, hard, nsoft, stride);
+    if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
+    return;
+  }
+#endif
+  if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
+  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
+  if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
+  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
+  if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
+}
+
 hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
                                  trx_c32 *bq, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
@@ -772,11 +1007,8 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
                    variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr, nullptr, nullptr);
-  if (prof) { prof->end(TRXSIG_K_EQUALIZE, st); prof->begin(TRXSIG_K_EQ_DELAY, st); }
-  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
-  if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
-  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride);
-  if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
+  if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
+  launch_eq_tail(st, dT, samples, fmt, off, len, B, amp, toa_eq, flags, w, bq, xd, xstride, soft, hard, nsoft, stride, nullptr, prof);
   return hipGetLastError();
 }
 
@@ -802,10 +1034,6 @@ hipError_t trx_launch_equalize_taps(hipStream_t st, const TrxTables *dT, const v
                                     const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd, int xstride,
                                     float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof, const int32_t *tap_ix) {
   if (B <= 0) return hipSuccess;
-  if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
-  EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
-  if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
-  launch_eq_dfe(st, dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
-  if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
+  launch_eq_tail(st, dT, samples, fmt, off, len, B, amp, toa_eq, flags, w, bq, xd, xstride, soft, hard, nsoft, stride, tap_ix, prof);
   return hipGetLastError();
 }
