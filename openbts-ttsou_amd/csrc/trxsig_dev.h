@@ -56,6 +56,11 @@ __device__ __forceinline__ v2f pk_cmul(v2f x, v2f a) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                     // (p.lo - q.lo, p.hi + q.hi)
   return r;
 }
+__device__ __forceinline__ v2f pk_mul(v2f x, v2f a) {       // (x.lo*a.lo, x.hi*a.hi): Complex * Real with a = (t, t) (Complex.h:84)
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a));
+  return r;
+}
 __device__ __forceinline__ v2f pk_cadd(v2f x, v2f a) {
   v2f r;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a));

@@ -120,18 +120,22 @@ __global__ __launch_bounds__(256) void k_eq_delay(const TrxTables *__restrict__ 
   //      position PADL + m + 10 - j = w[i + 20 - j] ----
   cx y[OPL];
   {
+    // packed float32 pairs (one v_pk_mul_f32 + one v_pk_add_f32 per complex-by-real multiply-add, each half rounded on its own:
+    // the same values as cmulr + cadd in half the instructions -- this kernel is bound by what its few waves can issue)
     const cx *W = S + (PADL + OPL * hl - 10);
-    cx w[OPL + 20];
+    v2f w[OPL + 20], tp2[21];
 #pragma unroll
-    for (int k = 0; k < OPL + 20; k++) w[k] = W[k];
+    for (int k = 0; k < OPL + 20; k++) w[k] = pk(W[k]);
+#pragma unroll
+    for (int j = 0; j < 21; j++) { tp2[j].x = tp[j]; tp2[j].y = tp[j]; }
 #pragma unroll
     for (int i = 0; i < OPL; i++) {
-      cx acc = mk(0, 0);
+      v2f acc = pk(mk(0, 0));
 #pragma unroll
-      for (int j = 0; j < 21; j++) acc = cadd(acc, cmulr(w[i + 20 - j], tp[j]));   // convolve(..., NO_DELAY), j ascending (:590)
+      for (int j = 0; j < 21; j++) acc = pk_cadd(acc, pk_mul(w[i + 20 - j], tp2[j]));   // convolve(..., NO_DELAY), j ascending (:590)
       const int t = OPL * hl + i - io;
-      const cx r = filt ? acc : w[i + 10];
-      y[i] = (t >= 0 && t < N) ? r : mk(0, 0);
+      const v2f r = filt ? acc : w[i + 10];
+      y[i] = (t >= 0 && t < N) ? mk(r.x, r.y) : mk(0, 0);
     }
   }
   // ---- through LDS again, so that a store instruction writes 16 consecutive samples of each burst ----
@@ -601,26 +605,26 @@ __global__ __launch_bounds__(64) void k_eq_dfe(const TrxTables *__restrict__ T, 
 // (Round 3 also ran this step on packed float32 pairs -- pk_cmul / pk_cadd of trxsig_dev.h, 31 instead of 66 instructions, the
 // same values: k_eq_dfe2 57.2 -> 60.1 us.  The recursion is bound by the latency of its dependent chain, not by the
 // consumer wave's instruction count.)
-__device__ __forceinline__ float dfe_step(int k, int nout, cx ff, cx rv, cx rt, const cx (&bq)[5], cx (&hist)[5]) {
-  float sv = 0.0f;
-  if (k < nout) {
-    cx d = ff;                                              // the feed-forward terms, already summed in order
+__device__ __forceinline__ float dfe_step(int k, int nout, cx ff, cx rv, cx rt, const v2f (&bq)[5], v2f (&hist)[5]) {
+  // Branch-free: a burst shorter than the tile keeps stepping (its history is never looked at again) and only the result is
+  // masked.  Packed float32 pairs (pk_cmul / pk_cadd, trxsig_dev.h: the reference's products and sums, each rounded on its
+  // own): a complex multiply-add is 4 instructions instead of 8.
+  v2f d = pk(ff);                                           // the feed-forward terms, already summed in order
 #pragma unroll
-    for (int j = 0; j < 5; j++)                             // feedback over past decisions (:1370-1374)
-      if (k - 1 - j >= 0) d = cadd(d, cmul(bq[j], hist[j]));
-    d = cmul(d, rv);                                        // :1375
-    const float re = d.r;
-    const cx dec = mk((re > 0.0f) ? 1.0f : -1.0f, 0.0f);    // :1378
-    const cx fbv = cmul(dec, rt);                           // :1380
+  for (int j = 0; j < 5; j++)                               // feedback over past decisions (:1370-1374)
+    if (k - 1 - j >= 0) d = pk_cadd(d, pk_cmul(bq[j], hist[j]));
+  d = pk_cmul(d, pk(rv));                                   // :1375
+  const float re = d.x;
+  const cx dec = mk((re > 0.0f) ? 1.0f : -1.0f, 0.0f);      // :1378
+  const v2f fbv = pk_cmul(pk(dec), pk(rt));                 // :1380
 #pragma unroll
-    for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
-    hist[0] = fbv;
-    sv = (re + 1.0F) * 0.5F;                                // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)); re + 1.0F is 0 or
-    //                                                         at least 2^-24 in magnitude, so halving it in float is exact too
-    if (sv > 1.0f) sv = 1.0f;
-    if (sv < 0.0f) sv = 0.0f;
-  }
-  return sv;
+  for (int j = 4; j > 0; j--) hist[j] = hist[j - 1];
+  hist[0] = fbv;
+  float sv = (re + 1.0F) * 0.5F;                            // vectorSlicer (:513-515): (float)(0.5*(double)(re + 1.0F)); re + 1.0F is 0 or
+  //                                                           at least 2^-24 in magnitude, so halving it in float is exact too
+  if (sv > 1.0f) sv = 1.0f;
+  if (sv < 0.0f) sv = 0.0f;
+  return k < nout ? sv : 0.0f;
 }
 
 #define EQ_TK 16             /* symbols per tile */
@@ -651,11 +655,11 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
   if (producer) {
     const int kc = lane & 15, r0 = lane >> 4;               // tile traffic: this lane moves column kc of rows r0 + 4 i
     const cx *x = xd + (size_t)bb * xstride;
-    cx w[7], win[6];
+    v2f w[7], win[6];
 #pragma unroll
-    for (int j = 0; j < 7; j++) w[j] = w_in[tb * 7 + j];
+    for (int j = 0; j < 7; j++) w[j] = pk(w_in[tb * 7 + j]);
 #pragma unroll
-    for (int m = 0; m < 6; m++) win[m] = (5 - m < N) ? x[5 - m] : mk(0, 0);   // win[m] = x[16 u + 5 - m]
+    for (int m = 0; m < 6; m++) win[m] = pk((5 - m < N) ? x[5 - m] : mk(0, 0));   // win[m] = x[16 u + 5 - m]
     // sample tile u: a = 16 u + 6 + c, c = 0..15 (output k = 16 u + i needs x[k + 6 - j]: FULL_SPAN keeps [6, 6+N), :1352-1356)
     auto load_tile = [&](int u, cx (&v)[16]) {
 #pragma unroll
@@ -683,20 +687,22 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
       for (int i = 0; i < 16; i++) xt[r0 + 4 * i][kc] = v[i];
       wave_lds_fence();
       if (u + 1 < EQ_NT) load_tile(u + 1, v);               // the next tile's loads fly during this tile's arithmetic
-      cx xa[16];
+      v2f xa[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) xa[i] = xt[lane][i];
+      for (int i = 0; i < 16; i++) xa[i] = pk(xt[lane][i]);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int k = EQ_TK * u + i;
-        cx d = mk(0, 0);
+        v2f d = pk(mk(0, 0));
 #pragma unroll
         for (int j = 0; j < 7; j++) {                       // convolve general branch: sum += a[t-j]*b[j], t = k+6
           const int ai = k + 6 - j;
-          const cx xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
-          if (ai >= 0 && ai < N) d = cadd(d, cmul(xv, w[j]));
+          const v2f xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
+          // (a term outside the burst is skipped in the reference; here it is added as the product with a zero SAMPLE
+          // instead: x is 0 there, the sum starts at +0 and +0 + (+-0) = +0, so the value is the same -- and no branch)
+          d = pk_cadd(d, pk_cmul((ai >= 0 && ai < N) ? xv : pk(mk(0, 0)), w[j]));
         }
-        fft[u & 1][lane][i] = d;
+        fft[u & 1][lane][i] = mk(d.x, d.y);
       }
 #pragma unroll
       for (int m = 0; m < 6; m++) win[m] = xa[15 - m];
@@ -706,9 +712,9 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
     __syncthreads();                                        // barrier 10
     write_out(EQ_NT - 1);
   } else {
-    cx bq[5], hist[5];
+    v2f bq[5], hist[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { bq[j] = b_in[tb * 5 + j]; hist[j] = mk(0, 0); }
+    for (int j = 0; j < 5; j++) { bq[j] = pk(b_in[tb * 5 + j]); hist[j] = pk(mk(0, 0)); }
     for (int u = 0; u < EQ_NT; u++) {
       __syncthreads();                                      // barrier u
       // the tile's operands up front: feed-forward sums (LDS), rotation factors (uniform -> scalar loads)
@@ -900,9 +906,9 @@ __global__ __launch_bounds__(256) void k_eq_dfe3(const TrxTables *__restrict__ T
     }
   } else {
     // ---- the decision-feedback recursion (k_eq_dfe2's consumer) ----
-    cx bq[5], hist[5];
+    v2f bq[5], hist[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { bq[j] = b_in[tb * 5 + j]; hist[j] = mk(0, 0); }
+    for (int j = 0; j < 5; j++) { bq[j] = pk(b_in[tb * 5 + j]); hist[j] = pk(mk(0, 0)); }
     for (int s = -1; s <= EQ_NT + 2; s++) {
       const int u = s - 2;
       if (u >= 0 && u <= EQ_NT - 1) {
