@@ -24,24 +24,28 @@ namespace {
 template <int LW, typename TAB>
 __device__ __forceinline__ cx peak_bisect(const TAB &tab, const cx (*loc)[LW], int lane, int M, float *peakIx) {
   // tab: float[512][24], either TrxTables::sinc_grid in global memory or a copy in LDS
-  auto load_row = [&](int f, float (&s)[24]) {
+  // Packed float32 pairs (trxsig_dev.h): a row is kept as 12 register pairs of two consecutive taps, and a complex-by-real
+  // multiply-add is one v_pk_mul_f32 (tap picked by op_sel) + one v_pk_add_f32 -- the same products and sums, each rounded on
+  // its own, in half the instructions; the lane-per-burst kernels that call this are bound by what one wave can issue.
+  auto load_row = [&](int f, v2f (&s)[12]) {
     const float4 *row = reinterpret_cast<const float4 *>(tab[f & 511]);
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       const float4 v = row[q];
-      s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w;
+      s[2 * q].x = v.x; s[2 * q].y = v.y; s[2 * q + 1].x = v.z; s[2 * q + 1].y = v.w;
     }
   };
   // pa = interpolatePoint(ix), pb = interpolatePoint(ix + dI2): same fractional part, row s
-  auto interp2 = [&](float ix, int dI2, const float (&s)[24], cx &pa, cx &pb) {
+  auto interp2 = [&](float ix, int dI2, const v2f (&s)[12], v2f &pa, v2f &pb) {
     const int I = (int)floorf(ix);
     int base = I - M + 2;                                  // loc index of tap j = 0 (0..3 by construction)
     base = base < 0 ? 0 : (base > 3 ? 3 : base);
-    pa = mk(0, 0); pb = mk(0, 0);
+    pa = pk(mk(0, 0)); pb = pk(mk(0, 0));
 #pragma unroll
     for (int j = 0; j < 21; j++) {
-      pa = cadd(pa, cmulr(loc[base + j][lane], s[j]));
-      pb = cadd(pb, cmulr(loc[base + j + dI2][lane], s[j]));
+      const v2f xa = pk(loc[base + j][lane]), xb = pk(loc[base + j + dI2][lane]);
+      if (j & 1) { pa = pk_cadd(pa, pk_mul_tap<1>(xa, s[j >> 1])); pb = pk_cadd(pb, pk_mul_tap<1>(xb, s[j >> 1])); }
+      else { pa = pk_cadd(pa, pk_mul_tap<0>(xa, s[j >> 1])); pb = pk_cadd(pb, pk_mul_tap<0>(xb, s[j >> 1])); }
     }
   };
   auto frac512 = [](float ix) { return (int)((ix - floorf(ix)) * 512.0f); };
@@ -49,15 +53,15 @@ __device__ __forceinline__ cx peak_bisect(const TAB &tab, const cx (*loc)[LW], i
   float early = (float)M - 1;
   float incr = 0.5f;
   bool active = true;
-  float cur[24], up[24], dn[24];
+  v2f cur[12], up[12], dn[12];
   load_row(0, cur);                                        // early = M-1 is an integer
 #pragma unroll 1
   for (int step = 0; step < 9; step++) {                   // incr = 2^-1 .. 2^-9  (> 1/1024)
     load_row(frac512(early + incr), up);                   // candidates for the next step / the final point
     load_row(frac512(early - incr), dn);
-    cx e, l;
+    v2f e, l;
     interp2(early, 2, cur, e, l);
-    const float ne = norm2(e), nl = norm2(l);
+    const float ne = norm2(unpk(e)), nl = norm2(unpk(l));
     const bool goUp = ne < nl, goDn = ne > nl;
     if (active) {
       if (goUp) early += incr;
@@ -67,12 +71,12 @@ __device__ __forceinline__ cx peak_bisect(const TAB &tab, const cx (*loc)[LW], i
     }
     const bool moved = active;                             // row changes only if the index moved
 #pragma unroll
-    for (int j = 0; j < 24; j++) cur[j] = moved ? (goUp ? up[j] : dn[j]) : cur[j];
+    for (int j = 0; j < 12; j++) cur[j] = moved ? (goUp ? up[j] : dn[j]) : cur[j];
   }
   *peakIx = early + 1.0f;                                  // same fractional part as `early`: row = cur
-  cx peak, dummy;
+  v2f peak, dummy;
   interp2(*peakIx, 0, cur, peak, dummy);
-  return peak;
+  return unpk(peak);
 }
 
 

@@ -61,6 +61,21 @@ __device__ __forceinline__ v2f pk_mul(v2f x, v2f a) {       // (x.lo*a.lo, x.hi*
   asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a));
   return r;
 }
+// Complex * Real (Complex.h:84) with the real factor taken from one half of a register pair that holds two consecutive taps:
+// HI = 0: (x.r*t.lo, x.i*t.lo), HI = 1: (x.r*t.hi, x.i*t.hi) -- a row of real taps feeds packed multiplies without being duplicated
+template <int HI>
+__device__ __forceinline__ v2f pk_mul_tap(v2f x, v2f t) {
+  v2f r;
+  if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(t));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(t));
+  return r;
+}
+__device__ __forceinline__ v2f pk_csub(v2f x, v2f a) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(a));
+  return r;
+}
+__device__ __forceinline__ cx unpk(v2f v) { return mk(v.x, v.y); }
 __device__ __forceinline__ v2f pk_cadd(v2f x, v2f a) {
   v2f r;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(a));

@@ -154,71 +154,79 @@ __global__ __launch_bounds__(256) void k_eq_delay(const TrxTables *__restrict__ 
 // designDFE(channelResponse, SNRestimate, Nf = 7, ...) (sigProcLib.cpp:1246-1340), nu = 5: fully unrolled in registers.
 // chan: the six channel taps (already scaled by 1/amp, Transceiver.cpp:346); w: feed-forward, bq: feedback taps.
 __device__ __forceinline__ void design_dfe7(const cx (&chan)[6], float snr, cx (&w)[7], cx (&bq)[5]) {
+  // Complex arithmetic on packed float32 pairs (pk_cmul / pk_cadd / pk_csub of trxsig_dev.h: Complex.h's products and sums, each
+  // rounded on its own); norms, divisions and square roots stay scalar.  A lane per channel estimate: what bounds it is the
+  // number of instructions one wave can issue.
   constexpr int Nf = 7, nu = 5;
-  cx G0[Nf], G1[Nf];
+  auto conj2 = [](v2f z) { v2f r; r.x = z.x; r.y = -z.y; return r; };
+  auto nrm = [](v2f z) { return z.y * z.y + z.x * z.x; };    // Complex::norm2 (Complex.h:119)
+  v2f G0[Nf], G1[Nf];
 #pragma unroll
-  for (int k = 0; k < Nf; k++) { G0[k] = mk(0, 0); G1[k] = mk(0, 0); }
-  G0[0] = mk((float)(1.0 / (double)sqrtf(snr)), 0.0f);     // :1261
+  for (int k = 0; k < Nf; k++) { G0[k] = pk(mk(0, 0)); G1[k] = pk(mk(0, 0)); }
+  G0[0] = pk(mk((float)(1.0 / (double)sqrtf(snr)), 0.0f));  // :1261
 #pragma unroll
-  for (int j = 0; j <= nu; j++) G1[j] = mk(chan[j].r, -chan[j].i);
-  cx Lu[Nf - 1][Nf - 1];                                   // L[i][j], i < j <= Nf-1, stored at [i][j-i-1]
-  cx Lfb[nu];                                              // L[Nf-1][Nf .. Nf+nu-1]
+  for (int j = 0; j <= nu; j++) G1[j] = pk(mk(chan[j].r, -chan[j].i));
+  v2f Lu[Nf - 1][Nf - 1];                                   // L[i][j], i < j <= Nf-1, stored at [i][j-i-1]
+  v2f Lfb[nu];                                              // L[Nf-1][Nf .. Nf+nu-1]
   float d = 0.0f;
 #pragma unroll
   for (int i = 0; i < Nf; i++) {
-    d = norm2(G0[0]) + norm2(G1[0]);                       // :1272
-    const cx g0c = mk(G0[0].r, -G0[0].i), g1c = mk(G1[0].r, -G1[0].i);
+    d = nrm(G0[0]) + nrm(G1[0]);                            // :1272
+    const v2f g0c = conj2(G0[0]), g1c = conj2(G1[0]);
 #pragma unroll
-    for (int k = 1; k < Nf; k++) {                         // *Lptr = (G0[k]*conj(G0[0]) + G1[k]*conj(G1[0]))/d (:1277)
+    for (int k = 1; k < Nf; k++) {                          // *Lptr = (G0[k]*conj(G0[0]) + G1[k]*conj(G1[0]))/d (:1277)
       const int col = i + k;
       const bool need = (i < Nf - 1) ? (col <= Nf - 1) : (col >= Nf && col < Nf + nu);
       if (need) {
-        const cx tt = cadd(cmul(G0[k], g0c), cmul(G1[k], g1c));
-        const cx v = mk(tt.r / d, tt.i / d);
+        const v2f tt = pk_cadd(pk_cmul(G0[k], g0c), pk_cmul(G1[k], g1c));
+        v2f v; v.x = tt.x / d; v.y = tt.y / d;
         if (i < Nf - 1) Lu[i][k - 1] = v; else Lfb[col - Nf] = v;
       }
     }
-    const cx kk = cdiv(G1[0], G0[0]);                      // :1282
+    v2f kk;                                                 // G1[0] / G0[0] = G1[0] * G0[0].inv() (:1282; Complex.h:85, 154-160)
+    {
+      const float n = nrm(G0[0]);
+      v2f inv; inv.x = G0[0].x / n; inv.y = -G0[0].y / n;
+      kk = pk_cmul(G1[0], inv);
+    }
     if (i != Nf - 1) {
-      cx G0n[Nf], G1n[Nf];
-      const cx kc = mk(kk.r, -kk.i), km = cmulr(kk, -1.0f);
+      v2f G0n[Nf], G1n[Nf];
+      const v2f kc = conj2(kk);
+      v2f km; km.x = kk.x * -1.0f; km.y = kk.y * -1.0f;      // k * -1
 #pragma unroll
-      for (int q = 0; q < Nf; q++) G0n[q] = cadd(cmul(G1[q], kc), G0[q]);      // :1285-1287
+      for (int q = 0; q < Nf; q++) G0n[q] = pk_cadd(pk_cmul(G1[q], kc), G0[q]);      // :1285-1287
 #pragma unroll
-      for (int q = 0; q < Nf; q++) G1n[q] = cadd(cmul(G0[q], km), G1[q]);      // :1289-1291
+      for (int q = 0; q < Nf; q++) G1n[q] = pk_cadd(pk_cmul(G0[q], km), G1[q]);      // :1289-1291
 #pragma unroll
-      for (int q = 0; q < Nf - 1; q++) G1n[q] = G1n[q + 1];                     // delayVector(G1new,-1) (:1292)
-      G1n[Nf - 1] = mk(0, 0);
-      const cx sc = mk((float)(1.0 / (double)sqrtf((float)(1.0 + (double)norm2(kk)))), 0.0f);   // :1294-1295
+      for (int q = 0; q < Nf - 1; q++) G1n[q] = G1n[q + 1];                           // delayVector(G1new,-1) (:1292)
+      G1n[Nf - 1] = pk(mk(0, 0));
+      const v2f sc = pk(mk((float)(1.0 / (double)sqrtf((float)(1.0 + (double)nrm(kk)))), 0.0f));   // :1294-1295
 #pragma unroll
-      for (int q = 0; q < Nf; q++) { G0[q] = cmul(G0n[q], sc); G1[q] = cmul(G1n[q], sc); }
+      for (int q = 0; q < Nf; q++) { G0[q] = pk_cmul(G0n[q], sc); G1[q] = pk_cmul(G1n[q], sc); }
     }
   }
 #pragma unroll
-  for (int j = 0; j < nu; j++) {                           // :1301-1304: * -1, conj
-    const cx t1 = cmul(Lfb[j], mk(-1.0f, 0.0f));
-    bq[j] = mk(t1.r, -t1.i);
+  for (int j = 0; j < nu; j++) {                            // :1301-1304: * -1, conj
+    const v2f t1 = pk_cmul(Lfb[j], pk(mk(-1.0f, 0.0f)));
+    bq[j] = mk(t1.x, -t1.y);
   }
-  cx v[Nf];
-  v[Nf - 1] = mk(1.0f, 0.0f);
+  v2f v[Nf];
+  v[Nf - 1] = pk(mk(1.0f, 0.0f));
 #pragma unroll
-  for (int k = Nf - 2; k >= 0; k--) {                      // :1310-1319
-    cx vk = mk(0, 0);
+  for (int k = Nf - 2; k >= 0; k--) {                       // :1310-1319
+    v2f vk = pk(mk(0, 0));
 #pragma unroll
-    for (int j = k + 1; j < Nf; j++) {
-      const cx pr = cmul(v[j], Lu[k][j - k - 1]);
-      vk.r -= pr.r; vk.i -= pr.i;
-    }
+    for (int j = k + 1; j < Nf; j++) vk = pk_csub(vk, pk_cmul(v[j], Lu[k][j - k - 1]));
     v[k] = vk;
   }
 #pragma unroll
-  for (int i = 0; i < Nf; i++) {                           // :1323-1335
-    cx wi = mk(0, 0);
+  for (int i = 0; i < Nf; i++) {                            // :1323-1335
+    v2f wi = pk(mk(0, 0));
     const int endPt = (nu < (Nf - 1 - i)) ? nu : (Nf - 1 - i);
 #pragma unroll
     for (int k = 0; k < Nf; k++)
-      if (k < endPt + 1) wi = cadd(wi, cmul(v[i + k < Nf ? i + k : Nf - 1], mk(chan[k < 6 ? k : 5].r, -chan[k < 6 ? k : 5].i)));
-    w[i] = mk(wi.r / d, wi.i / d);
+      if (k < endPt + 1) wi = pk_cadd(wi, pk_cmul(v[i + k < Nf ? i + k : Nf - 1], pk(mk(chan[k < 6 ? k : 5].r, -chan[k < 6 ? k : 5].i))));
+    w[i] = mk(wi.x / d, wi.y / d);
   }
 }
 
@@ -352,29 +360,29 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   for (int a = 0; a < NXMAX; a++) xp[PADF + a][lane] = wv[a];   // the lane's LDS column (zeros from La on)
 #pragma unroll
   for (int a = 0; a < CPAD; a++) cp[CPAD + ncorr + a][lane] = mk(0, 0);
-  cx ctap[16];
+  v2f ctap[16];                                              // (packed float32 pairs from here on: see trxsig_dev.h)
 #pragma unroll
-  for (int j = 0; j < 16; j++) ctap[j] = T->mid_ctap[tsc][15 - j];
+  for (int j = 0; j < 16; j++) ctap[j] = pk(T->mid_ctap[tsc][15 - j]);
   // every tap index t - j of every lag lies in [-PADF, NXMAX): no checks (always so for the geometries above)
   const bool padded = startIndex - 15 >= -PADF && startIndex + ncorr - 1 < NXMAX;
   if (padded) {
     for (int i = 0; i < ncorr; i++) {
       const cx (*row)[64] = xp + (PADF + startIndex + i);
-      cx sum = mk(0, 0);
+      v2f sum = pk(mk(0, 0));
 #pragma unroll
-      for (int j = 0; j < 16; j++) sum = cadd(sum, cmul(row[-j][lane], ctap[j]));   // tmp[j] = conj(mid[15-j]) (:480-498), j ascending
-      cp[CPAD + i][lane] = sum;
+      for (int j = 0; j < 16; j++) sum = pk_cadd(sum, pk_cmul(pk(row[-j][lane]), ctap[j]));   // tmp[j] = conj(mid[15-j]) (:480-498), j ascending
+      cp[CPAD + i][lane] = unpk(sum);
     }
   } else {
     for (int i = 0; i < ncorr; i++) {
       const int t = startIndex + i;
-      cx sum = mk(0, 0);
+      v2f sum = pk(mk(0, 0));
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int ai = t - j;
-        if (ai >= 0 && ai < La) sum = cadd(sum, cmul(xp[PADF + ai][lane], ctap[j]));
+        if (ai >= 0 && ai < La) sum = pk_cadd(sum, pk_cmul(pk(xp[PADF + ai][lane]), ctap[j]));
       }
-      cp[CPAD + i][lane] = sum;
+      cp[CPAD + i][lane] = unpk(sum);
     }
   }
 #pragma unroll
@@ -443,18 +451,19 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
         const float frac = delay - (float)io;
         const cx (*src)[64] = cp + CPAD;
         if (fabs((double)frac) > 1e-2) {
-          float row[24];
+          v2f row[12];                                     // two consecutive taps per register pair
           {
             const float4 *r4 = reinterpret_cast<const float4 *>(T->sinc_grid[(int)(frac * 512.0f) & 511]);
 #pragma unroll
-            for (int q = 0; q < 6; q++) { const float4 v4 = r4[q]; row[4 * q] = v4.x; row[4 * q + 1] = v4.y; row[4 * q + 2] = v4.z; row[4 * q + 3] = v4.w; }
+            for (int q = 0; q < 6; q++) { const float4 v4 = r4[q]; row[2 * q].x = v4.x; row[2 * q].y = v4.y; row[2 * q + 1].x = v4.z; row[2 * q + 1].y = v4.w; }
           }
           for (int t = 0; t < ncorr; t++) {                // taps t + 10 - j outside [0, ncorr) meet cp's zero pads
             const cx (*crow)[64] = cp + (CPAD + t + 10);
-            cx sum = mk(0, 0);
+            v2f sum = pk(mk(0, 0));
 #pragma unroll
-            for (int j = 0; j < 21; j++) sum = cadd(sum, cmulr(crow[-j][lane], row[j]));
-            shf[t][lane] = sum;
+            for (int j = 0; j < 21; j++)
+              sum = (j & 1) ? pk_cadd(sum, pk_mul_tap<1>(pk(crow[-j][lane]), row[j >> 1])) : pk_cadd(sum, pk_mul_tap<0>(pk(crow[-j][lane]), row[j >> 1]));
+            shf[t][lane] = unpk(sum);
           }
           src = shf;
         }
