@@ -441,15 +441,29 @@ int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, in
   return TRXSIG_OK;
 }
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
-                     float *d_soft, int nsoft, int soft_stride) {
+                     int need_mask, float *d_soft, int nsoft, int soft_stride) {
   if (!c) return TRXSIG_EINVAL;
   if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
   if (B < 0 || nsoft < 0 || nsoft > 148 || soft_stride < nsoft || (B > 0 && (!d_amp || !d_toa || (nsoft > 0 && !d_soft))))
     return fail(c, TRXSIG_EINVAL, "trx_ctx_rx_demod: bad argument");
   if (B == 0 || nsoft == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
-  HIPCHK(c, trx_launch_rx_demod(c->stream, c->d_tables, gen, B, (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, nullptr, nsoft,
+  HIPCHK(c, trx_launch_rx_demod(c->stream, c->d_tables, gen, B, (const trx_c32 *)d_amp, d_toa, d_enable, need_mask, d_soft, nullptr, nsoft,
                                 soft_stride, c->prof));
+  return TRXSIG_OK;
+}
+// trxsig_demodulate_batch with the enable test spelt out: a burst is demodulated when (d_enable[b] & need_mask) == need_mask
+int trx_ctx_demod_masked(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,
+                         const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable, int need_mask, float *d_soft, int nsoft,
+                         int soft_stride) {
+  if (!c) return TRXSIG_EINVAL;
+  if (bad_batch(d_samples, d_offset, d_length, B) || nsoft < 0 || nsoft > 157 || soft_stride < nsoft ||
+      (B > 0 && (!d_amp || !d_toa || !d_soft || !d_enable)))
+    return fail(c, TRXSIG_EINVAL, "trx_ctx_demod_masked: bad argument");
+  if (B == 0 || nsoft == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
+                             (const trx_c32 *)d_amp, d_toa, d_enable, need_mask, d_soft, nullptr, nsoft, soft_stride, c->prof));
   return TRXSIG_OK;
 }
 extern "C" {

@@ -14,7 +14,10 @@ int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float 
 int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
                     uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr);
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
-                     float *d_soft, int nsoft, int soft_stride);
+                     int need_mask, float *d_soft, int nsoft, int soft_stride);
+int trx_ctx_demod_masked(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,
+                         const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable, int need_mask, float *d_soft, int nsoft,
+                         int soft_stride);
 // the receive front end's side of a fused push (trxsig_frontend.cpp): which bursts this push completes and how the kernels
 // find their samples (begin), and the window / clock bookkeeping once the kernels are enqueued (end)
 struct trxsig_rxfe;

@@ -369,6 +369,12 @@ __device__ __forceinline__ cx rach_exact_lag(const cx *X, const cx *__restrict__
   typedef RachGeom<SPS> R;
   cx acc = mk(0, 0);
   const cx *xp = X + t + SPS;                              // X index of x[t-F+m] is t + m + SPS
+  // Neighbouring samples are read through two bases the compiler cannot relate (xo = xp + an opaque zero): it would otherwise
+  // pair them into ds_read2_b64, which the LDS serves at half the rate of two ds_read_b64 (4 array cycles per sample instead
+  // of 2; the file is compiled without the backend's load/store merging for the same reason -- see the Makefile).
+  int opaque0 = 0;
+  asm volatile("" : "+s"(opaque0));
+  const cx *xo = xp + opaque0;
   // Software pipelined in groups of TRX_RACH_EXACT_GROUP taps: the next group's samples (LDS) and taps (scalar loads) are in flight
   // while this group's 32 VALU run -- the wave shares its SIMD with only one or two others, so an exposed LDS/scalar
   // latency per group (the plain loop: 41 x ~250 cycles) is not hidden by anybody else.  Order of the sum unchanged.
@@ -381,13 +387,13 @@ __device__ __forceinline__ cx rach_exact_lag(const cx *X, const cx *__restrict__
   }
   cx xa[GS], ta[GS];
 #pragma unroll
-  for (int q = 0; q < GS; q++) { xa[q] = xp[m - q]; ta[q] = rseq[m - q]; }
+  for (int q = 0; q < GS; q++) { xa[q] = (q & 1) ? xo[m - q] : xp[m - q]; ta[q] = rseq[m - q]; }
 #pragma unroll 2
   for (int g = 0; g < NG; g++) {
     cx xb[GS], tb[GS];
     const int mn = (g + 1 < NG) ? m - GS : m;              // (the last iteration re-reads its own group: in range, unused)
 #pragma unroll
-    for (int q = 0; q < GS; q++) { xb[q] = xp[mn - q]; tb[q] = rseq[mn - q]; }
+    for (int q = 0; q < GS; q++) { xb[q] = (q & 1) ? xo[mn - q] : xp[mn - q]; tb[q] = rseq[mn - q]; }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < GS; q++) acc = cadd(acc, cmul(xa[q], mk(ta[q].r, -ta[q].i)));
@@ -509,8 +515,13 @@ struct RachRxSrc {
 #define RACH_SKIP (-1000)                                   // record marker: k_rach_front has already written this burst's outputs
 // SPLIT: stop after step 2 and hand the exact neighbourhood, M, the energy and the three candidate valley sums
 // (rint(toa) = M-1, M, M+1) to k_rach_peak2 through the record (rec: 25 complex slots, vsum: 3 float slots, [slot][Bpad]).
-template <int SPS, bool SPLIT, typename SRC>
-__device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__restrict__ T, const SRC &src,
+// NW = 2: a workgroup of two waves, a burst each, that SHARE the exact pass of step 2: a burst's contenders are its 26
+// neighbourhood lags and (mostly) a handful more, so one wave's lanes 0..31 recompute this wave's lags and its lanes 32..63
+// the other wave's (from the other burst's X) -- 1312 VALU instructions for two bursts instead of one.  A burst with more
+// than six far contenders (or none at all) makes its workgroup fall back to a wave per burst.  `live` false (NW = 2 only):
+// the odd wave of the last workgroup, which only tells its partner that it is not there.
+template <int SPS, bool SPLIT, int NW, typename SRC>
+__device__ __forceinline__ void rach_fast_burst(const int b, const bool live, const TrxTables *__restrict__ T, const SRC &src,
                                                 float detect_thresh, float energy_thresh, float amp_err,
                                                 uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                 float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
@@ -525,10 +536,20 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
   //       corr[M-12..M+11] (+2 zero slots).
   constexpr int PWN = 50 * SPS + 8;                        // 107 sps - 57 sps + 1 terms, three candidate peaks
   static_assert(Q::ZPAD <= Q::XPAD, "Z is written over X");
-  __shared__ __attribute__((aligned(16))) cx xs[1][Q::XPAD];
-  __shared__ __attribute__((aligned(16))) float side[PWN + 2 * 64 + 64 + 2 * 26];
-  const int lane = threadIdx.x;
-  constexpr int wave = 0;                                  // one wave per workgroup (14 KB of LDS each)
+  constexpr int SIDE = PWN + 2 * 64 + 64 + 2 * 26;
+  __shared__ __attribute__((aligned(16))) cx xs[NW][Q::XPAD];
+  __shared__ __attribute__((aligned(16))) float side_[NW][SIDE];
+  __shared__ int pinfo[NW][4];                             // NW = 2: {can share the exact pass, lags listed, N}
+  const int lane = threadIdx.x & 63;
+  const int wave = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
+  float *const side = side_[wave];
+  if constexpr (NW == 2) {
+    if (!live) {
+      if (lane == 0) pinfo[wave][0] = 0;
+      wave_lds_fence();
+      return;
+    }
+  }
 #ifdef TRX_RACH_PROBE                                      // tools/rach_probe.py: clock64() stamps come back through avgpwr
   long long pt_[16] = {0};
   int pk_ = 0;
@@ -549,7 +570,9 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     if (lane == 0) {
       flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = 0.0f;
       if (SPLIT) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(RACH_SKIP), 0.0f);
+      if (NW == 2) pinfo[wave][0] = 0;
     }
+    wave_lds_fence();
     return;
   }
   cx *X = xs[wave];
@@ -591,7 +614,9 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     if (lane == 0) {
       flags[b] = 0; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; if (avgpwr_out) avgpwr_out[b] = energy / (float)(unsigned)R::NE;
       if (SPLIT) rec[(size_t)24 * Bpad + b] = mk(__int_as_float(RACH_SKIP), 0.0f);
+      if (NW == 2) pinfo[wave][0] = 0;
     }
+    wave_lds_fence();
     return;
   }
   wave_lds_fence();
@@ -649,6 +674,9 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       }
     }
     wave_lds_fence();
+    int opaque0 = 0;                                       // (single 8-byte LDS reads: see rach_exact_lag)
+    asm volatile("" : "+s"(opaque0));
+    const cx *Xo = X + opaque0;
 #pragma unroll
     for (int c = 0; c < R::NCL; c++) {
       const int t = lane + 64 * c;
@@ -656,7 +684,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
       // pulse tails the reference's modulateBurst dropped: before symbol 0 (j < sps) and after symbol 40 (j = 2 sps)
       float e0r = 0.0f, e0i = 0.0f;
 #pragma unroll
-      for (int j = 0; j < SPS; j++) { const cx v = X[t + j]; e0r = fma_steer(pul[j], v.r, e0r); e0i = fma_steer(pul[j], v.i, e0i); }
+      for (int j = 0; j < SPS; j++) { const cx v = (j & 1) ? Xo[t + j] : X[t + j]; e0r = fma_steer(pul[j], v.r, e0r); e0i = fma_steer(pul[j], v.i, e0i); }
       const float s0 = (float)RachSym::v[0], s40 = (float)RachSym::v[40];
       a_r -= s0 * e0r; a_i -= s0 * e0i;                    // k = 0: conj(c_0) = s0
       const cx v40 = X[t + 42 * SPS];
@@ -697,6 +725,13 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     nfar += __popcll(mask);
   }
   wave_lds_fence();
+  bool paired = false;
+  if constexpr (NW == 2) {
+    // (a wave that left early has said so before it ended, and the barrier does not wait for it)
+    if (lane == 0) { pinfo[wave][0] = (Ma >= 0 && nfar <= 32 - Q::NB) ? 1 : 0; pinfo[wave][1] = Q::NB + nfar; pinfo[wave][2] = N; }
+    __syncthreads();
+    paired = pinfo[0][0] != 0 && pinfo[1][0] != 0;
+  }
   int M;                                                   // exact argmax
   if (Ma < 0 || nfar > 64 - Q::NB) {
     // flat or silent burst: exact correlation at every lag (the k_rach_corr route)
@@ -726,8 +761,21 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const TrxTables *__
     const int t = lane < nl ? LG[lane] : -1;
     cx v = mk(0, 0);
     const bool valid = t >= 0 && t < N;
-    if (valid) v = rach_exact_lag<SPS>(X, rseq, t);
-    exv_[lane] = v;
+    if (NW == 2 && paired) {
+      if (wave == 0) {                                     // both bursts' lags, 32 lanes each
+        const int h = lane >> 5, l = lane & 31;
+        const int *LGh = reinterpret_cast<const int *>(side_[h] + PWN + 128);
+        const int th = l < pinfo[h][1] ? LGh[l] : -1;
+        cx vh = mk(0, 0);
+        if (th >= 0 && th < pinfo[h][2]) vh = rach_exact_lag<SPS>(xs[h], rseq, th);
+        reinterpret_cast<cx *>(side_[h] + PWN)[l] = vh;
+      }
+      __syncthreads();
+      if (valid) v = exv_[lane];                           // (valid: lane < nl <= 32)
+    } else {
+      if (valid) v = rach_exact_lag<SPS>(X, rseq, t);
+      exv_[lane] = v;
+    }
     float bP = valid ? norm2(v) : 0.0f;
     int bT = (valid && bP > 0.0f) ? t : -1;
     if (bT < 0) bP = 0.0f;
@@ -861,7 +909,7 @@ __global__ __launch_bounds__(64) void k_rach_fast(const TrxTables *__restrict__ 
   const int n = list ? (*count < B ? *count : B) : B;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {        // (without a list: grid = B, one burst per workgroup)
     const int b = list ? list[i] : i;
-    rach_fast_burst<SPS, false>(b, T, RachMemSrc(samples, offset, length, b, SPS), detect_thresh, energy_thresh, amp_err, flags, amp_out,
+    rach_fast_burst<SPS, false, 1>(b, true, T, RachMemSrc(samples, offset, length, b, SPS), detect_thresh, energy_thresh, amp_err, flags, amp_out,
                                 toa_out, avgpwr_out, nullptr, nullptr, 0);
     wave_lds_fence();                                      // the next burst reuses the LDS
   }
@@ -876,7 +924,7 @@ __global__ __launch_bounds__(64) void k_rach_fast_rx(const TrxTables *__restrict
   const int n = *count < B ? *count : B;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const int b = list[i];
-    rach_fast_burst<SPS, false>(b, T, RachRxSrc(a, b), detect_thresh, energy_thresh, amp_err, flags, amp_out, toa_out, avgpwr_out,
+    rach_fast_burst<SPS, false, 1>(b, true, T, RachRxSrc(a, b), detect_thresh, energy_thresh, amp_err, flags, amp_out, toa_out, avgpwr_out,
                                 nullptr, nullptr, 0);
     wave_lds_fence();
   }
@@ -884,7 +932,7 @@ __global__ __launch_bounds__(64) void k_rach_fast_rx(const TrxTables *__restrict
 
 // steps 1-2 of k_rach_fast (approximate correlation, exact contenders and neighbourhood) for every burst
 template <int SPS>
-__global__ __launch_bounds__(64) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+__global__ __launch_bounds__(128) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                     const int32_t *__restrict__ offset,
                                                     const int32_t *__restrict__ length, int B, float energy_thresh, float amp_err,
                                                     uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
@@ -892,22 +940,24 @@ __global__ __launch_bounds__(64) void k_rach_front(const TrxTables *__restrict__
                                                     cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
                                                     int32_t *__restrict__ count) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;     // k_rach_peak2's hand-over list starts empty
-  if ((int)blockIdx.x < B)
-    rach_fast_burst<SPS, true>(blockIdx.x, T, RachMemSrc(samples, offset, length, blockIdx.x, SPS), 0.0f, energy_thresh, amp_err, flags,
-                               amp_out, toa_out, avgpwr_out, rec, vsum, Bpad);
+  const int b = 2 * blockIdx.x + (threadIdx.x >> 6);       // two waves, a burst each (they share the exact pass)
+  const bool live = b < B;
+  rach_fast_burst<SPS, true, 2>(b, live, T, RachMemSrc(samples, offset, length, live ? b : 0, SPS), 0.0f, energy_thresh, amp_err, flags,
+                                amp_out, toa_out, avgpwr_out, rec, vsum, Bpad);
 }
 // ... on bursts computed from the raw int16 stream of the receive front end (no resampled stream in memory)
 template <int SPS>
-__global__ __launch_bounds__(64) void k_rach_front_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B, float energy_thresh,
+__global__ __launch_bounds__(128) void k_rach_front_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B, float energy_thresh,
                                                        float amp_err, uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                        float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
                                                        cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
                                                        int32_t *__restrict__ count) {
   static_assert(SPS == 4, "the fused front end is the 260 : 96 resampler");
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;
-  if ((int)blockIdx.x < B)
-    rach_fast_burst<SPS, true>(blockIdx.x, T, RachRxSrc(a, blockIdx.x), 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out,
-                               avgpwr_out, rec, vsum, Bpad);
+  const int b = 2 * blockIdx.x + (threadIdx.x >> 6);
+  const bool live = b < B;
+  rach_fast_burst<SPS, true, 2>(b, live, T, RachRxSrc(a, live ? b : 0), 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out,
+                                avgpwr_out, rec, vsum, Bpad);
 }
 
 // steps 3-4 with TWO lanes per burst (pair_bisect): peakDetect's bisection on the exact neighbourhood and
@@ -1050,7 +1100,7 @@ static void launch_rach_fast(hipStream_t st, const TrxTables *dT, const trx_c32 
   float *vsum = ws + (size_t)2 * 25 * Bpad;
   int32_t *list = (int32_t *)(vsum + (size_t)4 * Bpad);
   int32_t *count = list + Bpad;
-  k_rach_front<S><<<dim3(B), dim3(64), 0, st>>>(dT, samples, off, len, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum,
+  k_rach_front<S><<<dim3((B + 1) / 2), dim3(128), 0, st>>>(dT, samples, off, len, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum,
                                                 Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
   k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr,
@@ -1086,7 +1136,7 @@ hipError_t trx_launch_rx_rach(hipStream_t st, const TrxTables *dT, const TrxRxGe
   int32_t *list = (int32_t *)(vsum + (size_t)4 * Bpad);
   int32_t *count = list + Bpad;
   if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
-  k_rach_front_rx<S><<<dim3(B), dim3(64), 0, st>>>(dT, gen, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum, Bpad, count);
+  k_rach_front_rx<S><<<dim3((B + 1) / 2), dim3(128), 0, st>>>(dT, gen, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum, Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
   k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr, list, count);
   k_rach_fast_rx<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, gen, B, detect_thresh, energy_thresh, amp_err, flags, amp, toa, avgpwr,

@@ -64,13 +64,18 @@ struct trxsig_trxgroup {
   int32_t *d_pos = nullptr;                                 // [8][S]
   TrxGroupArfcn *d_state = nullptr;
   double *d_exp = nullptr;
+  // the demodulating leg runs the state machine (two waves, latency-bound) BESIDE demodulateBurst: a side stream, forked
+  // from and joined back into the context's stream inside every pull
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // per-call workspace
   DevBuf<int32_t> rowmap, seg, off, len, tap_ix;
   DevBuf<float4> packed;
   DevBuf<uint8_t> flags, gate, ev, ev_flags;
   DevBuf<trx_c32> amp, ev_amp, w_tab, b_tab, in;
   DevBuf<float> toa, avgpwr, toa_eq, snr, ev_toa, ev_toaeq, soft, chan_off;
-  DevBuf<double> thr_after;
+  DevBuf<double> thr_after, thr_g;
+  DevBuf<uint8_t> succ_g;
   std::vector<int32_t> h_seg;
   // the last pull
   int n_slots = 0, n_rows = 0, n_tsc_rows = 0;
@@ -151,7 +156,10 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
       hipMalloc((void **)&g->d_exp, sizeof(double) * TRXG_EXP_N) != hipSuccess ||
       hipMemcpy(g->d_state, st.data(), sizeof(TrxGroupArfcn) * (size_t)S, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->d_exp, ex.data(), sizeof(double) * TRXG_EXP_N, hipMemcpyHostToDevice) != hipSuccess ||
-      g->w_tab.need(S8 * 7, nullptr) != hipSuccess || g->b_tab.need(S8 * 5, nullptr) != hipSuccess || g->chan_off.need(S8, nullptr) != hipSuccess) {
+      g->w_tab.need(S8 * 7, nullptr) != hipSuccess || g->b_tab.need(S8 * 5, nullptr) != hipSuccess || g->chan_off.need(S8, nullptr) != hipSuccess ||
+      hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess) {
     trxsig_trxgroup_destroy(g);
     return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);
   }
@@ -164,11 +172,14 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
   {
     Guard gd(trxsig_device(g->c));
     (void)hipStreamSynchronize((hipStream_t)trxsig_get_stream(g->c));
+    if (g->side) { (void)hipStreamSynchronize(g->side); (void)hipStreamDestroy(g->side); }
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
     g->rowmap.release(); g->seg.release(); g->off.release(); g->len.release(); g->tap_ix.release(); g->packed.release();
     g->flags.release(); g->gate.release(); g->ev.release(); g->ev_flags.release(); g->amp.release(); g->ev_amp.release();
     g->w_tab.release(); g->b_tab.release(); g->in.release(); g->toa.release(); g->avgpwr.release(); g->toa_eq.release();
-    g->snr.release(); g->ev_toa.release(); g->ev_toaeq.release(); g->soft.release(); g->chan_off.release(); g->thr_after.release();
+    g->snr.release(); g->ev_toa.release(); g->ev_toaeq.release(); g->soft.release(); g->chan_off.release(); g->thr_after.release(); g->thr_g.release(); g->succ_g.release();
   }
   delete g;
 }
@@ -258,6 +269,10 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   G_HIP(g, g->toa.need(R, st)); G_HIP(g, g->avgpwr.need(R, st)); G_HIP(g, g->toa_eq.need(R, st)); G_HIP(g, g->snr.need(R, st));
   G_HIP(g, g->ev_toa.need(R, st)); G_HIP(g, g->ev_toaeq.need(R, st)); G_HIP(g, g->thr_after.need(R, st));
   G_HIP(g, g->soft.need(R * kSoft, st));
+  if (g->leg != TRXSIG_TSCLEG_EQUALIZE) {
+    const size_t ns = trx_group_replay_scratch(S, n_slots);
+    G_HIP(g, g->thr_g.need(ns, st)); G_HIP(g, g->succ_g.need(ns, st));
+  }
   G_HIP(g, g->w_tab.need((S8 + R) * 7, st, S8 * 7)); G_HIP(g, g->b_tab.need((S8 + R) * 5, st, S8 * 5));
   G_HIP(g, g->chan_off.need(S8 + R, st, S8));
 
@@ -296,7 +311,19 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   rp.S = S; rp.n_slots = n_slots; rp.fn0 = fn; rp.tn0 = tn; rp.equalize = equalize; rp.n_tsc_rows = n_tsc;
   rp.rowmap = g->rowmap.p; rp.flags = g->flags.p; rp.amp = g->amp.p; rp.avgpwr = g->avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
   rp.gate = g->gate.p; rp.ev = g->ev.p; rp.tap_ix = g->tap_ix.p; rp.snr = g->snr.p; rp.thr_after = g->thr_after.p;
-  G_HIP(g, trx_launch_group_replay(st, rp, g->packed.p, trx_ctx_profiler(c)));
+  // Demodulating leg: demodulateBurst needs nothing the state machine decides except WHETHER a burst is handed up, and every
+  // burst the machine accepts is one the stateless detector flagged -- so the rows the detectors flagged are demodulated on
+  // the context's stream while the machine replays on the side stream (two waves for ~0.1 us per slot: it fills no CU), and
+  // d_valid (the machine's verdict) says which soft vectors count.  The equalising leg needs the machine's events first.
+  const bool beside = !equalize;
+  if (beside) {
+    G_HIP(g, hipEventRecord(g->ev_fork, st));
+    G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
+  }
+  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, g->packed.p, beside ? g->thr_g.p : nullptr, beside ? g->succ_g.p : nullptr,
+                                   trx_ctx_profiler(c)));
+  if (beside) G_HIP(g, hipEventRecord(g->ev_join, g->side));
+  const uint8_t *demod_gate = beside ? g->flags.p : g->gate.p;
 
   // ---- what comes back as a SoftVector ----
   if (n_tsc > 0) {
@@ -312,17 +339,18 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
       G_LIB(trx_ctx_group_equalize(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa_eq.p, g->gate.p,
                                    (const trxsig_c32 *)g->w_tab.p, (const trxsig_c32 *)g->b_tab.p, g->tap_ix.p, g->soft.p, kSoft, kSoft));
     } else if (!src.gen) {
-      G_LIB(trxsig_demodulate_batch(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa.p, g->gate.p, g->soft.p,
-                                    nullptr, kSoft, kSoft));
+      G_LIB(trx_ctx_demod_masked(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa.p, demod_gate, TRXSIG_F_DETECT,
+                                 g->soft.p, kSoft, kSoft));
     }
   }
   if (src.gen) {                                            // normal and access bursts alike: demodulateBurst on every gated row
     TrxRxGen gen = *src.gen;
     gen.sel = g->off.p;
-    G_LIB(trx_ctx_rx_demod(c, gen, n_rows, (const trxsig_c32 *)g->amp.p, g->toa.p, g->gate.p, g->soft.p, kSoft, kSoft));
+    G_LIB(trx_ctx_rx_demod(c, gen, n_rows, (const trxsig_c32 *)g->amp.p, g->toa.p, demod_gate, TRXSIG_F_DETECT, g->soft.p, kSoft, kSoft));
   } else if (n_rows > n_tsc)                                // :385-388
-    G_LIB(trxsig_demodulate_batch(c, d_samples, g->off.p + n_tsc, g->len.p + n_tsc, n_rows - n_tsc, (const trxsig_c32 *)g->amp.p + n_tsc,
-                                  g->toa.p + n_tsc, g->gate.p + n_tsc, g->soft.p + (size_t)n_tsc * kSoft, nullptr, kSoft, kSoft));
+    G_LIB(trx_ctx_demod_masked(c, d_samples, g->off.p + n_tsc, g->len.p + n_tsc, n_rows - n_tsc, (const trxsig_c32 *)g->amp.p + n_tsc,
+                               g->toa.p + n_tsc, demod_gate + n_tsc, TRXSIG_F_DETECT, g->soft.p + (size_t)n_tsc * kSoft, kSoft, kSoft));
+  if (beside) G_HIP(g, hipStreamWaitEvent(st, g->ev_join, 0));
   if (equalize) G_HIP(g, trx_launch_group_commit(st, S, g->d_state, g->w_tab.p, g->b_tab.p, g->chan_off.p));
 
   g->n_slots = n_slots; g->n_rows = n_rows; g->n_tsc_rows = n_tsc; g->have = true;
