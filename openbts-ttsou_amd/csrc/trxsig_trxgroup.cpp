@@ -83,6 +83,7 @@ struct trxsig_trxgroup {
 };
 
 namespace {
+constexpr int kBesideRows = 24576;                          // calls at least this large replay on the side stream
 #define G_HIP(g, call)                                                          \
   do {                                                                          \
     hipError_t e_ = (call);                                                     \
@@ -315,15 +316,18 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   // burst the machine accepts is one the stateless detector flagged -- so the rows the detectors flagged are demodulated on
   // the context's stream while the machine replays on the side stream (two waves for ~0.1 us per slot: it fills no CU), and
   // d_valid (the machine's verdict) says which soft vectors count.  The equalising leg needs the machine's events first.
-  const bool beside = !equalize;
+  // (a cross-stream dependency costs ~10 us each way: a small call keeps everything on one stream -- 1,024 bursts took 77
+  // instead of 48 us with the fork, 65,536 take 229 instead of 281)
+  const bool lean = !equalize;
+  const bool beside = lean && n_rows >= kBesideRows;
   if (beside) {
     G_HIP(g, hipEventRecord(g->ev_fork, st));
     G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
   }
-  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, g->packed.p, beside ? g->thr_g.p : nullptr, beside ? g->succ_g.p : nullptr,
+  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, g->packed.p, lean ? g->thr_g.p : nullptr, lean ? g->succ_g.p : nullptr,
                                    trx_ctx_profiler(c)));
   if (beside) G_HIP(g, hipEventRecord(g->ev_join, g->side));
-  const uint8_t *demod_gate = beside ? g->flags.p : g->gate.p;
+  const uint8_t *demod_gate = beside ? g->flags.p : g->gate.p;   // (gate holds TRXSIG_F_DETECT or 0: the same mask serves both)
 
   // ---- what comes back as a SoftVector ----
   if (n_tsc > 0) {
