@@ -930,9 +930,13 @@ __global__ __launch_bounds__(64) void k_rach_fast_rx(const TrxTables *__restrict
   }
 }
 
+#ifndef TRX_RACH_PAIR
+#define TRX_RACH_PAIR 1   /* 1: two bursts per workgroup share the exact pass (rach_fast_burst, NW = 2); 0: a wave per burst (A/B) */
+#endif
+constexpr int kRachNW = TRX_RACH_PAIR ? 2 : 1;
 // steps 1-2 of k_rach_fast (approximate correlation, exact contenders and neighbourhood) for every burst
 template <int SPS>
-__global__ __launch_bounds__(128) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
+__global__ __launch_bounds__(64 * kRachNW) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                     const int32_t *__restrict__ offset,
                                                     const int32_t *__restrict__ length, int B, float energy_thresh, float amp_err,
                                                     uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
@@ -940,23 +944,23 @@ __global__ __launch_bounds__(128) void k_rach_front(const TrxTables *__restrict_
                                                     cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
                                                     int32_t *__restrict__ count) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;     // k_rach_peak2's hand-over list starts empty
-  const int b = 2 * blockIdx.x + (threadIdx.x >> 6);       // two waves, a burst each (they share the exact pass)
+  const int b = kRachNW * blockIdx.x + (threadIdx.x >> 6);   // two waves, a burst each (they share the exact pass)
   const bool live = b < B;
-  rach_fast_burst<SPS, true, 2>(b, live, T, RachMemSrc(samples, offset, length, live ? b : 0, SPS), 0.0f, energy_thresh, amp_err, flags,
+  rach_fast_burst<SPS, true, kRachNW>(b, live, T, RachMemSrc(samples, offset, length, live ? b : 0, SPS), 0.0f, energy_thresh, amp_err, flags,
                                 amp_out, toa_out, avgpwr_out, rec, vsum, Bpad);
 }
 // ... on bursts computed from the raw int16 stream of the receive front end (no resampled stream in memory)
 template <int SPS>
-__global__ __launch_bounds__(128) void k_rach_front_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B, float energy_thresh,
+__global__ __launch_bounds__(64 * kRachNW) void k_rach_front_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B, float energy_thresh,
                                                        float amp_err, uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
                                                        float *__restrict__ toa_out, float *__restrict__ avgpwr_out,
                                                        cx *__restrict__ rec, float *__restrict__ vsum, int Bpad,
                                                        int32_t *__restrict__ count) {
   static_assert(SPS == 4, "the fused front end is the 260 : 96 resampler");
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;
-  const int b = 2 * blockIdx.x + (threadIdx.x >> 6);
+  const int b = kRachNW * blockIdx.x + (threadIdx.x >> 6);
   const bool live = b < B;
-  rach_fast_burst<SPS, true, 2>(b, live, T, RachRxSrc(a, live ? b : 0), 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out,
+  rach_fast_burst<SPS, true, kRachNW>(b, live, T, RachRxSrc(a, live ? b : 0), 0.0f, energy_thresh, amp_err, flags, amp_out, toa_out,
                                 avgpwr_out, rec, vsum, Bpad);
 }
 
@@ -1100,7 +1104,7 @@ static void launch_rach_fast(hipStream_t st, const TrxTables *dT, const trx_c32 
   float *vsum = ws + (size_t)2 * 25 * Bpad;
   int32_t *list = (int32_t *)(vsum + (size_t)4 * Bpad);
   int32_t *count = list + Bpad;
-  k_rach_front<S><<<dim3((B + 1) / 2), dim3(128), 0, st>>>(dT, samples, off, len, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum,
+  k_rach_front<S><<<dim3((B + kRachNW - 1) / kRachNW), dim3(64 * kRachNW), 0, st>>>(dT, samples, off, len, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum,
                                                 Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
   k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr,
@@ -1136,7 +1140,7 @@ hipError_t trx_launch_rx_rach(hipStream_t st, const TrxTables *dT, const TrxRxGe
   int32_t *list = (int32_t *)(vsum + (size_t)4 * Bpad);
   int32_t *count = list + Bpad;
   if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
-  k_rach_front_rx<S><<<dim3((B + 1) / 2), dim3(128), 0, st>>>(dT, gen, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum, Bpad, count);
+  k_rach_front_rx<S><<<dim3((B + kRachNW - 1) / kRachNW), dim3(64 * kRachNW), 0, st>>>(dT, gen, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum, Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
   k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr, list, count);
   k_rach_fast_rx<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, gen, B, detect_thresh, energy_thresh, amp_err, flags, amp, toa, avgpwr,
