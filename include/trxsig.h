@@ -457,6 +457,10 @@ int trxsig_kernel_count(void);
  *     workgroup and its demodulate workgroups in launch order.  TRXSIG_TUNE_CHAIN_SPIN: polls before a demodulate
  *     wave gives up waiting for its burst's detection (then the call is reported as failed at the library's next
  *     entry and path 0 is used from there on; 0 makes every wait that is not satisfied at once fail -- tests).
+ *     Path 5 is for A/B measurements only: its outputs are valid only after trxsig_synchronize (or the next library
+ *     call on the context) has returned TRXSIG_OK -- a caller that waits on the stream by other means would read the
+ *     soft bits of a batch whose hand-over timed out without seeing the error; its forward progress also rests on
+ *     workgroups starting in launch order, which HIP does not promise.
  *   TRXSIG_TUNE_RACH_PATH (initial value: env TRXSIG_RACH_VARIANT, else 2): 0 = exact correlation at every
  *     lag (k_rach_corr + k_rach_peak), 1 = approximate-then-exact in one kernel, a wave per burst (k_rach_fast),
  *     2 = the same with peakDetect's bisection and the tail in their own kernel, two lanes per burst
