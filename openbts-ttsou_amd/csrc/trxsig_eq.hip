@@ -271,11 +271,22 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #ifdef TRX_EQ_PROBE                                        // clock64() stamps come back through toa_out (tools/eq_probe.py)
   long long pt_[8] = {0};
   int pk_ = 0;
+#if TRX_EQ_PROBE == 2                                       // the staging block in detail instead of the phases
+#define TRX_STAMP()
+#define TRX_STAMP2() pt_[pk_++] = clock64()
+#else
 #define TRX_STAMP() pt_[pk_++] = clock64()
+#define TRX_STAMP2()
+#endif
 #else
 #define TRX_STAMP()
+#define TRX_STAMP2()
 #endif
+#if defined(TRX_EQ_PROBE) && TRX_EQ_PROBE == 2
+  pt_[pk_++] = clock64();
+#else
   TRX_STAMP();
+#endif
   const int off = live ? offset[b] : 0, N = live ? length[b] : 0;
   uint8_t fl = 0;
   cx amp = mk(0, 0);
@@ -308,31 +319,48 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   cx ev[20], wv[NXMAX];
   {
     const int step = variant52m ? 4 : 1;
-    const unsigned long long goodm = __ballot(good), winm = __ballot(good && winOk);
+    // No load is predicated per burst (a mask per load cost ~12 instructions with VALU -> SALU -> exec round trips: the 64
+    // loads took 12 k cycles to ISSUE): a burst that is not good reads the wave's first good burst instead, and an index
+    // beyond a burst's end (only possible when its window does not fit, which is refused below) is clamped to its last
+    // sample -- what such loads return is never used.
+    const unsigned long long goodm = __ballot(good);
+    TRX_STAMP2();                                          // (2: 1) offsets and lengths are here
+    const int safe_off = __builtin_amdgcn_readlane(off, goodm ? (int)__builtin_ctzll(goodm) : 0);
+    int offv = good ? off : safe_off, nm1v = good ? N - 1 : 0;
+    // (readlane below takes these from EVERY lane, also from lanes the branch around the loads masks off: pin them here, or
+    // the compiler sinks their computation under that mask and the masked lanes' registers hold whatever was there)
+    asm volatile("" : "+v"(offv), "+v"(nm1v));
 #pragma unroll
     for (int p = 0; p < NPASS; p++) {
       const int slot = lane + 64 * p;
       const bool is_win = slot >= 20;
       const bool slot_ok = slot < 20 + La && slot < NSLOT;
-      const int idx = is_win ? winStart + (slot - 20) : slot * step;
+      int idx = is_win ? winStart + (slot - 20) : slot * step;
+      idx = idx < 0 ? 0 : idx;
       typename SMP::raw_t v[64];                          // as stored; widened only once every load has been issued
 #pragma unroll
-      for (int k = 0; k < 64; k++) {
-        const int off_k = __builtin_amdgcn_readlane(off, k);
-        const bool ok_k = ((is_win ? winm : goodm) >> k) & 1ull;
-        v[k] = (slot_ok && ok_k) ? SMP::ldraw(samples, (long long)off_k + idx) : SMP::zero();
+      for (int k = 0; k < 64; k++) v[k] = SMP::zero();
+      if (slot_ok && goodm) {                              // (one mask for all 64 loads: it does not depend on the burst)
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+          const int off_k = __builtin_amdgcn_readlane(offv, k), nm1_k = __builtin_amdgcn_readlane(nm1v, k);
+          v[k] = SMP::ldraw(samples, (long long)off_k + (idx < nm1_k ? idx : nm1_k));
+        }
       }
+      TRX_STAMP2();                                        // (2: 2) loads issued
       if (slot < NSLOT) {
 #pragma unroll
         for (int k = 0; k < 64; k++) { const cx f = SMP::widen(v[k]); st_re[k * PITCH + slot] = f.r; st_im[k * PITCH + slot] = f.i; }
       }
     }
     wave_lds_fence();
+    TRX_STAMP2();                                          // (2: 3) loads complete, parked in LDS
 #pragma unroll
     for (int i = 0; i < 20; i++) ev[i] = mk(st_re[lane * PITCH + i], st_im[lane * PITCH + i]);
 #pragma unroll
     for (int a = 0; a < NXMAX; a++) wv[a] = mk(st_re[lane * PITCH + 20 + a], st_im[lane * PITCH + 20 + a]);   // zeros past La
     wave_lds_fence();                                      // the staging area is dead: xp / cp take its place
+    TRX_STAMP2();                                          // (2: 4) read back
   }
   if (!live) return;                                       // no barriers below: each lane owns its columns
   if (!good) {
@@ -519,7 +547,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #pragma unroll
   for (int j = 0; j < nu; j++) b_out[(size_t)b * nu + j] = bq[j];
 #ifdef TRX_EQ_PROBE
-  TRX_STAMP();                                             // 5: designDFE + taps
+  pt_[5] = clock64();                                      // 5: designDFE + taps
   {
     long long v_ = 0;
     for (int k = 1; k < 8; k++) if ((b & 7) == k) v_ = pt_[k] - pt_[0];
@@ -529,6 +557,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   }
 #endif
 #undef TRX_STAMP
+#undef TRX_STAMP2
 }
 
 // The burst's row of xd was written by k_eq_delay only if that kernel accepted the burst (k_demod's gate: DETECT flag,
