@@ -690,6 +690,12 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
   const size_t tb = (tap_ix && det) ? (size_t)tap_ix[bb] : (tap_ix ? (size_t)0 : (size_t)bb);
   // Barrier u (u = 0..9): ff tile u is ready and soft tile u-1 is complete; barrier 10: soft tile 9 is complete.
   // Both waves execute exactly eleven barriers.
+#ifdef TRX_DFE_PROBE
+  long long pw_ = 0, pt0_ = clock64();
+#define DFE_SYNC() do { const long long a_ = clock64(); __syncthreads(); pw_ += clock64() - a_; } while (0)
+#else
+#define DFE_SYNC() __syncthreads()
+#endif
   if (producer) {
     const int kc = lane & 15, r0 = lane >> 4;               // tile traffic: this lane moves column kc of rows r0 + 4 i
     const cx *x = xd + (size_t)bb * xstride;
@@ -744,17 +750,21 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
       }
 #pragma unroll
       for (int m = 0; m < 6; m++) win[m] = xa[15 - m];
-      __syncthreads();                                      // barrier u
+      DFE_SYNC();                                           // barrier u
       if (u >= 1) write_out(u - 1);
     }
-    __syncthreads();                                        // barrier 10
+    DFE_SYNC();                                             // barrier 10
     write_out(EQ_NT - 1);
+#ifdef TRX_DFE_PROBE
+    if (lane == 0 && b0 < B) { soft[(size_t)b0 * stride + 0] = (float)pw_; soft[(size_t)b0 * stride + 1] = (float)(clock64() - pt0_); }
+    __syncthreads();
+#endif
   } else {
     v2f bq[5], hist[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) { bq[j] = pk(b_in[tb * 5 + j]); hist[j] = pk(mk(0, 0)); }
     for (int u = 0; u < EQ_NT; u++) {
-      __syncthreads();                                      // barrier u
+      DFE_SYNC();                                           // barrier u
       // the tile's operands up front: feed-forward sums (LDS), rotation factors (uniform -> scalar loads)
       cx ffv[EQ_TK], rv[EQ_TK], rt[EQ_TK];
 #pragma unroll
@@ -766,9 +776,14 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
 #pragma unroll
       for (int i = 0; i < EQ_TK; i++) sft[u & 1][lane][i] = dfe_step(EQ_TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
     }
-    __syncthreads();                                        // barrier 10
+    DFE_SYNC();                                             // barrier 10
+#ifdef TRX_DFE_PROBE
+    __syncthreads();
+    if (lane == 0 && b0 < B) { soft[(size_t)b0 * stride + 2] = (float)pw_; soft[(size_t)b0 * stride + 3] = (float)(clock64() - pt0_); }
+#endif
   }
 }
+#undef DFE_SYNC
 
 #ifdef TRX_TUNING_BUILD   /* k_eq_dfe3: the single-kernel equaliser tail, measured slower; tuning library only */
 // ---------------------------------------------------------------------------------------------
