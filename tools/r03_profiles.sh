@@ -20,12 +20,14 @@ for W in normal rach config4 config4_stateless config4_wideband config5; do
   echo "== stats $W"
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py $(wl_args $W) --steps 200 --no-cpu-baseline --no-fresh > $O/bench_under_rocprof_$W.json 2> $O/stats_$W.err || echo "stats $W failed"
   python3 $R/tools/prof_summary.py $O/stats_$W > $O/kernel_stats_$W.csv
+  rm -rf $O/stats_$W                                       # (raw traces: gpurun brings back at most 64 MiB)
   cat $O/kernel_stats_$W.csv
 done
 for T in fec_bench txbe_bench; do
   echo "== stats $T"
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$T -- python3 $R/tools/$T.py > $O/$T.json 2> $O/stats_$T.err || echo "stats $T failed"
   python3 $R/tools/prof_summary.py $O/stats_$T > $O/kernel_stats_$T.csv
+  rm -rf $O/stats_$T
   cat $O/kernel_stats_$T.csv
 done
 fi
@@ -35,5 +37,10 @@ for W in normal rach config4 config5; do
   echo "== pmc $W"
   bash tools/pmc.sh r03prof/pmc_$W $(wl_args $W) --no-fresh > $O/pmc_$W.txt 2>&1 || echo "pmc $W failed"
   tail -3 $O/pmc_$W.txt
+done
+for T in fec_bench txbe_bench; do
+  echo "== pmc $T"
+  PMC_PROG=tools/$T.py bash tools/pmc.sh r03prof/pmc_$T > $O/pmc_$T.txt 2>&1 || echo "pmc $T failed"
+  tail -3 $O/pmc_$T.txt
 done
 fi
