@@ -232,6 +232,7 @@ class Config4:
         if self.wide:
             self.kernel_names["k_resample"] = "k_resample<int16 wideband, mix>"
         if self.group:
+            self.beside_kernels = ("k_group_replay",)      # the state machine replays on a side stream, beside demodulateBurst
             self.kernel_names.update({"k_rach_corr": "k_rach_front_rx", "k_rach_peak": "k_rach_peak2+k_rach_fast_rx(list)"})
             self.kernel_alg.update({"k_rach_corr": 4 * 236 + 8 * 25 + 16 + 17, "k_rach_peak": 8 * 25 + 16 + 17, "k_group_replay": 16 + 4 + 1 + 8})
         if self.fused:
@@ -648,7 +649,11 @@ def main():
     units = wl.units_per_step()
     value = world * units * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
-    dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
+    # the dominant DATA kernel: a workload may name kernels that are latency chains running beside the data path (config 4's
+    # k_group_replay: two waves on a side stream, a few bytes per burst) -- they are listed in kernels_ms, not priced against HBM
+    beside = getattr(wl, "beside_kernels", ())
+    cand = {k: v for k, v in prof.items() if k not in beside} or prof
+    dom = max(cand.items(), key=lambda kv: kv[1][0]) if cand else (None, (0.0, 0))
     roof = None
     if dom[0]:
         avg_ms = dom[1][0] / max(dom[1][1], 1)
@@ -667,6 +672,8 @@ def main():
                 "pipeline_achieved": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9, 1),
                 "pipeline_frac": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernels_ms": {wl.kernel_names.get(k, k): round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}}
+        if any(k in prof for k in beside):
+            roof["beside_the_data_path"] = {wl.kernel_names.get(k, k): round(prof[k][0] / max(prof[k][1], 1), 4) for k in beside if k in prof}
     roof_fresh = None
     if prof_fresh and dom[0] in prof_fresh:
         # the same kernel on inputs it has not seen a step ago (three batches in rotation, 1 GB > the 256 MB memory-side cache)
