@@ -62,7 +62,11 @@ typedef struct {
   const float *d_toa;          /* [n_rows] TOA in samples                                                                   */
   const float *d_avgpwr;       /* [n_rows] energyDetect's avgPwr                                                            */
   const double *d_threshold;   /* [n_rows] mEnergyThreshold after the burst                                                 */
-  const float *d_soft;         /* [n_rows][soft_stride]: the SoftVector's first 148 values; zeros where d_valid is 0        */
+  const float *d_soft;         /* [n_rows][soft_stride]: the SoftVector's first 148 values WHERE d_valid IS SET.  Elsewhere
+                                * unspecified: zeros, or -- demodulating leg, large calls, where the state machine replays
+                                * beside the demodulator -- the demodulated burst of a row the stateless detector flagged
+                                * and the machine then did not accept (energy gate).  d_valid decides, as the return
+                                * value of pullRadioVector does.                                                          */
   int soft_stride;
 } trxsig_trxgroup_result;
 
