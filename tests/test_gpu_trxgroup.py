@@ -55,7 +55,7 @@ def configure(ctl, a):
     return r
 
 
-def build_cells(sps, S, n_slots, fn0, tn0, seed):
+def build_cells(sps, S, n_slots, fn0, tn0, seed, quiet_slots=(700, 1200)):
     """The received bursts, [n_slots][S][CELL] complex64, and each cell's expected correlation type."""
     rng = np.random.default_rng(seed)
     cell = CELL_SYM * sps
@@ -81,7 +81,7 @@ def build_cells(sps, S, n_slots, fn0, tn0, seed):
         tn = (tn0 + t) % 8
         fn = (fn0 + (tn0 + t) // 8) % tm.HYPERFRAME
         n = (156 + (tn % 4 == 0)) * sps
-        quiet = 700 <= t < 1200                                          # > 50 frames of silence: the thresholds decay
+        quiet = quiet_slots[0] <= t < quiet_slots[1]                     # > 50 frames of silence: the thresholds decay
         for a in range(S):
             m.chan_type = chan[a]
             ct = m.expected_corr_type(tn, fn)
@@ -186,6 +186,37 @@ def test_group_equals_single_objects_and_model(pkg, sps, leg, frames):
     seen = check_against("model", lambda a, b, tn, fn: models[a].pull_radio_vector(b, tn, fn), ctype, x, sps, out, arfcns, fn0, tn0,
                          lambda a: models[a].energy_threshold)
     assert seen["tsc"] > 1000 and seen["rach"] > 100, seen
+
+
+@pytest.mark.parametrize("tn0", [0, 5])
+def test_group_across_the_hyperframe_wrap(pkg, tn0):
+    """The frame number wraps (GSM::Time, hyperframe 2,715,648) in the middle of the run, with a 60-frame silence across it: the
+    replay's frame difference to prevFalseDetectionTime is carried from slot to slot (k_group_replay_lean) and must wrap,
+    restart at every false detection and trigger the quiet decrements exactly where FNDelta does -- thresholds, verdicts and
+    soft bits against independent single-burst objects and the CPU model, calls that start on and off a frame boundary."""
+    sps, leg, S, frames = 4, 1, 32, 80
+    fn0 = tm.HYPERFRAME - 30
+    n_slots = 8 * frames
+    x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=777 + tn0, quiet_slots=(80, 560))
+    out, responses, final_thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=(5, 16, 1, 240, 33, 8))
+    thr = out["threshold"][~np.isnan(out["threshold"])]
+    assert thr.min() < 245 and thr.max() > 255
+    objs = [pkg.TrxHost(sps, 0, start=(fn0, tn0), tsc_leg=leg) for _ in range(S)]
+    for a in range(S):
+        assert configure(objs[a].control, a) == responses[a]
+    seen = check_against("single", lambda a, b, tn, fn: objs[a].pull_radio_vector(b, tn, fn), ctype, x, sps, out, range(S), fn0, tn0,
+                         lambda a: objs[a].energy_threshold)
+    assert seen["tsc"] > 300 and seen["none"] > 1000, seen
+    assert np.array_equal(final_thr, np.array([o.energy_threshold for o in objs]))
+    for o in objs:
+        o.close()
+    o = oraclebind.Oracle(sps)
+    arfcns = range(0, S, 3)
+    models = {a: tm.TransceiverModel(o, start=(fn0, tn0), need_dfe=False) for a in arfcns}
+    for a in arfcns:
+        assert configure(models[a].control, a) == responses[a]
+    check_against("model", lambda a, b, tn, fn: models[a].pull_radio_vector(b, tn, fn), ctype, x, sps, out, arfcns, fn0, tn0,
+                  lambda a: models[a].energy_threshold)
 
 
 def test_reconfiguration_and_limits(pkg):
