@@ -536,7 +536,10 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
   //       corr[M-12..M+11] (+2 zero slots).
   constexpr int PWN = 50 * SPS + 8;                        // 107 sps - 57 sps + 1 terms, three candidate peaks
   static_assert(Q::ZPAD <= Q::XPAD, "Z is written over X");
-  constexpr int SIDE = PWN + 2 * 64 + 64 + 2 * 26;
+  // (SPLIT: X is dead once the exact neighbourhood is known, and PWw is only written after that -- it takes X's place, and a
+  //  paired workgroup needs 15.2 KB instead of 16.9: ten workgroups = 20 waves per CU instead of nine = 18)
+  constexpr int PWS = SPLIT ? 0 : PWN;                     // floats of `side` that PWw takes
+  constexpr int SIDE = PWS + 2 * 64 + 64 + 2 * 26;
   __shared__ __attribute__((aligned(16))) cx xs[NW][Q::XPAD];
   __shared__ __attribute__((aligned(16))) float side_[NW][SIDE];
   __shared__ int pinfo[NW][4];                             // NW = 2: {can share the exact pass, lags listed, N}
@@ -577,10 +580,10 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
   }
   cx *X = xs[wave];
   cx *Z = xs[wave];                                        // the same storage, at different times
-  float *PWw = side;
-  cx *const exv_ = reinterpret_cast<cx *>(side + PWN);
-  int *const exl_ = reinterpret_cast<int *>(side + PWN + 128);
-  cx *const nb_ = reinterpret_cast<cx *>(side + PWN + 192);
+  float *PWw = SPLIT ? reinterpret_cast<float *>(xs[wave]) : side;
+  cx *const exv_ = reinterpret_cast<cx *>(side + PWS);
+  int *const exl_ = reinterpret_cast<int *>(side + PWS + 128);
+  cx *const nb_ = reinterpret_cast<cx *>(side + PWS + 192);
   const cx *rseq = T->rach;
 
   float ex = 0.0f;
@@ -764,11 +767,11 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
     if (NW == 2 && paired) {
       if (wave == 0) {                                     // both bursts' lags, 32 lanes each
         const int h = lane >> 5, l = lane & 31;
-        const int *LGh = reinterpret_cast<const int *>(side_[h] + PWN + 128);
+        const int *LGh = reinterpret_cast<const int *>(side_[h] + PWS + 128);
         const int th = l < pinfo[h][1] ? LGh[l] : -1;
         cx vh = mk(0, 0);
         if (th >= 0 && th < pinfo[h][2]) vh = rach_exact_lag<SPS>(xs[h], rseq, th);
-        reinterpret_cast<cx *>(side_[h] + PWN)[l] = vh;
+        reinterpret_cast<cx *>(side_[h] + PWS)[l] = vh;
       }
       __syncthreads();
       if (valid) v = exv_[lane];                           // (valid: lane < nl <= 32)
