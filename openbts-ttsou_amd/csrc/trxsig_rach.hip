@@ -539,7 +539,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
   // (SPLIT: X is dead once the exact neighbourhood is known, and PWw is only written after that -- it takes X's place, and a
   //  paired workgroup needs 15.2 KB instead of 16.9: ten workgroups = 20 waves per CU instead of nine = 18)
   constexpr int PWS = SPLIT ? 0 : PWN;                     // floats of `side` that PWw takes
-  constexpr int SIDE = PWS + 2 * 64 + 64 + 2 * 26;
+  constexpr int SIDE = PWS + 2 * 64 + 64;                  // (nb takes exl's place: the lag list is dead once M is known)
   __shared__ __attribute__((aligned(16))) cx xs[NW][Q::XPAD];
   __shared__ __attribute__((aligned(16))) float side_[NW][SIDE];
   __shared__ int pinfo[NW][4];                             // NW = 2: {can share the exact pass, lags listed, N}
@@ -583,7 +583,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
   float *PWw = SPLIT ? reinterpret_cast<float *>(xs[wave]) : side;
   cx *const exv_ = reinterpret_cast<cx *>(side + PWS);
   int *const exl_ = reinterpret_cast<int *>(side + PWS + 128);
-  cx *const nb_ = reinterpret_cast<cx *>(side + PWS + 192);
+  cx *const nb_ = reinterpret_cast<cx *>(side + PWS + 128);   // 26 complex over exl_'s 64 ints
   const cx *rseq = T->rach;
 
   float ex = 0.0f;
@@ -939,6 +939,8 @@ __global__ __launch_bounds__(64) void k_rach_fast_rx(const TrxTables *__restrict
 constexpr int kRachNW = TRX_RACH_PAIR ? 2 : 1;
 // steps 1-2 of k_rach_fast (approximate correlation, exact contenders and neighbourhood) for every burst
 template <int SPS>
+// (81 VGPRs: five waves per SIMD, which is what ten 14.8 KB workgroups per CU need.  Forced to 80 for a sixth -- an eleventh
+//  workgroup would fit the LDS -- the compiler spills 3 VGPRs and 11 SGPRs and the kernel takes 291 instead of 281 us.)
 __global__ __launch_bounds__(64 * kRachNW) void k_rach_front(const TrxTables *__restrict__ T, const cx *__restrict__ samples,
                                                     const int32_t *__restrict__ offset,
                                                     const int32_t *__restrict__ length, int B, float energy_thresh, float amp_err,
