@@ -431,41 +431,42 @@ constexpr bool rach_steer_used() {
     if (J - CJ * c >= 0 && J - CJ * c <= 40) return true;
   return false;
 }
-// groups of eight j: the next group's reads are issued before this group's additions (double buffer), the
+// groups of TRX_RACH_STEER_GROUP j: the next group's reads are issued before this group's additions (double buffer), the
 // accumulators are pinned after each group (hipcc otherwise sinks the accumulation chains below all 185 reads: 256 VGPRs)
-template <int SPS, int NCL, int J0>
-__device__ __forceinline__ void rach_steer_load(const cx *Zl, cx (&z)[8]) {
-  constexpr int JMAX = (64 / SPS) * (NCL - 1) + 40;
-#pragma unroll
-  for (int q = 0; q < 8; q++) z[q] = mk(0, 0);
-  if constexpr (J0 + 0 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 0>()) z[0] = Zl[SPS * (J0 + 0)]; }
-  if constexpr (J0 + 1 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 1>()) z[1] = Zl[SPS * (J0 + 1)]; }
-  if constexpr (J0 + 2 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 2>()) z[2] = Zl[SPS * (J0 + 2)]; }
-  if constexpr (J0 + 3 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 3>()) z[3] = Zl[SPS * (J0 + 3)]; }
-  if constexpr (J0 + 4 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 4>()) z[4] = Zl[SPS * (J0 + 4)]; }
-  if constexpr (J0 + 5 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 5>()) z[5] = Zl[SPS * (J0 + 5)]; }
-  if constexpr (J0 + 6 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 6>()) z[6] = Zl[SPS * (J0 + 6)]; }
-  if constexpr (J0 + 7 <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + 7>()) z[7] = Zl[SPS * (J0 + 7)]; }
-}
+#ifndef TRX_RACH_STEER_GROUP
+#define TRX_RACH_STEER_GROUP 8
+#endif
+constexpr int kSteerG = TRX_RACH_STEER_GROUP;
 template <int SPS, int NCL, int J0, int Q>
-__device__ __forceinline__ void rach_steer_group(const cx (&z)[8], float (&ar)[NCL], float (&ai)[NCL]) {
-  if constexpr (Q < 8) {
+__device__ __forceinline__ void rach_steer_load1(const cx *Zl, cx (&z)[kSteerG]) {
+  constexpr int JMAX = (64 / SPS) * (NCL - 1) + 40;
+  if constexpr (Q < kSteerG) {
+    z[Q] = mk(0, 0);
+    if constexpr (J0 + Q <= JMAX) { if constexpr (rach_steer_used<SPS, NCL, J0 + Q>()) z[Q] = Zl[SPS * (J0 + Q)]; }
+    rach_steer_load1<SPS, NCL, J0, Q + 1>(Zl, z);
+  }
+}
+template <int SPS, int NCL, int J0>
+__device__ __forceinline__ void rach_steer_load(const cx *Zl, cx (&z)[kSteerG]) { rach_steer_load1<SPS, NCL, J0, 0>(Zl, z); }
+template <int SPS, int NCL, int J0, int Q>
+__device__ __forceinline__ void rach_steer_group(const cx (&z)[kSteerG], float (&ar)[NCL], float (&ai)[NCL]) {
+  if constexpr (Q < kSteerG) {
     rach_steer_acc<SPS, NCL, J0 + Q, 0>(z[Q], ar, ai);     // (k outside 0..40 for every c: nothing happens)
     rach_steer_group<SPS, NCL, J0, Q + 1>(z, ar, ai);
   }
 }
 template <int SPS, int NCL, int J0>
-__device__ __forceinline__ void rach_steer(const cx *Zl, const cx (&zc)[8], float (&ar)[NCL], float (&ai)[NCL]) {
+__device__ __forceinline__ void rach_steer(const cx *Zl, const cx (&zc)[kSteerG], float (&ar)[NCL], float (&ai)[NCL]) {
   constexpr int JMAX = (64 / SPS) * (NCL - 1) + 40;
   if constexpr (J0 <= JMAX) {
-    cx zn[8];
-    rach_steer_load<SPS, NCL, J0 + 8>(Zl, zn);
+    cx zn[kSteerG];
+    rach_steer_load<SPS, NCL, J0 + kSteerG>(Zl, zn);
     __builtin_amdgcn_sched_barrier(0);
     rach_steer_group<SPS, NCL, J0, 0>(zc, ar, ai);
 #pragma unroll
     for (int c = 0; c < NCL; c++) { asm volatile("" : "+v"(ar[c])); asm volatile("" : "+v"(ai[c])); }
     __builtin_amdgcn_sched_barrier(0);
-    rach_steer<SPS, NCL, J0 + 8>(Zl, zn, ar, ai);
+    rach_steer<SPS, NCL, J0 + kSteerG>(Zl, zn, ar, ai);
   }
 }
 
@@ -661,7 +662,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
     float ar[R::NCL], ai[R::NCL];
 #pragma unroll
     for (int c = 0; c < R::NCL; c++) { ar[c] = 0.0f; ai[c] = 0.0f; }
-    cx z0[8];
+    cx z0[kSteerG];
     rach_steer_load<SPS, R::NCL, 0>(Z + lane, z0);
     rach_steer<SPS, R::NCL, 0>(Z + lane, z0, ar, ai);
     // ---- the burst again (L2 by now) over its filtered copy: everything below works on X ----
