@@ -376,6 +376,26 @@ class Config4:
     def fresh_inputs(self, steps):
         return None
 
+    def pipelined(self, steps):
+        """Side measurement (never `value`): the same steps with trxsig_trxgroup_set_pipelined -- a step returns without waiting
+        for its state machine, which replays on the group's side stream while the next step's detectors run."""
+        if not self.group:
+            return None
+        import torch
+        self.grp.set_pipelined(True)
+        for _ in range(max(steps // 10, 5)):
+            self.step()
+        self.grp.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.grp.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        self.grp.set_pipelined(False)
+        return {"value": round(self.units_per_step() * steps / dt / 1e6, 3), "unit": "Mbursts/s", "ms_per_step": round(dt / steps * 1e3, 4),
+                "steps": steps, "what": "trxsig_trxgroup_set_pipelined(1): d_valid / d_threshold of step i are complete after "
+                                        "trxsig_trxgroup_sync, its replay overlaps step i+1's detectors; same values (tests/test_gpu_trxgroup.py)"}
+
     def cpu_baseline(self, check):
         """The oracle's polyphaseResampleVector + analyzeTrafficBurst + demodulateBurst chain on ONE host core over a bounded
         sample of the streams (chunk by chunk with history, as RadioInterface::pullBuffer)."""
@@ -643,6 +663,7 @@ def main():
     prof_fresh = None
     if fresh is not None and "prof" in fresh:
         prof_fresh = fresh.pop("prof")
+    piped = wl.pipelined(args.steps) if (world == 1 and hasattr(wl, "pipelined")) else None
     sanity = wl.sanity()
     if rank != 0:
         return
@@ -700,6 +721,8 @@ def main():
                         "note": "`value` is the first repetition (the contract's K steps); the others follow it back to back"},
     }
     out.update(sanity)
+    if piped:
+        out["pipelined"] = piped
     if args.rehearse_one_gpu:
         out["rehearsal"] = "all %d ranks shared cuda:0 (gloo collectives): launch-path check, not a scaling number" % world
     if not args.no_cpu_baseline and world == 1:

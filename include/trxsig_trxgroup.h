@@ -99,6 +99,16 @@ int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft,
 int trxsig_trxgroup_pull_host(trxsig_trxgroup *g, const trxsig_c32 *h_samples, int64_t slot_stride, int64_t arfcn_stride,
                               int burst_len, int fn, int tn, int n_slots);
 
+/* Pipelined mode (off by default; demodulating leg): a large pull (the ones that replay the state machine on the group's side
+ * stream, see trxsig_trxgroup_pull) RETURNS WITHOUT JOINING that stream, so the machine of call i replays while call i+1's
+ * detectors run -- the replay is a latency chain of two waves per 128 ARFCNs and otherwise ends every call with the GPU idle.
+ * What that changes for the caller: d_flags, d_amp, d_toa, d_avgpwr and d_soft of a result are ordered on the context's stream
+ * as always; d_valid, d_threshold and the group's own state are complete on that stream only after trxsig_trxgroup_sync (or
+ * trxsig_trxgroup_collect / _energy_threshold, which call it, or any later pull that is not pipelined).  Results live in one of
+ * two workspace sets: a result stays valid until the SECOND pull after its own.  Values are the same in either mode. */
+int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on);
+/* the context's stream waits for every replay still in flight on the side stream (no host wait) */
+int trxsig_trxgroup_sync(trxsig_trxgroup *g);
 /* mEnergyThreshold of one ARFCN now (synchronises) */
 int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr);
 

@@ -661,6 +661,8 @@ class TrxGroup:
         L.trxsig_trxgroup_pull_rxfe.argtypes = [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(TrxGroupResult)]
         L.trxsig_trxgroup_collect.argtypes = [vp, vp, vp, vp, vp, vp]
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
+        L.trxsig_trxgroup_set_pipelined.argtypes = [vp, i32]
+        L.trxsig_trxgroup_sync.argtypes = [vp]
         self.S = n_arfcn
         self.h = vp()
         rc = L.trxsig_trxgroup_create(C.byref(self.h), ctx.h, n_arfcn, tsc_leg, start[0], start[1])
@@ -728,6 +730,13 @@ class TrxGroup:
         sh = (self.n_slots, self.S)
         return dict(valid=valid.reshape(sh).astype(bool), soft=None if sb is None else sb.reshape(sh + (148,)), rssi=rssi.reshape(sh),
                     timing=timing.reshape(sh), threshold=thr.reshape(sh))
+
+    def set_pipelined(self, on=True):
+        """Large pulls return without joining the side stream the state machine replays on (see trxsig_trxgroup.h)."""
+        self._chk(self.L.trxsig_trxgroup_set_pipelined(self.h, 1 if on else 0), "trxsig_trxgroup_set_pipelined")
+
+    def sync(self):
+        self._chk(self.L.trxsig_trxgroup_sync(self.h), "trxsig_trxgroup_sync")
 
     def energy_threshold(self, arfcn):
         v = C.c_double()

@@ -68,14 +68,27 @@ struct trxsig_trxgroup {
   // from and joined back into the context's stream inside every pull
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // per-call workspace
-  DevBuf<int32_t> rowmap, seg, off, len, tap_ix;
-  DevBuf<float4> packed;
-  DevBuf<uint8_t> flags, gate, ev, ev_flags;
-  DevBuf<trx_c32> amp, ev_amp, w_tab, b_tab, in;
-  DevBuf<float> toa, avgpwr, toa_eq, snr, ev_toa, ev_toaeq, soft, chan_off;
-  DevBuf<double> thr_after, thr_g;
-  DevBuf<uint8_t> succ_g;
+  // per-call workspace: two sets, so that in pipelined mode (trxsig_trxgroup_set_pipelined) the state machine can still be
+  // replaying call i's rows on the side stream while call i+1's detectors fill the other set
+  struct Work {
+    DevBuf<int32_t> rowmap, seg, off, len, tap_ix;
+    DevBuf<float4> packed;
+    DevBuf<uint8_t> flags, gate, ev, ev_flags, succ_g;
+    DevBuf<trx_c32> amp, ev_amp;
+    DevBuf<float> toa, avgpwr, toa_eq, snr, ev_toa, ev_toaeq, soft;
+    DevBuf<double> thr_after, thr_g;
+    hipEvent_t done = nullptr;                              // recorded on the side stream behind the set's last replay
+    bool in_flight = false;                                 // ... which the context's stream has not waited for yet
+    void release() {
+      rowmap.release(); seg.release(); off.release(); len.release(); tap_ix.release(); packed.release(); flags.release(); gate.release();
+      ev.release(); ev_flags.release(); succ_g.release(); amp.release(); ev_amp.release(); toa.release(); avgpwr.release(); toa_eq.release();
+      snr.release(); ev_toa.release(); ev_toaeq.release(); soft.release(); thr_after.release(); thr_g.release();
+    }
+  } wk[2];
+  int cur = 0;                                              // the set of the last pull
+  bool pipelined = false;
+  DevBuf<trx_c32> w_tab, b_tab, in;
+  DevBuf<float> chan_off;
   std::vector<int32_t> h_seg;
   // the last pull
   int n_slots = 0, n_rows = 0, n_tsc_rows = 0;
@@ -160,7 +173,9 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
       g->w_tab.need(S8 * 7, nullptr) != hipSuccess || g->b_tab.need(S8 * 5, nullptr) != hipSuccess || g->chan_off.need(S8, nullptr) != hipSuccess ||
       hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->wk[0].done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->wk[1].done, hipEventDisableTiming) != hipSuccess) {
     trxsig_trxgroup_destroy(g);
     return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);
   }
@@ -177,10 +192,8 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
-    g->rowmap.release(); g->seg.release(); g->off.release(); g->len.release(); g->tap_ix.release(); g->packed.release();
-    g->flags.release(); g->gate.release(); g->ev.release(); g->ev_flags.release(); g->amp.release(); g->ev_amp.release();
-    g->w_tab.release(); g->b_tab.release(); g->in.release(); g->toa.release(); g->avgpwr.release(); g->toa_eq.release();
-    g->snr.release(); g->ev_toa.release(); g->ev_toaeq.release(); g->soft.release(); g->chan_off.release(); g->thr_after.release(); g->thr_g.release(); g->succ_g.release();
+    for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
+    g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
   }
   delete g;
 }
@@ -219,6 +232,16 @@ struct PullSource {
   const TrxRxGen *gen = nullptr;
 };
 
+// every replay still in flight on the side stream (pipelined mode) is waited for by the context's stream
+int join_side(trxsig_trxgroup *g, hipStream_t st) {
+  for (int k = 0; k < 2; k++) {
+    if (!g->wk[k].in_flight) continue;
+    G_HIP(g, hipStreamWaitEvent(st, g->wk[k].done, 0));
+    g->wk[k].in_flight = false;
+  }
+  return TRXSIG_OK;
+}
+
 int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_slots, trxsig_trxgroup_result *res) {
   trxsig_ctx *c = g->c;
   const int S = g->S, sps = g->sps;
@@ -231,6 +254,14 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   g->have = false;
   if (g->dirty) G_LIB(derive_tables(g));
+  // the workspace set of this call: the other one than the last call's while that call may still be replaying (pipelined mode);
+  // whoever used this set last (two calls ago) is waited for before anything of it is overwritten
+  if (g->wk[g->cur].in_flight) g->cur ^= 1;
+  trxsig_trxgroup::Work &W = g->wk[g->cur];
+  if (W.in_flight) {
+    G_HIP(g, hipStreamWaitEvent(st, W.done, 0));
+    W.in_flight = false;
+  }
 
   // ---- expectedCorrType for every (slot, column): rows by class ----
   const int G = g->G;
@@ -263,26 +294,26 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   const size_t R = (size_t)(n_rows > 0 ? n_rows : 1), S8 = (size_t)S * 8;
 
   // ---- workspace (grow-only; an array that grows waits for the stream first) ----
-  G_HIP(g, g->rowmap.need((size_t)cells, st)); G_HIP(g, g->packed.need((size_t)cells, st)); G_HIP(g, g->seg.need((size_t)n_slots * G, st));
-  G_HIP(g, g->off.need(R, st)); G_HIP(g, g->len.need(R, st)); G_HIP(g, g->tap_ix.need(R, st));
-  G_HIP(g, g->flags.need(R, st)); G_HIP(g, g->gate.need(R, st)); G_HIP(g, g->ev.need(R, st)); G_HIP(g, g->ev_flags.need(R, st));
-  G_HIP(g, g->amp.need(R, st)); G_HIP(g, g->ev_amp.need(R, st));
-  G_HIP(g, g->toa.need(R, st)); G_HIP(g, g->avgpwr.need(R, st)); G_HIP(g, g->toa_eq.need(R, st)); G_HIP(g, g->snr.need(R, st));
-  G_HIP(g, g->ev_toa.need(R, st)); G_HIP(g, g->ev_toaeq.need(R, st)); G_HIP(g, g->thr_after.need(R, st));
-  G_HIP(g, g->soft.need(R * kSoft, st));
+  G_HIP(g, W.rowmap.need((size_t)cells, st)); G_HIP(g, W.packed.need((size_t)cells, st)); G_HIP(g, W.seg.need((size_t)n_slots * G, st));
+  G_HIP(g, W.off.need(R, st)); G_HIP(g, W.len.need(R, st)); G_HIP(g, W.tap_ix.need(R, st));
+  G_HIP(g, W.flags.need(R, st)); G_HIP(g, W.gate.need(R, st)); G_HIP(g, W.ev.need(R, st)); G_HIP(g, W.ev_flags.need(R, st));
+  G_HIP(g, W.amp.need(R, st)); G_HIP(g, W.ev_amp.need(R, st));
+  G_HIP(g, W.toa.need(R, st)); G_HIP(g, W.avgpwr.need(R, st)); G_HIP(g, W.toa_eq.need(R, st)); G_HIP(g, W.snr.need(R, st));
+  G_HIP(g, W.ev_toa.need(R, st)); G_HIP(g, W.ev_toaeq.need(R, st)); G_HIP(g, W.thr_after.need(R, st));
+  G_HIP(g, W.soft.need(R * kSoft, st));
   if (g->leg != TRXSIG_TSCLEG_EQUALIZE) {
     const size_t ns = trx_group_replay_scratch(S, n_slots);
-    G_HIP(g, g->thr_g.need(ns, st)); G_HIP(g, g->succ_g.need(ns, st));
+    G_HIP(g, W.thr_g.need(ns, st)); G_HIP(g, W.succ_g.need(ns, st));
   }
   G_HIP(g, g->w_tab.need((S8 + R) * 7, st, S8 * 7)); G_HIP(g, g->b_tab.need((S8 + R) * 5, st, S8 * 5));
   G_HIP(g, g->chan_off.need(S8 + R, st, S8));
 
   // (pageable source: the copy has consumed h_seg when the call returns)
-  G_HIP(g, hipMemcpyAsync(g->seg.p, g->h_seg.data(), sizeof(int32_t) * g->h_seg.size(), hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(W.seg.p, g->h_seg.data(), sizeof(int32_t) * g->h_seg.size(), hipMemcpyHostToDevice, st));
   TrxGroupExpand ex = {};
   ex.S = S; ex.n_slots = n_slots; ex.tn0 = tn; ex.sps = sps; ex.fixed_len = burst_len; ex.G = G;
   ex.slot_stride = src.slot_stride; ex.arfcn_stride = src.arfcn_stride; ex.base = 0; ex.rx_nb = src.gen ? src.gen->nb : 0;
-  ex.gid = g->d_gid; ex.pos = g->d_pos; ex.seg_base = g->seg.p; ex.rowmap = g->rowmap.p; ex.off = g->off.p; ex.len = g->len.p;
+  ex.gid = g->d_gid; ex.pos = g->d_pos; ex.seg_base = W.seg.p; ex.rowmap = W.rowmap.p; ex.off = W.off.p; ex.len = W.len.p;
   G_HIP(g, trx_launch_group_expand(st, ex));
 
   // ---- the stateless detectors, a launch per class in use; thresholds 3.0 / 5.0 (:331, 363), energy gate off ----
@@ -291,27 +322,27 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
     const int b0 = base[k];
     if (src.gen) {                                          // the detectors compute their samples from the raw stream; off = the selection
       TrxRxGen gen = *src.gen;
-      gen.sel = g->off.p + b0;
+      gen.sel = W.off.p + b0;
       if (k < TRXG_CLASS_RACH)
-        G_LIB(trx_ctx_rx_normal(c, gen, count[k], k, 3.0f, -1.0f, g->flags.p + b0, (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0,
-                                g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
+        G_LIB(trx_ctx_rx_normal(c, gen, count[k], k, 3.0f, -1.0f, W.flags.p + b0, (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0,
+                                W.avgpwr.p + b0, nullptr, nullptr, 0, 0));
       else
-        G_LIB(trx_ctx_rx_rach(c, gen, g->len.p + b0, count[k], 5.0f, -1.0f, g->flags.p + b0, (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0,
-                              g->avgpwr.p + b0));
+        G_LIB(trx_ctx_rx_rach(c, gen, W.len.p + b0, count[k], 5.0f, -1.0f, W.flags.p + b0, (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0,
+                              W.avgpwr.p + b0));
     } else if (k < TRXG_CLASS_RACH)
-      G_LIB(trxsig_detect_demod_normal_batch(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], k, 3.0f, -1.0f, g->flags.p + b0,
-                                             (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0, g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
+      G_LIB(trxsig_detect_demod_normal_batch(c, d_samples, W.off.p + b0, W.len.p + b0, count[k], k, 3.0f, -1.0f, W.flags.p + b0,
+                                             (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0, W.avgpwr.p + b0, nullptr, nullptr, 0, 0));
     else
-      G_LIB(trxsig_detect_demod_rach_batch(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], 5.0f, -1.0f, g->flags.p + b0,
-                                           (trxsig_c32 *)g->amp.p + b0, g->toa.p + b0, g->avgpwr.p + b0, nullptr, nullptr, 0, 0));
+      G_LIB(trxsig_detect_demod_rach_batch(c, d_samples, W.off.p + b0, W.len.p + b0, count[k], 5.0f, -1.0f, W.flags.p + b0,
+                                           (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0, W.avgpwr.p + b0, nullptr, nullptr, 0, 0));
   }
 
   // ---- the state machine, a lane per ARFCN ----
   const bool equalize = g->leg == TRXSIG_TSCLEG_EQUALIZE;
   TrxGroupReplay rp = {};
   rp.S = S; rp.n_slots = n_slots; rp.fn0 = fn; rp.tn0 = tn; rp.equalize = equalize; rp.n_tsc_rows = n_tsc;
-  rp.rowmap = g->rowmap.p; rp.flags = g->flags.p; rp.amp = g->amp.p; rp.avgpwr = g->avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
-  rp.gate = g->gate.p; rp.ev = g->ev.p; rp.tap_ix = g->tap_ix.p; rp.snr = g->snr.p; rp.thr_after = g->thr_after.p;
+  rp.rowmap = W.rowmap.p; rp.flags = W.flags.p; rp.amp = W.amp.p; rp.avgpwr = W.avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
+  rp.gate = W.gate.p; rp.ev = W.ev.p; rp.tap_ix = W.tap_ix.p; rp.snr = W.snr.p; rp.thr_after = W.thr_after.p;
   // Demodulating leg: demodulateBurst needs nothing the state machine decides except WHETHER a burst is handed up, and every
   // burst the machine accepts is one the stateless detector flagged -- so the rows the detectors flagged are demodulated on
   // the context's stream while the machine replays on the side stream (two waves for ~0.1 us per slot: it fills no CU), and
@@ -320,14 +351,22 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   // instead of 48 us with the fork, 65,536 take 229 instead of 281)
   const bool lean = !equalize;
   const bool beside = lean && n_rows >= kBesideRows;
+  const bool piped = beside && g->pipelined;                // the join is left to the next call but one / trxsig_trxgroup_sync
+  if (!piped) G_LIB(join_side(g, st));                      // (state order: nothing replays on this stream before the side stream is done)
+  // (an error return between the fork and the join must not leave the side stream working on this call's arrays)
+  struct SideGuard {
+    hipStream_t s = nullptr;
+    ~SideGuard() { if (s) (void)hipStreamSynchronize(s); }
+  } side_guard;
   if (beside) {
     G_HIP(g, hipEventRecord(g->ev_fork, st));
     G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
+    side_guard.s = g->side;
   }
-  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, g->packed.p, lean ? g->thr_g.p : nullptr, lean ? g->succ_g.p : nullptr,
+  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, W.packed.p, lean ? W.thr_g.p : nullptr, lean ? W.succ_g.p : nullptr,
                                    trx_ctx_profiler(c)));
-  if (beside) G_HIP(g, hipEventRecord(g->ev_join, g->side));
-  const uint8_t *demod_gate = beside ? g->flags.p : g->gate.p;   // (gate holds TRXSIG_F_DETECT or 0: the same mask serves both)
+  if (beside) G_HIP(g, hipEventRecord(piped ? W.done : g->ev_join, g->side));
+  const uint8_t *demod_gate = beside ? W.flags.p : W.gate.p;   // (gate holds TRXSIG_F_DETECT or 0: the same mask serves both)
 
   // ---- what comes back as a SoftVector ----
   if (n_tsc > 0) {
@@ -335,33 +374,39 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
       for (int k = 0; k < TRXG_CLASS_RACH; k++) {           // :341-349 for the rows the replay marked
         if (!count[k]) continue;
         const int b0 = base[k];
-        G_LIB(trx_ctx_group_estimate(c, d_samples, g->off.p + b0, g->len.p + b0, count[k], k, g->ev.p + b0, g->snr.p + b0, g->ev_flags.p + b0,
-                                     (trxsig_c32 *)g->ev_amp.p + b0, g->ev_toa.p + b0, g->ev_toaeq.p + b0, g->chan_off.p + S8 + b0,
+        G_LIB(trx_ctx_group_estimate(c, d_samples, W.off.p + b0, W.len.p + b0, count[k], k, W.ev.p + b0, W.snr.p + b0, W.ev_flags.p + b0,
+                                     (trxsig_c32 *)W.ev_amp.p + b0, W.ev_toa.p + b0, W.ev_toaeq.p + b0, g->chan_off.p + S8 + b0,
                                      (trxsig_c32 *)g->w_tab.p + (S8 + b0) * 7, (trxsig_c32 *)g->b_tab.p + (S8 + b0) * 5));
       }
-      G_HIP(g, trx_launch_group_toa_eq(st, n_tsc, g->gate.p, g->toa.p, g->tap_ix.p, g->chan_off.p, g->toa_eq.p));
-      G_LIB(trx_ctx_group_equalize(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa_eq.p, g->gate.p,
-                                   (const trxsig_c32 *)g->w_tab.p, (const trxsig_c32 *)g->b_tab.p, g->tap_ix.p, g->soft.p, kSoft, kSoft));
+      G_HIP(g, trx_launch_group_toa_eq(st, n_tsc, W.gate.p, W.toa.p, W.tap_ix.p, g->chan_off.p, W.toa_eq.p));
+      G_LIB(trx_ctx_group_equalize(c, d_samples, W.off.p, W.len.p, n_tsc, (const trxsig_c32 *)W.amp.p, W.toa_eq.p, W.gate.p,
+                                   (const trxsig_c32 *)g->w_tab.p, (const trxsig_c32 *)g->b_tab.p, W.tap_ix.p, W.soft.p, kSoft, kSoft));
     } else if (!src.gen) {
-      G_LIB(trx_ctx_demod_masked(c, d_samples, g->off.p, g->len.p, n_tsc, (const trxsig_c32 *)g->amp.p, g->toa.p, demod_gate, TRXSIG_F_DETECT,
-                                 g->soft.p, kSoft, kSoft));
+      G_LIB(trx_ctx_demod_masked(c, d_samples, W.off.p, W.len.p, n_tsc, (const trxsig_c32 *)W.amp.p, W.toa.p, demod_gate, TRXSIG_F_DETECT,
+                                 W.soft.p, kSoft, kSoft));
     }
   }
   if (src.gen) {                                            // normal and access bursts alike: demodulateBurst on every gated row
     TrxRxGen gen = *src.gen;
-    gen.sel = g->off.p;
-    G_LIB(trx_ctx_rx_demod(c, gen, n_rows, (const trxsig_c32 *)g->amp.p, g->toa.p, demod_gate, TRXSIG_F_DETECT, g->soft.p, kSoft, kSoft));
+    gen.sel = W.off.p;
+    G_LIB(trx_ctx_rx_demod(c, gen, n_rows, (const trxsig_c32 *)W.amp.p, W.toa.p, demod_gate, TRXSIG_F_DETECT, W.soft.p, kSoft, kSoft));
   } else if (n_rows > n_tsc)                                // :385-388
-    G_LIB(trx_ctx_demod_masked(c, d_samples, g->off.p + n_tsc, g->len.p + n_tsc, n_rows - n_tsc, (const trxsig_c32 *)g->amp.p + n_tsc,
-                               g->toa.p + n_tsc, demod_gate + n_tsc, TRXSIG_F_DETECT, g->soft.p + (size_t)n_tsc * kSoft, kSoft, kSoft));
-  if (beside) G_HIP(g, hipStreamWaitEvent(st, g->ev_join, 0));
+    G_LIB(trx_ctx_demod_masked(c, d_samples, W.off.p + n_tsc, W.len.p + n_tsc, n_rows - n_tsc, (const trxsig_c32 *)W.amp.p + n_tsc,
+                               W.toa.p + n_tsc, demod_gate + n_tsc, TRXSIG_F_DETECT, W.soft.p + (size_t)n_tsc * kSoft, kSoft, kSoft));
+  if (piped) {
+    W.in_flight = true;                                     // d_valid / d_threshold / the state: complete behind W.done
+    side_guard.s = nullptr;
+  } else if (beside) {
+    G_HIP(g, hipStreamWaitEvent(st, g->ev_join, 0));
+    side_guard.s = nullptr;                                 // joined: ordered on the context's stream from here on
+  }
   if (equalize) G_HIP(g, trx_launch_group_commit(st, S, g->d_state, g->w_tab.p, g->b_tab.p, g->chan_off.p));
 
   g->n_slots = n_slots; g->n_rows = n_rows; g->n_tsc_rows = n_tsc; g->have = true;
   if (res) {
     res->n_slots = n_slots; res->n_arfcn = S; res->n_rows = n_rows;
-    res->d_row = g->rowmap.p; res->d_valid = g->gate.p; res->d_flags = g->flags.p; res->d_amp = (const trxsig_c32 *)g->amp.p;
-    res->d_toa = g->toa.p; res->d_avgpwr = g->avgpwr.p; res->d_threshold = g->thr_after.p; res->d_soft = g->soft.p; res->soft_stride = kSoft;
+    res->d_row = W.rowmap.p; res->d_valid = W.gate.p; res->d_flags = W.flags.p; res->d_amp = (const trxsig_c32 *)W.amp.p;
+    res->d_toa = W.toa.p; res->d_avgpwr = W.avgpwr.p; res->d_threshold = W.thr_after.p; res->d_soft = W.soft.p; res->soft_stride = kSoft;
   }
   return TRXSIG_OK;
 }
@@ -415,19 +460,21 @@ int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft,
   if (!h_valid || !h_rssi || !h_timing) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_collect: bad argument", hipSuccess);
   Guard gd(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  G_LIB(join_side(g, st));
+  trxsig_trxgroup::Work &W = g->wk[g->cur];
   const size_t cells = (size_t)g->n_slots * g->S, R = (size_t)g->n_rows;
   std::vector<int32_t> row(cells);
   std::vector<uint8_t> gate(R);
   std::vector<trx_c32> amp(R);
   std::vector<float> toa(R), soft(h_soft ? R * kSoft : 0);
   std::vector<double> thr(h_threshold ? R : 0);
-  G_HIP(g, hipMemcpyAsync(row.data(), g->rowmap.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, st));
+  G_HIP(g, hipMemcpyAsync(row.data(), W.rowmap.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, st));
   if (R) {
-    G_HIP(g, hipMemcpyAsync(gate.data(), g->gate.p, R, hipMemcpyDeviceToHost, st));
-    G_HIP(g, hipMemcpyAsync(amp.data(), g->amp.p, sizeof(trx_c32) * R, hipMemcpyDeviceToHost, st));
-    G_HIP(g, hipMemcpyAsync(toa.data(), g->toa.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
-    if (h_soft) G_HIP(g, hipMemcpyAsync(soft.data(), g->soft.p, sizeof(float) * R * kSoft, hipMemcpyDeviceToHost, st));
-    if (h_threshold) G_HIP(g, hipMemcpyAsync(thr.data(), g->thr_after.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+    G_HIP(g, hipMemcpyAsync(gate.data(), W.gate.p, R, hipMemcpyDeviceToHost, st));
+    G_HIP(g, hipMemcpyAsync(amp.data(), W.amp.p, sizeof(trx_c32) * R, hipMemcpyDeviceToHost, st));
+    G_HIP(g, hipMemcpyAsync(toa.data(), W.toa.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+    if (h_soft) G_HIP(g, hipMemcpyAsync(soft.data(), W.soft.p, sizeof(float) * R * kSoft, hipMemcpyDeviceToHost, st));
+    if (h_threshold) G_HIP(g, hipMemcpyAsync(thr.data(), W.thr_after.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
   }
   G_HIP(g, hipStreamSynchronize(st));
   for (size_t i = 0; i < cells; i++) {
@@ -465,12 +512,29 @@ int trxsig_trxgroup_pull_host(trxsig_trxgroup *g, const trxsig_c32 *h_samples, i
   return trxsig_trxgroup_pull(g, (const trxsig_c32 *)g->in.p, slot_stride, arfcn_stride, burst_len, fn, tn, n_slots, nullptr);
 }
 
+int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on) {
+  if (!g) return TRXSIG_EINVAL;
+  if (g->leg != TRXSIG_TSCLEG_DEMOD && on)
+    return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_set_pipelined: the demodulating TSC leg only (the equalising leg needs the machine's events inside the call)", hipSuccess);
+  Guard gd(trxsig_device(g->c));
+  G_LIB(join_side(g, (hipStream_t)trxsig_get_stream(g->c)));
+  g->pipelined = on != 0;
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_sync(trxsig_trxgroup *g) {
+  if (!g) return TRXSIG_EINVAL;
+  Guard gd(trxsig_device(g->c));
+  return join_side(g, (hipStream_t)trxsig_get_stream(g->c));
+}
+
 int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr) {
   if (!g) return TRXSIG_EINVAL;
   if (arfcn < 0 || arfcn >= g->S || !thr) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_energy_threshold: bad argument", hipSuccess);
   Guard gd(trxsig_device(g->c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(g->c);
   TrxGroupArfcn a;
+  G_LIB(join_side(g, st));
   G_HIP(g, hipMemcpyAsync(&a, g->d_state + arfcn, sizeof a, hipMemcpyDeviceToHost, st));
   G_HIP(g, hipStreamSynchronize(st));
   *thr = a.thr;

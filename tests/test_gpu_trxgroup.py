@@ -102,11 +102,13 @@ def build_cells(sps, S, n_slots, fn0, tn0, seed, quiet_slots=(700, 1200)):
     return x, ctype
 
 
-def run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls):
+def run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, pipelined=False):
     import torch
     ctx = pkg.TrxSig(sps, 0)
     ctx.use_torch_stream()
     g = pkg.TrxGroup(ctx, S, tsc_leg=leg, start=(fn0, tn0))
+    if pipelined:
+        g.set_pipelined(True)
     cell = x.shape[2]
     out = dict(valid=np.zeros((n_slots, S), bool), soft=np.zeros((n_slots, S, 148), np.float32), rssi=np.zeros((n_slots, S), np.int32),
                timing=np.zeros((n_slots, S), np.int32), threshold=np.zeros((n_slots, S)))
@@ -217,6 +219,53 @@ def test_group_across_the_hyperframe_wrap(pkg, tn0):
         assert configure(models[a].control, a) == responses[a]
     check_against("model", lambda a, b, tn, fn: models[a].pull_radio_vector(b, tn, fn), ctype, x, sps, out, arfcns, fn0, tn0,
                   lambda a: models[a].energy_threshold)
+
+
+def test_pipelined_mode_gives_the_same(pkg):
+    """trxsig_trxgroup_set_pipelined: large pulls leave their replay running on the side stream while the next pull's detectors
+    fill the other workspace set.  Every output of every call (collected after each pull, which joins) equals the default mode's,
+    with large and small calls mixed (a small call replays on the context's stream and has to wait for the side stream first);
+    and two pipelined pulls in a row with nothing in between leave the FIRST one's result intact (two workspace sets)."""
+    import torch
+    sps, leg, S, frames, fn0, tn0 = 4, 1, 128, 160, 5000, 6
+    n_slots = 8 * frames
+    x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=4242, quiet_slots=(300, 740))
+    calls = (450, 8, 470, 3, 349)                                        # ~58 rows per slot here: from ~420 slots on a call is "large"
+    ref, _, thr_ref = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls)
+    out, _, thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, pipelined=True)
+    for key in ref:
+        assert np.array_equal(ref[key], out[key], equal_nan=True), key
+    assert np.array_equal(thr_ref, thr)
+    # back to back: pull A, pull B, then read A's device result (valid until the second pull after it) and B's through collect
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    g = pkg.TrxGroup(ctx, S, tsc_leg=leg, start=(fn0, tn0)); g.set_pipelined(True)
+    for a in range(S):
+        configure(lambda c, a=a: g.control(a, c), a)
+    cell = x.shape[2]
+    dx = torch.from_numpy(x.view(np.float32).reshape(-1)).to("cuda:0")
+    nA = nB = 512
+    fnB, tnB = (fn0 + (tn0 + nA) // 8) % tm.HYPERFRAME, (tn0 + nA) % 8
+    rA = g.pull(dx.data_ptr(), S * cell, cell, fn0, tn0, nA)
+    rB = g.pull(dx.data_ptr() + 8 * nA * S * cell, S * cell, cell, fnB, tnB, nB)
+    assert rA.n_rows >= 24576 and rB.n_rows >= 24576 and rA.d_row != rB.d_row        # both large: two workspace sets
+    g.sync(); torch.cuda.synchronize()
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    def dev(ptr, n, dtype):                                              # the result's device arrays -> host
+        a = np.empty(n, dtype)
+        assert hip.hipMemcpy(a.ctypes.data, ptr, a.nbytes, 2) == 0       # hipMemcpyDeviceToHost
+        return a
+    single, _, _ = run_group(pkg, sps, leg, S, nA + nB, fn0, tn0, x[:nA + nB], (nA, nB))
+    for r, lo in ((rA, 0), (rB, nA)):
+        row = dev(r.d_row, r.n_slots * S, np.int32).reshape(r.n_slots, S)
+        valid = dev(r.d_valid, r.n_rows, np.uint8)
+        thr_rows = dev(r.d_threshold, r.n_rows, np.float64)
+        got_valid = np.where(row >= 0, valid[np.maximum(row, 0)] != 0, False)
+        assert np.array_equal(got_valid, single["valid"][lo:lo + r.n_slots])
+        got_thr = np.where(row >= 0, thr_rows[np.maximum(row, 0)], np.nan)
+        assert np.array_equal(got_thr, single["threshold"][lo:lo + r.n_slots], equal_nan=True)
+    g.close(); ctx.close()
 
 
 def test_reconfiguration_and_limits(pkg):
@@ -385,3 +434,59 @@ def test_group_on_the_fused_front_end(pkg):
     for a in range(S):
         assert ga.energy_threshold(a) == gb.energy_threshold(a)
     ga.close(); gb.close(); fea.close(); feb.close(); ctx.close()
+
+
+def test_pipelined_mode_on_the_fused_front_end(pkg):
+    """trxsig_trxgroup_pull_rxfe with trxsig_trxgroup_set_pipelined: 128 ARFCN streams x three pushes of 125 chunks (1,000 slots,
+    ~59,000 rows each: large calls), the replay of push i overlapping the detectors of push i+1 -- every collected output and
+    the final thresholds equal the default mode's on the same int16 streams (normal bursts at 400 kS/s, combination V on TN 0 of
+    every 8th ARFCN so that the access-burst detector and false detections are in play, a stretch of silence)."""
+    import torch
+    from openbts_ttsou_amd.frontend import RxFrontEnd
+    sps, S, K, tsc, pushes = 4, 128, 125, 2, 3
+    dev = torch.device("cuda:0")
+    nb = (K * pushes * 585 // 156 + 4 + 3) // 4 * 4
+    x, off, length, meta = synth.normal_batch_torch(sps, S * nb, tsc, seed=77, device=dev, sigmas=(0.02, 0.05))
+    hi = x.reshape(-1)[: S * (x.numel() // S)].reshape(S, -1)
+    n_lo = K * pushes * 864
+    t = torch.arange(n_lo, device=dev, dtype=torch.float64) * (65.0 * sps / 96.0)
+    i0 = t.floor().long().clamp(max=hi.shape[1] - 2); fr = (t - i0).to(torch.float32)
+    lo = hi[:, i0] * (1 - fr) + hi[:, i0 + 1] * fr
+    lo = lo * (8000.0 / lo.abs().amax(dim=1, keepdim=True))
+    lo[:, 100 * 864:170 * 864] *= 1e-3                                   # ~150 ms of near silence: the thresholds decay
+    iq = torch.stack([lo.imag, lo.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()
+    lpf = synth.design_lpf(961, 65 * sps)
+    outs = []
+    for piped in (False, True):
+        ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+        g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
+        fe = RxFrontEnd(ctx, S, lpf, max_chunks=K)
+        for a in range(S):
+            g.control(a, "CMD SETTSC %d" % tsc)
+            for tn in range(8):
+                g.control(a, "CMD SETSLOT %d %d" % (tn, 5 if (tn == 0 and a % 8 == 0) else 1))
+        if piped:
+            g.set_pipelined(True)
+        got, slots = [], 0
+        if piped:                                                        # two pushes in flight before anything is collected
+            n0, r0 = g.pull_rxfe(fe, iq[:, :K * 864], 0)
+            n1, r1 = g.pull_rxfe(fe, iq[:, K * 864:2 * K * 864], (n0 // 8) % tm.HYPERFRAME)
+            assert r0.n_rows >= 24576 and r0.d_row != r1.d_row
+            got.append(g.collect()); slots = n0 + n1                     # (the second push's; the first is checked through the thresholds)
+            n2, _ = g.pull_rxfe(fe, iq[:, 2 * K * 864:], (slots // 8) % tm.HYPERFRAME)
+            got.append(g.collect())
+        else:
+            for p in range(pushes):
+                n, _ = g.pull_rxfe(fe, iq[:, p * K * 864:(p + 1) * K * 864], (slots // 8) % tm.HYPERFRAME)
+                slots += n
+                if p >= 1:
+                    got.append(g.collect())
+        thr = np.array([g.energy_threshold(a) for a in range(S)])
+        outs.append((got, thr))
+        g.close(); fe.close() if hasattr(fe, "close") else None; ctx.close()
+    (ga, ta), (gb, tb) = outs
+    assert np.array_equal(ta, tb)
+    for ra, rb in zip(ga, gb):
+        assert ra["valid"].sum() > 1000
+        for key in ra:
+            assert np.array_equal(ra[key], rb[key], equal_nan=True), key
