@@ -57,10 +57,11 @@ struct TrxGroupReplay {
   double *thr_after;                                       // mEnergyThreshold after the burst
 };
 // packed: scratch of n_slots * S float4 (the detectors' answers in (slot, ARFCN) order)
-// thr_g / succ_g (demodulating leg only, else NULL): trx_group_replay_scratch(S, n_slots) entries each, the lean replay's
+// thr_g / verdict_g (and tix_g on the equalising leg, else NULL): trx_group_replay_scratch(S, n_slots) entries each, the replay's
 // (slot, ARFCN)-ordered outputs before k_group_scatter moves them to the rows
 size_t trx_group_replay_scratch(int S, int n_slots);
-hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, float4 *packed, double *thr_g, uint8_t *succ_g, TrxProfiler *prof);
+hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, float4 *packed, double *thr_g, uint8_t *verdict_g, int32_t *tix_g,
+                                   TrxProfiler *prof);
 
 // toa_eq[row] = TOA - chanRespOffset[ts] (Transceiver.cpp:393) for the gated normal-burst rows
 hipError_t trx_launch_group_toa_eq(hipStream_t st, int n_rows, const uint8_t *gate, const float *toa, const int32_t *tap_ix,

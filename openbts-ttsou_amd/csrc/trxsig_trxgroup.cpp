@@ -71,7 +71,7 @@ struct trxsig_trxgroup {
   // per-call workspace: two sets, so that in pipelined mode (trxsig_trxgroup_set_pipelined) the state machine can still be
   // replaying call i's rows on the side stream while call i+1's detectors fill the other set
   struct Work {
-    DevBuf<int32_t> rowmap, seg, off, len, tap_ix;
+    DevBuf<int32_t> rowmap, seg, off, len, tap_ix, tix_g;
     DevBuf<float4> packed;
     DevBuf<uint8_t> flags, gate, ev, ev_flags, succ_g;
     DevBuf<trx_c32> amp, ev_amp;
@@ -82,7 +82,7 @@ struct trxsig_trxgroup {
     void release() {
       rowmap.release(); seg.release(); off.release(); len.release(); tap_ix.release(); packed.release(); flags.release(); gate.release();
       ev.release(); ev_flags.release(); succ_g.release(); amp.release(); ev_amp.release(); toa.release(); avgpwr.release(); toa_eq.release();
-      snr.release(); ev_toa.release(); ev_toaeq.release(); soft.release(); thr_after.release(); thr_g.release();
+      snr.release(); ev_toa.release(); ev_toaeq.release(); soft.release(); thr_after.release(); thr_g.release(); tix_g.release();
     }
   } wk[2];
   int cur = 0;                                              // the set of the last pull
@@ -301,9 +301,10 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   G_HIP(g, W.toa.need(R, st)); G_HIP(g, W.avgpwr.need(R, st)); G_HIP(g, W.toa_eq.need(R, st)); G_HIP(g, W.snr.need(R, st));
   G_HIP(g, W.ev_toa.need(R, st)); G_HIP(g, W.ev_toaeq.need(R, st)); G_HIP(g, W.thr_after.need(R, st));
   G_HIP(g, W.soft.need(R * kSoft, st));
-  if (g->leg != TRXSIG_TSCLEG_EQUALIZE) {
+  {
     const size_t ns = trx_group_replay_scratch(S, n_slots);
     G_HIP(g, W.thr_g.need(ns, st)); G_HIP(g, W.succ_g.need(ns, st));
+    if (g->leg == TRXSIG_TSCLEG_EQUALIZE) G_HIP(g, W.tix_g.need(ns, st));
   }
   G_HIP(g, g->w_tab.need((S8 + R) * 7, st, S8 * 7)); G_HIP(g, g->b_tab.need((S8 + R) * 5, st, S8 * 5));
   G_HIP(g, g->chan_off.need(S8 + R, st, S8));
@@ -363,7 +364,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
     G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
     side_guard.s = g->side;
   }
-  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, W.packed.p, lean ? W.thr_g.p : nullptr, lean ? W.succ_g.p : nullptr,
+  G_HIP(g, trx_launch_group_replay(beside ? g->side : st, rp, W.packed.p, W.thr_g.p, W.succ_g.p, equalize ? W.tix_g.p : nullptr,
                                    trx_ctx_profiler(c)));
   if (beside) G_HIP(g, hipEventRecord(piped ? W.done : g->ev_join, g->side));
   const uint8_t *demod_gate = beside ? W.flags.p : W.gate.p;   // (gate holds TRXSIG_F_DETECT or 0: the same mask serves both)

@@ -13,7 +13,7 @@ WANT = [("normal", "k_demod<4", "k_demod", 65536, {}), ("normal", "k_tsc_corr<4"
         ("config5", "k_eq_dfe2", "k_eq_dfe2", 65536, {}),
         ("config4", "k_demod_rx<4", "k_demod_rx", 59904, {}), ("config4", "k_tsc_corr_rx<4", "k_tsc_corr_rx", 59904, {}),
         ("config4", "k_rach_front_rx<4", "k_rach_front_rx", 59904, {"note": "per step of the group bench (the access-burst rows only: ~500 bursts)"}),
-        ("config4", "k_group_replay_lean", "k_group_replay", 59904, {"note": "per step: 128 ARFCNs x 1000 slots"}),
+        ("config4", "k_group_replay", "k_group_replay", 59904, {"note": "per step: 128 ARFCNs x 1000 slots"}),
         ("config5", "k_eq_dfe2", "k_eq_dfe", 65536, {"kernel": "k_eq_dfe2"}),
         ("config4_unfused", "k_rx_resample", "k_rx_resample", 128 * 125, {"note": "units = stream-chunks (128 streams x 125 chunks per launch)"}),
         ("config4_unfused", "k_rx_resample", "k_resample", 128 * 125, {"kernel": "k_rx_resample", "note": "units = stream-chunks (128 streams x 125 chunks per launch)"})]
