@@ -196,7 +196,8 @@ def test_group_across_the_hyperframe_wrap(pkg, tn0):
     replay's frame difference to prevFalseDetectionTime is carried from slot to slot (k_group_replay_lean) and must wrap,
     restart at every false detection and trigger the quiet decrements exactly where FNDelta does -- thresholds, verdicts and
     soft bits against independent single-burst objects and the CPU model, calls that start on and off a frame boundary."""
-    sps, leg, S, frames = 4, 1, 32, 80
+    sps, leg, frames = 4, 1, 80
+    S = 32 if tn0 == 0 else 100                                          # (100: two waves of lanes, the second one ragged)
     fn0 = tm.HYPERFRAME - 30
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=777 + tn0, quiet_slots=(80, 560))
