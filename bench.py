@@ -190,13 +190,13 @@ class Normal:
                     np_.array_equal(self.toa[:n].cpu().numpy(), otoa))
             out["oracle_check_first_%d" % n] = bool(same)
         import refbind
-        if self.rach or not refbind.available():
+        if not refbind.available():
             return out
         import subprocess
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "sample.npz")
-            np_.savez(path, x=xh, off=off, length=length, sps=self.sps, tsc=self.tsc)
+            np_.savez(path, x=xh, off=off, length=length, sps=self.sps, tsc=self.tsc, kind="rach" if self.rach else "normal")
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
                                    capture_output=True, text=True, timeout=300)
@@ -452,6 +452,24 @@ class Config4:
             same = np.array_equal(det, ok[:k].astype(bool)) and np.array_equal(self.toa[:k].cpu().numpy(), toa[:k]) and \
                 np.array_equal(self.soft[:k].cpu().numpy()[det], soft[:k, :NSOFT][det])
             out["oracle_check_fused_stream0_first_%d" % k] = bool(same)
+        # the real reference (oracle/_ref) on the box's cores: the same chain per stream, the streams shared out over processes
+        import refbind
+        if refbind.available():
+            import subprocess
+            import tempfile
+            cores = host_cores()
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "sample.npz")
+                np.savez(path, iq=self.iq[:, :nchunks * 864].cpu().numpy(), lpf=np.asarray(self.lpf, np.float32), sps=self.sps, tsc=self.tsc,
+                         kind="config4")
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
+                                       capture_output=True, text=True, timeout=300)
+                    port = out["cpu_baseline"]
+                    out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["cpu_port"] = port                  # the oracle port (one thread) beside the real reference
+                except Exception as e:                      # the reference leg is optional; the port leg stands
+                    sys.stderr.write("reference cpu baseline unavailable: %r\n" % (e,))
         return out
 
 

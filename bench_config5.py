@@ -109,4 +109,24 @@ class Config5:
                                           "ctypes), one thread, %.1f s" % (n, tt)}}
         if check:
             out["oracle_check_first_%d" % n] = bool(same)
+        # the real reference (Transceiver52M/sigProcLib.cpp compiled in place) on the box's cores, the calls strung together as
+        # Transceiver::pullRadioVector does (oracle/ref_driver.cpp ref_eq_batch), one process per core
+        import refbind
+        if refbind.available("52m"):
+            import json
+            import subprocess
+            import tempfile
+            from bench import host_cores
+            cores = host_cores()
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "sample.npz")
+                np.savez(path, x=xh, off=off, length=length, sps=1, tsc=self.tsc, kind="config5", energy_thresh=thr, max_toa=4)
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
+                                       capture_output=True, text=True, timeout=300)
+                    port = out["cpu_baseline"]
+                    out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["cpu_port"] = port
+                except Exception as e:
+                    sys.stderr.write("reference cpu baseline unavailable: %r\n" % (e,))
         return out

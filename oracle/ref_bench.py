@@ -4,7 +4,11 @@ keeps its tables in process globals), each looping over its own contiguous slice
 called by bench.py's cpu_baseline leg as a child process (it never touches the GPU).
 
     python oracle/ref_bench.py sample.npz P seconds      -> one JSON line
-sample.npz: x complex64 (packed bursts), off int32, length int32, sps, tsc."""
+sample.npz: x complex64 (packed bursts), off int32, length int32, sps, tsc; kind (optional): "normal" (default),
+"rach" (detectRACHBurst + demodulateBurst), "config5" (the Transceiver52M equalised leg: energyDetect + analyzeTrafficBurst with
+the channel response + designDFE + equalizeBurst, oracle/_ref/libref_sigproc52m.so; energy_thresh, max_toa in the file), or "config4": iq int16 [S][K*864][2] (Q first), lpf float32 taps -- per stream
+unUSRPify + polyphaseResampleVector chunk by chunk behind a 192-sample history (RadioInterface::pullBuffer) + the
+157-156-156-156 slicing + analyzeTrafficBurst + demodulateBurst, the streams shared out over the processes."""
 import json
 import multiprocessing as mp
 import sys
@@ -13,18 +17,54 @@ import time
 import numpy as np
 
 
+def kind_of(d):
+    return str(d["kind"]) if "kind" in d.files else "normal"
+
+
+def config4_stream(r, iq, lpf, sps, tsc):
+    """One stream through the reference: returns the number of bursts it cut and detected + demodulated."""
+    nchunks = iq.shape[0] // 864
+    hist = np.zeros(192, np.complex64)
+    rcv = []
+    for c in range(nchunks):
+        ch = iq[c * 864:(c + 1) * 864]
+        cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)   # unUSRPifyVector: I/Q swapped
+        y = r.polyphase_resample(np.concatenate([hist, cf]), 65 * sps, 96, lpf)
+        rcv.append(y[2 * 65 * sps:]); hist = cf[-192:]
+    xs = np.concatenate(rcv)
+    lens = []; pos = 0; tn = 0
+    while xs.size - pos > (156 + (tn % 4 == 0)) * sps:
+        n = (156 + (tn % 4 == 0)) * sps; lens.append(n); pos += n; tn = (tn + 1) % 8
+    lens = np.array(lens, np.int32); off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    r.normal_batch(xs, off, lens, tsc)
+    return len(lens)
+
+
 def worker(path, lo, hi, reps, start, done):
     import refbind
     d = np.load(path)
-    r = refbind.Ref(int(d["sps"]))
+    kind = kind_of(d)
+    r = refbind.Ref(int(d["sps"]), variant="52m" if kind == "config5" else "")
+    if kind == "config4":
+        iq, lpf, sps, tsc = np.ascontiguousarray(d["iq"][lo:hi]), d["lpf"], int(d["sps"]), int(d["tsc"])
+        config4_stream(r, iq[0][:864 * 4], lpf, sps, tsc)  # warm
+        start.wait()
+        for _ in range(reps):
+            for s in range(hi - lo):
+                config4_stream(r, iq[s], lpf, sps, tsc)
+        done.wait()
+        return
     x, off, length, tsc = d["x"], d["off"][lo:hi], d["length"][lo:hi], int(d["tsc"])
     base = int(off[0])
     xs = np.ascontiguousarray(x[base:int(off[-1] + length[-1])])
     off = (off - base).astype(np.int32)
-    r.normal_batch(xs, off, length, tsc)                 # warm (page in, allocator)
+    run = (lambda: r.rach_batch(xs, off, length)) if kind == "rach" else (lambda: r.normal_batch(xs, off, length, tsc))
+    if kind == "config5":
+        run = lambda: r.eq_batch(xs, off, length, tsc, 3.0, float(d["energy_thresh"]), int(d["max_toa"]))
+    run()                                                # warm (page in, allocator)
     start.wait()
     for _ in range(reps):
-        r.normal_batch(xs, off, length, tsc)
+        run()
     done.wait()
 
 
@@ -33,21 +73,40 @@ def main():
     sys.path.insert(0, __file__.rsplit("/", 1)[0])
     import refbind
     d = np.load(path)
-    B = len(d["off"])
-    # single-process calibration on the first 512 bursts
-    r = refbind.Ref(int(d["sps"]))
-    n1 = min(512, B)
-    off1, len1 = d["off"][:n1], d["length"][:n1]
-    x1 = np.ascontiguousarray(d["x"][:int(off1[-1] + len1[-1])])     # (an .npz member is re-read on every access)
-    r.normal_batch(x1, off1, len1, int(d["tsc"]))
-    t0 = time.perf_counter()
-    r.normal_batch(x1, off1, len1, int(d["tsc"]))
-    per_burst = (time.perf_counter() - t0) / n1
+    kind = kind_of(d)
+    r = refbind.Ref(int(d["sps"]), variant="52m" if kind == "config5" else "")
+    if kind == "config4":
+        iq = d["iq"]
+        S = iq.shape[0]
+        P = min(P, S)
+        config4_stream(r, iq[0][:864 * 4], d["lpf"], int(d["sps"]), int(d["tsc"]))
+        t0 = time.perf_counter()
+        nb1 = config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]))
+        per_burst = (time.perf_counter() - t0) / nb1
+        B = nb1 * S                                          # bursts per pass over all streams
+        units, what = S, ("%d streams x %d chunks (%d bursts): unUSRPify + polyphaseResampleVector chunk by chunk + slicing + "
+                          "analyzeTrafficBurst + demodulateBurst" % (S, iq.shape[1] // 864, B))
+    else:
+        B = len(d["off"])
+        # single-process calibration on the first 512 (normal) / 128 (access) bursts
+        n1 = min(512 if kind == "normal" else 128, B)
+        off1, len1 = d["off"][:n1], d["length"][:n1]
+        x1 = np.ascontiguousarray(d["x"][:int(off1[-1] + len1[-1])])     # (an .npz member is re-read on every access)
+        run1 = (lambda: r.rach_batch(x1, off1, len1)) if kind == "rach" else (lambda: r.normal_batch(x1, off1, len1, int(d["tsc"])))
+        if kind == "config5":
+            run1 = lambda: r.eq_batch(x1, off1, len1, int(d["tsc"]), 3.0, float(d["energy_thresh"]), int(d["max_toa"]))
+        run1()
+        t0 = time.perf_counter()
+        run1()
+        per_burst = (time.perf_counter() - t0) / n1
+        chain = {"rach": "detectRACHBurst + demodulateBurst", "normal": "analyzeTrafficBurst + demodulateBurst",
+                 "config5": "energyDetect + analyzeTrafficBurst(requestChannel, maxTOA) + designDFE + equalizeBurst"}[kind]
+        units, what = B, "the first %d bursts of the GPU batch (%s" % (B, chain)
     per_pass = per_burst * (B / P)
     reps = max(1, int(seconds / max(per_pass, 1e-4)))
     ctx = mp.get_context("fork")
     start, done = ctx.Barrier(P + 1), ctx.Barrier(P + 1)
-    edges = [B * i // P for i in range(P + 1)]
+    edges = [units * i // P for i in range(P + 1)]
     procs = [ctx.Process(target=worker, args=(path, edges[i], edges[i + 1], reps, start, done)) for i in range(P)]
     for p in procs:
         p.start()
@@ -59,9 +118,10 @@ def main():
         p.join()
     print(json.dumps({"value": round(B * reps / tt / 1e6, 6), "unit": "Mbursts/s", "cores": P, "kind": "reference",
                       "single_thread_Mbursts_per_s": round(1e-6 / per_burst, 6),
-                      "sample": "%d passes over the first %d bursts of the GPU batch (analyzeTrafficBurst + demodulateBurst of "
-                                "Transceiver/sigProcLib.cpp compiled in place, oracle/_ref/libref_sigproc.so, %d processes, %.1f s)"
-                                % (reps, B, P, tt)}))
+                      "sample": ("%d passes over %s" % (reps, what)) + (" of " if kind != "config4" else "; ") +
+                                "%s/sigProcLib.cpp compiled in place, oracle/_ref/libref_sigproc%s.so, %d processes, %.1f s%s"
+                                % ("Transceiver52M" if kind == "config5" else "Transceiver", "52m" if kind == "config5" else "", P, tt,
+                                   ")" if kind != "config4" else "")}))
 
 
 if __name__ == "__main__":

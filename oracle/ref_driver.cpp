@@ -351,6 +351,45 @@ int ref_normal_batch(const float *x, const int *off, const int *len, int B,
   }
   return found;
 }
+/* the equalised receive leg over a packed batch, as Transceiver::pullRadioVector strings the calls together
+   (Transceiver.cpp:298, 331-349, 391-396; Transceiver52M: the same with maxTOA): energyDetect -> analyzeTrafficBurst with
+   the channel response -> SNR, scaleVector(chan, 1/amp), designDFE(Nf 7) -> scaleVector(burst, 1/amp), equalizeBurst(TOA -
+   chanRespOffset).  Timing loop of bench.py's config-5 cpu_baseline; soft: B*157 (zeros where nothing came back). */
+int ref_eq_batch(const float *x, const int *off, const int *len, int B, unsigned tsc, float detect_thresh, float energy_thresh,
+                 int maxTOA, unsigned char *ok, float *soft)
+{
+  int found = 0;
+  for (int i = 0; i < B; i++) {
+    signalVector X((complex *)(x + 2 * (size_t)off[i]), 0, len[i]);
+    float *so = soft + (size_t)i * 157;
+    for (int k = 0; k < 157; k++) so[k] = 0.0f;
+    ok[i] = 0;
+    float avgPwr = 0.0f;
+    if (!energyDetect(X, 20 * gSps, energy_thresh, &avgPwr)) continue;
+    complex a = 0.0; float t = 0.0, choff = 0.0;
+    signalVector *cr = NULL;
+#ifdef REF_52M
+    bool d = analyzeTrafficBurst(X, tsc, detect_thresh, gSps, &a, &t, (unsigned)maxTOA, true, &cr, &choff);
+#else
+    (void)maxTOA;
+    bool d = analyzeTrafficBurst(X, tsc, detect_thresh, gSps, &a, &t, true, &cr, &choff);
+#endif
+    if (!d || !cr) { delete cr; continue; }
+    float snr = (float)((double)a.norm2() / ((double)(energy_thresh * energy_thresh) + 1.0));   /* Transceiver.cpp:340 */
+    scaleVector(*cr, complex(1.0, 0.0) / a);
+    signalVector *W = NULL, *Bq = NULL;
+    designDFE(*cr, snr, 7, &W, &Bq);
+    signalVector Y(X);
+    scaleVector(Y, complex(1.0, 0.0) / a);
+    SoftVector *s = equalizeBurst(Y, t - choff, gSps, *W, *Bq);
+    int ns = (int)s->size();
+    for (int k = 0; k < ns && k < 157; k++) so[k] = (*s)[k];
+    delete s; delete W; delete Bq; delete cr;
+    ok[i] = 1;
+    found++;
+  }
+  return found;
+}
 int ref_rach_batch(const float *x, const int *off, const int *len, int B,
                    float thresh, unsigned char *ok, float *amp, float *toa,
                    float *soft /* B*148 */)

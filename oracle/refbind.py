@@ -84,6 +84,8 @@ class Ref:
         L.ref_equalize.argtypes = [f32p, C.c_int, C.c_float, f32p, C.c_int, f32p, C.c_int, f32p]
         L.ref_normal_batch.argtypes = [f32p, i32p, i32p, C.c_int, C.c_uint, C.c_float, u8p, f32p, f32p, f32p]
         L.ref_rach_batch.argtypes = [f32p, i32p, i32p, C.c_int, C.c_float, u8p, f32p, f32p, f32p]
+        if hasattr(L, "ref_eq_batch"):
+            L.ref_eq_batch.argtypes = [f32p, i32p, i32p, C.c_int, C.c_uint, C.c_float, C.c_float, C.c_int, u8p, f32p]
         if hasattr(L, "ref_dB"):                              # the rest of sigProcLib.h's surface
             for n in ("ref_dB", "ref_dBinv"):
                 getattr(L, n).argtypes = [C.c_float]; getattr(L, n).restype = C.c_float
@@ -293,6 +295,14 @@ class Ref:
         self.lib.ref_normal_batch(x, np.ascontiguousarray(off, np.int32), np.ascontiguousarray(length, np.int32),
                                   B, tsc, thresh, ok, amp, toa, soft)
         return ok, amp.view(np.complex64), toa, soft.reshape(B, 148)
+
+    def eq_batch(self, x, off, length, tsc, detect_thresh=3.0, energy_thresh=10.0, max_toa=4):
+        """ref_eq_batch: the equalised receive leg burst by burst inside the reference (bench.py's config-5 baseline)."""
+        x = c64(x); B = len(off)
+        ok = np.zeros(B, np.uint8); soft = np.zeros(B * 157, np.float32)
+        self.lib.ref_eq_batch(x, np.ascontiguousarray(off, np.int32), np.ascontiguousarray(length, np.int32), B, tsc,
+                              np.float32(detect_thresh), np.float32(energy_thresh), max_toa, ok, soft)
+        return ok, soft.reshape(B, 157)
 
     def rach_batch(self, x, off, length, thresh=5.0):
         x = c64(x); B = len(off)
