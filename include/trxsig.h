@@ -466,6 +466,12 @@ int trxsig_kernel_count(void);
  *     2 = the same with peakDetect's bisection and the tail in their own kernel, two lanes per burst
  *     (k_rach_front + k_rach_peak2; bursts too close to the threshold to call from approximate valley powers
  *     are handed back to k_rach_fast).  All three give the reference's results.
+ *   TRXSIG_TUNE_DEMOD_BESIDE (both libraries; default 0): 1 = trxsig_detect_demod_normal_batch (path 0) detects on the context's
+ *     stream and DEMODULATES ON A SIDE STREAM of the context, from its own copy of (flags, amp, TOA): the call returns with
+ *     d_flags / d_amp / d_toa / d_avgpwr ordered on the context's stream as always, while d_soft / d_hard -- and the READS of
+ *     d_samples / d_offset / d_length -- complete only behind trxsig_synchronize (or the next call that is not of this kind).
+ *     The next call's correlator (VALU-bound) then runs beside this call's demodulator (HBM-bound): a throughput lever for a
+ *     caller that pipelines batches (bench.py reports it as a side field, never as `value`); same results.
  *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component" form (which
  *     is only taken when the actual taps have that shape).  Default 0.
  *   TRXSIG_TUNE_SPECULATIVE_PEAK: path 0's peakDetect kernel.  0 = two lanes per burst (early and late point of
@@ -474,7 +480,7 @@ int trxsig_kernel_count(void);
  *     64 K bursts, LDS bandwidth), 2 = a lane per burst, the reference's serial loop (k_tsc_peak; 18 us,
  *     k_tsc_peak2 15 us).  All three are bit-identical. */
 enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3,
-       TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5 };
+       TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5, TRXSIG_TUNE_DEMOD_BESIDE = 7 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* 1 in libtrxsig_tune.so (every implementation above selectable), 0 in the product library libtrxsig.so, which carries the
  * defaults only (normal path 0 with the two-lane peak kernel, RACH paths 1 and 2) and answers TRXSIG_EINVAL to the rest. */

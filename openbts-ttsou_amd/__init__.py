@@ -485,8 +485,10 @@ class TrxSig:
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
     def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None, chain_lag=None,
-                   chain_spin=None):
+                   chain_spin=None, demod_beside=None):
         """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
+        if demod_beside is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 7, int(demod_beside)), "trxsig_set_tuning")
         if chain_lag is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 4, int(chain_lag)), "trxsig_set_tuning")
         if chain_spin is not None:

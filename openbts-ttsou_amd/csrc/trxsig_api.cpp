@@ -72,6 +72,15 @@ struct trxsig_ctx {
   void *d_stage = nullptr;
   size_t pin_bytes = 0;              // pinned host mirror of the staging area (small host calls: one DMA each way)
   void *h_pin = nullptr;
+  // TRXSIG_TUNE_DEMOD_BESIDE: the demodulator on a side stream, from one of two private copies of (flags, amp, TOA)
+  int demod_beside = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_pk[2] = {nullptr, nullptr}, ev_dm[2] = {nullptr, nullptr};
+  bool dm_in_flight[2] = {false, false};
+  uint8_t *pb_flags[2] = {nullptr, nullptr};
+  trx_c32 *pb_amp[2] = {nullptr, nullptr};
+  float *pb_toa[2] = {nullptr, nullptr};
+  int pb_cap = 0, pb_k = 0;
   int rach_variant = 2;              // 2 = k_rach_front + k_rach_peak2 (approximate-then-exact, bisection in its own kernel), 1 = k_rach_fast alone, 0 = exact at every lag
   int variant = 0;                   // normal-burst path (TRXSIG_TUNE_NORMAL_PATH / env TRXSIG_TSC_VARIANT)
   int spec_peak = 0;                 // peak kernel of path 0: 0 = k_tsc_peak2 (2 lanes per burst), 1 = k_tsc_peak8 (8, speculated), 2 = k_tsc_peak (1)
@@ -164,6 +173,43 @@ int ensure_ws(trxsig_ctx *c, int B) {
   if (rach > per_burst) per_burst = rach;
   HIPCHK(c, hipMalloc((void **)&c->d_rec, per_burst * cap));
   c->cap_bursts = cap;
+  return TRXSIG_OK;
+}
+
+// the context's stream waits for every demodulator still running on the side stream (TRXSIG_TUNE_DEMOD_BESIDE)
+int join_demod(trxsig_ctx *c) {
+  for (int k = 0; k < 2; k++) {
+    if (!c->dm_in_flight[k]) continue;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dm[k], 0));
+    c->dm_in_flight[k] = false;
+  }
+  return TRXSIG_OK;
+}
+int ensure_beside(trxsig_ctx *c, int B) {
+  if (!c->side) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_pk[k], hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_dm[k], hipEventDisableTiming));
+    }
+  }
+  if (B <= c->pb_cap) return TRXSIG_OK;
+  HIPCHK(c, hipStreamSynchronize(c->side));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int cap = (B + 255) & ~255;
+  for (int k = 0; k < 2; k++) {
+    if (c->pb_flags[k]) { HIPCHK(c, hipFree(c->pb_flags[k])); c->pb_flags[k] = nullptr; }
+    if (c->pb_amp[k]) { HIPCHK(c, hipFree(c->pb_amp[k])); c->pb_amp[k] = nullptr; }
+    if (c->pb_toa[k]) { HIPCHK(c, hipFree(c->pb_toa[k])); c->pb_toa[k] = nullptr; }
+    c->dm_in_flight[k] = false;
+  }
+  c->pb_cap = 0;
+  for (int k = 0; k < 2; k++) {
+    HIPCHK(c, hipMalloc((void **)&c->pb_flags[k], (size_t)cap));
+    HIPCHK(c, hipMalloc((void **)&c->pb_amp[k], sizeof(trx_c32) * (size_t)cap));
+    HIPCHK(c, hipMalloc((void **)&c->pb_toa[k], sizeof(float) * (size_t)cap));
+  }
+  c->pb_cap = cap;
   return TRXSIG_OK;
 }
 
@@ -293,6 +339,14 @@ void trxsig_destroy(trxsig_ctx *c) {
     if (c->h_chain_status) (void)hipHostFree(c->h_chain_status);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tsc) (void)hipFree(c->d_tsc);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    for (int k = 0; k < 2; k++) {
+      if (c->ev_pk[k]) (void)hipEventDestroy(c->ev_pk[k]);
+      if (c->ev_dm[k]) (void)hipEventDestroy(c->ev_dm[k]);
+      if (c->pb_flags[k]) (void)hipFree(c->pb_flags[k]);
+      if (c->pb_amp[k]) (void)hipFree(c->pb_amp[k]);
+      if (c->pb_toa[k]) (void)hipFree(c->pb_toa[k]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c->prof;
@@ -308,6 +362,11 @@ void *trxsig_get_stream(trxsig_ctx *c) { return c ? (void *)c->stream : nullptr;
 int trxsig_get_device(trxsig_ctx *c) { return c ? c->device : -1; }
 int trxsig_synchronize(trxsig_ctx *c) {
   if (!c) return TRXSIG_EINVAL;
+  {
+    DeviceGuard g(c->device);
+    int rc = join_demod(c);
+    if (rc != TRXSIG_OK) return rc;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return chain_check(c);
 }
@@ -399,9 +458,35 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
     return TRXSIG_OK;
   }
 #endif
+  const bool beside = c->demod_beside && nsoft > 0;
+  int k = 0;
+  if (beside) {
+    rc = ensure_beside(c, B);
+    if (rc != TRXSIG_OK) return rc;
+    k = c->pb_k ^= 1;
+    if (c->dm_in_flight[k]) {                               // the demodulator that read this copy two calls ago
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dm[k], 0));
+      c->dm_in_flight[k] = false;
+    }
+  } else {
+    rc = join_demod(c);                                     // (outputs of this call must not be overtaken by an older demodulator)
+    if (rc != TRXSIG_OK) return rc;
+  }
   HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
                                   (trx_c32 *)d_amp, d_toa, d_avgpwr, c->generic_taps | (c->spec_peak == 1 ? 2 : 0) | (c->spec_peak == 2 ? 4 : 0), c->prof));
+  if (beside) {
+    HIPCHK(c, hipMemcpyAsync(c->pb_flags[k], d_flags, (size_t)B, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pb_amp[k], d_amp, sizeof(trx_c32) * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pb_toa[k], d_toa, sizeof(float) * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_pk[k], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pk[k], 0));
+    HIPCHK(c, trx_launch_demod(c->side, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, c->pb_amp[k], c->pb_toa[k],
+                               c->pb_flags[k], TRXSIG_F_DETECT, d_soft, d_hard, nsoft, soft_stride, c->prof));
+    HIPCHK(c, hipEventRecord(c->ev_dm[k], c->side));
+    c->dm_in_flight[k] = true;
+    return TRXSIG_OK;
+  }
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
@@ -1102,6 +1187,13 @@ int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (key == 6 && value >= 0 && value <= 3) { c->chain_dbg = value; return TRXSIG_OK; }   // timing experiments (tools/chain_roles.py)
   if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 2) { c->rach_variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_GENERIC_TAPS && value >= 0 && value <= 1) { c->generic_taps = value; return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_DEMOD_BESIDE && value >= 0 && value <= 1) {
+    DeviceGuard g(c->device);
+    int rc = join_demod(c);
+    if (rc != TRXSIG_OK) return rc;
+    c->demod_beside = value;
+    return TRXSIG_OK;
+  }
   if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 2) { c->spec_peak = value; return TRXSIG_OK; }
   return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: unknown key or value");
 }

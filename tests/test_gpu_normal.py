@@ -88,6 +88,38 @@ def test_random_batch_vs_oracle(pkg, ctx, sps, B):
         assert np.array_equal(r["hard"][clean][:, :148], meta["bits"][clean])
 
 
+def test_demodulator_beside_the_next_correlator(pkg):
+    """TRXSIG_TUNE_DEMOD_BESIDE: five different batches back to back, every call's demodulator on the context's side stream from
+    its own copy of (flags, amp, TOA) while the next call's correlator runs; one trxsig_synchronize at the end.  Every output of
+    every call equals the default mode's (two private copies alternate: the third call waits for the first one's demodulator)."""
+    sps, tsc = 4, 3
+    t = pkg.TrxSig(sps, 0); t.use_torch_stream()
+    sizes = (3000, 4096, 1, 2500, 4096)
+    batches = []
+    for i, B in enumerate(sizes):
+        x, off, length, _ = synth.normal_batch(sps, B, tsc, seed=900 + i, sigmas=(0.0, 0.1, 0.5, 2.0))
+        batches.append((GpuBatch(x, off, length, nsoft=156, stride=157), GpuBatch(x, off, length, nsoft=156, stride=157)))
+    for ref, _ in batches:
+        t.detect_demod_normal(ref.x, ref.off, ref.len, tsc, ref.flags, ref.amp, ref.toa, ref.soft, avgpwr=ref.pwr, hard=ref.hard,
+                              energy_thresh=0.0, nsoft=156, soft_stride=157)
+    t.set_tuning(demod_beside=1)
+    for _, gb in batches:
+        t.detect_demod_normal(gb.x, gb.off, gb.len, tsc, gb.flags, gb.amp, gb.toa, gb.soft, avgpwr=gb.pwr, hard=gb.hard,
+                              energy_thresh=0.0, nsoft=156, soft_stride=157)
+    t.synchronize()
+    for ref, gb in batches:
+        a, b = ref.results(), gb.results()
+        for key in a:
+            assert_veq(a[key], b[key], key)
+    t.set_tuning(demod_beside=0)                            # (a call of the ordinary kind afterwards is ordered behind everything)
+    ref, gb = batches[1]
+    gb.soft.fill_(-1.0)
+    t.detect_demod_normal(gb.x, gb.off, gb.len, tsc, gb.flags, gb.amp, gb.toa, gb.soft, avgpwr=gb.pwr, hard=gb.hard,
+                          energy_thresh=0.0, nsoft=156, soft_stride=157)
+    assert_veq(ref.results()["soft"], gb.results()["soft"], "soft after switching back")
+    t.close()
+
+
 def test_ragged_and_bad_bursts(pkg, ctx):
     """offset/length edge cases: bad lengths are flagged and skipped, neighbours are unaffected."""
     sps = 4
