@@ -243,6 +243,12 @@ class Config4:
     def __init__(self, args):
         self.S = args.streams
         self.K = args.chunks
+        # --reference-chain: the reference's OWN configuration -- one sample per symbol, RadioInterface's 65 : 96 resampler with
+        # its createLPF(., 961, 65) table, Transceiver with the equaliser (designDFE + equalizeBurst behind the per-slot channel
+        # cache) -- through the Transceiver group (equalising leg) on a push / pop front end
+        self.refchain = bool(getattr(args, "reference_chain", False))
+        if self.refchain:
+            self.sps = 1
         self.per_chunk = 585 * self.sps                      # resampled samples per 864-sample chunk
         self.alg_bytes = 4 * 625 * 96 // (65 * self.sps) + 4 * NSOFT + 16   # int16 in, soft bits out
         self.kernel_alg = {"k_resample": None}               # per stream-chunk, see roofline()
@@ -254,13 +260,14 @@ class Config4:
         # --wideband C: the channeliser -- S / C wideband streams at 8 x 400 kS/s with C carriers each, mixed down and resampled per
         # carrier in one kernel into the receive buffers, then pop + the normal-burst detector (through the resampled stream)
         self.wide = int(getattr(args, "wideband", 0) or 0)
-        self.fused = not bool(getattr(args, "unfused_frontend", False)) and not self.wide
-        self.group = self.fused and not bool(getattr(args, "stateless_frontend", False))
+        self.fused = not bool(getattr(args, "unfused_frontend", False)) and not self.wide and not self.refchain
+        self.group = (self.fused and not bool(getattr(args, "stateless_frontend", False))) or self.refchain
         if self.wide:
             self.kernel_names["k_resample"] = "k_resample<int16 wideband, mix>"
         if self.group:
             self.beside_kernels = ("k_group_replay",)      # the state machine replays on a side stream, beside demodulateBurst
-            self.kernel_names.update({"k_rach_corr": "k_rach_front_rx", "k_rach_peak": "k_rach_peak2+k_rach_fast_rx(list)"})
+            self.kernel_names.update({"k_rach_corr": "k_rach_front_rx", "k_rach_peak": "k_rach_peak2+k_rach_fast_rx(list)"} if self.fused else
+                                     {"k_rach_corr": "k_rach_front", "k_rach_peak": "k_rach_peak2+k_rach_fast(list)", "k_eq_dfe": "k_eq_dfe2"})
             self.kernel_alg.update({"k_rach_corr": 4 * 236 + 8 * 25 + 16 + 17, "k_rach_peak": 8 * 25 + 16 + 17, "k_group_replay": 16 + 4 + 1 + 8})
         if self.fused:
             self.kernel_names.update({"k_demod": "k_demod_rx", "k_tsc_corr": "k_tsc_corr_rx"})
@@ -298,6 +305,11 @@ class Config4:
         # createLPF(cutoff, 961, 65*sps) as pullBuffer asks for it -- designed for THIS ratio (synth.design_lpf says why the
         # reference's fixed table, made for 65:96, is not used at sps 4); the taps are an argument of the library
         self.lpf = synth.design_lpf(961, 65 * sps)
+        if self.refchain:                                     # radioInterface.cpp:230-234 at sps 1: the reference's table (a data fixture)
+            raw = np.load(os.path.join(ROOT, "tests", "golden", "resample.npz"))["sendLPF_961_raw"]
+            h = pkg.TrxHost(sps, dev.index or 0)
+            self.lpf = h.create_lpf(raw, 65.0)
+            h.close()
         if self.wide:
             # carriers 400 kHz apart round the centre of a 3.2 MS/s stream; each narrowband stream is brought to the wideband rate
             # by linear interpolation, shifted to its carrier and summed (content for a throughput run, not a calibrated radio)
@@ -324,7 +336,7 @@ class Config4:
         else:
             self.fe = RxFrontEnd(ctx, S, self.lpf, max_chunks=K)
         if self.group:
-            self.grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
+            self.grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_EQUALIZE if self.refchain else pkg.TSCLEG_DEMOD, start=(0, 0))
             for a in range(S):
                 self.grp.control(a, "CMD SETTSC %d" % self.tsc)
                 for tn in range(8):
@@ -376,6 +388,14 @@ class Config4:
         return self.S * self.K * self.per_chunk / (156.25 * self.sps)     # bursts' worth of samples per step
 
     def describe(self, world):
+        if self.refchain:
+            return {"workload": "config4 (reference chain): %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), "
+                                "unUSRPify + polyphaseResampleVector 65:96 with the reference's createLPF(., 961, 65) table (sps 1) + "
+                                "157/156/156/156 slicing + the Transceiver group on its equalising leg: expectedCorrType per (ARFCN, slot) "
+                                "(combination V on TN 0 of every 8th ARFCN), adaptive energy threshold, per-slot channel cache, "
+                                "analyzeTrafficBurst + designDFE + equalizeBurst to %d soft bits" % (self.S, self.K, NSOFT),
+                    "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
+                    "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
         return {"workload": "config4: %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), unUSRPify + "
                             "polyphase resample 260:96 (961-tap Kaiser LPF) + 157/156/156/156 slicing + TSC %d detect (thr 3.0) + demod to "
                             "%d soft bits; %s" % (self.S, self.K, self.tsc, NSOFT,
@@ -406,7 +426,7 @@ class Config4:
     def pipelined(self, steps):
         """Side measurement (never `value`): the same steps with trxsig_trxgroup_set_pipelined -- a step returns without waiting
         for its state machine, which replays on the group's side stream while the next step's detectors run."""
-        if not self.group:
+        if not self.group or self.refchain:
             return None
         import torch
         self.grp.set_pipelined(True)
@@ -429,8 +449,29 @@ class Config4:
         import numpy as np
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oraclebind
-        o = oraclebind.Oracle(self.sps)
         nchunks = min(self.KT, 125)
+        if self.refchain:
+            # the reference itself, equalising leg: resample chunk by chunk + ref_eq_batch (energyDetect, analyzeTrafficBurst with the
+            # channel, designDFE, equalizeBurst for EVERY burst -- the per-slot channel cache of Transceiver.cpp would skip most
+            # designDFE calls; the sigProcLib work per burst is otherwise the same), streams shared out over the host's cores
+            import refbind
+            if not refbind.available():
+                return {"cpu_baseline": None}
+            import subprocess
+            import tempfile
+            cores = host_cores()
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "sample.npz")
+                np.savez(path, iq=self.iq[:, :nchunks * 864].cpu().numpy(), lpf=np.asarray(self.lpf, np.float32), sps=self.sps, tsc=self.tsc,
+                         kind="config4", equalize=1)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
+                                   capture_output=True, text=True, timeout=300)
+                try:
+                    return {"cpu_baseline": json.loads(r.stdout.strip().splitlines()[-1])}
+                except Exception as e:
+                    sys.stderr.write("reference cpu baseline unavailable: %r %s\n" % (e, r.stderr[-300:]))
+                    return {"cpu_baseline": None}
+        o = oraclebind.Oracle(self.sps)
         n_bursts = 0
         t0 = time.perf_counter()
         for s in range(self.S):                               # one stream after the other until ~10 s of CPU work are done
@@ -579,6 +620,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--unfused-frontend", action="store_true", help="config4: push + pop + detect through the resampled complex float32 stream instead of the fused front end")
     ap.add_argument("--wideband", type=int, default=0, help="config4: the channeliser -- streams / N wideband streams at 3.2 MS/s carrying N ARFCNs each (N <= 8)")
+    ap.add_argument("--reference-chain", action="store_true", help="config4: the reference's own configuration -- sps 1, its createLPF(., 961, 65) "
+                    "table, the equalising Transceiver leg -- through the group on a push / pop front end")
     ap.add_argument("--stateless-frontend", action="store_true", help="config4: trxsig_rxfe_push_detect_demod_normal (TSC on every slot, fixed thresholds) instead of the Transceiver group")
     ap.add_argument("--repeats", type=int, default=None, help="extra timed repetitions of the K steps after the official one (min / median are reported beside `value`); default 4 when --steps < 100, else 0")
     ap.add_argument("--workload", choices=["normal", "rach", "config4", "config5"], default="normal",
@@ -732,7 +775,7 @@ def main():
         achieved = per_unit * launch_units / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": wl.kernel_names.get(dom[0], dom[0]), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(wl.kernel_names.get(dom[0], dom[0]), launch_units),
+                "traffic": None if getattr(wl, "refchain", False) else measured_traffic(wl.kernel_names.get(dom[0], dom[0]), launch_units),
                 "alg_bytes_per_launch": int(per_unit * launch_units), "avg_kernel_ms": round(avg_ms, 4),
                 "alg_bytes_per_unit": per_unit,
                 "pipeline_achieved": round(wl.alg_bytes * units * args.steps / (ev_ms * 1e-3) / 1e9, 1),

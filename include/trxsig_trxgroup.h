@@ -83,9 +83,18 @@ int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_
  * trxsig_rxfe_push_detect_demod_normal.  The detectors -- midamble and access-burst alike, by each slot's expectedCorrType --
  * compute their samples from the int16 chunks; the resampled stream never exists in memory.  The push completes *n_slots
  * timeslots (possibly 0); the first one is at time (fn, the front end's current TN) -- the GSM clock is the caller's
- * (radioInterface.cpp:364-366).  Needs the TRXSIG_TSCLEG_DEMOD leg. */
+ * (radioInterface.cpp:364-366).
+ * That fused form is the 260 : 96 resampler (sps 4) feeding the TRXSIG_TSCLEG_DEMOD leg.  A group on the equalising leg, or at
+ * another sps -- the reference's own configuration is sps 1 with the equaliser -- takes the same call through the resampled
+ * stream instead: trxsig_rxfe_push + trxsig_rxfe_pop + trxsig_trxgroup_pull_bursts on what the pop lists (such a front end is
+ * then a push / pop one).  Same results where both routes exist. */
 int trxsig_trxgroup_pull_rxfe(trxsig_trxgroup *g, trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int fn, int *n_slots,
                               trxsig_trxgroup_result *res);
+
+/* trxsig_trxgroup_pull on LISTED bursts: burst t of ARFCN a is entry a*n_per_arfcn + t of d_offset / d_length (samples into
+ * d_samples) -- the layout trxsig_rxfe_pop hands out, 157-156-156-156 lengths included; (fn, tn) = the time of burst 0. */
+int trxsig_trxgroup_pull_bursts(trxsig_trxgroup *g, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
+                                int n_per_arfcn, int fn, int tn, trxsig_trxgroup_result *res);
 
 /* What the caller of pullRadioVector sees, on the host, for the last pull (synchronises the stream): entry t*n_arfcn + a
  *   h_valid   1 where a SoftVector came back

@@ -25,6 +25,8 @@ struct TrxRxfePush { TrxRxGen gen; int nb, tn0, n_streams; };
 int trx_rxfe_fused_begin(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, TrxRxfePush *out);
 int trx_rxfe_fused_end(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, const TrxRxfePush &p);
 trxsig_ctx *trx_rxfe_ctx(trxsig_rxfe *fe);
+int trx_rxfe_streams(const trxsig_rxfe *fe);
+int trx_rxfe_next_tn(const trxsig_rxfe *fe);
 // Transceiver group (trxsig_trxgroup.cpp), equalising TSC leg (sps = 1):
 //   estimate: analyzeTrafficBurst(requestChannel) + scaleVector(chan, 1/amp) + designDFE(chan, d_snr[b], 7) for the bursts with
 //     d_enable[b] != 0 only (Transceiver.cpp:341-349); nothing is written for the others.  Detection threshold 3.0 (:331).

@@ -286,6 +286,8 @@ int trxsig_rxfe_pop(trxsig_rxfe *fe, const trxsig_c32 **d_samples, const int32_t
 }  // extern "C"
 
 trxsig_ctx *trx_rxfe_ctx(trxsig_rxfe *fe) { return fe ? fe->c : nullptr; }
+int trx_rxfe_streams(const trxsig_rxfe *fe) { return fe ? fe->S : 0; }
+int trx_rxfe_next_tn(const trxsig_rxfe *fe) { return fe ? fe->tn : 0; }   // TN of the next burst a pop will cut
 
 // the bursts a fused push completes and where the kernels find their samples
 int trx_rxfe_fused_begin(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, TrxRxfePush *out) {

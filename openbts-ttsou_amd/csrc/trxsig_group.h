@@ -36,6 +36,8 @@ struct TrxGroupExpand {
   long long slot_stride, arfcn_stride, base;               // burst (t, a) starts at sample base + t*slot_stride + a*arfcn_stride
   int rx_nb;                                               // > 0: the bursts are a receive front end's (trxsig_rxgen.h); `off` gets
                                                            // the row's burst index there, a*rx_nb + t, instead of a sample offset
+  const int32_t *src_off, *src_len;                        // non-NULL: the bursts are listed -- burst t of ARFCN a is entry a*src_nb + t
+  int src_nb;                                              // (a receive front end's trxsig_rxfe_pop); strides / fixed_len unused then
   const uint16_t *gid;                                     // [8][S]: which segment column ARFCN a belongs to on timeslot tn
   const int32_t *pos;                                      // [8][S]: its place inside that segment
   const int32_t *seg_base;                                 // [n_slots][G]: first row of the segment, -1 = no correlator (OFF / IDLE)

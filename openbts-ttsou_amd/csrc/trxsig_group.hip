@@ -32,8 +32,13 @@ __global__ __launch_bounds__(256) void k_group_expand(TrxGroupExpand a) {
   int row = -1;
   if (base >= 0) {
     row = base + a.pos[tn * a.S + s];
-    a.off[row] = a.rx_nb > 0 ? s * a.rx_nb + t : (int32_t)(a.base + (long long)t * a.slot_stride + (long long)s * a.arfcn_stride);
-    a.len[row] = a.fixed_len > 0 ? a.fixed_len : (156 + ((tn & 3) == 0)) * a.sps;   // radioInterface.cpp:370-378
+    if (a.src_off) {                                        // listed bursts (a front end's pop)
+      a.off[row] = a.src_off[(size_t)s * a.src_nb + t];
+      a.len[row] = a.src_len[(size_t)s * a.src_nb + t];
+    } else {
+      a.off[row] = a.rx_nb > 0 ? s * a.rx_nb + t : (int32_t)(a.base + (long long)t * a.slot_stride + (long long)s * a.arfcn_stride);
+      a.len[row] = a.fixed_len > 0 ? a.fixed_len : (156 + ((tn & 3) == 0)) * a.sps;   // radioInterface.cpp:370-378
+    }
   }
   a.rowmap[g] = row;
 }

@@ -230,6 +230,7 @@ struct PullSource {
   int64_t slot_stride = 0, arfcn_stride = 0;
   int burst_len = 0;
   const TrxRxGen *gen = nullptr;
+  const int32_t *d_off = nullptr, *d_len = nullptr;        // listed bursts: burst t of ARFCN a = entry a*n_slots + t
 };
 
 // every replay still in flight on the side stream (pipelined mode) is waited for by the context's stream
@@ -314,6 +315,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   TrxGroupExpand ex = {};
   ex.S = S; ex.n_slots = n_slots; ex.tn0 = tn; ex.sps = sps; ex.fixed_len = burst_len; ex.G = G;
   ex.slot_stride = src.slot_stride; ex.arfcn_stride = src.arfcn_stride; ex.base = 0; ex.rx_nb = src.gen ? src.gen->nb : 0;
+  ex.src_off = src.d_off; ex.src_len = src.d_len; ex.src_nb = n_slots;
   ex.gid = g->d_gid; ex.pos = g->d_pos; ex.seg_base = W.seg.p; ex.rowmap = W.rowmap.p; ex.off = W.off.p; ex.len = W.len.p;
   G_HIP(g, trx_launch_group_expand(st, ex));
 
@@ -431,14 +433,42 @@ int trxsig_trxgroup_pull(trxsig_trxgroup *g, const trxsig_c32 *d_samples, int64_
   return pull_core(g, src, fn, tn, n_slots, res);
 }
 
+int trxsig_trxgroup_pull_bursts(trxsig_trxgroup *g, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length,
+                                int n_per_arfcn, int fn, int tn, trxsig_trxgroup_result *res) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  if (!d_samples || !d_offset || !d_length || n_per_arfcn <= 0 || fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_bursts: bad argument", hipSuccess);
+  PullSource src;
+  src.d_samples = d_samples; src.d_off = d_offset; src.d_len = d_length;
+  return pull_core(g, src, fn, tn, n_per_arfcn, res);
+}
+
 int trxsig_trxgroup_pull_rxfe(trxsig_trxgroup *g, trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, int fn, int *n_slots,
                               trxsig_trxgroup_result *res) {
   if (!g) return TRXSIG_EINVAL;
   trxsig_ctx *c = g->c;
   if (!fe || !n_slots || fn < 0 || fn >= kHyperframe) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: bad argument", hipSuccess);
   if (trx_rxfe_ctx(fe) != c) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: the front end lives on another context", hipSuccess);
-  if (g->leg != TRXSIG_TSCLEG_DEMOD || g->sps != 4)
-    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: the fused front end needs sps == 4 and the demodulating TSC leg", hipSuccess);
+  if (g->leg != TRXSIG_TSCLEG_DEMOD || g->sps != 4) {
+    // The fused front end is the 260 : 96 resampler feeding the demodulating leg.  Everything else -- the equalising leg at one
+    // sample per symbol, the reference's own configuration -- goes through the resampled stream: push, pop, and the group on the
+    // bursts the pop lists (same results as the fused form where both exist: tests/test_gpu_trxgroup.py).
+    if (trx_rxfe_streams(fe) != g->S) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: one stream per ARFCN, please", hipSuccess);
+    G_LIB(trxsig_rxfe_push(fe, d_iq, n_chunks));
+    const trxsig_c32 *xs = nullptr;
+    const int32_t *off = nullptr, *len = nullptr;
+    const int tn0 = trx_rxfe_next_tn(fe);
+    int nb = 0;
+    G_LIB(trxsig_rxfe_pop(fe, &xs, &off, &len, nullptr, 0, &nb));
+    *n_slots = nb;
+    if (nb <= 0) {
+      g->have = false;
+      if (res) std::memset(res, 0, sizeof *res);
+      return TRXSIG_OK;
+    }
+    return trxsig_trxgroup_pull_bursts(g, xs, off, len, nb, fn, tn0, res);
+  }
   TrxRxfePush p;
   G_LIB(trx_rxfe_fused_begin(fe, d_iq, n_chunks, &p));
   if (p.n_streams != g->S) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_pull_rxfe: one stream per ARFCN, please", hipSuccess);

@@ -21,8 +21,9 @@ def kind_of(d):
     return str(d["kind"]) if "kind" in d.files else "normal"
 
 
-def config4_stream(r, iq, lpf, sps, tsc):
-    """One stream through the reference: returns the number of bursts it cut and detected + demodulated."""
+def config4_stream(r, iq, lpf, sps, tsc, equalize=False):
+    """One stream through the reference: returns the number of bursts it cut and detected + demodulated (equalize: the
+    equalised leg, ref_eq_batch, instead of analyzeTrafficBurst + demodulateBurst)."""
     nchunks = iq.shape[0] // 864
     hist = np.zeros(192, np.complex64)
     rcv = []
@@ -36,7 +37,10 @@ def config4_stream(r, iq, lpf, sps, tsc):
     while xs.size - pos > (156 + (tn % 4 == 0)) * sps:
         n = (156 + (tn % 4 == 0)) * sps; lens.append(n); pos += n; tn = (tn + 1) % 8
     lens = np.array(lens, np.int32); off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
-    r.normal_batch(xs, off, lens, tsc)
+    if equalize:
+        r.eq_batch(xs, off, lens, tsc, 3.0, 0.0, 4)
+    else:
+        r.normal_batch(xs, off, lens, tsc)
     return len(lens)
 
 
@@ -47,11 +51,12 @@ def worker(path, lo, hi, reps, start, done):
     r = refbind.Ref(int(d["sps"]), variant="52m" if kind == "config5" else "")
     if kind == "config4":
         iq, lpf, sps, tsc = np.ascontiguousarray(d["iq"][lo:hi]), d["lpf"], int(d["sps"]), int(d["tsc"])
-        config4_stream(r, iq[0][:864 * 4], lpf, sps, tsc)  # warm
+        eq = "equalize" in d.files and int(d["equalize"]) != 0
+        config4_stream(r, iq[0][:864 * 4], lpf, sps, tsc, eq)  # warm
         start.wait()
         for _ in range(reps):
             for s in range(hi - lo):
-                config4_stream(r, iq[s], lpf, sps, tsc)
+                config4_stream(r, iq[s], lpf, sps, tsc, eq)
         done.wait()
         return
     x, off, length, tsc = d["x"], d["off"][lo:hi], d["length"][lo:hi], int(d["tsc"])
@@ -79,13 +84,15 @@ def main():
         iq = d["iq"]
         S = iq.shape[0]
         P = min(P, S)
-        config4_stream(r, iq[0][:864 * 4], d["lpf"], int(d["sps"]), int(d["tsc"]))
+        eq = "equalize" in d.files and int(d["equalize"]) != 0
+        config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]), eq)        # warm: the whole stream once
         t0 = time.perf_counter()
-        nb1 = config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]))
+        nb1 = config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]), eq)
         per_burst = (time.perf_counter() - t0) / nb1
         B = nb1 * S                                          # bursts per pass over all streams
         units, what = S, ("%d streams x %d chunks (%d bursts): unUSRPify + polyphaseResampleVector chunk by chunk + slicing + "
-                          "analyzeTrafficBurst + demodulateBurst" % (S, iq.shape[1] // 864, B))
+                          "%s" % (S, iq.shape[1] // 864, B, "energyDetect + analyzeTrafficBurst(requestChannel) + designDFE + equalizeBurst"
+                                  if eq else "analyzeTrafficBurst + demodulateBurst"))
     else:
         B = len(d["off"])
         # single-process calibration on the first 512 (normal) / 128 (access) bursts

@@ -491,3 +491,76 @@ def test_pipelined_mode_on_the_fused_front_end(pkg):
         assert ra["valid"].sum() > 1000
         for key in ra:
             assert np.array_equal(ra[key], rb[key], equal_nan=True), key
+
+
+def test_group_on_a_front_end_at_one_sample_per_symbol(pkg, golden):
+    """The reference's own configuration -- RadioInterface's 65 : 96 resampler with ITS filter (createLPF(., 961, 65): the
+    reference table, tests/golden/resample.npz) at one sample per symbol, Transceiver with the equaliser -- through
+    trxsig_trxgroup_pull_rxfe, which there goes through the resampled stream (push + pop + trxsig_trxgroup_pull_bursts on the
+    listed bursts): every output equals push / pop on a second front end, the bursts repacked into cells on the host and
+    trxsig_trxgroup_pull; and both normal and access bursts came back equalised / demodulated."""
+    import torch
+    from openbts_ttsou_amd.frontend import RxFrontEnd, OUTCHUNK
+    sps, S, fn0, tn0 = 1, 24, 300, 2
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    h = pkg.TrxHost(sps, 0)
+    lpf = h.create_lpf(golden("resample.npz")["sendLPF_961_raw"], 65.0)        # radioInterface.cpp:230-234 at sps 1
+    h.close()
+    iq, nchunks = make_scheduled_streams(sps, S, 8 * 60, fn0, tn0, seed=33)
+    d_iq = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+    keys = ("valid", "soft", "rssi", "timing", "threshold")
+
+    def clock(t):
+        return (fn0 + (tn0 + t) // 8) % tm.HYPERFRAME, (tn0 + t) % 8
+
+    def group():
+        g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_EQUALIZE, start=(fn0, tn0))
+        for a in range(S):
+            configure(lambda c, a=a: g.control(a, c), a)
+        return g
+    ga, fea = group(), RxFrontEnd(ctx, S, lpf, max_chunks=9, start_tn=tn0)
+    got_a = {k: [] for k in keys}
+    c, t, sizes, k = 0, 0, (1, 3, 9, 2, 5), 0
+    while c < nchunks:
+        n = min(sizes[k % len(sizes)], nchunks - c); k += 1
+        ns, res = ga.pull_rxfe(fea, d_iq[:, c * OUTCHUNK:(c + n) * OUTCHUNK], clock(t)[0])
+        c += n
+        if ns:
+            assert res.n_slots == ns
+            r = ga.collect()
+            for key in keys:
+                got_a[key].append(r[key])
+            t += ns
+    total_a = t
+    gb, feb = group(), RxFrontEnd(ctx, S, lpf, max_chunks=4, start_tn=tn0)
+    got_b = {k: [] for k in keys}
+    cell = CELL_SYM * sps
+    c = t = 0
+    while c < nchunks:
+        n = min(4, nchunks - c)
+        feb.push_chunk(d_iq[:, c * OUTCHUNK:(c + n) * OUTCHUNK]); c += n
+        popped = feb.pop_bursts()
+        if popped is None:
+            continue
+        x, off, length, _ = popped
+        nb = off.numel() // S
+        xh = x.cpu().numpy().view(np.complex64).ravel(); offh = off.cpu().numpy(); lenh = length.cpu().numpy()
+        cells = np.zeros((nb, S, cell), np.complex64)
+        for s in range(S):
+            for j in range(nb):
+                i = s * nb + j
+                cells[j, s, :lenh[i]] = xh[offh[i]:offh[i] + lenh[i]]
+        dx = torch.from_numpy(cells.view(np.float32).reshape(-1)).cuda()
+        fn, tn = clock(t)
+        gb.pull(dx, S * cell, cell, fn, tn, nb)
+        r = gb.collect()
+        for key in keys:
+            got_b[key].append(r[key])
+        t += nb
+    assert t == total_a and t > 400
+    A = {k: np.concatenate(v) for k, v in got_a.items()}
+    B = {k: np.concatenate(v) for k, v in got_b.items()}
+    for key in keys:
+        assert np.array_equal(A[key], B[key], equal_nan=True), key
+    assert A["valid"].sum() > 0.2 * A["valid"].size
+    ga.close(); gb.close(); ctx.close()

@@ -20,4 +20,5 @@ run config4 --workload config4
 run config4_512 --workload config4 --streams 512 --chunks 25 --no-cpu-baseline
 run config4_stateless --workload config4 --stateless-frontend --no-cpu-baseline
 run config4_wideband --workload config4 --wideband 8 --no-cpu-baseline
+run config4_reference_chain --workload config4 --reference-chain
 run config5 --workload config5
