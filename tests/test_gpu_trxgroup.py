@@ -563,4 +563,4 @@ def test_group_on_a_front_end_at_one_sample_per_symbol(pkg, golden):
     for key in keys:
         assert np.array_equal(A[key], B[key], equal_nan=True), key
     assert A["valid"].sum() > 0.2 * A["valid"].size
-    ga.close(); gb.close(); ctx.close()
+    ga.close(); gb.close(); fea.close(); feb.close(); ctx.close()   # (the front ends before their context)

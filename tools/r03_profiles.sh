@@ -14,9 +14,10 @@ cd /tmp
 wl_args() { case $1 in
   config4_stateless) echo "--workload config4 --stateless-frontend";;
   config4_wideband) echo "--workload config4 --wideband 8";;
+  config4_reference_chain) echo "--workload config4 --reference-chain";;
   *) echo "--workload $1";; esac; }
 if [ $WHAT != pmc ]; then
-for W in normal rach config4 config4_stateless config4_wideband config5; do
+for W in normal rach config4 config4_stateless config4_wideband config4_reference_chain config5; do
   echo "== stats $W"
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py $(wl_args $W) --steps 200 --no-cpu-baseline --no-fresh > $O/bench_under_rocprof_$W.json 2> $O/stats_$W.err || echo "stats $W failed"
   python3 $R/tools/prof_summary.py $O/stats_$W > $O/kernel_stats_$W.csv
