@@ -61,7 +61,9 @@ enum {
 /* ---- library set-up: sigProcLibSetup / sigProcLibDestroy (sigProcLib.h:110-113) -------------
  * trxsig_create = generateGSMPulse(2,sps) + sigProcLibSetup(sps) + generateRACHSequence +
  * generateMidamble(0..7) (the calls of Transceiver.cpp:62-64, 424, 553), built on the host and
- * uploaded once.  device = HIP device ordinal.  sps in {1,2,4}. */
+ * uploaded once.  device = HIP device ordinal.  sps in {1,2,4}.
+ * trxsig_destroy on a context that front ends, back ends or Transceiver groups (trxsig_frontend.h, trxsig_trxgroup.h) still live
+ * on takes effect when the last of them has been destroyed: such an object never outlives the context it was created on. */
 int  trxsig_abi_version(void);
 int  trxsig_create(trxsig_ctx **out, int device, int sps);
 void trxsig_destroy(trxsig_ctx *ctx);

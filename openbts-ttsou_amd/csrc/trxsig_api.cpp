@@ -73,6 +73,8 @@ struct trxsig_ctx {
   size_t pin_bytes = 0;              // pinned host mirror of the staging area (small host calls: one DMA each way)
   void *h_pin = nullptr;
   // TRXSIG_TUNE_DEMOD_BESIDE: the demodulator on a side stream, from one of two private copies of (flags, amp, TOA)
+  int children = 0;                  // front ends, back ends and groups living on this context (trx_ctx_retain / _release)
+  bool zombie = false;               // trxsig_destroy came while some were alive: the last one to go destroys the context
   int demod_beside = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_pk[2] = {nullptr, nullptr}, ev_dm[2] = {nullptr, nullptr};
@@ -327,8 +329,19 @@ int trxsig_create_from_tables(trxsig_ctx **out, int device, const void *d_blob, 
   return TRXSIG_OK;
 }
 
+static void destroy_now(trxsig_ctx *c);
+extern "C++" {
+void trx_ctx_retain(trxsig_ctx *c) { if (c) c->children++; }
+void trx_ctx_release(trxsig_ctx *c) {
+  if (c && --c->children == 0 && c->zombie) destroy_now(c);
+}
+}
 void trxsig_destroy(trxsig_ctx *c) {
   if (!c) return;
+  if (c->children > 0) { c->zombie = true; return; }        // objects created on it are still alive: they keep it until they go
+  destroy_now(c);
+}
+static void destroy_now(trxsig_ctx *c) {
   {
     DeviceGuard g(c->device);
     if (c->d_tables) (void)hipFree(c->d_tables);

@@ -24,6 +24,9 @@ struct trxsig_rxfe;
 struct TrxRxfePush { TrxRxGen gen; int nb, tn0, n_streams; };
 int trx_rxfe_fused_begin(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, TrxRxfePush *out);
 int trx_rxfe_fused_end(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, const TrxRxfePush &p);
+// an object that lives on a context keeps it alive: trxsig_destroy on a context with such objects takes effect when the last is gone
+void trx_ctx_retain(trxsig_ctx *c);
+void trx_ctx_release(trxsig_ctx *c);
 trxsig_ctx *trx_rxfe_ctx(trxsig_rxfe *fe);
 int trx_rxfe_streams(const trxsig_rxfe *fe);
 int trx_rxfe_next_tn(const trxsig_rxfe *fe);

@@ -87,7 +87,7 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create: bad argument", hipSuccess);
   trxsig_rxfe *fe = new (std::nothrow) trxsig_rxfe;
   if (!fe) return TRXSIG_ENOMEM;
-  fe->c = c; fe->S = n_streams; fe->sps = trxsig_sps(c); fe->P = 65 * fe->sps; fe->L = L; fe->swap = swap_iq != 0;
+  fe->c = c; trx_ctx_retain(c); fe->S = n_streams; fe->sps = trxsig_sps(c); fe->P = 65 * fe->sps; fe->L = L; fe->swap = swap_iq != 0;
   fe->max_chunks = max_chunks; fe->tn = start_tn;
   fe->n_in = TRXSIG_OUTHISTORY + TRXSIG_OUTCHUNK;
   fe->n_out = trxsig_resample_out_len(fe->n_in, fe->P, TRXSIG_OUTRATE);
@@ -209,6 +209,7 @@ void trxsig_rxfe_destroy(trxsig_rxfe *fe) {
     (void)hipFree(fe->d_rcv); (void)hipFree(fe->d_tmp); (void)hipFree(fe->d_hist); (void)hipFree(fe->d_lpf); (void)hipFree(fe->d_idx);
     (void)hipFree(fe->d_keep); (void)hipFree(fe->d_tpb);
   }
+  trx_ctx_release(fe->c);
   delete fe;
 }
 
@@ -370,7 +371,7 @@ int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *c, int n_streams, int max_
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_create: bad argument", hipSuccess);
   trxsig_txbe *be = new (std::nothrow) trxsig_txbe;
   if (!be) return TRXSIG_ENOMEM;
-  be->c = c; be->S = n_streams; be->sps = trxsig_sps(c); be->Q = 65 * be->sps; be->L = L; be->gain = gain;
+  be->c = c; trx_ctx_retain(c); be->S = n_streams; be->sps = trxsig_sps(c); be->Q = 65 * be->sps; be->L = L; be->gain = gain;
   be->inchunk = 9 * be->Q; be->inhist = 2 * be->Q; be->max_bursts = max_bursts;
   // room for one chunk of left-over plus one push of the longest bursts
   const long long cap = (long long)be->inchunk + (long long)max_bursts * 157 * be->sps;
@@ -407,6 +408,7 @@ void trxsig_txbe_destroy(trxsig_txbe *be) {
     (void)hipFree(be->d_send[0]); (void)hipFree(be->d_send[1]); (void)hipFree(be->d_lpf); (void)hipFree(be->d_iq); (void)hipFree(be->d_meta);
     (void)hipFree(be->d_ring); (void)hipFree(be->d_rgain); (void)hipFree(be->d_tab);
   }
+  trx_ctx_release(be->c);
   delete be;
 }
 

@@ -153,7 +153,7 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_create: the equalising TSC leg (Transceiver.cpp:391-396) needs sps == 1", hipSuccess);
   trxsig_trxgroup *g = new (std::nothrow) trxsig_trxgroup;
   if (!g) return TRXSIG_ENOMEM;
-  g->c = c; g->S = n_arfcn; g->sps = trxsig_sps(c); g->leg = tsc_leg;
+  g->c = c; trx_ctx_retain(c); g->S = n_arfcn; g->sps = trxsig_sps(c); g->leg = tsc_leg;
   g->ctl.resize((size_t)n_arfcn);
   Guard gd(trxsig_device(c));
   const int S = n_arfcn;
@@ -195,6 +195,7 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
     g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
   }
+  trx_ctx_release(g->c);
   delete g;
 }
 

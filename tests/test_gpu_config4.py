@@ -239,3 +239,27 @@ def test_fused_front_end_argument_checks(golden):
     nb, tn = fe4.push_detect_demod(iq[:, :2 * OUTCHUNK], 0, o["flags"], o["amp"], o["toa"], o["soft"], nsoft=148, soft_stride=157)
     torch.cuda.synchronize()
     assert nb == 7 and list(tn) == [0, 1, 2, 3, 4, 5, 6] and not (o["flags"][:2 * nb] & pkg.F_DETECT).any()
+
+
+@pytest.mark.gpu
+def test_objects_keep_their_context_alive():
+    """trxsig_destroy on a context that a front end, a back end or a group still lives on takes effect when the last of them is
+    gone (the Python wrappers' destructors run in any order): destroying in the 'wrong' order must not touch freed memory, and the
+    library keeps working afterwards (a stale hipSetDevice error from a freed context once poisoned an unrelated test)."""
+    import torch
+    pkg = _pkg.load()
+    from openbts_ttsou_amd.frontend import RxFrontEnd, TxBackEnd
+    lpf = synth.design_lpf(961, 260)
+    ctx = pkg.TrxSig(4, 0); ctx.use_torch_stream()
+    fe = RxFrontEnd(ctx, 2, lpf, max_chunks=2)
+    be = TxBackEnd(ctx, 2, synth.design_lpf(651, 96), max_bursts=8)
+    g = pkg.TrxGroup(ctx, 2, tsc_leg=pkg.TSCLEG_DEMOD)
+    ctx.close()                                            # first the context ...
+    iq = torch.zeros(2, 864, 2, dtype=torch.int16, device="cuda:0")
+    fe.push_chunk(iq)                                      # ... which is still there for its objects
+    assert fe.pop_bursts() is not None
+    g.close(); be.close(); fe.close()                      # the last one to go takes the context with it
+    ctx2 = pkg.TrxSig(4, 0); ctx2.use_torch_stream()
+    fe2 = RxFrontEnd(ctx2, 1, lpf, max_chunks=1)
+    fe2.push_chunk(iq[:1]); torch.cuda.synchronize()
+    fe2.close(); ctx2.close()
