@@ -143,11 +143,14 @@ __global__ __launch_bounds__(256) void k_eq_delay(const TrxTables *__restrict__ 
 #pragma unroll
   for (int i = 0; i < OPL; i++) S[OPL * hl + i] = y[i];
   wave_lds_fence();
+  // The whole row is written: the delayed burst's N samples, zeros from N to the row's end (and a row of zeros for a burst the
+  // gate refused).  The equaliser's feed-forward sums then meet a zero SAMPLE wherever the reference skips a term beyond the
+  // burst -- +0 + (+-0) = +0, the same value -- and carry no range check per tap (k_eq_dfe2's producer).
   cx *out = xd + (size_t)(live ? b : 0) * xstride;
 #pragma unroll
   for (int i = 0; i < OPL; i++) {
     const int m = hl + 16 * i;
-    if (m < N) out[m] = S[m];
+    if (live && m < xstride) out[m] = m < N ? S[m] : mk(0, 0);
   }
 }
 
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
 #pragma unroll
     for (int j = 0; j < 7; j++) w[j] = pk(w_in[tb * 7 + j]);
 #pragma unroll
-    for (int m = 0; m < 6; m++) win[m] = pk((5 - m < N) ? x[5 - m] : mk(0, 0));   // win[m] = x[16 u + 5 - m]
+    for (int m = 0; m < 6; m++) win[m] = pk(x[5 - m]);       // win[m] = x[16 u + 5 - m] (the row holds zeros from N on: k_eq_delay)
     // sample tile u: a = 16 u + 6 + c, c = 0..15 (output k = 16 u + i needs x[k + 6 - j]: FULL_SPAN keeps [6, 6+N), :1352-1356)
     auto load_tile = [&](int u, cx (&v)[16]) {
 #pragma unroll
@@ -736,15 +739,14 @@ __global__ __launch_bounds__(128) void k_eq_dfe2(const TrxTables *__restrict__ T
       for (int i = 0; i < 16; i++) xa[i] = pk(xt[lane][i]);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int k = EQ_TK * u + i;
         v2f d = pk(mk(0, 0));
 #pragma unroll
         for (int j = 0; j < 7; j++) {                       // convolve general branch: sum += a[t-j]*b[j], t = k+6
-          const int ai = k + 6 - j;
           const v2f xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
-          // (a term outside the burst is skipped in the reference; here it is added as the product with a zero SAMPLE
-          // instead: x is 0 there, the sum starts at +0 and +0 + (+-0) = +0, so the value is the same -- and no branch)
-          d = pk_cadd(d, pk_cmul((ai >= 0 && ai < N) ? xv : pk(mk(0, 0)), w[j]));
+          // (a term beyond the burst is skipped in the reference; here it is added as the product with a zero SAMPLE instead --
+          // k_eq_delay wrote zeros from N to the end of the row, the tile loader zeros beyond it --: the sum starts at +0 and
+          // +0 + (+-0) = +0, so the value is the same, with no branch and no range check; k + 6 - j >= 0 always)
+          d = pk_cadd(d, pk_cmul(xv, w[j]));
         }
         fft[u & 1][lane][i] = mk(d.x, d.y);
       }
