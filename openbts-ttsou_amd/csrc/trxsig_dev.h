@@ -43,6 +43,46 @@ __device__ __forceinline__ float norm2(cx x) { return x.i * x.i + x.r * x.r; }  
 __device__ __forceinline__ cx cinv(cx x) { float n = norm2(x); return mk(x.r / n, -x.i / n); }  // Complex.h:154-160
 __device__ __forceinline__ cx cdiv(cx x, cx a) { return cmul(x, cinv(a)); }               // Complex.h:85
 
+// Whole-wave reductions without the LDS crossbar: four DPP steps inside each row of 16 lanes (lane ^ 1, lane ^ 2, the
+// row's half mirror, the row's mirror: every lane then holds its row's result), the four row results through readlane and
+// three more combines.  A __shfl_xor butterfly is six ds_bpermute round trips (~100+ cycles each on a wave that has little
+// company); this is ~0.1 k cycles.  The order of a sum differs from the butterfly's: only for values whose order is free.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float wave_sum_any_order(float v) {          // the total, in every lane
+  v += dpp_f<0xB1>(v);                                      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                                      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);                                     // row_half_mirror
+  v += dpp_f<0x140>(v);                                     // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return ((r0 + r1) + r2) + r3;
+}
+// argmax of (P, T) over the wave with the rule "larger P wins; equal P: the smaller valid T (T >= 0) wins"; result in every lane
+__device__ __forceinline__ void argmax_take(float &P, int &T, float oP, int oT) {
+  const bool take = (oP > P) || (oP == P && oT >= 0 && (T < 0 || oT < T));
+  P = take ? oP : P;
+  T = take ? oT : T;
+}
+__device__ __forceinline__ void wave_argmax(float &P, int &T) {
+  argmax_take(P, T, dpp_f<0xB1>(P), dpp_i<0xB1>(T));
+  argmax_take(P, T, dpp_f<0x4E>(P), dpp_i<0x4E>(T));
+  argmax_take(P, T, dpp_f<0x141>(P), dpp_i<0x141>(T));
+  argmax_take(P, T, dpp_f<0x140>(P), dpp_i<0x140>(T));
+  float bp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P), 0));
+  int bt = __builtin_amdgcn_readlane(T, 0);
+#pragma unroll
+  for (int r = 16; r < 64; r += 16)
+    argmax_take(bp, bt, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P), r)), __builtin_amdgcn_readlane(T, r));
+  P = bp; T = bt;
+}
+
 // Packed float32 pairs (v_pk_mul_f32 / v_pk_add_f32: both halves are separate IEEE operations, nothing is fused).  Worth it
 // only where ONE wave's instruction count is the limit (the decision-feedback recursion: a single wave per 64 bursts issues
 // an instruction every ~5 cycles whatever it is); throughput-bound kernels gain nothing (4.3 cycles per packed instruction).

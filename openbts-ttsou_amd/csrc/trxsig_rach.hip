@@ -600,8 +600,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
 #pragma unroll
     for (int it = 0; it < NIT; it++) ex += norm2(xv[it]);  // burst energy (any order: it only scales an error bound)
   }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) ex += __shfl_xor(ex, m, 64);
+  ex = wave_sum_any_order(ex);                             // (DPP + readlane instead of six ds_bpermute round trips: trxsig_dev.h)
   const float dlt = amp_err * sqrtf(ex) * 1.001f;          // |approximate - reference| correlation amplitude, any lag
   float nrm[R::NEQ];
 #pragma unroll
@@ -612,7 +611,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
     nrm[q] = norm2(v);
   }
   float energy = energy_chain<SPS, 0>(0.0f, nrm);
-  energy = __shfl(energy, 0, 64);
+  energy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(energy), 0));
   const bool energy_ok = energy_thresh < 0.0f || energy / (float)(unsigned)R::NE > energy_thresh * energy_thresh;
   if (!energy_ok) {                                        // Transceiver.cpp:298-306: correlator not run
     if (lane == 0) {
@@ -698,13 +697,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
       if (p > bestP) { bestP = p; bestT = t; }
     }
   }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const float oP = __shfl_xor(bestP, m, 64);
-    const int oT = __shfl_xor(bestT, m, 64);
-    const bool take = (oP > bestP) || (oP == bestP && oT >= 0 && (bestT < 0 || oT < bestT));
-    if (take) { bestP = oP; bestT = oT; }
-  }
+  wave_argmax(bestP, bestT);                               // larger power wins, equal powers: the lower lag
 
   TRX_STAMP();                                             // 3: approximate correlation + argmax done
   // ---- 2. exact recomputation of the contenders ----
@@ -783,13 +776,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
     float bP = valid ? norm2(v) : 0.0f;
     int bT = (valid && bP > 0.0f) ? t : -1;
     if (bT < 0) bP = 0.0f;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      const float oP = __shfl_xor(bP, m, 64);
-      const int oT = __shfl_xor(bT, m, 64);
-      const bool take = (oP > bP) || (oP == bP && oT >= 0 && (bT < 0 || oT < bT));
-      if (take) { bP = oP; bT = oT; }
-    }
+    wave_argmax(bP, bT);                                   // peakDetect's argmax: strict >, the first maximum wins (:672-678)
     M = bT;
     wave_lds_fence();
     if (M >= nb0 + 12 && M <= nb0 + 14) {                  // |M - Ma| <= 1: [M-12, M+11] lies inside the recomputed lags
@@ -828,10 +815,7 @@ __device__ __forceinline__ void rach_fast_burst(const int b, const bool live, co
       for (int i = i0 + lane; i <= last; i += 64) vs[a] += PWw[p + i - pw0];
     }
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {                     // the three reductions side by side
-      const float o0 = __shfl_xor(vs[0], m, 64), o1 = __shfl_xor(vs[1], m, 64), o2 = __shfl_xor(vs[2], m, 64);
-      vs[0] += o0; vs[1] += o1; vs[2] += o2;
-    }
+    for (int a = 0; a < 3; a++) vs[a] = wave_sum_any_order(vs[a]);   // (approximate sums: rach_decide's bracket covers any order)
     if (lane < 4) vsum[(size_t)lane * Bpad + b] = lane == 0 ? vs[0] : (lane == 1 ? vs[1] : (lane == 2 ? vs[2] : dlt));
     TRX_STAMP();                                           // 5: record written
     TRX_STAMP_FLUSH();
