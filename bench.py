@@ -50,12 +50,38 @@ def measured_traffic(kernel, units, key="bursts_per_launch"):
 
 
 def host_cores():
-    cores = min(os.cpu_count() or 1, 16)
+    """Worker count for the CPU baseline: every core this process may run on (scheduler affinity, then the cgroup's CPU quota
+    where one is set -- a GPU box hands a one-GPU job its share of a larger machine), at most 64 so that the default run stays
+    within the box's process budget."""
+    cores = os.cpu_count() or 1
     try:
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    return cores
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(cores, 64))
+
+
+def host_info():
+    """What the box is, beside `cores` (the threads actually used): logical CPUs of the machine, CPUs this process may use, model."""
+    info = {"host_logical_cpus": os.cpu_count() or 0}
+    try:
+        info["host_cpus_allowed"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return info
 
 
 # ======================================================================================================================
@@ -331,6 +357,7 @@ class Config4:
             wide = wide * (8000.0 / wide.abs().amax(dim=1, keepdim=True))
             wiq = torch.stack([wide.imag, wide.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()
             self.segs = [wiq[:, i * K * 864 * CW:(i + 1) * K * 864 * CW].contiguous() for i in range(KT // K)]
+            self.wiq, self.CW = wiq, CW
             self.fe = RxFrontEnd(ctx, S // C, self.lpf, max_chunks=K, carrier_freq=self.freqs, rate_factor=CW)
             del wide, lo_c
         else:
@@ -396,6 +423,16 @@ class Config4:
                                 "analyzeTrafficBurst + designDFE + equalizeBurst to %d soft bits" % (self.S, self.K, NSOFT),
                     "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                     "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
+        if self.wide:
+            return {"workload": "config4 (channeliser): %d wideband streams/GPU at 3.2 MS/s x %d carriers 400 kHz apart (= %d ARFCNs), %d chunks of "
+                                "%d int16 I/Q samples per stream per step; per carrier unUSRPify + frequencyShift (table trig) + polyphase "
+                                "resample 260:768 (8001-tap Kaiser LPF) behind a 1536-sample history in ONE kernel into the receive buffers, "
+                                "then 157/156/156/156 slicing (pop) + TSC %d detect (thr 3.0) + demod to %d soft bits through the resampled "
+                                "complex float32 stream; TSC on every slot, fixed thresholds"
+                                % (self.S // self.wide, self.wide, self.S, self.K, 864 * 8, self.tsc, NSOFT),
+                    "streams_per_gpu": self.S, "wideband_streams_per_gpu": self.S // self.wide, "carriers": self.wide,
+                    "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
+                    "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
         return {"workload": "config4: %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), unUSRPify + "
                             "polyphase resample 260:96 (961-tap Kaiser LPF) + 157/156/156/156 slicing + TSC %d detect (thr 3.0) + demod to "
                             "%d soft bits; %s" % (self.S, self.K, self.tsc, NSOFT,
@@ -403,10 +440,7 @@ class Config4:
                                                   "TN 0 of every 8th ARFCN (access-burst slots), combination I elsewhere --, adaptive energy threshold "
                                                   "per ARFCN replayed on the device, the resampled stream never written to HBM" if self.group else
                                                   ("one fused call, the resampled stream never written to HBM, TSC on every slot, fixed thresholds"
-                                                   if self.fused else ("CHANNELISER: %d wideband streams at 3.2 MS/s x %d carriers, frequencyShift + "
-                                                                       "polyphase 260:768 (8001-tap LPF) per carrier in one kernel, then pop + detect"
-                                                                       % (self.S // self.wide, self.wide) if self.wide else
-                                                                       "through the resampled complex float32 stream (push + pop + detect)"))),
+                                                   if self.fused else "through the resampled complex float32 stream (push + pop + detect)")),
                 "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                 "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
 
@@ -466,6 +500,27 @@ class Config4:
                          kind="config4", equalize=1)
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
                                    capture_output=True, text=True, timeout=300)
+                try:
+                    return {"cpu_baseline": json.loads(r.stdout.strip().splitlines()[-1])}
+                except Exception as e:
+                    sys.stderr.write("reference cpu baseline unavailable: %r %s\n" % (e, r.stderr[-300:]))
+                    return {"cpu_baseline": None}
+        if self.wide:
+            # the channeliser's work as the reference's primitives do it: per carrier frequencyShift + polyphaseResampleVector chunk by
+            # chunk, slicing, analyzeTrafficBurst + demodulateBurst -- the real reference, wideband streams shared out over the cores
+            import refbind
+            if not refbind.available():
+                return {"cpu_baseline": None}
+            import subprocess
+            import tempfile
+            cores = host_cores()
+            nch = min(nchunks, 25)                            # a bounded sample: 25 chunks of every wideband stream
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "sample.npz")
+                np.savez(path, iq=self.wiq[:, :nch * 864 * self.CW].cpu().numpy(), lpf=np.asarray(self.lpf, np.float32), sps=self.sps,
+                         tsc=self.tsc, kind="config4", freqs=np.asarray(self.freqs, np.float32), rate_factor=self.CW)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_bench.py"), path, str(cores), "6"],
+                                   capture_output=True, text=True, timeout=600)
                 try:
                     return {"cpu_baseline": json.loads(r.stdout.strip().splitlines()[-1])}
                 except Exception as e:
@@ -633,6 +688,8 @@ def main():
     ap.add_argument("--spec-peak", type=int, default=0, choices=[0, 1, 2],
                     help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
     ap.add_argument("--no-fresh", action="store_true", help="skip the rotating-inputs side measurement")
+    ap.add_argument("--no-lever", action="store_true", help="skip the workload's side measurement of an alternative arrangement (side streams, pipelined mode): "
+                    "a profiler run of the default step then sees that step only")
     ap.add_argument("--generic-taps", action="store_true", help="A/B: correlators without the tap-class specialisation")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank REHEARSAL on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host "
@@ -751,7 +808,7 @@ def main():
     prof_fresh = None
     if fresh is not None and "prof" in fresh:
         prof_fresh = fresh.pop("prof")
-    piped = wl.pipelined(args.steps) if (world == 1 and hasattr(wl, "pipelined")) else None
+    piped = wl.pipelined(args.steps) if (world == 1 and hasattr(wl, "pipelined") and not args.no_lever) else None
     sanity = wl.sanity()
     if rank != 0:
         return
@@ -815,6 +872,8 @@ def main():
         out["rehearsal"] = "all %d ranks shared cuda:0 (gloo collectives): launch-path check, not a scaling number" % world
     if not args.no_cpu_baseline and world == 1:
         out.update(wl.cpu_baseline(args.check))
+        if isinstance(out.get("cpu_baseline"), dict):
+            out["cpu_baseline"].update(host_info())         # `cores` = workers used; these say what the box is
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -355,6 +355,8 @@ inline bool vectorSlicer(signalVector *x) {
   return s.ctx && x && x->size() > 0 &&
          trxsig_elementwise_host(s.ctx, 3, (trxsig_c32 *)x->begin(), (int)x->size(), one, 0) == TRXSIG_OK;
 }
+// (a delay / index beyond +-TRXSIG_MAX_INDEX, infinite or NaN -- the reference's sinc range reduction never returns on those --
+//  is refused by the library: delayVector leaves the vector as it is, interpolatePoint answers (0, 0))
 inline void delayVector(signalVector &wBurst, float delay) {
   State &s = state();
   if (s.ctx && wBurst.size() > 0)

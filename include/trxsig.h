@@ -353,6 +353,12 @@ int trxsig_convolve_batch(trxsig_ctx *ctx, const trxsig_c32 *d_a, const int32_t 
                           int cust_len, trxsig_c32 *d_out, const int32_t *d_out_off);
 int trxsig_convolve_host(trxsig_ctx *ctx, const trxsig_c32 *h_a, int La, const trxsig_c32 *h_b, int Lb, int span, int flags,
                          int correlate, int cust_start, int cust_len, trxsig_c32 *h_out, int out_cap);   /* returns the length */
+/* A delay or an index beyond +-TRXSIG_MAX_INDEX (2^24: a float there has no fractional bits left), an infinity or a NaN is
+ * one the reference's table-sinc range reduction (sigProcLib.cpp:163-188, reached from :573-616 and :639-659) cannot reduce
+ * -- its `arg -= 1` loop no longer changes arg, the call never returns.  The host forms answer TRXSIG_EINVAL before any
+ * launch; the batch forms (the values are on the device) write zeros for such a vector / point.  The device-side reduction
+ * itself is loop-free (csrc/trxsig_dev.h, dev_range_reduce), so no argument can keep a wave running. */
+#define TRXSIG_MAX_INDEX 16777216.0f
 /* delayVector(x, delay): d_out has d_in's layout and must not overlap it */
 int trxsig_delay_vector_batch(trxsig_ctx *ctx, const trxsig_c32 *d_in, const int32_t *d_off, const int32_t *d_len, int B,
                               const float *d_delay, int real_only, trxsig_c32 *d_out);

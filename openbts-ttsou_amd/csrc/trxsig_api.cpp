@@ -1342,6 +1342,8 @@ int trxsig_delay_vector_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const int32
 int trxsig_delay_vector_host(trxsig_ctx *c, trxsig_c32 *h_x, int n, float delay, int real_only) {
   if (!c) return TRXSIG_EINVAL;
   if (!h_x || n <= 0) return fail(c, TRXSIG_EINVAL, "trxsig_delay_vector_host: bad argument");
+  if (!(std::fabs(delay) <= TRXSIG_MAX_INDEX))
+    return fail(c, TRXSIG_EINVAL, "trxsig_delay_vector_host: delay beyond +-2^24 (or not finite): the reference's sinc range reduction would not end");
   DeviceGuard g(c->device);
   Stager s(c);
   const size_t o_x = s.take(8 * (size_t)n), o_y = s.take(8 * (size_t)n), o_m = s.take(16);
@@ -1375,6 +1377,8 @@ int trxsig_interpolate_point_batch(trxsig_ctx *c, const trxsig_c32 *d_in, const 
 int trxsig_interpolate_point_host(trxsig_ctx *c, const trxsig_c32 *h_x, int n, float ix, int real_only, trxsig_c32 *h_out) {
   if (!c) return TRXSIG_EINVAL;
   if (!h_x || n <= 0 || !h_out) return fail(c, TRXSIG_EINVAL, "trxsig_interpolate_point_host: bad argument");
+  if (!(std::fabs(ix) <= TRXSIG_MAX_INDEX))
+    return fail(c, TRXSIG_EINVAL, "trxsig_interpolate_point_host: index beyond +-2^24 (or not finite): the reference's sinc range reduction would not end");
   DeviceGuard g(c->device);
   Stager s(c);
   const size_t o_x = s.take(8 * (size_t)n), o_m = s.take(16), o_out = s.take(8);

@@ -223,12 +223,23 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // sinLookup (sigProcLib.cpp:177-188) and sinc (:567-571) against the uploaded trig table
+// The reference reduces the argument with `while (arg > 1) arg -= 1; while (arg < 0) arg += 1;` -- on a CPU thread a long
+// loop, on the GPU a wave that never ends once |arg| >= 2^24 (arg - 1 == arg).  Here the reduction is its CLOSED FORM, no loop:
+// below 2^24 every subtraction of the first loop is exact (arg and 1 are multiples of ulp(arg) <= 1 and the difference is
+// smaller), so n steps leave arg - n with n = ceil(arg) - 1, one exact subtraction; of the second loop's n = ceil(-arg) steps
+// the first n - 1 are exact for the same reason and the last is ONE rounded addition of 1 to a value in [-1, 0) -- and
+// fl(arg + n) rounds that same exact sum once.  Same values for every argument the reference's loop ends on; for the others
+// (|arg| >= 2^24, infinities, NaN -- the reference never returns) the result is some table entry, the index clamped.
+__device__ __forceinline__ float dev_range_reduce(float arg) {
+  if (arg > 1.0F) arg = arg - (ceilf(arg) - 1.0F);
+  if (arg < 0.0F) arg = arg + ceilf(-arg);
+  return arg;
+}
 __device__ __forceinline__ float dev_sin_lookup(const float *__restrict__ sinT, float x) {
-  float arg = x * (1 / TRX_2PI_F);
-  while (arg > 1.0F) arg -= 1.0F;
-  while (arg < 0.0F) arg += 1.0F;
+  const float arg = dev_range_reduce(x * (1 / TRX_2PI_F));
   const float argT = arg * (float)TRX_TABLESIZE;
-  const int argI = (int)argT;
+  int argI = (int)argT;
+  argI = argI < 0 ? 0 : (argI > TRX_TABLESIZE ? TRX_TABLESIZE : argI);   // (a no-op for every argument the reference's loop ends on)
   const float delta = argT - argI;
   const float iDelta = 1.0F - delta;
   return iDelta * sinT[argI] + delta * sinT[argI + 1];
@@ -238,9 +249,7 @@ __device__ __forceinline__ float dev_sin_lookup(const float *__restrict__ sinT, 
 // a very long time
 #define TRX_FSHIFT_MAXPHASE 25000.0f
 __device__ __forceinline__ cx dev_expj_lookup(const TrxTables *__restrict__ T, float x) {
-  float arg = x * (1 / TRX_2PI_F);
-  for (int it = 0; it < 8192 && arg > 1.0F; it++) arg -= 1.0F;
-  for (int it = 0; it < 8192 && arg < 0.0F; it++) arg += 1.0F;
+  const float arg = dev_range_reduce(x * (1 / TRX_2PI_F));
   const float argT = arg * (float)TRX_TABLESIZE;
   int argI = (int)argT;
   argI = argI < 0 ? 0 : (argI > TRX_TABLESIZE ? TRX_TABLESIZE : argI);   // (only a phase the host refused could get here)

@@ -85,6 +85,10 @@ __global__ __launch_bounds__(256) void k_delay_vector(const TrxTables *__restric
   const cx *x = in + off[v];
   cx *y = out + off[v];
   const float d = delay[v];
+  if (!(fabsf(d) <= TRXSIG_MAX_INDEX)) {                   // beyond what the reference's sinc can reduce (or inf / NaN): zeros (trxsig.h)
+    for (int k = threadIdx.x; k < n; k += 256) y[k] = mk(0, 0);
+    return;
+  }
   const int io = (int)floorf(d);                           // :577
   const float frac = d - (float)io;                        // :578
   const bool filt = fabs((double)frac) > 1e-2;             // :582
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(64) void k_interpolate_point(const TrxTables *__res
                                                           const float *__restrict__ ix, int real_only, cx *__restrict__ out) {
   const int v = blockIdx.x;
   const int n = len[v];
-  if (n <= 0) { if (threadIdx.x == 0) out[v] = mk(0, 0); return; }
+  if (n <= 0 || !(fabsf(ix[v]) <= TRXSIG_MAX_INDEX)) { if (threadIdx.x == 0) out[v] = mk(0, 0); return; }   // (trxsig.h: TRXSIG_MAX_INDEX)
   const cx p = wave_interpolate(T, in + off[v], n, ix[v], real_only != 0, threadIdx.x);
   if (threadIdx.x == 0) out[v] = p;
 }

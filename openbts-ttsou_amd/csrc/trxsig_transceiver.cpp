@@ -132,54 +132,83 @@ int TrxControl::corrType(int chanType, int fn) {            // expectedCorrType 
 }
 int TrxControl::expectedCorrType(int tn, int fn) const { return corrType(chanType[tn & 7], fn); }
 
-int TrxControl::command(const char *buffer, char *response) {   // driveControl (:439-580)
-  char cmdcheck[4] = {0}, command[100] = {0};
+// ---- driveControl (Transceiver.cpp:439-580; SETMAXDELAY: Transceiver52M/Transceiver.cpp:476-486) as a table ----
+// A datagram is `CMD <verb> [int [int]]`; the answer is `RSP <verb> <status> [ints echoed]` (README.TRXManager).  One row per
+// verb: how many integers it takes and a rule that updates the state and says what goes back.  What is on the wire -- the
+// verbs, the status digit, which integers are echoed -- is the contract with TRXManager and follows the reference verb for
+// verb; an integer that is missing from the datagram reads as 0 here (the reference leaves its local uninitialised).
+namespace {
+struct Reply { int status; int n_echo; int echo[2]; bool silent; };
+typedef Reply (*VerbRule)(TrxControl &, const int *);
+Reply rule_poweroff(TrxControl &, const int *) { return {0, 0, {0, 0}, false}; }          // answers 0 and leaves the radio as it is (:472-475)
+Reply rule_poweron(TrxControl &c, const int *) {                                           // refused until both frequencies are set (:476-488)
+  if (!c.txFreq || !c.rxFreq) return {1, 0, {0, 0}, false};
+  if (!c.on) { c.power = -20; c.on = true; }
+  return {0, 0, {0, 0}, false};
+}
+Reply rule_setpower(TrxControl &c, const int *a) {                                        // only while on (:489-500)
+  if (!c.on) return {1, 1, {a[0], 0}, false};
+  c.power = a[0];
+  return {0, 1, {a[0], 0}, false};
+}
+Reply rule_adjpower(TrxControl &c, const int *a) {                                        // echoes the resulting power (:501-512)
+  if (!c.on) return {1, 1, {c.power, 0}, false};
+  c.power += a[0];
+  return {0, 1, {c.power, 0}, false};
+}
+Reply rule_rxtune(TrxControl &c, const int *a) {                                          // only while off (:513-528)
+  if (c.on) return {1, 1, {a[0], 0}, false};
+  c.rxFreq = a[0] * 1.0e3;
+  return {0, 1, {a[0], 0}, false};
+}
+Reply rule_txtune(TrxControl &c, const int *a) {                                          // (:529-544)
+  if (c.on) return {1, 1, {a[0], 0}, false};
+  c.txFreq = a[0] * 1.0e3;
+  return {0, 1, {a[0], 0}, false};
+}
+Reply rule_settsc(TrxControl &c, const int *a) {
+  // only while off (:545-556).  A training sequence outside 0..7 is refused (status 1): the reference stores it and then
+  // indexes gMidambles[] with it at the next normal burst (sigProcLib.cpp:946) -- undefined behaviour, nothing to reproduce
+  if (c.on || a[0] < 0 || a[0] > 7) return {1, 1, {a[0], 0}, false};
+  c.tsc = (unsigned)a[0]; c.epoch++;
+  return {0, 1, {a[0], 0}, false};
+}
+Reply rule_setslot(TrxControl &c, const int *a) {                                         // (:557-570): a timeslot outside 0..7 gets NO answer
+  if (a[0] < 0 || a[0] > 7) return {0, 0, {0, 0}, true};
+  c.chanType[a[0]] = a[1];
+  c.setModulus(a[0]);
+  c.epoch++;
+  return {0, 2, {a[0], a[1]}, false};
+}
+Reply rule_setmaxdelay(TrxControl &c, const int *a) {                                     // 52M: only while on
+  if (!c.on) return {1, 1, {a[0], 0}, false};
+  c.maxDelay = a[0];
+  return {0, 1, {a[0], 0}, false};
+}
+const struct { const char *verb; int n_args; VerbRule rule; } kVerbs[] = {
+  {"POWEROFF", 0, rule_poweroff}, {"POWERON", 0, rule_poweron},   {"SETPOWER", 1, rule_setpower},
+  {"ADJPOWER", 1, rule_adjpower}, {"RXTUNE", 1, rule_rxtune},     {"TXTUNE", 1, rule_txtune},
+  {"SETTSC", 1, rule_settsc},     {"SETSLOT", 2, rule_setslot},   {"SETMAXDELAY", 1, rule_setmaxdelay},
+};
+}  // namespace
+
+int TrxControl::command(const char *buffer, char *response) {
+  char tag[4] = {0}, verb[100] = {0};
+  int args[2] = {0, 0};
   response[0] = 0;
-  std::sscanf(buffer, "%3s %99s", cmdcheck, command);
-  if (std::strcmp(cmdcheck, "CMD") != 0) return 0;            // "bogus message": no response (:466-470)
-  if (std::strcmp(command, "POWEROFF") == 0) {
-    std::sprintf(response, "RSP POWEROFF 0");
-  } else if (std::strcmp(command, "POWERON") == 0) {
-    if (!txFreq || !rxFreq) std::sprintf(response, "RSP POWERON 1");
-    else {
-      std::sprintf(response, "RSP POWERON 0");
-      if (!on) { power = -20; on = true; }
-    }
-  } else if (std::strcmp(command, "SETPOWER") == 0) {
-    int dbPwr = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbPwr);
-    if (!on) std::sprintf(response, "RSP SETPOWER 1 %d", dbPwr);
-    else { power = dbPwr; std::sprintf(response, "RSP SETPOWER 0 %d", dbPwr); }
-  } else if (std::strcmp(command, "ADJPOWER") == 0) {
-    int dbStep = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &dbStep);
-    if (!on) std::sprintf(response, "RSP ADJPOWER 1 %d", power);
-    else { power += dbStep; std::sprintf(response, "RSP ADJPOWER 0 %d", power); }
-  } else if (std::strcmp(command, "RXTUNE") == 0) {
-    int freqKhz = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
-    if (on) std::sprintf(response, "RSP RXTUNE 1 %d", freqKhz);
-    else { rxFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP RXTUNE 0 %d", freqKhz); }
-  } else if (std::strcmp(command, "TXTUNE") == 0) {
-    int freqKhz = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &freqKhz);
-    if (on) std::sprintf(response, "RSP TXTUNE 1 %d", freqKhz);
-    else { txFreq = freqKhz * 1.0e3; std::sprintf(response, "RSP TXTUNE 0 %d", freqKhz); }
-  } else if (std::strcmp(command, "SETTSC") == 0) {
-    int TSC = 0;
-    std::sscanf(buffer, "%3s %99s %d", cmdcheck, command, &TSC);
-    if (on || TSC < 0 || TSC > 7) std::sprintf(response, "RSP SETTSC 1 %d", TSC);   // (the reference does not range-check)
-    else { tsc = (unsigned)TSC; epoch++; std::sprintf(response, "RSP SETTSC 0 %d", TSC); }
-  } else if (std::strcmp(command, "SETSLOT") == 0) {
-    int corrCode = 0, timeslot = 0;
-    std::sscanf(buffer, "%3s %99s %d %d", cmdcheck, command, &timeslot, &corrCode);
-    if (timeslot < 0 || timeslot > 7) return 0;               // returns without responding (:556-561)
-    chanType[timeslot] = corrCode;
-    setModulus(timeslot);
-    epoch++;
-    std::sprintf(response, "RSP SETSLOT 0 %d %d", timeslot, corrCode);
-  }                                                          // unknown command: empty response buffer is sent (:571-575)
-  return 1;
+  std::sscanf(buffer, "%3s %99s %d %d", tag, verb, &args[0], &args[1]);
+  if (std::strcmp(tag, "CMD") != 0) return 0;                 // "bogus message": no response (:466-470)
+  for (const auto &v : kVerbs) {
+    if (std::strcmp(verb, v.verb) != 0) continue;
+    if (v.n_args < 2) args[1] = 0;
+    if (v.n_args < 1) args[0] = 0;
+    const Reply r = v.rule(*this, args);
+    if (r.silent) return 0;
+    int n = std::sprintf(response, "RSP %s %d", v.verb, r.status);
+    for (int k = 0; k < r.n_echo; k++) n += std::sprintf(response + n, " %d", r.echo[k]);
+    return 1;
+  }
+  return 1;                                                   // unknown verb: the empty response buffer is sent (:571-575)
 }
 
 extern "C" {

@@ -9,6 +9,7 @@ struct TrxControl {
   double txFreq = 0.0, rxFreq = 0.0;
   int power = -10;
   unsigned tsc = 0;
+  int maxDelay = 0;                                         // mMaxExpectedDelay (Transceiver52M/Transceiver.cpp:62, SETMAXDELAY :476-486; stored, the TSC leg is chosen by trxsig_*_set_tsc_leg)
   int chanType[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // TRXSIG_CHAN_NONE
   int fillerModulus[8] = {26, 26, 26, 26, 26, 26, 26, 26};
   unsigned epoch = 0;                                       // bumped whenever chanType / tsc change (the group re-derives its tables)

@@ -8,7 +8,11 @@ sample.npz: x complex64 (packed bursts), off int32, length int32, sps, tsc; kind
 "rach" (detectRACHBurst + demodulateBurst), "config5" (the Transceiver52M equalised leg: energyDetect + analyzeTrafficBurst with
 the channel response + designDFE + equalizeBurst, oracle/_ref/libref_sigproc52m.so; energy_thresh, max_toa in the file), or "config4": iq int16 [S][K*864][2] (Q first), lpf float32 taps -- per stream
 unUSRPify + polyphaseResampleVector chunk by chunk behind a 192-sample history (RadioInterface::pullBuffer) + the
-157-156-156-156 slicing + analyzeTrafficBurst + demodulateBurst, the streams shared out over the processes."""
+157-156-156-156 slicing + analyzeTrafficBurst + demodulateBurst, the streams shared out over the processes.  With
+`freqs` (float32 [C], radians per wideband sample) and `rate_factor` in a config4 file, iq holds WIDEBAND streams
+[Sw][K*864*rate_factor][2] and every carrier of a stream is mixed down with frequencyShift (chunk by chunk, the running
+phase handed on) and resampled 65*sps : 96*rate_factor behind a 192*rate_factor-sample history before the same slicing +
+detection: the channeliser's work as the reference's primitives do it."""
 import json
 import multiprocessing as mp
 import sys
@@ -21,9 +25,15 @@ def kind_of(d):
     return str(d["kind"]) if "kind" in d.files else "normal"
 
 
-def config4_stream(r, iq, lpf, sps, tsc, equalize=False):
+def config4_stream(r, iq, lpf, sps, tsc, equalize=False, freqs=None, rate_factor=1):
     """One stream through the reference: returns the number of bursts it cut and detected + demodulated (equalize: the
-    equalised leg, ref_eq_batch, instead of analyzeTrafficBurst + demodulateBurst)."""
+    equalised leg, ref_eq_batch, instead of analyzeTrafficBurst + demodulateBurst).  freqs: a wideband stream, every carrier
+    in turn (frequencyShift + polyphaseResampleVector per chunk)."""
+    if freqs is not None:
+        total = 0
+        for f in freqs:
+            total += config4_carrier(r, iq, lpf, sps, tsc, float(f), rate_factor)
+        return total
     nchunks = iq.shape[0] // 864
     hist = np.zeros(192, np.complex64)
     rcv = []
@@ -32,7 +42,29 @@ def config4_stream(r, iq, lpf, sps, tsc, equalize=False):
         cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)   # unUSRPifyVector: I/Q swapped
         y = r.polyphase_resample(np.concatenate([hist, cf]), 65 * sps, 96, lpf)
         rcv.append(y[2 * 65 * sps:]); hist = cf[-192:]
-    xs = np.concatenate(rcv)
+    return cut_and_detect(r, np.concatenate(rcv), sps, tsc, equalize)
+
+
+def config4_carrier(r, iq, lpf, sps, tsc, freq, CW):
+    n = 864 * CW
+    nchunks = iq.shape[0] // n
+    hist = np.zeros(192 * CW, np.complex64)
+    rcv = []
+    phase = np.float32(0.0)
+    for c in range(nchunks):
+        ch = iq[c * n:(c + 1) * n]
+        cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)
+        # frequencyShift in blocks of 256 samples, the phase wrapped in between: over a whole chunk the running phase reaches
+        # ~10^4 rad and expjLookup's subtract-one range reduction, not the mixing, would be what is timed
+        for b0 in range(0, n, 256):
+            cf[b0:b0 + 256], phase = r.frequency_shift(cf[b0:b0 + 256], freq, phase)
+            phase = np.float32(np.fmod(float(phase), 2.0 * np.pi))
+        y = r.polyphase_resample(np.concatenate([hist, cf]), 65 * sps, 96 * CW, lpf)
+        rcv.append(y[2 * 65 * sps:]); hist = cf[-192 * CW:]
+    return cut_and_detect(r, np.concatenate(rcv), sps, tsc, False)
+
+
+def cut_and_detect(r, xs, sps, tsc, equalize):
     lens = []; pos = 0; tn = 0
     while xs.size - pos > (156 + (tn % 4 == 0)) * sps:
         n = (156 + (tn % 4 == 0)) * sps; lens.append(n); pos += n; tn = (tn + 1) % 8
@@ -52,11 +84,12 @@ def worker(path, lo, hi, reps, start, done):
     if kind == "config4":
         iq, lpf, sps, tsc = np.ascontiguousarray(d["iq"][lo:hi]), d["lpf"], int(d["sps"]), int(d["tsc"])
         eq = "equalize" in d.files and int(d["equalize"]) != 0
-        config4_stream(r, iq[0][:864 * 4], lpf, sps, tsc, eq)  # warm
+        freqs, CW = (d["freqs"], int(d["rate_factor"])) if "freqs" in d.files else (None, 1)
+        config4_stream(r, iq[0][:864 * 4 * CW], lpf, sps, tsc, eq, freqs, CW)  # warm
         start.wait()
         for _ in range(reps):
             for s in range(hi - lo):
-                config4_stream(r, iq[s], lpf, sps, tsc, eq)
+                config4_stream(r, iq[s], lpf, sps, tsc, eq, freqs, CW)
         done.wait()
         return
     x, off, length, tsc = d["x"], d["off"][lo:hi], d["length"][lo:hi], int(d["tsc"])
@@ -85,13 +118,16 @@ def main():
         S = iq.shape[0]
         P = min(P, S)
         eq = "equalize" in d.files and int(d["equalize"]) != 0
-        config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]), eq)        # warm: the whole stream once
+        freqs, CW = (d["freqs"], int(d["rate_factor"])) if "freqs" in d.files else (None, 1)
+        config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]), eq, freqs, CW)        # warm: the whole stream once
         t0 = time.perf_counter()
-        nb1 = config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]), eq)
+        nb1 = config4_stream(r, iq[0], d["lpf"], int(d["sps"]), int(d["tsc"]), eq, freqs, CW)
         per_burst = (time.perf_counter() - t0) / nb1
         B = nb1 * S                                          # bursts per pass over all streams
-        units, what = S, ("%d streams x %d chunks (%d bursts): unUSRPify + polyphaseResampleVector chunk by chunk + slicing + "
-                          "%s" % (S, iq.shape[1] // 864, B, "energyDetect + analyzeTrafficBurst(requestChannel) + designDFE + equalizeBurst"
+        units, what = S, ("%d %sstreams x %d chunks (%d bursts): unUSRPify + %spolyphaseResampleVector chunk by chunk + slicing + "
+                          "%s" % (S, "wideband " if freqs is not None else "", iq.shape[1] // (864 * CW), B,
+                                  "per carrier (%d) frequencyShift + " % len(freqs) if freqs is not None else "",
+                                  "energyDetect + analyzeTrafficBurst(requestChannel) + designDFE + equalizeBurst"
                                   if eq else "analyzeTrafficBurst + demodulateBurst"))
     else:
         B = len(d["off"])

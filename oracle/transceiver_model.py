@@ -62,7 +62,7 @@ class TransceiverModel:
         if len(parts) < 2 or parts[0][:3] != "CMD":
             return ""
         cmd = parts[1]
-        arg = lambda k: int(parts[2 + k])
+        arg = lambda k: int(parts[2 + k]) if len(parts) > 2 + k else 0      # (a missing integer reads as 0 in the product)
         if cmd == "POWEROFF":
             return "RSP POWEROFF 0"
         if cmd == "POWERON":
@@ -90,10 +90,17 @@ class TransceiverModel:
                 self.tx_freq = arg(0) * 1.0e3
             return "RSP %s 0 %d" % (cmd, arg(0))
         if cmd == "SETTSC":
-            if self.on:
+            # (a TSC outside 0..7: the reference stores it and then indexes gMidambles[] with it, sigProcLib.cpp:946 -- undefined
+            #  behaviour; the product refuses it with status 1 and so does this model)
+            if self.on or not 0 <= arg(0) <= 7:
                 return "RSP SETTSC 1 %d" % arg(0)
             self.tsc = arg(0)
             return "RSP SETTSC 0 %d" % arg(0)
+        if cmd == "SETMAXDELAY":                                             # Transceiver52M/Transceiver.cpp:476-486
+            if not self.on:
+                return "RSP SETMAXDELAY 1 %d" % arg(0)
+            self.max_delay = arg(0)
+            return "RSP SETMAXDELAY 0 %d" % arg(0)
         if cmd == "SETSLOT":
             ts, code = arg(0), arg(1)
             if ts < 0 or ts > 7:

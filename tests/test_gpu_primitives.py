@@ -159,6 +159,56 @@ def test_batch_forms_ragged(pkg, ctx):
                                        0, 0, 0, 0, dy.data_ptr(), doff.data_ptr()), "span 9")
 
 
+def test_unreducible_delay_and_index_return_promptly(pkg, ctx):
+    """The hang class of round 3 (a TOA of -1e9 sent the table sinc's subtract-one range reduction into a loop that never
+    ended): delays / indices the reference's loop (sigProcLib.cpp:163-188 under :573-616 and :639-659) cannot reduce are
+    refused by the host forms (TRXSIG_EINVAL, no launch) and give zeros in the batch forms; large but reducible ones still
+    equal the oracle bit for bit (the device reduction is the loop's closed form); hostile SAMPLES (NaN / inf) cannot keep
+    peakDetect running either.  Everything returns within seconds."""
+    import time
+    import torch
+    t = ctx[4]; o = oraclebind.Oracle(4)
+    rng = np.random.default_rng(404)
+    x = cn(rng, 300, 5.0)
+    t0 = time.time()
+    for bad in (1e10, -1e9, 3.0e7, -2.0e7, float("inf"), float("-inf"), float("nan")):
+        with pytest.raises(pkg.TrxSigError):
+            t.delay_vector_host(x, bad)
+        with pytest.raises(pkg.TrxSigError):
+            t.interpolate_point_host(x, bad)
+    # large, reducible: the closed form is the loop
+    for ix in (-3000.25, 5000.5, -1.0e5, 123456.75, 150.3, -0.7, 298.9, 299.5):
+        assert t.interpolate_point_host(x, ix) == o.interpolate_point(x, np.float32(ix)), ix
+    for d in (-999999.5, 4096.25, 16777216.0, -16777216.0, 299.5, -300.125):
+        assert_beq(t.delay_vector_host(x, d), o.delay_vector(x, np.float32(d)), "delay %r" % d)
+    # batch forms: hostile entries -> zeros, the others untouched by their neighbours
+    B = 12
+    lens = np.full(B, 300, np.int32); off = (np.arange(B) * 300).astype(np.int32)
+    xs = cn(rng, 300 * B, 3.0)
+    vals = np.array([1e10, -1e9, np.inf, -np.inf, np.nan, 3.5, -2.25, 1e30, -1e30, 0.0, 2.0e7, 7.125], np.float32)
+    dev = torch.device("cuda:0")
+    dx = torch.from_numpy(xs.view(np.float32).copy()).to(dev); doff = torch.from_numpy(off).to(dev); dlen = torch.from_numpy(lens).to(dev)
+    dv = torch.from_numpy(vals).to(dev); dy = torch.full_like(dx, 7.0); dp = torch.full((B, 2), 7.0, device=dev)
+    L = t.L
+    t._chk(L.trxsig_delay_vector_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, dv.data_ptr(), 0, dy.data_ptr()), "delay")
+    t._chk(L.trxsig_interpolate_point_batch(t.h, dx.data_ptr(), doff.data_ptr(), dlen.data_ptr(), B, dv.data_ptr(), 0, dp.data_ptr()), "interp")
+    torch.cuda.synchronize()
+    y = dy.cpu().numpy().view(np.complex64); p = dp.cpu().numpy().view(np.complex64).ravel()
+    for i in range(B):
+        xi = xs[off[i]:off[i] + 300]
+        if np.isfinite(vals[i]) and abs(vals[i]) <= 16777216.0:
+            assert_beq(y[off[i]:off[i] + 300], o.delay_vector(xi, vals[i]), "batch delay %d" % i)
+            assert p[i] == o.interpolate_point(xi, vals[i]), i
+        else:
+            assert not y[off[i]:off[i] + 300].any() and p[i] == 0, i
+    # hostile samples
+    for hostile in (np.nan, np.inf, -np.inf, 3.0e38):
+        xh = x.copy(); xh[100] = hostile; xh[7] = complex(0, hostile)
+        t.peak_detect_host(xh)
+        t.delay_vector_host(xh, 0.37)
+    assert time.time() - t0 < 30.0
+
+
 def test_rest_of_the_sigproclib_surface(ctx, golden):
     """dB / dBinv, sinc, vectorNorm2 / vectorPower, frequencyShift, addVector, offsetVector, gaussianNoise (fixed srand seed),
     resampleVector and convolve's ABSSYM form through the C-ABI against tests/golden/extras.npz (captured from the compiled

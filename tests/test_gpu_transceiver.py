@@ -140,10 +140,12 @@ def test_control_commands(pkg):
     o = oraclebind.Oracle(1)
     h = pkg.TrxHost(1, 0); m = tm.TransceiverModel(o)
     script = ["CMD POWERON", "CMD SETPOWER 5", "CMD ADJPOWER 3", "CMD RXTUNE 890200", "CMD POWERON", "CMD TXTUNE 935200",
-              "CMD SETTSC 3", "CMD SETSLOT 3 7", "CMD SETSLOT 9 1", "CMD POWERON", "CMD POWERON", "CMD SETPOWER 7",
+              "CMD SETTSC 3", "CMD SETTSC 9", "CMD SETTSC -1", "CMD SETMAXDELAY 3", "CMD SETSLOT 3 7", "CMD SETSLOT 9 1",
+              "CMD POWERON", "CMD POWERON", "CMD SETPOWER 7", "CMD SETMAXDELAY 2",
               "CMD ADJPOWER -4", "CMD RXTUNE 1", "CMD TXTUNE 2", "CMD SETTSC 2", "CMD POWEROFF", "XYZ POWERON", "CMD NOSUCH 1",
-              "CMD SETSLOT 0 4"]
+              "CMD SETSLOT 0 4", "CMD SETPOWER", "CMD SETSLOT -1 1"]
     for c in script:
         assert h.control(c) == m.control(c), c
-    assert h.control("CMD ADJPOWER 0") == "RSP ADJPOWER 0 3"
+    assert h.control("CMD ADJPOWER 0") == "RSP ADJPOWER 0 0"      # ("CMD SETPOWER" with its integer missing reads as 0)
+    assert h.control("CMD SETTSC 9") == "RSP SETTSC 1 9"          # out of range: refused by product and model alike
     h.close()

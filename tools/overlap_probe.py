@@ -1,6 +1,6 @@
 """Experiment: chunked two-stage pipelining of the normal-burst leg across two HIP streams --
 detection (k_tsc_corr + k_tsc_peak) of chunk i+1 runs while chunk i is demodulated (k_demod).
-Run on the GPU box:  python tools/overlap_test.py"""
+Run on the GPU box:  python tools/overlap_probe.py"""
 import sys, time
 sys.path.insert(0, '.')
 import torch
