@@ -480,6 +480,13 @@ int trxsig_kernel_count(void);
  *     d_samples / d_offset / d_length -- complete only behind trxsig_synchronize (or the next call that is not of this kind).
  *     The next call's correlator (VALU-bound) then runs beside this call's demodulator (HBM-bound): a throughput lever for a
  *     caller that pipelines batches (bench.py reports it as a side field, never as `value`); same results.
+ *   TRXSIG_TUNE_BESIDE_DET_CUS (both libraries; default 0; only meaningful with TRXSIG_TUNE_DEMOD_BESIDE = 1): x > 0 = the two
+ *     streams of that arrangement PARTITION the compute units (hipExtStreamCreateWithCUMask): the detectors (k_tsc_corr,
+ *     k_tsc_peak2) run on a stream of the library masked to x CUs, the demodulator on one masked to the other CUs, so that the
+ *     VALU-bound and the HBM-bound kernel of neighbouring calls co-run without contending for the same CUs' wave slots and LDS.
+ *     Then d_flags / d_amp / d_toa / d_avgpwr too are complete only behind trxsig_synchronize.  TRXSIG_TUNE_CU_LAYOUT: 0 = the
+ *     detect set is mask bits 0..x-1, 1 = every eighth-of-the-mask takes x/8 of them (tools/cu_split.py measures both).
+ *     TRXSIG_TUNE_BESIDE_PRIORITY (without masks): the side stream's priority, 0 = normal, 1 = the device's highest, 2 = its lowest.
  *   TRXSIG_TUNE_GENERIC_TAPS: 1 = midamble correlators without the "exactly +-1 tap component" form (which
  *     is only taken when the actual taps have that shape).  Default 0.
  *   TRXSIG_TUNE_SPECULATIVE_PEAK: path 0's peakDetect kernel.  0 = two lanes per burst (early and late point of
@@ -488,7 +495,8 @@ int trxsig_kernel_count(void);
  *     64 K bursts, LDS bandwidth), 2 = a lane per burst, the reference's serial loop (k_tsc_peak; 18 us,
  *     k_tsc_peak2 15 us).  All three are bit-identical. */
 enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3,
-       TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5, TRXSIG_TUNE_DEMOD_BESIDE = 7 };
+       TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5, TRXSIG_TUNE_DEMOD_BESIDE = 7, TRXSIG_TUNE_BESIDE_DET_CUS = 8,
+       TRXSIG_TUNE_CU_LAYOUT = 9, TRXSIG_TUNE_BESIDE_PRIORITY = 11 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* 1 in libtrxsig_tune.so (every implementation above selectable), 0 in the product library libtrxsig.so, which carries the
  * defaults only (normal path 0 with the two-lane peak kernel, RACH paths 1 and 2) and answers TRXSIG_EINVAL to the rest. */

@@ -485,10 +485,16 @@ class TrxSig:
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
     def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None, chain_lag=None,
-                   chain_spin=None, demod_beside=None):
+                   chain_spin=None, demod_beside=None, beside_det_cus=None, cu_layout=None, beside_priority=None):
         """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
         if demod_beside is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 7, int(demod_beside)), "trxsig_set_tuning")
+        if beside_det_cus is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 8, int(beside_det_cus)), "trxsig_set_tuning")
+        if beside_priority is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 11, int(beside_priority)), "trxsig_set_tuning")
+        if cu_layout is not None:
+            self._chk(self.L.trxsig_set_tuning(self.h, 9, int(cu_layout)), "trxsig_set_tuning")
         if chain_lag is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 4, int(chain_lag)), "trxsig_set_tuning")
         if chain_spin is not None:

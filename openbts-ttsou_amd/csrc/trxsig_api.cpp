@@ -76,6 +76,15 @@ struct trxsig_ctx {
   int children = 0;                  // front ends, back ends and groups living on this context (trx_ctx_retain / _release)
   bool zombie = false;               // trxsig_destroy came while some were alive: the last one to go destroys the context
   int demod_beside = 0;
+  int det_cus = 0;                   // TRXSIG_TUNE_BESIDE_DET_CUS: > 0 = the detectors on their own stream masked to that many CUs, the
+                                     // demodulator's side stream masked to the others (hipExtStreamCreateWithCUMask); 0 = no masks
+  int cu_layout = 0;                 // TRXSIG_TUNE_CU_LAYOUT: which bits of the mask the two sets take (see cu_mask())
+  hipStream_t det = nullptr;         // the masked detect stream (det_cus > 0)
+  hipEvent_t ev_in = nullptr;        // "the caller's inputs are ready" (context's stream -> detect stream)
+  bool det_in_flight = false;        // detectors issued on `det` since the last join
+  int side_prio = 0;                 // TRXSIG_TUNE_BESIDE_PRIORITY: 0 = the side stream at normal priority, 1 = highest, 2 = lowest
+  int beside_nodeps = 0;             // tuning build, TIMING EXPERIMENT ONLY (key 10; results are racy): 1 = no "inputs ready" wait,
+                                     // 2 = no cross-stream waits at all -- what the dependencies themselves cost (tools/cu_split.py)
   hipStream_t side = nullptr;
   hipEvent_t ev_pk[2] = {nullptr, nullptr}, ev_dm[2] = {nullptr, nullptr};
   bool dm_in_flight[2] = {false, false};
@@ -180,6 +189,10 @@ int ensure_ws(trxsig_ctx *c, int B) {
 
 // the context's stream waits for every demodulator still running on the side stream (TRXSIG_TUNE_DEMOD_BESIDE)
 int join_demod(trxsig_ctx *c) {
+  if (c->det_in_flight) {                                   // (flags / amp / TOA of the last call are written on the detect stream)
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pk[c->pb_k], 0));
+    c->det_in_flight = false;
+  }
   for (int k = 0; k < 2; k++) {
     if (!c->dm_in_flight[k]) continue;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dm[k], 0));
@@ -187,16 +200,57 @@ int join_demod(trxsig_ctx *c) {
   }
   return TRXSIG_OK;
 }
+// CU masks of the two streams.  `n_cu` CUs in all; the detect set takes `det` of them, the demodulate set the rest.
+// layout 0: the detect set is mask bits 0 .. det-1 (the driver deals mask bits out to the XCDs in turn, so a run of low bits is
+//           spread evenly over the eight XCDs); layout 1: bit i belongs to the detect set when i mod 8 < det / (n_cu / 8), i.e.
+//           if the bits were XCD-major instead, the same even spread -- the measurement says which reading holds
+void cu_mask(int n_cu, int det, int layout, bool detect_set, uint32_t *mask, int words) {
+  for (int w = 0; w < words; w++) mask[w] = 0;
+  for (int i = 0; i < n_cu && i < 32 * words; i++) {
+    bool in_det;
+    if (layout == 0) in_det = i < det;
+    else { const int per = n_cu / 8; in_det = (i % per) < det / 8; }
+    if (in_det == detect_set) mask[i >> 5] |= 1u << (i & 31);
+  }
+}
+int drop_beside_streams(trxsig_ctx *c) {
+  if (c->side) { HIPCHK(c, hipStreamSynchronize(c->side)); HIPCHK(c, hipStreamDestroy(c->side)); c->side = nullptr; }
+  if (c->det) { HIPCHK(c, hipStreamSynchronize(c->det)); HIPCHK(c, hipStreamDestroy(c->det)); c->det = nullptr; }
+  c->dm_in_flight[0] = c->dm_in_flight[1] = false;
+  c->det_in_flight = false;
+  return TRXSIG_OK;
+}
 int ensure_beside(trxsig_ctx *c, int B) {
   if (!c->side) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_pk[k], hipEventDisableTiming));
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_dm[k], hipEventDisableTiming));
+    if (c->det_cus > 0) {
+      hipDeviceProp_t p;
+      HIPCHK(c, hipGetDeviceProperties(&p, c->device));
+      const int n_cu = p.multiProcessorCount;
+      if (c->det_cus >= n_cu || n_cu > 512) return fail(c, TRXSIG_EINVAL, "TRXSIG_TUNE_BESIDE_DET_CUS: more CUs than the device has");
+      uint32_t m[16];
+      const int words = (n_cu + 31) / 32;
+      cu_mask(n_cu, c->det_cus, c->cu_layout, true, m, words);
+      HIPCHK(c, hipExtStreamCreateWithCUMask(&c->det, (uint32_t)words, m));
+      cu_mask(n_cu, c->det_cus, c->cu_layout, false, m, words);
+      HIPCHK(c, hipExtStreamCreateWithCUMask(&c->side, (uint32_t)words, m));
+    } else if (c->side_prio) {
+      int lo = 0, hi = 0;                                   // (numerically: `hi` is the greatest priority, the smaller number)
+      HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIPCHK(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, c->side_prio == 1 ? hi : lo));
+    } else {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    }
+    if (!c->ev_in) {
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+      for (int k = 0; k < 2; k++) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pk[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_dm[k], hipEventDisableTiming));
+      }
     }
   }
   if (B <= c->pb_cap) return TRXSIG_OK;
   HIPCHK(c, hipStreamSynchronize(c->side));
+  if (c->det) HIPCHK(c, hipStreamSynchronize(c->det));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int cap = (B + 255) & ~255;
   for (int k = 0; k < 2; k++) {
@@ -353,6 +407,8 @@ static void destroy_now(trxsig_ctx *c) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_tsc) (void)hipFree(c->d_tsc);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->det) { (void)hipStreamSynchronize(c->det); (void)hipStreamDestroy(c->det); }
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     for (int k = 0; k < 2; k++) {
       if (c->ev_pk[k]) (void)hipEventDestroy(c->ev_pk[k]);
       if (c->ev_dm[k]) (void)hipEventDestroy(c->ev_dm[k]);
@@ -473,27 +529,35 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
 #endif
   const bool beside = c->demod_beside && nsoft > 0;
   int k = 0;
+  hipStream_t sdet = c->stream;
   if (beside) {
     rc = ensure_beside(c, B);
     if (rc != TRXSIG_OK) return rc;
     k = c->pb_k ^= 1;
+    if (c->det) {                                           // masked detect stream: it starts when the caller's inputs are ready
+      sdet = c->det;
+      if (c->beside_nodeps < 1) {
+        HIPCHK(c, hipEventRecord(c->ev_in, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(sdet, c->ev_in, 0));
+      }
+    }
     if (c->dm_in_flight[k]) {                               // the demodulator that read this copy two calls ago
-      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dm[k], 0));
+      if (c->beside_nodeps < 2) HIPCHK(c, hipStreamWaitEvent(sdet, c->ev_dm[k], 0));
       c->dm_in_flight[k] = false;
     }
   } else {
     rc = join_demod(c);                                     // (outputs of this call must not be overtaken by an older demodulator)
     if (rc != TRXSIG_OK) return rc;
   }
-  HIPCHK(c, trx_launch_tsc_detect(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
+  HIPCHK(c, trx_launch_tsc_detect(sdet, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset, d_length,
                                   B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts, d_flags,
                                   (trx_c32 *)d_amp, d_toa, d_avgpwr, c->generic_taps | (c->spec_peak == 1 ? 2 : 0) | (c->spec_peak == 2 ? 4 : 0), c->prof));
   if (beside) {
-    HIPCHK(c, hipMemcpyAsync(c->pb_flags[k], d_flags, (size_t)B, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->pb_amp[k], d_amp, sizeof(trx_c32) * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->pb_toa[k], d_toa, sizeof(float) * (size_t)B, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_pk[k], c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pk[k], 0));
+    // the demodulator reads its own copy of the verdict: the next call's k_tsc_peak2 overwrites d_flags / d_amp / d_toa beside it
+    HIPCHK(c, trx_launch_copy_verdict(sdet, d_flags, (const trx_c32 *)d_amp, d_toa, B, c->pb_flags[k], c->pb_amp[k], c->pb_toa[k]));
+    HIPCHK(c, hipEventRecord(c->ev_pk[k], sdet));
+    if (c->det) c->det_in_flight = true;
+    if (c->beside_nodeps < 2) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pk[k], 0));
     HIPCHK(c, trx_launch_demod(c->side, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, c->pb_amp[k], c->pb_toa[k],
                                c->pb_flags[k], TRXSIG_F_DETECT, d_soft, d_hard, nsoft, soft_stride, c->prof));
     HIPCHK(c, hipEventRecord(c->ev_dm[k], c->side));
@@ -1191,13 +1255,14 @@ int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   // the product library carries the default implementations only (normal path 0 with the two-lane peak kernel, RACH paths 1
   // and 2); the alternates that measured slower live in libtrxsig_tune.so (make -C csrc tune)
   if ((key == TRXSIG_TUNE_NORMAL_PATH && value != 0) || (key == TRXSIG_TUNE_RACH_PATH && value == 0) ||
-      (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value != 0) || key == TRXSIG_TUNE_CHAIN_LAG || key == TRXSIG_TUNE_CHAIN_SPIN || key == 6)
+      (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value != 0) || key == TRXSIG_TUNE_CHAIN_LAG || key == TRXSIG_TUNE_CHAIN_SPIN || key == 6 || key == 10)
     return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: this implementation is only in the tuning build (libtrxsig_tune.so)");
 #endif
   if (key == TRXSIG_TUNE_NORMAL_PATH && value >= 0 && value <= 5) { c->variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_CHAIN_LAG && value >= 1) { c->chain_lag = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_CHAIN_SPIN && value >= 0) { c->chain_spin = (unsigned)value; return TRXSIG_OK; }
   if (key == 6 && value >= 0 && value <= 3) { c->chain_dbg = value; return TRXSIG_OK; }   // timing experiments (tools/chain_roles.py)
+  if (key == 10 && value >= 0 && value <= 2) { c->beside_nodeps = value; return TRXSIG_OK; }   // timing experiment (tools/cu_split.py)
   if (key == TRXSIG_TUNE_RACH_PATH && value >= 0 && value <= 2) { c->rach_variant = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_GENERIC_TAPS && value >= 0 && value <= 1) { c->generic_taps = value; return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_DEMOD_BESIDE && value >= 0 && value <= 1) {
@@ -1208,6 +1273,19 @@ int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
     return TRXSIG_OK;
   }
   if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 2) { c->spec_peak = value; return TRXSIG_OK; }
+  if ((key == TRXSIG_TUNE_BESIDE_DET_CUS && value >= 0 && value <= 504) || (key == TRXSIG_TUNE_CU_LAYOUT && value >= 0 && value <= 1) ||
+      (key == TRXSIG_TUNE_BESIDE_PRIORITY && value >= 0 && value <= 2)) {
+    DeviceGuard g(c->device);
+    int rc = join_demod(c);
+    if (rc != TRXSIG_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = drop_beside_streams(c);                            // re-created with the new masks at the next call
+    if (rc != TRXSIG_OK) return rc;
+    if (key == TRXSIG_TUNE_BESIDE_DET_CUS) c->det_cus = value;
+    else if (key == TRXSIG_TUNE_CU_LAYOUT) c->cu_layout = value;
+    else c->side_prio = value;
+    return TRXSIG_OK;
+  }
   return fail(c, TRXSIG_EINVAL, "trxsig_set_tuning: unknown key or value");
 }
 int trxsig_profile_enable(trxsig_ctx *c, int on) {

@@ -20,6 +20,8 @@ struct TrxProfiler {
 int trx_rec_slots(int sps);
 
 // dT: device tables, hT: the host copy (the midamble taps travel as a kernel argument)
+hipError_t trx_launch_copy_verdict(hipStream_t st, const uint8_t *flags, const trx_c32 *amp, const float *toa, int B, uint8_t *flags_out,
+                                   trx_c32 *amp_out, float *toa_out);
 hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,

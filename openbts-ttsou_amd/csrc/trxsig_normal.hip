@@ -572,6 +572,23 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
 }
 
+// the verdict of a batch (flags, amp, TOA) into a private copy: the demodulator of TRXSIG_TUNE_DEMOD_BESIDE reads it while the next
+// call's k_tsc_peak2 already overwrites the caller's arrays
+namespace {
+__global__ __launch_bounds__(256) void k_copy_verdict(const uint8_t *__restrict__ f, const cx *__restrict__ a, const float *__restrict__ t, int B,
+                                                      uint8_t *__restrict__ fo, cx *__restrict__ ao, float *__restrict__ to) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  fo[b] = f[b]; ao[b] = a[b]; to[b] = t[b];
+}
+}  // namespace
+hipError_t trx_launch_copy_verdict(hipStream_t st, const uint8_t *flags, const trx_c32 *amp, const float *toa, int B, uint8_t *flags_out,
+                                   trx_c32 *amp_out, float *toa_out) {
+  if (B <= 0) return hipSuccess;
+  k_copy_verdict<<<dim3((B + 255) / 256), dim3(256), 0, st>>>(flags, amp, toa, B, flags_out, amp_out, toa_out);
+  return hipGetLastError();
+}
+
 hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
                                  const int32_t *off, const int32_t *len, int B, int tsc,
                                  float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad,

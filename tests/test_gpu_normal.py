@@ -88,8 +88,10 @@ def test_random_batch_vs_oracle(pkg, ctx, sps, B):
         assert np.array_equal(r["hard"][clean][:, :148], meta["bits"][clean])
 
 
-def test_demodulator_beside_the_next_correlator(pkg):
-    """TRXSIG_TUNE_DEMOD_BESIDE: five different batches back to back, every call's demodulator on the context's side stream from
+@pytest.mark.parametrize("det_cus,layout", [(0, 0), (96, 0), (128, 1)])
+def test_demodulator_beside_the_next_correlator(pkg, det_cus, layout):
+    """(det_cus > 0: TRXSIG_TUNE_BESIDE_DET_CUS -- the detectors on a stream masked to that many compute units, the demodulator on
+    the others.)  TRXSIG_TUNE_DEMOD_BESIDE: five different batches back to back, every call's demodulator on the context's side stream from
     its own copy of (flags, amp, TOA) while the next call's correlator runs; one trxsig_synchronize at the end.  Every output of
     every call equals the default mode's (two private copies alternate: the third call waits for the first one's demodulator)."""
     sps, tsc = 4, 3
@@ -102,7 +104,7 @@ def test_demodulator_beside_the_next_correlator(pkg):
     for ref, _ in batches:
         t.detect_demod_normal(ref.x, ref.off, ref.len, tsc, ref.flags, ref.amp, ref.toa, ref.soft, avgpwr=ref.pwr, hard=ref.hard,
                               energy_thresh=0.0, nsoft=156, soft_stride=157)
-    t.set_tuning(demod_beside=1)
+    t.set_tuning(demod_beside=1, beside_det_cus=det_cus, cu_layout=layout)
     for _, gb in batches:
         t.detect_demod_normal(gb.x, gb.off, gb.len, tsc, gb.flags, gb.amp, gb.toa, gb.soft, avgpwr=gb.pwr, hard=gb.hard,
                               energy_thresh=0.0, nsoft=156, soft_stride=157)
@@ -111,7 +113,7 @@ def test_demodulator_beside_the_next_correlator(pkg):
         a, b = ref.results(), gb.results()
         for key in a:
             assert_veq(a[key], b[key], key)
-    t.set_tuning(demod_beside=0)                            # (a call of the ordinary kind afterwards is ordered behind everything)
+    t.set_tuning(demod_beside=0, beside_det_cus=0)          # (a call of the ordinary kind afterwards is ordered behind everything)
     ref, gb = batches[1]
     gb.soft.fill_(-1.0)
     t.detect_demod_normal(gb.x, gb.off, gb.len, tsc, gb.flags, gb.amp, gb.toa, gb.soft, avgpwr=gb.pwr, hard=gb.hard,
