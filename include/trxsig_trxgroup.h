@@ -1,6 +1,7 @@
 /* trxsig_trxgroup.h -- S `Transceiver` objects (one per ARFCN: TRXManager/TRXManager.cpp:44-54 makes one per carrier,
  * apps/OpenBTS.cpp:66) served by ONE GPU context at batch speed: the receive side of Transceiver/Transceiver.cpp:207-410
- * (expectedCorrType + pullRadioVector) for n_slots consecutive timeslots x S ARFCNs per call.
+ * (expectedCorrType + pullRadioVector) for n_slots consecutive timeslots x S ARFCNs per call, and (end of this header) the
+ * transmit side :100-181 (addRadioVector / pushRadioVector: priority queue, stale dump, filler table).
  *
  * Why it exists: include/trxsig_transceiver.h answers pullRadioVector one burst per call (a PCIe round trip and three to
  * six tiny launches each: 38-94 us, slower than the reference on one CPU core).  The batch detectors of trxsig.h are
@@ -120,6 +121,35 @@ int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on);
 int trxsig_trxgroup_sync(trxsig_trxgroup *g);
 /* mEnergyThreshold of one ARFCN now (synchronises) */
 int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr);
+
+/* ---- the transmit half: addRadioVector (:100-113) / pushRadioVector (:138-181) for every ARFCN of the group -------------------
+ * The transmit priority queue (mTransmitPriorityQueue), the stale-burst dump and the filler table fillerTable[FN % modulus][TN]
+ * (modulus 26 / 51 / 102 by the slot's channel combination, setModulus :183-204) live ON THE DEVICE, per ARFCN; a burst is kept
+ * as its 148 bits and its gain pow(10, -RSSI/10) (integer division, as the reference writes it), never as modulated samples --
+ * modulateBurst + scaleVector of the same bits and gain give the same samples each time, so what reaches the radio is decided
+ * here and FORMED by the transmit back end's one kernel (trxsig_txbe, fused: bits -> modulate -> resample -> gain -> int16).
+ * Bursts with equal timestamps leave the queue in the order they would leave the reference's std::priority_queue
+ * (csrc/trxsig_txq.h reproduces its moves; tests/test_txqueue_order.py).  Capacity: 256 queued bursts per ARFCN; a burst that
+ * does not fit is dropped and reported by trxsig_trxgroup_tx_queue_size. */
+
+/* driveTransmitPriorityQueue's parse + addRadioVector for n datagrams in arrival order: datagram i (154 bytes, host memory:
+ * TN, FN big-endian, RSSI, 148 bits -- Transceiver.cpp:596-620, TRXManager.cpp:173-200) belongs to ARFCN h_arfcn[i] (the data
+ * socket it arrived on).  A timeslot > 7, a frame number >= gHyperframe or an unknown ARFCN refuses the whole call
+ * (TRXSIG_EINVAL, nothing queued; cf. trxsig_trx_decode_tx_datagram).  Asynchronous; the host buffers are consumed at return. */
+int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, const int32_t *h_arfcn, int n);
+
+/* pushRadioVector(nowTime) for n_slots consecutive timeslots from (fn, tn), every ARFCN, in time order per ARFCN: stale bursts
+ * (earlier than the slot) move to the filler table at THEIR time's entry, a burst for exactly the slot replaces the slot's
+ * filler entry and goes out, otherwise the filler entry goes out.  What goes out, device resident, owned by the group, valid
+ * until its next push: *d_bits [n_arfcn][n_slots][148] (one bit per byte), *d_gain [n_arfcn][n_slots], *d_from_queue
+ * [n_arfcn][n_slots] (1: from the queue, 0: filler) -- the layout trxsig_txbe_push_bursts / trxsig_modulate_batch take. */
+int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const uint8_t **d_bits, const float **d_gain,
+                         const uint8_t **d_from_queue);
+/* the same, handed straight to a transmit back end with one stream per ARFCN (guard symbols 8 + (TN % 4 == 0), :105):
+ * n_slots <= the back end's max_bursts; trxsig_txbe_pop then yields the int16 stream for the radio */
+int trxsig_trxgroup_push_txbe(trxsig_trxgroup *g, trxsig_txbe *be, int fn, int tn, int n_slots);
+/* bursts waiting in ARFCN `arfcn`'s queue (synchronises); *dropped (may be NULL) = 1 if that ARFCN ever lost a burst to a full queue */
+int trxsig_trxgroup_tx_queue_size(trxsig_trxgroup *g, int arfcn, int *dropped);
 
 #ifdef __cplusplus
 }

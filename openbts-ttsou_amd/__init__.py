@@ -671,6 +671,10 @@ class TrxGroup:
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
         L.trxsig_trxgroup_set_pipelined.argtypes = [vp, i32]
         L.trxsig_trxgroup_sync.argtypes = [vp]
+        L.trxsig_trxgroup_add_bursts.argtypes = [vp, vp, vp, i32]
+        L.trxsig_trxgroup_push.argtypes = [vp, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.trxsig_trxgroup_push_txbe.argtypes = [vp, vp, i32, i32, i32]
+        L.trxsig_trxgroup_tx_queue_size.argtypes = [vp, i32, C.POINTER(i32)]
         self.S = n_arfcn
         self.h = vp()
         rc = L.trxsig_trxgroup_create(C.byref(self.h), ctx.h, n_arfcn, tsc_leg, start[0], start[1])
@@ -719,6 +723,34 @@ class TrxGroup:
         fe._keep = iq
         self.n_slots = n.value
         return n.value, res
+
+    # ---- transmit half ----
+    def add_bursts(self, datagrams, arfcn):
+        """datagrams: uint8 [n, 154] (the 154-byte transmit datagrams, host); arfcn: int32 [n] the ARFCN each arrived for."""
+        np = self.np
+        d = np.ascontiguousarray(datagrams, np.uint8); a = np.ascontiguousarray(arfcn, np.int32)
+        assert d.ndim == 2 and d.shape[1] == 154 and a.shape == (d.shape[0],)
+        self._chk(self.L.trxsig_trxgroup_add_bursts(self.h, d.ctypes.data, a.ctypes.data, d.shape[0]), "trxsig_trxgroup_add_bursts")
+
+    def push(self, fn, tn, n_slots, device="cuda:0"):
+        """pushRadioVector for n_slots timeslots from (fn, tn): (bits uint8 [S, n, 148], gain float32 [S, n], from_queue uint8 [S, n])
+        as torch views of the group's device buffers (valid until the next push)."""
+        import torch
+        from .frontend import _DevView
+        pb, pg, pq = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.trxsig_trxgroup_push(self.h, fn, tn, n_slots, C.byref(pb), C.byref(pg), C.byref(pq)), "trxsig_trxgroup_push")
+        dev = torch.device(device)
+        return (torch.as_tensor(_DevView(pb.value, (self.S, n_slots, 148), "|u1"), device=dev),
+                torch.as_tensor(_DevView(pg.value, (self.S, n_slots), "<f4"), device=dev),
+                torch.as_tensor(_DevView(pq.value, (self.S, n_slots), "|u1"), device=dev))
+
+    def push_txbe(self, be, fn, tn, n_slots):
+        self._chk(self.L.trxsig_trxgroup_push_txbe(self.h, be.h, fn, tn, n_slots), "trxsig_trxgroup_push_txbe")
+
+    def tx_queue_size(self, arfcn):
+        dropped = C.c_int()
+        n = self._chk(self.L.trxsig_trxgroup_tx_queue_size(self.h, arfcn, C.byref(dropped)), "trxsig_trxgroup_tx_queue_size")
+        return n, bool(dropped.value)
 
     def pull_host(self, x, slot_stride, arfcn_stride, fn, tn, n_slots, burst_len=0):
         np = self.np

@@ -70,3 +70,29 @@ hipError_t trx_launch_group_toa_eq(hipStream_t st, int n_rows, const uint8_t *ga
                                    const float *chan_off_tab, float *toa_eq);
 // end of a call: the taps estimated in this batch that are still a slot's current ones move into the slot's cache entry
 hipError_t trx_launch_group_commit(hipStream_t st, int S, TrxGroupArfcn *state, trx_c32 *w_tab, trx_c32 *b_tab, float *chan_off_tab);
+
+// ---- transmit half (trxsig_grouptx.hip): addRadioVector / pushRadioVector (Transceiver.cpp:100-113, 138-181) for S ARFCNs ----
+// A burst is kept as its PAYLOAD -- 148 bits, one per byte, then its gain pow(10, -RSSI/10) as a float: TRXG_PAYLOAD_WORDS
+// 32-bit words -- in a per-ARFCN pool; the queue and the filler table hold payload slots (-1 = the dummy burst every filler
+// entry starts as, Transceiver.cpp:66-75).  Arrays indexed [..][S] keep a lane-per-ARFCN walk coalesced.
+#define TRXG_PAYLOAD_WORDS 38
+struct TrxGroupTx {
+  int S, qcap, npool;              // ARFCNs; queue capacity and payload slots per ARFCN (npool >= qcap + 102*8)
+  int32_t *q_fn, *q_key;           // [qcap][S]: the priority queue (trxsig_txq.h), key = tn | slot << 3
+  int32_t *q_n;                    // [S] its size
+  int16_t *free_stack;             // [npool][S] free payload slots
+  int32_t *free_n;                 // [S]
+  int16_t *filler;                 // [102][8][S]: fillerTable[FN % modulus][TN] (Transceiver.h:79)
+  uint8_t *fmod;                   // [8][S]: fillerModulus[TN] (setModulus, :183-204)
+  uint32_t *pool;                  // [S][npool][TRXG_PAYLOAD_WORDS]
+  const uint32_t *dummy;           // [TRXG_PAYLOAD_WORDS]: gDummyBurst, gain 1
+  uint32_t *status;                // [S] bit 0: a burst was dropped because the queue / pool was full
+};
+// n new bursts, sorted by ARFCN (arrival order kept inside an ARFCN): seg[S+1] = where each ARFCN's run starts; s_pid[n] comes
+// back with the payload slot of each (-1: dropped); stage = their payloads in the same order
+hipError_t trx_launch_group_tx_add(hipStream_t st, const TrxGroupTx &x, int n, const int32_t *seg, const int32_t *s_fn, const int32_t *s_tn,
+                                   const int32_t *s_arfcn, int32_t *s_pid, const uint32_t *stage);
+// pushRadioVector for n_slots timeslots from (fn0, tn0) on every ARFCN: out_pid / out_fq [n_slots][S] scratch; bits_out
+// [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (1 = the burst came from the queue)
+hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,
+                                    uint8_t *bits_out, float *gain_out, uint8_t *fq_out);

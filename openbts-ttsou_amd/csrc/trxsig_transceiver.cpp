@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -39,10 +41,19 @@ const char kDummyBurst[149] =
     "0001111101101110110000010100100111000001001000100000001111100011100010111000101110001010111010010100"
     "011001100111001111010011111000100101111101010000";
 
+bool time_greater(const Time &a, const Time &b) { return a.fn == b.fn ? a.tn > b.tn : fn_compare(a.fn, b.fn) > 0; }   // GSMCommon.h:431-435
+
 struct Queued {
   Time time;
   std::vector<trxsig_c32> samples;
 };
+// VectorQueue (radioInterface.h:64-72) = InterthreadPriorityQueue<radioVector> (Interthread.h:432-528): the standard library's
+// priority_queue of POINTERS ordered by `*v1 > *v2` on the timestamps.  The same container with the same comparator here, so
+// that bursts with equal timestamps leave in the order they would leave the reference's queue (it depends on the heap's shape).
+struct QueuedLater {
+  bool operator()(const Queued *a, const Queued *b) const { return time_greater(a->time, b->time); }
+};
+typedef std::priority_queue<Queued *, std::vector<Queued *>, QueuedLater> TxQueue;
 
 }  // namespace
 
@@ -62,7 +73,7 @@ struct trxsig_trx {
   trxsig_c32 dfeW[8][7], dfeB[8][5];
   // transmit state (fillerModulus lives in ctl)
   std::vector<trxsig_c32> fillerTable[102][8];
-  std::vector<Queued> queue;                                // earliest time first (VectorQueue)
+  TxQueue queue;                                            // earliest time on top (VectorQueue)
   // device scratch for the single-burst calls
   char *d = nullptr;
   char *hpin = nullptr;              // pinned host mirror of the first part of d (samples + scalars + taps): one DMA per step
@@ -248,6 +259,7 @@ int trxsig_trx_create(trxsig_trx **out, int device, int sps, int start_fn, int s
 
 void trxsig_trx_destroy(trxsig_trx *t) {
   if (!t) return;
+  while (!t->queue.empty()) { delete t->queue.top(); t->queue.pop(); }
   if (t->d) (void)hipFree(t->d);
   if (t->hpin) (void)hipHostFree(t->hpin);
   if (t->ctx) trxsig_destroy(t->ctx);
@@ -448,14 +460,12 @@ int trxsig_trx_add_radio_vector(trxsig_trx *t, const uint8_t *bits, int RSSI, in
     return fail(t, TRXSIG_EINVAL, "trxsig_trx_add_radio_vector: bad argument (tn 0..7, fn 0..gHyperframe-1)");
   // scaleVector(*modBurst, pow(10,-RSSI/10)): integer division, double pow, complex(float) scale (:108)
   const float gain = (float)std::pow(10, -RSSI / 10);
-  Queued q;
-  q.time = Time{fn, tn};
-  int rc = modulate(t, bits, tn, &gain, q.samples);
-  if (rc != TRXSIG_OK) return rc;
-  // priority queue, earliest first; equal times keep arrival order
-  size_t pos = t->queue.size();
-  while (pos > 0 && time_less(q.time, t->queue[pos - 1].time)) pos--;
-  t->queue.insert(t->queue.begin() + (long)pos, std::move(q));
+  Queued *q = new (std::nothrow) Queued;
+  if (!q) return fail(t, TRXSIG_ENOMEM, "trxsig_trx_add_radio_vector: out of memory");
+  q->time = Time{fn, tn};
+  int rc = modulate(t, bits, tn, &gain, q->samples);
+  if (rc != TRXSIG_OK) { delete q; return rc; }
+  t->queue.push(q);                                         // mTransmitPriorityQueue.write(newVec) (:109)
   return TRXSIG_OK;
 }
 
@@ -464,17 +474,20 @@ int trxsig_trx_push_radio_vector(trxsig_trx *t, int tn, int fn, trxsig_c32 *h_ou
     return fail(t, TRXSIG_EINVAL, "trxsig_trx_push_radio_vector: bad argument (tn 0..7, fn 0..gHyperframe-1)");
   const Time now{fn, tn};
   // dump stale bursts into the filler table (:142-153)
-  while (!t->queue.empty() && time_less(t->queue.front().time, now)) {
-    const Time nt = t->queue.front().time;
-    const int modFN = nt.fn % t->ctl.fillerModulus[nt.tn];
-    t->fillerTable[modFN][nt.tn] = std::move(t->queue.front().samples);
-    t->queue.erase(t->queue.begin());
+  while (!t->queue.empty() && time_less(t->queue.top()->time, now)) {
+    Queued *q = t->queue.top();
+    t->queue.pop();
+    const int modFN = q->time.fn % t->ctl.fillerModulus[q->time.tn];
+    t->fillerTable[modFN][q->time.tn] = std::move(q->samples);
+    delete q;
   }
   const int modFN = fn % t->ctl.fillerModulus[tn];
   int fq = 0;
-  if (!t->queue.empty() && time_equal(t->queue.front().time, now)) {       // :159-173
-    t->fillerTable[modFN][tn] = t->queue.front().samples;
-    t->queue.erase(t->queue.begin());
+  if (!t->queue.empty() && time_equal(t->queue.top()->time, now)) {         // :159-173
+    Queued *q = t->queue.top();
+    t->queue.pop();
+    t->fillerTable[modFN][tn] = std::move(q->samples);
+    delete q;
     fq = 1;
   }
   const std::vector<trxsig_c32> &v = t->fillerTable[modFN][tn];             // :175-177 (or the burst just stored)

@@ -93,6 +93,19 @@ struct trxsig_trxgroup {
   // the last pull
   int n_slots = 0, n_rows = 0, n_tsc_rows = 0;
   bool have = false;
+  // ---- transmit half (created on first use): queue, filler table and payload pool on the device (trxsig_grouptx.hip) ----
+  bool tx_ready = false;
+  bool fmod_dirty = true;                                   // a SETSLOT changed some fillerModulus (setModulus, :183-204)
+  TrxGroupTx tx = {};
+  uint32_t *d_dummy = nullptr;
+  DevBuf<int32_t> tx_seg, tx_fn, tx_tn, tx_arfcn, tx_pid;
+  DevBuf<uint32_t> tx_stage;
+  DevBuf<int16_t> tx_opid;
+  DevBuf<uint8_t> tx_ofq, tx_bits, tx_fq;
+  DevBuf<float> tx_gain;
+  std::vector<int32_t> h_tx;                                // host staging of one add call (pageable; consumed by the copies at return)
+  std::vector<uint32_t> h_stage;
+  float gain_tab[26] = {0};                                 // pow(10, q), q = -12..13: every value -RSSI/10 of a signed char can take
 };
 
 namespace {
@@ -194,6 +207,13 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
     for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
     g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
+    if (g->tx_ready) {
+      (void)hipFree(g->tx.q_fn); (void)hipFree(g->tx.q_key); (void)hipFree(g->tx.q_n); (void)hipFree(g->tx.free_stack);
+      (void)hipFree(g->tx.free_n); (void)hipFree(g->tx.filler); (void)hipFree(g->tx.fmod); (void)hipFree(g->tx.pool);
+      (void)hipFree(g->tx.status); (void)hipFree(g->d_dummy);
+    }
+    g->tx_seg.release(); g->tx_fn.release(); g->tx_tn.release(); g->tx_arfcn.release(); g->tx_pid.release(); g->tx_stage.release();
+    g->tx_opid.release(); g->tx_ofq.release(); g->tx_bits.release(); g->tx_fq.release(); g->tx_gain.release();
   }
   trx_ctx_release(g->c);
   delete g;
@@ -209,7 +229,7 @@ int trxsig_trxgroup_control(trxsig_trxgroup *g, int arfcn, const char *command, 
   TrxControl &ctl = g->ctl[(size_t)arfcn];
   const unsigned before = ctl.epoch;
   const int answered = ctl.command(command, response);
-  if (ctl.epoch != before) g->dirty = true;
+  if (ctl.epoch != before) { g->dirty = true; g->fmod_dirty = true; }
   if (!answered) { response_out[0] = 0; return 0; }
   const int n = (int)std::strlen(response);
   if (n + 1 > cap) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_control: response buffer too small", hipSuccess);
@@ -571,6 +591,163 @@ int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr)
   G_HIP(g, hipStreamSynchronize(st));
   *thr = a.thr;
   return TRXSIG_OK;
+}
+
+}  // extern "C"
+
+// ======================================================================================================================
+// The transmit half: addRadioVector (:100-113) and pushRadioVector (:138-181) for every ARFCN of the group
+// ======================================================================================================================
+namespace {
+const char kDummyBits[149] =                                // gDummyBurst (GSM/GSMCommon.cpp:52-55, GSM 05.02 5.2.6)
+    "0001111101101110110000010100100111000001001000100000001111100011100010111000101110001010111010010100"
+    "011001100111001111010011111000100101111101010000";
+constexpr int kTxQueueCap = 256;                            // queued bursts per ARFCN (32 frames' worth of all eight timeslots)
+
+int tx_setup(trxsig_trxgroup *g) {
+  if (g->tx_ready) return TRXSIG_OK;
+  const int S = g->S;
+  TrxGroupTx &x = g->tx;
+  x.S = S; x.qcap = kTxQueueCap; x.npool = kTxQueueCap + 102 * 8;
+  const size_t nq = (size_t)x.qcap * S, np = (size_t)x.npool * S;
+  G_HIP(g, hipMalloc((void **)&x.q_fn, 4 * nq));
+  G_HIP(g, hipMalloc((void **)&x.q_key, 4 * nq));
+  G_HIP(g, hipMalloc((void **)&x.q_n, 4 * (size_t)S));
+  G_HIP(g, hipMalloc((void **)&x.free_stack, 2 * np));
+  G_HIP(g, hipMalloc((void **)&x.free_n, 4 * (size_t)S));
+  G_HIP(g, hipMalloc((void **)&x.filler, 2 * (size_t)102 * 8 * S));
+  G_HIP(g, hipMalloc((void **)&x.fmod, (size_t)8 * S));
+  G_HIP(g, hipMalloc((void **)&x.pool, 4 * np * TRXG_PAYLOAD_WORDS));
+  G_HIP(g, hipMalloc((void **)&x.status, 4 * (size_t)S));
+  G_HIP(g, hipMalloc((void **)&g->d_dummy, 4 * TRXG_PAYLOAD_WORDS));
+  // Transceiver::Transceiver (:66-75): every filler entry is the dummy burst, unscaled (a gain of 1 is the same samples)
+  std::vector<int16_t> fs(np), fill((size_t)102 * 8 * S, (int16_t)-1);
+  for (int k = 0; k < x.npool; k++)
+    for (int a = 0; a < S; a++) fs[(size_t)k * S + a] = (int16_t)(x.npool - 1 - k);   // slot 0 is handed out first
+  std::vector<int32_t> cnt((size_t)S, x.npool);
+  uint32_t dummy[TRXG_PAYLOAD_WORDS];
+  uint8_t *db = (uint8_t *)dummy;
+  for (int i = 0; i < 148; i++) db[i] = kDummyBits[i] == '1';
+  const float one = 1.0f;
+  std::memcpy(db + 148, &one, 4);
+  G_HIP(g, hipMemcpy(x.free_stack, fs.data(), 2 * np, hipMemcpyHostToDevice));
+  G_HIP(g, hipMemcpy(x.filler, fill.data(), 2 * fill.size(), hipMemcpyHostToDevice));
+  G_HIP(g, hipMemcpy(x.free_n, cnt.data(), 4 * (size_t)S, hipMemcpyHostToDevice));
+  G_HIP(g, hipMemset(x.q_n, 0, 4 * (size_t)S));
+  G_HIP(g, hipMemset(x.status, 0, 4 * (size_t)S));
+  G_HIP(g, hipMemcpy(g->d_dummy, dummy, sizeof dummy, hipMemcpyHostToDevice));
+  x.dummy = g->d_dummy;
+  // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division, pow in double, the scale a Complex<float>
+  for (int q = -12; q <= 13; q++) g->gain_tab[q + 12] = (float)std::pow(10, q);
+  g->tx_ready = true;
+  g->fmod_dirty = true;
+  return TRXSIG_OK;
+}
+
+int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st) {
+  if (!g->fmod_dirty) return TRXSIG_OK;
+  std::vector<uint8_t> fm((size_t)8 * g->S);
+  for (int tn = 0; tn < 8; tn++)
+    for (int a = 0; a < g->S; a++) fm[(size_t)tn * g->S + a] = (uint8_t)g->ctl[(size_t)a].fillerModulus[tn];
+  G_HIP(g, hipMemcpyAsync(g->tx.fmod, fm.data(), fm.size(), hipMemcpyHostToDevice, st));   // (pageable source: consumed at return)
+  g->fmod_dirty = false;
+  return TRXSIG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, const int32_t *h_arfcn, int n) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  if (n < 0 || (n > 0 && (!h_datagrams || !h_arfcn))) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: bad argument", hipSuccess);
+  if (n == 0) return TRXSIG_OK;
+  const int S = g->S;
+  // parse the headers as driveTransmitPriorityQueue does (:596-620) and sort by ARFCN, arrival order kept inside an ARFCN
+  std::vector<int32_t> &h = g->h_tx;
+  h.assign((size_t)(S + 1) + 4 * (size_t)n, 0);
+  int32_t *seg = h.data(), *s_fn = seg + S + 1, *s_tn = s_fn + n, *s_arfcn = s_tn + n, *s_src = s_arfcn + n;
+  for (int i = 0; i < n; i++) {
+    const uint8_t *d = h_datagrams + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
+    const int a = h_arfcn[i], tn = (int)(int8_t)d[0];
+    const uint32_t fn = ((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4];
+    if (a < 0 || a >= S || tn < 0 || tn > 7 || fn >= (uint32_t)kHyperframe)
+      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: ARFCN, timeslot or frame number out of range (nothing was queued)", hipSuccess);
+    seg[a + 1]++;
+  }
+  for (int a = 0; a < S; a++) seg[a + 1] += seg[a];
+  std::vector<int32_t> fillp(seg, seg + S);
+  g->h_stage.resize((size_t)n * TRXG_PAYLOAD_WORDS);
+  Guard gd(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  G_LIB(tx_setup(g));
+  for (int i = 0; i < n; i++) {
+    const uint8_t *d = h_datagrams + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
+    const int a = h_arfcn[i];
+    const int j = fillp[(size_t)a]++;
+    s_fn[j] = (int32_t)(((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4]);
+    s_tn[j] = d[0]; s_arfcn[j] = a; s_src[j] = i;
+    uint8_t *pay = (uint8_t *)(g->h_stage.data() + (size_t)j * TRXG_PAYLOAD_WORDS);
+    std::memcpy(pay, d + 6, 148);                           // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
+    const int RSSI = (int)(int8_t)d[5];                     // `int RSSI = (int) buffer[5]` on a char buffer (:617)
+    std::memcpy(pay + 148, &g->gain_tab[-RSSI / 10 + 12], 4);
+  }
+  G_LIB(tx_sync_modulus(g, st));
+  G_HIP(g, g->tx_seg.need((size_t)S + 1, st)); G_HIP(g, g->tx_fn.need((size_t)n, st)); G_HIP(g, g->tx_tn.need((size_t)n, st));
+  G_HIP(g, g->tx_arfcn.need((size_t)n, st)); G_HIP(g, g->tx_pid.need((size_t)n, st));
+  G_HIP(g, g->tx_stage.need((size_t)n * TRXG_PAYLOAD_WORDS, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_seg.p, seg, 4 * ((size_t)S + 1), hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_fn.p, s_fn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_tn.p, s_tn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_arfcn.p, s_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_stage.p, g->h_stage.data(), 4 * g->h_stage.size(), hipMemcpyHostToDevice, st));
+  G_HIP(g, trx_launch_group_tx_add(st, g->tx, n, g->tx_seg.p, g->tx_fn.p, g->tx_tn.p, g->tx_arfcn.p, g->tx_pid.p, g->tx_stage.p));
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const uint8_t **d_bits, const float **d_gain,
+                         const uint8_t **d_from_queue) {
+  if (!g) return TRXSIG_EINVAL;
+  trxsig_ctx *c = g->c;
+  if (fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7 || n_slots <= 0 || (long long)n_slots * g->S > (1LL << 28))
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_push: bad argument", hipSuccess);
+  Guard gd(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  G_LIB(tx_setup(g));
+  G_LIB(tx_sync_modulus(g, st));
+  const size_t cells = (size_t)n_slots * g->S;
+  G_HIP(g, g->tx_opid.need(cells, st)); G_HIP(g, g->tx_ofq.need(cells, st)); G_HIP(g, g->tx_bits.need(cells * 148, st));
+  G_HIP(g, g->tx_gain.need(cells, st)); G_HIP(g, g->tx_fq.need(cells, st));
+  G_HIP(g, trx_launch_group_tx_push(st, g->tx, fn, tn, n_slots, g->tx_opid.p, g->tx_ofq.p, g->tx_bits.p, g->tx_gain.p, g->tx_fq.p));
+  if (d_bits) *d_bits = g->tx_bits.p;
+  if (d_gain) *d_gain = g->tx_gain.p;
+  if (d_from_queue) *d_from_queue = g->tx_fq.p;
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_push_txbe(trxsig_trxgroup *g, trxsig_txbe *be, int fn, int tn, int n_slots) {
+  if (!g) return TRXSIG_EINVAL;
+  if (!be) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_push_txbe: no back end", hipSuccess);
+  const uint8_t *bits = nullptr;
+  const float *gain = nullptr;
+  G_LIB(trxsig_trxgroup_push(g, fn, tn, n_slots, &bits, &gain, nullptr));
+  std::vector<int32_t> guard((size_t)n_slots);
+  for (int t = 0; t < n_slots; t++) guard[(size_t)t] = 8 + ((((tn + t) & 7) % 4) == 0);   // modulateBurst(..., 8 + (TN % 4 == 0), ...) (:105)
+  return trxsig_txbe_push_bursts(be, bits, guard.data(), gain, n_slots);
+}
+
+int trxsig_trxgroup_tx_queue_size(trxsig_trxgroup *g, int arfcn, int *dropped) {
+  if (!g) return TRXSIG_EINVAL;
+  if (arfcn < 0 || arfcn >= g->S) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_tx_queue_size: bad argument", hipSuccess);
+  if (!g->tx_ready) { if (dropped) *dropped = 0; return 0; }
+  Guard gd(trxsig_device(g->c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(g->c);
+  int32_t n = 0; uint32_t stt = 0;
+  G_HIP(g, hipMemcpyAsync(&n, g->tx.q_n + arfcn, 4, hipMemcpyDeviceToHost, st));
+  G_HIP(g, hipMemcpyAsync(&stt, g->tx.status + arfcn, 4, hipMemcpyDeviceToHost, st));
+  G_HIP(g, hipStreamSynchronize(st));
+  if (dropped) *dropped = (int)(stt & 1u);
+  return n;
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@ Parity status: UNPINNED for the orchestration itself.  Transceiver.cpp cannot be
 radioInterface.h / the USRP driver headers, which this image lacks), and the reference ships no test or vector
 for it, so this file is a line-by-line restatement from the source; every sigProcLib call inside it goes to
 oracle/sigproc_oracle.c, which IS pinned.  Line numbers: Transceiver/Transceiver.cpp."""
+import heapq
 import math
 
 import numpy as np
@@ -31,6 +32,28 @@ def time_less(a, b):                        # GSM::Time::operator< (GSMCommon.h:
     if a[0] == b[0]:
         return a[1] < b[1]
     return fn_delta(a[0], b[0]) < 0
+
+
+def time_greater(a, b):                     # GSM::Time::operator> (GSMCommon.h:431-435)
+    if a[0] == b[0]:
+        return a[1] > b[1]
+    return fn_delta(a[0], b[0]) > 0
+
+
+class Queued:
+    """One entry of mTransmitPriorityQueue.  The reference's queue is a std::priority_queue<radioVector*, std::vector<...>,
+    PointerCompare> with the comparator *v1 > *v2 on the bursts' timestamps (CommonLibs/Interthread.h:432-463,
+    Transceiver/radioInterface.h:58, 64-72); which of two bursts with EQUAL timestamps leaves first depends on the heap's
+    shape.  Python's heapq moves elements exactly as libstdc++'s push_heap / pop_heap do (sift to a leaf taking the right child
+    on a tie, then up while strictly smaller), so with __lt__(a, b) = comp(b, a) the model's queue has the same shape
+    (tests/test_txqueue_order.py holds both against std::priority_queue itself)."""
+    __slots__ = ("time", "payload")
+
+    def __init__(self, time, payload):
+        self.time, self.payload = time, payload
+
+    def __lt__(self, other):
+        return time_greater(other.time, self.time)
 
 
 class TransceiverModel:
@@ -230,20 +253,17 @@ class TransceiverModel:
         m = self.o.modulate(np.asarray(bits, np.int8), 8 + (tn % 4 == 0))
         q = int(-rssi / 10)                                                  # C integer division truncates toward zero
         m = self.o.scale_vector(m, complex(np.float32(math.pow(10, q)), 0.0))
-        t = (fn, tn)
-        pos = len(self.queue)
-        while pos > 0 and time_less(t, self.queue[pos - 1][0]):
-            pos -= 1
-        self.queue.insert(pos, (t, m))
+        heapq.heappush(self.queue, Queued((fn, tn), m))                      # mTransmitPriorityQueue.write (:109)
 
     def push_radio_vector(self, tn, fn):
         now = (fn, tn)
-        while self.queue and time_less(self.queue[0][0], now):
-            (qfn, qtn), m = self.queue.pop(0)
-            self.filler[qfn % self.filler_modulus[qtn]][qtn] = m
+        while self.queue and time_less(self.queue[0].time, now):             # stale bursts go to the filler table (:142-153)
+            e = heapq.heappop(self.queue)
+            qfn, qtn = e.time
+            self.filler[qfn % self.filler_modulus[qtn]][qtn] = e.payload
         mod = fn % self.filler_modulus[tn]
         from_queue = False
-        if self.queue and self.queue[0][0] == now:
-            self.filler[mod][tn] = self.queue.pop(0)[1]
+        if self.queue and self.queue[0].time == now:                         # :159-173
+            self.filler[mod][tn] = heapq.heappop(self.queue).payload
             from_queue = True
         return self.filler[mod][tn], from_queue

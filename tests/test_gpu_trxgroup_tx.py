@@ -1,0 +1,186 @@
+"""The TRANSMIT half of the Transceiver group (include/trxsig_trxgroup.h, csrc/trxsig_grouptx.hip): addRadioVector /
+pushRadioVector (Transceiver/Transceiver.cpp:100-113, 138-181) for S ARFCNs with the priority queue, the stale-burst dump and
+the filler table [FN % modulus][TN] on the device.  Checked against
+  (1) S independent one-ARFCN objects (include/trxsig_transceiver.h: the reference's own container, std::priority_queue), fed the
+      same 154-byte datagrams in the same order, one burst per call;
+  (2) oracle/transceiver_model.py's add_radio_vector / push_radio_vector on the CPU oracle;
+on every (timeslot, ARFCN) cell: came-from-the-queue flag and the modulated, power-scaled burst that reaches the transmit FIFO,
+value for value -- and the int16 stream the fused transmit back end makes of the group's output against the oracle chain
+(modulateBurst -> scaleVector -> polyphaseResampleVector 96 : 65 -> x 13500 -> int16) on the model's bursts.
+S = 128 ARFCNs x 208 frames, channel combinations I / II / IV / V / VI / VII / NONE (filler moduli 26 / 51 / 102), bursts on
+time, LATE (stale on arrival: they must still land in the filler table), EARLY (many frames ahead), DUPLICATES (two bursts
+for one timestamp: the heap's shape decides which goes out), RSSI over the whole signed byte, pushes of 1 ... 40 timeslots
+starting on any timeslot, a start just below the hyperframe wrap."""
+import numpy as np
+import pytest
+
+import _pkg
+import oraclebind
+import synth
+import transceiver_model as tm
+from test_gpu_trxgroup import configure
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _pkg.load()
+
+
+def datagram(tn, fn, rssi, bits):
+    d = np.zeros(154, np.uint8)
+    d[0] = tn
+    d[1:5] = [(fn >> 24) & 255, (fn >> 16) & 255, (fn >> 8) & 255, fn & 255]
+    d[5] = np.uint8(rssi & 255)
+    d[6:] = bits
+    return d
+
+
+def traffic(rng, S, fn, chan_used, tame=()):
+    """The datagrams the GSM core sends while frame `fn` is on the air: (arfcn, datagram) in arrival order.  RSSI (an
+    attenuation in dB) covers the whole signed byte except on the ARFCNs in `tame`, whose int16 stream is compared: a negative
+    RSSI is a gain of up to 10^12, the samples leave the int16 range and the reference's (short) cast is undefined there."""
+    out = []
+    H = tm.HYPERFRAME
+    for a in range(S):
+        for tn in range(8):
+            if not chan_used[a][tn]:
+                continue
+            r = rng.random()
+            rssi = int(rng.integers(-128, 128)) if (rng.random() < 0.3 and a not in tame) else int(rng.integers(0, 40))
+            bits = lambda: rng.integers(0, 2, 148).astype(np.uint8) * (1 + 2 * int(rng.integers(0, 2)))   # (1 or 3: only bit 0 counts)
+            if r < 0.55:
+                out.append((a, datagram(tn, (fn + 3) % H, rssi, bits())))
+            elif r < 0.62:                                               # a duplicate: two bursts for one timestamp (and a third now and then)
+                for _ in range(2 + (rng.random() < 0.3)):
+                    out.append((a, datagram(tn, (fn + 3) % H, rssi, bits())))
+            elif r < 0.68:                                               # late: its slot has gone by
+                out.append((a, datagram(tn, (fn - 1 - int(rng.integers(0, 4))) % H, rssi, bits())))
+            elif r < 0.73:                                               # early
+                out.append((a, datagram(tn, (fn + 4 + int(rng.integers(0, 25))) % H, rssi, bits())))
+    order = rng.permutation(len(out))
+    return [out[i] for i in order]
+
+
+@pytest.mark.parametrize("sps,S,frames,fn0", [(1, 128, 208, tm.HYPERFRAME - 90), (4, 8, 40, 1234)])
+def test_group_transmit_half(pkg, golden, sps, S, frames, fn0):
+    import torch
+    from openbts_ttsou_amd.frontend import TxBackEnd, OUTHISTORY
+    dev = torch.device("cuda:0")
+    o = oraclebind.Oracle(sps)
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)        # group A: what goes out, cell by cell
+    grp_b = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)      # group B: the same straight into the transmit back end
+    lpf = golden("resample.npz")["lpf651_gain96"]
+    be = TxBackEnd(ctx, S, lpf, max_bursts=64)
+    objs = [pkg.TrxHost(sps, 0) for _ in range(S)]
+    models = [tm.TransceiverModel(o) for _ in range(S)]
+    chan_used = []
+    for a in range(S):
+        ra = configure(lambda m: grp.control(a, m), a)
+        assert ra == configure(lambda m: grp_b.control(a, m), a) == configure(objs[a].control, a) == configure(models[a].control, a)
+        chan_used.append([models[a].chan_type[tn] != tm.NONE or (a + tn) % 5 == 0 for tn in range(8)])   # (some traffic on idle slots too)
+    rng = np.random.default_rng(2024 + sps)
+    H = tm.HYPERFRAME
+    n_slots_total = frames * 8
+    pos = first = int(rng.integers(0, 8))                       # the first push starts on any timeslot
+    fed_until = -1                                              # last frame whose traffic has been added
+    streams = (0, 1, S - 1)                                     # int16 stream checked for these ARFCNs
+    hist = {s: np.zeros(2 * 65 * sps, np.complex64) for s in streams}
+    send = {s: np.zeros(0, np.complex64) for s in streams}
+    inchunk = 65 * 9 * sps
+    n_cells = n_fq = n_int16 = 0
+    while pos < n_slots_total:
+        n = int(rng.integers(1, 41))
+        n = min(n, n_slots_total - pos)
+        last_frame = (pos + n - 1) // 8
+        # the core's traffic up to the frame the push ends in (adds before pushes, as the two service loops interleave)
+        dgs, arf = [], []
+        for f in range(fed_until + 1, last_frame + 1):
+            for a, d in traffic(rng, S, (fn0 + f) % H, chan_used, tame=streams):
+                dgs.append(d); arf.append(a)
+        fed_until = max(fed_until, last_frame)
+        if dgs:
+            dg = np.stack(dgs); ar = np.array(arf, np.int32)
+            grp.add_bursts(dg, ar); grp_b.add_bursts(dg, ar)
+            for a, d in zip(arf, dgs):
+                tn, fn, rssi, bits = objs[a].decode_tx_datagram(d.tobytes())
+                assert (tn, fn) == (int(d[0]), int.from_bytes(d[1:5].tobytes(), "big"))
+                objs[a].add_radio_vector(bits, rssi, tn, fn)
+                mt, mf, mr, mb = models[a].decode_tx_datagram(d.tobytes())
+                models[a].add_radio_vector(mb, mr, mt, mf)
+        fn, tn = (fn0 + pos // 8) % H, pos % 8
+        bits_d, gain_d, fq_d = grp.push(fn, tn, n)
+        grp_b.push_txbe(be, fn, tn, n)
+        got_iq = be.pop_samples()
+        # the group's output, modulated on the device exactly as addRadioVector does (modulateBurst + scaleVector)
+        guard = np.array([8 + (((tn + t) % 8) % 4 == 0) for t in range(n)], np.int32)
+        guard_all = torch.from_numpy(np.tile(guard, S)).to(dev)
+        length = (sps * (148 + np.tile(guard, S))).astype(np.int32)
+        off = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
+        out = torch.zeros(int(length.sum()), 2, device=dev)
+        ctx.modulate(bits_d.reshape(S * n, 148).contiguous(), guard_all, out, torch.from_numpy(off).to(dev), gain=gain_d.reshape(-1).contiguous())
+        xs = out.cpu().numpy().view(np.complex64).ravel()
+        fq = fq_d.cpu().numpy()
+        for t in range(n):
+            sfn, stn = (fn0 + (pos + t) // 8) % H, (pos + t) % 8
+            for a in range(S):
+                want, wfq = objs[a].push_radio_vector(stn, sfn)
+                mwant, mfq = models[a].push_radio_vector(stn, sfn)
+                k = a * n + t
+                mine = xs[off[k]:off[k] + length[k]]
+                assert bool(fq[a, t]) == wfq == mfq, (a, sfn, stn)
+                assert np.array_equal(mine, want) and np.array_equal(mine, mwant), (a, sfn, stn)
+                n_fq += wfq
+                if a in send:
+                    send[a] = np.concatenate([send[a], mwant])
+        n_cells += n * S
+        # the int16 stream of group B through the fused back end against the oracle chain on the model's bursts
+        nch = len(send[streams[0]]) // inchunk
+        if nch == 0:
+            assert got_iq is None
+        else:
+            iq = got_iq.cpu().numpy()
+            for s in streams:
+                tr = send[s][:nch * inchunk]
+                y = o.polyphase_resample(np.concatenate([hist[s], tr]), 96, 65 * sps, lpf)
+                y = o.scale_vector(y, complex(13500.0, 0.0))
+                want = np.stack([np.trunc(y.real), np.trunc(y.imag)], axis=1).astype(np.int16)[OUTHISTORY:]
+                assert iq[s].shape == want.shape and np.array_equal(iq[s], want), (s, pos)
+                hist[s] = tr[-2 * 65 * sps:]
+                send[s] = send[s][nch * inchunk:]
+                n_int16 += want.shape[0]
+        pos += n
+    assert pos == n_slots_total and n_cells == (n_slots_total - first) * S
+    assert n_fq > n_cells // 4 and n_int16 > 1000
+    for a in (0, S // 2, S - 1):                                # what is left queued (the early bursts) agrees too, nothing was dropped
+        q, dropped = grp.tx_queue_size(a)
+        assert q == objs[a].L.trxsig_trx_queue_size(objs[a].h) == len(models[a].queue) and not dropped
+    for x in objs:
+        x.close()
+    be.close(); grp.close(); grp_b.close(); ctx.close()
+
+
+def test_group_transmit_refusals_and_overflow(pkg):
+    """Bad datagrams refuse the whole call; a queue that fills up drops the overflow and says so."""
+    import torch
+    ctx = pkg.TrxSig(1, 0); ctx.use_torch_stream()
+    grp = pkg.TrxGroup(ctx, 4, tsc_leg=pkg.TSCLEG_DEMOD)
+    bits = np.ones(148, np.uint8)
+    ok = datagram(3, 100, 0, bits)
+    for bad, arf in ((datagram(8, 100, 0, bits), 0), (datagram(3, tm.HYPERFRAME, 0, bits), 0), (ok, 4), (ok, -1)):
+        with pytest.raises(pkg.TrxSigError):
+            grp.add_bursts(np.stack([ok, bad]), np.array([0, arf], np.int32))
+    assert grp.tx_queue_size(0) == (0, False)
+    grp.add_bursts(np.stack([datagram(k % 8, 1000 + k // 8, 0, bits) for k in range(300)]), np.full(300, 2, np.int32))
+    assert grp.tx_queue_size(2) == (256, True) and grp.tx_queue_size(1) == (0, False)
+    b, g, fq = grp.push(1000, 0, 64)                            # the 256 that fitted go out in order, ARFCN 1 sends the dummy burst
+    torch.cuda.synchronize()
+    fq = fq.cpu().numpy()
+    assert fq[2].all() and not fq[1].any()
+    dummy = np.array([int(c) for c in tm.DUMMY_BURST], np.uint8)
+    assert np.array_equal(b.cpu().numpy()[1, 5], dummy) and float(g.cpu().numpy()[1, 5]) == 1.0
+    grp.close(); ctx.close()

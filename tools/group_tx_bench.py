@@ -1,0 +1,66 @@
+"""Side measurement, the TRANSMIT half of the Transceiver group: per step the GSM core's datagrams for F frames of S ARFCNs
+(every timeslot carries a burst) are added (trxsig_trxgroup_add_bursts: host parse + sort, one upload, queue insertion on the
+device) and the same F frames are pushed straight into the fused transmit back end (trxsig_trxgroup_push_txbe: queue / stale
+dump / filler table on the device, then ONE kernel bits -> modulate -> resample -> int16 at the pop).
+    python tools/group_tx_bench.py [S] [frames per step]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+import numpy as np
+import torch
+import _pkg
+pkg = _pkg.load()
+from openbts_ttsou_amd.frontend import TxBackEnd
+from openbts_ttsou_amd import synth
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+sps = 4
+lpf = synth.design_lpf(651, 96)
+ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+for a in range(S):
+    for tn in range(8):
+        grp.control(a, "CMD SETSLOT %d %d" % (tn, 5 if (tn == 0 and a % 8 == 0) else 1))
+be = TxBackEnd(ctx, S, lpf, max_bursts=8 * F)
+rng = np.random.default_rng(3)
+n = S * 8 * F
+base = np.zeros((n, 154), np.uint8)
+base[:, 6:] = rng.integers(0, 2, (n, 148))
+base[:, 5] = rng.integers(0, 30, n)
+arf = np.repeat(np.arange(S, dtype=np.int32), 8 * F)
+tn = np.tile(np.tile(np.arange(8), F), S)
+fo = np.tile(np.repeat(np.arange(F), 8), S)
+base[:, 0] = tn
+perm = rng.permutation(n)                                   # arrival order: ARFCNs interleaved
+base, arf, fo = base[perm], arf[perm], fo[perm]
+fn = 1000
+t_add = t_push = 0.0
+
+
+def step():
+    global fn, t_add, t_push
+    f = (fn + fo).astype(np.uint32)
+    base[:, 1] = f >> 24; base[:, 2] = (f >> 16) & 255; base[:, 3] = (f >> 8) & 255; base[:, 4] = f & 255
+    t0 = time.perf_counter()
+    grp.add_bursts(base, arf)
+    t1 = time.perf_counter()
+    grp.push_txbe(be, fn, 0, 8 * F)
+    iq = be.pop_samples()
+    t_add += t1 - t0; t_push += time.perf_counter() - t1
+    fn += F
+    return iq
+
+for _ in range(10): iq = step()
+torch.cuda.synchronize()
+K = 100
+t_add = t_push = 0.0
+t0 = time.perf_counter()
+for _ in range(K): iq = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+q, dropped = grp.tx_queue_size(0)
+print(json.dumps({"arfcns": S, "frames_per_step": F, "bursts_per_step": n, "us_per_step": round(dt * 1e6, 1),
+                  "Mbursts_per_s": round(n / dt / 1e6, 2), "host_us_in_add_bursts": round(t_add / K * 1e6, 1),
+                  "host_us_in_push_and_pop": round(t_push / K * 1e6, 1), "int16_pairs_out_per_stream": int(iq.shape[1]),
+                  "queue_left": q, "dropped": dropped,
+                  "one_burst_per_call_object": "trxsig_trx_add_radio_vector + _push_radio_vector: ~40 + ~10 us per burst (tools/host_path_bench.py)"}))
