@@ -87,6 +87,31 @@ double trxsig_trx_energy_threshold(const trxsig_trx *t);
 int trxsig_trx_filler_modulus(const trxsig_trx *t, int tn);
 int trxsig_trx_queue_size(const trxsig_trx *t);
 
+/* ---- driveTransmitFIFO's deadline clock and latency controller (:679-729) and writeClockInterface (:733-746) as a pure state
+ * machine (no device, no socket: a service loop feeds it the radio clock and moves its answers).  GSM::Time arithmetic as the
+ * reference's class does it (GSM/GSMCommon.h:327-455: operator+(Time), incTN, decTN, the wrap-aware comparisons).
+ *   mTransmitDeadlineClock = the burst that must be pushed into the transmit FIFO now; mTransmitLatency = how far ahead of the
+ *   radio clock it runs (runTransceiver.cpp:53: GSM::Time(2,0)); after an under-run the latency grows by one frame (at most
+ *   once per 10 frames), after 216 frames without one it shrinks by a timeslot while above GSM::Time(1,1). */
+typedef struct {
+  int deadline_fn, deadline_tn;        /* mTransmitDeadlineClock */
+  int latency_fn, latency_tn;          /* mTransmitLatency */
+  int latency_update_fn, latency_update_tn;   /* mLatencyUpdateTime */
+  int last_clock_fn, last_clock_tn;    /* mLastClockUpdateTime */
+} trxsig_txclock;
+/* Transceiver::Transceiver (:50-57): all three clocks start at the start time */
+void trxsig_txclock_init(trxsig_txclock *c, int start_fn, int start_tn, int latency_fn, int latency_tn);
+/* One pass of driveTransmitFIFO's loop `while (radioClock + latency > deadline) { ...; pushRadioVector(deadline); deadline.incTN(); }`
+ * with the radio clock at (radio_fn, radio_tn).  *underrun = RadioInterface::isUnderrun()'s flag, read and cleared where the
+ * reference reads it (first iteration).  Returns how many timeslots to push, starting at (*push_fn, *push_tn) = the deadline
+ * before the call; at most max_slots per call (call again for the rest; 0 = nothing due). */
+int trxsig_txclock_advance(trxsig_txclock *c, int radio_fn, int radio_tn, int *underrun, int max_slots, int *push_fn, int *push_tn);
+/* "periodically update GSM core clock" (:617-618): 1 when mTransmitDeadlineClock > mLastClockUpdateTime + GSM::Time(216,0) */
+int trxsig_txclock_indication_due(const trxsig_txclock *c);
+/* writeClockInterface (:733-746): "IND CLOCK <deadline FN + 20>" into msg (NUL-terminated; send strlen + 1 bytes), and
+ * mLastClockUpdateTime = mTransmitDeadlineClock.  Returns the string length, < 0 when cap is too small. */
+int trxsig_txclock_indication(trxsig_txclock *c, char *msg, int cap);
+
 /* createLPF (sigProcLib.cpp:1102-1150): the reference loads one of two coefficient tables (651 receive /
  * 961 send; the cutoff argument is ignored) and normalises it to gainDC / sum(taps), the sum in double.
  * The tables are reference data and are passed in by the caller. */

@@ -42,6 +42,20 @@ const char kDummyBurst[149] =
     "011001100111001111010011111000100101111101010000";
 
 bool time_greater(const Time &a, const Time &b) { return a.fn == b.fn ? a.tn > b.tn : fn_compare(a.fn, b.fn) > 0; }   // GSMCommon.h:431-435
+Time time_plus(const Time &a, const Time &b) {               // Time::operator+(const Time&) (GSMCommon.h:405-410)
+  Time r;
+  r.tn = (a.tn + b.tn) % 8;
+  r.fn = (int)(((long long)a.fn + b.fn + (a.tn + b.tn) / 8) % kHyperframe);
+  return r;
+}
+void time_inc_tn(Time &t) {                                  // incTN() (GSMCommon.h:375-386)
+  t.tn += 1;
+  if (t.tn > 7) { t.tn -= 8; t.fn = (t.fn + 1) % kHyperframe; }
+}
+void time_dec_tn(Time &t) {                                  // decTN() (GSMCommon.h:363-373)
+  t.tn -= 1;
+  if (t.tn < 0) { t.tn += 8; t.fn -= 1; if (t.fn < 0) t.fn += kHyperframe; }
+}
 
 struct Queued {
   Time time;
@@ -495,6 +509,53 @@ int trxsig_trx_push_radio_vector(trxsig_trx *t, int tn, int fn, trxsig_c32 *h_ou
   *n_out = (int)v.size();
   if (from_queue) *from_queue = fq;
   return TRXSIG_OK;
+}
+
+// ---- driveTransmitFIFO's controller (:679-729) ----
+
+void trxsig_txclock_init(trxsig_txclock *c, int start_fn, int start_tn, int latency_fn, int latency_tn) {
+  if (!c) return;
+  c->deadline_fn = c->latency_update_fn = c->last_clock_fn = start_fn;
+  c->deadline_tn = c->latency_update_tn = c->last_clock_tn = start_tn;
+  c->latency_fn = latency_fn; c->latency_tn = latency_tn;
+}
+
+int trxsig_txclock_advance(trxsig_txclock *c, int radio_fn, int radio_tn, int *underrun, int max_slots, int *push_fn, int *push_tn) {
+  if (!c || !push_fn || !push_tn || max_slots <= 0) return TRXSIG_EINVAL;
+  const Time radio{radio_fn, radio_tn};
+  Time deadline{c->deadline_fn, c->deadline_tn}, latency{c->latency_fn, c->latency_tn}, upd{c->latency_update_fn, c->latency_update_tn};
+  *push_fn = deadline.fn; *push_tn = deadline.tn;
+  int n = 0;
+  while (n < max_slots && time_greater(time_plus(radio, latency), deadline)) {
+    if (underrun && *underrun) {                             // isUnderrun() reads and clears the flag (radioInterface.h:172)
+      *underrun = 0;
+      // only do latency update every 10 frames, so we don't over update (:697-703)
+      if (time_greater(radio, time_plus(upd, Time{10, 0}))) { latency = time_plus(latency, Time{1, 0}); upd = radio; }
+    } else if (time_greater(latency, Time{1, 1})) {          // no under-run for a second (216 frames): one timeslot less (:705-714)
+      if (time_greater(radio, time_plus(upd, Time{216, 0}))) { time_dec_tn(latency); upd = radio; }
+    }
+    time_inc_tn(deadline);                                   // pushRadioVector(mTransmitDeadlineClock); mTransmitDeadlineClock.incTN() (:716-717)
+    n++;
+  }
+  c->deadline_fn = deadline.fn; c->deadline_tn = deadline.tn;
+  c->latency_fn = latency.fn; c->latency_tn = latency.tn;
+  c->latency_update_fn = upd.fn; c->latency_update_tn = upd.tn;
+  return n;
+}
+
+int trxsig_txclock_indication_due(const trxsig_txclock *c) {
+  if (!c) return 0;
+  return time_greater(Time{c->deadline_fn, c->deadline_tn}, time_plus(Time{c->last_clock_fn, c->last_clock_tn}, Time{216, 0})) ? 1 : 0;
+}
+
+int trxsig_txclock_indication(trxsig_txclock *c, char *msg, int cap) {
+  if (!c || !msg) return TRXSIG_EINVAL;
+  char tmp[50];
+  const int n = std::snprintf(tmp, sizeof tmp, "IND CLOCK %llu", (unsigned long long)(c->deadline_fn + 20));
+  if (n + 1 > cap) return TRXSIG_EINVAL;
+  std::memcpy(msg, tmp, (size_t)n + 1);
+  c->last_clock_fn = c->deadline_fn; c->last_clock_tn = c->deadline_tn;
+  return n;
 }
 
 int trxsig_create_lpf_host(const float *raw, int len, float gainDC, float *out) {

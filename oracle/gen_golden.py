@@ -457,7 +457,8 @@ def gen_gsm_time():
          equal=np.array([g(2, x, y) for x, y in pairs], np.int32), minus=np.array([g(3, x, y) for x, y in pairs], np.int32),
          tn_step=steps, inc_tn=np.array([g(5, x, s=s) for (x, _), s in zip(pairs, steps)], np.int32),
          dec_tn=np.array([g(6, x, s=s) for (x, _), s in zip(pairs, steps)], np.int32),
-         fn_step=fsteps, add_fn=np.array([g(7, x, s=s) for (x, _), s in zip(pairs, fsteps)], np.int32))
+         fn_step=fsteps, add_fn=np.array([g(7, x, s=s) for (x, _), s in zip(pairs, fsteps)], np.int32),
+         plus=np.array([g(8, x, y) for x, y in pairs], np.int32))
 
 
 BITVECTORTEST_MC = ("000000000000111100000000000001110000011100001101000011000000000000000111000011110000100100001010"

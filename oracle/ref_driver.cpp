@@ -478,6 +478,7 @@ int ref_gsm_time(int op, int fn1, int tn1, int fn2, int tn2, int step, int *out,
     case 5: a.incTN((unsigned)step); break;
     case 6: a.decTN((unsigned)step); break;
     case 7: a += step; break;
+    case 8: a = a + b; break;                               // Time::operator+(const Time&) (GSMCommon.h:405-410)
     default: return -1;
   }
   *out_fn = a.FN(); *out_tn = (int)a.TN();

@@ -32,7 +32,7 @@ def c64(x):
 
 def gsm_time(lib, op, a, b=(0, 0), step=0):
     """GSM::Time of the compiled reference: op 0 a<b, 1 a>b, 2 a==b, 3 a-b, 4 FNDelta(a.fn, b.fn) -> int;
-    op 5 incTN(step), 6 decTN(step), 7 a += step -> (fn, tn)."""
+    op 5 incTN(step), 6 decTN(step), 7 a += step, 8 a + b -> (fn, tn)."""
     out, ofn, otn = C.c_int(), C.c_int(), C.c_int()
     rc = lib.ref_gsm_time(op, int(a[0]), int(a[1]), int(b[0]), int(b[1]), int(step), C.byref(out), C.byref(ofn), C.byref(otn))
     assert rc == 0
