@@ -122,7 +122,7 @@ struct Loopback {
 }  // namespace
 
 int main(int argc, char **argv) {
-  int port = 5700, N = 1, sps = 1, device = 0, frame_us = 4615, frames = 0, stall_frame = -1, stall_ms = 0;
+  int port = 5700, N = 1, sps = 1, device = 0, frame_us = 4615, frames = 0, stall_frame = -1, stall_ms = 0, dbg_arfcn = -1;
   const char *leg_name = nullptr;
   for (int i = 1; i + 1 < argc; i += 2) {
     if (!std::strcmp(argv[i], "--port")) port = std::atoi(argv[i + 1]);
@@ -135,6 +135,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--device")) device = std::atoi(argv[i + 1]);
     else if (!std::strcmp(argv[i], "--stall-frame")) stall_frame = std::atoi(argv[i + 1]);
     else if (!std::strcmp(argv[i], "--stall-ms")) stall_ms = std::atoi(argv[i + 1]);
+    else if (!std::strcmp(argv[i], "--debug-arfcn")) dbg_arfcn = std::atoi(argv[i + 1]);
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
   if (N < 1 || N > 1024 || frame_us < 1) { std::fprintf(stderr, "--arfcns 1..1024, --frame-us >= 1\n"); return 2; }
@@ -228,9 +229,15 @@ int main(int argc, char **argv) {
       int pfn = 0, ptn = 0;
       const int n = trxsig_txclock_advance(&txc, fn, 0, &pending_underrun, 64, &pfn, &ptn);
       if (n <= 0) break;
-      const uint8_t *d_bits = nullptr;
+      const uint8_t *d_bits = nullptr, *d_fq = nullptr;
       const float *d_gain = nullptr;
-      CHK(trxsig_trxgroup_push(grp, pfn, ptn, n, &d_bits, &d_gain, nullptr), "trxsig_trxgroup_push");
+      CHK(trxsig_trxgroup_push(grp, pfn, ptn, n, &d_bits, &d_gain, &d_fq), "trxsig_trxgroup_push");
+      if (dbg_arfcn >= 0) {                                 // --debug-arfcn A: which of A's timeslots left the queue (stderr)
+        std::vector<uint8_t> fq((size_t)n);
+        (void)hipMemcpy(fq.data(), d_fq + (size_t)dbg_arfcn * n, (size_t)n, hipMemcpyDeviceToHost);
+        for (int t = 0; t < n; t++)
+          if (fq[(size_t)t]) std::fprintf(stderr, "tx arfcn %d radio fn %d: slot %d of push (%d,%d)+%d from the queue\n", dbg_arfcn, fn, t, pfn, ptn, n);
+      }
       CHK(air.transmit(d_bits, d_gain, pfn, ptn, n), "loopback transmit");
       if (n < 64) break;
     }
@@ -242,6 +249,7 @@ int main(int argc, char **argv) {
       for (int i = 0; i < N; i++) {
         const size_t c = (size_t)tn * N + i;
         if (!valid[c]) continue;
+        if (i == dbg_arfcn) std::fprintf(stderr, "rx arfcn %d fn %d tn %d rssi %d toa %d\n", i, fn, tn, rssi[c], timing[c]);
         uint8_t out[TRXSIG_RX_DATAGRAM_BYTES];
         trxsig_trx_encode_rx_datagram(tn, fn, rssi[c], timing[c], soft.data() + c * 148, 148, out);
         send_to(dat[(size_t)i], port + 102 + 2 * i, out, sizeof out);
