@@ -62,6 +62,10 @@ struct TrxGroupReplay {
 // thr_g / verdict_g (and tix_g on the equalising leg, else NULL): trx_group_replay_scratch(S, n_slots) entries each, the replay's
 // (slot, ARFCN)-ordered outputs before k_group_scatter moves them to the rows
 size_t trx_group_replay_scratch(int S, int n_slots);
+// the gather first, on its own: on a large call it runs on the context's stream BEFORE the fork, so that the side stream's first
+// kernel is the replay itself and starts together with the demodulator -- once that kernel has filled the machine, the replay's
+// few workgroups wait for it to drain (measured: 80 us instead of 15)
+hipError_t trx_launch_group_pack(hipStream_t st, const TrxGroupReplay &a, float4 *packed);
 hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, float4 *packed, double *thr_g, uint8_t *verdict_g, int32_t *tix_g,
                                    TrxProfiler *prof);
 

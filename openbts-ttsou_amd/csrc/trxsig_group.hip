@@ -2,7 +2,8 @@
 //   k_group_expand : (slot, ARFCN) -> row of its correlator class, and the row's burst offset / length;
 //   k_group_pack   : the stateless detectors' answers gathered into (slot, ARFCN) order for the replay;
 //   k_group_replay : class Transceiver's receive state machine (Transceiver/Transceiver.cpp:288-376) for S ARFCNs, a
-//                    lane per ARFCN walking its bursts in time order;
+//                    lane per ARFCN walking its bursts in time order (the adaptive threshold: the serial part);
+//   k_group_cache  : the per-timeslot channel / DFE cache of the equalising leg, a lane per (ARFCN, timeslot);
 //   k_group_toa_eq, k_group_commit : what the equaliser needs from the replay, and the per-slot DFE cache update.
 // The arithmetic of the state machine is the reference's host arithmetic, type by type (double where it uses double);
 // built with -ffp-contract=off like the rest of the library.  exp() comes from a table the host fills with ITS libm
@@ -79,44 +80,67 @@ __global__ __launch_bounds__(256) void k_group_pack(long long n, int n_tsc_rows,
 // being formed per slot, and exp(-frames) is looked up only on a slot where some lane's correlator missed behind an open
 // gate.  Verdicts, thresholds (and the channel cache's events) leave in (slot, ARFCN) order -- one coalesced store each, no
 // predication: the scratch is padded to whole groups and whole waves -- and k_group_scatter puts them where the rows are
-// (and forms SNRestimate, :340, a double division, for the bursts that estimate).  Per-timeslot cache state sits in registers
-// ROTATED so that entry r belongs to timeslot (tn0 + r) & 7: slot i of a 16-slot group always uses entry i & 7.
+// (and forms SNRestimate, :340, a double division, for the bursts that estimate).  The equalising leg's per-timeslot channel
+// cache is NOT in this chain (round 4): it needs the verdicts only and runs after it, a lane per (ARFCN, timeslot): k_group_cache.
 // A step touches only this lane's state; the inputs of a group are loaded ahead of the 16 steps before them.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kReplayDepth = 16;                            // two frames: a group starts on the call's first timeslot number
 constexpr int kExpLds = 64;                                 // exp(-k), k = 0 .. 63, sits in LDS (false detections come in runs)
-enum { RV_SUCC = TRXSIG_F_DETECT, RV_EVT = 0x40 };          // the verdict byte: the gate's value, + "this burst estimates"
+enum { RV_SUCC = TRXSIG_F_DETECT, RV_CONS = 0x08, RV_MARK = 0x10, RV_PASS = 0x20, RV_EVT = 0x40 };   // the verdict byte: the gate's value, + "energy gate open", + "this burst estimates"
 
-template <bool EQ>
+// One burst's step of the machine: (thr, prev_false, dcur) -> the same after the burst; returns the verdict byte.
+// exp_s: exp(-k), k = 0 .. kExpLds-1 in LDS; exp_tab: the whole table in memory (trxsig_group.h).
+__device__ __forceinline__ int replay_step(double &thr, int &prev_false, int &dcur, int code, float avg, int fn, const double *exp_s,
+                                           const double *__restrict__ exp_tab) {
+  const bool act = (code & RP_ACT) != 0;                   // OFF / IDLE slots never reach the state (:288-291)
+  const bool det = (code & RP_DET) != 0;
+  const float thrF = (float)thr;
+  const bool pass = act && (avg > thrF * thrF);
+  const bool succ = pass && det, fail = pass && !det;
+  const bool qdec = act && !pass && dcur > 50;             // ((double)d > 50 of an integer d)
+  double t1 = thr - 1.0;                                   // mEnergyThreshold -= 1.0F; floor 0 (:338-339, 368-369)
+  t1 = t1 < 0.0 ? 0.0 : t1;
+  double tn_ = succ ? t1 : (qdec ? thr - 10.0 : thr);
+  if (__any(fail)) {                                       // exp(-framesElapsed) (:355, 374)
+    const int d = dcur;
+    const bool near = (unsigned)d < (unsigned)kExpLds;
+    double e = exp_s[near ? d : 0];
+    if (__any(fail && !near)) {
+      const int k = d < -TRXG_EXP_LO ? -TRXG_EXP_LO : (d > TRXG_EXP_HI ? TRXG_EXP_HI : d);
+      const double eg = exp_tab[k + TRXG_EXP_LO];
+      e = near ? e : eg;
+    }
+    tn_ = fail ? thr + 10.0 * e : tn_;                     // 10.0F*exp(...): float * double
+  }
+  thr = tn_;
+  const bool mark = fail || qdec;                          // prevFalseDetectionTime = this burst's time
+  prev_false = mark ? fn : prev_false;
+  dcur = mark ? 0 : dcur;
+  // RV_CONS: the step looked at the frame difference to prevFalseDetectionTime (the quiet test or exp(-frames)); RV_MARK: it re-based it
+  return (succ ? RV_SUCC : 0) | (pass ? RV_PASS : 0) | (((act && !pass) || fail) ? RV_CONS : 0) | (mark ? RV_MARK : 0);
+}
+
 __global__ __launch_bounds__(64) void k_group_replay(TrxGroupReplay a, const float4 *__restrict__ packed, double *__restrict__ thr_g,
-                                                     uint8_t *__restrict__ verdict_g, int32_t *__restrict__ tix_g, int Spad) {
-  __shared__ int rot_i[2][8][64];
+                                                     uint8_t *__restrict__ verdict_g, int Spad) {
   __shared__ double exp_s[kExpLds];
+  // a latency chain of a few waves that usually runs BESIDE a kernel filling every SIMD (the demodulator, on the group's side
+  // stream): ask the instruction arbiter for the highest wave priority, or every step waits behind eight other waves' turns
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   exp_s[lane] = a.exp_tab[TRXG_EXP_LO + lane];
   const int col = blockIdx.x * 64 + lane;
   const bool mine = col < a.S;
   const int sc = mine ? col : a.S - 1;                      // (a spare lane shadows the last ARFCN; its state is not stored)
-  TrxGroupArfcn st = a.state[sc];
-  int est[8], src[8];
-  if (EQ) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) { rot_i[0][k][lane] = st.est_fn[k]; rot_i[1][k][lane] = st.tap_src[k]; }
-#pragma unroll
-    for (int r = 0; r < 8; r++) { est[r] = rot_i[0][(a.tn0 + r) & 7][lane]; src[r] = rot_i[1][(a.tn0 + r) & 7][lane]; }
-  }
   __syncthreads();                                          // exp_s complete (the only barrier; every lane reaches it)
-  double thr = st.thr;
-  int prev_false = st.prev_false_fn;
-  const int S8 = a.S * 8;
+  double thr = a.state[sc].thr;
+  int prev_false = a.state[sc].prev_false_fn;
   int fnA = a.fn0;
   // dcur = rxBurst->time() - prevFalseDetectionTime in frames (fn_delta), kept current: +1 (with the hyperframe wrap) at
   // every slot that starts a frame -- the call's very first slot included when it is a timeslot 0, hence the -1 here
   constexpr int half = kHyperframe / 2;
   int dcur = fn_delta(a.fn0, prev_false) - ((a.tn0 & 7) == 0 ? 1 : 0);
   float2 cur[kReplayDepth];
-  int crow[kReplayDepth];
-  auto fetch = [&](int t0, float2 (&v)[kReplayDepth], int (&r)[kReplayDepth]) {
+  auto fetch = [&](int t0, float2 (&v)[kReplayDepth]) {
 #pragma unroll
     for (int i = 0; i < kReplayDepth; i++) {
       const int t = t0 + i;
@@ -124,83 +148,210 @@ __global__ __launch_bounds__(64) void k_group_replay(TrxGroupReplay a, const flo
       const size_t g = (size_t)(in ? t : 0) * a.S + sc;
       const float2 w = *reinterpret_cast<const float2 *>(packed + g);   // {code, avgPwr}; the amplitude is k_group_scatter's business
       v[i] = in ? w : make_float2(0.0f, 0.0f);
-      if (EQ) r[i] = in ? a.rowmap[g] : -1;                 // (the cache remembers WHICH row's taps a slot uses)
     }
   };
-  fetch(0, cur, crow);
+  fetch(0, cur);
   for (int t0 = 0; t0 < a.n_slots; t0 += kReplayDepth) {
     float2 nxt[kReplayDepth];
-    int nrow[kReplayDepth];
-    fetch(t0 + kReplayDepth, nxt, nrow);
+    fetch(t0 + kReplayDepth, nxt);
     double *__restrict__ thr_row = thr_g + (size_t)t0 * Spad;
     uint8_t *__restrict__ v_row = verdict_g + (size_t)t0 * Spad;
-    int32_t *__restrict__ tix_row = EQ ? tix_g + (size_t)t0 * Spad : nullptr;
 #pragma unroll
     for (int i = 0; i < kReplayDepth; i++) {
-      const int r = i & 7;
       int fn = fnA + ((a.tn0 + i) >> 3);                     // (uniform)
       fn -= fn >= kHyperframe ? kHyperframe : 0;
       if (((a.tn0 + i) & 7) == 0) {                          // a new frame (uniform branch)
         dcur += 1;
         dcur -= dcur >= half ? kHyperframe : 0;
       }
-      const int code = __float_as_int(cur[i].x);
-      const bool act = (code & RP_ACT) != 0;                 // OFF / IDLE slots never reach the state (:288-291)
-      const bool det = (code & RP_DET) != 0;
-      const float thrF = (float)thr;
-      const bool pass = act && (cur[i].y > thrF * thrF);
-      const bool succ = pass && det, fail = pass && !det;
-      const bool qdec = act && !pass && dcur > 50;           // ((double)d > 50 of an integer d)
-      bool evt = false;
-      int tix = 0;
-      if (EQ) {                                              // the per-timeslot channel cache (:313-325, 341-349, 357, 370)
-        const bool is_tsc = (code & RP_TSC) != 0;
-        const bool stale = pass && is_tsc && ((double)fn_delta(fn, est[r]) > 50 || src[r] < 0);
-        int sr = stale ? -1 : src[r];
-        evt = succ && stale;                                 // this burst estimates the channel
-        sr = evt ? S8 + crow[i] : sr;
-        est[r] = evt ? fn : est[r];
-        tix = (succ && is_tsc) ? sr : 0;
-        sr = ((fail && is_tsc) || (succ && !is_tsc)) ? -1 : sr;   // a missed normal burst / a detected access burst drop it
-        src[r] = sr;
-      }
-      double t1 = thr - 1.0;                                 // mEnergyThreshold -= 1.0F; floor 0 (:338-339, 368-369)
-      t1 = t1 < 0.0 ? 0.0 : t1;
-      double tn_ = succ ? t1 : (qdec ? thr - 10.0 : thr);
-      if (__any(fail)) {                                     // exp(-framesElapsed) (:355, 374)
-        const int d = dcur;
-        const bool near = (unsigned)d < (unsigned)kExpLds;
-        double e = exp_s[near ? d : 0];
-        if (__any(fail && !near)) {
-          const int k = d < -TRXG_EXP_LO ? -TRXG_EXP_LO : (d > TRXG_EXP_HI ? TRXG_EXP_HI : d);
-          const double eg = a.exp_tab[k + TRXG_EXP_LO];
-          e = near ? e : eg;
-        }
-        tn_ = fail ? thr + 10.0 * e : tn_;                   // 10.0F*exp(...): float * double
-      }
-      thr = tn_;
-      const bool mark = fail || qdec;                        // prevFalseDetectionTime = this burst's time
-      prev_false = mark ? fn : prev_false;
-      dcur = mark ? 0 : dcur;
+      const int v = replay_step(thr, prev_false, dcur, __float_as_int(cur[i].x), cur[i].y, fn, exp_s, a.exp_tab);
       thr_row[(size_t)i * Spad + col] = thr;
-      v_row[(size_t)i * Spad + col] = (uint8_t)((succ ? RV_SUCC : 0) | (evt ? RV_EVT : 0));
-      if (EQ) tix_row[(size_t)i * Spad + col] = tix;
+      v_row[(size_t)i * Spad + col] = (uint8_t)(v & (RV_SUCC | RV_PASS));
     }
     fnA += kReplayDepth / 8;
     fnA -= fnA >= kHyperframe ? kHyperframe : 0;
 #pragma unroll
-    for (int i = 0; i < kReplayDepth; i++) { cur[i] = nxt[i]; crow[i] = nrow[i]; }
+    for (int i = 0; i < kReplayDepth; i++) cur[i] = nxt[i];
   }
   if (!mine) return;
-  st.thr = thr;
-  st.prev_false_fn = prev_false;
-  if (EQ) {
+  a.state[col].thr = thr;
+  a.state[col].prev_false_fn = prev_false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_group_replay_seg<K>: the same machine for a LONG call, parallel in time (round 4).  The chain above is one dependent step per
+// timeslot -- 1,000 slots replay in ~100 us however few ARFCNs there are.  Here an ARFCN's slots are cut into K segments, a
+// lane per (ARFCN, segment); the segments are replayed SIDE BY SIDE from assumed start states (first: the call's own start
+// state), then a lane per ARFCN walks the segment boundaries from the true start and VALIDATES each segment in turn:
+//   a segment's recorded outputs and end state stand if it started from exactly the threshold (the double, bit for bit) the walk
+//   arrives with, and from the same prevFalseDetectionTime -- or never looked at the clock before re-basing it itself (RV_CONS /
+//   RV_MARK: then its outputs do not depend on the incoming prevFalseDetectionTime, and it hands that value on unchanged if it
+//   never re-based it).
+// The first segment that fails the test is replayed again from the state the walk arrived with (which is the TRUE state: everything
+// before it is validated), later segments from the walk's best knowledge; so the validated prefix grows by at least one segment
+// per round, the loop ends after at most K rounds with the serial result value for value, and after one or two when the state
+// forgets its past inside a segment -- the threshold on its floor of 0, a false detection re-basing the clock -- the steady
+// state of a running cell.  Workgroup = 256 / K ARFCNs x K segments, everything about the boundaries in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, const float4 *__restrict__ packed, double *__restrict__ thr_g,
+                                                          uint8_t *__restrict__ verdict_g, int Spad, int Ls) {
+  constexpr int A = 256 / K;
+  enum { SF_CONS = 1, SF_MARK = 2 };                         // looked at the incoming clock before re-basing it / re-based it
+  __shared__ double exp_s[kExpLds];
+  __shared__ long long n_thr[K][A], u_thr[K][A], e_thr[K][A];   // next start / start last run from / end of the last run (as bits)
+  __shared__ int n_pf[K][A], u_pf[K][A], e_pf[K][A];
+  __shared__ uint8_t need[K][A], sflag[K][A];
+  __shared__ int all_done[2];                                // (by round parity: a slow reader of one never meets the next round's writer)
+  __builtin_amdgcn_s_setprio(3);                            // (as k_group_replay: a few latency-bound waves beside a machine-filling kernel)
+  const int tid = threadIdx.x;
+  if (tid < kExpLds) exp_s[tid] = a.exp_tab[TRXG_EXP_LO + tid];
+  const int ai = tid % A, j = tid / A;
+  const int col = blockIdx.x * A + ai;
+  const bool mine = col < a.S;
+  const int sc = mine ? col : a.S - 1;
+  const long long s0_thr = __double_as_longlong(a.state[sc].thr);
+  const int s0_pf = a.state[sc].prev_false_fn;
+  n_thr[j][ai] = s0_thr; n_pf[j][ai] = s0_pf; need[j][ai] = 1;
+  __syncthreads();
+  const int ts = j * Ls, te = (ts + Ls < a.n_slots) ? ts + Ls : a.n_slots;   // this lane's slots [ts, te)
+  constexpr int half = kHyperframe / 2;
+#ifdef TRX_REPLAY_DEBUG
+  long long tk0 = wall_clock64(), t_run = 0, t_walk = 0;
+#endif
+  for (int round = 0;; round++) {
+#ifdef TRX_REPLAY_DEBUG
+    const long long tr0 = wall_clock64();
+#endif
+    if (need[j][ai]) {
+      const long long s_thr = n_thr[j][ai];
+      const int s_pf = n_pf[j][ai];
+      double thr = __longlong_as_double(s_thr);
+      int prev_false = s_pf;
+      // Ls is a multiple of 8 (the launcher's choice), so every segment starts on the call's first timeslot number: the position
+      // of the frame boundary inside a group of eight steps (i0) is the same for every lane -- the step's control flow is uniform
+      const int i0 = (8 - (a.tn0 & 7)) & 7;                  // step i of a group of eight has timeslot number 0 iff i == i0
+      int fn = a.fn0 + ((a.tn0 + ts) >> 3);
+      fn %= kHyperframe;
+      const int dcur0 = fn_delta(fn, prev_false);
+      // the step with timeslot number 0 moves fn and the frame difference on by one BEFORE the burst is looked at; a segment that
+      // starts on such a step starts one behind
+      fn -= i0 == 0 ? 1 : 0;
+      fn += fn < 0 ? kHyperframe : 0;
+      int dcur = dcur0 - (i0 == 0 ? 1 : 0);
+      int seen = 0;                                          // RV_CONS before the first RV_MARK; RV_MARK
+      // the inputs of the next eight slots are in flight while these eight are replayed; slots past the segment's (the call's)
+      // end read as inactive (code 0: the state does not move) and store nothing
+      float2 w[8], wn[8];
+      auto fetch = [&](int t0, float2 (&v)[8]) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) { rot_i[0][(a.tn0 + r) & 7][lane] = est[r]; rot_i[1][(a.tn0 + r) & 7][lane] = src[r]; }
+        for (int i = 0; i < 8; i++) {
+          const int t = t0 + i;
+          const bool in = t < te;
+          const float2 x = *reinterpret_cast<const float2 *>(packed + (size_t)(in ? t : 0) * a.S + sc);
+          v[i] = in ? x : make_float2(0.0f, 0.0f);
+        }
+      };
+      fetch(ts, w);
+      double *pt = thr_g + (size_t)ts * Spad + col;
+      uint8_t *pv = verdict_g + (size_t)ts * Spad + col;
+#pragma unroll 1
+      for (int t0 = ts; t0 < ts + Ls; t0 += 8) {             // (uniform trip count; Ls % 8 == 0)
+        fetch(t0 + 8, wn);
+        const int n_valid = mine ? te - t0 : 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { st.est_fn[k] = rot_i[0][k][lane]; st.tap_src[k] = rot_i[1][k][lane]; }
+        for (int i = 0; i < 8; i++) {
+          if (i == i0) {                                     // a new frame (uniform)
+            fn += 1; fn -= fn >= kHyperframe ? kHyperframe : 0;
+            dcur += 1; dcur -= dcur >= half ? kHyperframe : 0;
+          }
+          const int v = replay_step(thr, prev_false, dcur, __float_as_int(w[i].x), w[i].y, fn, exp_s, a.exp_tab);
+          seen |= ((seen & RV_MARK) ? 0 : (v & RV_CONS)) | (v & RV_MARK);
+          if (i < n_valid) {
+            pt[(size_t)i * Spad] = thr;
+            pv[(size_t)i * Spad] = (uint8_t)(v & (RV_SUCC | RV_PASS));
+          }
+        }
+        pt += (size_t)8 * Spad; pv += (size_t)8 * Spad;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = wn[i];
+      }
+      u_thr[j][ai] = s_thr; u_pf[j][ai] = s_pf;
+      e_thr[j][ai] = __double_as_longlong(thr); e_pf[j][ai] = prev_false;
+      sflag[j][ai] = (uint8_t)(((seen & RV_CONS) ? SF_CONS : 0) | ((seen & RV_MARK) ? SF_MARK : 0));
+    }
+    const int par = round & 1;
+    if (tid == 0) all_done[par] = 1;
+    __syncthreads();
+#ifdef TRX_REPLAY_DEBUG
+    const long long tr1 = wall_clock64();
+    t_run += tr1 - tr0;
+#endif
+    if (j == 0) {                                            // the walk: a lane per ARFCN over its K boundaries
+      long long w_thr = s0_thr;
+      int w_pf = s0_pf;
+      bool prefix = true;                                    // everything before jj is validated: (w_thr, w_pf) is the TRUE state
+      for (int jj = 0; jj < K; jj++) {
+        const int fl = sflag[jj][ai];
+        const bool ok = u_thr[jj][ai] == w_thr && (u_pf[jj][ai] == w_pf || !(fl & SF_CONS));
+        need[jj][ai] = ok ? 0 : 1;
+        if (!ok) { n_thr[jj][ai] = w_thr; n_pf[jj][ai] = w_pf; prefix = false; }
+        // what the walk knows of the state behind segment jj: exact while `prefix`, else the best guess for the segments after it
+        w_thr = e_thr[jj][ai];
+        w_pf = (fl & SF_MARK) ? e_pf[jj][ai] : w_pf;
+      }
+      if (!prefix) all_done[par] = 0;
+      else if (mine) { a.state[col].thr = __longlong_as_double(w_thr); a.state[col].prev_false_fn = w_pf; }
+    }
+    __syncthreads();
+#ifdef TRX_REPLAY_DEBUG
+    t_walk += wall_clock64() - tr1;
+    if ((all_done[par] || round > K + 1) && tid == 0) printf("replay_seg<%d> block %d: %d rounds (n_slots %d, Ls %d) total %lld run %lld walk %lld ticks (100 MHz)\n", K, blockIdx.x, round + 1, a.n_slots, Ls, wall_clock64() - tk0, t_run, t_walk);
+    if (!all_done[par] && j == 0 && round >= 3) {
+      int first_bad = -1;
+      for (int jj = 0; jj < K; jj++) if (need[jj][ai] && first_bad < 0) first_bad = jj;
+      printf("  round %d block %d arfcn %d first invalid segment %d: used thr %.17g pf %d  flags %d\n", round, blockIdx.x, col, first_bad,
+             __longlong_as_double(u_thr[first_bad < 0 ? 0 : first_bad][ai]), u_pf[first_bad < 0 ? 0 : first_bad][ai], sflag[first_bad < 0 ? 0 : first_bad][ai]);
+    }
+#endif
+    if (all_done[par] || round > K + 1) return;                   // (at most K rounds; the bound only makes the exit unconditional)
   }
-  a.state[col] = st;
+}
+
+// The per-timeslot channel cache of the equalising leg (:313-325, 341-349, 357, 370).  What it needs from the threshold
+// recurrence is only each burst's verdict (energy gate open? correlator detected?), and a timeslot's cache entry is touched by
+// that timeslot's bursts alone -- so it is NOT part of the serial chain: a lane per (ARFCN, timeslot) walks its own bursts, one
+// per frame (an eighth of the steps, eight times the lanes, integer work only), after k_group_replay has left the verdicts in
+// (slot, ARFCN) order.  Per burst: the entry is stale when 50 frames have passed since its estimate or it is empty (:317); a
+// detected normal burst behind a stale entry estimates the channel (RV_EVT; its row's taps become the entry); tix = the
+// tap-table entry that equalises the burst; a missed normal burst or a detected access burst drops the entry (:357, :370).
+__global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const float4 *__restrict__ packed, uint8_t *__restrict__ verdict_g,
+                                                     int32_t *__restrict__ tix_g, int Spad) {
+  const int id = blockIdx.x * 256 + threadIdx.x;            // timeslot-major: neighbouring lanes are neighbouring ARFCNs
+  if (id >= 8 * a.S) return;
+  const int tn = id / a.S, col = id - tn * a.S;
+  const int S8 = a.S * 8;
+  int est = a.state[col].est_fn[tn], src = a.state[col].tap_src[tn];
+  for (int t = (tn - a.tn0) & 7; t < a.n_slots; t += 8) {   // the call's slots with this timeslot number
+    int fn = a.fn0 + ((a.tn0 + t) >> 3);
+    fn -= fn >= kHyperframe ? kHyperframe : 0;              // (n_slots < 8 * gHyperframe)
+    const size_t g = (size_t)t * a.S + col, q = (size_t)t * Spad + col;
+    const int code = __float_as_int(packed[g].x);
+    const int v = verdict_g[q];
+    const bool is_tsc = (code & RP_TSC) != 0;
+    const bool pass = (v & RV_PASS) != 0, succ = (v & RV_SUCC) != 0, fail = pass && !succ;
+    const bool stale = pass && is_tsc && (fn_delta(fn, est) > 50 || src < 0);   // ((double)d > 50 of an integer d)
+    int sr = stale ? -1 : src;
+    const bool evt = succ && stale;                          // this burst estimates the channel
+    sr = evt ? S8 + a.rowmap[g] : sr;
+    est = evt ? fn : est;
+    tix_g[q] = (succ && is_tsc) ? sr : 0;
+    sr = ((fail && is_tsc) || (succ && !is_tsc)) ? -1 : sr;
+    src = sr;
+    if (evt) verdict_g[q] = (uint8_t)(v | RV_EVT);
+  }
+  a.state[col].est_fn[tn] = est;
+  a.state[col].tap_src[tn] = src;
 }
 
 // (slot, ARFCN) order -> rows: gate, the threshold after the burst and, on the equalising leg, the estimation events, the tap
@@ -264,15 +415,25 @@ size_t trx_group_replay_scratch(int S, int n_slots) {         // entries of thr_
   return (size_t)((n_slots + kReplayDepth - 1) / kReplayDepth * kReplayDepth) * (size_t)((S + 63) / 64 * 64);
 }
 
+hipError_t trx_launch_group_pack(hipStream_t st, const TrxGroupReplay &a, float4 *packed) {
+  const long long n = (long long)a.n_slots * a.S;
+  if (n <= 0) return hipSuccess;
+  k_group_pack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, a.n_tsc_rows, a.rowmap, a.flags, a.avgpwr, a.amp, packed);
+  return hipGetLastError();
+}
+
 hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, float4 *packed, double *thr_g, uint8_t *verdict_g, int32_t *tix_g,
                                    TrxProfiler *prof) {
   const long long n = (long long)a.n_slots * a.S;
   if (n <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_GROUP, st);
-  k_group_pack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, a.n_tsc_rows, a.rowmap, a.flags, a.avgpwr, a.amp, packed);
   const int Spad = (a.S + 63) / 64 * 64;
-  if (a.equalize) k_group_replay<true><<<dim3(Spad / 64), dim3(64), 0, st>>>(a, packed, thr_g, verdict_g, tix_g, Spad);
-  else k_group_replay<false><<<dim3(Spad / 64), dim3(64), 0, st>>>(a, packed, thr_g, verdict_g, tix_g, Spad);
+  // long calls replay parallel in time (k_group_replay_seg), short ones one step after the other
+  // (segment length: a multiple of eight timeslots, so that every segment starts on the same timeslot number)
+  if (a.n_slots >= 384) k_group_replay_seg<16><<<dim3((a.S + 15) / 16), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 15) / 16 + 7) / 8 * 8);
+  else if (a.n_slots >= 128) k_group_replay_seg<8><<<dim3((a.S + 31) / 32), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 7) / 8 + 7) / 8 * 8);
+  else k_group_replay<<<dim3(Spad / 64), dim3(64), 0, st>>>(a, packed, thr_g, verdict_g, Spad);
+  if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, packed, verdict_g, tix_g, Spad);
   k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g, tix_g);
   if (prof) prof->end(TRXSIG_K_GROUP, st);
   return hipGetLastError();

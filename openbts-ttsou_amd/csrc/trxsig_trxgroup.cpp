@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -109,7 +110,12 @@ struct trxsig_trxgroup {
 };
 
 namespace {
-constexpr int kBesideRows = 24576;                          // calls at least this large replay on the side stream
+// Calls with at least this many rows replay on the group's side stream, beside the demodulator.  Round 3's default was 24,576: the
+// replay was a chain of ~0.1 us per timeslot and hid under the demodulator.  Since round 4 a long call's replay runs parallel in
+// time (k_group_replay_seg: 15 us instead of 88 for 468 slots) and, started beside a kernel that fills the machine, its few
+// workgroups wait for that kernel to drain (80 us): everything on ONE stream is faster (309 against 279 Mbursts/s on bench.py
+// --workload config4).  The side-stream arrangement stays selectable (environment TRXSIG_GROUP_BESIDE_ROWS) and tested.
+constexpr int kBesideRows = 0x7fffffff;
 #define G_HIP(g, call)                                                          \
   do {                                                                          \
     hipError_t e_ = (call);                                                     \
@@ -374,7 +380,9 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   // (a cross-stream dependency costs ~10 us each way: a small call keeps everything on one stream -- 1,024 bursts took 77
   // instead of 48 us with the fork, 65,536 take 229 instead of 281)
   const bool lean = !equalize;
-  const bool beside = lean && n_rows >= kBesideRows;
+  const char *beside_env = std::getenv("TRXSIG_GROUP_BESIDE_ROWS");          // (A/B and the tests of the side-stream arrangement)
+  const int beside_rows = beside_env ? std::atoi(beside_env) : kBesideRows;
+  const bool beside = lean && n_rows >= beside_rows;
   const bool piped = beside && g->pipelined;                // the join is left to the next call but one / trxsig_trxgroup_sync
   if (!piped) G_LIB(join_side(g, st));                      // (state order: nothing replays on this stream before the side stream is done)
   // (an error return between the fork and the join must not leave the side stream working on this call's arrays)
@@ -382,6 +390,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
     hipStream_t s = nullptr;
     ~SideGuard() { if (s) (void)hipStreamSynchronize(s); }
   } side_guard;
+  G_HIP(g, trx_launch_group_pack(st, rp, W.packed.p));
   if (beside) {
     G_HIP(g, hipEventRecord(g->ev_fork, st));
     G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));

@@ -2,6 +2,8 @@
 // int16 / fp16 I/Q conversion.
 // Numerical contract: see trxsig_dev.h / DESIGN.md (every float32 operation is the reference's, in the
 // reference's order; built with -ffp-contract=off).
+#include <cstdlib>
+
 #include "trxsig_dev.h"
 
 namespace {
@@ -272,8 +274,9 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rx_resample: k_resample<int16 in> for the receive front end's shape -- one whole window per workgroup, at most four taps
-//   per output (L <= 4 P) -- with the index walk taken out of the inner loop:
+// k_rx_resample<KQ>: k_resample<int16 in> for the receive front end's shape -- one whole window per workgroup, at most 4 KQ taps
+//   per output (L <= 4 KQ P: KQ = 1 for the 260 : 96 front end at four samples per symbol, KQ = 4 for the reference's own 65 : 96
+//   with its 961-tap table: 15 taps per output) -- with the index walk taken out of the inner loop:
 //     * the window sits in LDS between zero pads, so the reference's two edge rules (skip the taps whose sample lies past the
 //       end, :1183-1186; stop at the first sample before the start, :1196) become products with zero samples -- the samples
 //       are int16 values, hence finite, and adding +-0 to the running sum never changes its value;
@@ -283,56 +286,70 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
 //     * outputIx*Q = branch + P*inOff is divided once per lane and then advanced by 256 Q per output.
 //   Same terms in the same order as k_resample: value-identical (tests/test_gpu_config4.py compares both with the oracle).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a) {
+template <int KQ>                                           // taps per output: at most 4 KQ (L <= 4 KQ P)
+__global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a, int n_windows, int wpb) {
   extern __shared__ __attribute__((aligned(16))) char res_lds[];
-  // [4 zero samples][n window samples][4 zero samples] then the branch-major taps (P x 4 floats)
-  cx *X = reinterpret_cast<cx *>(res_lds) + 4;
-  float4 *TPB = reinterpret_cast<float4 *>(res_lds + sizeof(cx) * (size_t)(a.n + 8));
-  const int w = blockIdx.y, s = blockIdx.z;
+  // [KT zero samples][n window samples][KT zero samples] then the branch-major taps: KQ float4 per branch (one more of pitch when
+  // KQ > 1: consecutive outputs sit Q mod P branches apart, and a power-of-two row pitch would put a wave's rows on a few banks).
+  // A workgroup serves `wpb` consecutive windows of a stream with ONE staging of the taps; the next window's raw samples are
+  // loaded (into registers) before the current window is filtered, so their latency hides under the arithmetic.
+  constexpr int KT = 4 * KQ, TP = KQ > 1 ? KQ + 1 : 1, NQ = 5;      // NQ * 256 >= the longest window (the launcher checks)
+  cx *X = reinterpret_cast<cx *>(res_lds) + KT;
+  float4 *TPB = reinterpret_cast<float4 *>(res_lds + sizeof(cx) * (size_t)(a.n + 2 * KT));
+  const int s = blockIdx.z;
+  const int w0 = blockIdx.y * wpb, w1 = w0 + wpb < n_windows ? w0 + wpb : n_windows;
   const int D = (a.L - 1) / 2 / a.Q;                                // :1177
-  for (int br = threadIdx.x; br < a.P; br += 256) {
+  const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
+  const short2 *hist = a.hist + (size_t)s * a.hist_len;
+  short2 v[NQ];
+  auto fetch = [&](int w) {
+    const int base = w * a.win_step - a.hist_len;                   // raw index of the window's sample 0
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int i = (int)threadIdx.x + 256 * q, r = base + i;
+      v[q] = i < a.n ? (r < 0 ? hist[a.hist_len + r] : raw[r]) : make_short2(0, 0);
+    }
+  };
+  fetch(w0);
+  for (int e = threadIdx.x; e < a.P * KQ; e += 256) {
+    const int br = e / KQ, q = e - br * KQ;
     float t[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int fi = br + a.P * k; t[k] = fi < a.L ? a.lpf[fi] : 0.0f; }
-    TPB[br] = make_float4(t[0], t[1], t[2], t[3]);
+    for (int k = 0; k < 4; k++) { const int fi = br + a.P * (4 * q + k); t[k] = fi < a.L ? a.lpf[fi] : 0.0f; }
+    TPB[br * TP + q] = make_float4(t[0], t[1], t[2], t[3]);
   }
-  if (threadIdx.x < 8) X[threadIdx.x < 4 ? (int)threadIdx.x - 4 : a.n + (int)threadIdx.x - 4] = mk(0, 0);
-  {
-    const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
-    const short2 *hist = a.hist + (size_t)s * a.hist_len;
-    const int base = w * a.win_step - a.hist_len;                   // raw index of the window's sample 0
-    for (int i0 = threadIdx.x; i0 < a.n; i0 += 256 * 8) {
-      short2 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int i = i0 + 256 * q, r = base + i;
-        v[q] = i < a.n ? (r < 0 ? hist[a.hist_len + r] : raw[r]) : make_short2(0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int i = i0 + 256 * q;
-        if (i < a.n) X[i] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
-      }
-    }
-  }
-  __syncthreads();
+  if (threadIdx.x < 2 * KT) X[threadIdx.x < KT ? (int)threadIdx.x - KT : a.n + (int)threadIdx.x - KT] = mk(0, 0);
   const unsigned oq0 = (unsigned)(a.o_skip + (int)threadIdx.x + D) * (unsigned)a.Q;
-  int branch = (int)(oq0 % (unsigned)a.P), inOff = (int)(oq0 / (unsigned)a.P);
+  const int branch0 = (int)(oq0 % (unsigned)a.P), inOff0 = (int)(oq0 / (unsigned)a.P);
   const int step_b = (256 * a.Q) % a.P, step_i = (256 * a.Q) / a.P;
-  cx *out = reinterpret_cast<cx *>(a.out) + (size_t)s * a.out_stride + (size_t)w * a.out_win_step;
-  for (int o = a.o_skip + threadIdx.x; o < a.n_out; o += 256) {
-    // tap k of the reference's walk (fi = branch + P k) meets sample inOff - k; samples outside [0, n) are the zero pads
-    // (the launcher guarantees 0 <= inOff <= n + 3, so every index lies in [-3, n + 3])
-    const float4 tp = TPB[branch];
-    const cx x0 = X[inOff], x1 = X[inOff - 1], x2 = X[inOff - 2], x3 = X[inOff - 3];
-    cx sum = mk(0, 0);
-    sum = cadd(sum, cmulr(x0, tp.x));
-    sum = cadd(sum, cmulr(x1, tp.y));
-    sum = cadd(sum, cmulr(x2, tp.z));
-    sum = cadd(sum, cmulr(x3, tp.w));
-    out[o - a.o_skip] = sum;
-    branch += step_b; inOff += step_i;
-    if (branch >= a.P) { branch -= a.P; inOff++; }
+  for (int w = w0; w < w1; w++) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int i = (int)threadIdx.x + 256 * q;
+      if (i < a.n) X[i] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
+    }
+    __syncthreads();
+    if (w + 1 < w1) fetch(w + 1);
+    int branch = branch0, inOff = inOff0;
+    cx *out = reinterpret_cast<cx *>(a.out) + (size_t)s * a.out_stride + (size_t)w * a.out_win_step;
+    for (int o = a.o_skip + threadIdx.x; o < a.n_out; o += 256) {
+      // tap k of the reference's walk (fi = branch + P k) meets sample inOff - k; samples outside [0, n) are the zero pads
+      // (the launcher guarantees 0 <= inOff <= n + KT - 1, so every index lies in [-(KT - 1), n + KT - 1]); taps past the
+      // filter's end are zeros -- the reference stops there, and a product with 0 adds +-0
+      cx sum = mk(0, 0);
+#pragma unroll
+      for (int q = 0; q < KQ; q++) {
+        const float4 tp = TPB[branch * TP + q];
+        sum = cadd(sum, cmulr(X[inOff - 4 * q], tp.x));
+        sum = cadd(sum, cmulr(X[inOff - 4 * q - 1], tp.y));
+        sum = cadd(sum, cmulr(X[inOff - 4 * q - 2], tp.z));
+        sum = cadd(sum, cmulr(X[inOff - 4 * q - 3], tp.w));
+      }
+      out[o - a.o_skip] = sum;
+      branch += step_b; inOff += step_i;
+      if (branch >= a.P) { branch -= a.P; inOff++; }
+    }
+    __syncthreads();                                                // every lane is done with X before the next window lands
   }
 }
 
@@ -443,12 +460,20 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
   const dim3 grid((a.n_out - a.o_skip + a.OB - 1) / a.OB, n_windows, S), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
   // the receive front end's shape (whole window per workgroup, <= 4 taps per output, indices inside 32 bits): k_rx_resample
-  const bool rx_fast = in_i16 && !out_i16 && a.OB == a.n_out - a.o_skip && a.L <= 4 * a.P && a.n <= 4096 && a.P <= 1024 &&
+  const int kq = a.L <= 4 * a.P ? 1 : (a.L <= 8 * a.P ? 2 : 4);
+  const bool rx_fast = in_i16 && !out_i16 && a.OB == a.n_out - a.o_skip && a.L <= 16 * a.P && a.n <= 5 * 256 && a.P <= 1024 &&
                        (long long)(a.n_out + (a.L - 1) / 2 / a.Q + 256) * a.Q < 0x7fffffffLL && (long long)n_windows * a.win_step < 0x7fffffffLL &&
-                       ((long long)(a.n_out - 1 + (a.L - 1) / 2 / a.Q) * a.Q) / a.P <= a.n + 3;
+                       ((long long)(a.n_out - 1 + (a.L - 1) / 2 / a.Q) * a.Q) / a.P <= a.n + 4 * kq - 1;
   if (rx_fast) {
-    const size_t lds2 = sizeof(trx_c32) * (size_t)(a.n + 8) + sizeof(float) * 4 * (size_t)a.P;
-    k_rx_resample<<<dim3(1, n_windows, S), block, lds2, st>>>(a);
+    const size_t lds2 = sizeof(trx_c32) * (size_t)(a.n + 8 * kq) + sizeof(float) * 4 * (size_t)a.P * (kq > 1 ? kq + 1 : 1);
+    // windows per workgroup: enough workgroups left to fill the machine several times over, else one window each
+    int wpb = 1;
+    while (wpb < 8 && (long long)S * (n_windows / (2 * wpb)) >= 4096) wpb *= 2;
+    if (const char *e = std::getenv("TRXSIG_RXRES_WPB")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) wpb = v; }   // (tests: small cases through the multi-window loop)
+    const dim3 g2(1, (n_windows + wpb - 1) / wpb, S);
+    if (kq == 1) k_rx_resample<1><<<g2, block, lds2, st>>>(a, n_windows, wpb);
+    else if (kq == 2) k_rx_resample<2><<<g2, block, lds2, st>>>(a, n_windows, wpb);
+    else k_rx_resample<4><<<g2, block, lds2, st>>>(a, n_windows, wpb);
   } else if (in_bits && out_i16 && !in_i16) k_resample<RES_IN_BITS, true><<<grid, block, lds, st>>>(a);
   else if (in_bits) return hipErrorInvalidValue;
   else if (in_i16 && !out_i16) k_resample<RES_IN_I16, false><<<grid, block, lds, st>>>(a);

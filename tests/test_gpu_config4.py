@@ -140,6 +140,59 @@ def test_multi_chunk_push_equals_chunk_by_chunk(golden):
         fe.push_chunk(d_iq[:, 2 * OUTCHUNK:4 * OUTCHUNK])
 
 
+@pytest.mark.parametrize("sps,table,taps_per_output", [(1, "sendLPF_961_raw", 15), (1, "rcvLPF_651_raw", 11), (2, "sendLPF_961_raw", 8)])
+def test_rx_resampler_with_many_taps_per_output(golden, sps, table, taps_per_output, monkeypatch):
+    """k_rx_resample<KQ> beyond four taps per output: the reference's own receive configuration is one sample per symbol, 65 : 96
+    with its 961-tap table (createLPF(., 961, 65): radioInterface.cpp:230-234) = 15 taps per output.  The resampled streams
+    equal the oracle's polyphaseResampleVector chunk by chunk behind the 192-sample history, bit for bit."""
+    import torch
+    assert torch.cuda.is_available()
+    pkg = _pkg.load()
+    from openbts_ttsou_amd.frontend import RxFrontEnd, OUTCHUNK, OUTHISTORY
+    S = 3
+    raw = golden("resample.npz")[table]
+    h = pkg.TrxHost(sps, 0)
+    lpf = h.create_lpf(raw, 65.0 * sps)
+    h.close()
+    assert (len(lpf) + 65 * sps - 1) // (65 * sps) == taps_per_output
+    monkeypatch.setenv("TRXSIG_RXRES_WPB", "2")                # two windows per workgroup (what a 128-stream push does) in this small case
+    iq, nchunks = make_streams(sps, S, 12, 3, seed=21 + sps)
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    fe = RxFrontEnd(ctx, S, lpf, max_chunks=4)
+    o = oraclebind.Oracle(sps)
+    hist = [np.zeros(OUTHISTORY, np.complex64) for _ in range(S)]
+    rcv = [np.zeros(0, np.complex64) for _ in range(S)]
+    tn_o, checked, c = 0, 0, 0
+    while c < nchunks:
+        k = min(1 + (c % 3), nchunks - c)                     # pushes of 1, 2, 3 chunks
+        chunk = iq[:, c * OUTCHUNK:(c + k) * OUTCHUNK]
+        fe.push_chunk(torch.from_numpy(np.ascontiguousarray(chunk)).cuda())
+        got = fe.pop_bursts()
+        for s in range(S):
+            for j in range(k):
+                ch = chunk[s, j * OUTCHUNK:(j + 1) * OUTCHUNK]
+                cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)
+                y = o.polyphase_resample(np.concatenate([hist[s], cf]), 65 * sps, 96, lpf)
+                rcv[s] = np.concatenate([rcv[s], y[2 * 65 * sps:]])
+                hist[s] = cf[-OUTHISTORY:]
+        c += k
+        pos, tn = 0, tn_o
+        while len(rcv[0]) - pos > (156 + (tn % 4 == 0)) * sps:
+            pos += (156 + (tn % 4 == 0)) * sps; tn = (tn + 1) % 8
+        if pos == 0:
+            assert got is None
+            continue
+        tn_o = tn
+        x, off, length, tnv = got
+        nb = off.numel() // S
+        xh = x.cpu().numpy().view(np.complex64).ravel(); offh = off.cpu().numpy()
+        for s in range(S):
+            assert_veq(xh[offh[s * nb]:offh[s * nb] + pos], rcv[s][:pos], "resampled stream %d after chunk %d" % (s, c))
+            rcv[s] = rcv[s][pos:]
+        checked += pos
+    assert checked > 1200 * sps
+
+
 @pytest.mark.parametrize("lpf_kind", ["reference_table", "designed"])
 def test_fused_front_end_equals_push_pop_detect(golden, lpf_kind):
     """trxsig_rxfe_push_detect_demod_normal (the detectors compute their samples from the int16 chunks; no resampled stream

@@ -162,7 +162,7 @@ def test_group_equals_single_objects_and_model(pkg, sps, leg, frames):
     S, fn0, tn0 = 128, 1000, 3
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=100 + sps)
-    out, responses, final_thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=(1, 7, 8, 64, 400, 3, 123, 16))
+    out, responses, final_thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=(1, 7, 8, 64, 400, 3, 123, 16, 700))   # (>= 128 slots: the replay runs parallel in time, 8 segments; >= 512: 16)
     thr = out["threshold"][~np.isnan(out["threshold"])]
     assert thr.min() < 200 and thr.max() > 255                           # the thresholds really moved both ways
     assert out["valid"].sum() > 0.2 * (ctype == tm.TSC).sum()
@@ -201,7 +201,7 @@ def test_group_across_the_hyperframe_wrap(pkg, tn0):
     fn0 = tm.HYPERFRAME - 30
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=777 + tn0, quiet_slots=(80, 560))
-    out, responses, final_thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=(5, 16, 1, 240, 33, 8))
+    out, responses, final_thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=(5, 16, 1, 240, 33, 8, 530))       # (the wrap falls into the 240-slot call: segments start on both sides of it)
     thr = out["threshold"][~np.isnan(out["threshold"])]
     assert thr.min() < 245 and thr.max() > 255
     objs = [pkg.TrxHost(sps, 0, start=(fn0, tn0), tsc_leg=leg) for _ in range(S)]
@@ -222,12 +222,14 @@ def test_group_across_the_hyperframe_wrap(pkg, tn0):
                   lambda a: models[a].energy_threshold)
 
 
-def test_pipelined_mode_gives_the_same(pkg):
-    """trxsig_trxgroup_set_pipelined: large pulls leave their replay running on the side stream while the next pull's detectors
+def test_pipelined_mode_gives_the_same(pkg, monkeypatch):
+    """(The side-stream arrangement is no longer the default -- since the replay runs parallel in time, one stream is faster --
+    and is selected here through TRXSIG_GROUP_BESIDE_ROWS.)  trxsig_trxgroup_set_pipelined: large pulls leave their replay running on the side stream while the next pull's detectors
     fill the other workspace set.  Every output of every call (collected after each pull, which joins) equals the default mode's,
     with large and small calls mixed (a small call replays on the context's stream and has to wait for the side stream first);
     and two pipelined pulls in a row with nothing in between leave the FIRST one's result intact (two workspace sets)."""
     import torch
+    monkeypatch.setenv("TRXSIG_GROUP_BESIDE_ROWS", "24576")
     sps, leg, S, frames, fn0, tn0 = 4, 1, 128, 160, 5000, 6
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=4242, quiet_slots=(300, 740))
@@ -437,12 +439,13 @@ def test_group_on_the_fused_front_end(pkg):
     ga.close(); gb.close(); fea.close(); feb.close(); ctx.close()
 
 
-def test_pipelined_mode_on_the_fused_front_end(pkg):
+def test_pipelined_mode_on_the_fused_front_end(pkg, monkeypatch):
     """trxsig_trxgroup_pull_rxfe with trxsig_trxgroup_set_pipelined: 128 ARFCN streams x three pushes of 125 chunks (1,000 slots,
     ~59,000 rows each: large calls), the replay of push i overlapping the detectors of push i+1 -- every collected output and
     the final thresholds equal the default mode's on the same int16 streams (normal bursts at 400 kS/s, combination V on TN 0 of
     every 8th ARFCN so that the access-burst detector and false detections are in play, a stretch of silence)."""
     import torch
+    monkeypatch.setenv("TRXSIG_GROUP_BESIDE_ROWS", "24576")          # (the side-stream arrangement, no longer the default)
     from openbts_ttsou_amd.frontend import RxFrontEnd
     sps, S, K, tsc, pushes = 4, 128, 125, 2, 3
     dev = torch.device("cuda:0")
