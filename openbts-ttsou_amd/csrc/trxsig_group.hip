@@ -325,58 +325,85 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
 // (slot, ARFCN) order.  Per burst: the entry is stale when 50 frames have passed since its estimate or it is empty (:317); a
 // detected normal burst behind a stale entry estimates the channel (RV_EVT; its row's taps become the entry); tix = the
 // tap-table entry that equalises the burst; a missed normal burst or a detected access burst drops the entry (:357, :370).
-__global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const float4 *__restrict__ packed, uint8_t *__restrict__ verdict_g,
-                                                     int32_t *__restrict__ tix_g, int Spad) {
+__global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const float4 *__restrict__ packed, const uint8_t *__restrict__ verdict_g,
+                                                     const double *__restrict__ thr_g, int Spad) {
   const int id = blockIdx.x * 256 + threadIdx.x;            // timeslot-major: neighbouring lanes are neighbouring ARFCNs
   if (id >= 8 * a.S) return;
   const int tn = id / a.S, col = id - tn * a.S;
   const int S8 = a.S * 8;
   int est = a.state[col].est_fn[tn], src = a.state[col].tap_src[tn];
-  for (int t = (tn - a.tn0) & 7; t < a.n_slots; t += 8) {   // the call's slots with this timeslot number
-    int fn = a.fn0 + ((a.tn0 + t) >> 3);
-    fn -= fn >= kHyperframe ? kHyperframe : 0;              // (n_slots < 8 * gHyperframe)
-    const size_t g = (size_t)t * a.S + col, q = (size_t)t * Spad + col;
-    const int code = __float_as_int(packed[g].x);
-    const int v = verdict_g[q];
-    const bool is_tsc = (code & RP_TSC) != 0;
-    const bool pass = (v & RV_PASS) != 0, succ = (v & RV_SUCC) != 0, fail = pass && !succ;
-    const bool stale = pass && is_tsc && (fn_delta(fn, est) > 50 || src < 0);   // ((double)d > 50 of an integer d)
-    int sr = stale ? -1 : src;
-    const bool evt = succ && stale;                          // this burst estimates the channel
-    sr = evt ? S8 + a.rowmap[g] : sr;
-    est = evt ? fn : est;
-    tix_g[q] = (succ && is_tsc) ? sr : 0;
-    sr = ((fail && is_tsc) || (succ && !is_tsc)) ? -1 : sr;
-    src = sr;
-    if (evt) verdict_g[q] = (uint8_t)(v | RV_EVT);
+  const int t_first = (tn - a.tn0) & 7;                     // the call's first slot with this timeslot number
+  int fn = a.fn0 + ((a.tn0 + t_first) >> 3);
+  fn -= fn >= kHyperframe ? kHyperframe : 0;
+  // eight frames' inputs are loaded together (their addresses do not depend on the cache's state) and the next eight are in
+  // flight while these are walked
+  int code[8], ver[8], row[8], ncode[8], nver[8], nrow[8];
+  double thr[8], nthr[8];
+  auto fetch = [&](int tb, int (&c)[8], int (&v)[8], int (&r)[8], double (&th)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int t = tb + 8 * i;
+      const bool in = t < a.n_slots;
+      const size_t g = (size_t)(in ? t : 0) * a.S + col, q = (size_t)(in ? t : 0) * Spad + col;
+      c[i] = in ? __float_as_int(*reinterpret_cast<const float *>(packed + g)) : 0;
+      v[i] = in ? verdict_g[q] : 0;
+      r[i] = in ? a.rowmap[g] : -1;
+      th[i] = thr_g[q];
+    }
+  };
+  fetch(t_first, code, ver, row, thr);
+  for (int tb = t_first; tb < a.n_slots; tb += 64) {
+    fetch(tb + 64, ncode, nver, nrow, nthr);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int t = tb + 8 * i;
+      if (t < a.n_slots) {
+        const int v = ver[i];
+        const bool is_tsc = (code[i] & RP_TSC) != 0;
+        const bool pass = (v & RV_PASS) != 0, succ = (v & RV_SUCC) != 0, fail = pass && !succ;
+        const bool stale = pass && is_tsc && (fn_delta(fn, est) > 50 || src < 0);   // ((double)d > 50 of an integer d)
+        int sr = stale ? -1 : src;
+        const bool evt = succ && stale;                      // this burst estimates the channel
+        sr = evt ? S8 + row[i] : sr;
+        est = evt ? fn : est;
+        const int tix = (succ && is_tsc) ? sr : 0;
+        sr = ((fail && is_tsc) || (succ && !is_tsc)) ? -1 : sr;
+        src = sr;
+        // ... and what k_group_scatter does on the other leg, for this cell's row: the gate, the threshold after the burst, the
+        // estimation event, the tap index, SNRestimate = |amp|^2 / (thr^2 + 1) in double with the threshold AFTER its decrement (:340)
+        const int rw = row[i];
+        if (rw >= 0) {
+          a.gate[rw] = (uint8_t)(v & RV_SUCC);
+          a.thr_after[rw] = thr[i];
+          a.ev[rw] = evt ? 1 : 0;
+          a.tap_ix[rw] = tix;
+          if (evt) {
+            const trx_c32 am = a.amp[rw];
+            const float n2 = am.i * am.i + am.r * am.r;       // Complex::norm2 (Complex.h:119)
+            a.snr[rw] = (float)((double)n2 / (thr[i] * thr[i] + 1.0));
+          }
+        }
+      }
+      fn += 1; fn -= fn >= kHyperframe ? kHyperframe : 0;   // the next frame's slot with this timeslot number
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { code[i] = ncode[i]; ver[i] = nver[i]; row[i] = nrow[i]; thr[i] = nthr[i]; }
   }
   a.state[col].est_fn[tn] = est;
   a.state[col].tap_src[tn] = src;
 }
 
-// (slot, ARFCN) order -> rows: gate, the threshold after the burst and, on the equalising leg, the estimation events, the tap
-// index and SNRestimate = |amp|^2 / (thr^2 + 1) in double with the threshold AFTER its decrement (:340)
+// (slot, ARFCN) order -> rows on the demodulating leg: gate and the threshold after the burst (the equalising leg: k_group_cache)
 __global__ __launch_bounds__(256) void k_group_scatter(TrxGroupReplay a, int Spad, const double *__restrict__ thr_g,
-                                                       const uint8_t *__restrict__ verdict_g, const int32_t *__restrict__ tix_g) {
+                                                       const uint8_t *__restrict__ verdict_g) {
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   if (g >= (long long)a.n_slots * a.S) return;
   const int row = a.rowmap[g];
   if (row < 0) return;
   const int t = (int)(g / a.S), s = (int)(g - (long long)t * a.S);
   const size_t q = (size_t)t * Spad + s;
-  const int v = verdict_g[q];
-  const double thr = thr_g[q];
-  a.gate[row] = (uint8_t)(v & RV_SUCC);
-  a.thr_after[row] = thr;
-  if (a.equalize) {
-    a.ev[row] = (v & RV_EVT) ? 1 : 0;
-    a.tap_ix[row] = tix_g[q];
-    if (v & RV_EVT) {
-      const trx_c32 am = a.amp[row];
-      const float n2 = am.i * am.i + am.r * am.r;           // Complex::norm2 (Complex.h:119)
-      a.snr[row] = (float)((double)n2 / (thr * thr + 1.0));
-    }
-  }
+  a.gate[row] = (uint8_t)(verdict_g[q] & RV_SUCC);
+  a.thr_after[row] = thr_g[q];
 }
 
 __global__ __launch_bounds__(256) void k_group_toa_eq(int n, const uint8_t *__restrict__ gate, const float *__restrict__ toa,
@@ -433,8 +460,10 @@ hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, floa
   if (a.n_slots >= 384) k_group_replay_seg<16><<<dim3((a.S + 15) / 16), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 15) / 16 + 7) / 8 * 8);
   else if (a.n_slots >= 128) k_group_replay_seg<8><<<dim3((a.S + 31) / 32), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 7) / 8 + 7) / 8 * 8);
   else k_group_replay<<<dim3(Spad / 64), dim3(64), 0, st>>>(a, packed, thr_g, verdict_g, Spad);
-  if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, packed, verdict_g, tix_g, Spad);
-  k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g, tix_g);
+  // the equalising leg's cache walk visits every (slot, ARFCN) cell once and leaves the rows' results itself; the other leg scatters
+  (void)tix_g;
+  if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, packed, verdict_g, thr_g, Spad);
+  else k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g);
   if (prof) prof->end(TRXSIG_K_GROUP, st);
   return hipGetLastError();
 }
