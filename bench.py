@@ -359,6 +359,10 @@ class Config4:
             self.segs = [wiq[:, i * K * 864 * CW:(i + 1) * K * 864 * CW].contiguous() for i in range(KT // K)]
             self.wiq, self.CW = wiq, CW
             self.fe = RxFrontEnd(ctx, S // C, self.lpf, max_chunks=K, carrier_freq=self.freqs, rate_factor=CW)
+            self.shared = not bool(getattr(args, "per_carrier_channeliser", False))
+            if self.shared:
+                self.fe.set_shared_filter(True)
+                self.kernel_names["k_resample"] = "k_channelise16<%d>" % C
             del wide, lo_c
         else:
             self.fe = RxFrontEnd(ctx, S, self.lpf, max_chunks=K)
@@ -424,12 +428,15 @@ class Config4:
                     "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                     "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
         if self.wide:
+            form = ("SHARED-FILTER form: unUSRPify, sixteen partial sums of the 8001-tap Kaiser LPF's 260:768 polyphase branches on the raw "
+                    "samples, sixteen complex multiply-adds per carrier (one pass for all carriers; ~1e-6 from the per-carrier form)"
+                    if getattr(self, "shared", False) else
+                    "per carrier unUSRPify + frequencyShift (table trig) + polyphase resample 260:768 (8001-tap Kaiser LPF)")
             return {"workload": "config4 (channeliser): %d wideband streams/GPU at 3.2 MS/s x %d carriers 400 kHz apart (= %d ARFCNs), %d chunks of "
-                                "%d int16 I/Q samples per stream per step; per carrier unUSRPify + frequencyShift (table trig) + polyphase "
-                                "resample 260:768 (8001-tap Kaiser LPF) behind a 1536-sample history in ONE kernel into the receive buffers, "
+                                "%d int16 I/Q samples per stream per step; %s behind a 1536-sample history in ONE kernel into the receive buffers, "
                                 "then 157/156/156/156 slicing (pop) + TSC %d detect (thr 3.0) + demod to %d soft bits through the resampled "
                                 "complex float32 stream; TSC on every slot, fixed thresholds"
-                                % (self.S // self.wide, self.wide, self.S, self.K, 864 * 8, self.tsc, NSOFT),
+                                % (self.S // self.wide, self.wide, self.S, self.K, 864 * 8, form, self.tsc, NSOFT),
                     "streams_per_gpu": self.S, "wideband_streams_per_gpu": self.S // self.wide, "carriers": self.wide,
                     "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                     "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
@@ -679,6 +686,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="also check a sample against the CPU oracle")
     ap.add_argument("--unfused-frontend", action="store_true", help="config4: push + pop + detect through the resampled complex float32 stream instead of the fused front end")
     ap.add_argument("--wideband", type=int, default=0, help="config4: the channeliser -- streams / N wideband streams at 3.2 MS/s carrying N ARFCNs each (N <= 8)")
+    ap.add_argument("--per-carrier-channeliser", action="store_true", help="config4 --wideband: the per-carrier form (bit-equal to the reference's "
+                    "frequencyShift + polyphaseResampleVector per carrier) instead of the shared-filter form (one pass for all carriers, ~1e-6)")
     ap.add_argument("--reference-chain", action="store_true", help="config4: the reference's own configuration -- sps 1, its createLPF(., 961, 65) "
                     "table, the equalising Transceiver leg -- through the group on a push / pop front end")
     ap.add_argument("--stateless-frontend", action="store_true", help="config4: trxsig_rxfe_push_detect_demod_normal (TSC on every slot, fixed thresholds) instead of the Transceiver group")

@@ -88,6 +88,15 @@ int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *ctx, int n_wide_s
                                 int rate_factor, int max_chunks, const float *h_lpf, int L, int swap_iq, int start_tn);
 /* d_iq: int16 I/Q pairs [n_wide_streams][n_chunks * 864 * rate_factor][2] (device): n_chunks chunks of 2.16 ms each */
 int trxsig_rxfe_push_wideband(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks);
+/* The SHARED-FILTER form of the channeliser (round 4; off by default -- the per-carrier form above is the one pinned on the
+ * reference's primitives).  When every carrier lies on the grid of sixteenths of the wideband rate (theta_c = 2 pi k / 16 rad per
+ * sample: with rate_factor 8 that is every 200 kHz) the mixer has period 16 and the C per-carrier filters collapse into ONE pass
+ * over the raw samples: sixteen partial sums of real taps on raw samples per output instant, shared by all carriers, then sixteen
+ * complex multiply-adds per carrier from registers (csrc/trxsig_chan.hip).  The same sum in another order, with exact cos / sin
+ * instead of the reference's table trig and fused multiply-adds: equal to the per-carrier form to ~1e-6 of the signal's scale
+ * (tests/test_gpu_channeliser.py grades it at 1e-4, identical hard bits), 5-10x faster.  Needs 1, 2, 4, 8 or 16 carriers on that
+ * grid and at most 32 taps per output (L <= 32 P); TRXSIG_EINVAL otherwise.  on = 0 returns to the per-carrier form. */
+int trxsig_rxfe_set_shared_filter(trxsig_rxfe *fe, int on);
 
 /* h_lpf: the L (normally 651, createLPF(cutoff, 651, 96): radioInterface.cpp:134-138) normalised taps.  max_bursts: the
  * most bursts per stream one push may carry. */

@@ -4,6 +4,7 @@
 // side only keeps read / write positions and the TN schedule; no sample ever visits the host.
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -47,6 +48,9 @@ struct trxsig_rxfe {
   // output stream s = carrier s % C of raw stream s / C
   int Cw = 0, C = 0, Sw = 0;
   float *d_freq = nullptr;
+  std::vector<float> h_freq;                                // the carrier frequencies as given (trxsig_rxfe_set_shared_filter checks their grid)
+  int shared = 0;                                           // 1: the shared-filter form (trxsig_chan.hip)
+  float2 *d_tw = nullptr;                                   // [C][16] exp(-j theta_c j)
   long long n_total = 0;                                    // raw samples (per wideband stream) received so far, offset by the history
 };
 
@@ -143,6 +147,7 @@ int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *c, int n_wide_str
   if (rc != TRXSIG_OK) return rc;
   trxsig_rxfe *fe = *out;
   fe->Cw = rate_factor; fe->C = n_carriers; fe->Sw = n_wide_streams;
+  fe->h_freq.assign(h_carrier_freq, h_carrier_freq + n_carriers);
   if (trxsig_resample_out_len(fe->n_in * rate_factor, fe->P, TRXSIG_OUTRATE * rate_factor) != fe->n_out) {
     trxsig_rxfe_destroy(fe);
     *out = nullptr;
@@ -192,7 +197,8 @@ int trxsig_rxfe_push_wideband(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks
   a.o_skip = fe->skip; a.n_out = fe->n_out;
   a.out = fe->d_rcv + fe->wr; a.out_stride = fe->stride; a.out_win_step = fe->per_chunk;
   a.mix_freq = fe->d_freq; a.mix_carriers = fe->C; a.mix_n0 = fe->n_total; a.mix_tables = (const TrxTables *)trxsig_tables_device(c);
-  FE_HIP(c, trx_launch_resample_ex(st, a, fe->S, n_chunks, true, false, trx_ctx_profiler(c)));
+  if (fe->shared) FE_HIP(c, trx_launch_channelise16(st, a, fe->Sw, fe->C, n_chunks, fe->d_tw, trx_ctx_profiler(c)));
+  else FE_HIP(c, trx_launch_resample_ex(st, a, fe->S, n_chunks, true, false, trx_ctx_profiler(c)));
   const short2 *tail = reinterpret_cast<const short2 *>(d_iq) + ((size_t)n_chunks * chunk - hist);
   FE_HIP(c, hipMemcpy2DAsync(fe->d_hist, sizeof(short2) * (size_t)hist, tail, sizeof(short2) * (size_t)n_chunks * chunk,
                              sizeof(short2) * (size_t)hist, fe->Sw, hipMemcpyDeviceToDevice, st));
@@ -201,11 +207,41 @@ int trxsig_rxfe_push_wideband(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks
   return TRXSIG_OK;
 }
 
+int trxsig_rxfe_set_shared_filter(trxsig_rxfe *fe, int on) {
+  if (!fe) return TRXSIG_EINVAL;
+  trxsig_ctx *c = fe->c;
+  if (!fe->Cw) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: not a wideband front end", hipSuccess);
+  if (!on) { fe->shared = 0; return TRXSIG_OK; }
+  const int C = fe->C;
+  if (!(C == 1 || C == 2 || C == 4 || C == 8 || C == 16))
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: 1, 2, 4, 8 or 16 carriers", hipSuccess);
+  if ((fe->L + fe->P - 1) / fe->P > 32 || (TRXSIG_OUTCHUNK * fe->Cw) % 16 || (TRXSIG_OUTHISTORY * fe->Cw) % 16)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: needs at most 32 taps per output and chunks of a multiple of 16 samples", hipSuccess);
+  // every carrier on the grid of sixteenths of the wideband rate: theta_c = 2 pi k_c / 16 (to float accuracy)
+  std::vector<float2> tw((size_t)C * 16);
+  for (int k = 0; k < C; k++) {
+    const double bins = (double)fe->h_freq[(size_t)k] / (2.0 * M_PI / 16.0);
+    const double kb = std::nearbyint(bins);
+    if (std::fabs(bins - kb) > 1e-5)
+      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: a carrier frequency is not a multiple of 2 pi / 16 rad per sample", hipSuccess);
+    for (int j = 0; j < 16; j++) {
+      const double ph = 2.0 * M_PI * std::fmod(kb * j, 16.0) / 16.0;
+      tw[(size_t)k * 16 + j] = make_float2((float)std::cos(ph), (float)-std::sin(ph));   // exp(-j theta_c j)
+    }
+  }
+  Guard g(trxsig_device(c));
+  if (!fe->d_tw && hipMalloc((void **)&fe->d_tw, sizeof(float2) * tw.size()) != hipSuccess)
+    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_set_shared_filter: device allocation failed", hipSuccess);
+  FE_HIP(c, hipMemcpy(fe->d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+  fe->shared = 1;
+  return TRXSIG_OK;
+}
+
 void trxsig_rxfe_destroy(trxsig_rxfe *fe) {
   if (!fe) return;
   {
     Guard g(trxsig_device(fe->c));
-    (void)hipFree(fe->d_freq);
+    (void)hipFree(fe->d_freq); (void)hipFree(fe->d_tw);
     (void)hipFree(fe->d_rcv); (void)hipFree(fe->d_tmp); (void)hipFree(fe->d_hist); (void)hipFree(fe->d_lpf); (void)hipFree(fe->d_idx);
     (void)hipFree(fe->d_keep); (void)hipFree(fe->d_tpb);
   }

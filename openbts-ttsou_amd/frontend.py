@@ -32,6 +32,7 @@ def _bind(L):
                                                        C.POINTER(i32)]
     L.trxsig_rxfe_create_wideband.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, i32, vp, i32, i32, i32]
     L.trxsig_rxfe_push_wideband.argtypes = [vp, vp, i32]
+    L.trxsig_rxfe_set_shared_filter.argtypes = [vp, i32]
     L.trxsig_txbe_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp, i32, C.c_float]
     L.trxsig_txbe_destroy.argtypes = [vp]; L.trxsig_txbe_destroy.restype = None
     L.trxsig_txbe_push_bursts.argtypes = [vp, vp, vp, vp, i32]
@@ -66,6 +67,11 @@ class RxFrontEnd:
                                                start_tn), "trxsig_rxfe_create")
             self.S = n_streams
         self.h = h
+
+    def set_shared_filter(self, on=True):
+        """The channeliser's shared-filter form (carriers on the grid of sixteenths of the wideband rate): one pass over the raw
+        samples for all carriers, ~1e-6 from the per-carrier form instead of bit-equal."""
+        self.ctx._chk(self.L.trxsig_rxfe_set_shared_filter(self.h, int(on)), "trxsig_rxfe_set_shared_filter")
 
     def push_wideband(self, iq):
         """iq: int16 tensor [Sw, K*864*rate_factor, 2] (device), K whole chunks per wideband stream."""

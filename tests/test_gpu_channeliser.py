@@ -148,3 +148,86 @@ def test_channeliser_equals_reference_primitives_per_carrier():
             pos += n
     print("channeliser vs running-sum frequencyShift: worst soft-bit difference %.2e" % worst)
     assert worst < 0.1                                                  # (measured: 3e-2 -- the running sum's own drift, not ours)
+
+
+
+@pytest.mark.parametrize("offsets", [(-600e3, -200e3, 200e3, 600e3), (-1400e3, -1000e3, -600e3, -200e3, 200e3, 600e3, 1000e3, 1400e3)])
+def test_shared_filter_form_against_the_per_carrier_form(offsets):
+    """trxsig_rxfe_set_shared_filter: the carriers lie on the grid of sixteenths of the wideband rate, so ONE pass over the raw
+    samples (sixteen partial sums of real taps, then sixteen complex multiply-adds per carrier) replaces the per-carrier mixers
+    and filters.  Graded against the per-carrier form (the one pinned on the reference's primitives): resampled streams within
+    1e-4 of the signal's scale, the same bursts detected, soft bits within 1e-4, hard bits identical -- over pushes of different
+    sizes; frequencies off the grid and filters longer than 32 taps per output are refused."""
+    import torch
+    assert torch.cuda.is_available()
+    pkg = _pkg.load()
+    from openbts_ttsou_amd.frontend import RxFrontEnd
+    Sw, tsc = 2, 3
+    fs = 400e3 * CW
+    freqs = np.float32([-2.0 * np.pi * f / fs for f in offsets])
+    P = 65 * SPS
+    lpf = synth.design_lpf(8001, P, beta=6.0, cutoff=0.09)
+    iq, nchunks, bits_all = make_wideband(Sw, offsets, 30, tsc, seed=11)
+    nchunks = min(nchunks, 6)
+    C = len(offsets); S = Sw * C
+    chunk = 864 * CW
+    d_iq = torch.from_numpy(np.ascontiguousarray(iq[:, :nchunks * chunk])).cuda()
+    ctx = pkg.TrxSig(SPS, 0); ctx.use_torch_stream()
+    res = {}
+    for shared in (False, True):
+        fe = RxFrontEnd(ctx, Sw, lpf, max_chunks=3, carrier_freq=freqs, rate_factor=CW)
+        if shared:
+            fe.set_shared_filter(True)
+        xs, softs, flags_all = [np.zeros(0, np.complex64) for _ in range(S)], [], []
+        c = 0
+        for k in (1, 3, 2)[:3]:
+            k = min(k, nchunks - c)
+            if k <= 0:
+                break
+            fe.push_wideband(d_iq[:, c * chunk:(c + k) * chunk]); c += k
+            x, off, length, tnv = fe.pop_bursts()
+            nb = off.numel() // S
+            xh = x.cpu().numpy().view(np.complex64).ravel(); offh = off.cpu().numpy(); lenh = length.cpu().numpy()
+            for s in range(S):
+                n = int(lenh[s * nb:(s + 1) * nb].sum())
+                xs[s] = np.concatenate([xs[s], xh[offh[s * nb]:offh[s * nb] + n]])
+            B = S * nb
+            flags = torch.zeros(B, dtype=torch.uint8, device="cuda"); amp = torch.zeros(B, 2, device="cuda")
+            toa = torch.zeros(B, device="cuda"); soft = torch.zeros(B, 148, device="cuda")
+            ctx.detect_demod_normal(x, off, length, tsc, flags, amp, toa, soft, energy_thresh=50.0)
+            torch.cuda.synchronize()
+            softs.append(soft.cpu().numpy()); flags_all.append(flags.cpu().numpy())
+        res[shared] = (xs, np.concatenate(softs), np.concatenate(flags_all))
+        fe.close()
+    (xa, sa, fa), (xb, sb, fb) = res[False], res[True]
+    scale = max(float(np.abs(x).max()) for x in xa)
+    # The per-carrier form mixes with the carrier frequency AS A float32 (phase = n * (double) freq), the shared form with the
+    # grid frequency 2 pi k / 16 itself: the float32 is off by up to 6e-8 rad per sample (a 0.03 Hz offset), which after 40,000
+    # samples is a rotation of milliradians -- a property of the number handed in, not of either form.  Taken out (the rotation
+    # dtheta * n at output o, n = o * 768 / 260 raw samples) the two agree to 1e-4 of the signal's scale and better.
+    worst = raw_worst = 0.0
+    for s_, (a, b) in enumerate(zip(xa, xb)):
+        f32 = float(freqs[s_ % C])
+        dth = f32 - 2.0 * np.pi * np.rint(f32 / (2.0 * np.pi / 16.0)) / 16.0
+        n_raw = np.arange(a.size, dtype=np.float64) * (96.0 * CW) / (65.0 * SPS)
+        raw_worst = max(raw_worst, float(np.abs(a - b).max()) / scale)
+        ac = a * np.exp(-1j * dth * n_raw)
+        ac = ac * np.exp(-1j * np.angle(np.vdot(b, ac)))      # (and the constant part: n counts from the mixer's sample 0, filter delay included)
+        worst = max(worst, float(np.abs(ac - b).max()) / scale)
+    print("shared-filter form vs per-carrier form: worst sample difference %.2e of the signal's scale (%.2e before the float32 "
+          "carrier frequencies' own drift is taken out)" % (worst, raw_worst))
+    assert worst < 1e-4 and raw_worst < 5e-3
+    assert np.array_equal(fa, fb)
+    det = (fa & pkg.F_DETECT) != 0
+    assert det.sum() > 0.7 * det.size
+    assert float(np.abs(sa[det] - sb[det]).max()) < 1e-4
+    assert np.array_equal(sa[det] > 0.5, sb[det] > 0.5)
+    # refusals
+    off_grid = RxFrontEnd(ctx, 1, lpf, max_chunks=1, carrier_freq=np.float32([0.1, 0.2]), rate_factor=CW)
+    with pytest.raises(pkg.TrxSigError):
+        off_grid.set_shared_filter(True)
+    off_grid.close()
+    long_lpf = RxFrontEnd(ctx, 1, synth.design_lpf(33 * P + 1, P, beta=6.0, cutoff=0.09), max_chunks=1, carrier_freq=freqs[:2], rate_factor=CW)
+    with pytest.raises(pkg.TrxSigError):
+        long_lpf.set_shared_filter(True)
+    long_lpf.close()

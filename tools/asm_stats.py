@@ -30,8 +30,11 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
     # ... and the fused multiply-adds of a steering pass (fma_steer, trxsig_dev.h): approximate values that only select
     # which lags are recomputed exactly
     steer = sum(1 for i in ins if "; steering" in i)
+    # ... and those of a form that is approximate by construction and graded with a tolerance (the shared-filter channeliser,
+    # trxsig_chan.hip: the per-carrier sums in another order)
+    approx = sum(1 for i in ins if "; approx-form" in i)
     fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma_f|mac_f|fmac_f|mad_f|pk_fma)", o)
-           and "exact-product" not in ins[i] and "; steering" not in ins[i]]
+           and "exact-product" not in ins[i] and "; steering" not in ins[i] and "; approx-form" not in ins[i]]
     # hipcc's correctly-rounded division / sqrt expansions keep their fma's next to
     # v_div_scale / v_rcp / v_div_fmas / v_div_fixup / v_sqrt / v_rsq (f32 and f64)
     bad = 0
@@ -43,4 +46,4 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
     label = "%s<sps=%s>" % (kind.group(1), kind.group(2)) if kind else name[:50]
     print("%-28s total %5d  %s  fma %d (outside a division: %d)%s" % (
         label, len(ops), dict(c), len(fma), bad, ("  exact-product fma %d" % exact if exact else "") +
-        ("  steering fma %d" % steer if steer else "")))
+        ("  steering fma %d" % steer if steer else "") + ("  approx-form fma %d" % approx if approx else "")))
