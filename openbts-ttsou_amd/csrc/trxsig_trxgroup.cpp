@@ -104,8 +104,14 @@ struct trxsig_trxgroup {
   DevBuf<int16_t> tx_opid;
   DevBuf<uint8_t> tx_ofq, tx_bits, tx_fq;
   DevBuf<float> tx_gain;
-  std::vector<int32_t> h_tx;                                // host staging of one add call (pageable; consumed by the copies at return)
-  std::vector<uint32_t> h_stage;
+  // host staging of an add call: two sets in turn, each guarded by an event recorded behind its uploads -- a set is refilled only
+  // when the copies that read it have run (the library does not rely on pageable hipMemcpyAsync being synchronous)
+  std::vector<int32_t> h_tx[2];
+  std::vector<uint32_t> h_stage[2];
+  std::vector<uint8_t> h_fmod[2];
+  hipEvent_t tx_ev[2] = {nullptr, nullptr};
+  bool tx_ev_armed[2] = {false, false};
+  int tx_set = 0;
   float gain_tab[26] = {0};                                 // pow(10, q), q = -12..13: every value -RSSI/10 of a signed char can take
 };
 
@@ -218,6 +224,7 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
       (void)hipFree(g->tx.free_n); (void)hipFree(g->tx.filler); (void)hipFree(g->tx.fmod); (void)hipFree(g->tx.pool);
       (void)hipFree(g->tx.status); (void)hipFree(g->d_dummy);
     }
+    for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
     g->tx_seg.release(); g->tx_fn.release(); g->tx_tn.release(); g->tx_arfcn.release(); g->tx_pid.release(); g->tx_stage.release();
     g->tx_opid.release(); g->tx_ofq.release(); g->tx_bits.release(); g->tx_fq.release(); g->tx_gain.release();
   }
@@ -648,17 +655,31 @@ int tx_setup(trxsig_trxgroup *g) {
   x.dummy = g->d_dummy;
   // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division, pow in double, the scale a Complex<float>
   for (int q = -12; q <= 13; q++) g->gain_tab[q + 12] = (float)std::pow(10, q);
+  for (int k = 0; k < 2; k++) G_HIP(g, hipEventCreateWithFlags(&g->tx_ev[k], hipEventDisableTiming));
   g->tx_ready = true;
   g->fmod_dirty = true;
   return TRXSIG_OK;
 }
 
-int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st) {
+// the next host staging set, free to be refilled (its previous uploads have run)
+int tx_take_set(trxsig_trxgroup *g, int *k) {
+  *k = g->tx_set ^= 1;
+  if (g->tx_ev_armed[*k]) { G_HIP(g, hipEventSynchronize(g->tx_ev[*k])); g->tx_ev_armed[*k] = false; }
+  return TRXSIG_OK;
+}
+int tx_seal_set(trxsig_trxgroup *g, int k, hipStream_t st) {
+  G_HIP(g, hipEventRecord(g->tx_ev[k], st));
+  g->tx_ev_armed[k] = true;
+  return TRXSIG_OK;
+}
+// fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT; `k`: the staging set the caller holds
+int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st, int k) {
   if (!g->fmod_dirty) return TRXSIG_OK;
-  std::vector<uint8_t> fm((size_t)8 * g->S);
+  std::vector<uint8_t> &fm = g->h_fmod[k];
+  fm.assign((size_t)8 * g->S, 0);
   for (int tn = 0; tn < 8; tn++)
     for (int a = 0; a < g->S; a++) fm[(size_t)tn * g->S + a] = (uint8_t)g->ctl[(size_t)a].fillerModulus[tn];
-  G_HIP(g, hipMemcpyAsync(g->tx.fmod, fm.data(), fm.size(), hipMemcpyHostToDevice, st));   // (pageable source: consumed at return)
+  G_HIP(g, hipMemcpyAsync(g->tx.fmod, fm.data(), fm.size(), hipMemcpyHostToDevice, st));
   g->fmod_dirty = false;
   return TRXSIG_OK;
 }
@@ -673,7 +694,13 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
   if (n == 0) return TRXSIG_OK;
   const int S = g->S;
   // parse the headers as driveTransmitPriorityQueue does (:596-620) and sort by ARFCN, arrival order kept inside an ARFCN
-  std::vector<int32_t> &h = g->h_tx;
+  Guard gd(trxsig_device(c));
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  G_LIB(tx_setup(g));
+  int set = 0;
+  G_LIB(tx_take_set(g, &set));
+  std::vector<int32_t> &h = g->h_tx[set];
+  std::vector<uint32_t> &stage = g->h_stage[set];
   h.assign((size_t)(S + 1) + 4 * (size_t)n, 0);
   int32_t *seg = h.data(), *s_fn = seg + S + 1, *s_tn = s_fn + n, *s_arfcn = s_tn + n, *s_src = s_arfcn + n;
   for (int i = 0; i < n; i++) {
@@ -686,22 +713,19 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
   }
   for (int a = 0; a < S; a++) seg[a + 1] += seg[a];
   std::vector<int32_t> fillp(seg, seg + S);
-  g->h_stage.resize((size_t)n * TRXG_PAYLOAD_WORDS);
-  Guard gd(trxsig_device(c));
-  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
-  G_LIB(tx_setup(g));
+  stage.resize((size_t)n * TRXG_PAYLOAD_WORDS);
   for (int i = 0; i < n; i++) {
     const uint8_t *d = h_datagrams + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
     const int a = h_arfcn[i];
     const int j = fillp[(size_t)a]++;
     s_fn[j] = (int32_t)(((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4]);
     s_tn[j] = d[0]; s_arfcn[j] = a; s_src[j] = i;
-    uint8_t *pay = (uint8_t *)(g->h_stage.data() + (size_t)j * TRXG_PAYLOAD_WORDS);
+    uint8_t *pay = (uint8_t *)(stage.data() + (size_t)j * TRXG_PAYLOAD_WORDS);
     std::memcpy(pay, d + 6, 148);                           // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
     const int RSSI = (int)(int8_t)d[5];                     // `int RSSI = (int) buffer[5]` on a char buffer (:617)
     std::memcpy(pay + 148, &g->gain_tab[-RSSI / 10 + 12], 4);
   }
-  G_LIB(tx_sync_modulus(g, st));
+  G_LIB(tx_sync_modulus(g, st, set));
   G_HIP(g, g->tx_seg.need((size_t)S + 1, st)); G_HIP(g, g->tx_fn.need((size_t)n, st)); G_HIP(g, g->tx_tn.need((size_t)n, st));
   G_HIP(g, g->tx_arfcn.need((size_t)n, st)); G_HIP(g, g->tx_pid.need((size_t)n, st));
   G_HIP(g, g->tx_stage.need((size_t)n * TRXG_PAYLOAD_WORDS, st));
@@ -709,7 +733,8 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
   G_HIP(g, hipMemcpyAsync(g->tx_fn.p, s_fn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
   G_HIP(g, hipMemcpyAsync(g->tx_tn.p, s_tn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
   G_HIP(g, hipMemcpyAsync(g->tx_arfcn.p, s_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_stage.p, g->h_stage.data(), 4 * g->h_stage.size(), hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_stage.p, stage.data(), 4 * stage.size(), hipMemcpyHostToDevice, st));
+  G_LIB(tx_seal_set(g, set, st));
   G_HIP(g, trx_launch_group_tx_add(st, g->tx, n, g->tx_seg.p, g->tx_fn.p, g->tx_tn.p, g->tx_arfcn.p, g->tx_pid.p, g->tx_stage.p));
   return TRXSIG_OK;
 }
@@ -723,7 +748,12 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
   Guard gd(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   G_LIB(tx_setup(g));
-  G_LIB(tx_sync_modulus(g, st));
+  if (g->fmod_dirty) {
+    int set = 0;
+    G_LIB(tx_take_set(g, &set));
+    G_LIB(tx_sync_modulus(g, st, set));
+    G_LIB(tx_seal_set(g, set, st));
+  }
   const size_t cells = (size_t)n_slots * g->S;
   G_HIP(g, g->tx_opid.need(cells, st)); G_HIP(g, g->tx_ofq.need(cells, st)); G_HIP(g, g->tx_bits.need(cells * 148, st));
   G_HIP(g, g->tx_gain.need(cells, st)); G_HIP(g, g->tx_fq.need(cells, st));
