@@ -23,10 +23,16 @@ namespace {
 //                 recursion of equalizeBurst (:1352-1384) and the slicer.
 // ---------------------------------------------------------------------------------------------
 #define EQ_NC 36            /* max correlation lags kept per burst */
+// A/B: TRXSIG_EQ_DETECT_GENERIC=1 keeps the padded kernel also where the fixed-geometry one applies (maxTOA 4)
+static bool eq_detect_generic() {
+  static const bool v = std::getenv("TRXSIG_EQ_DETECT_GENERIC") && std::atoi(std::getenv("TRXSIG_EQ_DETECT_GENERIC")) != 0;
+  return v;
+}
 // two instantiations: the 52M windowed correlation with maxTOA <= 5 (11 lags, 26 window samples: 25 KB of LDS, four
 // workgroups per CU) and everything else (the classic 36-lag window, wide 52M windows)
 #define EQ_DETECT_LAUNCH_T(SMP, ...)                                                                        \
-  if (variant52m && max_toa <= 5) k_eq_detect<12, 26, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
+  if (variant52m && max_toa == 4 && !eq_detect_generic()) k_eq_detect<9, 26, SMP, 4><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
+  else if (variant52m && max_toa <= 5) k_eq_detect<12, 26, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
   else k_eq_detect<EQ_NC, 52, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__)
 #define EQ_DETECT_LAUNCH(...)                                                                               \
   do { if (fmt == TRXSIG_SAMPLES_F16) { EQ_DETECT_LAUNCH_T(SmpF16, __VA_ARGS__); } else { EQ_DETECT_LAUNCH_T(SmpC32, __VA_ARGS__); } } while (0)
@@ -233,7 +239,12 @@ __device__ __forceinline__ void design_dfe7(const cx (&chan)[6], float snr, cx (
   }
 }
 
-template <int NCMAX, int NXMAX, typename SMP>               // correlation lags / window samples kept per burst; sample storage
+// FIXT > 0 (round 4): the 52M windowed geometry with maxTOA = FIXT KNOWN AT COMPILE TIME (2 FIXT + 1 lags from lag 20 - FIXT on, a
+// 26-sample window): every tap index is a constant, so the zero pads -- 20 of the 58 LDS rows -- are not needed (a term that would meet
+// a pad is simply not formed: it would add +-0), and fp16 samples are parked as stored (4 bytes).  18 KB instead of 29 per 64 bursts:
+// EIGHT one-wave workgroups per CU instead of five -- the kernel's waves wait on each other's instruction latencies, and what was
+// missing was a second wave per SIMD, which the LDS, not the batch size, was denying.
+template <int NCMAX, int NXMAX, typename SMP, int FIXT = 0>  // correlation lags / window samples kept per burst; sample storage
 __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ T, const void *__restrict__ samples,
                                                   const int32_t *__restrict__ offset,
                                                   const int32_t *__restrict__ length, int B, int tsc,
@@ -258,15 +269,20 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   // (+-0: adding them never changes a value), so the inner loops carry no bounds checks.  The same storage first serves as
   // the staging area of the burst loads.  29 KB for the 52M window: five workgroups per CU (four would be every one of the
   // 1024 workgroups of a 65,536-burst launch resident only if the dispatcher balanced them perfectly).
-  constexpr int PADF = 10, XROWS = PADF + NXMAX, CPAD = 10, CROWS = NCMAX + CPAD;    // cp body + back pad
+  constexpr bool FIX = FIXT > 0;
+  constexpr int F_NC = 2 * FIXT + 1, F_START = 20 - FIXT;   // lags kept; window sample under lag 0's last tap (expectedTOAPeak 20, ref52:990-1000)
+  static_assert(!FIX || (FIXT >= 3 && FIXT <= 5 && NCMAX == F_NC && NXMAX == 26), "the fixed 52M geometry: maxTOA 3..5, span 5");
+  constexpr int PADF = FIX ? 0 : 10, XROWS = PADF + NXMAX, CPAD = FIX ? 0 : 10, CROWS = NCMAX + CPAD;    // cp body + back pad
   constexpr int NSLOT = 20 + NXMAX, PITCH = NSLOT | 1, NPASS = (NSLOT + 63) / 64;
   static_assert(XROWS - CPAD >= 26 && XROWS - CPAD >= NCMAX, "loc / shf must stay clear of cp's front pad");
-  constexpr size_t kWork = sizeof(cx) * 64 * (XROWS + CROWS), kStage = sizeof(float) * 2 * 64 * PITCH;
+  constexpr bool RAWST = FIX && sizeof(typename SMP::raw_t) == 4;   // park the samples as stored (fp16 pairs), widen on the way back
+  constexpr size_t kWork = sizeof(cx) * 64 * (XROWS + CROWS), kStage = (RAWST ? sizeof(unsigned) : sizeof(float) * 2) * 64 * PITCH;
   __shared__ __attribute__((aligned(16))) char lds_raw[kWork > kStage ? kWork : kStage];
   cx (*xp)[64] = reinterpret_cast<cx (*)[64]>(lds_raw);
   cx (*cp)[64] = xp + (XROWS - CPAD);
   cx (*shf)[64] = xp;
   float *st_re = reinterpret_cast<float *>(lds_raw), *st_im = st_re + 64 * PITCH;
+  typename SMP::raw_t *st_raw = reinterpret_cast<typename SMP::raw_t *>(lds_raw);
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
   const bool live = b < B && (!enable || enable[b < B ? b : 0] != 0);
@@ -352,16 +368,28 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
       }
       TRX_STAMP2();                                        // (2: 2) loads issued
       if (slot < NSLOT) {
+        if (RAWST) {
 #pragma unroll
-        for (int k = 0; k < 64; k++) { const cx f = SMP::widen(v[k]); st_re[k * PITCH + slot] = f.r; st_im[k * PITCH + slot] = f.i; }
+          for (int k = 0; k < 64; k++) st_raw[k * PITCH + slot] = v[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 64; k++) { const cx f = SMP::widen(v[k]); st_re[k * PITCH + slot] = f.r; st_im[k * PITCH + slot] = f.i; }
+        }
       }
     }
     wave_lds_fence();
     TRX_STAMP2();                                          // (2: 3) loads complete, parked in LDS
+    if (RAWST) {
 #pragma unroll
-    for (int i = 0; i < 20; i++) ev[i] = mk(st_re[lane * PITCH + i], st_im[lane * PITCH + i]);
+      for (int i = 0; i < 20; i++) ev[i] = SMP::widen(st_raw[lane * PITCH + i]);
 #pragma unroll
-    for (int a = 0; a < NXMAX; a++) wv[a] = mk(st_re[lane * PITCH + 20 + a], st_im[lane * PITCH + 20 + a]);   // zeros past La
+      for (int a = 0; a < NXMAX; a++) wv[a] = SMP::widen(st_raw[lane * PITCH + 20 + a]);   // zeros past La
+    } else {
+#pragma unroll
+      for (int i = 0; i < 20; i++) ev[i] = mk(st_re[lane * PITCH + i], st_im[lane * PITCH + i]);
+#pragma unroll
+      for (int a = 0; a < NXMAX; a++) wv[a] = mk(st_re[lane * PITCH + 20 + a], st_im[lane * PITCH + 20 + a]);   // zeros past La
+    }
     wave_lds_fence();                                      // the staging area is dead: xp / cp take its place
     TRX_STAMP2();                                          // (2: 4) read back
   }
@@ -385,6 +413,8 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
     flags[b] = TRXSIG_F_BADLEN; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
     return;
   }
+  // the fixed geometry is what the launcher promised (else: the checked loops below, which need no pads either)
+  const bool fixed_ok = FIX && variant52m && maxTOA == (unsigned)FIXT && startIndex == F_START && ncorr == F_NC && La == NXMAX;
 #pragma unroll
   for (int a = 0; a < PADF; a++) xp[a][lane] = mk(0, 0);
 #pragma unroll
@@ -395,8 +425,17 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #pragma unroll
   for (int j = 0; j < 16; j++) ctap[j] = pk(T->mid_ctap[tsc][15 - j]);
   // every tap index t - j of every lag lies in [-PADF, NXMAX): no checks (always so for the geometries above)
-  const bool padded = startIndex - 15 >= -PADF && startIndex + ncorr - 1 < NXMAX;
-  if (padded) {
+  const bool padded = !FIX && startIndex - 15 >= -PADF && startIndex + ncorr - 1 < NXMAX;
+  if (FIX && fixed_ok) {
+    // every index a constant: straight from the window's registers (F_START + i - j lies in [F_START - 15, F_START + F_NC - 1] = inside the window)
+#pragma unroll
+    for (int i = 0; i < F_NC; i++) {
+      v2f sum = pk(mk(0, 0));
+#pragma unroll
+      for (int j = 0; j < 16; j++) sum = pk_cadd(sum, pk_cmul(pk(wv[(F_START + i - j >= 0 && F_START + i - j < NXMAX) ? F_START + i - j : 0]), ctap[j]));
+      cp[i][lane] = unpk(sum);
+    }
+  } else if (padded) {
     for (int i = 0; i < ncorr; i++) {
       const cx (*row)[64] = xp + (PADF + startIndex + i);
       v2f sum = pk(mk(0, 0));
@@ -418,6 +457,7 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
   }
 #pragma unroll
   for (int a = 0; a < CPAD; a++) cp[a][lane] = mk(0, 0);    // the window is dead: its last rows become cp's front pad
+  static_assert(!FIX || F_START - 15 >= 0, "the fixed geometry's taps stay inside the window");
 
   TRX_STAMP();                                             // 2: correlation
   // ---- peakDetect (:663-711) ----
@@ -488,13 +528,33 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #pragma unroll
             for (int q = 0; q < 6; q++) { const float4 v4 = r4[q]; row[2 * q].x = v4.x; row[2 * q].y = v4.y; row[2 * q + 1].x = v4.z; row[2 * q + 1].y = v4.w; }
           }
-          for (int t = 0; t < ncorr; t++) {                // taps t + 10 - j outside [0, ncorr) meet cp's zero pads
-            const cx (*crow)[64] = cp + (CPAD + t + 10);
-            v2f sum = pk(mk(0, 0));
+          if (FIX) {
+            // no pads: a tap that would meet one is not formed (it would add +-0 to a sum that starts at +0: the same value).  With the
+            // promised geometry every index is a constant and the correlation comes from registers; else the checks are live.
+            v2f cr[NCMAX];
 #pragma unroll
-            for (int j = 0; j < 21; j++)
-              sum = (j & 1) ? pk_cadd(sum, pk_mul_tap<1>(pk(crow[-j][lane]), row[j >> 1])) : pk_cadd(sum, pk_mul_tap<0>(pk(crow[-j][lane]), row[j >> 1]));
-            shf[t][lane] = unpk(sum);
+            for (int i = 0; i < NCMAX; i++) cr[i] = pk(cp[i][lane]);
+#pragma unroll
+            for (int t = 0; t < NCMAX; t++) {
+              v2f sum = pk(mk(0, 0));
+#pragma unroll
+              for (int j = 0; j < 21; j++) {
+                const int q = t + 10 - j;
+                if (q >= 0 && q < NCMAX && q < ncorr)
+                  sum = (j & 1) ? pk_cadd(sum, pk_mul_tap<1>(cr[q < 0 ? 0 : (q >= NCMAX ? NCMAX - 1 : q)], row[j >> 1]))
+                                : pk_cadd(sum, pk_mul_tap<0>(cr[q < 0 ? 0 : (q >= NCMAX ? NCMAX - 1 : q)], row[j >> 1]));
+              }
+              if (t < ncorr) shf[t][lane] = unpk(sum);
+            }
+          } else {
+            for (int t = 0; t < ncorr; t++) {              // taps t + 10 - j outside [0, ncorr) meet cp's zero pads
+              const cx (*crow)[64] = cp + (CPAD + t + 10);
+              v2f sum = pk(mk(0, 0));
+#pragma unroll
+              for (int j = 0; j < 21; j++)
+                sum = (j & 1) ? pk_cadd(sum, pk_mul_tap<1>(pk(crow[-j][lane]), row[j >> 1])) : pk_cadd(sum, pk_mul_tap<0>(pk(crow[-j][lane]), row[j >> 1]));
+              shf[t][lane] = unpk(sum);
+            }
           }
           src = shf;
         }
