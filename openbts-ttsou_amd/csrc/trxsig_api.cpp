@@ -700,7 +700,8 @@ int trxsig_estimate_dfe_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const 
   if (rc != TRXSIG_OK) return rc;
   HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc,
                                     detect_thresh, snr_thresh, snr_value, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
-                                    (float *)c->d_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b, nullptr, c->prof));
+                                    (float *)c->d_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b, nullptr, c->prof, nullptr, nullptr,
+                                    trx_eq52_geometry(c->h_tables, tsc)));
   return TRXSIG_OK;
 }
 
@@ -722,7 +723,7 @@ int trxsig_channel_estimate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, co
   trx_c32 *bq = w + (size_t)7 * c->eq_cap;
   HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc,
                                     detect_thresh, -1.0f, 1.0f, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa, toa_eq,
-                                    d_chan_off, w, bq, (trx_c32 *)d_chan, c->prof));
+                                    d_chan_off, w, bq, (trx_c32 *)d_chan, c->prof, nullptr, nullptr, trx_eq52_geometry(c->h_tables, tsc)));
   return TRXSIG_OK;
 }
 
@@ -801,7 +802,7 @@ int trxsig_equalize_normal_batch_fmt(trxsig_ctx *c, const void *d_samples, int s
   if (d_b) bq = (trx_c32 *)d_b;
   HIPCHK(c, trx_launch_equalize(c->stream, c->d_tables, d_samples, sample_format, d_offset, d_length, B, tsc,
                                 detect_thresh, energy_thresh, variant52m, max_toa, d_flags, (trx_c32 *)d_amp, d_toa,
-                                toa_eq, w, bq, xd, XS, d_soft, d_hard, nsoft, soft_stride, c->prof));
+                                toa_eq, w, bq, xd, XS, d_soft, d_hard, nsoft, soft_stride, c->prof, trx_eq52_geometry(c->h_tables, tsc)));
   return TRXSIG_OK;
 }
 
@@ -816,7 +817,7 @@ int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc, 3.0f, -1.0f, 1.0f,
                                     0, 0, d_flags, (trx_c32 *)d_amp, d_toa, d_toa_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b,
-                                    nullptr, c->prof, d_enable, d_snr));
+                                    nullptr, c->prof, d_enable, d_snr, trx_eq52_geometry(c->h_tables, tsc)));
   return TRXSIG_OK;
 }
 int trx_ctx_group_equalize(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,

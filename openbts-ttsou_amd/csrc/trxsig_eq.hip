@@ -24,14 +24,16 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 #define EQ_NC 36            /* max correlation lags kept per burst */
 // A/B: TRXSIG_EQ_DETECT_GENERIC=1 keeps the padded kernel also where the fixed-geometry one applies (maxTOA 4)
-static bool eq_detect_generic() {
-  static const bool v = std::getenv("TRXSIG_EQ_DETECT_GENERIC") && std::atoi(std::getenv("TRXSIG_EQ_DETECT_GENERIC")) != 0;
+static int eq_detect_generic() {
+  static const int v = std::getenv("TRXSIG_EQ_DETECT_GENERIC") ? std::atoi(std::getenv("TRXSIG_EQ_DETECT_GENERIC")) : 0;
   return v;
 }
-// two instantiations: the 52M windowed correlation with maxTOA <= 5 (11 lags, 26 window samples: 25 KB of LDS, four
-// workgroups per CU) and everything else (the classic 36-lag window, wide 52M windows)
+// instantiations: k_eq_detect52 for config 5's geometry (52M window, maxTOA 4, expectedTOAPeak 20: `geom52`, which the caller derives
+// from the host's copy of the tables -- trx_eq52_geometry, trxsig_launch.h); else k_eq_detect for the 52M window with maxTOA <= 5 (11
+// lags, 26 window samples; maxTOA 4 without zero pads) and for everything else (the classic 36-lag window, wide 52M windows).
+// TRXSIG_EQ_DETECT_GENERIC=1 (A/B measurements): 1 = never k_eq_detect52, 2 = nor the pad-free instantiation.
 #define EQ_DETECT_LAUNCH_T(SMP, ...)                                                                        \
-  if (variant52m && max_toa == 4 && !eq_detect_generic()) k_eq_detect<9, 26, SMP, 4><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
+  if (variant52m && max_toa == 4 && eq_detect_generic() < 2) k_eq_detect<9, 26, SMP, 4><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
   else if (variant52m && max_toa <= 5) k_eq_detect<12, 26, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__); \
   else k_eq_detect<EQ_NC, 52, SMP><<<dim3((B + 63) / 64), dim3(64), 0, st>>>(__VA_ARGS__)
 #define EQ_DETECT_LAUNCH(...)                                                                               \
@@ -623,6 +625,337 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 #undef TRX_STAMP2
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_eq_detect52 (round 4): k_eq_detect's job for the ONE geometry config 5 runs -- the 52M window with maxTOA = 4 (nine lags from
+// lag 16 on, a 26-sample window from sample 61, expectedTOAPeak = 20: ref52:983-1000; the launcher checks the last on the host's
+// copy of the tables) -- with 256 threads = four waves, still a lane per burst, around ONE copy of the sinc table in LDS.
+// What the general kernel spends and this one does not (tools/eq_probe.py: 67 k cycles per wave, 23 k of them in peakDetect):
+//   * the bisection's sinc rows came from L2 with twelve 16-byte gathers per step, every lane another row (64 lines per
+//     instruction: the texture path, shared by the CU's four waves, was the bound).  Here they are ten 4-byte LDS reads;
+//   * with nine lags interpolatePoint's loop (:646-657) runs over the SAME eight lags i = 0..7 at every point the bisection
+//     visits (start = max(0, floor(ix) - 10) = 0 and end = min(floor(ix) + 11, 8) = 8 for floor(ix) in [-3, 9], which
+//     M - 2 <= floor(ix) <= M + 1, -1 <= M <= 8 guarantees), tap i - floor(ix) + 10 in [1, 20]: eight multiply-adds from
+//     registers per point in place of twenty-one (thirteen of them products with the zeros that stood for skipped terms);
+//     early, late and final point of a step share floor(early) after step 0, hence one run of ten taps serves all three;
+//   * the correlation never leaves registers for the argmax, the bisection and delayVector; valley, channel pick and the
+//     integer shift read their dynamic lags from the lane's LDS column with all reads in flight at once.
+// Same terms in the same order as k_eq_detect (and the reference): the results are the same values.
+// LDS: 48 KB table + per wave max(staging area, 18 rows of 64 complex): 96 KB (fp16 storage) / 144 KB (complex float) -- one
+// workgroup per CU, as many waves per SIMD as the 64-thread form has at 65,536 bursts.
+// ---------------------------------------------------------------------------------------------
+template <typename SMP>
+struct EqDetect52 {
+  static constexpr int MT = 4, NC = 2 * MT + 1, NX = 26, START = 20 - MT, WIN0 = 61;
+  static constexpr int NSLOT = 20 + NX, PITCH = NSLOT | 1;
+  static constexpr bool RAWST = sizeof(typename SMP::raw_t) == 4;
+  static constexpr size_t kStage = (RAWST ? sizeof(unsigned) : sizeof(float) * 2) * 64 * PITCH;
+  static constexpr size_t kCols = sizeof(cx) * 64 * (2 * NC);
+  static constexpr size_t kSlice = ((kStage > kCols ? kStage : kCols) + 15) & ~(size_t)15;
+  static constexpr size_t kLds = sizeof(SincLds) + 4 * kSlice;
+};
+
+template <typename SMP>
+__global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict__ T, const void *__restrict__ samples,
+                                                     const int32_t *__restrict__ offset, const int32_t *__restrict__ length, int B, int tsc,
+                                                     float detect_thresh, float energy_thresh, uint8_t *__restrict__ flags,
+                                                     cx *__restrict__ amp_out, float *__restrict__ toa_out, float *__restrict__ toa_eq,
+                                                     cx *__restrict__ w_out, cx *__restrict__ b_out, float snr_thresh, float snr_value,
+                                                     float *__restrict__ chan_off_out, cx *__restrict__ chan_out,
+                                                     const uint8_t *__restrict__ enable, const float *__restrict__ snr_in) {
+  typedef EqDetect52<SMP> G;
+  constexpr int NC = G::NC, NX = G::NX, PITCH = G::PITCH, NSLOT = G::NSLOT;
+  extern __shared__ __attribute__((aligned(16))) char lds52[];
+  SincLds &stab = *reinterpret_cast<SincLds *>(lds52);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char *mine = lds52 + sizeof(SincLds) + (size_t)wave * G::kSlice;
+  cx (*cp)[64] = reinterpret_cast<cx (*)[64]>(mine);        // the correlation, a column per lane; shf: its delayed copy
+  cx (*shf)[64] = cp + NC;
+  float *st_re = reinterpret_cast<float *>(mine), *st_im = st_re + 64 * PITCH;
+  typename SMP::raw_t *st_raw = reinterpret_cast<typename SMP::raw_t *>(mine);
+  const int b = blockIdx.x * 256 + tid;
+  const bool live = b < B && (!enable || enable[b < B ? b : 0] != 0);
+  if (enable && !__syncthreads_or(live)) return;            // (workgroup-uniform)
+#ifdef TRX_EQ_PROBE
+  long long pt_[8] = {0};
+  int pk_ = 0;
+#define TRX_STAMP() pt_[pk_++] = clock64()
+#else
+#define TRX_STAMP()
+#endif
+  TRX_STAMP();
+  const int off = live ? offset[b] : 0, N = live ? length[b] : 0;
+  uint8_t fl = 0;
+  cx amp = mk(0, 0);
+  float toa = 0.0f;
+  const bool good = live && (off >= 0) && (N >= 92) && (N <= 157);
+  const bool winOk = G::WIN0 + NX <= N;                     // ref52:993-1000: the window must lie inside the burst
+  // ---- the burst loads, coalesced through LDS exactly as k_eq_detect does them (see there) ----
+  cx ev[20], wv[NX];
+  {
+    const unsigned long long goodm = __ballot(good);
+    const int safe_off = __builtin_amdgcn_readlane(off, goodm ? (int)__builtin_ctzll(goodm) : 0);
+    int offv = good ? off : safe_off, nm1v = good ? N - 1 : 0;
+    asm volatile("" : "+v"(offv), "+v"(nm1v));
+    const int slot = lane;
+    const bool slot_ok = slot < NSLOT;
+    const int idx = slot >= 20 ? G::WIN0 + (slot - 20) : slot * 4;   // energyDetect strides by 4 (ref52:946-963)
+    typename SMP::raw_t v[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) v[k] = SMP::zero();
+    if (slot_ok && goodm) {
+#pragma unroll
+      for (int k = 0; k < 64; k++) {
+        const int off_k = __builtin_amdgcn_readlane(offv, k), nm1_k = __builtin_amdgcn_readlane(nm1v, k);
+        v[k] = SMP::ldraw(samples, (long long)off_k + (idx < nm1_k ? idx : nm1_k));
+      }
+    }
+    {                                                      // the table's loads queue behind the bursts': nothing waits for them alone
+      float4 tv[3072 / 256];
+      sinc_lds_issue<256>(T, tid, tv);
+      sinc_lds_store<256>(stab, tid, tv);
+    }
+    if (slot_ok) {
+      if (G::RAWST) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) st_raw[k * PITCH + slot] = v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 64; k++) { const cx f = SMP::widen(v[k]); st_re[k * PITCH + slot] = f.r; st_im[k * PITCH + slot] = f.i; }
+      }
+    }
+    wave_lds_fence();
+    if (G::RAWST) {
+#pragma unroll
+      for (int i = 0; i < 20; i++) ev[i] = SMP::widen(st_raw[lane * PITCH + i]);
+#pragma unroll
+      for (int a = 0; a < NX; a++) wv[a] = SMP::widen(st_raw[lane * PITCH + 20 + a]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 20; i++) ev[i] = mk(st_re[lane * PITCH + i], st_im[lane * PITCH + i]);
+#pragma unroll
+      for (int a = 0; a < NX; a++) wv[a] = mk(st_re[lane * PITCH + 20 + a], st_im[lane * PITCH + 20 + a]);
+    }
+    wave_lds_fence();                                      // the staging area is dead: cp / shf take its place
+  }
+  __syncthreads();                                         // the table is whole; no barrier below (each lane owns its columns)
+  if (!live) return;
+  if (!good || !winOk) {
+    // (energyDetect comes first in the reference: a short burst that fails it reports 0, not BADLEN -- as k_eq_detect)
+    bool e_ok = true;
+    if (good) {
+      float energy = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 20; i++) energy += norm2(ev[i]);
+      e_ok = energy_thresh < 0.0f || energy / (float)20u > energy_thresh * energy_thresh;
+    }
+    flags[b] = e_ok ? TRXSIG_F_BADLEN : 0; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f;
+    return;
+  }
+  // ---- energyDetect ----
+  {
+    float energy = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 20; i++) energy += norm2(ev[i]);
+    const bool ok = energy_thresh < 0.0f || energy / (float)20u > energy_thresh * energy_thresh;
+    if (!ok) { flags[b] = 0; amp_out[b] = amp; toa_out[b] = 0.0f; toa_eq[b] = 0.0f; return; }
+    fl = TRXSIG_F_ENERGY;
+  }
+  TRX_STAMP();                                             // 1: energy
+  // ---- correlation (:480-498): lag i ends on window sample START + i; tmp[j] = conj(mid[15 - j]), j ascending ----
+  v2f cr[NC];
+  {
+    v2f ctap[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) ctap[j] = pk(T->mid_ctap[tsc][15 - j]);
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      v2f sum = pk(mk(0, 0));
+#pragma unroll
+      for (int j = 0; j < 16; j++) sum = pk_cadd(sum, pk_cmul(pk(wv[G::START + i - j]), ctap[j]));
+      cr[i] = sum;
+      cp[i][lane] = unpk(sum);
+    }
+  }
+  static_assert(G::START - 15 >= 0 && G::START + NC - 1 < NX, "every tap of every lag lies inside the window");
+  TRX_STAMP();                                             // 2: correlation
+  // ---- peakDetect (:663-711) ----
+  float maxP = 0.0f, maxIndex = -1.0f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const float p = norm2(unpk(cr[i]));
+    if (p > maxP) { maxP = p; maxIndex = (float)i; }
+  }
+  int e = 0;
+  {
+    const int M = (int)maxIndex;
+    // the ten taps row[f][col0 .. col0 + 9], col0 = 8 - floor(early): late point = taps 0..7, final point 1..8, early point 2..9
+    v2f t[5];
+    auto load_taps = [&](int f, int col0) {
+      const float *rw = &stab.row[f][col0];
+#pragma unroll
+      for (int k = 0; k < 5; k++) { t[k].x = rw[2 * k]; t[k].y = rw[2 * k + 1]; }
+    };
+    auto point = [&](auto sh) {                            // interpolatePoint: sum over lags 0..7 of corr[i] * tap[sh + i], i ascending
+      constexpr int SH = decltype(sh)::value;
+      v2f pt = pk(mk(0, 0));
+#pragma unroll
+      for (int i = 0; i < NC - 1; i++)
+        pt = ((SH + i) & 1) ? pk_cadd(pt, pk_mul_tap<1>(cr[i], t[(SH + i) >> 1])) : pk_cadd(pt, pk_mul_tap<0>(cr[i], t[(SH + i) >> 1]));
+      return unpk(pt);
+    };
+    bool active = true;
+    auto decide = [&](int inc) {                           // :690-697
+      const float ne = norm2(point(std::integral_constant<int, 2>())), nl = norm2(point(std::integral_constant<int, 0>()));
+      if (active) {
+        if (ne < nl) e += inc;
+        else if (ne > nl) e -= inc;
+        else active = false;                               // "else break" (:695)
+      }
+    };
+    load_taps(0, 9 - M);                                   // early = M - 1: floor = M - 1
+    decide(256);
+    const int col0 = e < 0 ? 10 - M : 9 - M;               // floor(early) = M - 2 once the first step went down, else M - 1: it stays
+#pragma unroll 1
+    for (int inc = 128; inc >= 1; inc >>= 1) {             // increments 2^-2 .. 2^-9
+      load_taps(e & 511, col0);
+      decide(inc);
+    }
+    load_taps(e & 511, col0);                              // early + 1 has the same fractional part
+    amp = point(std::integral_constant<int, 1>());
+    toa = ((float)(M - 1) + (float)e * 0.001953125f) + 1.0f;   // exact: the reference's +-2^-k steps are exact too
+  }
+  TRX_STAMP();                                             // 3: peakDetect
+  // ---- analyzeTrafficBurst's tail (:961-1035, ref52) ----
+  bool detected = false;
+  float chanOff = 0.0f;
+  cx chan[6];
+  if ((toa < 0.0f) || (toa > (float)NC)) {
+    amp = mk(0, 0);
+  } else {
+    const int p = (int)rintf(toa);
+    cx vlo[4], vhi[4];
+#pragma unroll
+    for (int i = 2; i <= 5; i++) {                          // all eight reads in flight
+      const int a = p - i, c = p + i;
+      vlo[i - 2] = cp[a < 0 ? 0 : (a > NC - 1 ? NC - 1 : a)][lane];
+      vhi[i - 2] = cp[c < 0 ? 0 : (c > NC - 1 ? NC - 1 : c)][lane];
+    }
+    float valley = 0.0f;
+    int numRms = 0;
+#pragma unroll
+    for (int i = 2; i <= 5; i++) {
+      if (p - i >= 0) { valley += norm2(vlo[i - 2]); numRms++; }
+      if (p + i < NC) { valley += norm2(vhi[i - 2]); numRms++; }
+    }
+    if (numRms < 2) {
+      amp = mk(0, 0);
+    } else {
+      const float RMS = (float)((double)sqrtf(valley / (float)numRms) + 0.00001);
+      const float peakToMean = sqrtf(norm2(amp)) / RMS;
+      amp = cdiv(amp, T->mid_gain[tsc]);
+      toa = toa - (float)(unsigned)G::MT;
+      const float TOAoffset = (float)(unsigned)G::MT;
+      detected = peakToMean > detect_thresh;
+      if (detected) {
+        // delayVector(corr, -TOA) (:573-616): a tap that would meet a lag outside [0, NC) is not formed (it would add +-0)
+        const float delay = -toa;
+        const int io = (int)floorf(delay);
+        const float frac = delay - (float)io;
+        const cx (*src)[64] = cp;
+        if (fabs((double)frac) > 1e-2) {
+          v2f row[12];
+          {
+            const float4 *r4 = reinterpret_cast<const float4 *>(stab.row[(int)(frac * 512.0f) & 511]);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const float4 v4 = r4[q]; row[2 * q].x = v4.x; row[2 * q].y = v4.y; row[2 * q + 1].x = v4.z; row[2 * q + 1].y = v4.w; }
+          }
+#pragma unroll
+          for (int tq = 0; tq < NC; tq++) {
+            v2f sum = pk(mk(0, 0));
+#pragma unroll
+            for (int j = 0; j < 21; j++) {
+              const int q = tq + 10 - j;
+              if (q >= 0 && q < NC)
+                sum = (j & 1) ? pk_cadd(sum, pk_mul_tap<1>(cr[q < 0 ? 0 : (q >= NC ? NC - 1 : q)], row[j >> 1]))
+                              : pk_cadd(sum, pk_mul_tap<0>(cr[q < 0 ? 0 : (q >= NC ? NC - 1 : q)], row[j >> 1]));
+            }
+            shf[tq][lane] = unpk(sum);
+          }
+          src = shf;
+        }
+        // integer shift folded into the reads: w[k] = src[k - io] inside [0, NC), else 0
+        auto wdyn = [&](int k) {
+          const int q = k - io;
+          return (q >= 0 && q < NC) ? src[q][lane] : mk(0, 0);
+        };
+        cx wk[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+          const int q = k - io;
+          const cx r = src[q < 0 ? 0 : (q > NC - 1 ? NC - 1 : q)][lane];
+          wk[k] = (q >= 0 && q < NC) ? r : mk(0, 0);
+        }
+        float nk[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) nk[k] = norm2(wk[k]);
+        // :1012-1021 with TOAoffset = 4 and nine lags: windows i = 1..4 start on lag i - 1 (i = 0: st < 0; i = 5, 6: st + 6 > 9)
+        float maxEnergy = -1.0f;
+        int maxI = -1;
+#pragma unroll
+        for (int i = 1; i <= 4; i++) {
+          float energy = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 6; k++) energy += nk[i - 1 + k];
+          if ((double)energy > 0.95 * (double)maxEnergy) { maxI = i; maxEnergy = energy; }
+        }
+        static_assert(G::MT == 4 && NC == 9, "the window list above");
+        const cx ginv = cdiv(mk(1.0f, 0.0f), T->mid_gain[tsc]);
+        // (dynamic reads of the lane's column again: a select chain over wk[] makes the compiler put wk[] in scratch.  maxI = -1 --
+        //  no window taken, energies that do not compare: NaN -- reads from TOAoffset - 6 on like the reference)
+        const int s0 = (int)floorf(TOAoffset + (float)(maxI - 5));
+#pragma unroll
+        for (int k = 0; k < 6; k++) chan[k] = cmul(wdyn(s0 + k), ginv);   // :1024-1025
+        chanOff = (float)(5 - maxI);                       // :1029
+      }
+    }
+  }
+  fl |= detected ? TRXSIG_F_DETECT : 0;
+  flags[b] = fl;
+  amp_out[b] = amp;
+  toa_out[b] = toa;
+  toa_eq[b] = toa - chanOff;
+  if (chan_off_out) chan_off_out[b] = chanOff;
+  if (chan_out) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) chan_out[(size_t)b * 6 + k] = detected ? chan[k] : mk(0, 0);
+  }
+  if (!detected) return;
+  TRX_STAMP();                                             // 4: tail, delayVector, channel pick
+  // ---- Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7) ----
+  const float thr = snr_thresh >= 0.0f ? snr_thresh : (energy_thresh < 0.0f ? 0.0f : energy_thresh);
+  const float snr = snr_in ? snr_in[b] : (snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0)));
+  const cx ainv = cdiv(mk(1.0f, 0.0f), amp);
+#pragma unroll
+  for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
+  cx w7[7], bq[5];
+  design_dfe7(chan, snr, w7, bq);
+#pragma unroll
+  for (int i = 0; i < 7; i++) w_out[(size_t)b * 7 + i] = w7[i];
+#pragma unroll
+  for (int j = 0; j < 5; j++) b_out[(size_t)b * 5 + j] = bq[j];
+#ifdef TRX_EQ_PROBE
+  pt_[5] = clock64();
+  {
+    long long v_ = 0;
+    for (int k = 1; k < 8; k++) if ((b & 7) == k) v_ = pt_[k] - pt_[0];
+    if ((b & 7) == 6) v_ = pt_[0] & 0xFFFFFF;
+    if ((b & 7) == 7) v_ = pt_[5] & 0xFFFFFF;
+    toa_out[b] = (float)v_;
+  }
+#endif
+#undef TRX_STAMP
+}
+
 // The burst's row of xd was written by k_eq_delay only if that kernel accepted the burst (k_demod's gate: DETECT flag,
 // 92..157 samples, |TOA| <= 4096 and not NaN).  The equaliser must apply the same gate, or it would equalise whatever an
 // earlier call left in the row and hand back plausible-looking soft bits.
@@ -1110,6 +1443,22 @@ static void launch_eq_tail(hipStream_t st, const TrxTables *dT, const void *samp
   if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
 }
 
+// k_eq_detect52 needs more LDS than a kernel gets by default: raise the limit once per instantiation
+template <typename SMP, typename... A>
+static hipError_t launch_eq_detect52(hipStream_t st, int B, A... a) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_detect52<SMP>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)EqDetect52<SMP>::kLds);
+  if (attr != hipSuccess) return attr;
+  k_eq_detect52<SMP><<<dim3((B + 255) / 256), dim3(256), EqDetect52<SMP>::kLds, st>>>(a...);
+  return hipSuccess;
+}
+#define EQ_DETECT52_LAUNCH(...)                                                                             \
+  do {                                                                                                      \
+    const hipError_t e52_ = fmt == TRXSIG_SAMPLES_F16 ? launch_eq_detect52<SmpF16>(st, B, __VA_ARGS__)      \
+                                                      : launch_eq_detect52<SmpC32>(st, B, __VA_ARGS__);     \
+    if (e52_ != hipSuccess) { if (prof) prof->end(TRXSIG_K_EQUALIZE, st); return e52_; }                    \
+  } while (0)
+
 hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
                                  trx_c32 *bq, TrxProfiler *prof) {
   if (B <= 0) return hipSuccess;
@@ -1123,11 +1472,15 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
                                const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
                                int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
                                trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
-                               int nsoft, int stride, TrxProfiler *prof) {
+                               int nsoft, int stride, TrxProfiler *prof, bool geom52) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
-  EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
-                   variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr, nullptr, nullptr);
+  if (geom52 && variant52m && max_toa == 4 && eq_detect_generic() == 0)
+    EQ_DETECT52_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq, -1.0f,
+                       0.0f, (float *)nullptr, (cx *)nullptr, (const uint8_t *)nullptr, (const float *)nullptr);
+  else
+    EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
+                     variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr, nullptr, nullptr);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   launch_eq_tail(st, dT, samples, fmt, off, len, B, amp, toa_eq, flags, w, bq, xd, xstride, soft, hard, nsoft, stride, nullptr, prof);
   return hipGetLastError();
@@ -1140,12 +1493,15 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof,
-                                   const uint8_t *enable, const float *snr_in) {
+                                   const uint8_t *enable, const float *snr_in, bool geom52) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
-  EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
-                                                        max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan,
-                                                        enable, snr_in);
+  if (geom52 && variant52m && max_toa == 4 && eq_detect_generic() == 0)
+    EQ_DETECT52_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq, snr_thresh,
+                       snr_value, chan_off, (cx *)chan, enable, snr_in);
+  else
+    EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
+                     max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan, enable, snr_in);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }

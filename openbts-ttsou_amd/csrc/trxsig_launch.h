@@ -169,7 +169,12 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
                                const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh,
                                int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa, float *toa_eq,
                                trx_c32 *w, trx_c32 *bq, trx_c32 *xd, int xstride, float *soft, uint8_t *hard,
-                               int nsoft, int stride, TrxProfiler *prof);
+                               int nsoft, int stride, TrxProfiler *prof, bool geom52 = false /* trx_eq52_geometry(host tables, tsc) */);
+// analyzeTrafficBurst's 52M window (ref52:983-1000) has the geometry k_eq_detect52 is written for when maxTOA = 4 AND the
+// training sequence's expectedTOAPeak is 20 (true of all eight sequences of the tables this library builds; checked, not assumed)
+inline bool trx_eq52_geometry(const TrxTables *hT, int tsc) {
+  return hT && tsc >= 0 && tsc < 8 && (unsigned)round((double)((hT->mid_toa[tsc] + 5.0f) + (float)(size_t)((16 - 1) / 2))) == 20u;
+}
 
 
 // L1 FEC soft decode (trxsig_fec.hip).  mode 0: generic SoftVector::decode of nblk blocks of n soft values ->
@@ -188,7 +193,8 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan /* B x 6 or NULL */,
                                    TrxProfiler *prof, const uint8_t *enable = nullptr /* only bursts with enable[b] != 0; nothing
-                                   is written for the others */, const float *snr_in = nullptr /* SNR estimate per burst */);
+                                   is written for the others */, const float *snr_in = nullptr /* SNR estimate per burst */,
+                                   bool geom52 = false);
 // designDFE(chan, snr, 7) alone; amp != NULL: scaleVector(chan, 1/amp) first
 hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
                                  trx_c32 *bq, TrxProfiler *prof);

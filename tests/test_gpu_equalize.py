@@ -222,6 +222,56 @@ def test_channel_estimate_and_design_dfe_on_their_own(pkg, t1, variant52m):
     assert ndet > B // 2
 
 
+@pytest.mark.parametrize("tsc", [0, 5, 7])
+def test_channel_estimate_52m_every_peak_position(pkg, t1, tsc):
+    """The 52M window with maxTOA = 4 runs in its own kernel (k_eq_detect52: nine lags in registers, interpolatePoint over
+    lags 0..7 at every point of the bisection): bursts that arrive up to five symbols early or late (the peak on every lag,
+    TOAs outside the window), pure noise (peaks anywhere, most not detected), single impulses (equal powers on every lag:
+    peakDetect's "else break" and the argmax's first-wins rule), all-zero bursts (no peak at all: maxIndex = -1) and ragged
+    lengths -- flags, amplitude, TOA, channel response and offset value for value against the oracle, energy gate off."""
+    import torch
+    from openbts_ttsou_amd import synth
+    o = oraclebind.Oracle(1, variant52m=True)
+    rng = np.random.default_rng(52 + tsc)
+    B, mt = 1000, 4                                              # (not a multiple of the kernel's 256 bursts per workgroup)
+    x, off, length, meta = synth.normal_batch(1, B, tsc, seed=9000 + tsc, sigmas=(0.02, 0.3), max_delay=5.2)
+    x = x.copy()
+    kinds = rng.integers(0, 10, B)
+    for i in range(B):
+        s = x[off[i]:off[i] + length[i]]
+        if kinds[i] in (0, 1, 2):                                # noise only
+            s[:] = (rng.standard_normal(len(s)) + 1j * rng.standard_normal(len(s))).astype(np.complex64) * np.float32(100.0)
+        elif kinds[i] == 3:                                      # one impulse inside the correlation window
+            s[:] = 0
+            s[int(rng.integers(58, 90))] = np.complex64(complex(rng.integers(1, 50), rng.integers(-50, 50)))
+        elif kinds[i] == 4 and i % 3 == 0:                       # nothing at all
+            s[:] = 0
+    length = length.copy()
+    cut = np.flatnonzero(kinds == 5)
+    length[cut] = rng.integers(92, 157, len(cut))                # ragged (the window always fits: 87 samples)
+    dev = "cuda"
+    dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    doff = torch.from_numpy(off.astype(np.int32)).cuda(); dlen = torch.from_numpy(length.astype(np.int32)).cuda()
+    flags = torch.zeros(B, dtype=torch.uint8, device=dev); amp = torch.zeros(B, 2, device=dev); toa = torch.zeros(B, device=dev)
+    choff = torch.zeros(B, device=dev); chan = torch.zeros(B, 6, 2, device=dev)
+    t1.channel_estimate(dx, doff, dlen, tsc, flags, amp, toa, choff, chan, variant52m=True, max_toa=mt)
+    torch.cuda.synchronize()
+    fl = flags.cpu().numpy(); ch = chan.cpu().numpy().view(np.complex64).reshape(B, 6); co = choff.cpu().numpy()
+    am = amp.cpu().numpy().view(np.complex64).ravel(); tv = toa.cpu().numpy()
+    ndet, peaks = 0, set()
+    for i in range(B):
+        a = o.analyze_traffic(x[off[i]:off[i] + length[i]], tsc, 3.0, req_chan=True, max_toa=mt)
+        assert bool(fl[i] & pkg.F_DETECT) == a["ok"], (i, kinds[i])
+        assert am[i] == a["amp"] and tv[i] == a["toa"], (i, kinds[i], am[i], a["amp"], tv[i], a["toa"])
+        if not a["ok"]:
+            assert not ch[i].any()
+            continue
+        ndet += 1
+        peaks.add(int(np.rint(a["toa"])))
+        assert_veq(ch[i], a["chan"], "chan %d" % i); assert co[i] == a["chan_off"], i
+    assert ndet > B // 4 and len(peaks) >= 8, (ndet, sorted(peaks))
+
+
 def test_equalize_taps_rejected_burst_is_not_equalised_from_stale_scratch(pkg, t1):
     """trxsig_equalize_taps_batch with caller-supplied flags: a burst the delay kernel refuses (bad length, |TOA| > 4096 or
     NaN) must come back as zeros even when its scratch row still holds an earlier call's burst."""
