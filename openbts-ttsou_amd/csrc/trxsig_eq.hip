@@ -646,8 +646,11 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
 template <typename SMP>
 struct EqDetect52 {
   static constexpr int MT = 4, NC = 2 * MT + 1, NX = 26, START = 20 - MT, WIN0 = 61;
-  static constexpr int NSLOT = 20 + NX, PITCH = NSLOT | 1;
   static constexpr bool RAWST = sizeof(typename SMP::raw_t) == 4;
+  // fp16 storage: a burst's first NCHUNK 16-byte pieces (samples 0 .. 4 NCHUNK - 1: the energy samples 0, 4, .., 76 and the window
+  // 61 .. 86) are parked as stored; complex float storage: the 46 samples themselves, widened
+  static constexpr int NCHUNK = (WIN0 + NX + 3) / 4;
+  static constexpr int NSLOT = RAWST ? 4 * NCHUNK : 20 + NX, PITCH = NSLOT | 1;
   static constexpr size_t kStage = (RAWST ? sizeof(unsigned) : sizeof(float) * 2) * 64 * PITCH;
   static constexpr size_t kCols = sizeof(cx) * 64 * (2 * NC);
   static constexpr size_t kSlice = ((kStage > kCols ? kStage : kCols) + 15) & ~(size_t)15;
@@ -678,11 +681,22 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
 #ifdef TRX_EQ_PROBE
   long long pt_[8] = {0};
   int pk_ = 0;
+#if TRX_EQ_PROBE == 2                                       // the staging block in detail instead of the phases
+#define TRX_STAMP()
+#define TRX_STAMP2() pt_[pk_++] = clock64()
+#else
 #define TRX_STAMP() pt_[pk_++] = clock64()
+#define TRX_STAMP2()
+#endif
 #else
 #define TRX_STAMP()
+#define TRX_STAMP2()
 #endif
+#if defined(TRX_EQ_PROBE) && TRX_EQ_PROBE == 2
+  pt_[pk_++] = clock64();
+#else
   TRX_STAMP();
+#endif
   const int off = live ? offset[b] : 0, N = live ? length[b] : 0;
   uint8_t fl = 0;
   cx amp = mk(0, 0);
@@ -693,43 +707,74 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
   cx ev[20], wv[NX];
   {
     const unsigned long long goodm = __ballot(good);
+    TRX_STAMP2();                                          // (2: 1) offsets and lengths are here
     const int safe_off = __builtin_amdgcn_readlane(off, goodm ? (int)__builtin_ctzll(goodm) : 0);
     int offv = good ? off : safe_off, nm1v = good ? N - 1 : 0;
     asm volatile("" : "+v"(offv), "+v"(nm1v));
-    const int slot = lane;
-    const bool slot_ok = slot < NSLOT;
-    const int idx = slot >= 20 ? G::WIN0 + (slot - 20) : slot * 4;   // energyDetect strides by 4 (ref52:946-963)
-    typename SMP::raw_t v[64];
+    if constexpr (G::RAWST) {
+      // fp16 storage: TWO bursts per load instruction, a lane per 16-byte piece (lanes 0..21 burst 2 j, lanes 32..53 burst 2 j + 1):
+      // the same lines as a lane per sample would touch, in half the load instructions, four samples per lane.  (A good burst has
+      // at least 92 samples: pieces 0 .. NCHUNK - 1 = samples 0..87 lie inside it.)
+      static_assert(G::NCHUNK <= 32 && 4 * G::NCHUNK <= 92, "two bursts per wave instruction, inside the shortest burst");
+      struct __attribute__((packed, aligned(4))) Piece { unsigned q[4]; };
+      const int c = lane & 31, half = lane >> 5;
+      const bool piece_ok = c < G::NCHUNK;
+      Piece v[32];
 #pragma unroll
-    for (int k = 0; k < 64; k++) v[k] = SMP::zero();
-    if (slot_ok && goodm) {
+      for (int j = 0; j < 32; j++) v[j] = Piece{{0u, 0u, 0u, 0u}};
+      int off_k[32];                                       // (every lane takes part in the exchange: before the branch)
 #pragma unroll
-      for (int k = 0; k < 64; k++) {
-        const int off_k = __builtin_amdgcn_readlane(offv, k), nm1_k = __builtin_amdgcn_readlane(nm1v, k);
-        v[k] = SMP::ldraw(samples, (long long)off_k + (idx < nm1_k ? idx : nm1_k));
+      for (int j = 0; j < 32; j++) off_k[j] = __shfl(offv, 2 * j + half, 64);
+      if (piece_ok && goodm) {
+#pragma unroll
+        for (int j = 0; j < 32; j++)
+          v[j] = *reinterpret_cast<const Piece *>(reinterpret_cast<const unsigned *>(samples) + ((long long)off_k[j] + 4 * c));
       }
-    }
-    {                                                      // the table's loads queue behind the bursts': nothing waits for them alone
-      float4 tv[3072 / 256];
-      sinc_lds_issue<256>(T, tid, tv);
-      sinc_lds_store<256>(stab, tid, tv);
-    }
-    if (slot_ok) {
-      if (G::RAWST) {
+      TRX_STAMP2();                                        // (2: 2) loads issued
+      {                                                    // the table's loads queue behind the bursts': nothing waits for them alone
+        float4 tv[3072 / 256];
+        sinc_lds_issue<256>(T, tid, tv);
+        sinc_lds_store<256>(stab, tid, tv);
+      }
+      if (piece_ok) {
 #pragma unroll
-        for (int k = 0; k < 64; k++) st_raw[k * PITCH + slot] = v[k];
-      } else {
+        for (int j = 0; j < 32; j++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) st_raw[(2 * j + half) * PITCH + 4 * c + q] = v[j].q[q];
+        }
+      }
+      wave_lds_fence();
+      TRX_STAMP2();                                        // (2: 3) loads complete, table and bursts parked
+#pragma unroll
+      for (int i = 0; i < 20; i++) ev[i] = SMP::widen(st_raw[lane * PITCH + 4 * i]);   // energyDetect strides by 4 (ref52:946-963)
+#pragma unroll
+      for (int a = 0; a < NX; a++) wv[a] = SMP::widen(st_raw[lane * PITCH + G::WIN0 + a]);
+    } else {
+      const int slot = lane;
+      const bool slot_ok = slot < NSLOT;
+      const int idx = slot >= 20 ? G::WIN0 + (slot - 20) : slot * 4;   // energyDetect strides by 4 (ref52:946-963)
+      typename SMP::raw_t v[64];
+#pragma unroll
+      for (int k = 0; k < 64; k++) v[k] = SMP::zero();
+      if (slot_ok && goodm) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+          const int off_k = __builtin_amdgcn_readlane(offv, k), nm1_k = __builtin_amdgcn_readlane(nm1v, k);
+          v[k] = SMP::ldraw(samples, (long long)off_k + (idx < nm1_k ? idx : nm1_k));
+        }
+      }
+      TRX_STAMP2();                                        // (2: 2) loads issued
+      {
+        float4 tv[3072 / 256];
+        sinc_lds_issue<256>(T, tid, tv);
+        sinc_lds_store<256>(stab, tid, tv);
+      }
+      if (slot_ok) {
 #pragma unroll
         for (int k = 0; k < 64; k++) { const cx f = SMP::widen(v[k]); st_re[k * PITCH + slot] = f.r; st_im[k * PITCH + slot] = f.i; }
       }
-    }
-    wave_lds_fence();
-    if (G::RAWST) {
-#pragma unroll
-      for (int i = 0; i < 20; i++) ev[i] = SMP::widen(st_raw[lane * PITCH + i]);
-#pragma unroll
-      for (int a = 0; a < NX; a++) wv[a] = SMP::widen(st_raw[lane * PITCH + 20 + a]);
-    } else {
+      wave_lds_fence();
+      TRX_STAMP2();                                        // (2: 3) loads complete, table and bursts parked
 #pragma unroll
       for (int i = 0; i < 20; i++) ev[i] = mk(st_re[lane * PITCH + i], st_im[lane * PITCH + i]);
 #pragma unroll
@@ -737,7 +782,9 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
     }
     wave_lds_fence();                                      // the staging area is dead: cp / shf take its place
   }
+  TRX_STAMP2();                                            // (2: 4) read back
   __syncthreads();                                         // the table is whole; no barrier below (each lane owns its columns)
+  TRX_STAMP2();                                            // (2: 5) barrier
   if (!live) return;
   if (!good || !winOk) {
     // (energyDetect comes first in the reference: a short burst that fails it reports 0, not BADLEN -- as k_eq_detect)
@@ -954,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
   }
 #endif
 #undef TRX_STAMP
+#undef TRX_STAMP2
 }
 
 // The burst's row of xd was written by k_eq_delay only if that kernel accepted the burst (k_demod's gate: DETECT flag,
