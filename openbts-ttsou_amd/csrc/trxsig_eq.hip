@@ -1494,9 +1494,15 @@ static void launch_eq_tail(hipStream_t st, const TrxTables *dT, const void *samp
 // k_eq_detect52 needs more LDS than a kernel gets by default: raise the limit once per instantiation
 template <typename SMP, typename... A>
 static hipError_t launch_eq_detect52(hipStream_t st, int B, A... a) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_detect52<SMP>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)EqDetect52<SMP>::kLds);
-  if (attr != hipSuccess) return attr;
+  static bool raised[64] = {};                              // per device (a process may drive several)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!raised[dev]) {                                       // (idempotent: two threads racing here both set the same value)
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_eq_detect52<SMP>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EqDetect52<SMP>::kLds);
+    if (attr != hipSuccess) return attr;
+    raised[dev] = true;
+  }
   k_eq_detect52<SMP><<<dim3((B + 255) / 256), dim3(256), EqDetect52<SMP>::kLds, st>>>(a...);
   return hipSuccess;
 }

@@ -114,7 +114,7 @@ struct TrxResampleArgs {
   int o_skip, n_out;                                       // outputs [o_skip, n_out) of every window are produced
   void *out; long long out_stride, out_win_step;           // window w of stream s writes at out + s*out_stride + w*out_win_step
   float gain;                                              // int16 output
-  int OB, xcap, taps_lds, tap_pitch, tap_g;                // filled in by the launcher
+  int OB, xcap, taps_lds, tap_pitch, tap_g, row_inv;       // filled in by the launcher
   // int16 input, wideband (the channeliser): output stream s is carrier s % mix_carriers of raw stream s / mix_carriers, mixed down
   // on the way into LDS: z[n] = x[n] * expjLookup(phase[n]) (frequencyShift's arithmetic, sigProcLib.cpp:459) with the phase of
   // raw sample n formed directly, phase[n] = (float)(t - 2 pi floor(t / 2 pi)), t = (double) n * (double) freq, instead of by

@@ -289,19 +289,22 @@ __global__ __launch_bounds__(256) void k_resample(TrxResampleArgs a) {
 template <int KQ>                                           // taps per output: at most 4 KQ (L <= 4 KQ P)
 __global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a, int n_windows, int wpb) {
   extern __shared__ __attribute__((aligned(16))) char res_lds[];
-  // [KT zero samples][n window samples][KT zero samples] then the branch-major taps: KQ float4 per branch (one more of pitch when
+  // [KT zero samples][n window samples][KT zero samples] -- AS RECEIVED, int16 I/Q pairs (4 bytes: the kernel is bound by its LDS
+  // reads, sixteen samples per output at KQ = 4, and a wave's 4-byte reads are one pass where its 8-byte reads of converted samples
+  // were two to four; the conversion is exact either way and costs two instructions per read) -- then the branch-major taps: KQ float4 per branch (one more of pitch when
   // KQ > 1: consecutive outputs sit Q mod P branches apart, and a power-of-two row pitch would put a wave's rows on a few banks).
   // A workgroup serves `wpb` consecutive windows of a stream with ONE staging of the taps; the next window's raw samples are
   // loaded (into registers) before the current window is filtered, so their latency hides under the arithmetic.
   constexpr int KT = 4 * KQ, TP = KQ > 1 ? KQ + 1 : 1, NQ = 5;      // NQ * 256 >= the longest window (the launcher checks)
-  cx *X = reinterpret_cast<cx *>(res_lds) + KT;
-  float4 *TPB = reinterpret_cast<float4 *>(res_lds + sizeof(cx) * (size_t)(a.n + 2 * KT));
+  short2 *X = reinterpret_cast<short2 *>(res_lds) + KT;
+  float4 *TPB = reinterpret_cast<float4 *>(res_lds + ((sizeof(short2) * (size_t)(a.n + 2 * KT) + 15) & ~(size_t)15));
   const int s = blockIdx.z;
   const int w0 = blockIdx.y * wpb, w1 = w0 + wpb < n_windows ? w0 + wpb : n_windows;
   const int D = (a.L - 1) / 2 / a.Q;                                // :1177
   const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
   const short2 *hist = a.hist + (size_t)s * a.hist_len;
   short2 v[NQ];
+  auto xf = [](short2 r) { return mk((float)r.x, (float)r.y); };
   auto fetch = [&](int w) {
     const int base = w * a.win_step - a.hist_len;                   // raw index of the window's sample 0
 #pragma unroll
@@ -311,26 +314,36 @@ __global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a, int n_wi
     }
   };
   fetch(w0);
+  // The taps' rows are kept in the ORDER THE OUTPUTS VISIT THE BRANCHES: consecutive outputs (a wave's lanes) sit Q mod P branches
+  // apart, so with rows in branch order a wave's 16-byte tap reads fall on rows scattered over the table -- the LDS serves sixteen
+  // such reads per pass, and sixteen scattered rows share banks (half of this kernel's LDS cycles were bank conflicts:
+  // SQ_LDS_BANK_CONFLICT 14.1 M of SQ_LDS_IDX_ACTIVE 28.3 M).  Row of branch br = br * (Q mod P)^-1 mod P (row_inv, from the
+  // launcher; 0 when Q mod P has no inverse: rows in branch order): consecutive lanes read consecutive rows, whose odd pitch in
+  // 16-byte units walks all sixteen bank groups.
+  const int row_inv = a.row_inv;
   for (int e = threadIdx.x; e < a.P * KQ; e += 256) {
     const int br = e / KQ, q = e - br * KQ;
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int fi = br + a.P * (4 * q + k); t[k] = fi < a.L ? a.lpf[fi] : 0.0f; }
-    TPB[br * TP + q] = make_float4(t[0], t[1], t[2], t[3]);
+    const int row = row_inv ? (int)(((unsigned)br * (unsigned)row_inv) % (unsigned)a.P) : br;
+    TPB[row * TP + q] = make_float4(t[0], t[1], t[2], t[3]);
   }
-  if (threadIdx.x < 2 * KT) X[threadIdx.x < KT ? (int)threadIdx.x - KT : a.n + (int)threadIdx.x - KT] = mk(0, 0);
+  if (threadIdx.x < 2 * KT) X[threadIdx.x < KT ? (int)threadIdx.x - KT : a.n + (int)threadIdx.x - KT] = make_short2(0, 0);
   const unsigned oq0 = (unsigned)(a.o_skip + (int)threadIdx.x + D) * (unsigned)a.Q;
   const int branch0 = (int)(oq0 % (unsigned)a.P), inOff0 = (int)(oq0 / (unsigned)a.P);
   const int step_b = (256 * a.Q) % a.P, step_i = (256 * a.Q) / a.P;
+  const int row0 = row_inv ? (int)(((unsigned)branch0 * (unsigned)row_inv) % (unsigned)a.P) : branch0;
+  const int step_r = row_inv ? 256 % a.P : step_b;          // a row per output: 256 outputs on
   for (int w = w0; w < w1; w++) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
       const int i = (int)threadIdx.x + 256 * q;
-      if (i < a.n) X[i] = a.swap ? mk((float)v[q].y, (float)v[q].x) : mk((float)v[q].x, (float)v[q].y);   // unUSRPifyVector (:108-109)
+      if (i < a.n) X[i] = a.swap ? make_short2(v[q].y, v[q].x) : v[q];   // unUSRPifyVector's order (:108-109); its int16 -> float on the way out
     }
     __syncthreads();
     if (w + 1 < w1) fetch(w + 1);
-    int branch = branch0, inOff = inOff0;
+    int branch = branch0, inOff = inOff0, row = row0;
     cx *out = reinterpret_cast<cx *>(a.out) + (size_t)s * a.out_stride + (size_t)w * a.out_win_step;
     for (int o = a.o_skip + threadIdx.x; o < a.n_out; o += 256) {
       // tap k of the reference's walk (fi = branch + P k) meets sample inOff - k; samples outside [0, n) are the zero pads
@@ -339,15 +352,16 @@ __global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a, int n_wi
       cx sum = mk(0, 0);
 #pragma unroll
       for (int q = 0; q < KQ; q++) {
-        const float4 tp = TPB[branch * TP + q];
-        sum = cadd(sum, cmulr(X[inOff - 4 * q], tp.x));
-        sum = cadd(sum, cmulr(X[inOff - 4 * q - 1], tp.y));
-        sum = cadd(sum, cmulr(X[inOff - 4 * q - 2], tp.z));
-        sum = cadd(sum, cmulr(X[inOff - 4 * q - 3], tp.w));
+        const float4 tp = TPB[row * TP + q];
+        sum = cadd(sum, cmulr(xf(X[inOff - 4 * q]), tp.x));
+        sum = cadd(sum, cmulr(xf(X[inOff - 4 * q - 1]), tp.y));
+        sum = cadd(sum, cmulr(xf(X[inOff - 4 * q - 2]), tp.z));
+        sum = cadd(sum, cmulr(xf(X[inOff - 4 * q - 3]), tp.w));
       }
       out[o - a.o_skip] = sum;
-      branch += step_b; inOff += step_i;
+      branch += step_b; inOff += step_i; row += step_r;
       if (branch >= a.P) { branch -= a.P; inOff++; }
+      if (row >= a.P) row -= a.P;
     }
     __syncthreads();                                                // every lane is done with X before the next window lands
   }
@@ -465,12 +479,17 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
                        (long long)(a.n_out + (a.L - 1) / 2 / a.Q + 256) * a.Q < 0x7fffffffLL && (long long)n_windows * a.win_step < 0x7fffffffLL &&
                        ((long long)(a.n_out - 1 + (a.L - 1) / 2 / a.Q) * a.Q) / a.P <= a.n + 4 * kq - 1;
   if (rx_fast) {
-    const size_t lds2 = sizeof(trx_c32) * (size_t)(a.n + 8 * kq) + sizeof(float) * 4 * (size_t)a.P * (kq > 1 ? kq + 1 : 1);
+    const size_t lds2 = ((sizeof(short2) * (size_t)(a.n + 8 * kq) + 15) & ~(size_t)15) + sizeof(float) * 4 * (size_t)a.P * (kq > 1 ? kq + 1 : 1);
     // windows per workgroup: enough workgroups left to fill the machine several times over, else one window each
     int wpb = 1;
     while (wpb < 8 && (long long)S * (n_windows / (2 * wpb)) >= 4096) wpb *= 2;
     if (const char *e = std::getenv("TRXSIG_RXRES_WPB")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) wpb = v; }   // (tests: small cases through the multi-window loop)
     const dim3 g2(1, (n_windows + wpb - 1) / wpb, S);
+    a.row_inv = 0;                                          // (Q mod P)^-1 mod P, if it exists: the rows of the tap table in visiting order
+    for (int v = 1; v < a.P; v++)
+      if (((long long)v * (a.Q % a.P)) % a.P == 1) { a.row_inv = v; break; }
+    if ((long long)a.P * a.P > 0x7fffffffLL) a.row_inv = 0;
+    if (const char *e = std::getenv("TRXSIG_RXRES_ROWS")) { if (std::atoi(e) == 0) a.row_inv = 0; }   // (A/B: rows in branch order)
     if (kq == 1) k_rx_resample<1><<<g2, block, lds2, st>>>(a, n_windows, wpb);
     else if (kq == 2) k_rx_resample<2><<<g2, block, lds2, st>>>(a, n_windows, wpb);
     else k_rx_resample<4><<<g2, block, lds2, st>>>(a, n_windows, wpb);
