@@ -14,7 +14,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET --kernel-include-regex "k_(tsc|demod|rach|normal|modulate|resample|rx_resample|energy|eq_|design_dfe|fec_|unpack|pack|convolve|delay|peak_detect|interpolate|elementwise|decimate|burst_index|group|vector|frequency|add_vector|tx_ring)" --output-format csv -d $OUT/p$i -- \
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET --kernel-include-regex "k_(tsc|demod|rach|normal|modulate|resample|rx_resample|channelise|energy|eq_|design_dfe|fec_|unpack|pack|convolve|delay|peak_detect|interpolate|elementwise|decimate|burst_index|group|vector|frequency|add_vector|tx_ring)" --output-format csv -d $OUT/p$i -- \
       python3 $R/${PMC_PROG:-bench.py} $([ -z "$PMC_PROG" ] && echo "--steps 3 --warmup 1 --no-cpu-baseline") "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
 done
 python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1

@@ -9,7 +9,7 @@ P = os.path.join(ROOT, "profiles")
 WANT = [("normal", "k_demod<4", "k_demod", 65536, {}), ("normal", "k_tsc_corr<4", "k_tsc_corr", 65536, {}),
         ("normal", "k_tsc_peak2<4", "k_tsc_peak2", 65536, {}), ("normal", "k_tsc_peak2<4", "k_tsc_peak", 65536, {}),
         ("rach", "k_rach_front<4", "k_rach_front", 65536, {}), ("rach", "k_rach_peak2<4", "k_rach_peak2", 65536, {}),
-        ("config5", "k_eq_delay<", "k_eq_delay", 65536, {}), ("config5", "k_eq_detect<", "k_eq_detect", 65536, {}),
+        ("config5", "k_eq_delay<", "k_eq_delay", 65536, {}), ("config5", "k_eq_detect52<", "k_eq_detect", 65536, {"kernel": "k_eq_detect52"}),
         ("config5", "k_eq_dfe2", "k_eq_dfe2", 65536, {}),
         ("config4", "k_demod_rx<4", "k_demod_rx", 59904, {}), ("config4", "k_tsc_corr_rx<4", "k_tsc_corr_rx", 59904, {}),
         ("config4", "k_rach_front_rx<4", "k_rach_front_rx", 59904, {"note": "per step of the group bench (the access-burst rows only: ~500 bursts)"}),
