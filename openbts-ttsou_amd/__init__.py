@@ -107,6 +107,7 @@ def _load(path):
         L.trxsig_fec_xcch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.trxsig_fec_rach_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.trxsig_channel_estimate_batch.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, i32, i32, vp, vp, vp, vp, vp]
+        L.trxsig_estimate_dfe_batch.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp]
         L.trxsig_design_dfe_batch.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L.trxsig_fec_xcch_encode_batch.argtypes = [vp, vp, i32, i32, vp]
         L.trxsig_fec_tch_decode_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
@@ -458,6 +459,13 @@ class TrxSig:
         self._chk(self.L.trxsig_channel_estimate_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), offset.numel(), tsc,
                                                        detect_thresh, int(variant52m), max_toa, _ptr(flags), _ptr(amp), _ptr(toa),
                                                        _ptr(chan_off), _ptr(chan)), "trxsig_channel_estimate_batch")
+
+    def estimate_dfe(self, samples, offset, length, tsc, flags, amp, toa, chan_off, w, b, detect_thresh=3.0, snr_thresh=-1.0,
+                     snr_value=0.0, variant52m=False, max_toa=4):
+        """analyzeTrafficBurst(requestChannel) + scaleVector(chan, 1/amp) + designDFE(., SNR, 7) (Transceiver.cpp:326-347), no energy gate."""
+        self._chk(self.L.trxsig_estimate_dfe_batch(self.h, _ptr(samples), _ptr(offset), _ptr(length), offset.numel(), tsc,
+                                                   detect_thresh, snr_thresh, snr_value, int(variant52m), max_toa, _ptr(flags), _ptr(amp),
+                                                   _ptr(toa), _ptr(chan_off), _ptr(w), _ptr(b)), "trxsig_estimate_dfe_batch")
 
     def design_dfe(self, chan, snr, w, b, amp=None):
         self._chk(self.L.trxsig_design_dfe_batch(self.h, _ptr(chan), _ptr(amp), _ptr(snr), snr.numel(), _ptr(w), _ptr(b)),

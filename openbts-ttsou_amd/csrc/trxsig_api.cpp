@@ -815,9 +815,13 @@ int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int
   if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "the channel estimate / DFE path needs sps == 1");
   if (B <= 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
+  int rc = ensure_eq(c, B);
+  if (rc != TRXSIG_OK) return rc;
+  // (the list of the marked bursts goes where trx_ctx_group_equalize will afterwards put the delayed bursts)
+  int32_t *work = (int32_t *)(c->d_eq + (size_t)c->eq_cap * (4 + 56 + 40));
   HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc, 3.0f, -1.0f, 1.0f,
                                     0, 0, d_flags, (trx_c32 *)d_amp, d_toa, d_toa_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b,
-                                    nullptr, c->prof, d_enable, d_snr, trx_eq52_geometry(c->h_tables, tsc)));
+                                    nullptr, c->prof, d_enable, d_snr, trx_eq52_geometry(c->h_tables, tsc), d_enable ? work : nullptr));
   return TRXSIG_OK;
 }
 int trx_ctx_group_equalize(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,

@@ -23,6 +23,7 @@ namespace {
 //                 recursion of equalizeBurst (:1352-1384) and the slicer.
 // ---------------------------------------------------------------------------------------------
 #define EQ_NC 36            /* max correlation lags kept per burst */
+static constexpr int kEqWaveMax = 2048;   // k_eq_estimate_wave: waves launched; a call of at most this many bursts takes it without a list
 // A/B: TRXSIG_EQ_DETECT_GENERIC=1 keeps the padded kernel also where the fixed-geometry one applies (maxTOA 4)
 static int eq_detect_generic() {
   static const int v = std::getenv("TRXSIG_EQ_DETECT_GENERIC") ? std::atoi(std::getenv("TRXSIG_EQ_DETECT_GENERIC")) : 0;
@@ -1004,6 +1005,310 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
 #undef TRX_STAMP2
 }
 
+// designDFE(Nf = 7, nu = 5) with the lanes of a wave (design_dfe7 above is the same computation in one lane): lane q holds G0[q] and
+// G1[q]; every iteration of the recursion (:1270-1297) updates the seven columns side by side, element 0 is broadcast, G1's delay by
+// one (:1292) is a shift between neighbouring lanes.  Lane k's column quotients L[i][i + k] go to LDS for the back-substitution
+// (:1310-1319), which is serial and done by every lane alike; lane i then forms w[i] (:1323-1335).  Every element sees the operations
+// design_dfe7 applies to it, in the same order: the same values.  Results: lane i < 7 returns w[i], lane j + 1 (j < 5) returns b[j].
+// Lu_s: 36 complex, v_s: 8 complex of the wave's LDS.
+__device__ __forceinline__ void design_dfe7_lanes(const cx (&chan)[6], float snr, int lane, cx *Lu_s, cx *v_s, cx &w_mine, cx &b_mine) {
+  constexpr int Nf = 7, nu = 5;
+  auto conj2 = [](v2f z) { v2f r; r.x = z.x; r.y = -z.y; return r; };
+  auto nrm = [](v2f z) { return z.y * z.y + z.x * z.x; };    // Complex::norm2 (Complex.h:119)
+  auto bcast0 = [](v2f z) {
+    v2f r;
+    r.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z.x), 0));
+    r.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z.y), 0));
+    return r;
+  };
+  const int q = lane < Nf ? lane : Nf - 1;                   // (lanes beyond the seventh shadow lane 6: their values are never used)
+  v2f G0 = pk(mk(0, 0)), G1 = pk(mk(0, 0));
+  if (q == 0) G0 = pk(mk((float)(1.0 / (double)sqrtf(snr)), 0.0f));   // :1261
+#pragma unroll
+  for (int j = 0; j <= nu; j++)
+    if (q == j) G1 = pk(mk(chan[j].r, -chan[j].i));
+  v2f lfb = pk(mk(0, 0));
+  float d = 0.0f;
+#pragma unroll
+  for (int i = 0; i < Nf; i++) {
+    const v2f G00 = bcast0(G0), G10 = bcast0(G1);
+    d = nrm(G00) + nrm(G10);                                 // :1272
+    const v2f g0c = conj2(G00), g1c = conj2(G10);
+    {                                                        // *Lptr = (G0[k]*conj(G0[0]) + G1[k]*conj(G1[0]))/d (:1277), k = this lane
+      const v2f tt = pk_cadd(pk_cmul(G0, g0c), pk_cmul(G1, g1c));
+      v2f v; v.x = tt.x / d; v.y = tt.y / d;
+      const int col = i + q;
+      if (i < Nf - 1) { if (q >= 1 && col <= Nf - 1 && lane < Nf) Lu_s[i * 6 + (q - 1)] = unpk(v); }
+      else if (q >= 1 && col >= Nf && col < Nf + nu) lfb = v;
+    }
+    v2f kk;                                                  // G1[0] / G0[0] (:1282)
+    {
+      const float n = nrm(G00);
+      v2f inv; inv.x = G00.x / n; inv.y = -G00.y / n;
+      kk = pk_cmul(G10, inv);
+    }
+    if (i != Nf - 1) {
+      const v2f kc = conj2(kk);
+      v2f km; km.x = kk.x * -1.0f; km.y = kk.y * -1.0f;
+      const v2f G0n = pk_cadd(pk_cmul(G1, kc), G0);          // :1285-1287
+      v2f G1n = pk_cadd(pk_cmul(G0, km), G1);                // :1289-1291
+      v2f sh;                                                // delayVector(G1new, -1) (:1292): lane q takes lane q + 1's, the last a zero
+      sh.x = __shfl_down(G1n.x, 1, 64); sh.y = __shfl_down(G1n.y, 1, 64);
+      G1n = (lane < Nf - 1) ? sh : pk(mk(0, 0));
+      const v2f sc = pk(mk((float)(1.0 / (double)sqrtf((float)(1.0 + (double)nrm(kk)))), 0.0f));   // :1294-1295
+      G0 = pk_cmul(G0n, sc);
+      G1 = pk_cmul(G1n, sc);
+    }
+  }
+  {                                                          // :1301-1304: * -1, conj
+    const v2f t1 = pk_cmul(lfb, pk(mk(-1.0f, 0.0f)));
+    b_mine = mk(t1.x, -t1.y);
+  }
+  wave_lds_fence();
+  v2f v[Nf];
+  v[Nf - 1] = pk(mk(1.0f, 0.0f));
+#pragma unroll
+  for (int k = Nf - 2; k >= 0; k--) {                        // :1310-1319
+    v2f vk = pk(mk(0, 0));
+#pragma unroll
+    for (int j = k + 1; j < Nf; j++) vk = pk_csub(vk, pk_cmul(v[j], pk(Lu_s[k * 6 + (j - k - 1)])));
+    v[k] = vk;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < Nf; k++) v_s[k] = unpk(v[k]);
+  }
+  wave_lds_fence();
+  {                                                          // :1323-1335, i = this lane
+    v2f wi = pk(mk(0, 0));
+    const int endPt = (nu < (Nf - 1 - q)) ? nu : (Nf - 1 - q);
+#pragma unroll
+    for (int k = 0; k < Nf - 1; k++)
+      if (k < endPt + 1) wi = pk_cadd(wi, pk_cmul(pk(v_s[q + k < Nf ? q + k : Nf - 1]), pk(mk(chan[k].r, -chan[k].i))));
+    w_mine = mk(wi.x / d, wi.y / d);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_eq_list + k_eq_estimate_wave (round 4): analyzeTrafficBurst(requestChannel) + designDFE for FEW bursts, a WAVE per burst.
+// The Transceiver asks for a channel estimate once per timeslot and 51 frames (Transceiver.cpp:313-325): of the group's rows some 2 %
+// are marked, one or two per wave of a lane-per-burst kernel -- k_eq_detect<36, 52> then runs 936 waves at one or two active lanes
+// each and takes one wave's full latency (46 us with VALU 0 % busy, profiles/r04_pmc_config4_reference_chain.txt), and the one-ARFCN
+// object's one-burst call (trxsig_estimate_dfe_batch, B = 1) pays the same.  Here the marked bursts are listed first (k_eq_list: one
+// workgroup, a prefix sum over the flags -- the list comes out in the same order every run) and each listed burst gets a wave:
+//   lanes 0..35 the 36 lags of the correlation (sigProcLib.cpp:480-498; the Transceiver/ variant: whole 36-lag window from sample 56);
+//   the argmax by a wave reduction with the reference's first-maximum rule; peakDetect's bisection SPECULATED in two super-steps
+//   (trxsig_bisect.h: every node of the next five / four levels evaluated at once, the decisions replayed along the reference's path);
+//   fused_tail (valley, peak-to-mean, TOA bookkeeping); lanes 0..35 the outputs of delayVector on the correlation; lanes 0..6 the
+//   channel-pick windows; designDFE with a lane per column of its generator recursion (design_dfe7_lanes).
+// Each value is formed by the same operations in the same order as in k_eq_detect (and the reference): same results.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_eq_list(const uint8_t *__restrict__ enable, int B, int32_t *__restrict__ list, int32_t *__restrict__ count) {
+  // thread t owns bursts t, t + 1024, t + 2048, ...: a wave's loads are 64 consecutive bytes, 32 of a thread's in flight at a time
+  // (unconditional, index clamped: a load under a branch is waited for at the join).  The first 64 flags of a thread are kept as a
+  // bit mask, so a call of up to 65,536 bursts reads its flags once.  The list holds thread 0's bursts first, then thread 1's, ...:
+  // not sorted, but the same on every run.
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int K = (B + 1023) / 1024;
+  int n = 0;
+  unsigned long long m = 0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    uint8_t v[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++) { const int i = (k0 + u) * 1024 + t; v[u] = enable[i < B ? i : B - 1]; }
+#pragma unroll
+    for (int u = 0; u < 32; u++) {
+      const bool on = ((k0 + u) * 1024 + t < B) && v[u] != 0;
+      n += on;
+      if (k0 + u < 64) m |= (unsigned long long)on << ((k0 + u) & 63);
+    }
+  }
+  int incl = n;                                             // inclusive prefix sum: inside the wave, then over the sixteen waves
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) before += w < wave ? wsum[w] : 0;
+  int pos = before + incl - n;
+  while (m) {
+    const int k = (int)__builtin_ctzll(m);
+    m &= m - 1;
+    list[pos++] = k * 1024 + t;
+  }
+  for (int k = 64; k < K; k++) {                            // (calls beyond 65,536 bursts)
+    const int i = k * 1024 + t;
+    if (i < B && enable[i] != 0) list[pos++] = i;
+  }
+  if (t == 1023) *count = before + incl;
+}
+
+template <typename SMP>
+__global__ __launch_bounds__(256) void k_eq_estimate_wave(const TrxTables *__restrict__ T, const void *__restrict__ samples,
+                                                          const int32_t *__restrict__ offset, const int32_t *__restrict__ length, int B, int tsc,
+                                                          float detect_thresh, uint8_t *__restrict__ flags, cx *__restrict__ amp_out,
+                                                          float *__restrict__ toa_out, float *__restrict__ toa_eq, cx *__restrict__ w_out,
+                                                          cx *__restrict__ b_out, float snr_thresh, float snr_value,
+                                                          float *__restrict__ chan_off_out, cx *__restrict__ chan_out,
+                                                          const float *__restrict__ snr_in, const int32_t *__restrict__ list,
+                                                          const int32_t *__restrict__ count) {
+  constexpr int NL = 36, FRONT = 8, BACK = 8, PADC = 13, W0 = 56, START = 7;   // :951-955, 295-300: NO_DELAY correlation, Lb = 16
+  static_assert(START - 15 >= -FRONT && START + NL - 1 < NL + BACK, "every tap of every lag meets a sample or a zero pad");
+  __shared__ cx Ws[4][FRONT + NL + BACK];
+  __shared__ cx Cs[4][PADC + NL + PADC];
+  __shared__ cx locs[4][26];
+  __shared__ cx shfs[4][NL];
+  __shared__ __attribute__((aligned(16))) float Vs[4][8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cx *W = Ws[wave], *Cc = Cs[wave], *loc = locs[wave], *shf = shfs[wave];
+  float *V = Vs[wave];
+  const int n_waves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  const int n = list ? *count : B;
+  const cx gain = T->mid_gain[tsc];
+  const float mid_toa = T->mid_toa[tsc];
+  cx ctap[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) ctap[j] = T->mid_ctap[tsc][15 - j];   // tmp[j] = conj(mid[15 - j]) (:480-498)
+  for (int it = w0; it < n; it += n_waves) {
+    const int b = __builtin_amdgcn_readfirstlane(list ? list[it] : it);
+    const int off = offset[b], N = length[b];
+    if (!((off >= 0) && (N >= 92) && (N <= 157))) {
+      if (lane == 0) { flags[b] = TRXSIG_F_BADLEN; amp_out[b] = mk(0, 0); toa_out[b] = 0.0f; toa_eq[b] = 0.0f; }
+      continue;
+    }
+    // ---- the window between zero pads; the correlation's pads ----
+    if (lane < FRONT) W[lane] = mk(0, 0);
+    if (lane < BACK) W[FRONT + NL + lane] = mk(0, 0);
+    if (lane < PADC) { Cc[lane] = mk(0, 0); Cc[PADC + NL + lane] = mk(0, 0); }
+    if (lane < NL) W[FRONT + lane] = SMP::ld(samples, (long long)off + W0 + lane);
+    wave_lds_fence();
+    // ---- correlation: lag i = lane ends on window sample START + i; j ascending ----
+    float P = 0.0f;
+    int Tm = -1;
+    if (lane < NL) {
+      cx acc = mk(0, 0);
+      const cx *wp = W + (FRONT + START + lane);
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc = cadd(acc, cmul(wp[-j], ctap[j]));
+      Cc[PADC + lane] = acc;
+      const float pw = norm2(acc);
+      if (pw > 0.0f) { P = pw; Tm = lane; }                 // "if (p > maxP)" from maxP = 0 (:675): a lag without power is never the maximum
+    }
+    // the first super-step's points do not depend on the data (early starts at M - 1): fetch its sinc rows under the reduction
+    const int relA = kFusedRel5.v[lane];
+    const int eA = (relA >> 2) * 16;
+    float rowA[24];
+    fused_row(T, eA, rowA);
+    wave_argmax(P, Tm);                                     // larger power wins, equal power: the smaller lag (the first maximum)
+    const int M = Tm;
+    wave_lds_fence();
+    if (lane < 26) {                                        // lags M-12 .. M+11 as interpolatePoint sees them (never the last sample, :646)
+      const int lag = M - 12 + lane;
+      loc[lane] = (lane >= 24 || lag < 0 || lag > NL - 2) ? mk(0, 0) : Cc[PADC + lag];
+    }
+    wave_lds_fence();
+    // ---- peakDetect's bisection, speculated (k_normal_fused's arrangement for 64 lanes per burst) ----
+    int e = 0;                                              // early = M-1 + e/512
+    bool active = true;
+    cx peak = mk(0, 0);
+    {
+      const cx ptA = fused_point(loc, eA, relA & 3, rowA);                  // levels 1-5: +-256 .. +-16
+      fused_decide<64, 5, false>(ptA, lane, 256, e, active, peak);
+      const int relB = kFusedRel4F.v[lane], eB = e + (relB >> 2);           // levels 6-9: +-8 .. +-1, and the finals
+      float rowB[24];
+      fused_row(T, eB, rowB);
+      const cx ptB = fused_point(loc, eB, relB & 3, rowB);
+      fused_decide<64, 4, true>(ptB, lane, 8, e, active, peak);
+    }
+    if (!active) {                                          // the reference left its loop on equal powers (:695): interpolatePoint(early + 1) where it stopped
+      float srow[24];
+      fused_row(T, e, srow);
+      peak = fused_point(loc, e, 1, srow);
+    }
+    cx amp;
+    float toa;
+    bool detected, energy_ok;
+    fused_tail<1, 64>([&](int lag) { return norm2(Cc[PADC + lag]); }, V, lane, M, e, peak, true, 0.0f, cinv(gain), mid_toa, detect_thresh,
+                      -1.0f, amp, toa, detected, energy_ok);
+    float chanOff = 0.0f;
+    cx chan[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) chan[k] = mk(0, 0);
+    if (detected) {                                         // (wave-uniform)
+      const float TOAoffset = mid_toa + 10.0f;
+      // delayVector(corr, -TOA) (:573-616): output t = lane; taps t + 10 - j outside [0, 36) meet the zero pads
+      const float delay = -toa;
+      const int io = (int)floorf(delay);
+      const float frac = delay - (float)io;
+      const cx *src = Cc + PADC;
+      if (fabs((double)frac) > 1e-2) {
+        const float *row = T->sinc_grid[(int)(frac * 512.0f) & 511];
+        if (lane < NL) {
+          cx sum = mk(0, 0);
+          const cx *cp = Cc + (PADC + lane + 10);
+#pragma unroll
+          for (int j = 0; j < 21; j++) sum = cadd(sum, cmulr(cp[-j], row[j]));
+          shf[lane] = sum;
+        }
+        src = shf;
+        wave_lds_fence();
+      }
+      auto wv = [&](int k) {                                // the integer shift folded into the reads
+        const int q = k - io;
+        return (q >= 0 && q < NL) ? src[q] : mk(0, 0);
+      };
+      // :1012-1021: window i = lane
+      float energy = 0.0f;
+      bool valid = false;
+      if (lane < 7) {
+        const float st = TOAoffset + (float)(lane - 5);
+        valid = !(st + (float)6u > (float)(unsigned)NL) && !(st < 0.0f);
+        const int s0 = (int)floorf(st);
+        for (int k = 0; k < 6; k++) energy += norm2(wv(s0 + k));
+      }
+      float maxEnergy = -1.0f;
+      int maxI = -1;
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const float en = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(energy), i));
+        const bool ok = __builtin_amdgcn_readlane((int)valid, i) != 0;
+        if (ok && (double)en > 0.95 * (double)maxEnergy) { maxI = i; maxEnergy = en; }
+      }
+      const int s0 = (int)floorf(TOAoffset + (float)(maxI - 5));
+      const cx ginv = cdiv(mk(1.0f, 0.0f), gain);
+#pragma unroll
+      for (int k = 0; k < 6; k++) chan[k] = cmul(wv(s0 + k), ginv);   // :1024-1025
+      chanOff = (float)(5 - maxI);                           // :1029
+    }
+    if (lane == 0) {
+      flags[b] = (uint8_t)(TRXSIG_F_ENERGY | (detected ? TRXSIG_F_DETECT : 0));
+      amp_out[b] = amp;
+      toa_out[b] = toa;
+      toa_eq[b] = toa - chanOff;
+      if (chan_off_out) chan_off_out[b] = chanOff;
+    }
+    if (chan_out && lane == 0) {                           // zeros if not detected
+#pragma unroll
+      for (int k = 0; k < 6; k++) chan_out[(size_t)b * 6 + k] = chan[k];
+    }
+    if (detected) {
+      // Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7)
+      const float thr = snr_thresh >= 0.0f ? snr_thresh : 0.0f;
+      const float snr = snr_in ? snr_in[b] : (snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0)));
+      const cx ainv = cdiv(mk(1.0f, 0.0f), amp);
+#pragma unroll
+      for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
+      cx w_mine, b_mine;
+      design_dfe7_lanes(chan, snr, lane, shf, loc, w_mine, b_mine);   // (shf, loc: dead by now)
+      if (lane < 7) w_out[(size_t)b * 7 + lane] = w_mine;
+      if (lane >= 1 && lane < 6) b_out[(size_t)b * 5 + (lane - 1)] = b_mine;
+    }
+    wave_lds_fence();                                       // the next burst reuses the wave's LDS
+  }
+}
+
 // The burst's row of xd was written by k_eq_delay only if that kernel accepted the burst (k_demod's gate: DETECT flag,
 // 92..157 samples, |TOA| <= 4096 and not NaN).  The equaliser must apply the same gate, or it would equalise whatever an
 // earlier call left in the row and hand back plausible-looking soft bits.
@@ -1547,10 +1852,25 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof,
-                                   const uint8_t *enable, const float *snr_in, bool geom52) {
+                                   const uint8_t *enable, const float *snr_in, bool geom52, int32_t *work) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
-  if (geom52 && variant52m && max_toa == 4 && eq_detect_generic() == 0)
+  // few bursts (the Transceiver/ variant): a wave per burst -- a marked subset (listed first; `work`: B + 1 ints) or a small call
+  if (!variant52m && eq_detect_generic() == 0 && ((enable && work) || (!enable && B <= kEqWaveMax))) {
+    const int32_t *list = nullptr, *count = nullptr;
+    if (enable) {
+      k_eq_list<<<dim3(1), dim3(1024), 0, st>>>(enable, B, work + 1, work);
+      list = work + 1; count = work;
+    }
+    const int waves = B < kEqWaveMax ? B : kEqWaveMax;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (fmt == TRXSIG_SAMPLES_F16)
+      k_eq_estimate_wave<SmpF16><<<grid, block, 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq,
+                                                         snr_thresh, snr_value, chan_off, (cx *)chan, snr_in, list, count);
+    else
+      k_eq_estimate_wave<SmpC32><<<grid, block, 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq,
+                                                         snr_thresh, snr_value, chan_off, (cx *)chan, snr_in, list, count);
+  } else if (geom52 && variant52m && max_toa == 4 && eq_detect_generic() == 0)
     EQ_DETECT52_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq, snr_thresh,
                        snr_value, chan_off, (cx *)chan, enable, snr_in);
   else

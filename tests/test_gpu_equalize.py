@@ -272,6 +272,61 @@ def test_channel_estimate_52m_every_peak_position(pkg, t1, tsc):
     assert ndet > B // 4 and len(peaks) >= 8, (ndet, sorted(peaks))
 
 
+@pytest.mark.parametrize("tsc", [1, 6])
+def test_estimate_dfe_a_wave_per_burst_and_a_lane_per_burst(pkg, t1, tsc):
+    """trxsig_estimate_dfe_batch on the Transceiver/ variant (the 36-lag window) takes a wave per burst for small calls and marked
+    subsets (k_eq_estimate_wave: speculated bisection, designDFE across lanes) and a lane per burst for large ones (k_eq_detect): the
+    same bursts through both -- a call of 700 and the same 700 inside a call of 2,900 -- must agree value for value with each other
+    and with the oracle: flags, amplitude, TOA, channel offset and both DFE filters.  Early / late bursts, noise, an impulse, silence."""
+    import torch
+    import synth
+    o = oraclebind.Oracle(1, variant52m=False)
+    rng = np.random.default_rng(77 + tsc)
+    Bs, Bl = 700, 2900
+    x, off, length, meta = synth.normal_batch(1, Bl, tsc, seed=300 + tsc, sigmas=(0.02, 0.3), max_delay=6.0)
+    x = x.copy()
+    for i in range(0, Bs, 7):
+        s = x[off[i]:off[i] + length[i]]
+        kind = (i // 7) % 4
+        if kind == 0:
+            s[:] = (rng.standard_normal(len(s)) + 1j * rng.standard_normal(len(s))).astype(np.complex64) * np.float32(50.0)
+        elif kind == 1:
+            s[:] = 0; s[int(rng.integers(56, 92))] = np.complex64(complex(rng.integers(1, 50), rng.integers(-50, 50)))
+        elif kind == 2 and i % 3 == 0:
+            s[:] = 0
+    dev = "cuda"
+    dx = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    out = {}
+    for B in (Bs, Bl):
+        doff = torch.from_numpy(off[:B].astype(np.int32)).cuda(); dlen = torch.from_numpy(length[:B].astype(np.int32)).cuda()
+        r = dict(flags=torch.zeros(B, dtype=torch.uint8, device=dev), amp=torch.zeros(B, 2, device=dev), toa=torch.zeros(B, device=dev),
+                 co=torch.zeros(B, device=dev), w=torch.zeros(B, 7, 2, device=dev), b=torch.zeros(B, 5, 2, device=dev))
+        t1.estimate_dfe(dx, doff, dlen, tsc, r["flags"], r["amp"], r["toa"], r["co"], r["w"], r["b"], snr_thresh=12.0)
+        torch.cuda.synchronize()
+        out[B] = dict(fl=r["flags"].cpu().numpy(), am=r["amp"].cpu().numpy().view(np.complex64).ravel(), toa=r["toa"].cpu().numpy(),
+                      co=r["co"].cpu().numpy(), w=r["w"].cpu().numpy().view(np.complex64).reshape(B, 7),
+                      b=r["b"].cpu().numpy().view(np.complex64).reshape(B, 5))
+    a, c = out[Bs], out[Bl]
+    ndet = 0
+    for i in range(Bs):
+        ref = o.analyze_traffic(x[off[i]:off[i] + length[i]], tsc, 3.0, req_chan=True, max_toa=4)
+        for r in (a, c):
+            assert bool(r["fl"][i] & pkg.F_DETECT) == ref["ok"], i
+            assert r["am"][i] == ref["amp"] and r["toa"][i] == ref["toa"], (i, r["am"][i], ref["amp"], r["toa"][i], ref["toa"])
+        if not ref["ok"]:
+            continue
+        ndet += 1
+        am = ref["amp"]
+        n2 = np.float32(np.float32(am.imag * am.imag) + np.float32(am.real * am.real))
+        inv = complex(np.float32(am.real / n2), np.float32(-am.imag / n2))
+        snr = np.float32(np.float64(n2) / (np.float64(np.float32(12.0 * 12.0)) + 1.0))
+        ow, ob = o.design_dfe(o.scale_vector(ref["chan"], inv), float(snr), 7)
+        for r in (a, c):
+            assert r["co"][i] == ref["chan_off"], i
+            assert_veq(r["w"][i], ow, "w %d" % i); assert_veq(r["b"][i], ob, "b %d" % i)
+    assert ndet > Bs // 2
+
+
 def test_equalize_taps_rejected_burst_is_not_equalised_from_stale_scratch(pkg, t1):
     """trxsig_equalize_taps_batch with caller-supplied flags: a burst the delay kernel refuses (bad length, |TOA| > 4096 or
     NaN) must come back as zeros even when its scratch row still holds an earlier call's burst."""
