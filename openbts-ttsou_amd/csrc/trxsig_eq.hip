@@ -24,6 +24,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 #define EQ_NC 36            /* max correlation lags kept per burst */
 static constexpr int kEqWaveMax = 2048;   // k_eq_estimate_wave: waves launched; a call of at most this many bursts takes it without a list
+// more marked bursts than this: a lane per burst (k_eq_detect) is the faster arrangement again (TRXSIG_EQ_DENSE: the tests force either route)
+static int eq_dense() {                                     // (read at every call: a test switches it between cases)
+  const char *e = std::getenv("TRXSIG_EQ_DENSE");
+  return e ? std::atoi(e) : 4096;
+}
 // A/B: TRXSIG_EQ_DETECT_GENERIC=1 keeps the padded kernel also where the fixed-geometry one applies (maxTOA 4)
 static int eq_detect_generic() {
   static const int v = std::getenv("TRXSIG_EQ_DETECT_GENERIC") ? std::atoi(std::getenv("TRXSIG_EQ_DETECT_GENERIC")) : 0;
@@ -257,7 +262,11 @@ __global__ __launch_bounds__(64) void k_eq_detect(const TrxTables *__restrict__ 
                                                   float *__restrict__ toa_eq, cx *__restrict__ w_out,
                                                   cx *__restrict__ b_out, float snr_thresh, float snr_value,
                                                   float *__restrict__ chan_off_out, cx *__restrict__ chan_out,
-                                                  const uint8_t *__restrict__ enable, const float *__restrict__ snr_in) {
+                                                  const uint8_t *__restrict__ enable, const float *__restrict__ snr_in,
+                                                  const int32_t *__restrict__ dense_gate, int dense_min) {
+  // dense_gate (optional): the number of marked bursts (k_eq_list); this kernel serves the call only when they are MANY
+  // (> dense_min: the wave-per-burst kernel launched before it has then left them alone), else it ends at once.
+  if (dense_gate && *dense_gate <= dense_min) return;
   // enable (optional): only bursts with enable[b] != 0 are processed, nothing is written for the others (the Transceiver
   // group estimates the channel of the few bursts its replay marks, trxsig_group.hip); snr_in (optional): the SNR
   // estimate per burst.  snr_value > 0: the SNR estimate itself (the Transceiver facade forms it on the host in the reference's
@@ -1153,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_eq_estimate_wave(const TrxTables *__res
                                                           cx *__restrict__ b_out, float snr_thresh, float snr_value,
                                                           float *__restrict__ chan_off_out, cx *__restrict__ chan_out,
                                                           const float *__restrict__ snr_in, const int32_t *__restrict__ list,
-                                                          const int32_t *__restrict__ count) {
+                                                          const int32_t *__restrict__ count, int dense_min) {
   constexpr int NL = 36, FRONT = 8, BACK = 8, PADC = 13, W0 = 56, START = 7;   // :951-955, 295-300: NO_DELAY correlation, Lb = 16
   static_assert(START - 15 >= -FRONT && START + NL - 1 < NL + BACK, "every tap of every lag meets a sample or a zero pad");
   __shared__ cx Ws[4][FRONT + NL + BACK];
@@ -1166,6 +1175,7 @@ __global__ __launch_bounds__(256) void k_eq_estimate_wave(const TrxTables *__res
   float *V = Vs[wave];
   const int n_waves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
   const int n = list ? *count : B;
+  if (list && n > dense_min) return;                         // many marked bursts: k_eq_detect, launched next, takes the call
   const cx gain = T->mid_gain[tsc];
   const float mid_toa = T->mid_toa[tsc];
   cx ctap[16];
@@ -1839,7 +1849,7 @@ hipError_t trx_launch_equalize(hipStream_t st, const TrxTables *dT, const void *
                        0.0f, (float *)nullptr, (cx *)nullptr, (const uint8_t *)nullptr, (const float *)nullptr);
   else
     EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, energy_thresh,
-                     variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr, nullptr, nullptr);
+                     variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, -1.0f, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   launch_eq_tail(st, dT, samples, fmt, off, len, B, amp, toa_eq, flags, w, bq, xd, xstride, soft, hard, nsoft, stride, nullptr, prof);
   return hipGetLastError();
@@ -1866,16 +1876,19 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
     const dim3 grid((waves + 3) / 4), block(256);
     if (fmt == TRXSIG_SAMPLES_F16)
       k_eq_estimate_wave<SmpF16><<<grid, block, 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq,
-                                                         snr_thresh, snr_value, chan_off, (cx *)chan, snr_in, list, count);
+                                                         snr_thresh, snr_value, chan_off, (cx *)chan, snr_in, list, count, eq_dense());
     else
       k_eq_estimate_wave<SmpC32><<<grid, block, 0, st>>>(dT, samples, off, len, B, tsc, detect_thresh, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq,
-                                                         snr_thresh, snr_value, chan_off, (cx *)chan, snr_in, list, count);
+                                                         snr_thresh, snr_value, chan_off, (cx *)chan, snr_in, list, count, eq_dense());
+    if (enable && B > eq_dense())                             // the marked bursts may be many (a cell in bad shape: every miss costs the slot its cache)
+      EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m, max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh,
+                       snr_value, chan_off, chan, enable, snr_in, count, eq_dense());
   } else if (geom52 && variant52m && max_toa == 4 && eq_detect_generic() == 0)
     EQ_DETECT52_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, flags, (cx *)amp, toa, toa_eq, (cx *)w, (cx *)bq, snr_thresh,
                        snr_value, chan_off, (cx *)chan, enable, snr_in);
   else
     EQ_DETECT_LAUNCH(dT, samples, off, len, B, tsc, detect_thresh, -1.0f, variant52m,
-                     max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan, enable, snr_in);
+                     max_toa, flags, amp, toa, toa_eq, w, bq, snr_thresh, snr_value, chan_off, chan, enable, snr_in, nullptr, 0);
   if (prof) prof->end(TRXSIG_K_EQUALIZE, st);
   return hipGetLastError();
 }

@@ -157,8 +157,12 @@ def check_against(name, pull, ctype, x, sps, out, arfcns, fn0, tn0, thr_of):
     return seen
 
 
-@pytest.mark.parametrize("sps,leg,frames", [(1, 0, 200), (4, 1, 60)])
-def test_group_equals_single_objects_and_model(pkg, sps, leg, frames):
+@pytest.mark.parametrize("sps,leg,frames,dense", [(1, 0, 200, None), (1, 0, 200, 0), (4, 1, 60, None)])
+def test_group_equals_single_objects_and_model(pkg, sps, leg, frames, dense, monkeypatch):
+    # dense = 0: the equalising leg's channel estimates through the lane-per-burst kernel, the route for calls with MANY marked bursts
+    # (TRXSIG_EQ_DENSE: the number of marked bursts above which it takes over from the wave-per-burst kernel; default 4096)
+    if dense is not None:
+        monkeypatch.setenv("TRXSIG_EQ_DENSE", str(dense))
     S, fn0, tn0 = 128, 1000, 3
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=100 + sps)
