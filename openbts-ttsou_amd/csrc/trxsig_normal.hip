@@ -273,8 +273,16 @@ __global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restric
 //   which the CU's vector cache serves one lane at a time -- 1.4 k cycles per step with few distinct rows, 3 k with
 //   256.)  The valley powers come from registers too (three candidate alignments, selected by rint(toa) - M).
 // ---------------------------------------------------------------------------------------------
+// (round 4: the kernel's first 12.6 k of 22 k cycles per wave were its loads -- 66 per thread, the table's 48 KB once per 128 bursts
+//  among them, profiles/r04_peak_probe.txt.  A workgroup is now 512 threads = 256 bursts round one copy of the table.  Leaving the
+//  valley's loads to the even lane alone -- the odd lane's tail is never stored -- was slower: 17.8 against 14.7 us; the pair's two
+//  lanes ask for the same address, which the load unit merges, and a load under a branch is waited for at the join.)
+#ifndef TRX_PEAK2_THREADS
+#define TRX_PEAK2_THREADS 512
+#endif
+constexpr int kPeak2Threads = TRX_PEAK2_THREADS;
 template <int SPS>
-__global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec, int Bpad,
+__global__ __launch_bounds__(kPeak2Threads) void k_tsc_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec, int Bpad,
                                                    int B, cx gain_inv, float mid_toa, float detect_thresh,
                                                    float energy_thresh, uint8_t *__restrict__ flags,
                                                    cx *__restrict__ amp_out, float *__restrict__ toa_out,
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
   __shared__ __attribute__((aligned(16))) SincLds stab;
   const int tid = threadIdx.x;
   const int h = tid & 1;                                   // 0: early point (and the final one), 1: late point
-  const int b = blockIdx.x * 128 + (tid >> 1);
+  const int b = blockIdx.x * (kPeak2Threads / 2) + (tid >> 1);
   const bool live = b < B;
   const int bb = live ? b : B - 1;
 #ifdef TRX_PEAK_PROBE                                      // tools/peak_probe.py: clock64() stamps come back through avgpwr
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
   TRX_STAMP();
 
   // ---- loads first: this thread's 12 float4 of the table, then its part of the detect->peak record ----
-  float4 tv[12];
-  sinc_lds_issue<256>(T, tid, tv);
+  float4 tv[3072 / kPeak2Threads];
+  sinc_lds_issue<kPeak2Threads>(T, tid, tv);
   const cx meta = rec[(size_t)G::NS * Bpad + bb];
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
@@ -312,13 +320,13 @@ __global__ __launch_bounds__(256) void k_tsc_peak2(const TrxTables *__restrict__
   }
   // corr at M - (5sps+1) + k and M + (2sps-1) + k, k < NP: every lag the valley can touch (|rint(toa) - M| <= 1);
   // in flight with the rest, first needed in the tail
-  cx vlo_[NP], vhi_[NP];
+  cx vlo_[NP], vhi_[NP];                                   // (both lanes of a pair: one address, merged in the load unit)
 #pragma unroll
   for (int k = 0; k < NP; k++) {
     vlo_[k] = rec[(size_t)(G::H - (5 * SPS + 1) + k) * Bpad + bb];
     vhi_[k] = rec[(size_t)(G::H + (2 * SPS - 1) + k) * Bpad + bb];
   }
-  sinc_lds_store<256>(stab, tid, tv);
+  sinc_lds_store<kPeak2Threads>(stab, tid, tv);
   TRX_STAMP();
   __syncthreads();                                         // the only barrier
   TRX_STAMP();
@@ -566,7 +574,7 @@ static void launch_tsc_detect(hipStream_t st, const TrxTables *dT, const TrxTabl
   } else
 #endif
   {
-    k_tsc_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
+    k_tsc_peak2<S><<<dim3((B + kPeak2Threads / 2 - 1) / (kPeak2Threads / 2)), dim3(kPeak2Threads), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh,
                                                                 energy_thresh, flags, amp, toa, avgpwr);
   }
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
@@ -623,7 +631,7 @@ hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTa
   const trx_c32 g = hT->mid_gain[tsc];                     // gain.inv() (Complex.h:154-160), as launch_tsc_detect
   const float n = g.i * g.i + g.r * g.r;
   trx_c32 ginv; ginv.r = g.r / n; ginv.i = -g.i / n;
-  k_tsc_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh,
+  k_tsc_peak2<S><<<dim3((B + kPeak2Threads / 2 - 1) / (kPeak2Threads / 2)), dim3(kPeak2Threads), 0, st>>>(dT, rec, Bpad, B, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh,
                                                               flags, amp, toa, avgpwr);
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
   if (nsoft > 0) {
