@@ -957,8 +957,10 @@ __global__ __launch_bounds__(64 * kRachNW) void k_rach_front_rx(const TrxTables 
 // steps 3-4 with TWO lanes per burst (pair_bisect): peakDetect's bisection on the exact neighbourhood and
 // detectRACHBurst's tail (:875-913) with the approximate valley.  A burst whose threshold lies inside the valley's error
 // bar (rach_decide) goes on the hand-over list instead (k_rach_fast in list mode recomputes its valley exactly).
+// (512 threads = 256 bursts round one LDS copy of the sinc table: see k_tsc_peak2)
+constexpr int kRachPeak2Threads = 512;
 template <int SPS>
-__global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec,
+__global__ __launch_bounds__(kRachPeak2Threads) void k_rach_peak2(const TrxTables *__restrict__ T, const cx *__restrict__ rec,
                                                     const float *__restrict__ vsum, const int32_t *__restrict__ length,
                                                     int Bpad, int B, float detect_thresh, uint8_t *__restrict__ flags,
                                                     cx *__restrict__ amp_out, float *__restrict__ toa_out,
@@ -968,11 +970,11 @@ __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict_
   __shared__ __attribute__((aligned(16))) SincLds stab;
   const int tid = threadIdx.x;
   const int h = tid & 1;
-  const int b = blockIdx.x * 128 + (tid >> 1);
+  const int b = blockIdx.x * (kRachPeak2Threads / 2) + (tid >> 1);
   const bool live = b < B;
   const int bb = live ? b : B - 1;
-  float4 tv[12];
-  sinc_lds_issue<256>(T, tid, tv);
+  float4 tv[3072 / kRachPeak2Threads];
+  sinc_lds_issue<kRachPeak2Threads>(T, tid, tv);
   const cx meta = rec[(size_t)24 * Bpad + bb];
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
@@ -987,7 +989,7 @@ __global__ __launch_bounds__(256) void k_rach_peak2(const TrxTables *__restrict_
 #pragma unroll
   for (int a = 0; a < 3; a++) vs3[a] = vsum[(size_t)a * Bpad + bb];
   const float dlt = vsum[(size_t)3 * Bpad + bb];
-  sinc_lds_store<256>(stab, tid, tv);
+  sinc_lds_store<kRachPeak2Threads>(stab, tid, tv);
   __syncthreads();                                         // the only barrier
 
   int e;
@@ -1097,7 +1099,7 @@ static void launch_rach_fast(hipStream_t st, const TrxTables *dT, const trx_c32 
   k_rach_front<S><<<dim3((B + kRachNW - 1) / kRachNW), dim3(64 * kRachNW), 0, st>>>(dT, samples, off, len, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum,
                                                 Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
-  k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr,
+  k_rach_peak2<S><<<dim3((B + kRachPeak2Threads / 2 - 1) / (kRachPeak2Threads / 2)), dim3(kRachPeak2Threads), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr,
                                                                list, count);
   k_rach_fast<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, samples, off, len, B, detect_thresh, energy_thresh, amp_err, flags,
                                                                amp, toa, avgpwr, list, count);
@@ -1132,7 +1134,7 @@ hipError_t trx_launch_rx_rach(hipStream_t st, const TrxTables *dT, const TrxRxGe
   if (prof) prof->begin(TRXSIG_K_RACH_CORR, st);
   k_rach_front_rx<S><<<dim3((B + kRachNW - 1) / kRachNW), dim3(64 * kRachNW), 0, st>>>(dT, gen, B, energy_thresh, amp_err, flags, amp, toa, avgpwr, rec, vsum, Bpad, count);
   if (prof) { prof->end(TRXSIG_K_RACH_CORR, st); prof->begin(TRXSIG_K_RACH_PEAK, st); }
-  k_rach_peak2<S><<<dim3((B + 127) / 128), dim3(256), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr, list, count);
+  k_rach_peak2<S><<<dim3((B + kRachPeak2Threads / 2 - 1) / (kRachPeak2Threads / 2)), dim3(kRachPeak2Threads), 0, st>>>(dT, rec, vsum, len, Bpad, B, detect_thresh, flags, amp, toa, avgpwr, list, count);
   k_rach_fast_rx<S><<<dim3(B < 512 ? B : 512), dim3(64), 0, st>>>(dT, gen, B, detect_thresh, energy_thresh, amp_err, flags, amp, toa, avgpwr,
                                                                   list, count);
   if (prof) prof->end(TRXSIG_K_RACH_PEAK, st);
