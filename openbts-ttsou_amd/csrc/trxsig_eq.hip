@@ -1740,6 +1740,245 @@ __global__ __launch_bounds__(256) void k_eq_dfe3(const TrxTables *__restrict__ T
 
 #endif  // TRX_TUNING_BUILD
 
+// ---------------------------------------------------------------------------------------------
+// k_eq_dfe4 (round 4): scaleVector + delayVector + equalizeBurst in ONE kernel -- what k_eq_delay and k_eq_dfe2 do through the
+//   160-sample scratch row of every burst (84 MB written, 107 MB read back per 65,536 bursts), with that row never leaving the chip.
+//   k_eq_dfe3 (round 3, tuning library) had the same aim and lost: its sample ring and 16-symbol tiles took 78 KB of LDS, two
+//   workgroups per CU, two generations.  Here the delay waves keep their 28-sample windows in REGISTERS, fed by 16-byte loads of the
+//   lane's own burst (a lane per burst in every wave: no transposition, no ring), and the tiles are EIGHT symbols: 23 KB of LDS,
+//   all 1,024 workgroups of a 65,536-burst call resident at four waves per SIMD (28 KB with the tile buffer in three copies).
+//   64 bursts per workgroup, four waves, lane l of every wave = burst l; time runs in steps of eight symbols:
+//     waves 2, 3  delayVector (:573-616; k_eq_delay's arithmetic: scaleVector(1/amp) on the way in, 21 real taps from the sinc grid or
+//                 the table sinc, j ascending) -- tile u (delayed samples 8 u + 6 .. 8 u + 13) is wave 2 + (u & 1)'s, over steps
+//                 u - 2 and u - 1, four outputs in each; tile -1 (samples 0 .. 5: the first window of the feed-forward filter) too;
+//     wave 1      the feed-forward FIR of tile u in step u (k_eq_dfe2's producer), soft bits of tile u - 2 out (lanes along k);
+//     wave 0      the decision-feedback recursion of tile u - 1 (k_eq_dfe2's consumer).
+//   One workgroup barrier per step, 25 steps.  Same terms in the same order as k_eq_delay + k_eq_dfe2: the same values.
+// ---------------------------------------------------------------------------------------------
+#define EQ4_TK 8
+#define EQ4_NT 20             /* 160 >= 157 symbols */
+template <typename SMP>
+__global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict__ T, const void *__restrict__ samples,
+                                                    const int32_t *__restrict__ offset, const int32_t *__restrict__ length, int B,
+                                                    const cx *__restrict__ amp_in, const float *__restrict__ toa_eq,
+                                                    const uint8_t *__restrict__ flags, const cx *__restrict__ w_in,
+                                                    const cx *__restrict__ b_in, const int32_t *__restrict__ tap_ix,
+                                                    float *__restrict__ soft, uint8_t *__restrict__ hard, int nsoft, int stride) {
+  constexpr int TK = EQ4_TK, NT = EQ4_NT, S0 = -3, S1 = NT + 1;   // steps S0 .. S1
+  __shared__ cx xt[3][64][TK + 1];                          // delay waves -> feed-forward wave (tile u in xt[u mod 3]: written over steps u - 2, u - 1, read in step u)
+  __shared__ cx fft[2][64][TK + 1];                         // feed-forward wave -> consumer
+  __shared__ float sft[2][64][TK + 1];                      // consumer -> feed-forward wave (soft bits on their way out)
+  __shared__ __attribute__((aligned(8))) float tapl[2][64][22];   // a delay wave's 21 taps per lane (registers are what the delay waves are short of)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int b0 = blockIdx.x * 64;
+  const int b = b0 + lane;
+  const int bb = b < B ? b : B - 1;
+  const int N = length[bb];
+  const float te = toa_eq[bb];
+  const bool det = b < B && eq_enabled(flags[bb], N, te);  // k_eq_dfe2's gate
+  if (wave >= 2) {
+    // ---- delayVector: this wave's tiles u = d - 2, d, d + 2, ... (d = wave - 2; wave 3 starts with tile -1) ----
+    const int d = wave - 2;
+    const int off = offset[bb];
+    const int Nd = (det && off >= 0) ? N : 0;              // k_eq_delay's gate: a refused burst is a row of zeros
+    const long long base = Nd > 0 ? (long long)off : 0;
+    const v2f inv = pk(cdiv(mk(1.0f, 0.0f), amp_in[bb]));  // ((complex)1.0)/amp (Transceiver.cpp:391)
+    const float delay = det ? -te : 0.0f;                  // (a burst that is not equalised may carry any TOA: see k_eq_dfe3)
+    const int io = (int)floorf(delay);
+    const float frac = delay - (float)io;
+    const bool filt = fabs((double)frac) > 1e-2;
+    v2f *const tl = reinterpret_cast<v2f *>(tapl[d][lane]);   // taps 2 q, 2 q + 1 at tl[q]
+    {
+      const float f512 = frac * 512.0f;
+      const int f = (int)f512;
+      const bool grid = f < 512 && (float)f == f512;       // (frac can round to exactly 1.0 for a tiny negative delay: off the grid)
+      const float4 *row = reinterpret_cast<const float4 *>(T->sinc_grid[f & 511]);
+      float g[24];
+#pragma unroll
+      for (int q = 0; q < 6; q++) { const float4 r4 = row[q]; g[4 * q] = r4.x; g[4 * q + 1] = r4.y; g[4 * q + 2] = r4.z; g[4 * q + 3] = r4.w; }
+      if (__any(!grid)) {                                  // off the grid (never after peakDetect): sinc(pi*((j - 10) - frac)) (:588)
+#pragma unroll
+        for (int j = 0; j < 21; j++) {
+          const float tj = dev_sinc(T->sinT, TRX_PI_F * ((float)(j - 10) - frac));
+          g[j] = grid ? g[j] : tj;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 11; q++) { v2f t2; t2.x = g[2 * q]; t2.y = g[2 * q + 1]; tl[q] = t2; }
+    }
+    wave_lds_fence();
+    // The window: a RING of 32 scaled samples in registers, sample n at w[(n - n0) & 31] (n0 = the first own tile's first sample).  Own
+    // tile number k (u = u_first + 2 k) reads samples n0 + 16 k .. n0 + 16 k + 27 -- tap j of output c meets ring entry
+    // (16 k + c + 20 - j) & 31, a compile-time index once k's parity is one (the loop below runs two own tiles per round) -- and the
+    // sixteen samples the next own tile adds replace the sixteen this one read first.  No entry is ever moved.
+    v2f w[32];
+    constexpr int PER = 16 / (16 / SMP::kBytes);           // 16-byte loads that bring sixteen samples (4 at fp16, 8 at complex float)
+    constexpr int SPL = 16 / SMP::kBytes;                  // samples per load
+    struct __attribute__((packed, aligned(4))) Piece { typename SMP::raw_t q[SPL]; };
+    // sixteen samples n .. n + 15 in two moves: the loads (into rv, as stored) are issued a step before they are needed ...
+    typename SMP::raw_t rv[16];
+    bool rv_inside = false;                                // (wave-uniform) every lane's sixteen lie inside its burst: no masks when they are taken
+    auto issue16 = [&](int n) {
+      const bool inside = n >= 0 && n + 15 < Nd;
+      rv_inside = __all(inside || Nd == 0);
+      if (rv_inside) {                                     // (a refused burst reads burst 0's samples: its outputs are zeros whatever they are)
+        Piece pc[PER];
+        const long long a0 = base + (Nd > 0 ? n : 0);
+#pragma unroll
+        for (int q = 0; q < PER; q++) pc[q] = *reinterpret_cast<const Piece *>(reinterpret_cast<const typename SMP::raw_t *>(samples) + (a0 + SPL * q));
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+#pragma unroll
+          for (int e = 0; e < SPL; e++) rv[SPL * q + e] = pc[q].q[e];
+        }
+      } else {                                              // a burst's edge in some lane: sample by sample, index clamped
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int nn = n + k;
+          const int nc = nn < 0 ? 0 : (nn >= Nd ? (Nd > 0 ? Nd - 1 : 0) : nn);
+          rv[k] = SMP::ldraw(samples, base + nc);
+        }
+      }
+    };
+    // ... and scaled into ring entries R0 .. R0 + 15 (zeros outside [0, Nd)) once the entries' old samples have been read
+    auto take16 = [&](int n, auto r0_) {
+      constexpr int R0 = decltype(r0_)::value;
+      if (rv_inside) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[R0 + k] = pk_cmul(pk(SMP::widen(rv[k])), inv);   // scaleVector (:713-723)
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int nn = n + k;
+          const v2f sc = pk_cmul(pk(SMP::widen(rv[k])), inv);
+          w[R0 + k] = (nn >= 0 && nn < Nd) ? sc : pk(mk(0, 0));
+        }
+      }
+    };
+    const int u_first = d == 1 ? -1 : 0;
+    const int n_own = d == 1 ? (NT + 1) / 2 + 1 : NT / 2;  // own tiles: -1, 1, .., NT - 1 / 0, 2, .., NT - 2
+    const int n0 = TK * u_first + 6 - io - 10;
+    issue16(n0); take16(n0, std::integral_constant<int, 0>());
+    issue16(n0 + 16); take16(n0 + 16, std::integral_constant<int, 16>());
+    // outputs C0 .. C0 + NC - 1 of own tile u (ring phase PH) into its tile buffer.  (Five in the tile's first step, three in its second, which
+    // also takes the next samples in: the two delay waves are in opposite halves of their tiles, and the longer half sets the workgroup's step.)
+    constexpr int NC1 = 5;
+    auto outputs = [&](int u, auto ph_, auto c0_, auto nc_) {
+      constexpr int PH = decltype(ph_)::value, C0 = decltype(c0_)::value, NC = decltype(nc_)::value;
+      const int m0 = TK * u + 6;
+      cx *row = xt[((u % 3) + 3) % 3][lane];
+      v2f acc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; c++) acc[c] = pk(mk(0, 0));
+#pragma unroll
+      for (int q = 0; q < 11; q++) {                       // convolve(..., NO_DELAY), j ascending (:590): the outputs side by side, tap pair by tap pair
+        const v2f tq = tl[q];
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = pk_cadd(acc[c], pk_mul_tap<0>(w[(PH + C0 + c + 20 - 2 * q) & 31], tq));
+        if (2 * q + 1 <= 20) {
+#pragma unroll
+          for (int c = 0; c < NC; c++) acc[c] = pk_cadd(acc[c], pk_mul_tap<1>(w[(PH + C0 + c + 19 - 2 * q) & 31], tq));
+        }
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (the tap reads four pairs at a time: all eleven up front cost the registers they were moved to LDS for)
+      }
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const int m = m0 + C0 + c, t = m - io;
+        const v2f r = filt ? acc[c] : w[(PH + C0 + c + 10) & 31];
+        row[C0 + c] = (t >= 0 && t < Nd && m < Nd) ? unpk(r) : mk(0, 0);   // shifted[m] inside [0, N), else 0 (:597-613); the row holds zeros from N on
+      }
+    };
+    // one own tile = two steps.  k: its number; the samples of own tile k + 1 beyond this one's: n0 + 16 k + 32 .. + 47, into the ring's half
+    // this tile read first
+    auto own_tile = [&](int k, auto ph_) {
+      constexpr int PH = decltype(ph_)::value;
+      const int u = u_first + 2 * k;
+      outputs(u, ph_, std::integral_constant<int, 0>(), std::integral_constant<int, NC1>());
+      const bool more = k + 1 < n_own;
+      if (more) issue16(n0 + 16 * k + 32);                 // (after the sums: sixteen more live registers they have no room for) a step to land
+      __syncthreads();
+      outputs(u, ph_, std::integral_constant<int, NC1>(), std::integral_constant<int, TK - NC1>());
+      if (more) take16(n0 + 16 * k + 32, std::integral_constant<int, PH>());
+      __syncthreads();
+    };
+    constexpr int STEPS = S1 - S0 + 1;
+    const int lead = d == 1 ? 0 : 1;                       // wave 3's tile -1 starts in step S0, wave 2's tile 0 a step later
+    for (int i = 0; i < lead; i++) __syncthreads();
+    for (int k = 0; k < n_own; k += 2) {
+      own_tile(k, std::integral_constant<int, 0>());
+      if (k + 1 < n_own) own_tile(k + 1, std::integral_constant<int, 16>());
+    }
+    for (int i = lead + 2 * n_own; i < STEPS; i++) __syncthreads();
+  } else if (wave == 1) {
+    // ---- the feed-forward FIR (k_eq_dfe2's producer) and the soft bits' way out ----
+    const size_t tb = (tap_ix && det) ? (size_t)tap_ix[bb] : (tap_ix ? (size_t)0 : (size_t)bb);
+    v2f wf[7], win[6];
+#pragma unroll
+    for (int j = 0; j < 7; j++) wf[j] = pk(w_in[tb * 7 + j]);
+#pragma unroll
+    for (int m = 0; m < 6; m++) win[m] = pk(mk(0, 0));
+    const int kc = lane & (TK - 1), r0 = lane / TK;          // tile traffic: this lane moves column kc of rows r0 + (64 / TK) i
+    auto write_out = [&](int u) {                           // soft tile u, lanes along k
+#pragma unroll
+      for (int i = 0; i < TK; i++) {
+        const int r = r0 + (64 / TK) * i, k = TK * u + kc, rb = b0 + r;
+        if (rb < B && k < nsoft) {
+          const float sv = sft[u & 1][r][kc];
+          soft[(size_t)rb * stride + k] = sv;
+          if (hard) hard[(size_t)rb * stride + k] = sv > 0.5F;
+        }
+      }
+    };
+    for (int s = S0; s <= S1; s++) {
+      const int u = s;
+      if (u >= -1 && u <= NT - 1) {
+        v2f xa[TK];
+#pragma unroll
+        for (int i = 0; i < TK; i++) xa[i] = pk(xt[((u % 3) + 3) % 3][lane][i]);
+        if (u >= 0) {
+#pragma unroll
+          for (int i = 0; i < TK; i++) {
+            v2f dsum = pk(mk(0, 0));
+#pragma unroll
+            for (int j = 0; j < 7; j++) {                   // convolve general branch: sum += a[t-j]*b[j], t = k+6 (zero samples beyond the burst: see k_eq_dfe2)
+              const v2f xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
+              dsum = pk_cadd(dsum, pk_cmul(xv, wf[j]));
+            }
+            fft[u & 1][lane][i] = unpk(dsum);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 6; m++) win[m] = xa[TK - 1 - m];  // delayed samples 8 u + 13 - m: the next tile's x[k + 6 - j], j > i
+      }
+      if (s - 2 >= 0 && s - 2 <= NT - 1) write_out(s - 2);
+      __syncthreads();
+    }
+  } else {
+    // ---- the decision-feedback recursion (k_eq_dfe2's consumer) ----
+    const int nout = det ? (nsoft < N ? nsoft : N) : 0;     // symbols this burst really produces (zeros beyond)
+    const size_t tb = (tap_ix && det) ? (size_t)tap_ix[bb] : (tap_ix ? (size_t)0 : (size_t)bb);
+    v2f bq[5], hist[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { bq[j] = pk(b_in[tb * 5 + j]); hist[j] = pk(mk(0, 0)); }
+    for (int s = S0; s <= S1; s++) {
+      const int u = s - 1;
+      if (u >= 0 && u <= NT - 1) {
+        cx ffv[TK], rv[TK], rt[TK];
+#pragma unroll
+        for (int i = 0; i < TK; i++) {
+          ffv[i] = fft[u & 1][lane][i];
+          rv[i] = T->rev[TK * u + i];                       // (rev/rot hold 157 * 4 entries: in range for k < 160)
+          rt[i] = T->rot[TK * u + i];
+        }
+#pragma unroll
+        for (int i = 0; i < TK; i++) sft[u & 1][lane][i] = dfe_step(TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // TRXSIG_EQ_DFE_VARIANT=1 (environment, A/B): the lane-per-burst k_eq_dfe instead of the producer/consumer k_eq_dfe2
 void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
                    const float *toa_eq, const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride,
@@ -1786,6 +2025,11 @@ static int eq_dfe_variant() {
   return v;
 }
 #endif
+// TRXSIG_EQ_TAIL=2 (environment, A/B and the tests): k_eq_delay + k_eq_dfe2 through the scratch rows instead of the fused k_eq_dfe4
+static bool eq_tail_fused() {
+  const char *e = std::getenv("TRXSIG_EQ_TAIL");
+  return !(e && std::atoi(e) == 2);
+}
 static void launch_eq_tail(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off, const int32_t *len, int B,
                            const trx_c32 *amp, const float *toa_eq, const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd,
                            int xstride, float *soft, uint8_t *hard, int nsoft, int stride, const int32_t *tap_ix, TrxProfiler *prof) {
@@ -1799,6 +2043,14 @@ static void launch_eq_tail(hipStream_t st, const TrxTables *dT, const void *samp
     return;
   }
 #endif
+  if (eq_tail_fused()) {                                    // one kernel: the delayed burst stays on the chip
+    if (prof) prof->begin(TRXSIG_K_EQ_DFE, st);
+    const dim3 g((B + 63) / 64), blk(256);
+    if (fmt == TRXSIG_SAMPLES_F16) k_eq_dfe4<SmpF16><<<g, blk, 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags, w, bq, tap_ix, soft, hard, nsoft, stride);
+    else k_eq_dfe4<SmpC32><<<g, blk, 0, st>>>(dT, samples, off, len, B, amp, toa_eq, flags, w, bq, tap_ix, soft, hard, nsoft, stride);
+    if (prof) prof->end(TRXSIG_K_EQ_DFE, st);
+    return;
+  }
   if (prof) prof->begin(TRXSIG_K_EQ_DELAY, st);
   EQ_DELAY_LAUNCH(dT, samples, off, len, B, amp, toa_eq, flags, TRXSIG_F_DETECT, xd, xstride);
   if (prof) { prof->end(TRXSIG_K_EQ_DELAY, st); prof->begin(TRXSIG_K_EQ_DFE, st); }
