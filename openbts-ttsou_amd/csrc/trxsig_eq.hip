@@ -1756,6 +1756,9 @@ __global__ __launch_bounds__(256) void k_eq_dfe3(const TrxTables *__restrict__ T
 //   One workgroup barrier per step, 25 steps.  Same terms in the same order as k_eq_delay + k_eq_dfe2: the same values.
 // ---------------------------------------------------------------------------------------------
 #define EQ4_TK 8
+#ifndef TRX_D4_EXP
+#define TRX_D4_EXP 0          /* 1, 2, 3: timing experiments (wrong results): the delay / feed-forward / recursion role with most of its arithmetic left out */
+#endif
 #define EQ4_NT 20             /* 160 >= 157 symbols */
 template <typename SMP>
 __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict__ T, const void *__restrict__ samples,
@@ -1770,7 +1773,9 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
   __shared__ float sft[2][64][TK + 1];                      // consumer -> feed-forward wave (soft bits on their way out)
   __shared__ __attribute__((aligned(8))) float tapl[2][64][22];   // a delay wave's 21 taps per lane (registers are what the delay waves are short of)
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // (the roles rotate from workgroup to workgroup: a SIMD then hosts one wave of each role instead of four of a kind, and what it has to
+  //  issue per step is the roles' average, not the heaviest role's)
+  const int wave = __builtin_amdgcn_readfirstlane((((int)threadIdx.x >> 6) + (int)blockIdx.x) & 3);
   const int b0 = blockIdx.x * 64;
   const int b = b0 + lane;
   const int bb = b < B ? b : B - 1;
@@ -1872,7 +1877,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
 #pragma unroll
       for (int c = 0; c < NC; c++) acc[c] = pk(mk(0, 0));
 #pragma unroll
-      for (int q = 0; q < 11; q++) {                       // convolve(..., NO_DELAY), j ascending (:590): the outputs side by side, tap pair by tap pair
+      for (int q = 0; q < (TRX_D4_EXP == 1 ? 1 : 11); q++) {   // convolve(..., NO_DELAY), j ascending (:590): the outputs side by side, tap pair by tap pair
         const v2f tq = tl[q];
 #pragma unroll
         for (int c = 0; c < NC; c++) acc[c] = pk_cadd(acc[c], pk_mul_tap<0>(w[(PH + C0 + c + 20 - 2 * q) & 31], tq));
@@ -1941,7 +1946,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
           for (int i = 0; i < TK; i++) {
             v2f dsum = pk(mk(0, 0));
 #pragma unroll
-            for (int j = 0; j < 7; j++) {                   // convolve general branch: sum += a[t-j]*b[j], t = k+6 (zero samples beyond the burst: see k_eq_dfe2)
+            for (int j = 0; j < (TRX_D4_EXP == 2 ? 1 : 7); j++) {   // convolve general branch: sum += a[t-j]*b[j], t = k+6 (zero samples beyond the burst: see k_eq_dfe2)
               const v2f xv = (i - j >= 0) ? xa[(i - j >= 0) ? i - j : 0] : win[(j - i - 1 < 6) ? j - i - 1 : 5];
               dsum = pk_cadd(dsum, pk_cmul(xv, wf[j]));
             }
@@ -1972,7 +1977,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
           rt[i] = T->rot[TK * u + i];
         }
 #pragma unroll
-        for (int i = 0; i < TK; i++) sft[u & 1][lane][i] = dfe_step(TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
+        for (int i = 0; i < (TRX_D4_EXP == 3 ? 1 : TK); i++) sft[u & 1][lane][i] = dfe_step(TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
       }
       __syncthreads();
     }

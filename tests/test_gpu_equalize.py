@@ -76,8 +76,12 @@ def test_golden_dfe_52m(pkg, t1, golden):
             assert_veq(r["soft"][j, :n - 1 if n == 157 else n][:156], g["soft"][i, :156][:n], "DFE soft %d" % i)
 
 
-@pytest.mark.parametrize("variant52m", [True, False])
-def test_random_dfe_vs_oracle(pkg, t1, variant52m):
+@pytest.mark.parametrize("variant52m,tail", [(True, None), (False, None), (True, "2")])
+def test_random_dfe_vs_oracle(pkg, t1, variant52m, tail, monkeypatch):
+    # tail "2": scaleVector + delayVector + equalizeBurst as two kernels through the scratch rows (k_eq_delay + k_eq_dfe2) instead of the fused
+    # k_eq_dfe4 (TRXSIG_EQ_TAIL, read at every call)
+    if tail:
+        monkeypatch.setenv("TRXSIG_EQ_TAIL", tail)
     rng = np.random.default_rng(99 + variant52m)
     o = oraclebind.Oracle(1, variant52m=variant52m)
     from openbts_ttsou_amd import synth
