@@ -1775,7 +1775,8 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
   const int lane = threadIdx.x & 63;
   // (the roles rotate from workgroup to workgroup: a SIMD then hosts one wave of each role instead of four of a kind, and what it has to
   //  issue per step is the roles' average, not the heaviest role's)
-  const int wave = __builtin_amdgcn_readfirstlane((((int)threadIdx.x >> 6) + (int)blockIdx.x) & 3);
+  // (workgroups 256 apart tend to share a CU -- the dispatcher deals them out round-robin over 8 XCDs x 32 CUs --: those get different rotations)
+  const int wave = __builtin_amdgcn_readfirstlane((((int)threadIdx.x >> 6) + ((int)blockIdx.x >> 8) + (int)blockIdx.x) & 3);
   const int b0 = blockIdx.x * 64;
   const int b = b0 + lane;
   const int bb = b < B ? b : B - 1;
