@@ -293,7 +293,9 @@ class Config4:
         if self.group:
             self.beside_kernels = ("k_group_replay",)      # the state machine: a latency chain of a few workgroups, not priced against HBM
             self.kernel_names.update({"k_rach_corr": "k_rach_front_rx", "k_rach_peak": "k_rach_peak2+k_rach_fast_rx(list)"} if self.fused else
-                                     {"k_rach_corr": "k_rach_front", "k_rach_peak": "k_rach_peak2+k_rach_fast(list)", "k_eq_dfe": "k_eq_dfe2"})
+                                     {"k_rach_corr": "k_rach_front", "k_rach_peak": "k_rach_peak2+k_rach_fast(list)",
+                                      "k_eq_dfe": "k_eq_dfe2" if os.environ.get("TRXSIG_EQ_TAIL") == "2" else "k_eq_dfe4",
+                                      "k_eq_detect": "k_eq_list+k_eq_estimate_wave"})
             self.kernel_alg.update({"k_rach_corr": 4 * 236 + 8 * 25 + 16 + 17, "k_rach_peak": 8 * 25 + 16 + 17, "k_group_replay": 16 + 4 + 1 + 8})
         if self.fused:
             self.kernel_names.update({"k_demod": "k_demod_rx", "k_tsc_corr": "k_tsc_corr_rx"})

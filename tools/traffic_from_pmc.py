@@ -9,12 +9,12 @@ P = os.path.join(ROOT, "profiles")
 WANT = [("normal", "k_demod<4", "k_demod", 65536, {}), ("normal", "k_tsc_corr<4", "k_tsc_corr", 65536, {}),
         ("normal", "k_tsc_peak2<4", "k_tsc_peak2", 65536, {}), ("normal", "k_tsc_peak2<4", "k_tsc_peak", 65536, {}),
         ("rach", "k_rach_front<4", "k_rach_front", 65536, {}), ("rach", "k_rach_peak2<4", "k_rach_peak2", 65536, {}),
-        ("config5", "k_eq_delay<", "k_eq_delay", 65536, {}), ("config5", "k_eq_detect52<", "k_eq_detect", 65536, {"kernel": "k_eq_detect52"}),
-        ("config5", "k_eq_dfe2", "k_eq_dfe2", 65536, {}),
+        ("config5", "k_eq_detect52<", "k_eq_detect", 65536, {"kernel": "k_eq_detect52"}),
+        ("config5", "k_eq_dfe4<", "k_eq_dfe4", 65536, {}),
         ("config4", "k_demod_rx<4", "k_demod_rx", 59904, {}), ("config4", "k_tsc_corr_rx<4", "k_tsc_corr_rx", 59904, {}),
         ("config4", "k_rach_front_rx<4", "k_rach_front_rx", 59904, {"note": "per step of the group bench (the access-burst rows only: ~500 bursts)"}),
         ("config4", "k_group_replay_seg", "k_group_replay", 59904, {"kernel": "k_group_replay_seg<16>", "note": "per step: 128 ARFCNs x 468 slots"}),
-        ("config5", "k_eq_dfe2", "k_eq_dfe", 65536, {"kernel": "k_eq_dfe2"}),
+        ("config5", "k_eq_dfe4<", "k_eq_dfe", 65536, {"kernel": "k_eq_dfe4"}),
         ("config4_unfused", "k_rx_resample", "k_rx_resample", 128 * 125, {"note": "units = stream-chunks (128 streams x 125 chunks per launch)"}),
         ("config4_unfused", "k_rx_resample", "k_resample", 128 * 125, {"kernel": "k_rx_resample", "note": "units = stream-chunks (128 streams x 125 chunks per launch)"})]
 
