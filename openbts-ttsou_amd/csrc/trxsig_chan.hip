@@ -14,6 +14,8 @@
 // one and the default); checked against it at 1e-4 of the signal's scale with identical hard bits (tests/test_gpu_channeliser.py).
 // Because the form is approximate by construction its multiply-adds may fuse (explicit v_fma_f32 with the marker comment
 // "approx-form", counted apart by tools/asm_stats.py); the twiddles are exact cos / sin (double, rounded once).
+// With four carriers or more the sixteen sums sum_j conj(m_c[j]) T_j are taken from ONE 16-point FFT of T (they are bins k_c of its
+// DFT: theta_c = 2 pi k_c / 16) -- ~190 operations for all sixteen bins where the direct form spends 64 per carrier.
 #include "trxsig_dev.h"
 
 namespace {
@@ -29,13 +31,44 @@ __device__ __forceinline__ float fma_as(float a, float b_sgpr, float c) {   // a
   return r;
 }
 
+// X[k] = sum_j a[j] exp(-2 pi i j k / 16), k = 0..15, in place; X[k] is left in a[bitrev4(k)] (decimation in frequency, radix 2)
+__device__ __forceinline__ cx tw16(cx x, int m) {            // x * exp(-2 pi i m / 16), m a compile-time constant after unrolling
+  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
+  switch (m & 15) {
+    case 0: return x;
+    case 1: return mk(x.r * c1 + x.i * s1, x.i * c1 - x.r * s1);
+    case 2: return mk((x.r + x.i) * r, (x.i - x.r) * r);
+    case 3: return mk(x.r * s1 + x.i * c1, x.i * s1 - x.r * c1);
+    case 4: return mk(x.i, -x.r);
+    case 5: return mk(x.i * c1 - x.r * s1, -(x.r * c1 + x.i * s1));
+    case 6: return mk((x.i - x.r) * r, -((x.r + x.i) * r));
+    case 7: return mk(x.i * s1 - x.r * c1, -(x.r * s1 + x.i * c1));
+    default: return tw16(mk(-x.r, -x.i), m - 8);
+  }
+}
+template <int SPAN>
+__device__ __forceinline__ void fft16_stage(cx (&a)[16]) {    // (a template per stage: every index a compile-time constant, the array stays in registers)
+#pragma unroll
+  for (int o = 0; o < 16; o += 2 * SPAN) {
+#pragma unroll
+    for (int i = 0; i < SPAN; i++) {
+      const cx u = a[o + i], v = a[o + i + SPAN];
+      a[o + i] = mk(u.r + v.r, u.i + v.i);
+      a[o + i + SPAN] = tw16(mk(u.r - v.r, u.i - v.i), i * (8 / SPAN));
+    }
+  }
+}
+__device__ __forceinline__ void fft16(cx (&a)[16]) {
+  fft16_stage<8>(a); fft16_stage<4>(a); fft16_stage<2>(a); fft16_stage<1>(a);
+}
+
 constexpr int kTile = 256;                                   // outputs per workgroup (one per thread, every carrier)
 constexpr int kTapPitch = 33;                                // 32 taps per branch + 1 (odd pitch)
 
 // grid (tiles, windows, wideband streams).  tw: [C][16] = conj(m_c[j]) = exp(-j theta_c j).
 // LDS: X[xcap] the tile's span of the window as complex float (zeros outside the window), TP[(P/g) x 33] the taps by branch.
 template <int C>
-__global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const float2 *__restrict__ tw, int xcap, int kt) {
+__global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const float2 *__restrict__ tw, int xcap, int kt, unsigned long long binmap) {
   extern __shared__ __attribute__((aligned(16))) char ch_lds[];
   cx *X = reinterpret_cast<cx *>(ch_lds);
   float *TP = reinterpret_cast<float *>(ch_lds + sizeof(cx) * (size_t)xcap);
@@ -83,6 +116,35 @@ __global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const f
   }
   const int rho = inOff & 15;                               // the window starts on a multiple of 16 raw samples (the host checks)
   cx *out = reinterpret_cast<cx *>(a.out) + (size_t)w * a.out_win_step + (o - a.o_skip);
+  if constexpr (C >= 4) {
+    // binmap: four bits per carrier, k_c.  Bin by bin (a compile-time register), the carriers that sit on it (a uniform test)
+    // binmap: four bits per carrier, k_c (no two carriers on one bin: the caller checks).  Bin by bin -- a compile-time register --: is there
+    // a carrier on it (sixteen uniform tests), which one (its index only enters addresses)
+    fft16(T);
+    unsigned occupied = 0;
+    unsigned long long who = 0;                              // four bits per bin: the carrier on it
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      const unsigned kc = (unsigned)((binmap >> (4 * c)) & 15ull);
+      occupied |= 1u << kc;
+      who |= (unsigned long long)c << (4 * kc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {                          // T[i] = X[k], k = bitrev4(i)
+      constexpr int dummy = 0; (void)dummy;
+      const int k = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+      if ((occupied >> k) & 1u) {
+        const int c = (int)((who >> (4 * k)) & 15ull);
+        const cx acc = T[i];
+        const float2 m = tw[c * 16 + rho];                  // conj(m_c[rho]); y = m_c[rho] * acc
+        cx y;
+        y.r = fma_af(acc.r, m.x, acc.i * m.y);
+        y.i = fma_af(acc.i, m.x, -(acc.r * m.y));
+        out[(size_t)(s * C + c) * a.out_stride] = y;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < C; c++) {
     cx acc = mk(0, 0);
@@ -106,7 +168,8 @@ __global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const f
 
 // tw: device table [C][16] of exp(-j theta_c j).  Requirements (checked by the caller, trxsig_frontend.cpp): int16 input, window
 // start and length multiples of 16 raw samples, at most 32 taps per output, C in {1, 2, 4, 8, 16}.
-hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide, int C, int n_windows, const float2 *tw, TrxProfiler *prof) {
+hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide, int C, int n_windows, const float2 *tw, TrxProfiler *prof,
+                                   unsigned long long binmap) {
   if (S_wide <= 0 || n_windows <= 0 || a.n_out <= a.o_skip) return hipSuccess;
   const int kt = (a.L + a.P - 1) / a.P;
   if (kt > 32 || S_wide > 65535 || n_windows > 65535) return hipErrorInvalidValue;
@@ -119,11 +182,11 @@ hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide
   const dim3 grid((a.n_out - a.o_skip + kTile - 1) / kTile, n_windows, S_wide), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
   switch (C) {
-    case 1: k_channelise16<1><<<grid, block, lds, st>>>(a, tw, xcap, kt); break;
-    case 2: k_channelise16<2><<<grid, block, lds, st>>>(a, tw, xcap, kt); break;
-    case 4: k_channelise16<4><<<grid, block, lds, st>>>(a, tw, xcap, kt); break;
-    case 8: k_channelise16<8><<<grid, block, lds, st>>>(a, tw, xcap, kt); break;
-    case 16: k_channelise16<16><<<grid, block, lds, st>>>(a, tw, xcap, kt); break;
+    case 1: k_channelise16<1><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
+    case 2: k_channelise16<2><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
+    case 4: k_channelise16<4><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
+    case 8: k_channelise16<8><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
+    case 16: k_channelise16<16><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
     default: if (prof) prof->end(TRXSIG_K_RESAMPLE, st); return hipErrorInvalidValue;
   }
   if (prof) prof->end(TRXSIG_K_RESAMPLE, st);

@@ -51,6 +51,7 @@ struct trxsig_rxfe {
   std::vector<float> h_freq;                                // the carrier frequencies as given (trxsig_rxfe_set_shared_filter checks their grid)
   int shared = 0;                                           // 1: the shared-filter form (trxsig_chan.hip)
   float2 *d_tw = nullptr;                                   // [C][16] exp(-j theta_c j)
+  unsigned long long binmap = 0;                            // four bits per carrier: k_c, theta_c = 2 pi k_c / 16
   long long n_total = 0;                                    // raw samples (per wideband stream) received so far, offset by the history
 };
 
@@ -197,7 +198,7 @@ int trxsig_rxfe_push_wideband(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks
   a.o_skip = fe->skip; a.n_out = fe->n_out;
   a.out = fe->d_rcv + fe->wr; a.out_stride = fe->stride; a.out_win_step = fe->per_chunk;
   a.mix_freq = fe->d_freq; a.mix_carriers = fe->C; a.mix_n0 = fe->n_total; a.mix_tables = (const TrxTables *)trxsig_tables_device(c);
-  if (fe->shared) FE_HIP(c, trx_launch_channelise16(st, a, fe->Sw, fe->C, n_chunks, fe->d_tw, trx_ctx_profiler(c)));
+  if (fe->shared) FE_HIP(c, trx_launch_channelise16(st, a, fe->Sw, fe->C, n_chunks, fe->d_tw, trx_ctx_profiler(c), fe->binmap));
   else FE_HIP(c, trx_launch_resample_ex(st, a, fe->S, n_chunks, true, false, trx_ctx_profiler(c)));
   const short2 *tail = reinterpret_cast<const short2 *>(d_iq) + ((size_t)n_chunks * chunk - hist);
   FE_HIP(c, hipMemcpy2DAsync(fe->d_hist, sizeof(short2) * (size_t)hist, tail, sizeof(short2) * (size_t)n_chunks * chunk,
@@ -219,11 +220,17 @@ int trxsig_rxfe_set_shared_filter(trxsig_rxfe *fe, int on) {
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: needs at most 32 taps per output and chunks of a multiple of 16 samples", hipSuccess);
   // every carrier on the grid of sixteenths of the wideband rate: theta_c = 2 pi k_c / 16 (to float accuracy)
   std::vector<float2> tw((size_t)C * 16);
+  unsigned long long binmap = 0;
   for (int k = 0; k < C; k++) {
     const double bins = (double)fe->h_freq[(size_t)k] / (2.0 * M_PI / 16.0);
     const double kb = std::nearbyint(bins);
     if (std::fabs(bins - kb) > 1e-5)
       return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: a carrier frequency is not a multiple of 2 pi / 16 rad per sample", hipSuccess);
+    const unsigned long long bin = (unsigned long long)((((long long)kb % 16) + 16) % 16);
+    for (int q = 0; q < k; q++)
+      if (((binmap >> (4 * q)) & 15ull) == bin)
+        return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_set_shared_filter: two carriers on one sixteenth of the wideband rate", hipSuccess);
+    binmap |= bin << (4 * k);
     for (int j = 0; j < 16; j++) {
       const double ph = 2.0 * M_PI * std::fmod(kb * j, 16.0) / 16.0;
       tw[(size_t)k * 16 + j] = make_float2((float)std::cos(ph), (float)-std::sin(ph));   // exp(-j theta_c j)
@@ -233,6 +240,7 @@ int trxsig_rxfe_set_shared_filter(trxsig_rxfe *fe, int on) {
   if (!fe->d_tw && hipMalloc((void **)&fe->d_tw, sizeof(float2) * tw.size()) != hipSuccess)
     return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_set_shared_filter: device allocation failed", hipSuccess);
   FE_HIP(c, hipMemcpy(fe->d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+  fe->binmap = binmap;
   fe->shared = 1;
   return TRXSIG_OK;
 }

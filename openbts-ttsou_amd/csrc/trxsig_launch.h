@@ -130,7 +130,9 @@ struct TrxResampleArgs {
 hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int n_windows, bool in_i16, bool out_i16,
                                   TrxProfiler *prof, bool in_bits = false);
 // the channeliser's shared-filter form (trxsig_chan.hip): C carriers on a grid of sixteenths of the wideband rate in one pass
-hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide, int C, int n_windows, const float2 *tw, TrxProfiler *prof);
+// binmap: four bits per carrier c, its bin k_c (theta_c = 2 pi k_c / 16): with four carriers or more the kernel takes the bins from one FFT
+hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide, int C, int n_windows, const float2 *tw, TrxProfiler *prof,
+                                   unsigned long long binmap);
 hipError_t trx_launch_tx_ring_store(hipStream_t st, const uint8_t *bits, const float *gain, int S, int nb, int head, int cap, uint8_t *ring,
                                     float *gring);
 hipError_t trx_launch_burst_index(hipStream_t st, int S, int nb, long long stride, int rd, int tn0, int sps, int32_t *off,
