@@ -16,6 +16,7 @@
 // "approx-form", counted apart by tools/asm_stats.py); the twiddles are exact cos / sin (double, rounded once).
 // With four carriers or more the sixteen sums sum_j conj(m_c[j]) T_j are taken from ONE 16-point FFT of T (they are bins k_c of its
 // DFT: theta_c = 2 pi k_c / 16) -- ~190 operations for all sixteen bins where the direct form spends 64 per carrier.
+#include <cstdlib>
 #include "trxsig_dev.h"
 
 namespace {
@@ -68,49 +69,89 @@ constexpr int kTapPitch = 33;                                // 32 taps per bran
 // grid (tiles, windows, wideband streams).  tw: [C][16] = conj(m_c[j]) = exp(-j theta_c j).
 // LDS: X[xcap] the tile's span of the window as complex float (zeros outside the window), TP[(P/g) x 33] the taps by branch.
 template <int C>
-__global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const float2 *__restrict__ tw, int xcap, int kt, unsigned long long binmap) {
+__global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const float2 *__restrict__ tw, int xcap, int kt, unsigned long long binmap, int tpw) {
   extern __shared__ __attribute__((aligned(16))) char ch_lds[];
-  cx *X = reinterpret_cast<cx *>(ch_lds);
-  float *TP = reinterpret_cast<float *>(ch_lds + sizeof(cx) * (size_t)xcap);
+  // the window as received (int16 pairs: a wave's 4-byte reads are one LDS pass, its 8-byte reads of converted samples were two to four;
+  // the conversion is exact either way), the taps' rows in the order the outputs visit the branches (see k_rx_resample, trxsig_tx.hip)
+  short2 *X = reinterpret_cast<short2 *>(ch_lds);
+  float *TP = reinterpret_cast<float *>(ch_lds + ((sizeof(short2) * (size_t)xcap + 15) & ~(size_t)15));
   const int w = blockIdx.y, s = blockIdx.z;
   const int D = (a.L - 1) / 2 / a.Q;                        // sigProcLib.cpp:1177
   const int g = a.tap_g, nbr = a.P / g;
-  for (int e = threadIdx.x; e < nbr * 32; e += 256) {
-    const int bi = e >> 5, k = e & 31, fi = bi * g + a.P * k;
-    TP[bi * kTapPitch + k] = (k < kt && fi < a.L) ? a.lpf[fi] : 0.0f;   // (the reference's walk ends at the filter's end: zero taps)
-  }
-  const int o0 = a.o_skip + blockIdx.x * kTile;
-  const long long oq_first = (long long)(o0 + D) * a.Q;
-  const int lo = (int)(oq_first / a.P) - 31;                // first window sample any tap of this tile can meet
-  {
-    const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
-    const short2 *hist = a.hist + (size_t)s * a.hist_len;
-    const int base = w * a.win_step - a.hist_len;           // raw index of the window's sample 0
-    for (int i = threadIdx.x; i < xcap; i += 256) {
-      const int idx = lo + i;
-      cx v = mk(0, 0);
-      if (idx >= 0 && idx < a.n) {                           // outside: "skip the tap" (:1183-1186, :1196) = a zero sample
-        const int r = base + idx;
-        const short2 q = r < 0 ? hist[a.hist_len + r] : raw[r];
-        v = a.swap ? mk((float)q.y, (float)q.x) : mk((float)q.x, (float)q.y);   // unUSRPifyVector (radioInterface.cpp:108-109)
+  // the rotation factors conj(m_c[rho]) too: rho differs from lane to lane, and a global load per carrier and output, each waited for
+  // before its product, was where the kernel spent three quarters of its time (SQ_WAIT_ANY 74 %)
+  float2 *TWS = reinterpret_cast<float2 *>(TP + (((size_t)nbr * kTapPitch + 1) & ~(size_t)1));
+  for (int e = threadIdx.x; e < C * 16; e += 256) TWS[e] = tw[e];
+  // (every load below is unconditional, its index clamped and the value selected afterwards: a load under a branch whose value is used
+  //  inside the branch is waited for before the next one is issued -- four trips to L2 in a row per tile, eight for the taps)
+  for (int e0 = 0; e0 < nbr * 32; e0 += 256 * 4) {
+    float tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + 256 * u + (int)threadIdx.x, bi = e >> 5, k = e & 31, fi = bi * g + a.P * k;
+      tv[u] = a.lpf[fi < a.L ? fi : a.L - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + 256 * u + (int)threadIdx.x, bi = e >> 5, k = e & 31, fi = bi * g + a.P * k;
+      if (e < nbr * 32) {
+        const int row = a.row_inv ? (int)(((unsigned)bi * (unsigned)a.row_inv) % (unsigned)nbr) : bi;
+        TP[row * kTapPitch + k] = (k < kt && fi < a.L) ? tv[u] : 0.0f;   // (the reference's walk ends at the filter's end: zero taps)
       }
-      X[i] = v;
     }
   }
-  __syncthreads();
+  // A workgroup serves `tpw` consecutive tiles with ONE staging of the taps, and the next tile's raw samples are loaded (into registers)
+  // before the current tile is filtered: a one-tile workgroup lived for two trips to L2 and a few hundred instructions, and the kernel
+  // was bound by how fast such workgroups can be turned over (167 us for 28 us' worth of instructions).
+  constexpr int NQ = 4;                                     // NQ * 256 >= xcap (the launcher checks)
+  const short2 *raw = reinterpret_cast<const short2 *>(a.in) + (size_t)s * a.in_stride;
+  const short2 *hist = a.hist + (size_t)s * a.hist_len;
+  const int base = w * a.win_step - a.hist_len;             // raw index of the window's sample 0
+  const int n_tiles = (a.n_out - a.o_skip + kTile - 1) / kTile;
+  const int t0 = blockIdx.x * tpw, t1 = t0 + tpw < n_tiles ? t0 + tpw : n_tiles;
+  auto tile_lo = [&](int t) {                               // first window sample any tap of tile t can meet
+    const long long oq_first = (long long)(a.o_skip + t * kTile + D) * a.Q;
+    return (int)(oq_first / a.P) - 31;
+  };
+  short2 v[NQ];
+  auto fetch = [&](int t) {
+    const int lo = tile_lo(t);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int i = (int)threadIdx.x + 256 * q, idx = lo + i;
+      const bool in = i < xcap && idx >= 0 && idx < a.n;     // outside: "skip the tap" (:1183-1186, :1196) = a zero sample
+      const int r = base + (in ? idx : 0);
+      const short2 *p = r < 0 ? hist + (a.hist_len + r) : raw + r;
+      const short2 qv = *p;                                 // (base + 0 is a valid sample of the stream or its history)
+      v[q] = in ? qv : make_short2(0, 0);
+    }
+  };
+  fetch(t0);
+  for (int t = t0; t < t1; t++) {
+  const int o0 = a.o_skip + t * kTile;
+  const int lo = tile_lo(t);
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int i = (int)threadIdx.x + 256 * q;
+    if (i < xcap) X[i] = a.swap ? make_short2(v[q].y, v[q].x) : v[q];   // unUSRPifyVector's order (radioInterface.cpp:108-109); its int16 -> float on the way out
+  }
+  lds_barrier();                                            // (X and, the first time, the taps: LDS only -- see lds_barrier)
+  if (t + 1 < t1) fetch(t + 1);
   const int o = o0 + (int)threadIdx.x;
-  if (o >= a.n_out) return;
+  if (o < a.n_out) {
   const long long oq = (long long)(o + D) * a.Q;
   const int branch = (int)(oq % a.P), inOff = (int)(oq / a.P);
-  const float *tp = TP + (branch / g) * kTapPitch;
-  const cx *xs = X + (inOff - lo);                          // xs[-k] = window sample inOff - k
+  const int bi = branch / g;
+  const float *tp = TP + (a.row_inv ? (int)(((unsigned)bi * (unsigned)a.row_inv) % (unsigned)nbr) : bi) * kTapPitch;
+  const short2 *xs = X + (inOff - lo);                      // xs[-k] = window sample inOff - k
   cx T[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) T[j] = mk(0, 0);
 #pragma unroll
   for (int k = 0; k < 32; k++) {                            // taps past the filter's end are zeros
     const float h = tp[k];
-    const cx x = xs[-k];
+    const short2 xq = xs[-k];
+    const cx x = mk((float)xq.x, (float)xq.y);
     T[k & 15].r = fma_af(h, x.r, T[k & 15].r);
     T[k & 15].i = fma_af(h, x.i, T[k & 15].i);
   }
@@ -136,15 +177,14 @@ __global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const f
       if ((occupied >> k) & 1u) {
         const int c = (int)((who >> (4 * k)) & 15ull);
         const cx acc = T[i];
-        const float2 m = tw[c * 16 + rho];                  // conj(m_c[rho]); y = m_c[rho] * acc
+        const float2 m = TWS[c * 16 + rho];                  // conj(m_c[rho]); y = m_c[rho] * acc
         cx y;
         y.r = fma_af(acc.r, m.x, acc.i * m.y);
         y.i = fma_af(acc.i, m.x, -(acc.r * m.y));
         out[(size_t)(s * C + c) * a.out_stride] = y;
       }
     }
-    return;
-  }
+  } else {
 #pragma unroll
   for (int c = 0; c < C; c++) {
     cx acc = mk(0, 0);
@@ -156,12 +196,16 @@ __global__ __launch_bounds__(256) void k_channelise16(TrxResampleArgs a, const f
       acc.i = fma_as(T[j].i, t.x, acc.i);
       acc.i = fma_as(T[j].r, t.y, acc.i);
     }
-    const float2 m = tw[c * 16 + rho];                      // conj(m_c[rho]); y = m_c[rho] * acc
+    const float2 m = TWS[c * 16 + rho];                      // conj(m_c[rho]); y = m_c[rho] * acc
     cx y;
     y.r = fma_af(acc.r, m.x, acc.i * m.y);
     y.i = fma_af(acc.i, m.x, -(acc.r * m.y));
     out[(size_t)(s * C + c) * a.out_stride] = y;
   }
+  }
+  }                                                         // (o < n_out)
+  lds_barrier();                                            // every thread is done with X before the next tile lands (its stores may still be in flight)
+  }                                                         // (tiles)
 }
 
 }  // namespace
@@ -177,16 +221,28 @@ hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide
   while (r) { const int t = g % r; g = r; r = t; }          // gcd(P, Q): only branches that are multiples of it occur
   a.tap_g = g;
   const int xcap = (int)(((long long)(kTile - 1) * a.Q) / a.P + 32 + 4);
-  const size_t lds = sizeof(trx_c32) * (size_t)xcap + sizeof(float) * (size_t)(a.P / g) * kTapPitch;
+  const size_t lds = ((sizeof(short2) * (size_t)xcap + 15) & ~(size_t)15) + sizeof(float) * ((((size_t)(a.P / g) * kTapPitch) + 1) & ~(size_t)1) +
+                     sizeof(float2) * 16 * (size_t)C;
+  a.row_inv = 0;                                            // ((Q mod P) / g)^-1 mod P / g: the rows of the tap table in visiting order
+  {
+    const int nbr = a.P / g, st1 = (a.Q % a.P) / g;
+    for (int v = 1; v < nbr; v++)
+      if (((long long)v * st1) % nbr == 1) { a.row_inv = v; break; }
+  }
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const dim3 grid((a.n_out - a.o_skip + kTile - 1) / kTile, n_windows, S_wide), block(256);
+  if (xcap > 4 * 256) return hipErrorInvalidValue;
+  const int n_tiles = (a.n_out - a.o_skip + kTile - 1) / kTile;
+  int tpw = 1;                                              // tiles per workgroup: as many as leave the machine several workgroups per CU
+  while (tpw < 8 && tpw * 2 <= n_tiles && (long long)S_wide * n_windows * (n_tiles / (tpw * 2)) >= 4096) tpw *= 2;
+  if (const char *e = std::getenv("TRXSIG_CHAN_TPW")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) tpw = v; }
+  const dim3 grid((n_tiles + tpw - 1) / tpw, n_windows, S_wide), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
   switch (C) {
-    case 1: k_channelise16<1><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
-    case 2: k_channelise16<2><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
-    case 4: k_channelise16<4><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
-    case 8: k_channelise16<8><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
-    case 16: k_channelise16<16><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap); break;
+    case 1: k_channelise16<1><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap, tpw); break;
+    case 2: k_channelise16<2><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap, tpw); break;
+    case 4: k_channelise16<4><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap, tpw); break;
+    case 8: k_channelise16<8><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap, tpw); break;
+    case 16: k_channelise16<16><<<grid, block, lds, st>>>(a, tw, xcap, kt, binmap, tpw); break;
     default: if (prof) prof->end(TRXSIG_K_RESAMPLE, st); return hipErrorInvalidValue;
   }
   if (prof) prof->end(TRXSIG_K_RESAMPLE, st);

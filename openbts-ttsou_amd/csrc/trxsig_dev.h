@@ -214,6 +214,12 @@ __device__ __forceinline__ float row_shl(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
 }
 
+// A workgroup barrier for data that travels through LDS only.  __syncthreads() is a barrier AND a fence over every address space:
+// the compiler puts s_waitcnt vmcnt(0) in front of it, so a wave that has just issued global stores (results on their way out) sits
+// there until they have landed -- microseconds, at every step of a pipelined kernel.  Here only the LDS traffic is waited for.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from
   // reordering them across the point where lanes start reading what other lanes wrote.
