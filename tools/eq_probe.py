@@ -1,5 +1,7 @@
-"""Where does k_eq_detect's time go?  Needs trxsig_eq.hip built with -DTRX_EQ_PROBE (clock64() stamps of the detected
-bursts come back through toa):  TRXSIG_LIB=.../libtrxsig_eqprobe.so python tools/eq_probe.py"""
+"""Where does k_eq_detect52's (k_eq_detect's) time go?  Needs trxsig_eq.hip built with -DTRX_EQ_PROBE (clock64() stamps of the detected
+bursts come back through toa):
+    make -C openbts-ttsou_amd/csrc probe_eq EQP=1 && TRXSIG_LIB=openbts-ttsou_amd/csrc/build_probe/libtrxsig_eqprobe1.so python tools/eq_probe.py
+(EQP=2: the staging block in detail -- rows then read: offsets here / loads issued / landed + parked / read back / end of kernel)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
