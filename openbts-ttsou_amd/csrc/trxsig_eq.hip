@@ -708,6 +708,9 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
   TRX_STAMP();
 #endif
   const int off = live ? offset[b] : 0, N = live ? length[b] : 0;
+  // (loaded here, with the offsets: a load issued behind the result stores further down would make the wave wait for those stores to land --
+  //  the counter of outstanding memory operations does not tell loads from stores -- before designDFE could start)
+  const float snr_pre = (snr_in && live) ? snr_in[b] : 0.0f;
   uint8_t fl = 0;
   cx amp = mk(0, 0);
   float toa = 0.0f;
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(256) void k_eq_detect52(const TrxTables *__restrict
   TRX_STAMP();                                             // 4: tail, delayVector, channel pick
   // ---- Transceiver.cpp:341-347: SNR, scaleVector(chan, 1/amp), designDFE(chan, SNR, 7) ----
   const float thr = snr_thresh >= 0.0f ? snr_thresh : (energy_thresh < 0.0f ? 0.0f : energy_thresh);
-  const float snr = snr_in ? snr_in[b] : (snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0)));
+  const float snr = snr_in ? snr_pre : (snr_value > 0.0f ? snr_value : (float)((double)norm2(amp) / ((double)(thr * thr) + 1.0)));
   const cx ainv = cdiv(mk(1.0f, 0.0f), amp);
 #pragma unroll
   for (int k = 0; k < 6; k++) chan[k] = cmul(chan[k], ainv);
