@@ -320,12 +320,11 @@ __global__ __launch_bounds__(kPeak2Threads) void k_tsc_peak2(const TrxTables *__
   }
   // corr at M - (5sps+1) + k and M + (2sps-1) + k, k < NP: every lag the valley can touch (|rint(toa) - M| <= 1);
   // in flight with the rest, first needed in the tail
-  cx vlo_[NP], vhi_[NP];                                   // (both lanes of a pair: one address, merged in the load unit)
+  // (the pair shares them: the even lane loads the side below the peak, the odd lane the side above -- one unconditional load each, the
+  //  slot chosen by the lane's parity -- and the powers cross over by DPP when the tail wants them)
+  cx vmine_[NP];
 #pragma unroll
-  for (int k = 0; k < NP; k++) {
-    vlo_[k] = rec[(size_t)(G::H - (5 * SPS + 1) + k) * Bpad + bb];
-    vhi_[k] = rec[(size_t)(G::H + (2 * SPS - 1) + k) * Bpad + bb];
-  }
+  for (int k = 0; k < NP; k++) vmine_[k] = rec[(size_t)((h ? G::H + (2 * SPS - 1) : G::H - (5 * SPS + 1)) + k) * Bpad + bb];
   sinc_lds_store<kPeak2Threads>(stab, tid, tv);
   TRX_STAMP();
   __syncthreads();                                         // the only barrier
@@ -349,7 +348,11 @@ __global__ __launch_bounds__(kPeak2Threads) void k_tsc_peak2(const TrxTables *__
     // changes nothing; numRms is counted arithmetically.
     float plo[NP], phi[NP];
 #pragma unroll
-    for (int k = 0; k < NP; k++) { plo[k] = norm2(vlo_[k]); phi[k] = norm2(vhi_[k]); }
+    for (int k = 0; k < NP; k++) {
+      const float mine = norm2(vmine_[k]);
+      const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+      plo[k] = h ? other : mine; phi[k] = h ? mine : other;
+    }
     float valley = 0.0f;
 #pragma unroll
     for (int i = 2 * SPS; i <= 5 * SPS; i++) {
