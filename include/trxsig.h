@@ -163,6 +163,23 @@ int trxsig_demodulate_batch(trxsig_ctx *ctx,
                             const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
                             float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
 
+/* trxsig_set_soft_mode: how demodulateBurst's soft bits (sigProcLib.cpp:1056-1097) are computed behind the three calls above
+ *   (and behind the Transceiver group's demodulating leg on a complex float32 stream).  Flags, amplitude, TOA and avgPwr are the
+ *   reference's values bit for bit in either mode, and so is every HARD bit (SoftVector::bit, soft > 0.5F).
+ *   TRXSIG_SOFT_EXACT (the default): every soft bit equals the reference's float32 value (IEEE ==): scaleVector, delayVector's
+ *     21 taps, the reverse rotation and the slicer operation by operation, in the reference's order.
+ *   TRXSIG_SOFT_TOLERANCE: the accuracy the reference's users are promised elsewhere ("within 1e-4 on soft symbols") spent on
+ *     speed -- 1/amp is applied to the 148 outputs instead of the 625 samples and the delay filter accumulates with fused
+ *     multiply-adds (csrc/trxsig_demod.h, fused_demod_tol: ~200 instead of ~530 VALU instructions per burst).  Guaranteed
+ *     |soft - reference soft| <= 7.4e-5 on the [0, 1] scale of a soft bit (derivation there; measured <= 1.5e-6); a burst for
+ *     which the guarantee cannot be given (a soft symbol too close to the slicer's 0.5 for the hard bit to be certain, a NaN or
+ *     infinity anywhere, max|sample| * |1/amp| > 8, a TOA off peakDetect's 1/512 grid, an odd burst geometry) is computed by
+ *     the exact code inside the same launch and comes out IEEE-equal.  nsoft > 148 always takes the exact code.
+ *   Takes effect from the next call on (host-side switch, no synchronisation). */
+enum { TRXSIG_SOFT_EXACT = 0, TRXSIG_SOFT_TOLERANCE = 1 };
+int trxsig_set_soft_mode(trxsig_ctx *ctx, int mode);
+int trxsig_get_soft_mode(const trxsig_ctx *ctx);
+
 /* ---- TX path: modulateBurst (sigProcLib.h:171-174) as called by Transceiver::addRadioVector
  *   (Transceiver.cpp:100-113): bits -> GMSK-rotated impulses -> pulse shaping, then scaleVector by
  *   a real gain.  d_bits: B x 148 bytes (only bit 0 is used, BitVector.cpp:54-63); d_guard[b] =

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRXSIG_LIB", os.path.join(_HERE, "libtrxsig.so"))   # TRXSIG_LIB: tuning builds
 
 F_ENERGY, F_DETECT, F_BADLEN = 1, 2, 128
+SOFT_EXACT, SOFT_TOLERANCE = 0, 1                # trxsig_set_soft_mode
 ABI_VERSION = 2                                  # TRXSIG_ABI_VERSION of include/trxsig.h
 
 
@@ -149,6 +150,8 @@ def _load(path):
         L.trxsig_kernel_name.argtypes = [i32]; L.trxsig_kernel_name.restype = C.c_char_p
         L.trxsig_profile_enable.argtypes = [vp, i32]
         L.trxsig_set_tuning.argtypes = [vp, i32, i32]
+        L.trxsig_set_soft_mode.argtypes = [vp, i32]
+        L.trxsig_get_soft_mode.argtypes = [vp]
         L.trxsig_profile_collect.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
         L.trxsig_profile_collect_n.argtypes = [vp, i32, C.POINTER(f32), C.POINTER(i32)]
         L.trxsig_kernel_count.restype = i32
@@ -515,6 +518,14 @@ class TrxSig:
             self._chk(self.L.trxsig_set_tuning(self.h, 0, int(normal_path)), "trxsig_set_tuning")
         if rach_path is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 1, int(rach_path)), "trxsig_set_tuning")
+
+    def set_soft_mode(self, mode):
+        """SOFT_EXACT (default: soft bits IEEE-equal to the reference's) or SOFT_TOLERANCE (hard bits, flags, amp, TOA exact;
+        soft bits within 7.4e-5 of the reference's -- trxsig_set_soft_mode)."""
+        self._chk(self.L.trxsig_set_soft_mode(self.h, int(mode)), "trxsig_set_soft_mode")
+
+    def soft_mode(self):
+        return int(self.L.trxsig_get_soft_mode(self.h))
 
     def profile_enable(self, on=True):
         self._chk(self.L.trxsig_profile_enable(self.h, int(on)), "trxsig_profile_enable")

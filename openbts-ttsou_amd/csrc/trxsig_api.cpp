@@ -76,6 +76,7 @@ struct trxsig_ctx {
   int children = 0;                  // front ends, back ends and groups living on this context (trx_ctx_retain / _release)
   bool zombie = false;               // trxsig_destroy came while some were alive: the last one to go destroys the context
   int demod_beside = 0;
+  int soft_mode = 0;                 // trxsig_set_soft_mode: TRXSIG_SOFT_EXACT (0) / TRXSIG_SOFT_TOLERANCE (1), demodulateBurst's arithmetic
   int det_cus = 0;                   // TRXSIG_TUNE_BESIDE_DET_CUS: > 0 = the detectors on their own stream masked to that many CUs, the
                                      // demodulator's side stream masked to the others (hipExtStreamCreateWithCUMask); 0 = no masks
   int cu_layout = 0;                 // TRXSIG_TUNE_CU_LAYOUT: which bits of the mask the two sets take (see cu_mask())
@@ -500,7 +501,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
     HIPCHK(c, trx_launch_normal_chain(c->stream, c->sps, c->d_tables, c->h_tables, (const trx_c32 *)d_samples, d_offset,
                                       d_length, B, tsc, detect_thresh, energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa,
                                       d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->d_det, c->d_chain_status,
-                                      c->chain_lag, c->chain_spin, c->generic_taps, c->prof, c->chain_dbg));
+                                      c->chain_lag, c->chain_spin, c->generic_taps, c->prof, c->chain_dbg, c->soft_mode));
     return TRXSIG_OK;
   }
 #endif
@@ -515,7 +516,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
     if (nsoft > 0)
       HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                  (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
-                                 soft_stride, c->prof));
+                                 soft_stride, c->prof, c->soft_mode));
     return TRXSIG_OK;
   }
   if (c->variant >= 1 && c->variant <= 3 && nsoft <= 148) {
@@ -523,7 +524,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
     HIPCHK(c, trx_launch_normal_fused(c->stream, c->sps, c->variant == 1 ? 64 : (c->variant == 2 ? 32 : 16), c->d_tables, c->h_tables,
                                       (const trx_c32 *)d_samples, d_offset, d_length, B, tsc, detect_thresh,
                                       energy_thresh, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft,
-                                      soft_stride, c->generic_taps, c->prof));
+                                      soft_stride, c->generic_taps, c->prof, c->soft_mode));
     return TRXSIG_OK;
   }
 #endif
@@ -559,7 +560,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
     if (c->det) c->det_in_flight = true;
     if (c->beside_nodeps < 2) HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pk[k], 0));
     HIPCHK(c, trx_launch_demod(c->side, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B, c->pb_amp[k], c->pb_toa[k],
-                               c->pb_flags[k], TRXSIG_F_DETECT, d_soft, d_hard, nsoft, soft_stride, c->prof));
+                               c->pb_flags[k], TRXSIG_F_DETECT, d_soft, d_hard, nsoft, soft_stride, c->prof, c->soft_mode));
     HIPCHK(c, hipEventRecord(c->ev_dm[k], c->side));
     c->dm_in_flight[k] = true;
     return TRXSIG_OK;
@@ -567,7 +568,7 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
-                               soft_stride, c->prof));
+                               soft_stride, c->prof, c->soft_mode));
   return TRXSIG_OK;
 }
 
@@ -625,7 +626,7 @@ int trx_ctx_demod_masked(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32
   if (B == 0 || nsoft == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
-                             (const trx_c32 *)d_amp, d_toa, d_enable, need_mask, d_soft, nullptr, nsoft, soft_stride, c->prof));
+                             (const trx_c32 *)d_amp, d_toa, d_enable, need_mask, d_soft, nullptr, nsoft, soft_stride, c->prof, c->soft_mode));
   return TRXSIG_OK;
 }
 extern "C" {
@@ -653,7 +654,7 @@ int trxsig_detect_demod_rach_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, c
   if (nsoft > 0)
     HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
                                (const trx_c32 *)d_amp, d_toa, d_flags, TRXSIG_F_DETECT, d_soft, d_hard, nsoft,
-                               soft_stride, c->prof));
+                               soft_stride, c->prof, c->soft_mode));
   return TRXSIG_OK;
 }
 
@@ -668,7 +669,7 @@ int trxsig_demodulate_batch(trxsig_ctx *c, const trxsig_c32 *d_samples, const in
   if (B == 0 || nsoft == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_demod(c->stream, c->sps, c->d_tables, (const trx_c32 *)d_samples, d_offset, d_length, B,
-                             (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride, c->prof));
+                             (const trx_c32 *)d_amp, d_toa, d_enable, 0, d_soft, d_hard, nsoft, soft_stride, c->prof, c->soft_mode));
   return TRXSIG_OK;
 }
 
@@ -1253,6 +1254,14 @@ int trxsig_tuning_build(void) {
   return 0;
 #endif
 }
+
+int trxsig_set_soft_mode(trxsig_ctx *c, int mode) {
+  if (!c) return TRXSIG_EINVAL;
+  if (mode != TRXSIG_SOFT_EXACT && mode != TRXSIG_SOFT_TOLERANCE) return fail(c, TRXSIG_EINVAL, "trxsig_set_soft_mode: unknown mode");
+  c->soft_mode = mode;                                      // (read at the next launch: stream-ordered like every other call)
+  return TRXSIG_OK;
+}
+int trxsig_get_soft_mode(const trxsig_ctx *c) { return c ? c->soft_mode : TRXSIG_EINVAL; }
 
 int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (!c) return TRXSIG_EINVAL;

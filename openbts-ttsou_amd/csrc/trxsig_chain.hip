@@ -74,7 +74,7 @@ struct ChainGeom {
   static constexpr int LDS_B = ((Q_B > D_B ? Q_B : D_B) + 15) & ~15;
 };
 
-template <int SPS, unsigned TAPCLS>
+template <int SPS, unsigned TAPCLS, bool TOL = false>
 __global__ __launch_bounds__(256, TRX_CHAIN_WPS) void k_normal_chain(
     const TrxTables *__restrict__ T, const cx *__restrict__ samples, const int32_t *__restrict__ offset,
     const int32_t *__restrict__ length, int B, TapArg taps, cx gain_inv, float mid_toa, float detect_thresh,
@@ -269,8 +269,10 @@ __global__ __launch_bounds__(256, TRX_CHAIN_WPS) void k_normal_chain(
       for (int m = ln; m < nsoft; m += 64) { sb[m] = 0.0f; if (hb) hb[m] = 0; }
     } else {
       const bool wide = (off & 1) == 0;
-      if (wide && (N & 1) == 0) fused_demod<SPS, 64>(T, P, v, N, amp, toa, ln, sb, hb, nsoft, [] {}, nullptr, nullptr);
-      else demod_core<SPS, false, 148>(T, P, samples, off, N, wide, v, amp, toa, ln, sb, hb, nullptr, nsoft);
+      if (wide && (N & 1) == 0) {
+        if (!(TOL && fused_demod_tol<SPS>(T, P, v, N, amp, toa, ln, sb, hb, nsoft)))   // (TOL: TRXSIG_SOFT_TOLERANCE)
+          fused_demod<SPS, 64>(T, P, v, N, amp, toa, ln, sb, hb, nsoft, [] {}, nullptr, nullptr);
+      } else demod_core<SPS, false, 148>(T, P, samples, off, N, wide, v, amp, toa, ln, sb, hb, nullptr, nsoft);
       wave_lds_fence();                                    // staging reads done before the next burst overwrites it
     }
 #pragma unroll
@@ -287,7 +289,7 @@ template <int S>
 static void launch_chain(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples, const int32_t *off,
                          const int32_t *len, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *flags,
                          trx_c32 *amp, float *toa, float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
-                         void *det, unsigned *status, int lag, unsigned spin_limit, int generic_taps, int dbg) {
+                         void *det, unsigned *status, int lag, unsigned spin_limit, int generic_taps, int dbg, int tol) {
   TapArg ta;
   for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
   // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
@@ -299,7 +301,11 @@ static void launch_chain(hipStream_t st, const TrxTables *dT, const TrxTables *h
   const dim3 grid(8 * (TRX_CHAIN_NDW + 1) * LT), block(256);
 #define TRX_CHAIN_ARGS dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, \
                        avgpwr, soft, hard, nsoft, stride, (u32x4 *)det, status, LT, Lg, spin_limit, dbg
-  if (!generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value)
+  if (tol && !generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value)
+    k_normal_chain<S, TapPattern<S>::value, true><<<grid, block, 0, st>>>(TRX_CHAIN_ARGS);
+  else if (tol)
+    k_normal_chain<S, TRX_TAPS_GENERIC, true><<<grid, block, 0, st>>>(TRX_CHAIN_ARGS);
+  else if (!generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value)
     k_normal_chain<S, TapPattern<S>::value><<<grid, block, 0, st>>>(TRX_CHAIN_ARGS);
   else
     k_normal_chain<S, TRX_TAPS_GENERIC><<<grid, block, 0, st>>>(TRX_CHAIN_ARGS);
@@ -310,14 +316,14 @@ hipError_t trx_launch_normal_chain(hipStream_t st, int sps, const TrxTables *dT,
                                    const int32_t *off, const int32_t *len, int B, int tsc, float detect_thresh,
                                    float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, float *soft,
                                    uint8_t *hard, int nsoft, int stride, void *det, unsigned *status, int lag,
-                                   unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg) {
+                                   unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg, int soft_tolerance) {
   if (B <= 0) return hipSuccess;
   if (nsoft <= 0 || nsoft > 148 || !det || !status) return hipErrorInvalidValue;
   if (prof) prof->begin(TRXSIG_K_NORMAL_CHAIN, st);
   switch (sps) {
-    case 1: launch_chain<1>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft, hard, nsoft, stride, det, status, lag, spin_limit, generic_taps, dbg); break;
-    case 2: launch_chain<2>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft, hard, nsoft, stride, det, status, lag, spin_limit, generic_taps, dbg); break;
-    case 4: launch_chain<4>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft, hard, nsoft, stride, det, status, lag, spin_limit, generic_taps, dbg); break;
+    case 1: launch_chain<1>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft, hard, nsoft, stride, det, status, lag, spin_limit, generic_taps, dbg, soft_tolerance); break;
+    case 2: launch_chain<2>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft, hard, nsoft, stride, det, status, lag, spin_limit, generic_taps, dbg, soft_tolerance); break;
+    case 4: launch_chain<4>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, avgpwr, soft, hard, nsoft, stride, det, status, lag, spin_limit, generic_taps, dbg, soft_tolerance); break;
     default: return hipErrorInvalidValue;
   }
   if (prof) prof->end(TRXSIG_K_NORMAL_CHAIN, st);

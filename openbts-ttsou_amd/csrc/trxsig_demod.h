@@ -312,7 +312,189 @@ __device__ __forceinline__ void fused_demod(const TrxTables *__restrict__ T, cx 
 }
 
 
-template <int SPS, bool RAW, int NSMAX, typename SMP = SmpC32>
+// ---------------------------------------------------------------------------------------------
+// The TOLERANCE-MODE demodulator (trxsig_set_soft_mode(ctx, TRXSIG_SOFT_TOLERANCE); the default stays the value-exact one).
+// north_star grants "1e-4 relative on soft symbols, bit-exact on hard-decision bits"; detection, amplitude and TOA stay the
+// reference's values bit for bit (they come in from k_tsc_peak2), only the arithmetic BEHIND them is rearranged:
+//   * the samples are staged as they are -- scaleVector's 625 complex products (sigProcLib.cpp:713-723) go; 1/amp is folded
+//     into the reverse rotation and applied to the 148 outputs: re = Re((rev[m] * inv) * Y), Y = sum_j tap[j] * x[...];
+//   * the 21-tap delay filter (:584-590) accumulates with fused multiply-adds (one rounding per term instead of two);
+//   * the slicer (:513-515) is one fma.
+// ≈200 instead of ≈530 VALU instructions per burst.  Both forms round the same real number R = Re(rev * inv * sum tap * x)
+// (same float32 inv, same taps, same samples):
+//   reference order:  |re  - R| <= 26.2 u (|c|+|d|) S Z        u = 2^-24, (c,d) = rev[m], S = sum_j |tap[j]| <= 4 (every row of
+//   this form:        |re' - R| <= 25.0 u (|c|+|d|) S Z        the sinc grid: tests/test_soft_tolerance.py), Z = max|x|_inf * (|inv.r|+|inv.i|)
+// (scaleVector 2u per component, 22 u for the 21 rounded products and 21 rounded sums, 2u + propagation for the rotation; fma chain 21 u,
+// the folded factor 2u, the last product-difference 2u), so |re - re'| <= 51.2 * 1.5 * 4 u Z < 308 u Z, and a soft bit (re + 1) / 2
+// moves by at most 154 u Z + u = 9.2e-6 Z.  The fast form is only taken when Z <= 8 (and everything is far from the float
+// range's ends), i.e. GUARANTEED |soft' - soft| <= 7.4e-5 on the [0, 1] scale; measured: <= 1.5e-6 (profiles/r05_parity_campaign.txt).
+// HARD BITS ARE EXACT: a burst with a valid output whose |re'| is not above 512 u Z + 2^-22 (where the two forms could fall on
+// different sides of the slicer's 0.5), or with a NaN anywhere (the test is written so that NaN fails it), or off the 1/512
+// TOA grid, or with an odd geometry, is redone by the value-exact code in the same wave (the samples are still in registers):
+// no list, no second launch.  Returns true when the burst's outputs have been stored.
+// ---------------------------------------------------------------------------------------------
+// (one asm statement per staged word: both components of every output it feeds; the marker is what tools/asm_stats.py and
+//  tests/test_no_fma_contraction.py look for.  t*: wave-uniform taps in SGPRs -- at most one distinct SGPR per instruction.)
+__device__ __forceinline__ void fma_tol_1(cx &y0, float t0, cx x) {
+  asm("v_fma_f32 %0, %2, %4, %0 ; soft-tolerance\n\tv_fma_f32 %1, %3, %4, %1 ; soft-tolerance"
+      : "+v"(y0.r), "+v"(y0.i) : "v"(x.r), "v"(x.i), "s"(t0));
+}
+__device__ __forceinline__ void fma_tol_2(cx &y0, float t0, cx &y1, float t1, cx x) {
+  asm("v_fma_f32 %0, %4, %6, %0 ; soft-tolerance\n\tv_fma_f32 %1, %5, %6, %1 ; soft-tolerance\n\t"
+      "v_fma_f32 %2, %4, %7, %2 ; soft-tolerance\n\tv_fma_f32 %3, %5, %7, %3 ; soft-tolerance"
+      : "+v"(y0.r), "+v"(y0.i), "+v"(y1.r), "+v"(y1.i) : "v"(x.r), "v"(x.i), "s"(t0), "s"(t1));
+}
+__device__ __forceinline__ void fma_tol_3(cx &y0, float t0, cx &y1, float t1, cx &y2, float t2, cx x) {
+  asm("v_fma_f32 %0, %6, %8, %0 ; soft-tolerance\n\tv_fma_f32 %1, %7, %8, %1 ; soft-tolerance\n\t"
+      "v_fma_f32 %2, %6, %9, %2 ; soft-tolerance\n\tv_fma_f32 %3, %7, %9, %3 ; soft-tolerance\n\t"
+      "v_fma_f32 %4, %6, %10, %4 ; soft-tolerance\n\tv_fma_f32 %5, %7, %10, %5 ; soft-tolerance"
+      : "+v"(y0.r), "+v"(y0.i), "+v"(y1.r), "+v"(y1.i), "+v"(y2.r), "+v"(y2.i) : "v"(x.r), "v"(x.i), "s"(t0), "s"(t1), "s"(t2));
+}
+__device__ __forceinline__ float fma_tol(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 ; soft-tolerance" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max(|a|, |b|, c) for c >= 0 (one instruction; a NaN operand is passed over -- see fused_demod_tol)
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the larger of two NON-NEGATIVE floats as an integer maximum (same order; no canonicalising v_max x, x in front)
+__device__ __forceinline__ float umax_f(float a, float b) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  return __uint_as_float(ua > ub ? ua : ub);
+}
+#define TRX_TOL_ZMAX 8.0f                     /* fast form only when max|x| * |1/amp|_1 <= this: |soft' - soft| <= 7.4e-5 guaranteed */
+#define TRX_TOL_GUARD 3.0517578125e-05f       /* 512 u = 2^-15: |re'| must exceed this times Z (+ 2^-22) for the hard bit to be safe */
+
+template <int SPS>
+__device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + 63) / 64],
+                                                int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft) {
+  typedef FusedGeom<SPS, 64> G;
+  typedef typename G::D D;
+  static_assert(128 % SPS == 0, "pairs of a lane keep their phase from load to load");
+  static_assert(G::OPL == 3, "three soft bits per lane");
+  const bool lane_owner = G::OPL * hl < 148;
+  const int m0 = G::OPL * (lane_owner ? hl : 0);
+  const cx inv = cdiv(mk(1.0f, 0.0f), amp);                // ((complex)1.0)/channel (:1066): the reference's value
+  const float delay = -toa;
+  const int io = (int)floorf(delay);
+  const float frac = delay - (float)io;
+  const bool filt = fabs((double)frac) > 1e-2;
+  const float f512 = frac * 512.0f;
+  int f = (int)f512;
+  const int lo = io + D::C, hi = N + io + D::C;            // samples occupy positions [lo, hi)
+  // ---- may this burst take the fast form at all? (every quantity is wave-uniform) ----
+  float xm = 0.0f;
+#pragma unroll
+  for (int i = 0; i < G::NLD; i++) {                       // (lanes past the burst's end hold zeros)
+    xm = max3_abs(v[i].x, v[i].y, xm);
+    xm = max3_abs(v[i].z, v[i].w, xm);
+  }
+  xm = umax_f(xm, dpp_f<0xB1>(xm));
+  xm = umax_f(xm, dpp_f<0x4E>(xm));
+  xm = umax_f(xm, dpp_f<0x141>(xm));
+  xm = umax_f(xm, dpp_f<0x140>(xm));
+  xm = umax_f(umax_f(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xm), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xm), 16))),
+              umax_f(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xm), 32)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xm), 48))));
+  const float inv1 = fabsf(inv.r) + fabsf(inv.i);
+  const float Z = xm * inv1;
+  // (written so that a NaN or an infinity in amp / TOA fails; a NaN SAMPLE passes fmaxf unseen and is caught at the outputs below)
+  const bool eligible = (f < 512) && ((float)f == f512) && (lo >= 0) && (xm >= 1e-15f) && (xm <= 1e15f) && (inv1 >= 1e-15f) &&
+                        (inv1 <= 1e15f) && (Z <= TRX_TOL_ZMAX);
+  if (!__builtin_amdgcn_readfirstlane(eligible)) return false;
+  f = __builtin_amdgcn_readfirstlane(f);
+  float tp[21];
+#pragma unroll
+  for (int j = 0; j < 21; j++) tp[j] = T->sinc_grid[f & 511][j];      // wave-uniform: s_load
+
+  // ---- stage the samples AS THEY ARE at position n + io + C (polyphase order); zero the positions left uncovered ----
+  wave_lds_fence();
+  for (int u = hl; u < lo && u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
+  for (int u = hi + hl; u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
+  {
+    const int ua = 2 * hl + lo, ub = ua + 1;
+    cx *pa = P + (ua % SPS) * D::QLEN + ua / SPS;
+    cx *pb = P + (ub % SPS) * D::QLEN + ub / SPS;
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      if (2 * (hl + 64 * i) < N) {
+        if (ua + 128 * i < D::U) pa[i * (128 / SPS)] = mk(v[i].x, v[i].y);
+        if (ub + 128 * i < D::U) pb[i * (128 / SPS)] = mk(v[i].z, v[i].w);
+      }
+    }
+  }
+  wave_lds_fence();
+
+  cx y[G::OPL];
+#pragma unroll
+  for (int i = 0; i < G::OPL; i++) y[i] = mk(0, 0);
+  if (filt) {
+    // the word walk of fused_demod_ex: output m0+i, tap j reads position SPS*(m0+i) + c0, c0 = 10 - j + C
+    constexpr int CMAX = 10 + D::C + SPS * (G::OPL - 1), CMIN = D::C - 10, NWD = CMAX - CMIN + 1;
+#pragma unroll
+    for (int w0 = 0; w0 < NWD; w0 += 8) {
+      cx wd[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int c = CMAX - (w0 + q);
+        if (c >= CMIN) wd[q] = P[(c % SPS) * D::QLEN + c / SPS + m0];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int c = CMAX - (w0 + q);
+        const int j0 = 10 + D::C - c, j1 = j0 + SPS, j2 = j1 + SPS;
+        const bool u0 = c >= CMIN && j0 >= 0 && j0 <= 20, u1 = c >= CMIN && j1 >= 0 && j1 <= 20, u2 = c >= CMIN && j2 >= 0 && j2 <= 20;
+        const float t0 = tp[u0 ? j0 : 0], t1 = tp[u1 ? j1 : 0], t2 = tp[u2 ? j2 : 0];
+        if (u0 && u1 && u2) fma_tol_3(y[0], t0, y[1], t1, y[2], t2, wd[q]);
+        else if (u0 && u1) fma_tol_2(y[0], t0, y[1], t1, wd[q]);
+        else if (u1 && u2) fma_tol_2(y[1], t1, y[2], t2, wd[q]);
+        else if (u0 && u2) fma_tol_2(y[0], t0, y[2], t2, wd[q]);
+        else if (u0) fma_tol_1(y[0], t0, wd[q]);
+        else if (u1) fma_tol_1(y[1], t1, wd[q]);
+        else if (u2) fma_tol_1(y[2], t2, wd[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::OPL; i++) y[i] = P[(D::C % SPS) * D::QLEN + D::C / SPS + m0 + i];
+  }
+  const cx *rev = T->rev;
+  const float guard = fma_tol(Z, TRX_TOL_GUARD, 2.384185791015625e-07f);
+  float sv[G::OPL];
+  bool risky = false;
+#pragma unroll
+  for (int i = 0; i < G::OPL; i++) {
+    const int m = m0 + i;
+    const int t = SPS * m - io;                            // shifted[k] = filtered[k - intOffset] (:597-613)
+    const cx rv = rev[SPS * m];
+    // (rev[m] * inv) * Y, real part: the reference rounds x * inv, the sums and rev * y one by one (see the bound above)
+    const float a = fma_tol(rv.r, inv.r, -(rv.i * inv.i));
+    const float b = fma_tol(rv.r, inv.i, rv.i * inv.r);
+    const float re = fma_tol(a, y[i].r, -(b * y[i].i));
+    const bool in_range = (t >= 0 && t < N);               // else the reference's filtered sample is 0: soft 0.5, hard 0, either form
+    float s = fma_tol(re, 0.5F, 0.5F);                     // vectorSlicer (:513-515): (re + 1) / 2, halving is exact
+    s = fminf(fmaxf(s, 0.0f), 1.0f);
+    sv[i] = in_range ? s : 0.5F;
+    risky = risky || (lane_owner && m < nsoft && in_range && !(fabsf(re) > guard));
+  }
+  if (__builtin_amdgcn_ballot_w64(risky) != 0) return false;          // the value-exact form redoes this burst
+#pragma unroll
+  for (int i = 0; i < G::OPL; i++) {
+    const int m = m0 + i;
+    if (lane_owner && m < nsoft) {
+      sb[m] = sv[i];
+      if (hbp) hbp[m] = sv[i] > 0.5F;                      // SoftVector::bit (BitVector.h:415-420)
+    }
+  }
+  return true;
+}
+
+
+template <int SPS, bool RAW, int NSMAX, typename SMP = SmpC32, bool TOL = false>
 __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables *__restrict__ T,
                                                const void *__restrict__ samples,
                                                const int32_t *__restrict__ offset,
@@ -359,6 +541,9 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables 
   // but a lane owns three CONSECUTIVE soft bits, whose filter windows share 34 of their 63 staged words
   // (measured: 68.0 -> 64.6 us per 64 K bursts)
   if (!RAW && NSMAX == 148 && wide && (N & 1) == 0) {
+    if (TOL) {                                             // tolerance mode: the rearranged form, unless this burst has to be exact
+      if (fused_demod_tol<SPS>(T, ph[wave], v, N, amp, toa, lane, sb, hb, nsoft)) return;
+    }
     fused_demod<SPS, 64>(T, ph[wave], v, N, amp, toa, lane, sb, hb, nsoft, [] {}, nullptr, nullptr);
     return;
   }

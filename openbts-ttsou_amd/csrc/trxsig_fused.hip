@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * TRX_FUSED_WAVES) void k_normal_fused(
 //   busy, which is what the wave-per-burst kernel above cannot do; the price is that the window and
 //   the energy samples are read twice (the second time from L2).  No workgroup barrier.
 // ---------------------------------------------------------------------------------------------
-template <int SPS, unsigned TAPCLS, bool DEMOD>
+template <int SPS, unsigned TAPCLS, bool DEMOD, bool TOL = false>
 __global__ __launch_bounds__(256) void k_normal_quad(
     const TrxTables *__restrict__ T, const cx *__restrict__ samples, const int32_t *__restrict__ offset,
     const int32_t *__restrict__ length, int B, TapArg taps, cx gain_inv, float mid_toa, float detect_thresh,
@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256) void k_normal_quad(
 #pragma unroll
         for (int j = 0; j < 21; j++)
           tp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 16 ? tap_lo : tap_hi), 16 * rr + (j & 15)));
-        fused_demod<SPS, 64>(T, P, v, N, a, ta, ln, sb, hbp, nsoft, [] {}, tp, rvl);
+        // (TOL: trxsig_set_soft_mode(TRXSIG_SOFT_TOLERANCE) -- the rearranged form unless this burst has to be exact)
+        if (!(TOL && fused_demod_tol<SPS>(T, P, v, N, a, ta, ln, sb, hbp, nsoft)))
+          fused_demod<SPS, 64>(T, P, v, N, a, ta, ln, sb, hbp, nsoft, [] {}, tp, rvl);
         wave_lds_fence();                                  // staging reads done before the next burst overwrites it
       } else {
         for (int m = ln; m < nsoft; m += 64) { sb[m] = 0.0f; if (hbp) hbp[m] = 0; }
@@ -447,7 +449,7 @@ template <int S, int LPB>
 static void launch_normal_fused(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const trx_c32 *samples,
                                 const int32_t *off, const int32_t *len, int B, int tsc, float detect_thresh,
                                 float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr,
-                                float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps) {
+                                float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps, int tol) {
   TapArg ta;
   for (int k = 0; k < 16; k++) { ta.v[2 * k] = hT->mid_ctap[tsc][k].r; ta.v[2 * k + 1] = hT->mid_ctap[tsc][k].i; }
   // gain.inv() (Complex.h:154-160) in the reference's float arithmetic; this file is built with -ffp-contract=off
@@ -459,7 +461,10 @@ static void launch_normal_fused(hipStream_t st, const TrxTables *dT, const TrxTa
 #define TRX_QUAD_ARGS dT, samples, off, len, B, ta, ginv, hT->mid_toa[tsc], detect_thresh, energy_thresh, flags, amp, toa, \
                       avgpwr, soft, hard, nsoft, stride
     const bool spec = !generic_taps && tap_classes(hT, tsc) == TapPattern<S>::value;
-    if (nsoft > 0) {
+    if (nsoft > 0 && tol) {
+      if (spec) k_normal_quad<S, TapPattern<S>::value, true, true><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
+      else k_normal_quad<S, TRX_TAPS_GENERIC, true, true><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
+    } else if (nsoft > 0) {
       if (spec) k_normal_quad<S, TapPattern<S>::value, true><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
       else k_normal_quad<S, TRX_TAPS_GENERIC, true><<<qgrid, qblock, 0, st>>>(TRX_QUAD_ARGS);
     } else {
@@ -480,7 +485,7 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
                                    const trx_c32 *samples, const int32_t *off, const int32_t *len, int B, int tsc,
                                    float detect_thresh, float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
-                                   int generic_taps, TrxProfiler *prof) {
+                                   int generic_taps, TrxProfiler *prof, int soft_tolerance) {
   if (B <= 0) return hipSuccess;
   if (nsoft > 148 || (lanes_per_burst != 64 && lanes_per_burst != 32 && lanes_per_burst != 16)) return hipErrorInvalidValue;
   if (prof) prof->begin(TRXSIG_K_NORMAL_FUSED, st);
@@ -488,13 +493,13 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
   case S:                                                                                                              \
     if (lanes_per_burst == 64)                                                                                         \
       launch_normal_fused<S, 64>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
-                                 avgpwr, soft, hard, nsoft, stride, generic_taps);                                                   \
+                                 avgpwr, soft, hard, nsoft, stride, generic_taps, soft_tolerance);                                   \
     else if (lanes_per_burst == 16)                                                                                    \
       launch_normal_fused<S, 16>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
-                                 avgpwr, soft, hard, nsoft, stride, generic_taps);                                                   \
+                                 avgpwr, soft, hard, nsoft, stride, generic_taps, soft_tolerance);                                   \
     else                                                                                                               \
       launch_normal_fused<S, 32>(st, dT, hT, samples, off, len, B, tsc, detect_thresh, energy_thresh, flags, amp, toa, \
-                                 avgpwr, soft, hard, nsoft, stride, generic_taps);                                                   \
+                                 avgpwr, soft, hard, nsoft, stride, generic_taps, soft_tolerance);                                   \
     break;
   switch (sps) {
     TRX_FUSED_CASE(1)

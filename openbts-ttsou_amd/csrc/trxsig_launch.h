@@ -34,7 +34,7 @@ hipError_t trx_launch_normal_fused(hipStream_t st, int sps, int lanes_per_burst,
                                    const trx_c32 *samples, const int32_t *off, const int32_t *len, int B, int tsc,
                                    float detect_thresh, float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride,
-                                   int generic_taps /* 1: no tap-class specialisation */, TrxProfiler *prof);
+                                   int generic_taps /* 1: no tap-class specialisation */, TrxProfiler *prof, int soft_tolerance = 0);
 
 // the whole normal-burst leg in ONE launch with an in-launch hand-over (trxsig_chain.hip); nsoft 1..148; det: 16 bytes
 // per burst, tag words clear on entry (left clear on exit); status: host-visible word raised when a wait runs out
@@ -43,7 +43,7 @@ hipError_t trx_launch_normal_chain(hipStream_t st, int sps, const TrxTables *dT,
                                    const int32_t *off, const int32_t *len, int B, int tsc, float detect_thresh,
                                    float energy_thresh, uint8_t *flags, trx_c32 *amp, float *toa, float *avgpwr, float *soft,
                                    uint8_t *hard, int nsoft, int stride, void *det, unsigned *status, int lag,
-                                   unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg = 0);
+                                   unsigned spin_limit, int generic_taps, TrxProfiler *prof, int dbg = 0, int soft_tolerance = 0);
 
 // free-standing vector primitives of sigProcLib.h (trxsig_prim.hip); op: 0 scaleVector, 1 GMSKRotate, 2 GMSKReverseRotate,
 // 3 vectorSlicer, 4 offsetVector (scale[v] = the offset)
@@ -97,7 +97,8 @@ hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, co
 hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,
-                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
+                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof, int soft_tolerance = 0);
+// (soft_tolerance: TRXSIG_SOFT_TOLERANCE -- the rearranged demodulator of trxsig_demod.h; hard bits exact, soft bits within 7.4e-5)
 
 hipError_t trx_launch_modulate(hipStream_t st, int sps, const TrxTables *dT, const uint8_t *bits, const int32_t *guard,
                                const float *gain, int B, trx_c32 *out, const int32_t *out_off, TrxProfiler *prof);

@@ -660,13 +660,16 @@ hipError_t trx_launch_rx_demod(hipStream_t st, const TrxTables *dT, const TrxRxG
 hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,
-                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+                            uint8_t *hard, int nsoft, int stride, TrxProfiler *prof, int soft_tolerance) {
   if (B <= 0) return hipSuccess;
   const dim3 grid((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), block(64 * TRX_DEMOD_WAVES);
   if (prof) prof->begin(TRXSIG_K_DEMOD, st);
 #define TRX_DEMOD_CASE(S)                                                                                          \
   case S:                                                                                                          \
-    if (nsoft <= 148)                                                                                              \
+    if (nsoft <= 148 && soft_tolerance)                                                                            \
+      k_demod<S, false, 148, SmpC32, true><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, \
+                                                     nsoft, stride);                                              \
+    else if (nsoft <= 148)                                                                                         \
       k_demod<S, false, 148><<<grid, block, 0, st>>>(dT, samples, off, len, B, amp, toa, flags, need_mask, soft, hard, \
                                                      nsoft, stride);                                              \
     else                                                                                                           \

@@ -1,7 +1,7 @@
 """Numerical-contract audit on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles): outside
 hipcc's correctly-rounded division / sqrt expansions no kernel may contain a fused multiply-add, except the two
 marked kinds (and, in the shared-filter channeliser alone -- an approximate form by construction, off by default, graded with a
-tolerance -- the "approx-form" kind) that tools/asm_stats.py counts apart: the exact-product FMAs of the midamble correlators (a tap
+tolerance -- the "approx-form" kind; and, in the kernels instantiated for trxsig_set_soft_mode(TRXSIG_SOFT_TOLERANCE) alone, the "soft-tolerance" kind) that tools/asm_stats.py counts apart: the exact-product FMAs of the midamble correlators (a tap
 component of exactly +-1: single rounding == separate mul and add) and the FMAs of a steering pass (fma_steer:
 approximate correlations that only decide which lags are recomputed with the reference's exact arithmetic), which
 may appear in the kernels listed below and nowhere else."""
@@ -34,5 +34,9 @@ def test_kernels_have_no_contracted_fma():
             assert any(k in l for k in steering_ok), l
         if "approx-form fma" in l:                           # only the shared-filter channeliser (graded at 1e-4, never the default)
             assert "k_channelise16" in l, l
+        if "soft-tolerance fma" in l:                        # only kernels instantiated for TRXSIG_SOFT_TOLERANCE (TOL = true: the last
+            sym = re.search(r"\[(\w+)\]", l).group(1)       # template argument of k_demod / k_normal_quad / k_normal_chain)
+            assert re.search(r"(7k_demodILi\dELb0ELi148ENS_6SmpC32ELb1EEE|k_normal_quadILi\d.*ELb1EEE|k_normal_chainILi\d.*ELb1EEE|k_demod_rxILi4ELb1EEE)", sym), l
     assert any("steering fma" in l and "k_rach_front" in l for l in rows)
     assert any("approx-form fma" in l and "k_channelise16" in l for l in rows)
+    assert any("soft-tolerance fma" in l and "k_demod" in l for l in rows)

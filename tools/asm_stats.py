@@ -33,8 +33,12 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
     # ... and those of a form that is approximate by construction and graded with a tolerance (the shared-filter channeliser,
     # trxsig_chan.hip: the per-carrier sums in another order)
     approx = sum(1 for i in ins if "; approx-form" in i)
+    # ... and those of the tolerance-mode demodulator (fused_demod_tol, trxsig_demod.h: TRXSIG_SOFT_TOLERANCE -- soft bits within
+    # 7.4e-5 of the reference's, hard bits exact; only in kernels instantiated with TOL = true)
+    tol = sum(1 for i in ins if "; soft-tolerance" in i)
     fma = [i for i, o in enumerate(ops) if re.match(r"v_(fma_f|mac_f|fmac_f|mad_f|pk_fma)", o)
-           and "exact-product" not in ins[i] and "; steering" not in ins[i] and "; approx-form" not in ins[i]]
+           and "exact-product" not in ins[i] and "; steering" not in ins[i] and "; approx-form" not in ins[i]
+           and "; soft-tolerance" not in ins[i]]
     # hipcc's correctly-rounded division / sqrt expansions keep their fma's next to
     # v_div_scale / v_rcp / v_div_fmas / v_div_fixup / v_sqrt / v_rsq (f32 and f64)
     bad = 0
@@ -46,4 +50,5 @@ for m in re.finditer(r"\n(_Z\w+):.*?\n(.*?)\n\.Lfunc_end", text, flags=re.S):
     label = "%s<sps=%s>" % (kind.group(1), kind.group(2)) if kind else name[:50]
     print("%-28s total %5d  %s  fma %d (outside a division: %d)%s" % (
         label, len(ops), dict(c), len(fma), bad, ("  exact-product fma %d" % exact if exact else "") +
-        ("  steering fma %d" % steer if steer else "") + ("  approx-form fma %d" % approx if approx else "")))
+        ("  steering fma %d" % steer if steer else "") + ("  approx-form fma %d" % approx if approx else "") +
+        ("  soft-tolerance fma %d [%s]" % (tol, name) if tol else "")))
