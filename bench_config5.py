@@ -19,9 +19,9 @@ class Config5:
         self.alg_bytes = 4 * 625 // 4 + 4 * 156 + 16           # 4*156.25 B of fp16 I/Q read; 156 soft bits + flag / amp / TOA written
         # per-kernel algorithmic bytes per burst: k_eq_detect52 reads the 26-sample window + 20 energy samples (fp16) and writes
         # flag / amp / TOA / toa_eq + 12 taps; k_eq_dfe4 (scaleVector + delayVector + equalizeBurst in one kernel) reads the burst
-        # (fp16), amp / TOA / flag and the taps and writes 156 soft bits.  (TRXSIG_EQ_TAIL=2, the two-kernel route: k_eq_delay reads the
+        # (fp16), amp / TOA / flag and the taps and writes 156 soft bits.  (--eq-tail 2 = trxsig_set_tuning(TRXSIG_TUNE_EQ_TAIL, 2), the two-kernel route: k_eq_delay reads the
         # burst and writes 157 delayed c64, k_eq_dfe2 reads those + the taps and writes the soft bits.)
-        two = os.environ.get("TRXSIG_EQ_TAIL") == "2"
+        two = getattr(args, "eq_tail", 1) == 2
         self.kernel_alg = {"k_eq_detect": 4 * 46 + 17 + 4 + 96, "k_eq_delay": 625 + 13 + 8 * 157,
                            "k_eq_dfe": (8 * 157 + 96 + 4 * 156) if two else (625 + 13 + 96 + 4 * 156)}
         self.kernel_names = {"k_eq_dfe": "k_eq_dfe2" if two else "k_eq_dfe4", "k_eq_detect": "k_eq_detect52"}

@@ -69,6 +69,9 @@ int  trxsig_create(trxsig_ctx **out, int device, int sps);
 void trxsig_destroy(trxsig_ctx *ctx);
 int  trxsig_sps(const trxsig_ctx *ctx);
 int  trxsig_device(const trxsig_ctx *ctx);
+/* front ends, back ends and Transceiver groups currently alive on the context (each keeps it alive past trxsig_destroy);
+ * a create call that fails leaves this count where it was */
+int  trxsig_live_children(const trxsig_ctx *ctx);
 /* stream = hipStream_t (NULL = the device's null stream).  One context per calling thread. */
 int  trxsig_set_stream(trxsig_ctx *ctx, void *hip_stream);
 /* hipStreamSynchronize on the context's stream */
@@ -510,10 +513,18 @@ int trxsig_kernel_count(void);
  *     each bisection step side by side, sinc table in LDS, window in registers; k_tsc_peak2, the default),
  *     1 = eight lanes per burst with the bisection speculated two levels at a time (k_tsc_peak8; 25 us per
  *     64 K bursts, LDS bandwidth), 2 = a lane per burst, the reference's serial loop (k_tsc_peak; 18 us,
- *     k_tsc_peak2 15 us).  All three are bit-identical. */
+ *     k_tsc_peak2 15 us).  All three are bit-identical.
+ *   LIBRARY-WIDE knobs (both libraries; they act on every context of the process and are read by the launchers -- the library
+ *   reads no environment variable on a launch path; all give the same results):
+ *   TRXSIG_TUNE_EQ_TAIL: 1 = scaleVector + delayVector + equalizeBurst in one kernel (k_eq_dfe4, the default), 2 = k_eq_delay +
+ *     k_eq_dfe2 through the scratch rows.  TRXSIG_TUNE_EQ_DENSE: marked bursts per call above which the Transceiver group's channel
+ *     estimate runs a lane per burst instead of a wave per burst (default 4096).  TRXSIG_TUNE_RXRES_WPB: windows per workgroup of the
+ *     receive resampler (0 = chosen from the launch size); TRXSIG_TUNE_RXRES_ROWS: 1 = its tap rows in visiting order (default),
+ *     0 = in branch order.  TRXSIG_TUNE_CHAN_TPW: tiles per workgroup of the shared-filter channeliser (0 = chosen from the launch size). */
 enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3,
        TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5, TRXSIG_TUNE_DEMOD_BESIDE = 7, TRXSIG_TUNE_BESIDE_DET_CUS = 8,
-       TRXSIG_TUNE_CU_LAYOUT = 9, TRXSIG_TUNE_BESIDE_PRIORITY = 11 };
+       TRXSIG_TUNE_CU_LAYOUT = 9, TRXSIG_TUNE_BESIDE_PRIORITY = 11, TRXSIG_TUNE_EQ_TAIL = 12, TRXSIG_TUNE_EQ_DENSE = 13,
+       TRXSIG_TUNE_RXRES_WPB = 14, TRXSIG_TUNE_RXRES_ROWS = 15, TRXSIG_TUNE_CHAN_TPW = 16 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* 1 in libtrxsig_tune.so (every implementation above selectable), 0 in the product library libtrxsig.so, which carries the
  * defaults only (normal path 0 with the two-lane peak kernel, RACH paths 1 and 2) and answers TRXSIG_EINVAL to the rest. */

@@ -113,6 +113,11 @@ void trxsig_txbe_destroy(trxsig_txbe *be);
  * buffers: d_bits [n_streams][n_bursts][148] (one bit per byte), h_guard[n_bursts] guard symbols per burst (host; the same
  * schedule on every stream: 8 + (TN % 4 == 0), Transceiver.cpp:105), d_gain [n_streams][n_bursts] or NULL. */
 int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_t *h_guard, const float *d_gain, int n_bursts);
+/* Would trxsig_txbe_push_bursts accept this push now?  TRXSIG_OK, or the error that call would return (text in
+ * trxsig_last_error) -- nothing is changed either way.  For a caller that must not have consumed its bursts when the push is
+ * refused (trxsig_trxgroup_push_txbe).  trxsig_txbe_streams: the n_streams the back end was created with. */
+int trxsig_txbe_can_push(trxsig_txbe *be, const int32_t *h_guard, int n_bursts);
+int trxsig_txbe_streams(const trxsig_txbe *be);
 /* pushBuffer for every stream: *n_samples int16 I/Q pairs per stream at *d_iq + s * *stream_stride pairs (device; valid
  * until the next pop), 0 while less than one chunk is buffered. */
 int trxsig_txbe_pop(trxsig_txbe *be, const int16_t **d_iq, int64_t *stream_stride, int *n_samples);

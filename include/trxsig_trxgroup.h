@@ -117,6 +117,10 @@ int trxsig_trxgroup_pull_host(trxsig_trxgroup *g, const trxsig_c32 *h_samples, i
  * trxsig_trxgroup_collect / _energy_threshold, which call it, or any later pull that is not pipelined).  Results live in one of
  * two workspace sets: a result stays valid until the SECOND pull after its own.  Values are the same in either mode. */
 int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on);
+/* Which pulls replay the state machine on the group's SIDE stream, beside the demodulator (demodulating leg): those with at
+ * least `rows` (slot, ARFCN) rows; 0 = never (the default since round 4: a long call's replay is parallel in time and one stream
+ * is faster).  An implementation choice for A/B measurements and for pipelined mode; same values either way. */
+int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows);
 /* the context's stream waits for every replay still in flight on the side stream (no host wait) */
 int trxsig_trxgroup_sync(trxsig_trxgroup *g);
 /* mEnergyThreshold of one ARFCN now (synchronises) */

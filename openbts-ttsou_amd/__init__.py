@@ -496,8 +496,13 @@ class TrxSig:
         self._chk(self.L.trxsig_pack_int16(self.h, _ptr(x), n, _ptr(iq)), "trxsig_pack_int16")
 
     def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None, chain_lag=None,
-                   chain_spin=None, demod_beside=None, beside_det_cus=None, cu_layout=None, beside_priority=None):
-        """A/B implementation choice (results are bit-identical): see trxsig_set_tuning."""
+                   chain_spin=None, demod_beside=None, beside_det_cus=None, cu_layout=None, beside_priority=None,
+                   eq_tail=None, eq_dense=None, rxres_wpb=None, rxres_rows=None, chan_tpw=None):
+        """A/B implementation choice (results are bit-identical): see trxsig_set_tuning.  eq_tail / eq_dense / rxres_* / chan_tpw
+        are LIBRARY-WIDE (every context of the process): restore the default (1 / 4096 / 0 / 1 / 0) when done."""
+        for key, v in ((12, eq_tail), (13, eq_dense), (14, rxres_wpb), (15, rxres_rows), (16, chan_tpw)):
+            if v is not None:
+                self._chk(self.L.trxsig_set_tuning(self.h, key, int(v)), "trxsig_set_tuning")
         if demod_beside is not None:
             self._chk(self.L.trxsig_set_tuning(self.h, 7, int(demod_beside)), "trxsig_set_tuning")
         if beside_det_cus is not None:
@@ -689,6 +694,7 @@ class TrxGroup:
         L.trxsig_trxgroup_collect.argtypes = [vp, vp, vp, vp, vp, vp]
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
         L.trxsig_trxgroup_set_pipelined.argtypes = [vp, i32]
+        L.trxsig_trxgroup_set_beside_rows.argtypes = [vp, i32]
         L.trxsig_trxgroup_sync.argtypes = [vp]
         L.trxsig_trxgroup_add_bursts.argtypes = [vp, vp, vp, i32]
         L.trxsig_trxgroup_push.argtypes = [vp, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -793,6 +799,10 @@ class TrxGroup:
     def set_pipelined(self, on=True):
         """Large pulls return without joining the side stream the state machine replays on (see trxsig_trxgroup.h)."""
         self._chk(self.L.trxsig_trxgroup_set_pipelined(self.h, 1 if on else 0), "trxsig_trxgroup_set_pipelined")
+
+    def set_beside_rows(self, rows):
+        """Pulls with at least `rows` rows replay the state machine on the group's side stream (0 = never, the default)."""
+        self._chk(self.L.trxsig_trxgroup_set_beside_rows(self.h, int(rows)), "trxsig_trxgroup_set_beside_rows")
 
     def sync(self):
         self._chk(self.L.trxsig_trxgroup_sync(self.h), "trxsig_trxgroup_sync")

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -427,6 +428,7 @@ static void destroy_now(trxsig_ctx *c) {
 
 int trxsig_sps(const trxsig_ctx *c) { return c ? c->sps : TRXSIG_EINVAL; }
 int trxsig_device(const trxsig_ctx *c) { return c ? c->device : TRXSIG_EINVAL; }
+int trxsig_live_children(const trxsig_ctx *c) { return c ? c->children : TRXSIG_EINVAL; }
 int trxsig_set_stream(trxsig_ctx *c, void *s) { if (!c) return TRXSIG_EINVAL; c->stream = (hipStream_t)s; return TRXSIG_OK; }
 void *trxsig_get_stream(trxsig_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int trxsig_get_device(trxsig_ctx *c) { return c ? c->device : -1; }
@@ -1255,6 +1257,13 @@ int trxsig_tuning_build(void) {
 #endif
 }
 
+// library-wide implementation knobs (trxsig_launch.h): plain atomics, defaults here
+static std::atomic<int> g_knob[TRX_KNOB_COUNT] = {{1}, {4096}, {0}, {1}, {0}};
+extern "C++" {
+int trx_knob(int id) { return (id >= 0 && id < TRX_KNOB_COUNT) ? g_knob[id].load(std::memory_order_relaxed) : 0; }
+void trx_knob_set(int id, int value) { if (id >= 0 && id < TRX_KNOB_COUNT) g_knob[id].store(value, std::memory_order_relaxed); }
+}
+
 int trxsig_set_soft_mode(trxsig_ctx *c, int mode) {
   if (!c) return TRXSIG_EINVAL;
   if (mode != TRXSIG_SOFT_EXACT && mode != TRXSIG_SOFT_TOLERANCE) return fail(c, TRXSIG_EINVAL, "trxsig_set_soft_mode: unknown mode");
@@ -1287,6 +1296,12 @@ int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
     return TRXSIG_OK;
   }
   if (key == TRXSIG_TUNE_SPECULATIVE_PEAK && value >= 0 && value <= 2) { c->spec_peak = value; return TRXSIG_OK; }
+  // library-wide knobs (every context of the process; read by the launchers)
+  if (key == TRXSIG_TUNE_EQ_TAIL && (value == 1 || value == 2)) { trx_knob_set(TRX_KNOB_EQ_TAIL, value); return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_EQ_DENSE && value >= 0) { trx_knob_set(TRX_KNOB_EQ_DENSE, value); return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_RXRES_WPB && value >= 0 && value <= 64) { trx_knob_set(TRX_KNOB_RXRES_WPB, value); return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_RXRES_ROWS && value >= 0 && value <= 1) { trx_knob_set(TRX_KNOB_RXRES_ROWS, value); return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_CHAN_TPW && value >= 0 && value <= 64) { trx_knob_set(TRX_KNOB_CHAN_TPW, value); return TRXSIG_OK; }
   if ((key == TRXSIG_TUNE_BESIDE_DET_CUS && value >= 0 && value <= 504) || (key == TRXSIG_TUNE_CU_LAYOUT && value >= 0 && value <= 1) ||
       (key == TRXSIG_TUNE_BESIDE_PRIORITY && value >= 0 && value <= 2)) {
     DeviceGuard g(c->device);

@@ -235,7 +235,7 @@ hipError_t trx_launch_channelise16(hipStream_t st, TrxResampleArgs a, int S_wide
   int tpw = 1;                                              // tiles per workgroup: up to four (measured: 1: 174, 2: 130, 4: 117, 8: 145 us), as long as
   for (int cand = 4; cand > 1; cand >>= 1)                  // the machine keeps eight workgroups per CU
     if (cand <= n_tiles && (long long)S_wide * n_windows * ((n_tiles + cand - 1) / cand) >= 2048) { tpw = cand; break; }
-  if (const char *e = std::getenv("TRXSIG_CHAN_TPW")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) tpw = v; }
+  { const int v = trx_knob(TRX_KNOB_CHAN_TPW); if (v >= 1 && v <= 64) tpw = v; }   // (TRXSIG_TUNE_CHAN_TPW, A/B)
   const dim3 grid((n_tiles + tpw - 1) / tpw, n_windows, S_wide), block(256);
   if (prof) prof->begin(TRXSIG_K_RESAMPLE, st);
   switch (C) {

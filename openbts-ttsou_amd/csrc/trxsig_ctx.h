@@ -27,6 +27,8 @@ int trx_rxfe_fused_end(trxsig_rxfe *fe, const int16_t *d_iq, int n_chunks, const
 // an object that lives on a context keeps it alive: trxsig_destroy on a context with such objects takes effect when the last is gone
 void trx_ctx_retain(trxsig_ctx *c);
 void trx_ctx_release(trxsig_ctx *c);
+struct trxsig_txbe;
+trxsig_ctx *trx_txbe_context(const trxsig_txbe *be);         // the context a transmit back end was created on (trxsig_frontend.cpp)
 trxsig_ctx *trx_rxfe_ctx(trxsig_rxfe *fe);
 int trx_rxfe_streams(const trxsig_rxfe *fe);
 int trx_rxfe_next_tn(const trxsig_rxfe *fe);

@@ -25,14 +25,15 @@ namespace {
 #define EQ_NC 36            /* max correlation lags kept per burst */
 static constexpr int kEqWaveMax = 2048;   // k_eq_estimate_wave: waves launched; a call of at most this many bursts takes it without a list
 // more marked bursts than this: a lane per burst (k_eq_detect) is the faster arrangement again (TRXSIG_EQ_DENSE: the tests force either route)
-static int eq_dense() {                                     // (read at every call: a test switches it between cases)
-  const char *e = std::getenv("TRXSIG_EQ_DENSE");
-  return e ? std::atoi(e) : 4096;
-}
-// A/B: TRXSIG_EQ_DETECT_GENERIC=1 keeps the padded kernel also where the fixed-geometry one applies (maxTOA 4)
+static int eq_dense() { return trx_knob(TRX_KNOB_EQ_DENSE); }   // (trxsig_set_tuning(TRXSIG_TUNE_EQ_DENSE): a test switches it between cases)
+// A/B (tuning build only): TRXSIG_EQ_DETECT_GENERIC=1 keeps the padded kernel also where the fixed-geometry one applies (maxTOA 4)
 static int eq_detect_generic() {
+#ifdef TRX_TUNING_BUILD
   static const int v = std::getenv("TRXSIG_EQ_DETECT_GENERIC") ? std::atoi(std::getenv("TRXSIG_EQ_DETECT_GENERIC")) : 0;
   return v;
+#else
+  return 0;
+#endif
 }
 // instantiations: k_eq_detect52 for config 5's geometry (52M window, maxTOA 4, expectedTOAPeak 20: `geom52`, which the caller derives
 // from the host's copy of the tables -- trx_eq52_geometry, trxsig_launch.h); else k_eq_detect for the 52M window with maxTOA <= 5 (11
@@ -1992,7 +1993,11 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
 void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
                    const float *toa_eq, const cx *w, const cx *bq, float *soft, uint8_t *hard, int nsoft, int stride,
                    const int32_t *tap_ix = nullptr) {
+#ifdef TRX_TUNING_BUILD
   static const bool legacy = std::getenv("TRXSIG_EQ_DFE_VARIANT") && std::atoi(std::getenv("TRXSIG_EQ_DFE_VARIANT")) == 1;   // (2: k_eq_dfe2)
+#else
+  constexpr bool legacy = false;
+#endif
   if (legacy)
     k_eq_dfe<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(dT, xd, xstride, len, B, flags, toa_eq, w, bq, soft, hard, nsoft, stride, tap_ix);
   else
@@ -2034,11 +2039,8 @@ static int eq_dfe_variant() {
   return v;
 }
 #endif
-// TRXSIG_EQ_TAIL=2 (environment, A/B and the tests): k_eq_delay + k_eq_dfe2 through the scratch rows instead of the fused k_eq_dfe4
-static bool eq_tail_fused() {
-  const char *e = std::getenv("TRXSIG_EQ_TAIL");
-  return !(e && std::atoi(e) == 2);
-}
+// trxsig_set_tuning(TRXSIG_TUNE_EQ_TAIL, 2) (A/B and the tests): k_eq_delay + k_eq_dfe2 through the scratch rows instead of the fused k_eq_dfe4
+static bool eq_tail_fused() { return trx_knob(TRX_KNOB_EQ_TAIL) != 2; }
 static void launch_eq_tail(hipStream_t st, const TrxTables *dT, const void *samples, int fmt, const int32_t *off, const int32_t *len, int B,
                            const trx_c32 *amp, const float *toa_eq, const uint8_t *flags, const trx_c32 *w, const trx_c32 *bq, trx_c32 *xd,
                            int xstride, float *soft, uint8_t *hard, int nsoft, int stride, const int32_t *tap_ix, TrxProfiler *prof) {

@@ -101,8 +101,10 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
   fe->stride = ((long long)157 * fe->sps + (long long)max_chunks * fe->per_chunk + 63) & ~63LL;
   // burst offsets (k_burst_index) and burst counts (S * bursts per push) are 32-bit
   if (fe->stride * fe->S > 0x7fffffffLL || ((long long)max_chunks * fe->per_chunk / (156 * fe->sps) + 2) * fe->S > 0x7fffffffLL) {
+    const int rc = trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create: n_streams x max_chunks exceeds 2^31 samples (32-bit burst offsets): use several front ends", hipSuccess);
+    trx_ctx_release(c);                                     // the reference taken above (error text first: the release may be the context's end)
     delete fe;
-    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create: n_streams x max_chunks exceeds 2^31 samples (32-bit burst offsets): use several front ends", hipSuccess);
+    return rc;
   }
   Guard g(trxsig_device(c));
   const size_t rcv_b = sizeof(trx_c32) * (size_t)fe->stride * fe->S, tmp_b = sizeof(trx_c32) * (size_t)157 * fe->sps * fe->S;
@@ -111,8 +113,9 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
       hipMalloc((void **)&fe->d_lpf, sizeof(float) * (size_t)L) != hipSuccess ||
       hipMemset(fe->d_hist, 0, sizeof(short2) * TRXSIG_OUTHISTORY * (size_t)fe->S) != hipSuccess ||   // rcvHistory->fill(0) (:238-241)
       hipMemcpy(fe->d_lpf, h_lpf, sizeof(float) * (size_t)L, hipMemcpyHostToDevice) != hipSuccess) {
+    const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
     trxsig_rxfe_destroy(fe);
-    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);
+    return rc;
   }
   if (fe->sps == 4 && L <= 4 * fe->P) {                     // the fused call's tables (sps 4, at most four taps per output)
     // only the 65 branches 4 m occur (96 = 4*24, 260 = 4*65); slot n holds branch 4*(24 n mod 65) (trxsig_rxgen.h)
@@ -125,8 +128,9 @@ int trxsig_rxfe_create(trxsig_rxfe **out, trxsig_ctx *c, int n_streams, int max_
         hipMemcpy(fe->d_tpb, tpb.data(), sizeof(float4) * 65, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&fe->d_keep, sizeof(short2) * (size_t)fe->n_in * fe->S) != hipSuccess ||
         hipMemset(fe->d_keep, 0, sizeof(short2) * (size_t)fe->n_in * fe->S) != hipSuccess) {
+      const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
       trxsig_rxfe_destroy(fe);
-      return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create: device allocation failed", hipSuccess);
+      return rc;
     }
   }
   *out = fe;
@@ -150,9 +154,10 @@ int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *c, int n_wide_str
   fe->Cw = rate_factor; fe->C = n_carriers; fe->Sw = n_wide_streams;
   fe->h_freq.assign(h_carrier_freq, h_carrier_freq + n_carriers);
   if (trxsig_resample_out_len(fe->n_in * rate_factor, fe->P, TRXSIG_OUTRATE * rate_factor) != fe->n_out) {
+    const int rc = trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create_wideband: this rate factor changes the resampler's output length", hipSuccess);   // (first the error text: the release below may be the context's end)
     trxsig_rxfe_destroy(fe);
     *out = nullptr;
-    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_rxfe_create_wideband: this rate factor changes the resampler's output length", hipSuccess);
+    return rc;
   }
   fe->n_total = (long long)TRXSIG_OUTHISTORY * rate_factor;   // (the zero history in front of the stream holds raw samples 0 .. hist - 1)
   Guard g(trxsig_device(c));
@@ -163,9 +168,10 @@ int trxsig_rxfe_create_wideband(trxsig_rxfe **out, trxsig_ctx *c, int n_wide_str
   if (hipMalloc((void **)&fe->d_hist, hb) != hipSuccess || hipMemset(fe->d_hist, 0, hb) != hipSuccess ||
       hipMalloc((void **)&fe->d_freq, sizeof(float) * (size_t)n_carriers) != hipSuccess ||
       hipMemcpy(fe->d_freq, h_carrier_freq, sizeof(float) * (size_t)n_carriers, hipMemcpyHostToDevice) != hipSuccess) {
+    const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create_wideband: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
     trxsig_rxfe_destroy(fe);
     *out = nullptr;
-    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_rxfe_create_wideband: device allocation failed", hipSuccess);
+    return rc;
   }
   return TRXSIG_OK;
 }
@@ -438,8 +444,9 @@ int trxsig_txbe_create(trxsig_txbe **out, trxsig_ctx *c, int n_streams, int max_
        hipMalloc((void **)&be->d_rgain, sizeof(float) * (size_t)be->ring_cap * be->S) == hipSuccess &&
        hipMalloc((void **)&be->d_tab, sizeof(int32_t) * 2 * (size_t)be->tab_cap) == hipSuccess && be->ring_cap < 65536;
   if (!ok) {
+    const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_txbe_create: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
     trxsig_txbe_destroy(be);
-    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_txbe_create: device allocation failed", hipSuccess);
+    return rc;
   }
   *out = be;
   return TRXSIG_OK;
@@ -465,10 +472,15 @@ int trxsig_txbe_set_fused(trxsig_txbe *be, int fused) {
   return TRXSIG_OK;
 }
 
-int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_t *h_guard, const float *d_gain, int n_bursts) {
+int trxsig_txbe_streams(const trxsig_txbe *be) { return be ? be->S : TRXSIG_EINVAL; }
+extern "C++" { trxsig_ctx *trx_txbe_context(const trxsig_txbe *be) { return be ? be->c : nullptr; } }
+
+// everything trxsig_txbe_push_bursts can refuse, checked without touching the back end (the Transceiver group asks BEFORE it pops
+// its transmit queue: a refused push must not have consumed the bursts)
+int trxsig_txbe_can_push(trxsig_txbe *be, const int32_t *h_guard, int n_bursts) {
   if (!be) return TRXSIG_EINVAL;
   trxsig_ctx *c = be->c;
-  if (!d_bits || !h_guard || n_bursts <= 0 || n_bursts > be->max_bursts)
+  if (!h_guard || n_bursts <= 0 || n_bursts > be->max_bursts)
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: bad argument", hipSuccess);
   long long tot = 0;
   for (int j = 0; j < n_bursts; j++) {
@@ -477,13 +489,24 @@ int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_
   }
   if (be->inhist + be->fill + tot > be->stride)
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: send buffers full (call trxsig_txbe_pop first)", hipSuccess);
+  if (be->fused && (int)be->live.size() + n_bursts > be->ring_cap)
+    return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: burst ring full (call trxsig_txbe_pop first)", hipSuccess);
+  return TRXSIG_OK;
+}
+
+int trxsig_txbe_push_bursts(trxsig_txbe *be, const uint8_t *d_bits, const int32_t *h_guard, const float *d_gain, int n_bursts) {
+  if (!be) return TRXSIG_EINVAL;
+  trxsig_ctx *c = be->c;
+  if (!d_bits) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: bad argument", hipSuccess);
+  const int ok = trxsig_txbe_can_push(be, h_guard, n_bursts);
+  if (ok != TRXSIG_OK) return ok;
+  long long tot = 0;
+  for (int j = 0; j < n_bursts; j++) tot += (long long)be->sps * (148 + h_guard[j]);
   Guard g(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   be->started = 1;
   if (be->fused) {
     // only the bits travel: burst j of this push takes ring slot head + j and starts where the pending samples end
-    if ((int)be->live.size() + n_bursts > be->ring_cap)
-      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_txbe_push_bursts: burst ring full (call trxsig_txbe_pop first)", hipSuccess);
     FE_HIP(c, trx_launch_tx_ring_store(st, d_bits, d_gain, be->S, n_bursts, be->ring_head, be->ring_cap, be->d_ring, be->d_rgain));
     long long pos = (long long)be->inhist + be->fill;
     for (int j = 0; j < n_bursts; j++) {

@@ -94,6 +94,17 @@ hipError_t trx_launch_rach_fast(hipStream_t st, int sps, const TrxTables *dT, co
 
 // need_mask != 0: burst enabled iff (flags[b] & need_mask) == need_mask; need_mask == 0: iff flags[b] != 0;
 // flags == NULL: every burst enabled.
+// Library-wide implementation knobs (A/B measurements and the tests that force a route): set through trxsig_set_tuning, read by the
+// launchers -- the library reads NO environment variable on a launch path.  Defaults in trxsig_api.cpp.
+enum { TRX_KNOB_EQ_TAIL = 0,      // 1 = k_eq_dfe4 (scale + delay + DFE in one kernel, default), 2 = k_eq_delay + k_eq_dfe2 through the scratch rows
+       TRX_KNOB_EQ_DENSE = 1,     // marked bursts above which the lane-per-burst k_eq_detect takes over from the wave-per-burst estimate (4096)
+       TRX_KNOB_RXRES_WPB = 2,    // k_rx_resample: windows per workgroup; 0 = chosen from the launch size
+       TRX_KNOB_RXRES_ROWS = 3,   // k_rx_resample: 1 = tap rows in visiting order (default), 0 = in branch order
+       TRX_KNOB_CHAN_TPW = 4,     // k_channelise16: tiles per workgroup; 0 = chosen from the launch size
+       TRX_KNOB_COUNT = 5 };
+int trx_knob(int id);
+void trx_knob_set(int id, int value);
+
 hipError_t trx_launch_demod(hipStream_t st, int sps, const TrxTables *dT, const trx_c32 *samples,
                             const int32_t *off, const int32_t *len, int B, const trx_c32 *amp,
                             const float *toa, const uint8_t *flags, int need_mask, float *soft,

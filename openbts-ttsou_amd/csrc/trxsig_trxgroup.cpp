@@ -88,6 +88,7 @@ struct trxsig_trxgroup {
   } wk[2];
   int cur = 0;                                              // the set of the last pull
   bool pipelined = false;
+  int beside_rows = 0x7fffffff;      // trxsig_trxgroup_set_beside_rows: calls with at least this many rows replay on the side stream (kBesideRows)
   DevBuf<trx_c32> w_tab, b_tab, in;
   DevBuf<float> chan_off;
   std::vector<int32_t> h_seg;
@@ -120,7 +121,7 @@ namespace {
 // replay was a chain of ~0.1 us per timeslot and hid under the demodulator.  Since round 4 a long call's replay runs parallel in
 // time (k_group_replay_seg: 15 us instead of 88 for 468 slots) and, started beside a kernel that fills the machine, its few
 // workgroups wait for that kernel to drain (80 us): everything on ONE stream is faster (309 against 279 Mbursts/s on bench.py
-// --workload config4).  The side-stream arrangement stays selectable (environment TRXSIG_GROUP_BESIDE_ROWS) and tested.
+// --workload config4).  The side-stream arrangement stays selectable (trxsig_trxgroup_set_beside_rows) and tested.
 constexpr int kBesideRows = 0x7fffffff;
 #define G_HIP(g, call)                                                          \
   do {                                                                          \
@@ -201,8 +202,9 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
       hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->wk[0].done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->wk[1].done, hipEventDisableTiming) != hipSuccess) {
+    const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
     trxsig_trxgroup_destroy(g);
-    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);
+    return rc;
   }
   *out = g;
   return TRXSIG_OK;
@@ -387,9 +389,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   // (a cross-stream dependency costs ~10 us each way: a small call keeps everything on one stream -- 1,024 bursts took 77
   // instead of 48 us with the fork, 65,536 take 229 instead of 281)
   const bool lean = !equalize;
-  const char *beside_env = std::getenv("TRXSIG_GROUP_BESIDE_ROWS");          // (A/B and the tests of the side-stream arrangement)
-  const int beside_rows = beside_env ? std::atoi(beside_env) : kBesideRows;
-  const bool beside = lean && n_rows >= beside_rows;
+  const bool beside = lean && n_rows >= g->beside_rows;   // (trxsig_trxgroup_set_beside_rows: A/B and the tests of the side-stream arrangement)
   const bool piped = beside && g->pipelined;                // the join is left to the next call but one / trxsig_trxgroup_sync
   if (!piped) G_LIB(join_side(g, st));                      // (state order: nothing replays on this stream before the side stream is done)
   // (an error return between the fork and the join must not leave the side stream working on this call's arrays)
@@ -590,6 +590,15 @@ int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on) {
   return TRXSIG_OK;
 }
 
+int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows) {
+  if (!g) return TRXSIG_EINVAL;
+  if (rows < 0) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_set_beside_rows: negative threshold", hipSuccess);
+  Guard gd(trxsig_device(g->c));
+  G_LIB(join_side(g, (hipStream_t)trxsig_get_stream(g->c)));
+  g->beside_rows = rows == 0 ? kBesideRows : rows;
+  return TRXSIG_OK;
+}
+
 int trxsig_trxgroup_sync(trxsig_trxgroup *g) {
   if (!g) return TRXSIG_EINVAL;
   Guard gd(trxsig_device(g->c));
@@ -743,7 +752,9 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
                          const uint8_t **d_from_queue) {
   if (!g) return TRXSIG_EINVAL;
   trxsig_ctx *c = g->c;
-  if (fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7 || n_slots <= 0 || (long long)n_slots * g->S > (1LL << 28))
+  // (n_slots < 8 * gHyperframe: k_group_tx_push wraps a slot's frame number with at most two subtractions, trxsig_grouptx.hip)
+  if (fn < 0 || fn >= kHyperframe || tn < 0 || tn > 7 || n_slots <= 0 || (long long)n_slots * g->S > (1LL << 28) ||
+      (long long)n_slots >= 8LL * kHyperframe)
     return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_push: bad argument", hipSuccess);
   Guard gd(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
@@ -767,11 +778,19 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
 int trxsig_trxgroup_push_txbe(trxsig_trxgroup *g, trxsig_txbe *be, int fn, int tn, int n_slots) {
   if (!g) return TRXSIG_EINVAL;
   if (!be) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_push_txbe: no back end", hipSuccess);
+  // everything the back end could refuse is settled BEFORE the queue is popped: a refused call leaves queue, filler table and the
+  // caller's deadline clock where they were (the bursts of those slots are not consumed)
+  if (trx_txbe_context(be) != g->c)
+    return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_push_txbe: the back end lives on another context (another stream: its reads would race the gather)", hipSuccess);
+  if (trxsig_txbe_streams(be) != g->S)
+    return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_push_txbe: the back end's stream count is not the group's ARFCN count", hipSuccess);
+  if (n_slots <= 0 || tn < 0 || tn > 7) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_push_txbe: bad argument", hipSuccess);
+  std::vector<int32_t> guard((size_t)n_slots);
+  for (int t = 0; t < n_slots; t++) guard[(size_t)t] = 8 + ((((tn + t) & 7) % 4) == 0);   // modulateBurst(..., 8 + (TN % 4 == 0), ...) (:105)
+  G_LIB(trxsig_txbe_can_push(be, guard.data(), n_slots));
   const uint8_t *bits = nullptr;
   const float *gain = nullptr;
   G_LIB(trxsig_trxgroup_push(g, fn, tn, n_slots, &bits, &gain, nullptr));
-  std::vector<int32_t> guard((size_t)n_slots);
-  for (int t = 0; t < n_slots; t++) guard[(size_t)t] = 8 + ((((tn + t) & 7) % 4) == 0);   // modulateBurst(..., 8 + (TN % 4 == 0), ...) (:105)
   return trxsig_txbe_push_bursts(be, bits, guard.data(), gain, n_slots);
 }
 

@@ -483,13 +483,13 @@ hipError_t trx_launch_resample_ex(hipStream_t st, TrxResampleArgs a, int S, int 
     // windows per workgroup: enough workgroups left to fill the machine several times over, else one window each
     int wpb = 1;
     while (wpb < 8 && (long long)S * (n_windows / (2 * wpb)) >= 4096) wpb *= 2;
-    if (const char *e = std::getenv("TRXSIG_RXRES_WPB")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) wpb = v; }   // (tests: small cases through the multi-window loop)
+    { const int v = trx_knob(TRX_KNOB_RXRES_WPB); if (v >= 1 && v <= 64) wpb = v; }   // (TRXSIG_TUNE_RXRES_WPB; tests: small cases through the multi-window loop)
     const dim3 g2(1, (n_windows + wpb - 1) / wpb, S);
     a.row_inv = 0;                                          // (Q mod P)^-1 mod P, if it exists: the rows of the tap table in visiting order
     for (int v = 1; v < a.P; v++)
       if (((long long)v * (a.Q % a.P)) % a.P == 1) { a.row_inv = v; break; }
     if ((long long)a.P * a.P > 0x7fffffffLL) a.row_inv = 0;
-    if (const char *e = std::getenv("TRXSIG_RXRES_ROWS")) { if (std::atoi(e) == 0) a.row_inv = 0; }   // (A/B: rows in branch order)
+    if (trx_knob(TRX_KNOB_RXRES_ROWS) == 0) a.row_inv = 0;   // (TRXSIG_TUNE_RXRES_ROWS, A/B: rows in branch order)
     if (kq == 1) k_rx_resample<1><<<g2, block, lds2, st>>>(a, n_windows, wpb);
     else if (kq == 2) k_rx_resample<2><<<g2, block, lds2, st>>>(a, n_windows, wpb);
     else k_rx_resample<4><<<g2, block, lds2, st>>>(a, n_windows, wpb);

@@ -15,7 +15,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TRXQ_HD __host__ __device__ __forceinline__
 #else
 #define TRXQ_HD inline

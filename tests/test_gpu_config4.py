@@ -141,7 +141,7 @@ def test_multi_chunk_push_equals_chunk_by_chunk(golden):
 
 
 @pytest.mark.parametrize("sps,table,taps_per_output", [(1, "sendLPF_961_raw", 15), (1, "rcvLPF_651_raw", 11), (2, "sendLPF_961_raw", 8)])
-def test_rx_resampler_with_many_taps_per_output(golden, sps, table, taps_per_output, monkeypatch):
+def test_rx_resampler_with_many_taps_per_output(golden, sps, table, taps_per_output, request):
     """k_rx_resample<KQ> beyond four taps per output: the reference's own receive configuration is one sample per symbol, 65 : 96
     with its 961-tap table (createLPF(., 961, 65): radioInterface.cpp:230-234) = 15 taps per output.  The resampled streams
     equal the oracle's polyphaseResampleVector chunk by chunk behind the 192-sample history, bit for bit."""
@@ -155,9 +155,10 @@ def test_rx_resampler_with_many_taps_per_output(golden, sps, table, taps_per_out
     lpf = h.create_lpf(raw, 65.0 * sps)
     h.close()
     assert (len(lpf) + 65 * sps - 1) // (65 * sps) == taps_per_output
-    monkeypatch.setenv("TRXSIG_RXRES_WPB", "2")                # two windows per workgroup (what a 128-stream push does) in this small case
     iq, nchunks = make_streams(sps, S, 12, 3, seed=21 + sps)
     ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    ctx.set_tuning(rxres_wpb=2)                                # two windows per workgroup (what a 128-stream push does) in this small case
+    request.addfinalizer(lambda: pkg.TrxSig(sps, 0).set_tuning(rxres_wpb=0))      # (library-wide: back to the default)
     fe = RxFrontEnd(ctx, S, lpf, max_chunks=4)
     o = oraclebind.Oracle(sps)
     hist = [np.zeros(OUTHISTORY, np.complex64) for _ in range(S)]
@@ -316,3 +317,29 @@ def test_objects_keep_their_context_alive():
     fe2 = RxFrontEnd(ctx2, 1, lpf, max_chunks=1)
     fe2.push_chunk(iq[:1]); torch.cuda.synchronize()
     fe2.close(); ctx2.close()
+
+
+def test_refused_front_end_leaves_the_context_unreferenced():
+    """trxsig_rxfe_create takes a reference on the context; every refusal path gives it back (round 4: the 2^31-sample refusal
+    did not, and that context was never destroyed).  trxsig_live_children counts the references."""
+    import ctypes as C
+    pkg = _pkg.load()
+    ctx = pkg.TrxSig(4, 0)
+    L = ctx.L
+    L.trxsig_live_children.argtypes = [C.c_void_p]
+    assert L.trxsig_live_children(ctx.h) == 0
+    lpf = np.ones(64, np.float32)
+    h = C.c_void_p()
+    L.trxsig_rxfe_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    # 65,535 streams x 65,535 chunks of 2,340 samples: beyond 2^31 samples (refused before anything is allocated)
+    rc = L.trxsig_rxfe_create(C.byref(h), ctx.h, 65535, 65535, lpf.ctypes.data, lpf.size, 1, 0)
+    assert rc == -1 and not h.value and b"2^31" in L.trxsig_last_error(ctx.h)
+    assert L.trxsig_live_children(ctx.h) == 0
+    rc = L.trxsig_rxfe_create(C.byref(h), ctx.h, 0, 4, lpf.ctypes.data, lpf.size, 1, 0)      # bad argument: no reference taken
+    assert rc == -1 and L.trxsig_live_children(ctx.h) == 0
+    rc = L.trxsig_rxfe_create(C.byref(h), ctx.h, 2, 4, lpf.ctypes.data, lpf.size, 1, 0)
+    assert rc == 0 and L.trxsig_live_children(ctx.h) == 1
+    L.trxsig_rxfe_destroy.argtypes = [C.c_void_p]
+    L.trxsig_rxfe_destroy(h)
+    assert L.trxsig_live_children(ctx.h) == 0
+    ctx.close()

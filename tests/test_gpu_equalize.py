@@ -77,11 +77,12 @@ def test_golden_dfe_52m(pkg, t1, golden):
 
 
 @pytest.mark.parametrize("variant52m,tail", [(True, None), (False, None), (True, "2")])
-def test_random_dfe_vs_oracle(pkg, t1, variant52m, tail, monkeypatch):
+def test_random_dfe_vs_oracle(pkg, t1, variant52m, tail, request):
     # tail "2": scaleVector + delayVector + equalizeBurst as two kernels through the scratch rows (k_eq_delay + k_eq_dfe2) instead of the fused
-    # k_eq_dfe4 (TRXSIG_EQ_TAIL, read at every call)
+    # k_eq_dfe4 (trxsig_set_tuning(TRXSIG_TUNE_EQ_TAIL): library-wide, read at every call)
     if tail:
-        monkeypatch.setenv("TRXSIG_EQ_TAIL", tail)
+        t1.set_tuning(eq_tail=int(tail))
+        request.addfinalizer(lambda: t1.set_tuning(eq_tail=1))
     rng = np.random.default_rng(99 + variant52m)
     o = oraclebind.Oracle(1, variant52m=variant52m)
     from openbts_ttsou_amd import synth

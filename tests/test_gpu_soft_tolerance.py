@@ -128,7 +128,7 @@ def test_hostile_bursts_equal_the_exact_mode(pkg):
     tt = pkg.TrxSig(sps, 0); tt.use_torch_stream(); tt.set_soft_mode(pkg.SOFT_TOLERANCE)
     base_x, off, length, meta = synth.normal_batch(sps, 64, tsc, seed=77, sigmas=(0.0, 0.05))
     x = base_x.copy()
-    amp = np.full(64, 1.0 + 0.5j, np.complex64)
+    amp = np.asarray(meta["amp"], np.complex64).copy()       # the channel the bursts were made with: soft symbols near +-1, Z about 1.5
     toa = np.zeros(64, np.float32)
     rng = np.random.default_rng(3)
     toa[:] = (rng.integers(-3 * 512, 6 * 512, 64) / 512.0).astype(np.float32)   # on the grid, |TOA| small
@@ -146,15 +146,15 @@ def test_hostile_bursts_equal_the_exact_mode(pkg):
     x[burst(22)][100] = complex(np.nan, 0); cases["a NaN sample"] = [22]
     x[burst(23)][200] = complex(0, np.inf); cases["an infinite sample"] = [23]
     x[burst(24)] = 0; cases["all-zero samples (every soft symbol on the slicer's 0.5)"] = [24]
-    x[burst(25)] *= np.float32(1e-20); amp[25] = np.complex64(1e-20); cases["tiny samples, tiny amplitude"] = [25]
-    x[burst(26)] *= np.float32(1e20); amp[26] = np.complex64(1e20); cases["huge samples, huge amplitude"] = [26]
-    amp[27] = np.complex64(0.01); cases["Z far above 8"] = [27]
+    x[burst(25)] *= np.float32(1e-20); amp[25] *= np.float32(1e-20); cases["tiny samples, tiny amplitude"] = [25]
+    x[burst(26)] *= np.float32(1e20); amp[26] *= np.float32(1e20); cases["huge samples, huge amplitude"] = [26]
+    amp[27] *= np.float32(0.01); cases["Z far above 8"] = [27]
     toa[28] = np.float32(-2.0); cases["integer delay (no filter)"] = [28]
     toa[29] = np.float32(1.00390625); cases["fraction 0.996"] = [29]
     toa[30] = np.float32(14.5); cases["samples fall off the front of the staging area"] = [30]
     toa[31] = np.float32(-3.5); cases["the first soft symbol reads before the burst"] = [31]
     toa[32] = np.float32(-0.001953125); cases["fraction 1/512: below the filter threshold"] = [32]
-    amp[33] = np.complex64(1e-30); cases["denormal-range 1/amp products"] = [33]
+    x[burst(33)] *= np.float32(1e-30); amp[33] *= np.float32(1e-30); cases["1/amp beyond 1e15"] = [33]
     x[burst(34)][::2] = 0; cases["every other sample zero"] = [34]
     cases["ordinary, second half"] = list(range(35, 64))
 

@@ -102,11 +102,13 @@ def build_cells(sps, S, n_slots, fn0, tn0, seed, quiet_slots=(700, 1200)):
     return x, ctype
 
 
-def run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, pipelined=False):
+def run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, pipelined=False, beside_rows=0):
     import torch
     ctx = pkg.TrxSig(sps, 0)
     ctx.use_torch_stream()
     g = pkg.TrxGroup(ctx, S, tsc_leg=leg, start=(fn0, tn0))
+    if beside_rows:
+        g.set_beside_rows(beside_rows)
     if pipelined:
         g.set_pipelined(True)
     cell = x.shape[2]
@@ -158,11 +160,13 @@ def check_against(name, pull, ctype, x, sps, out, arfcns, fn0, tn0, thr_of):
 
 
 @pytest.mark.parametrize("sps,leg,frames,dense", [(1, 0, 200, None), (1, 0, 200, 0), (4, 1, 60, None)])
-def test_group_equals_single_objects_and_model(pkg, sps, leg, frames, dense, monkeypatch):
+def test_group_equals_single_objects_and_model(pkg, sps, leg, frames, dense, request):
     # dense = 0: the equalising leg's channel estimates through the lane-per-burst kernel, the route for calls with MANY marked bursts
-    # (TRXSIG_EQ_DENSE: the number of marked bursts above which it takes over from the wave-per-burst kernel; default 4096)
+    # (TRXSIG_TUNE_EQ_DENSE, library-wide: the number of marked bursts above which it takes over from the wave-per-burst kernel; default 4096)
     if dense is not None:
-        monkeypatch.setenv("TRXSIG_EQ_DENSE", str(dense))
+        knob = pkg.TrxSig(sps, 0)
+        knob.set_tuning(eq_dense=dense)
+        request.addfinalizer(lambda: (knob.set_tuning(eq_dense=4096), knob.close()))
     S, fn0, tn0 = 128, 1000, 3
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=100 + sps)
@@ -226,26 +230,25 @@ def test_group_across_the_hyperframe_wrap(pkg, tn0):
                   lambda a: models[a].energy_threshold)
 
 
-def test_pipelined_mode_gives_the_same(pkg, monkeypatch):
+def test_pipelined_mode_gives_the_same(pkg):
     """(The side-stream arrangement is no longer the default -- since the replay runs parallel in time, one stream is faster --
-    and is selected here through TRXSIG_GROUP_BESIDE_ROWS.)  trxsig_trxgroup_set_pipelined: large pulls leave their replay running on the side stream while the next pull's detectors
+    and is selected here through trxsig_trxgroup_set_beside_rows.)  trxsig_trxgroup_set_pipelined: large pulls leave their replay running on the side stream while the next pull's detectors
     fill the other workspace set.  Every output of every call (collected after each pull, which joins) equals the default mode's,
     with large and small calls mixed (a small call replays on the context's stream and has to wait for the side stream first);
     and two pipelined pulls in a row with nothing in between leave the FIRST one's result intact (two workspace sets)."""
     import torch
-    monkeypatch.setenv("TRXSIG_GROUP_BESIDE_ROWS", "24576")
     sps, leg, S, frames, fn0, tn0 = 4, 1, 128, 160, 5000, 6
     n_slots = 8 * frames
     x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=4242, quiet_slots=(300, 740))
     calls = (450, 8, 470, 3, 349)                                        # ~58 rows per slot here: from ~420 slots on a call is "large"
-    ref, _, thr_ref = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls)
-    out, _, thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, pipelined=True)
+    ref, _, thr_ref = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, beside_rows=24576)
+    out, _, thr = run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls, pipelined=True, beside_rows=24576)
     for key in ref:
         assert np.array_equal(ref[key], out[key], equal_nan=True), key
     assert np.array_equal(thr_ref, thr)
     # back to back: pull A, pull B, then read A's device result (valid until the second pull after it) and B's through collect
     ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
-    g = pkg.TrxGroup(ctx, S, tsc_leg=leg, start=(fn0, tn0)); g.set_pipelined(True)
+    g = pkg.TrxGroup(ctx, S, tsc_leg=leg, start=(fn0, tn0)); g.set_beside_rows(24576); g.set_pipelined(True)
     for a in range(S):
         configure(lambda c, a=a: g.control(a, c), a)
     cell = x.shape[2]
@@ -443,13 +446,12 @@ def test_group_on_the_fused_front_end(pkg):
     ga.close(); gb.close(); fea.close(); feb.close(); ctx.close()
 
 
-def test_pipelined_mode_on_the_fused_front_end(pkg, monkeypatch):
+def test_pipelined_mode_on_the_fused_front_end(pkg):
     """trxsig_trxgroup_pull_rxfe with trxsig_trxgroup_set_pipelined: 128 ARFCN streams x three pushes of 125 chunks (1,000 slots,
     ~59,000 rows each: large calls), the replay of push i overlapping the detectors of push i+1 -- every collected output and
     the final thresholds equal the default mode's on the same int16 streams (normal bursts at 400 kS/s, combination V on TN 0 of
     every 8th ARFCN so that the access-burst detector and false detections are in play, a stretch of silence)."""
     import torch
-    monkeypatch.setenv("TRXSIG_GROUP_BESIDE_ROWS", "24576")          # (the side-stream arrangement, no longer the default)
     from openbts_ttsou_amd.frontend import RxFrontEnd
     sps, S, K, tsc, pushes = 4, 128, 125, 2, 3
     dev = torch.device("cuda:0")
@@ -468,6 +470,7 @@ def test_pipelined_mode_on_the_fused_front_end(pkg, monkeypatch):
     for piped in (False, True):
         ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
         g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
+        g.set_beside_rows(24576)                                         # (the side-stream arrangement, no longer the default)
         fe = RxFrontEnd(ctx, S, lpf, max_chunks=K)
         for a in range(S):
             g.control(a, "CMD SETTSC %d" % tsc)

@@ -184,3 +184,50 @@ def test_group_transmit_refusals_and_overflow(pkg):
     dummy = np.array([int(c) for c in tm.DUMMY_BURST], np.uint8)
     assert np.array_equal(b.cpu().numpy()[1, 5], dummy) and float(g.cpu().numpy()[1, 5]) == 1.0
     grp.close(); ctx.close()
+
+
+def test_push_txbe_refusals_leave_the_queue_alone(pkg):
+    """trxsig_trxgroup_push_txbe settles everything the back end could refuse BEFORE it pops the transmit queue: a back end with
+    another stream count, a back end on another context, and a back end whose send buffers cannot take the push all answer
+    EINVAL with the queued bursts still queued (the caller's deadline clock has not advanced either); the same push into a
+    back end with room then sends them."""
+    import torch
+    from openbts_ttsou_amd.frontend import TxBackEnd
+    from openbts_ttsou_amd import synth
+    sps, S = 1, 4
+    ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
+    other = pkg.TrxSig(sps, 0); other.use_torch_stream()
+    grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+    lpf = synth.design_lpf(961, 65 * sps)
+    bits = np.ones(148, np.uint8)
+    grp.add_bursts(np.stack([datagram(k % 8, 2000 + k // 8, 0, bits) for k in range(16)]), np.full(16, 1, np.int32))
+    assert grp.tx_queue_size(1) == (16, False)
+    wrong_s = TxBackEnd(ctx, S + 1, lpf, max_bursts=16)
+    wrong_ctx = TxBackEnd(other, S, lpf, max_bursts=16)
+    small = TxBackEnd(ctx, S, lpf, max_bursts=4)             # 8 slots do not fit a back end made for 4 bursts per push
+    good = TxBackEnd(ctx, S, lpf, max_bursts=16)
+    for be in (wrong_s, wrong_ctx, small):
+        with pytest.raises(pkg.TrxSigError):
+            grp.push_txbe(be, 2000, 0, 8)
+        assert grp.tx_queue_size(1) == (16, False)
+    # a full back end: fill `good` until it refuses, then the group's push is refused too and the queue is untouched
+    filler = np.zeros((S, 16, 148), np.uint8)
+    guard = np.array([8 + ((t % 8) % 4 == 0) for t in range(16)], np.int32)
+    n_fill = 0
+    while True:
+        try:
+            good.push_bursts(filler, guard)
+            n_fill += 1
+        except pkg.TrxSigError:
+            break
+        assert n_fill < 64
+    with pytest.raises(pkg.TrxSigError):
+        grp.push_txbe(good, 2000, 0, 16)
+    assert grp.tx_queue_size(1) == (16, False)
+    roomy = TxBackEnd(ctx, S, lpf, max_bursts=16)
+    grp.push_txbe(roomy, 2000, 0, 16)
+    torch.cuda.synchronize()
+    assert grp.tx_queue_size(1) == (0, False)
+    for be in (wrong_s, wrong_ctx, small, good, roomy):
+        be.close()
+    grp.close(); ctx.close(); other.close()
