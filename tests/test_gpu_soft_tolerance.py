@@ -143,8 +143,9 @@ def test_hostile_bursts_equal_the_exact_mode(pkg):
     toa[19] = np.float32(0.3); cases["TOA off the grid"] = [19]
     toa[20] = np.float32(np.nan); cases["TOA NaN"] = [20]
     toa[21] = np.float32(5000.0); cases["TOA out of range"] = [21]
-    x[burst(22)][100] = complex(np.nan, 0); cases["a NaN sample"] = [22]
-    x[burst(23)][200] = complex(0, np.inf); cases["an infinite sample"] = [23]
+    # (a TOA with a real fraction: with |frac| <= 0.01 delayVector does not filter and three samples in four are never read)
+    x[burst(22)][100] = complex(np.nan, 0); toa[22] = np.float32(0.5); cases["a NaN sample"] = [22]
+    x[burst(23)][200] = complex(0, np.inf); toa[23] = np.float32(1.25); cases["an infinite sample"] = [23]
     x[burst(24)] = 0; cases["all-zero samples (every soft symbol on the slicer's 0.5)"] = [24]
     x[burst(25)] *= np.float32(1e-20); amp[25] *= np.float32(1e-20); cases["tiny samples, tiny amplitude"] = [25]
     x[burst(26)] *= np.float32(1e20); amp[26] *= np.float32(1e20); cases["huge samples, huge amplitude"] = [26]
