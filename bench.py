@@ -328,6 +328,7 @@ class Config4:
         # its createLPF(., 961, 65) table, Transceiver with the equaliser (designDFE + equalizeBurst behind the per-slot channel
         # cache) -- through the Transceiver group (equalising leg) on a push / pop front end
         self.refchain = bool(getattr(args, "reference_chain", False))
+        self.soft_mode = getattr(args, "soft_mode", "tolerance")
         if self.refchain:
             self.sps = 1
         self.per_chunk = 585 * self.sps                      # resampled samples per 864-sample chunk
@@ -504,8 +505,10 @@ class Config4:
                                                   "TN 0 of every 8th ARFCN (access-burst slots), combination I elsewhere --, adaptive energy threshold "
                                                   "per ARFCN replayed on the device, the resampled stream never written to HBM" if self.group else
                                                   ("one fused call, the resampled stream never written to HBM, TSC on every slot, fixed thresholds"
-                                                   if self.fused else "through the resampled complex float32 stream (push + pop + detect)")),
-                "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
+                                                   if self.fused else "through the resampled complex float32 stream (push + pop + detect)"))
+                            + ("; soft mode TOLERANCE (flags / amp / TOA / thresholds / hard bits bit-exact, soft bits within 7.4e-5)"
+                               if self.soft_mode == "tolerance" else "; soft mode EXACT"),
+                "soft_mode": self.soft_mode, "streams_per_gpu": self.S, "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
                 "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
 
     def sanity(self):
@@ -833,6 +836,8 @@ def main():
         ctx.set_tuning(spec_peak=args.spec_peak)
     if args.eq_tail != 1:
         ctx.set_tuning(eq_tail=args.eq_tail)
+    # demodulateBurst's arithmetic (normal, rach and config 4's demodulating legs; config 5 and the reference chain equalise instead)
+    ctx.set_soft_mode(pkg.SOFT_TOLERANCE if args.soft_mode == "tolerance" else pkg.SOFT_EXACT)
 
     wl.setup(pkg, ctx, dev, rank, args)
     step = wl.step

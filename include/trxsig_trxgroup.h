@@ -121,6 +121,10 @@ int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on);
  * least `rows` (slot, ARFCN) rows; 0 = never (the default since round 4: a long call's replay is parallel in time and one stream
  * is faster).  An implementation choice for A/B measurements and for pipelined mode; same values either way. */
 int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows);
+/* 1 (the default): trxsig_trxgroup_pull_rxfe runs the access-burst class's detectors (a few hundred bursts of a pull: launches that
+ * fill no machine) on the group's side stream BESIDE the normal-burst detectors; 0: one class after the other on the context's
+ * stream.  Same values; every output is ordered on the context's stream either way. */
+int trxsig_trxgroup_set_rach_beside(trxsig_trxgroup *g, int on);
 /* the context's stream waits for every replay still in flight on the side stream (no host wait) */
 int trxsig_trxgroup_sync(trxsig_trxgroup *g);
 /* mEnergyThreshold of one ARFCN now (synchronises) */

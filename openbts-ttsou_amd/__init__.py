@@ -695,6 +695,7 @@ class TrxGroup:
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
         L.trxsig_trxgroup_set_pipelined.argtypes = [vp, i32]
         L.trxsig_trxgroup_set_beside_rows.argtypes = [vp, i32]
+        L.trxsig_trxgroup_set_rach_beside.argtypes = [vp, i32]
         L.trxsig_trxgroup_sync.argtypes = [vp]
         L.trxsig_trxgroup_add_bursts.argtypes = [vp, vp, vp, i32]
         L.trxsig_trxgroup_push.argtypes = [vp, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -799,6 +800,10 @@ class TrxGroup:
     def set_pipelined(self, on=True):
         """Large pulls return without joining the side stream the state machine replays on (see trxsig_trxgroup.h)."""
         self._chk(self.L.trxsig_trxgroup_set_pipelined(self.h, 1 if on else 0), "trxsig_trxgroup_set_pipelined")
+
+    def set_rach_beside(self, on=True):
+        """Access-burst detectors of a fused pull on the side stream beside the normal-burst ones (default on)."""
+        self._chk(self.L.trxsig_trxgroup_set_rach_beside(self.h, 1 if on else 0), "trxsig_trxgroup_set_rach_beside")
 
     def set_beside_rows(self, rows):
         """Pulls with at least `rows` rows replay the state machine on the group's side stream (0 = never, the default)."""

@@ -589,7 +589,8 @@ int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float 
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
   HIPCHK(c, trx_launch_rx_normal(c->stream, c->d_tables, c->h_tables, gen, B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts,
-                                 d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->generic_taps, c->prof));
+                                 d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->generic_taps, c->prof,
+                                 c->soft_mode));
   return TRXSIG_OK;
 }
 int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
@@ -605,6 +606,18 @@ int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, in
                                c->cap_bursts, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   return TRXSIG_OK;
 }
+int trx_ctx_rx_rach_on(trxsig_ctx *c, hipStream_t st, float *d_rec, int rec_cap, const TrxRxGen &gen, const int32_t *d_len, int B,
+                       float detect_thresh, float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr) {
+  if (!c) return TRXSIG_EINVAL;
+  if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
+  if (B < 0 || !d_rec || rec_cap < B || (rec_cap & 255) || (B > 0 && (!d_len || !d_flags || !d_amp || !d_toa)))
+    return fail(c, TRXSIG_EINVAL, "trx_ctx_rx_rach_on: bad argument");
+  if (B == 0) return TRXSIG_OK;
+  DeviceGuard g(c->device);
+  HIPCHK(c, trx_launch_rx_rach(st, c->d_tables, gen, d_len, B, detect_thresh, energy_thresh, c->rach_amp_err, d_rec, rec_cap, d_flags,
+                               (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+  return TRXSIG_OK;
+}
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
                      int need_mask, float *d_soft, int nsoft, int soft_stride) {
   if (!c) return TRXSIG_EINVAL;
@@ -614,7 +627,7 @@ int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32
   if (B == 0 || nsoft == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
   HIPCHK(c, trx_launch_rx_demod(c->stream, c->d_tables, gen, B, (const trx_c32 *)d_amp, d_toa, d_enable, need_mask, d_soft, nullptr, nsoft,
-                                soft_stride, c->prof));
+                                soft_stride, c->prof, c->soft_mode));
   return TRXSIG_OK;
 }
 // trxsig_demodulate_batch with the enable test spelt out: a burst is demodulated when (d_enable[b] & need_mask) == need_mask

@@ -369,9 +369,12 @@ __device__ __forceinline__ float umax_f(float a, float b) {
 #define TRX_TOL_ZMAX 8.0f                     /* fast form only when max|x| * |1/amp|_1 <= this: |soft' - soft| <= 7.4e-5 guaranteed */
 #define TRX_TOL_GUARD 3.0517578125e-05f       /* 512 u = 2^-15: |re'| must exceed this times Z (+ 2^-22) for the hard bit to be safe */
 
-template <int SPS>
-__device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + 63) / 64],
-                                                int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft) {
+// fused_demod_tol_ex: the staging step handed in, as fused_demod_ex -- stage_raw(P, lo) writes sample n, AS IT IS, to position
+// u = n + lo (entry (u % SPS) * QLEN + u / SPS) for every n in [0, N) whose position lies in [0, U); it is only called with
+// lo >= 0, after the positions outside [lo, lo + N) have been zeroed.  xm_lane: max(|re|, |im|) over the samples this lane holds.
+template <int SPS, typename STAGE>
+__device__ __forceinline__ bool fused_demod_tol_ex(const TrxTables *__restrict__ T, cx *P, int N, cx amp, float toa, int hl, float *sb,
+                                                   uint8_t *hbp, int nsoft, float xm_lane, STAGE stage_raw) {
   typedef FusedGeom<SPS, 64> G;
   typedef typename G::D D;
   static_assert(128 % SPS == 0, "pairs of a lane keep their phase from load to load");
@@ -387,12 +390,7 @@ __device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T,
   int f = (int)f512;
   const int lo = io + D::C, hi = N + io + D::C;            // samples occupy positions [lo, hi)
   // ---- may this burst take the fast form at all? (every quantity is wave-uniform) ----
-  float xm = 0.0f;
-#pragma unroll
-  for (int i = 0; i < G::NLD; i++) {                       // (lanes past the burst's end hold zeros)
-    xm = max3_abs(v[i].x, v[i].y, xm);
-    xm = max3_abs(v[i].z, v[i].w, xm);
-  }
+  float xm = xm_lane;
   xm = umax_f(xm, dpp_f<0xB1>(xm));
   xm = umax_f(xm, dpp_f<0x4E>(xm));
   xm = umax_f(xm, dpp_f<0x141>(xm));
@@ -414,18 +412,7 @@ __device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T,
   wave_lds_fence();
   for (int u = hl; u < lo && u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
   for (int u = hi + hl; u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
-  {
-    const int ua = 2 * hl + lo, ub = ua + 1;
-    cx *pa = P + (ua % SPS) * D::QLEN + ua / SPS;
-    cx *pb = P + (ub % SPS) * D::QLEN + ub / SPS;
-#pragma unroll
-    for (int i = 0; i < G::NLD; i++) {
-      if (2 * (hl + 64 * i) < N) {
-        if (ua + 128 * i < D::U) pa[i * (128 / SPS)] = mk(v[i].x, v[i].y);
-        if (ub + 128 * i < D::U) pb[i * (128 / SPS)] = mk(v[i].z, v[i].w);
-      }
-    }
-  }
+  stage_raw(P, lo);
   wave_lds_fence();
 
   cx y[G::OPL];
@@ -493,6 +480,33 @@ __device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T,
   return true;
 }
 
+
+// the same from the 16-byte loads of k_demod / k_normal_quad / k_normal_chain: pair q = hl + 64 i of v[] holds samples 2q, 2q+1
+template <int SPS>
+__device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T, cx *P, const float4 (&v)[(157 * SPS / 2 + 63) / 64],
+                                                int N, cx amp, float toa, int hl, float *sb, uint8_t *hbp, int nsoft) {
+  typedef FusedGeom<SPS, 64> G;
+  typedef typename G::D D;
+  float xm = 0.0f;
+#pragma unroll
+  for (int i = 0; i < G::NLD; i++) {                       // (lanes past the burst's end hold zeros)
+    xm = max3_abs(v[i].x, v[i].y, xm);
+    xm = max3_abs(v[i].z, v[i].w, xm);
+  }
+  auto stage_raw = [&](cx *P_, int lo) {
+    const int ua = 2 * hl + lo, ub = ua + 1;
+    cx *pa = P_ + (ua % SPS) * D::QLEN + ua / SPS;
+    cx *pb = P_ + (ub % SPS) * D::QLEN + ub / SPS;
+#pragma unroll
+    for (int i = 0; i < G::NLD; i++) {
+      if (2 * (hl + 64 * i) < N) {
+        if (ua + 128 * i < D::U) pa[i * (128 / SPS)] = mk(v[i].x, v[i].y);
+        if (ub + 128 * i < D::U) pb[i * (128 / SPS)] = mk(v[i].z, v[i].w);
+      }
+    }
+  };
+  return fused_demod_tol_ex<SPS>(T, P, N, amp, toa, hl, sb, hbp, nsoft, xm, stage_raw);
+}
 
 template <int SPS, bool RAW, int NSMAX, typename SMP = SmpC32, bool TOL = false>
 __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES) void k_demod(const TrxTables *__restrict__ T,

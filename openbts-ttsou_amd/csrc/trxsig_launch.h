@@ -164,7 +164,7 @@ struct TrxRxGen {
 hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const TrxRxGen &gen, int B, int tsc,
                                 float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp,
                                 float *toa, float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps,
-                                TrxProfiler *prof);
+                                TrxProfiler *prof, int soft_tolerance = 0);
 // the other legs on bursts computed from the raw stream (the Transceiver group's fused front end): detectRACHBurst
 // (k_rach_front_rx + k_rach_peak2 + the hand-over in k_rach_fast_rx; ws as trx_launch_rach_fast) and demodulateBurst alone
 // with caller-supplied amplitude / TOA / enable flags (k_demod_rx)
@@ -172,7 +172,8 @@ hipError_t trx_launch_rx_rach(hipStream_t st, const TrxTables *dT, const TrxRxGe
                               float detect_thresh, float energy_thresh, float amp_err, float *ws, int Bpad, uint8_t *flags, trx_c32 *amp,
                               float *toa, float *avgpwr, TrxProfiler *prof);
 hipError_t trx_launch_rx_demod(hipStream_t st, const TrxTables *dT, const TrxRxGen &gen, int B, const trx_c32 *amp, const float *toa,
-                               const uint8_t *flags, int need_mask, float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof);
+                               const uint8_t *flags, int need_mask, float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof,
+                               int soft_tolerance = 0);
 // pack: 0 = int16 I/Q -> complex float (swap: I/Q flipped), 1 = complex float -> int16 I/Q, 2 = fp16 I/Q -> complex float
 hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long long n, int swap, void *out,
                               TrxProfiler *prof, float gain = 1.0f /* pack == 1: scaleVector before the cast */);

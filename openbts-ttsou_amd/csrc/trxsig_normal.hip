@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, TRX_RXC_WPS) void k_tsc_corr_rx(TrxRxGen a, in
   corr_round<SPS, true, true, TAPCLS>(in, rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
 }
 
-template <int SPS>
+template <int SPS, bool TOL = false>
 __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES, TRX_RXD_WPS) void k_demod_rx(const TrxTables *__restrict__ T, TrxRxGen a, int B,
                                                                   const cx *__restrict__ amp_in, const float *__restrict__ toa_in,
                                                                   const uint8_t *__restrict__ flags, int need_mask,
@@ -532,6 +532,21 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES, TRX_RXD_WPS) void k_demod_rx(
       }
     }
   };
+  if (TOL) {                                                // TRXSIG_SOFT_TOLERANCE: the rearranged form unless this burst has to be exact
+    float xm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NSL; i++)
+      if (lane + 64 * i < N) xm = max3_abs(sv[i].r, sv[i].i, xm);
+    auto stage_raw = [&](cx *P, int lo) {                   // (lo >= 0: nothing falls off the front)
+      typedef DemodGeom<SPS, 148> D;
+      const int u0 = lane + lo;
+      cx *p0 = P + (u0 % SPS) * D::QLEN + u0 / SPS;
+#pragma unroll
+      for (int i = 0; i < NSL; i++)
+        if (lane + 64 * i < N && u0 + 64 * i < D::U) p0[i * (64 / SPS)] = sv[i];
+    };
+    if (fused_demod_tol_ex<SPS>(T, ph[wave], N, amp, toa, lane, sb, hb, nsoft, xm, stage_raw)) return;
+  }
   fused_demod_ex<SPS, 64>(T, ph[wave], N, amp, toa, lane, sb, hb, nsoft, stage, [] {}, nullptr, nullptr);   // (starts with an LDS fence)
 }
 
@@ -618,7 +633,7 @@ hipError_t trx_launch_tsc_detect(hipStream_t st, int sps, const TrxTables *dT, c
 hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTables *hT, const TrxRxGen &gen, int B, int tsc,
                                 float detect_thresh, float energy_thresh, trx_c32 *rec, int Bpad, uint8_t *flags, trx_c32 *amp,
                                 float *toa, float *avgpwr, float *soft, uint8_t *hard, int nsoft, int stride, int generic_taps,
-                                TrxProfiler *prof) {
+                                TrxProfiler *prof, int soft_tolerance) {
   if (B <= 0) return hipSuccess;
   if (nsoft > 148 || gen.nb <= 0) return hipErrorInvalidValue;
   constexpr int S = 4;
@@ -639,20 +654,29 @@ hipError_t trx_launch_rx_normal(hipStream_t st, const TrxTables *dT, const TrxTa
   if (prof) prof->end(TRXSIG_K_TSC_PEAK, st);
   if (nsoft > 0) {
     if (prof) prof->begin(TRXSIG_K_DEMOD, st);
-    k_demod_rx<S><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
-        dT, gen, B, amp, toa, flags, TRXSIG_F_DETECT, soft, hard, nsoft, stride);
+    if (soft_tolerance)
+      k_demod_rx<S, true><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
+          dT, gen, B, amp, toa, flags, TRXSIG_F_DETECT, soft, hard, nsoft, stride);
+    else
+      k_demod_rx<S><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(
+          dT, gen, B, amp, toa, flags, TRXSIG_F_DETECT, soft, hard, nsoft, stride);
     if (prof) prof->end(TRXSIG_K_DEMOD, st);
   }
   return hipGetLastError();
 }
 
 hipError_t trx_launch_rx_demod(hipStream_t st, const TrxTables *dT, const TrxRxGen &gen, int B, const trx_c32 *amp, const float *toa,
-                               const uint8_t *flags, int need_mask, float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof) {
+                               const uint8_t *flags, int need_mask, float *soft, uint8_t *hard, int nsoft, int stride, TrxProfiler *prof,
+                               int soft_tolerance) {
   if (B <= 0 || nsoft <= 0) return hipSuccess;
   if (nsoft > 148 || gen.nb <= 0) return hipErrorInvalidValue;
   if (prof) prof->begin(TRXSIG_K_DEMOD, st);
-  k_demod_rx<4><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, gen, B, amp, toa, flags, need_mask,
-                                                                                                          soft, hard, nsoft, stride);
+  if (soft_tolerance)
+    k_demod_rx<4, true><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, gen, B, amp, toa, flags,
+                                                                                                                  need_mask, soft, hard, nsoft, stride);
+  else
+    k_demod_rx<4><<<dim3((B + TRX_DEMOD_WAVES - 1) / TRX_DEMOD_WAVES), dim3(64 * TRX_DEMOD_WAVES), 0, st>>>(dT, gen, B, amp, toa, flags, need_mask,
+                                                                                                            soft, hard, nsoft, stride);
   if (prof) prof->end(TRXSIG_K_DEMOD, st);
   return hipGetLastError();
 }

@@ -89,6 +89,9 @@ struct trxsig_trxgroup {
   int cur = 0;                                              // the set of the last pull
   bool pipelined = false;
   int beside_rows = 0x7fffffff;      // trxsig_trxgroup_set_beside_rows: calls with at least this many rows replay on the side stream (kBesideRows)
+  DevBuf<float> rach_rec;            // record scratch of the access-burst class when it runs on the side stream (trx_rach_rec_floats per burst)
+  hipEvent_t ev_rach = nullptr;      // ... and the event the context's stream waits for before the state machine reads that class's answers
+  int rach_beside = 1;               // 1: the access-burst detectors of a fused pull run on the side stream beside the normal-burst ones
   DevBuf<trx_c32> w_tab, b_tab, in;
   DevBuf<float> chan_off;
   std::vector<int32_t> h_seg;
@@ -200,6 +203,7 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
       hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_rach, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->wk[0].done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->wk[1].done, hipEventDisableTiming) != hipSuccess) {
     const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
@@ -218,6 +222,8 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     if (g->side) { (void)hipStreamSynchronize(g->side); (void)hipStreamDestroy(g->side); }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->ev_rach) (void)hipEventDestroy(g->ev_rach);
+    g->rach_rec.release();
     (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
     for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
     g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
@@ -356,8 +362,31 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   G_HIP(g, trx_launch_group_expand(st, ex));
 
   // ---- the stateless detectors, a launch per class in use; thresholds 3.0 / 5.0 (:331, 363), energy gate off ----
+  // A fused pull's access-burst class (a few hundred bursts among tens of thousands: two latency-bound launches that fill
+  // no machine, 33 us of a 200 us step) runs on the SIDE stream beside the normal-burst detectors, from its own record scratch;
+  // the context's stream waits for it before the state machine reads the answers.
+  struct SideGuard {                                        // (an error return between a fork and its join must not leave the side stream working on this call's arrays)
+    hipStream_t s = nullptr;
+    ~SideGuard() { if (s) (void)hipStreamSynchronize(s); }
+  } side_guard;
+  bool rach_forked = false;
+  if (src.gen && g->rach_beside && count[TRXG_CLASS_RACH] > 0 && n_tsc > 0 && !g->wk[0].in_flight && !g->wk[1].in_flight) {
+    const int k = TRXG_CLASS_RACH, b0 = base[k];
+    const int cap = (count[k] + 255) & ~255;
+    G_HIP(g, g->rach_rec.need((size_t)trx_rach_rec_floats(sps) * (size_t)cap, st));
+    TrxRxGen gen = *src.gen;
+    gen.sel = W.off.p + b0;
+    G_HIP(g, hipEventRecord(g->ev_fork, st));               // (behind k_group_expand: the selection and the lengths are there)
+    G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
+    side_guard.s = g->side;
+    G_LIB(trx_ctx_rx_rach_on(c, g->side, g->rach_rec.p, cap, gen, W.len.p + b0, count[k], 5.0f, -1.0f, W.flags.p + b0,
+                             (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0, W.avgpwr.p + b0));
+    G_HIP(g, hipEventRecord(g->ev_rach, g->side));
+    rach_forked = true;
+  }
   for (int k = 0; k < TRXG_NCLASS; k++) {
     if (!count[k]) continue;
+    if (k == TRXG_CLASS_RACH && rach_forked) continue;
     const int b0 = base[k];
     if (src.gen) {                                          // the detectors compute their samples from the raw stream; off = the selection
       TrxRxGen gen = *src.gen;
@@ -392,11 +421,10 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   const bool beside = lean && n_rows >= g->beside_rows;   // (trxsig_trxgroup_set_beside_rows: A/B and the tests of the side-stream arrangement)
   const bool piped = beside && g->pipelined;                // the join is left to the next call but one / trxsig_trxgroup_sync
   if (!piped) G_LIB(join_side(g, st));                      // (state order: nothing replays on this stream before the side stream is done)
-  // (an error return between the fork and the join must not leave the side stream working on this call's arrays)
-  struct SideGuard {
-    hipStream_t s = nullptr;
-    ~SideGuard() { if (s) (void)hipStreamSynchronize(s); }
-  } side_guard;
+  if (rach_forked) {                                        // the access-burst class's answers: the state machine reads them next
+    G_HIP(g, hipStreamWaitEvent(st, g->ev_rach, 0));
+    side_guard.s = nullptr;
+  }
   G_HIP(g, trx_launch_group_pack(st, rp, W.packed.p));
   if (beside) {
     G_HIP(g, hipEventRecord(g->ev_fork, st));
@@ -596,6 +624,14 @@ int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows) {
   Guard gd(trxsig_device(g->c));
   G_LIB(join_side(g, (hipStream_t)trxsig_get_stream(g->c)));
   g->beside_rows = rows == 0 ? kBesideRows : rows;
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_set_rach_beside(trxsig_trxgroup *g, int on) {
+  if (!g) return TRXSIG_EINVAL;
+  Guard gd(trxsig_device(g->c));
+  G_LIB(join_side(g, (hipStream_t)trxsig_get_stream(g->c)));
+  g->rach_beside = on != 0;
   return TRXSIG_OK;
 }
 

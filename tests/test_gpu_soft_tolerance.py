@@ -252,3 +252,53 @@ def test_full_batch_sample_tolerance(pkg):
     assert_veq(tol["hard"][pick].cpu().numpy(), (soft > 0.5).astype(np.uint8), "hard")
     e, _ = grade(tol["soft"][pick].cpu().numpy()[okb], soft[okb], "soft")
     assert e <= MEASURED, e
+
+
+@pytest.mark.parametrize("rach_beside", [True, False])
+def test_group_on_the_fused_front_end_tolerance(pkg, rach_beside):
+    """The Transceiver group on the fused receive front end (config 4's default call: schedule with access-burst slots, per-ARFCN
+    threshold state, k_demod_rx) in tolerance mode against itself in exact mode, three pushes: valid / RSSI / timing / thresholds
+    identical, hard bits identical, soft bits within the bound -- with the access-burst class on the side stream and without."""
+    import torch
+    from openbts_ttsou_amd import synth as gsynth
+    from openbts_ttsou_amd.frontend import RxFrontEnd
+    sps, S, K, tsc, pushes = 4, 16, 25, 2, 3
+    dev = torch.device("cuda:0")
+    nb = (K * pushes * 585 // 156 + 4 + 3) // 4 * 4
+    x, off, length, meta = gsynth.normal_batch_torch(sps, S * nb, tsc, seed=91, device=dev, sigmas=(0.02, 0.05))
+    hi = x.reshape(-1)[: S * (x.numel() // S)].reshape(S, -1)
+    t = torch.arange(K * pushes * 864, device=dev, dtype=torch.float64) * (65.0 * sps / 96.0)
+    i0 = t.floor().long().clamp(max=hi.shape[1] - 2); fr = (t - i0).to(torch.float32)
+    lo = hi[:, i0] * (1 - fr) + hi[:, i0 + 1] * fr
+    lo = lo * (8000.0 / lo.abs().amax(dim=1, keepdim=True))
+    iq = torch.stack([lo.imag, lo.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()
+    lpf = gsynth.design_lpf(961, 65 * sps)
+    outs = []
+    for mode in (pkg.SOFT_EXACT, pkg.SOFT_TOLERANCE):
+        ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream(); ctx.set_soft_mode(mode)
+        g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
+        g.set_rach_beside(rach_beside)
+        fe = RxFrontEnd(ctx, S, lpf, max_chunks=K)
+        for a in range(S):
+            g.control(a, "CMD SETTSC %d" % tsc)
+            for tn in range(8):
+                g.control(a, "CMD SETSLOT %d %d" % (tn, 5 if (tn == 0 and a % 4 == 0) else 1))
+        got, slots = [], 0
+        for p in range(pushes):
+            ns, _ = g.pull_rxfe(fe, iq[:, p * K * 864:(p + 1) * K * 864], (slots // 8))
+            got.append(g.collect()); slots += ns
+        outs.append(got)
+        fe.close(); g.close(); ctx.close()
+    n_valid = 0
+    worst = 0.0
+    for a, b in zip(*outs):
+        for key in ("valid", "rssi", "timing", "threshold"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+        v = a["valid"]
+        n_valid += int(v.sum())
+        assert np.array_equal(a["soft"][v] > 0.5, b["soft"][v] > 0.5)
+        d = np.abs(a["soft"][v].astype(np.float64) - b["soft"][v])
+        assert d.max() <= BOUND
+        worst = max(worst, float(d.max()))
+        assert np.array_equal(a["soft"][~v], b["soft"][~v])
+    assert n_valid > 500 and 0 < worst <= 4 * MEASURED, (n_valid, worst)
