@@ -121,10 +121,6 @@ int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on);
  * least `rows` (slot, ARFCN) rows; 0 = never (the default since round 4: a long call's replay is parallel in time and one stream
  * is faster).  An implementation choice for A/B measurements and for pipelined mode; same values either way. */
 int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows);
-/* 1 (the default): trxsig_trxgroup_pull_rxfe runs the access-burst class's detectors (a few hundred bursts of a pull: launches that
- * fill no machine) on the group's side stream BESIDE the normal-burst detectors; 0: one class after the other on the context's
- * stream.  Same values; every output is ordered on the context's stream either way. */
-int trxsig_trxgroup_set_rach_beside(trxsig_trxgroup *g, int on);
 /* the context's stream waits for every replay still in flight on the side stream (no host wait) */
 int trxsig_trxgroup_sync(trxsig_trxgroup *g);
 /* mEnergyThreshold of one ARFCN now (synchronises) */
@@ -145,6 +141,15 @@ int trxsig_trxgroup_energy_threshold(trxsig_trxgroup *g, int arfcn, double *thr)
  * socket it arrived on).  A timeslot > 7, a frame number >= gHyperframe or an unknown ARFCN refuses the whole call
  * (TRXSIG_EINVAL, nothing queued; cf. trxsig_trx_decode_tx_datagram).  Asynchronous; the host buffers are consumed at return. */
 int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, const int32_t *h_arfcn, int n);
+/* The same without the host copy (round 5): the group lends a PINNED block to receive into -- recvfrom() straight into
+ * (*h_datagrams)[154 i], the socket's ARFCN into (*h_arfcn)[i], i < n_max -- and trxsig_trxgroup_add_staged(g, n) adds its first n
+ * datagrams: the host only checks the headers (the refusal rule above), the block goes up in one DMA as it arrived, and parsing
+ * (TN, big-endian FN, RSSI -> pow(10, -RSSI/10) with the integer division), the per-ARFCN sort that keeps the arrival order, the
+ * queue insertion and the payload copies are ONE kernel (k_group_tx_ingest).  Two blocks alternate: after add_staged the
+ * pointers are the DMA's; ask again for the next batch (the call waits, if it must, for the upload that last used that block).
+ * trxsig_trxgroup_add_bursts is this with a copy into the block first. */
+int trxsig_trxgroup_tx_staging(trxsig_trxgroup *g, int n_max, uint8_t **h_datagrams, int32_t **h_arfcn);
+int trxsig_trxgroup_add_staged(trxsig_trxgroup *g, int n);
 
 /* pushRadioVector(nowTime) for n_slots consecutive timeslots from (fn, tn), every ARFCN, in time order per ARFCN: stale bursts
  * (earlier than the slot) move to the filler table at THEIR time's entry, a burst for exactly the slot replaces the slot's

@@ -695,9 +695,10 @@ class TrxGroup:
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
         L.trxsig_trxgroup_set_pipelined.argtypes = [vp, i32]
         L.trxsig_trxgroup_set_beside_rows.argtypes = [vp, i32]
-        L.trxsig_trxgroup_set_rach_beside.argtypes = [vp, i32]
         L.trxsig_trxgroup_sync.argtypes = [vp]
         L.trxsig_trxgroup_add_bursts.argtypes = [vp, vp, vp, i32]
+        L.trxsig_trxgroup_tx_staging.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+        L.trxsig_trxgroup_add_staged.argtypes = [vp, i32]
         L.trxsig_trxgroup_push.argtypes = [vp, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.trxsig_trxgroup_push_txbe.argtypes = [vp, vp, i32, i32, i32]
         L.trxsig_trxgroup_tx_queue_size.argtypes = [vp, i32, C.POINTER(i32)]
@@ -758,6 +759,20 @@ class TrxGroup:
         assert d.ndim == 2 and d.shape[1] == 154 and a.shape == (d.shape[0],)
         self._chk(self.L.trxsig_trxgroup_add_bursts(self.h, d.ctypes.data, a.ctypes.data, d.shape[0]), "trxsig_trxgroup_add_bursts")
 
+    def tx_staging(self, n_max):
+        """The pinned block to RECEIVE the next batch into: (datagrams uint8 [n_max, 154], arfcn int32 [n_max]) as numpy views of the
+        library's memory; valid until add_staged."""
+        np = self.np
+        pd, pa = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.trxsig_trxgroup_tx_staging(self.h, int(n_max), C.byref(pd), C.byref(pa)), "trxsig_trxgroup_tx_staging")
+        d = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_uint8)), shape=(n_max, 154))
+        a = np.ctypeslib.as_array(C.cast(pa, C.POINTER(C.c_int32)), shape=(n_max,))
+        return d, a
+
+    def add_staged(self, n):
+        """The first n datagrams of the staging block: header check on the host, one upload, one kernel."""
+        self._chk(self.L.trxsig_trxgroup_add_staged(self.h, int(n)), "trxsig_trxgroup_add_staged")
+
     def push(self, fn, tn, n_slots, device="cuda:0"):
         """pushRadioVector for n_slots timeslots from (fn, tn): (bits uint8 [S, n, 148], gain float32 [S, n], from_queue uint8 [S, n])
         as torch views of the group's device buffers (valid until the next push)."""
@@ -800,10 +815,6 @@ class TrxGroup:
     def set_pipelined(self, on=True):
         """Large pulls return without joining the side stream the state machine replays on (see trxsig_trxgroup.h)."""
         self._chk(self.L.trxsig_trxgroup_set_pipelined(self.h, 1 if on else 0), "trxsig_trxgroup_set_pipelined")
-
-    def set_rach_beside(self, on=True):
-        """Access-burst detectors of a fused pull on the side stream beside the normal-burst ones (default on)."""
-        self._chk(self.L.trxsig_trxgroup_set_rach_beside(self.h, 1 if on else 0), "trxsig_trxgroup_set_rach_beside")
 
     def set_beside_rows(self, rows):
         """Pulls with at least `rows` rows replay the state machine on the group's side stream (0 = never, the default)."""

@@ -606,18 +606,6 @@ int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, in
                                c->cap_bursts, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   return TRXSIG_OK;
 }
-int trx_ctx_rx_rach_on(trxsig_ctx *c, hipStream_t st, float *d_rec, int rec_cap, const TrxRxGen &gen, const int32_t *d_len, int B,
-                       float detect_thresh, float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr) {
-  if (!c) return TRXSIG_EINVAL;
-  if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
-  if (B < 0 || !d_rec || rec_cap < B || (rec_cap & 255) || (B > 0 && (!d_len || !d_flags || !d_amp || !d_toa)))
-    return fail(c, TRXSIG_EINVAL, "trx_ctx_rx_rach_on: bad argument");
-  if (B == 0) return TRXSIG_OK;
-  DeviceGuard g(c->device);
-  HIPCHK(c, trx_launch_rx_rach(st, c->d_tables, gen, d_len, B, detect_thresh, energy_thresh, c->rach_amp_err, d_rec, rec_cap, d_flags,
-                               (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
-  return TRXSIG_OK;
-}
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
                      int need_mask, float *d_soft, int nsoft, int soft_stride) {
   if (!c) return TRXSIG_EINVAL;

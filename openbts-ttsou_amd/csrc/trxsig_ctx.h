@@ -13,11 +13,6 @@ int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float 
 // amplitude / TOA for the bursts whose d_enable[b] != 0, on such bursts
 int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
                     uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr);
-// the same on a stream and a record scratch of the caller's (trx_rach_rec_floats(sps) * rec_cap floats, rec_cap a multiple of 256 and
-// >= B): the Transceiver group runs its access-burst class on its side stream BESIDE the normal-burst detectors, which use the
-// context's own scratch
-int trx_ctx_rx_rach_on(trxsig_ctx *c, hipStream_t st, float *d_rec, int rec_cap, const TrxRxGen &gen, const int32_t *d_len, int B,
-                       float detect_thresh, float energy_thresh, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr);
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
                      int need_mask, float *d_soft, int nsoft, int soft_stride);
 int trx_ctx_demod_masked(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,

@@ -92,10 +92,11 @@ struct TrxGroupTx {
   const uint32_t *dummy;           // [TRXG_PAYLOAD_WORDS]: gDummyBurst, gain 1
   uint32_t *status;                // [S] bit 0: a burst was dropped because the queue / pool was full
 };
-// n new bursts, sorted by ARFCN (arrival order kept inside an ARFCN): seg[S+1] = where each ARFCN's run starts; s_pid[n] comes
-// back with the payload slot of each (-1: dropped); stage = their payloads in the same order
-hipError_t trx_launch_group_tx_add(hipStream_t st, const TrxGroupTx &x, int n, const int32_t *seg, const int32_t *s_fn, const int32_t *s_tn,
-                                   const int32_t *s_arfcn, int32_t *s_pid, const uint32_t *stage);
+// n new bursts as they arrived: dgram n x 154 bytes (TN, FN big-endian, RSSI, 148 bits one per byte), arfcn[n] the ARFCN each came
+// for (all checked by the host); gain_tab26[q + 12] = (float)pow(10, q), q = -12 .. 13.  Parsing, the per-ARFCN sort (arrival order
+// kept), queue insertion and the payload copies are one launch.
+hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn,
+                                      const float *gain_tab26);
 // pushRadioVector for n_slots timeslots from (fn0, tn0) on every ARFCN: out_pid / out_fq [n_slots][S] scratch; bits_out
 // [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (1 = the burst came from the queue)
 hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,

@@ -1,12 +1,17 @@
 // trxsig_grouptx.hip -- the TRANSMIT half of the Transceiver group (include/trxsig_trxgroup.h): addRadioVector /
 // pushRadioVector (Transceiver/Transceiver.cpp:100-113, 138-181) for S ARFCNs with the priority queue, the stale-burst dump
 // and the filler table [FN % modulus][TN] on the device.
-//   k_group_tx_add    : a lane per ARFCN takes its new bursts in arrival order: a payload slot from the ARFCN's free stack,
-//                       the (time, slot) entry into its queue (trxsig_txq.h: std::priority_queue's moves);
-//   k_group_tx_store  : the bursts' 148 bits + gain into their payload slots (every thread a word);
+//   k_group_tx_ingest : driveTransmitPriorityQueue's parsing (:596-620) + addRadioVector (:100-113) ON THE DEVICE (round 5) from the
+//                       raw 154-byte datagrams and their ARFCN ids, as they arrived: a workgroup owns sixteen ARFCNs, finds
+//                       its datagrams (a stable counting sort by wave ballots: arrival order is kept inside an ARFCN),
+//                       parses TN / big-endian FN / RSSI, and a lane per ARFCN enters them in its queue -- the queue
+//                       (trxsig_txq.h: std::priority_queue's moves) sits in LDS for the duration, the payload slots to hand
+//                       out are fetched ahead -- then every thread copies payload words (148 bits + gain) to the slots;
 //   k_group_tx_push   : a lane per ARFCN walks n_slots timeslots: stale entries leave the queue for the filler table, the
 //                       entry for exactly this time (if any) replaces the filler entry and goes out, else the filler entry
-//                       goes out (:142-177) -- as payload REFERENCES, nothing is copied on the serial path;
+//                       goes out (:142-177) -- as payload REFERENCES, nothing is copied on the serial path; the sixteen
+//                       ARFCNs' queues AND filler tables are in LDS for the walk (round 5: a dependent global access per
+//                       queue move and per slot was the whole kernel);
 //   k_group_tx_gather : the referenced payloads into the layout trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n]
 //                       gains): what the fused transmit back end then modulates, resamples and packs to int16.
 // What is kept per burst is its bits and its gain, never its modulated samples: modulateBurst + scaleVector of the same bits
@@ -17,37 +22,150 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void k_group_tx_add(TrxGroupTx x, const int32_t *__restrict__ seg, const int32_t *__restrict__ s_fn,
-                                                     const int32_t *__restrict__ s_tn, int32_t *__restrict__ s_pid) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
-  if (a >= x.S) return;
-  const TrxqView q = {x.q_fn + a, x.q_key + a, x.S};
-  int nq = x.q_n[a], nf = x.free_n[a];
-  const int j1 = seg[a + 1];
-  for (int j = seg[a]; j < j1; j++) {
-    if (nq >= x.qcap || nf == 0) {                          // queue or payload pool full: the burst is dropped and the ARFCN marked
-      x.status[a] |= 1u;
-      s_pid[j] = -1;
-      continue;
+constexpr int kTxA = 16;                                   // ARFCNs per workgroup
+constexpr int kTxQ = 256;                                   // queue entries per ARFCN held in LDS (= the queue's capacity, trxsig_trxgroup.cpp)
+constexpr int kTxWin = 4096;                                // datagrams per round: 64 chunks of a wave's width
+constexpr int kTxChunks = kTxWin / 64;
+
+struct TxGainTab { float v[26]; };                          // pow(10, q), q = -12 .. 13 (host: the reference's double pow, rounded to float)
+
+// the sixteen queues of a workgroup, LDS <-> memory (element i of ARFCN a lives at [i * S + a])
+__device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, int32_t (*qf)[kTxQ], int32_t (*qk)[kTxQ], const int *nq) {
+  const int k = threadIdx.x & (kTxA - 1);
+  if (a0 + k < x.S)
+    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+      qf[k][i] = x.q_fn[(size_t)i * x.S + a0 + k];
+      qk[k][i] = x.q_key[(size_t)i * x.S + a0 + k];
     }
-    nf--;
-    const int pid = x.free_stack[(size_t)nf * x.S + a];
-    nq = trxq_push(q, nq, s_fn[j], s_tn[j] | (pid << 3));   // mTransmitPriorityQueue.write(newVec) (:109)
-    s_pid[j] = pid;
-  }
-  x.q_n[a] = nq;
-  x.free_n[a] = nf;
+}
+__device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const int32_t (*qf)[kTxQ], const int32_t (*qk)[kTxQ], const int *nq) {
+  const int k = threadIdx.x & (kTxA - 1);
+  if (a0 + k < x.S)
+    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+      x.q_fn[(size_t)i * x.S + a0 + k] = qf[k][i];
+      x.q_key[(size_t)i * x.S + a0 + k] = qk[k][i];
+    }
 }
 
-// stage: [n][TRXG_PAYLOAD_WORDS] words (148 bits one per byte, then the gain), ARFCN-sorted like s_pid / s_arfcn
-__global__ __launch_bounds__(256) void k_group_tx_store(TrxGroupTx x, int n, const int32_t *__restrict__ s_arfcn, const int32_t *__restrict__ s_pid,
-                                                        const uint32_t *__restrict__ stage) {
-  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (g >= (long long)n * TRXG_PAYLOAD_WORDS) return;
-  const int j = (int)(g / TRXG_PAYLOAD_WORDS), w = (int)(g - (long long)j * TRXG_PAYLOAD_WORDS);
-  const int pid = s_pid[j];
-  if (pid < 0) return;
-  x.pool[((size_t)s_arfcn[j] * x.npool + pid) * TRXG_PAYLOAD_WORDS + w] = stage[g];
+// dgram: n x 154 bytes as they arrived ([0] TN, [1..4] FN big-endian, [5] RSSI, [6..153] one bit per byte); arfcn: n ids (the host
+// has checked every header: a call with a bad one queues nothing).
+__global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn,
+                                                          TxGainTab gt) {
+  __shared__ int32_t qf[kTxA][kTxQ], qk[kTxA][kTxQ];
+  __shared__ int32_t lf[kTxWin], lk[kTxWin];                // this round's entries, ARFCN by ARFCN: frame number (then payload slot), key
+  __shared__ int16_t fs[kTxWin];                            // the payload slots those entries will be handed, fetched ahead
+  __shared__ int32_t cnt[kTxChunks][kTxA];
+  __shared__ int nq[kTxA], nf[kTxA], nf0[kTxA], tot[kTxA], lbase[kTxA + 1], st_[kTxA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a0 = blockIdx.x * kTxA;
+  if (tid < kTxA) {
+    const bool mine = a0 + tid < x.S;
+    nq[tid] = mine ? x.q_n[a0 + tid] : 0;
+    nf[tid] = mine ? x.free_n[a0 + tid] : 0;
+    st_[tid] = 0;
+  }
+  __syncthreads();
+  tx_queues_load(x, a0, qf, qk, nq);
+  for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 4096 datagrams (LDS is sized for one)
+    // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN) by ballots ----
+    constexpr int CPW = kTxChunks / 16;                     // chunks per wave
+    int my_i[CPW], my_k[CPW], my_rank[CPW];
+#pragma unroll
+    for (int cc = 0; cc < CPW; cc++) {
+      const int c = wave * CPW + cc;
+      const int i = w0 + c * 64 + lane;
+      const int local = (i < n ? arfcn[i] : -1) - a0;
+      const bool valid = (unsigned)local < (unsigned)kTxA;
+      int mycount = 0, rank = 0;
+#pragma unroll
+      for (int k = 0; k < kTxA; k++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(valid && local == k);
+        if (lane == k) mycount = __builtin_popcountll(m);
+        if (local == k) rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      }
+      if (lane < kTxA) cnt[c][lane] = mycount;
+      my_i[cc] = i; my_k[cc] = valid ? local : -1; my_rank[cc] = rank;
+    }
+    __syncthreads();
+    if (tid < kTxA) {                                       // exclusive scan over the chunks, per ARFCN
+      int run = 0;
+      for (int c = 0; c < kTxChunks; c++) { const int v = cnt[c][tid]; cnt[c][tid] = run; run += v; }
+      tot[tid] = run;
+      nf0[tid] = nf[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int k = 0; k < kTxA; k++) { lbase[k] = run; run += tot[k]; }
+      lbase[kTxA] = run;
+    }
+    __syncthreads();
+    // ---- every datagram's header into its place (arrival order inside an ARFCN); the payload slots fetched ahead ----
+#pragma unroll
+    for (int cc = 0; cc < CPW; cc++) {
+      if (my_k[cc] < 0) continue;
+      const int c = wave * CPW + cc, k = my_k[cc];
+      const int lp = lbase[k] + cnt[c][k] + my_rank[cc];
+      const uint8_t *d = dgram + (size_t)my_i[cc] * 154;    // (154 i is even: two-byte loads)
+      const unsigned h0 = reinterpret_cast<const uint16_t *>(d)[0], h1 = reinterpret_cast<const uint16_t *>(d)[1], h2 = reinterpret_cast<const uint16_t *>(d)[2];
+      const int tn = (int)(int8_t)(h0 & 255);
+      const unsigned fn = ((h0 >> 8) << 24) | ((h1 & 255) << 16) | ((h1 >> 8) << 8) | (h2 & 255);
+      const int RSSI = (int)(int8_t)(h2 >> 8);              // `int RSSI = (int) buffer[5]` on a char buffer (:617)
+      const int gi = -RSSI / 10 + 12;                       // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division
+      lf[lp] = (int32_t)fn;
+      lk[lp] = (tn & 7) | (gi << 3) | (k << 8) | ((my_i[cc] - w0) << 12);
+    }
+    {
+      const int k = tid & (kTxA - 1);
+      const int want = tot[k] < nf0[k] ? tot[k] : nf0[k];
+      if (a0 + k < x.S)
+        for (int j = tid / kTxA; j < want; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf0[k] - 1 - j) * x.S + a0 + k];
+    }
+    __syncthreads();
+    // ---- addRadioVector, a lane per ARFCN, everything it touches in LDS ----
+    if (tid < kTxA && a0 + tid < x.S) {
+      const int k = tid;
+      const TrxqView q = {&qf[k][0], &qk[k][0], 1};
+      int n_q = nq[k], n_f = nf[k], used = 0, stt = st_[k];
+      for (int e = lbase[k]; e < lbase[k + 1]; e++) {
+        int pid = -1;
+        if (n_q >= x.qcap || n_f == 0) {                    // queue or payload pool full: the burst is dropped and the ARFCN marked
+          stt |= 1;
+        } else {
+          n_f--;
+          pid = fs[lbase[k] + used++];
+          n_q = trxq_push(q, n_q, lf[e], (lk[e] & 7) | (pid << 3));   // mTransmitPriorityQueue.write(newVec) (:109)
+        }
+        lf[e] = pid;
+      }
+      nq[k] = n_q; nf[k] = n_f; st_[k] = stt;
+    }
+    __syncthreads();
+    // ---- the payloads to their slots: every thread a word (37 words of bits, then the gain) ----
+    const int total = lbase[kTxA] * TRXG_PAYLOAD_WORDS;
+    for (int idx = tid; idx < total; idx += 1024) {
+      const int e = idx / TRXG_PAYLOAD_WORDS, w = idx - e * TRXG_PAYLOAD_WORDS;
+      const int pid = lf[e];
+      if (pid < 0) continue;
+      const int key = lk[e];
+      const int k = (key >> 8) & 15, src = w0 + (key >> 12);
+      uint32_t v;
+      if (w < 37) {
+        const uint16_t *p = reinterpret_cast<const uint16_t *>(dgram + (size_t)src * 154 + 6) + 2 * w;
+        v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);        // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
+      } else {
+        v = __float_as_uint(gt.v[(key >> 3) & 31]);
+      }
+      x.pool[((size_t)(a0 + k) * x.npool + pid) * TRXG_PAYLOAD_WORDS + w] = v;
+    }
+    __syncthreads();                                        // lf / lk / fs / cnt are the next round's
+  }
+  tx_queues_store(x, a0, qf, qk, nq);
+  if (tid < kTxA && a0 + tid < x.S) {
+    x.q_n[a0 + tid] = nq[tid];
+    x.free_n[a0 + tid] = nf[tid];
+    if (st_[tid]) x.status[a0 + tid] |= 1u;
+  }
 }
 
 __device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int pid) {
@@ -56,43 +174,72 @@ __device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int
   nf++;
 }
 
-__global__ __launch_bounds__(64) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
-                                                      uint8_t *__restrict__ out_fq) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
-  if (a >= x.S) return;
-  const TrxqView q = {x.q_fn + a, x.q_key + a, x.S};
-  int nq = x.q_n[a], nf = x.free_n[a];
-  int mod[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) mod[k] = x.fmod[k * x.S + a];
-  for (int t = 0; t < n_slots; t++) {
-    const int tn = (tn0 + t) & 7;
-    int fn = fn0 + ((tn0 + t) >> 3);
-    fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;      // (n_slots < 8 * gHyperframe: the host checks)
-    fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
-    // dump stale bursts, if any: "even if the burst is stale, put it in the filler table" (:142-153)
-    while (nq > 0 && trxq_time_lt(q.fn[0], q.key[0] & 7, fn, tn)) {
-      int32_t efn, ekey;
-      nq = trxq_pop(q, nq, &efn, &ekey);
-      const int etn = ekey & 7;
-      int16_t *cell = x.filler + ((size_t)(efn % mod[etn]) * 8 + etn) * x.S + a;
-      tx_free(x, a, nf, *cell);
-      *cell = (int16_t)(ekey >> 3);
-    }
-    int16_t *cell = x.filler + ((size_t)(fn % mod[tn]) * 8 + tn) * x.S + a;
-    int fq = 0;
-    if (nq > 0 && q.fn[0] == fn && (q.key[0] & 7) == tn) {  // data at the desired timestamp (:159-173)
-      int32_t efn, ekey;
-      nq = trxq_pop(q, nq, &efn, &ekey);
-      tx_free(x, a, nf, *cell);
-      *cell = (int16_t)(ekey >> 3);
-      fq = 1;
-    }
-    out_pid[(size_t)t * x.S + a] = *cell;                   // otherwise the filler entry (:175-177)
-    out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+constexpr int kTxCells = 102 * 8;                           // fillerTable[102][8] (Transceiver.h:79)
+__global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
+                                                       uint8_t *__restrict__ out_fq) {
+  __shared__ int32_t qf[kTxA][kTxQ], qk[kTxA][kTxQ];
+  __shared__ int16_t fl[kTxA][kTxCells];                    // the sixteen filler tables
+  __shared__ int nq[kTxA], nf[kTxA];
+  const int tid = threadIdx.x, a0 = blockIdx.x * kTxA;
+  if (tid < kTxA) {
+    const bool mine = a0 + tid < x.S;
+    nq[tid] = mine ? x.q_n[a0 + tid] : 0;
+    nf[tid] = mine ? x.free_n[a0 + tid] : 0;
   }
-  x.q_n[a] = nq;
-  x.free_n[a] = nf;
+  __syncthreads();
+  tx_queues_load(x, a0, qf, qk, nq);
+  {
+    const int k = tid & (kTxA - 1);
+    if (a0 + k < x.S)
+      for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
+  }
+  __syncthreads();
+  if (tid < kTxA && a0 + tid < x.S) {
+    const int k = tid, a = a0 + tid;
+    const TrxqView q = {&qf[k][0], &qk[k][0], 1};
+    int n_q = nq[k], n_f = nf[k];
+    int mod[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) mod[m] = x.fmod[m * x.S + a];
+    for (int t = 0; t < n_slots; t++) {
+      const int tn = (tn0 + t) & 7;
+      int fn = fn0 + ((tn0 + t) >> 3);
+      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;    // (n_slots < 8 * gHyperframe: trxsig_trxgroup_push checks)
+      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+      // dump stale bursts, if any: "even if the burst is stale, put it in the filler table" (:142-153)
+      while (n_q > 0 && trxq_time_lt(q.fn[0], q.key[0] & 7, fn, tn)) {
+        int32_t efn, ekey;
+        n_q = trxq_pop(q, n_q, &efn, &ekey);
+        const int etn = ekey & 7;
+        int16_t *cell = &fl[k][(efn % mod[etn]) * 8 + etn];
+        tx_free(x, a, n_f, *cell);
+        *cell = (int16_t)(ekey >> 3);
+      }
+      int16_t *cell = &fl[k][(fn % mod[tn]) * 8 + tn];
+      int fq = 0;
+      if (n_q > 0 && q.fn[0] == fn && (q.key[0] & 7) == tn) {   // data at the desired timestamp (:159-173)
+        int32_t efn, ekey;
+        n_q = trxq_pop(q, n_q, &efn, &ekey);
+        tx_free(x, a, n_f, *cell);
+        *cell = (int16_t)(ekey >> 3);
+        fq = 1;
+      }
+      out_pid[(size_t)t * x.S + a] = *cell;                 // otherwise the filler entry (:175-177)
+      out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+    }
+    nq[k] = n_q; nf[k] = n_f;
+  }
+  __syncthreads();
+  tx_queues_store(x, a0, qf, qk, nq);
+  {
+    const int k = tid & (kTxA - 1);
+    if (a0 + k < x.S)
+      for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) x.filler[(size_t)c * x.S + a0 + k] = fl[k][c];
+  }
+  if (tid < kTxA && a0 + tid < x.S) {
+    x.q_n[a0 + tid] = nq[tid];
+    x.free_n[a0 + tid] = nf[tid];
+  }
 }
 
 // bits_out [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (the transposes of out_pid / out_fq's [n_slots][S])
@@ -116,19 +263,20 @@ __global__ __launch_bounds__(256) void k_group_tx_gather(TrxGroupTx x, int n_slo
 
 }  // namespace
 
-hipError_t trx_launch_group_tx_add(hipStream_t st, const TrxGroupTx &x, int n, const int32_t *seg, const int32_t *s_fn, const int32_t *s_tn,
-                                   const int32_t *s_arfcn, int32_t *s_pid, const uint32_t *stage) {
+hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn, const float *gain_tab26) {
   if (n <= 0) return hipSuccess;
-  k_group_tx_add<<<dim3((x.S + 63) / 64), dim3(64), 0, st>>>(x, seg, s_fn, s_tn, s_pid);
-  const long long words = (long long)n * TRXG_PAYLOAD_WORDS;
-  k_group_tx_store<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(x, n, s_arfcn, s_pid, stage);
+  if (x.qcap != kTxQ) return hipErrorInvalidValue;          // (the kernel's LDS copy of a queue)
+  TxGainTab gt;
+  for (int q = 0; q < 26; q++) gt.v[q] = gain_tab26[q];
+  k_group_tx_ingest<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, n, dgram, arfcn, gt);
   return hipGetLastError();
 }
 
 hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,
                                     uint8_t *bits_out, float *gain_out, uint8_t *fq_out) {
   if (n_slots <= 0) return hipSuccess;
-  k_group_tx_push<<<dim3((x.S + 63) / 64), dim3(64), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq);
+  if (x.qcap != kTxQ) return hipErrorInvalidValue;
+  k_group_tx_push<<<dim3((x.S + kTxA - 1) / kTxA), dim3(256), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq);
   const long long words = (long long)x.S * n_slots * TRXG_PAYLOAD_WORDS;
   k_group_tx_gather<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(x, n_slots, out_pid, out_fq, (uint32_t *)bits_out, gain_out,
                                                                                    fq_out);

@@ -89,9 +89,6 @@ struct trxsig_trxgroup {
   int cur = 0;                                              // the set of the last pull
   bool pipelined = false;
   int beside_rows = 0x7fffffff;      // trxsig_trxgroup_set_beside_rows: calls with at least this many rows replay on the side stream (kBesideRows)
-  DevBuf<float> rach_rec;            // record scratch of the access-burst class when it runs on the side stream (trx_rach_rec_floats per burst)
-  hipEvent_t ev_rach = nullptr;      // ... and the event the context's stream waits for before the state machine reads that class's answers
-  int rach_beside = 1;               // 1: the access-burst detectors of a fused pull run on the side stream beside the normal-burst ones
   DevBuf<trx_c32> w_tab, b_tab, in;
   DevBuf<float> chan_off;
   std::vector<int32_t> h_seg;
@@ -103,15 +100,16 @@ struct trxsig_trxgroup {
   bool fmod_dirty = true;                                   // a SETSLOT changed some fillerModulus (setModulus, :183-204)
   TrxGroupTx tx = {};
   uint32_t *d_dummy = nullptr;
-  DevBuf<int32_t> tx_seg, tx_fn, tx_tn, tx_arfcn, tx_pid;
-  DevBuf<uint32_t> tx_stage;
+  DevBuf<int32_t> tx_arfcn;
+  DevBuf<uint8_t> tx_dgram;          // the datagrams of an add call as they arrived (k_group_tx_ingest parses and sorts them)
+  uint8_t *tx_pin[2] = {nullptr, nullptr};   // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), two in turn
+  int tx_pin_cap[2] = {0, 0};
+  bool tx_stage_held = false;        // the current set has been handed out and not yet added
   DevBuf<int16_t> tx_opid;
   DevBuf<uint8_t> tx_ofq, tx_bits, tx_fq;
   DevBuf<float> tx_gain;
   // host staging of an add call: two sets in turn, each guarded by an event recorded behind its uploads -- a set is refilled only
   // when the copies that read it have run (the library does not rely on pageable hipMemcpyAsync being synchronous)
-  std::vector<int32_t> h_tx[2];
-  std::vector<uint32_t> h_stage[2];
   std::vector<uint8_t> h_fmod[2];
   hipEvent_t tx_ev[2] = {nullptr, nullptr};
   bool tx_ev_armed[2] = {false, false};
@@ -203,7 +201,6 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
       hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g->ev_rach, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->wk[0].done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->wk[1].done, hipEventDisableTiming) != hipSuccess) {
     const int rc = trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup_create: device allocation failed", hipSuccess);   // (first the error text: the release below may be the context's end)
@@ -222,8 +219,6 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     if (g->side) { (void)hipStreamSynchronize(g->side); (void)hipStreamDestroy(g->side); }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    if (g->ev_rach) (void)hipEventDestroy(g->ev_rach);
-    g->rach_rec.release();
     (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
     for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
     g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
@@ -233,7 +228,8 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
       (void)hipFree(g->tx.status); (void)hipFree(g->d_dummy);
     }
     for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
-    g->tx_seg.release(); g->tx_fn.release(); g->tx_tn.release(); g->tx_arfcn.release(); g->tx_pid.release(); g->tx_stage.release();
+    g->tx_arfcn.release(); g->tx_dgram.release();
+    for (int k = 0; k < 2; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
     g->tx_opid.release(); g->tx_ofq.release(); g->tx_bits.release(); g->tx_fq.release(); g->tx_gain.release();
   }
   trx_ctx_release(g->c);
@@ -362,31 +358,12 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   G_HIP(g, trx_launch_group_expand(st, ex));
 
   // ---- the stateless detectors, a launch per class in use; thresholds 3.0 / 5.0 (:331, 363), energy gate off ----
-  // A fused pull's access-burst class (a few hundred bursts among tens of thousands: two latency-bound launches that fill
-  // no machine, 33 us of a 200 us step) runs on the SIDE stream beside the normal-burst detectors, from its own record scratch;
-  // the context's stream waits for it before the state machine reads the answers.
   struct SideGuard {                                        // (an error return between a fork and its join must not leave the side stream working on this call's arrays)
     hipStream_t s = nullptr;
     ~SideGuard() { if (s) (void)hipStreamSynchronize(s); }
   } side_guard;
-  bool rach_forked = false;
-  if (src.gen && g->rach_beside && count[TRXG_CLASS_RACH] > 0 && n_tsc > 0 && !g->wk[0].in_flight && !g->wk[1].in_flight) {
-    const int k = TRXG_CLASS_RACH, b0 = base[k];
-    const int cap = (count[k] + 255) & ~255;
-    G_HIP(g, g->rach_rec.need((size_t)trx_rach_rec_floats(sps) * (size_t)cap, st));
-    TrxRxGen gen = *src.gen;
-    gen.sel = W.off.p + b0;
-    G_HIP(g, hipEventRecord(g->ev_fork, st));               // (behind k_group_expand: the selection and the lengths are there)
-    G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
-    side_guard.s = g->side;
-    G_LIB(trx_ctx_rx_rach_on(c, g->side, g->rach_rec.p, cap, gen, W.len.p + b0, count[k], 5.0f, -1.0f, W.flags.p + b0,
-                             (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0, W.avgpwr.p + b0));
-    G_HIP(g, hipEventRecord(g->ev_rach, g->side));
-    rach_forked = true;
-  }
   for (int k = 0; k < TRXG_NCLASS; k++) {
     if (!count[k]) continue;
-    if (k == TRXG_CLASS_RACH && rach_forked) continue;
     const int b0 = base[k];
     if (src.gen) {                                          // the detectors compute their samples from the raw stream; off = the selection
       TrxRxGen gen = *src.gen;
@@ -421,10 +398,6 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   const bool beside = lean && n_rows >= g->beside_rows;   // (trxsig_trxgroup_set_beside_rows: A/B and the tests of the side-stream arrangement)
   const bool piped = beside && g->pipelined;                // the join is left to the next call but one / trxsig_trxgroup_sync
   if (!piped) G_LIB(join_side(g, st));                      // (state order: nothing replays on this stream before the side stream is done)
-  if (rach_forked) {                                        // the access-burst class's answers: the state machine reads them next
-    G_HIP(g, hipStreamWaitEvent(st, g->ev_rach, 0));
-    side_guard.s = nullptr;
-  }
   G_HIP(g, trx_launch_group_pack(st, rp, W.packed.p));
   if (beside) {
     G_HIP(g, hipEventRecord(g->ev_fork, st));
@@ -627,14 +600,6 @@ int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows) {
   return TRXSIG_OK;
 }
 
-int trxsig_trxgroup_set_rach_beside(trxsig_trxgroup *g, int on) {
-  if (!g) return TRXSIG_EINVAL;
-  Guard gd(trxsig_device(g->c));
-  G_LIB(join_side(g, (hipStream_t)trxsig_get_stream(g->c)));
-  g->rach_beside = on != 0;
-  return TRXSIG_OK;
-}
-
 int trxsig_trxgroup_sync(trxsig_trxgroup *g) {
   if (!g) return TRXSIG_EINVAL;
   Guard gd(trxsig_device(g->c));
@@ -732,56 +697,82 @@ int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st, int k) {
 
 extern "C" {
 
+// the pinned staging block of set k, grown to hold n_max datagrams + their ARFCN ids ([ids: 4 n_max bytes][datagrams: 154 n_max])
+static int tx_stage_need(trxsig_trxgroup *g, int k, int n_max) {
+  if (n_max <= g->tx_pin_cap[k]) return TRXSIG_OK;
+  if (g->tx_ev_armed[k]) { G_HIP(g, hipEventSynchronize(g->tx_ev[k])); g->tx_ev_armed[k] = false; }
+  const int cap = n_max + n_max / 4 + 256;
+  void *q = nullptr;
+  G_HIP(g, hipHostMalloc(&q, (size_t)cap * (TRXSIG_TX_DATAGRAM_BYTES + 4), hipHostMallocDefault));
+  if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
+  g->tx_pin[k] = (uint8_t *)q;
+  g->tx_pin_cap[k] = cap;
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_tx_staging(trxsig_trxgroup *g, int n_max, uint8_t **h_datagrams, int32_t **h_arfcn) {
+  if (!g) return TRXSIG_EINVAL;
+  if (n_max <= 0 || !h_datagrams || !h_arfcn) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_tx_staging: bad argument", hipSuccess);
+  Guard gd(trxsig_device(g->c));
+  G_LIB(tx_setup(g));
+  if (!g->tx_stage_held) {                                  // the next set, free to be refilled (its previous upload has run)
+    int set = 0;
+    G_LIB(tx_take_set(g, &set));
+    g->tx_stage_held = true;
+  }
+  const int k = g->tx_set;
+  G_LIB(tx_stage_need(g, k, n_max));
+  *h_arfcn = (int32_t *)g->tx_pin[k];
+  *h_datagrams = g->tx_pin[k] + (size_t)4 * g->tx_pin_cap[k];
+  return TRXSIG_OK;
+}
+
+// driveTransmitPriorityQueue's checks on the headers (:596-620), then ONE upload of the block as it arrived and one launch
+static int tx_add_staged(trxsig_trxgroup *g, int n) {
+  trxsig_ctx *c = g->c;
+  const int S = g->S, k = g->tx_set;
+  const int32_t *h_arfcn = (const int32_t *)g->tx_pin[k];
+  const uint8_t *h_d = g->tx_pin[k] + (size_t)4 * g->tx_pin_cap[k];
+  for (int i = 0; i < n; i++) {
+    const uint8_t *d = h_d + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
+    const int a = h_arfcn[i], tn = (int)(int8_t)d[0];
+    const uint32_t fn = ((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4];
+    if (a < 0 || a >= S || tn < 0 || tn > 7 || fn >= (uint32_t)kHyperframe)
+      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: ARFCN, timeslot or frame number out of range (nothing was queued)", hipSuccess);
+  }
+  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
+  G_LIB(tx_sync_modulus(g, st, k));
+  G_HIP(g, g->tx_dgram.need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES, st)); G_HIP(g, g->tx_arfcn.need((size_t)n, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_arfcn.p, h_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_dgram.p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, st));
+  G_LIB(tx_seal_set(g, k, st));
+  g->tx_stage_held = false;                                 // (the set is the DMA's until its event has passed: the next staging call takes the other)
+  G_HIP(g, trx_launch_group_tx_ingest(st, g->tx, n, g->tx_dgram.p, g->tx_arfcn.p, g->gain_tab));
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_add_staged(trxsig_trxgroup *g, int n) {
+  if (!g) return TRXSIG_EINVAL;
+  if (!g->tx_stage_held || n < 0 || n > g->tx_pin_cap[g->tx_set])
+    return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_add_staged: no staging block is held (trxsig_trxgroup_tx_staging first) or n exceeds it", hipSuccess);
+  if (n == 0) return TRXSIG_OK;
+  Guard gd(trxsig_device(g->c));
+  return tx_add_staged(g, n);
+}
+
 int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, const int32_t *h_arfcn, int n) {
   if (!g) return TRXSIG_EINVAL;
   trxsig_ctx *c = g->c;
   if (n < 0 || (n > 0 && (!h_datagrams || !h_arfcn))) return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: bad argument", hipSuccess);
   if (n == 0) return TRXSIG_OK;
-  const int S = g->S;
-  // parse the headers as driveTransmitPriorityQueue does (:596-620) and sort by ARFCN, arrival order kept inside an ARFCN
+  // the caller's (pageable) arrays into the pinned staging block, then as trxsig_trxgroup_add_staged
+  uint8_t *pd = nullptr;
+  int32_t *pa = nullptr;
+  G_LIB(trxsig_trxgroup_tx_staging(g, n, &pd, &pa));
+  std::memcpy(pa, h_arfcn, 4 * (size_t)n);
+  std::memcpy(pd, h_datagrams, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES);
   Guard gd(trxsig_device(c));
-  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
-  G_LIB(tx_setup(g));
-  int set = 0;
-  G_LIB(tx_take_set(g, &set));
-  std::vector<int32_t> &h = g->h_tx[set];
-  std::vector<uint32_t> &stage = g->h_stage[set];
-  h.assign((size_t)(S + 1) + 4 * (size_t)n, 0);
-  int32_t *seg = h.data(), *s_fn = seg + S + 1, *s_tn = s_fn + n, *s_arfcn = s_tn + n, *s_src = s_arfcn + n;
-  for (int i = 0; i < n; i++) {
-    const uint8_t *d = h_datagrams + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
-    const int a = h_arfcn[i], tn = (int)(int8_t)d[0];
-    const uint32_t fn = ((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4];
-    if (a < 0 || a >= S || tn < 0 || tn > 7 || fn >= (uint32_t)kHyperframe)
-      return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: ARFCN, timeslot or frame number out of range (nothing was queued)", hipSuccess);
-    seg[a + 1]++;
-  }
-  for (int a = 0; a < S; a++) seg[a + 1] += seg[a];
-  std::vector<int32_t> fillp(seg, seg + S);
-  stage.resize((size_t)n * TRXG_PAYLOAD_WORDS);
-  for (int i = 0; i < n; i++) {
-    const uint8_t *d = h_datagrams + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
-    const int a = h_arfcn[i];
-    const int j = fillp[(size_t)a]++;
-    s_fn[j] = (int32_t)(((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4]);
-    s_tn[j] = d[0]; s_arfcn[j] = a; s_src[j] = i;
-    uint8_t *pay = (uint8_t *)(stage.data() + (size_t)j * TRXG_PAYLOAD_WORDS);
-    std::memcpy(pay, d + 6, 148);                           // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
-    const int RSSI = (int)(int8_t)d[5];                     // `int RSSI = (int) buffer[5]` on a char buffer (:617)
-    std::memcpy(pay + 148, &g->gain_tab[-RSSI / 10 + 12], 4);
-  }
-  G_LIB(tx_sync_modulus(g, st, set));
-  G_HIP(g, g->tx_seg.need((size_t)S + 1, st)); G_HIP(g, g->tx_fn.need((size_t)n, st)); G_HIP(g, g->tx_tn.need((size_t)n, st));
-  G_HIP(g, g->tx_arfcn.need((size_t)n, st)); G_HIP(g, g->tx_pid.need((size_t)n, st));
-  G_HIP(g, g->tx_stage.need((size_t)n * TRXG_PAYLOAD_WORDS, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_seg.p, seg, 4 * ((size_t)S + 1), hipMemcpyHostToDevice, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_fn.p, s_fn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_tn.p, s_tn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_arfcn.p, s_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_stage.p, stage.data(), 4 * stage.size(), hipMemcpyHostToDevice, st));
-  G_LIB(tx_seal_set(g, set, st));
-  G_HIP(g, trx_launch_group_tx_add(st, g->tx, n, g->tx_seg.p, g->tx_fn.p, g->tx_tn.p, g->tx_arfcn.p, g->tx_pid.p, g->tx_stage.p));
-  return TRXSIG_OK;
+  return tx_add_staged(g, n);
 }
 
 int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const uint8_t **d_bits, const float **d_gain,

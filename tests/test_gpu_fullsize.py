@@ -208,19 +208,23 @@ def test_config4_stream_independence(pkg):
 
 
 def test_config4_fused_stream_independence_and_equivalence(pkg, golden):
-    """The fused front end (trxsig_rxfe_push_detect_demod_normal) on 128 ARFCN streams x 12 chunks in one call, with the
-    REFERENCE'S OWN filter table (createLPF(sendLPF_961, 961, 260), captured in golden/resample.npz): every burst's
+    """The fused front end (trxsig_rxfe_push_detect_demod_normal) on 128 ARFCN streams x 12 chunks in one call: every burst's
     flags / amplitude / TOA / soft bits equal (bit for bit) what the unfused chain gives, and what a front end carrying only
     that stream gives in three calls of four chunks -- and a sample of more than 512 bursts drawn from 13 streams across the
     launch equals the ORACLE chain (unUSRPify -> polyphaseResampleVector chunk by chunk behind the 192-sample history ->
-    157/156/156/156 slicing -> energyDetect -> analyzeTrafficBurst -> demodulateBurst), IEEE ==, as configs 2, 3 and 5 are graded."""
+    157/156/156/156 slicing -> energyDetect -> analyzeTrafficBurst -> demodulateBurst), IEEE ==, as configs 2, 3 and 5 are graded.
+    The oracle sample is taken twice: with the filter designed for this ratio (synth.design_lpf: nearly every burst detected, so
+    the soft bits are compared too) and with the REFERENCE'S OWN table (createLPF(sendLPF_961, 961, 260), golden/resample.npz --
+    made for 65 : 96, it passes little of a 260 : 96 signal and few bursts are detected; flags, amplitudes and TOAs still have
+    to agree value for value)."""
     import torch
     from openbts_ttsou_amd import synth
     from openbts_ttsou_amd.frontend import RxFrontEnd, OUTCHUNK, OUTHISTORY
     dev = torch.device("cuda:0")
     S, K, tsc = 128, 12, 2
     t = pkg.TrxSig(4, 0); t.use_torch_stream()
-    lpf = golden("resample.npz")["lpf961_gain260"]
+    lpf = synth.design_lpf(961, 260)
+    lpf_ref = golden("resample.npz")["lpf961_gain260"]
     # detectable content: modulated bursts brought to 400 kS/s by linear interpolation (as bench.py's config 4)
     nb0 = (K * 585 // 156 + 8) // 4 * 4
     x, off, length, meta = synth.normal_batch_torch(4, S * nb0, tsc, seed=21, device=dev, sigmas=(0.02, 0.05))
@@ -235,7 +239,7 @@ def test_config4_fused_stream_independence_and_equivalence(pkg, golden):
         return dict(flags=torch.zeros(n, dtype=torch.uint8, device=dev), amp=torch.zeros(n, 2, device=dev), toa=torch.zeros(n, device=dev),
                     soft=torch.full((n, NS), -1.0, device=dev))
 
-    def fused(streams, per_push):
+    def fused(streams, per_push, lpf=lpf):
         fe = RxFrontEnd(t, len(streams), lpf, max_chunks=K)
         sub = iq[streams].contiguous()
         per_stream = [[] for _ in streams]
@@ -283,29 +287,38 @@ def test_config4_fused_stream_independence_and_equivalence(pkg, golden):
     # ---- a sample of the 128-stream call against the oracle chain on the same int16 samples ----
     o = oraclebind.Oracle(4)
     iqh = iq.cpu().numpy()
-    checked = 0
-    for s in list(range(0, S, 11)) + [S - 1]:                # 13 streams spread over the launch (workgroups, XCDs)
-        hist = np.zeros(OUTHISTORY, np.complex64)
-        rcv = np.zeros(0, np.complex64)
-        for c in range(K):
-            ch = iqh[s, c * OUTCHUNK:(c + 1) * OUTCHUNK]
-            cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)   # unUSRPify: Q first
-            y = o.polyphase_resample(np.concatenate([hist, cf]), 260, 96, lpf)
-            rcv = np.concatenate([rcv, y[2 * 260:]])
-            hist = cf[-OUTHISTORY:]
-        pos, tn = 0, 0
-        for (tn_g, fl, a_g, toa_g, soft_g) in full[s]:
-            n = (156 + (tn % 4 == 0)) * 4
-            assert tn_g == tn and pos + n <= len(rcv)
-            burst = rcv[pos:pos + n]; pos += n; tn = (tn + 1) % 8
-            eok, _ = o.energy_detect(burst, 80, 0.0)
-            assert bool(fl & pkg.F_ENERGY) == eok
-            if not eok:
-                continue
-            r = o.analyze_traffic(burst, tsc, 3.0)
-            assert bool(fl & pkg.F_DETECT) == r["ok"], (s, tn_g)
-            assert np.complex64(complex(float(a_g[0]), float(a_g[1]))) == r["amp"] and np.float32(float(toa_g)) == r["toa"], (s, tn_g)
-            if r["ok"]:
-                assert_veq(soft_g.cpu().numpy(), o.demodulate(burst, r["amp"], r["toa"])[:NS], "soft, stream %d" % s)
-            checked += 1
-    assert checked >= 512, checked
+
+    def oracle_sample(result, taps):
+        checked = detected = 0
+        for s in list(range(0, S, 11)) + [S - 1]:            # 13 streams spread over the launch (workgroups, XCDs)
+            hist = np.zeros(OUTHISTORY, np.complex64)
+            rcv = np.zeros(0, np.complex64)
+            for c in range(K):
+                ch = iqh[s, c * OUTCHUNK:(c + 1) * OUTCHUNK]
+                cf = (ch[:, 1].astype(np.float32) + 1j * ch[:, 0].astype(np.float32)).astype(np.complex64)   # unUSRPify: Q first
+                y = o.polyphase_resample(np.concatenate([hist, cf]), 260, 96, taps)
+                rcv = np.concatenate([rcv, y[2 * 260:]])
+                hist = cf[-OUTHISTORY:]
+            pos, tn = 0, 0
+            for (tn_g, fl, a_g, toa_g, soft_g) in result[s]:
+                n = (156 + (tn % 4 == 0)) * 4
+                assert tn_g == tn and pos + n <= len(rcv)
+                burst = rcv[pos:pos + n]; pos += n; tn = (tn + 1) % 8
+                eok, _ = o.energy_detect(burst, 80, 0.0)
+                assert bool(fl & pkg.F_ENERGY) == eok
+                checked += 1
+                if not eok:
+                    continue
+                r = o.analyze_traffic(burst, tsc, 3.0)
+                assert bool(fl & pkg.F_DETECT) == r["ok"], (s, tn_g)
+                assert np.complex64(complex(float(a_g[0]), float(a_g[1]))) == r["amp"] and np.float32(float(toa_g)) == r["toa"], (s, tn_g)
+                if r["ok"]:
+                    assert_veq(soft_g.cpu().numpy(), o.demodulate(burst, r["amp"], r["toa"])[:NS], "soft, stream %d" % s)
+                    detected += 1
+                else:
+                    assert not soft_g.any().item()
+        return checked, detected
+    checked, detected = oracle_sample(full, lpf)
+    assert checked >= 512 and detected > 0.9 * checked, (checked, detected)
+    checked, detected = oracle_sample(fused(list(range(S)), K, lpf=lpf_ref), lpf_ref)
+    assert checked >= 512 and detected > 0, (checked, detected)

@@ -254,11 +254,10 @@ def test_full_batch_sample_tolerance(pkg):
     assert e <= MEASURED, e
 
 
-@pytest.mark.parametrize("rach_beside", [True, False])
-def test_group_on_the_fused_front_end_tolerance(pkg, rach_beside):
+def test_group_on_the_fused_front_end_tolerance(pkg):
     """The Transceiver group on the fused receive front end (config 4's default call: schedule with access-burst slots, per-ARFCN
     threshold state, k_demod_rx) in tolerance mode against itself in exact mode, three pushes: valid / RSSI / timing / thresholds
-    identical, hard bits identical, soft bits within the bound -- with the access-burst class on the side stream and without."""
+    identical, hard bits identical, soft bits within the bound."""
     import torch
     from openbts_ttsou_amd import synth as gsynth
     from openbts_ttsou_amd.frontend import RxFrontEnd
@@ -277,7 +276,6 @@ def test_group_on_the_fused_front_end_tolerance(pkg, rach_beside):
     for mode in (pkg.SOFT_EXACT, pkg.SOFT_TOLERANCE):
         ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream(); ctx.set_soft_mode(mode)
         g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
-        g.set_rach_beside(rach_beside)
         fe = RxFrontEnd(ctx, S, lpf, max_chunks=K)
         for a in range(S):
             g.control(a, "CMD SETTSC %d" % tsc)

@@ -231,3 +231,52 @@ def test_push_txbe_refusals_leave_the_queue_alone(pkg):
     for be in (wrong_s, wrong_ctx, small, good, roomy):
         be.close()
     grp.close(); ctx.close(); other.close()
+
+
+def test_staged_add_equals_the_copying_add(pkg):
+    """trxsig_trxgroup_tx_staging + _add_staged (the datagrams received straight into the group's pinned block) against
+    trxsig_trxgroup_add_bursts on the same datagrams -- more than one round of the ingest kernel (10,000 > 4,096 per round), ARFCNs
+    interleaved, late, early and duplicate bursts, a run that overflows one ARFCN's queue: the pushes hand out the same bits, gains
+    and from-queue marks, the queues end up the same size, the same ARFCN reports the drop; a bad header in the staged block
+    refuses the batch and leaves the block with the caller."""
+    import torch
+    rng = np.random.default_rng(12)
+    S, F = 20, 40                                           # 20 ARFCNs (two workgroups of the ingest kernel, the second partly filled)
+    ctx = pkg.TrxSig(1, 0); ctx.use_torch_stream()
+    ga = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+    gb = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+    for g in (ga, gb):
+        for a in range(S):
+            configure(lambda c, a=a: g.control(a, c), a)
+    n = S * 8 * F
+    dg = np.zeros((n, 154), np.uint8)
+    arf = rng.integers(0, S, n).astype(np.int32)
+    fn = 3000 + rng.integers(-3, F + 3, n)                  # some already stale, some beyond the frames pushed below
+    dg[:, 0] = rng.integers(0, 8, n)
+    dg[:, 1] = fn >> 24; dg[:, 2] = (fn >> 16) & 255; dg[:, 3] = (fn >> 8) & 255; dg[:, 4] = fn & 255
+    dg[:, 5] = rng.integers(-128, 128, n).astype(np.int8).view(np.uint8)
+    dg[:, 6:] = rng.integers(0, 2, (n, 148))
+    extra = np.repeat(dg[:1], 300, axis=0); extra[:, 1:5] = [0, 0, 0x0c, 0x00]       # 300 more for one ARFCN: its queue overflows
+    dg = np.concatenate([dg, extra]); arf = np.concatenate([arf, np.full(300, 7, np.int32)])
+    n = len(dg)
+    assert n > 2 * 4096
+    ga.add_bursts(dg, arf)
+    d, a = gb.tx_staging(n)
+    d[:] = dg; a[:] = arf
+    bad = d[5].copy(); d[5, 0] = 9                          # TN 9: the staged batch is refused, nothing queued, the block stays ours
+    with pytest.raises(pkg.TrxSigError):
+        gb.add_staged(n)
+    assert gb.tx_queue_size(3) == (0, False)
+    d[5] = bad
+    gb.add_staged(n)
+    for a_ in range(S):
+        assert ga.tx_queue_size(a_) == gb.tx_queue_size(a_)
+    assert ga.tx_queue_size(7)[1]                           # the overflow was reported
+    for f0 in (2990, 3010, 3030):
+        ra = ga.push(f0, 0, 8 * 20); rb = gb.push(f0, 0, 8 * 20)
+        torch.cuda.synchronize()
+        for xa, xb in zip(ra, rb):
+            assert torch.equal(xa, xb)
+    for a_ in range(S):
+        assert ga.tx_queue_size(a_) == gb.tx_queue_size(a_)
+    ga.close(); gb.close(); ctx.close()

