@@ -110,7 +110,9 @@ struct trxsig_trxgroup {
   DevBuf<float> tx_gain;
   // host staging of an add call: two sets in turn, each guarded by an event recorded behind its uploads -- a set is refilled only
   // when the copies that read it have run (the library does not rely on pageable hipMemcpyAsync being synchronous)
-  std::vector<uint8_t> h_fmod[2];
+  std::vector<uint8_t> h_fmod;
+  hipEvent_t tx_fm_ev = nullptr;
+  bool tx_fm_armed = false;
   hipEvent_t tx_ev[2] = {nullptr, nullptr};
   bool tx_ev_armed[2] = {false, false};
   int tx_set = 0;
@@ -228,6 +230,7 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
       (void)hipFree(g->tx.status); (void)hipFree(g->d_dummy);
     }
     for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
+    if (g->tx_fm_ev) (void)hipEventDestroy(g->tx_fm_ev);
     g->tx_arfcn.release(); g->tx_dgram.release();
     for (int k = 0; k < 2; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
     g->tx_opid.release(); g->tx_ofq.release(); g->tx_bits.release(); g->tx_fq.release(); g->tx_gain.release();
@@ -666,6 +669,8 @@ int tx_setup(trxsig_trxgroup *g) {
   // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division, pow in double, the scale a Complex<float>
   for (int q = -12; q <= 13; q++) g->gain_tab[q + 12] = (float)std::pow(10, q);
   for (int k = 0; k < 2; k++) G_HIP(g, hipEventCreateWithFlags(&g->tx_ev[k], hipEventDisableTiming));
+  G_HIP(g, hipEventCreateWithFlags(&g->tx_fm_ev, hipEventDisableTiming));
+
   g->tx_ready = true;
   g->fmod_dirty = true;
   return TRXSIG_OK;
@@ -682,14 +687,17 @@ int tx_seal_set(trxsig_trxgroup *g, int k, hipStream_t st) {
   g->tx_ev_armed[k] = true;
   return TRXSIG_OK;
 }
-// fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT; `k`: the staging set the caller holds
-int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st, int k) {
+// fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT (rare: its own host staging vector, waited for before it is refilled)
+int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st) {
   if (!g->fmod_dirty) return TRXSIG_OK;
-  std::vector<uint8_t> &fm = g->h_fmod[k];
+  if (g->tx_fm_armed) { G_HIP(g, hipEventSynchronize(g->tx_fm_ev)); g->tx_fm_armed = false; }
+  std::vector<uint8_t> &fm = g->h_fmod;
   fm.assign((size_t)8 * g->S, 0);
   for (int tn = 0; tn < 8; tn++)
     for (int a = 0; a < g->S; a++) fm[(size_t)tn * g->S + a] = (uint8_t)g->ctl[(size_t)a].fillerModulus[tn];
   G_HIP(g, hipMemcpyAsync(g->tx.fmod, fm.data(), fm.size(), hipMemcpyHostToDevice, st));
+  G_HIP(g, hipEventRecord(g->tx_fm_ev, st));
+  g->tx_fm_armed = true;
   g->fmod_dirty = false;
   return TRXSIG_OK;
 }
@@ -741,7 +749,10 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
       return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: ARFCN, timeslot or frame number out of range (nothing was queued)", hipSuccess);
   }
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
-  G_LIB(tx_sync_modulus(g, st, k));
+  G_LIB(tx_sync_modulus(g, st));
+  // (everything on the context's stream: the upload on a stream of its own, so that batch i + 1's DMA would run beside batch i's
+  //  kernels, was measured -- 170 instead of 85 us per 8,192-burst step: the cross-stream waits cost the host calls and the queue
+  //  more than the 25 us of DMA they hide, profiles/r05_group_tx_bench.txt)
   G_HIP(g, g->tx_dgram.need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES, st)); G_HIP(g, g->tx_arfcn.need((size_t)n, st));
   G_HIP(g, hipMemcpyAsync(g->tx_arfcn.p, h_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
   G_HIP(g, hipMemcpyAsync(g->tx_dgram.p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, st));
@@ -786,12 +797,7 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
   Guard gd(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   G_LIB(tx_setup(g));
-  if (g->fmod_dirty) {
-    int set = 0;
-    G_LIB(tx_take_set(g, &set));
-    G_LIB(tx_sync_modulus(g, st, set));
-    G_LIB(tx_seal_set(g, set, st));
-  }
+  G_LIB(tx_sync_modulus(g, st));
   const size_t cells = (size_t)n_slots * g->S;
   G_HIP(g, g->tx_opid.need(cells, st)); G_HIP(g, g->tx_ofq.need(cells, st)); G_HIP(g, g->tx_bits.need(cells * 148, st));
   G_HIP(g, g->tx_gain.need(cells, st)); G_HIP(g, g->tx_fq.need(cells, st));

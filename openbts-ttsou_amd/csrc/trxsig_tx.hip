@@ -370,6 +370,21 @@ __global__ __launch_bounds__(256) void k_rx_resample(TrxResampleArgs a, int n_wi
 // trxsig_txbe_push_bursts, fused mode: the bits (and gains) of the pushed bursts go into the per-stream burst ring
 __global__ __launch_bounds__(256) void k_tx_ring_store(const uint8_t *__restrict__ bits, const float *__restrict__ gain, int S, int nb,
                                                        int head, int cap, uint8_t *__restrict__ ring, float *__restrict__ gring) {
+  // a thread per 32-bit word (148 bytes = 37 words; both arrays are word-aligned: hipMalloc'd, 148 = 4 * 37), the 38th thread of a burst its gain
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)S * nb * 38) return;
+  const int i = (int)(g / 38), w = (int)(g - (long long)i * 38);   // i = (stream, burst)
+  const int s = i / nb, j = i - s * nb;
+  const int slot = (head + j) % cap;
+  if (w < 37)
+    reinterpret_cast<uint32_t *>(ring + ((size_t)s * cap + slot) * 148)[w] = reinterpret_cast<const uint32_t *>(bits + (size_t)i * 148)[w];
+  else
+    gring[(size_t)s * cap + slot] = gain ? gain[i] : 1.0f;
+}
+
+// (the same byte by byte, for a caller's bit array that is not word-aligned)
+__global__ __launch_bounds__(256) void k_tx_ring_store_bytes(const uint8_t *__restrict__ bits, const float *__restrict__ gain, int S, int nb,
+                                                             int head, int cap, uint8_t *__restrict__ ring, float *__restrict__ gring) {
   const int i = blockIdx.x;                                // (stream, burst)
   const int s = i / nb, j = i - s * nb;
   const int slot = (head + j) % cap;
@@ -536,6 +551,11 @@ hipError_t trx_launch_convert(hipStream_t st, int pack, const void *in, long lon
 hipError_t trx_launch_tx_ring_store(hipStream_t st, const uint8_t *bits, const float *gain, int S, int nb, int head, int cap, uint8_t *ring,
                                     float *gring) {
   if (S * nb <= 0) return hipSuccess;
-  k_tx_ring_store<<<dim3(S * nb), dim3(256), 0, st>>>(bits, gain, S, nb, head, cap, ring, gring);
+  if (((uintptr_t)bits | (uintptr_t)ring) & 3) {
+    k_tx_ring_store_bytes<<<dim3(S * nb), dim3(256), 0, st>>>(bits, gain, S, nb, head, cap, ring, gring);
+    return hipGetLastError();
+  }
+  const long long words = (long long)S * nb * 38;
+  k_tx_ring_store<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(bits, gain, S, nb, head, cap, ring, gring);
   return hipGetLastError();
 }

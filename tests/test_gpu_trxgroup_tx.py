@@ -241,7 +241,7 @@ def test_staged_add_equals_the_copying_add(pkg):
     refuses the batch and leaves the block with the caller."""
     import torch
     rng = np.random.default_rng(12)
-    S, F = 20, 40                                           # 20 ARFCNs (two workgroups of the ingest kernel, the second partly filled)
+    S, F = 20, 60                                           # 20 ARFCNs (two workgroups of the ingest kernel, the second partly filled)
     ctx = pkg.TrxSig(1, 0); ctx.use_torch_stream()
     ga = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
     gb = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
