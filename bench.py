@@ -183,12 +183,17 @@ class Normal:
         self.ctx.set_soft_mode(pkg.SOFT_TOLERANCE if self.soft_mode == "tolerance" else pkg.SOFT_EXACT)
         self.step(); self.ctx.synchronize(); torch.cuda.synchronize()      # (the outputs the later checks read are this mode's again)
         d = (mine[3].double() - theirs[3].double()).abs()
+        # what goes on the wire: (char) round(soft * 255) (Transceiver.cpp:669)
+        wa, wb = torch.round(mine[3] * 255.0).to(torch.int32), torch.round(theirs[3] * 255.0).to(torch.int32)
+        wire_diff = (wa != wb)
         return {"soft_mode": other, "value": round(B * steps / dt / 1e6, 3), "unit": "Mbursts/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
                 "kernels_ms": {self.kernel_names.get(k, k): round(v[0] / max(v[1], 1), 4) for k, v in pf.items()},
                 "against_this_mode": {"flags_identical": bool(torch.equal(mine[0], theirs[0])), "amp_identical": bool(torch.equal(mine[1], theirs[1])),
                                       "toa_identical": bool(torch.equal(mine[2], theirs[2])), "hard_bits_identical": bool(torch.equal(hard_a, hard_b)),
                                       "soft_max_abs_diff": float(d.max().item()), "soft_values_not_identical": round(float((d > 0).float().mean().item()), 4),
-                                      "guaranteed_bound": 7.4e-5}}
+                                      "guaranteed_bound": 7.4e-5,
+                                      "wire_bytes_differ": round(float(wire_diff.float().mean().item()), 7),
+                                      "wire_bytes_max_step": int((wa - wb).abs().max().item())}}
 
     def sanity(self):
         torch = self.torch

@@ -32,7 +32,14 @@ struct CorrGeom {
   static constexpr int NS = 2 * H + 1;                   // corr slots in a record (+1 meta slot)
   static constexpr int NE = 20 * SPS;                    // energyDetect window
   static constexpr int NEQ = (NE + 15) / 16;
+  // the detect -> peak record in memory (round 5): slot PAIRS -- float4 number j * Bpad + b holds slots 2j and 2j + 1 of burst
+  // b (slot NS = {M, energy}) -- so that k_tsc_peak2 fetches its 23-lag window and a side of the valley in 12 + 8 sixteen-byte
+  // loads instead of 38 eight-byte ones (a wave's load costs the vector memory pipe the same sixteen steps either way)
+  static constexpr int NPAIR = (NS + 2) / 2;
 };
+// slot s of burst b in the paired record (an eight-byte access: the peak kernels of the tuning build, the meta slot)
+template <typename T>
+__device__ __forceinline__ T &rec_slot(T *rec, int Bpad, int s, int b) { return rec[2 * ((size_t)(s >> 1) * Bpad + b) + (s & 1)]; }
 
 // energy += norm2(x[I]) for I = 0 .. NE-1 strictly in order; norm I lives in lane I%16 of
 // register nrm[I/16], and lane 0 of the row pulls it over with a DPP row shift.
@@ -70,51 +77,38 @@ __device__ __forceinline__ float energy_chain(float acc, const float (&nrm)[Corr
 // costs of the single-round kernel measured perfectly additive).
 template <int SPS>
 struct CorrIn {
+  typedef CorrGeom<SPS> G;
   static constexpr int NW = (CorrGeom<SPS>::NL + 15) / 16;     // window samples per lane
   cx w[NW];
   cx e[CorrGeom<SPS>::NEQ];
   int b;
   bool live, good;
+  // lane r holds window samples r, r + 16, .. and energy-window samples likewise: into the row / the norms' place
+  __device__ __forceinline__ void stage_window(cx *W, int r) const {
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const int q = r + 16 * i;
+      if (q < G::NL) W[G::FRONT + q] = w[i];
+    }
+  }
+  __device__ __forceinline__ void stage_norms(float *ef, int r) const {
+#pragma unroll
+    for (int q = 0; q < G::NEQ; q++) {
+      const int i = r + 16 * q;
+      if (i < G::NE) ef[i] = norm2(e[q]);
+    }
+  }
 };
-
-template <int SPS>
-__device__ __forceinline__ void corr_issue(CorrIn<SPS> &in, int b, int B, int r, const cx *__restrict__ samples,
-                                           const int32_t *__restrict__ offset, const int32_t *__restrict__ length) {
-  typedef CorrGeom<SPS> G;
-  in.b = b;
-  in.live = b < B;
-  int off = 0, len = 0;
-  if (in.live) { off = offset[b]; len = length[b]; }
-  in.good = in.live && (off >= 0) && (len >= 92 * SPS) && (len <= 157 * SPS) && (len % SPS == 0);
-  const cx *x = samples + (in.good ? off : 0);
-#pragma unroll
-  for (int i = 0; i < CorrIn<SPS>::NW; i++) {
-    const int q = r + 16 * i;
-    in.w[i] = (in.good && q < G::NL) ? x[56 * SPS + q] : mk(0, 0);
-  }
-#pragma unroll
-  for (int q = 0; q < G::NEQ; q++) {
-    const int i = r + 16 * q;
-    in.e[q] = (in.good && i < G::NE) ? x[i] : mk(0, 0);
-  }
-}
 
 // REC: write the detect->peak record (k_tsc_corr); otherwise the correlation just stays in W[0, NL)
 // (k_normal_quad).  M_out / energy_out: argmax lag and energy sum of the lane's burst.
 // EFIRST: E aliases the row (k_normal_quad): the energy window's norms are staged, summed and done
 // with before the correlation window is written over them.
-template <int SPS, bool REC, bool EFIRST = false, unsigned TAPCLS = TRX_TAPS_GENERIC>
-__device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 *E, int lane, int r, const cx (&tap)[16],
+template <int SPS, bool REC, bool EFIRST = false, unsigned TAPCLS = TRX_TAPS_GENERIC, typename IN = CorrIn<SPS>>
+__device__ __forceinline__ void corr_round(const IN &in, cx *W, float4 *E, int lane, int r, const cx (&tap)[16],
                                            cx *__restrict__ rec, int Bpad, int &M_out, float &energy_out) {
   typedef CorrGeom<SPS> G;
-  auto stage_norms = [&] {
-    float *ef = reinterpret_cast<float *>(E);
-#pragma unroll
-    for (int q = 0; q < G::NEQ; q++) {
-      const int i = r + 16 * q;
-      if (i < G::NE) ef[i] = norm2(in.e[q]);
-    }
-  };
+  auto stage_norms = [&] { in.stage_norms(reinterpret_cast<float *>(E), r); };
   // energyDetect: energy += norm2(x[i]), i = 0 .. 20*sps-1, strictly in order (:925-928).  Every
   // lane of the row adds the norms up sequentially (same address in a row -> broadcast reads);
   // a DPP row-shift chain does the same but issues ~5x slower per step.
@@ -141,11 +135,7 @@ __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 
   // ---- window (zero padded) and the energy window's norms into LDS ----
   for (int q = r; q < G::FRONT; q += 16) W[q] = mk(0, 0);
   for (int q = G::FRONT + G::NL + r; q < G::WPAD; q += 16) W[q] = mk(0, 0);
-#pragma unroll
-  for (int i = 0; i < CorrIn<SPS>::NW; i++) {
-    const int q = r + 16 * i;
-    if (q < G::NL) W[G::FRONT + q] = in.w[i];
-  }
+  in.stage_window(W, r);
   if (!EFIRST) stage_norms();
   wave_lds_fence();
   if (!EFIRST) energy = sum_norms();
@@ -194,18 +184,22 @@ __device__ __forceinline__ void corr_round(const CorrIn<SPS> &in, cx *W, float4 
 
   M_out = bestT;
   energy_out = energy;
-  // ---- record: corr[M-H .. M+H] (zeros outside [0,NL)), then {M, energy} ----
+  // ---- record: corr[M-H .. M+H] (zeros outside [0,NL)), then {M, energy}; a lane writes slot pairs (one 16-byte store each) ----
   if (REC && in.live) {
     const int M = bestT;
-    for (int s = r; s <= G::NS; s += 16) {
+    auto slot = [&](int s) {
       cx v = mk(0, 0);
       if (s < G::NS) {
         const int lag = M - G::H + s;
         if (lag >= 0 && lag < G::NL) v = W[lag];
-      } else {
+      } else if (s == G::NS) {
         v = mk(__int_as_float(in.good ? M : -2), energy);  // M = -2 marks an invalid burst
       }
-      rec[(size_t)s * Bpad + in.b] = v;
+      return v;
+    };
+    for (int j = r; j < G::NPAIR; j += 16) {
+      const cx a = slot(2 * j), c = slot(2 * j + 1);
+      reinterpret_cast<float4 *>(rec)[(size_t)j * Bpad + in.b] = make_float4(a.r, a.i, c.r, c.i);
     }
   }
   wave_lds_fence();                                        // record reads done before the row is reused

@@ -24,7 +24,7 @@ namespace {
 
 constexpr int kTxA = 16;                                   // ARFCNs per workgroup
 constexpr int kTxQ = 256;                                   // queue entries per ARFCN held in LDS (= the queue's capacity, trxsig_trxgroup.cpp)
-constexpr int kTxWin = 4096;                                // datagrams per round: 64 chunks of a wave's width
+constexpr int kTxWin = 8192;                                // datagrams per round: 128 chunks of a wave's width (120 KB of LDS in all)
 constexpr int kTxChunks = kTxWin / 64;
 
 struct TxGainTab { float v[26]; };                          // pow(10, q), q = -12 .. 13 (host: the reference's double pow, rounded to float)
@@ -87,11 +87,22 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       my_i[cc] = i; my_k[cc] = valid ? local : -1; my_rank[cc] = rank;
     }
     __syncthreads();
-    if (tid < kTxA) {                                       // exclusive scan over the chunks, per ARFCN
-      int run = 0;
-      for (int c = 0; c < kTxChunks; c++) { const int v = cnt[c][tid]; cnt[c][tid] = run; run += v; }
-      tot[tid] = run;
-      nf0[tid] = nf[tid];
+    {                                                       // exclusive scan over the chunks, per ARFCN: wave k scans ARFCN k's column
+      static_assert(kTxChunks % 64 == 0 && kTxA == 16, "a wave per ARFCN, whole waves of chunks");
+      const int k = wave;
+      int carry = 0;
+      for (int c0 = 0; c0 < kTxChunks; c0 += 64) {
+        const int v = cnt[c0 + lane][k];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += o;
+        }
+        cnt[c0 + lane][k] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+      }
+      if (lane == 0) { tot[k] = carry; nf0[k] = nf[k]; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       const int RSSI = (int)(int8_t)(h2 >> 8);              // `int RSSI = (int) buffer[5]` on a char buffer (:617)
       const int gi = -RSSI / 10 + 12;                       // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division
       lf[lp] = (int32_t)fn;
-      lk[lp] = (tn & 7) | (gi << 3) | (k << 8) | ((my_i[cc] - w0) << 12);
+      lk[lp] = (tn & 7) | (gi << 3) | (k << 8) | ((my_i[cc] - w0) << 12);   // (13 bits of position: a round is 8,192 datagrams)
     }
     {
       const int k = tid & (kTxA - 1);

@@ -44,15 +44,15 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
 #pragma unroll
   for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
 
-  CorrIn<SPS> in[TRX_CORR_ROUNDS];
+  CorrInWide<SPS> in[TRX_CORR_ROUNDS];                       // (sixteen-byte loads: trxsig_corr.h)
 #pragma unroll
   for (int i = 0; i < TRX_CORR_ROUNDS; i++)
-    corr_issue<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
+    corr_issue_wide<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
 #pragma unroll
   for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
     int M;
     float energy;
-    corr_round<SPS, true, true, TAPCLS>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+    corr_round<SPS, true, true, TAPCLS, CorrInWide<SPS>>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
   }
 }
 
@@ -79,13 +79,13 @@ __global__ __launch_bounds__(64) void k_tsc_peak(const TrxTables *__restrict__ T
   const int bb = live ? b : B - 1;
 
   // ---- everything this lane will need from the record, loaded up front (coalesced across lanes) ----
-  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const cx meta = rec_slot(rec, Bpad, G::NS, bb);
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
   const bool good = M != -2;
 #pragma unroll
   for (int s = 0; s < G::NS; s++) {
-    const cx v = rec[(size_t)s * Bpad + bb];
+    const cx v = rec_slot(rec, Bpad, s, bb);
     pw[s][lane] = norm2(v);
     const int j = s - (G::H - 12);
     if (j >= 0 && j < 24) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restric
   cx *loc = reinterpret_cast<cx *>(S);
   float *pw = S + P8::O_PW, *V = S + P8::O_V;
 
-  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const cx meta = rec_slot(rec, Bpad, G::NS, bb);
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
   const bool good = M != -2;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 8) void k_tsc_peak8(const TrxTables *__restric
   for (int s0 = 0; s0 < G::NS; s0 += 8) {
     const int sl = s0 + r;
     if (sl < G::NS) {
-      const cx v = rec[(size_t)sl * Bpad + bb];
+      const cx v = rec_slot(rec, Bpad, sl, bb);
       pw[sl] = norm2(v);
       const int j = sl - (G::H - 12);
       if (j >= 0 && j < 24) loc[j] = (M - 12 + j > G::NL - 2) ? mk(0, 0) : v;   // never the last sample (:646)
@@ -307,24 +307,43 @@ __global__ __launch_bounds__(kPeak2Threads) void k_tsc_peak2(const TrxTables *__
   // ---- loads first: this thread's 12 float4 of the table, then its part of the detect->peak record ----
   float4 tv[3072 / kPeak2Threads];
   sinc_lds_issue<kPeak2Threads>(T, tid, tv);
-  const cx meta = rec[(size_t)G::NS * Bpad + bb];
+  const cx meta = rec_slot(rec, Bpad, G::NS, bb);
   const int M = __float_as_int(meta.r);
   const float energy = meta.i;
   const bool good = M != -2;
-  cx q[23];                                                // pair_bisect's window: corr[M - 12 + k + 2h]
+  const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
+  cx q[23];                                                // pair_bisect's window: corr[M - 12 + k + 2h] = record slots H - 12 + 2h + k
+  {
+    // twelve slot pairs from pair (H - 12) / 2 + h on: slot H - 12 + k + 2h is half (H - 12 + k) & 1 of pair number
+    // ((H - 12 + k) >> 1) - ((H - 12) >> 1) of them, whatever h is
+    constexpr int S0 = G::H - 12, P0 = S0 >> 1;
+    float4 pw[12];
 #pragma unroll
-  for (int k = 0; k < 23; k++) {
-    const int ix = k + 2 * h;
-    const cx v = rec[(size_t)(G::H - 12 + ix) * Bpad + bb];
-    q[k] = (M - 12 + ix > NL - 2) ? mk(0, 0) : v;          // interpolatePoint never uses the last sample (:646)
+    for (int i = 0; i < 12; i++) pw[i] = rec4[(size_t)(P0 + h + i) * Bpad + bb];
+#pragma unroll
+    for (int k = 0; k < 23; k++) {
+      const int ix = k + 2 * h;
+      const float4 p4 = pw[((S0 + k) >> 1) - P0];
+      const cx v = ((S0 + k) & 1) ? mk(p4.z, p4.w) : mk(p4.x, p4.y);
+      q[k] = (M - 12 + ix > NL - 2) ? mk(0, 0) : v;        // interpolatePoint never uses the last sample (:646)
+    }
   }
   // corr at M - (5sps+1) + k and M + (2sps-1) + k, k < NP: every lag the valley can touch (|rint(toa) - M| <= 1);
   // in flight with the rest, first needed in the tail
   // (the pair shares them: the even lane loads the side below the peak, the odd lane the side above -- one unconditional load each, the
   //  slot chosen by the lane's parity -- and the powers cross over by DPP when the tail wants them)
   cx vmine_[NP];
+  constexpr int VLO = G::H - (5 * SPS + 1), VHI = G::H + (2 * SPS - 1);
+  if constexpr ((VLO & 1) == 0 && (VHI & 1) == 0) {         // both sides start on a pair (sps 4): eight 16-byte loads
+    float4 pv[(NP + 1) / 2];
 #pragma unroll
-  for (int k = 0; k < NP; k++) vmine_[k] = rec[(size_t)((h ? G::H + (2 * SPS - 1) : G::H - (5 * SPS + 1)) + k) * Bpad + bb];
+    for (int i = 0; i < (NP + 1) / 2; i++) pv[i] = rec4[(size_t)(((h ? VHI : VLO) >> 1) + i) * Bpad + bb];
+#pragma unroll
+    for (int k = 0; k < NP; k++) vmine_[k] = (k & 1) ? mk(pv[k >> 1].z, pv[k >> 1].w) : mk(pv[k >> 1].x, pv[k >> 1].y);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NP; k++) vmine_[k] = rec_slot(rec, Bpad, (h ? VHI : VLO) + k, bb);
+  }
   sinc_lds_store<kPeak2Threads>(stab, tid, tv);
   TRX_STAMP();
   __syncthreads();                                         // the only barrier
@@ -557,9 +576,9 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES, TRX_RXD_WPS) void k_demod_rx(
 // ---------------------------------------------------------------------------------------------
 int trx_rec_slots(int sps) {
   switch (sps) {
-    case 1: return CorrGeom<1>::NS + 1;
-    case 2: return CorrGeom<2>::NS + 1;
-    case 4: return CorrGeom<4>::NS + 1;
+    case 1: return 2 * CorrGeom<1>::NPAIR;                  // (slot pairs: trxsig_corr.h)
+    case 2: return 2 * CorrGeom<2>::NPAIR;
+    case 4: return 2 * CorrGeom<4>::NPAIR;
   }
   return 0;
 }
