@@ -14,6 +14,9 @@
 #include "trxsig_demod.h"
 #include "trxsig_rxgen.h"
 
+#ifndef TRX_CORR_WIDE
+#define TRX_CORR_WIDE 1                                     /* k_tsc_corr: 1 = sixteen-byte sample loads (A/B: 0 = eight-byte, one sample per lane and load) */
+#endif
 #ifndef TRX_RXC_WPS
 #define TRX_RXC_WPS 1
 #endif
@@ -44,15 +47,25 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
 #pragma unroll
   for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
 
-  CorrInWide<SPS> in[TRX_CORR_ROUNDS];                       // (sixteen-byte loads: trxsig_corr.h)
+#if TRX_CORR_WIDE
+  typedef CorrInWide<SPS> In;                               // (sixteen-byte loads: trxsig_corr.h)
+#else
+  typedef CorrIn<SPS> In;
+#endif
+  In in[TRX_CORR_ROUNDS];
 #pragma unroll
-  for (int i = 0; i < TRX_CORR_ROUNDS; i++)
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
+#if TRX_CORR_WIDE
     corr_issue_wide<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
+#else
+    corr_issue<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
+#endif
+  }
 #pragma unroll
   for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
     int M;
     float energy;
-    corr_round<SPS, true, true, TAPCLS, CorrInWide<SPS>>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
+    corr_round<SPS, true, true, TAPCLS, In>(in[i], rows[slot], reinterpret_cast<float4 *>(rows[slot]), lane, r, tap, rec, Bpad, M, energy);
   }
 }
 
