@@ -122,59 +122,6 @@ __device__ __forceinline__ void corr_issue(CorrIn<SPS> &in, int b, int B, int r,
   }
 }
 
-// The same inputs fetched SIXTEEN bytes at a time (round 5, A/B: TRX_CORR_WIDE): lane r holds the sample PAIRS r, r + 16, .. of each
-// window -- 5 + 3 loads instead of 9 + 5 at sps 4.
-template <int SPS>
-struct CorrInWide {
-  typedef CorrGeom<SPS> G;
-  static_assert(G::NL % 2 == 0 && G::NE % 2 == 0 && G::FRONT % 2 == 0, "whole pairs, sixteen-byte aligned in the row");
-  static constexpr int NWP = (G::NL / 2 + 15) / 16, NEP = (G::NE / 2 + 15) / 16;
-  float4 w[NWP], e[NEP];
-  int b;
-  bool live, good;
-  __device__ __forceinline__ void stage_window(cx *W, int r) const {
-#pragma unroll
-    for (int i = 0; i < NWP; i++) {
-      const int p = r + 16 * i;
-      if (2 * p < G::NL) *reinterpret_cast<float4 *>(W + G::FRONT + 2 * p) = w[i];
-    }
-  }
-  __device__ __forceinline__ void stage_norms(float *ef, int r) const {
-#pragma unroll
-    for (int i = 0; i < NEP; i++) {
-      const int p = r + 16 * i;
-      if (2 * p < G::NE) *reinterpret_cast<float2 *>(ef + 2 * p) = make_float2(norm2(mk(e[i].x, e[i].y)), norm2(mk(e[i].z, e[i].w)));
-    }
-  }
-};
-template <int SPS>
-__device__ __forceinline__ void corr_issue_wide(CorrInWide<SPS> &in, int b, int B, int r, const cx *__restrict__ samples,
-                                                const int32_t *__restrict__ offset, const int32_t *__restrict__ length) {
-  typedef CorrGeom<SPS> G;
-  in.b = b;
-  in.live = b < B;
-  int off = 0, len = 0;
-  if (in.live) { off = offset[b]; len = length[b]; }
-  in.good = in.live && (off >= 0) && (len >= 92 * SPS) && (len <= 157 * SPS) && (len % SPS == 0);
-  const cx *x = samples + (in.good ? off : 0);
-  const bool even = (off & 1) == 0;                         // sixteen-byte aligned burst (56 * SPS is even); else two halves
-  auto pair = [&](const cx *p) {
-    if (even) return *reinterpret_cast<const float4 *>(p);
-    const cx a = p[0], c = p[1];
-    return make_float4(a.r, a.i, c.r, c.i);
-  };
-#pragma unroll
-  for (int i = 0; i < CorrInWide<SPS>::NWP; i++) {
-    const int p = r + 16 * i;
-    in.w[i] = (in.good && 2 * p < G::NL) ? pair(x + 56 * SPS + 2 * p) : make_float4(0, 0, 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < CorrInWide<SPS>::NEP; i++) {
-    const int p = r + 16 * i;
-    in.e[i] = (in.good && 2 * p < G::NE) ? pair(x + 2 * p) : make_float4(0, 0, 0, 0);
-  }
-}
-
 // REC: write the detect->peak record (k_tsc_corr); otherwise the correlation just stays in W[0, NL)
 // (k_normal_quad).  M_out / energy_out: argmax lag and energy sum of the lane's burst.
 // EFIRST: E aliases the row (k_normal_quad): the energy window's norms are staged, summed and done

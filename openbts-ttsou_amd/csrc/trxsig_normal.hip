@@ -14,9 +14,6 @@
 #include "trxsig_demod.h"
 #include "trxsig_rxgen.h"
 
-#ifndef TRX_CORR_WIDE
-#define TRX_CORR_WIDE 1                                     /* k_tsc_corr: 1 = sixteen-byte sample loads (A/B: 0 = eight-byte, one sample per lane and load) */
-#endif
 #ifndef TRX_RXC_WPS
 #define TRX_RXC_WPS 1
 #endif
@@ -47,20 +44,13 @@ __global__ __launch_bounds__(256, TRX_CORR_WPS) void k_tsc_corr(const TrxTables 
 #pragma unroll
   for (int k = 0; k < 16; k++) tap[k] = mk(taps.v[2 * k], taps.v[2 * k + 1]);
 
-#if TRX_CORR_WIDE
-  typedef CorrInWide<SPS> In;                               // (sixteen-byte loads: trxsig_corr.h)
-#else
+  // (sixteen-byte sample loads -- lane r the sample PAIRS r, r + 16, ..: 5 + 3 loads instead of 9 + 5, 16-byte LDS writes -- were built
+  //  and measured in round 5, same box, three times back to back: 34.2-35.9 against 33.0-34.0 us; not kept, profiles/r05_corr_wide_loads_ab.txt)
   typedef CorrIn<SPS> In;
-#endif
   In in[TRX_CORR_ROUNDS];
 #pragma unroll
-  for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
-#if TRX_CORR_WIDE
-    corr_issue_wide<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
-#else
+  for (int i = 0; i < TRX_CORR_ROUNDS; i++)
     corr_issue<SPS>(in[i], (blockIdx.x * TRX_CORR_ROUNDS + i) * 16 + slot, B, r, samples, offset, length);
-#endif
-  }
 #pragma unroll
   for (int i = 0; i < TRX_CORR_ROUNDS; i++) {
     int M;
