@@ -370,8 +370,9 @@ __device__ __forceinline__ float umax_f(float a, float b) {
 #define TRX_TOL_GUARD 3.0517578125e-05f       /* 512 u = 2^-15: |re'| must exceed this times Z (+ 2^-22) for the hard bit to be safe */
 
 // fused_demod_tol_ex: the staging step handed in, as fused_demod_ex -- stage_raw(P, lo) writes sample n, AS IT IS, to position
-// u = n + lo (entry (u % SPS) * QLEN + u / SPS) for every n in [0, N) whose position lies in [0, U); it is only called with
-// lo >= 0, after the positions outside [lo, lo + N) have been zeroed.  xm_lane: max(|re|, |im|) over the samples this lane holds.
+// u = n + lo (entry (u % SPS) * QLEN + u / SPS) for every n in [0, N) whose position lies in [0, U) (lo may be negative: an access
+// burst's delay shifts samples off the front), after the positions outside [lo, lo + N) have been zeroed.  xm_lane: max(|re|, |im|)
+// over the samples this lane holds.
 template <int SPS, typename STAGE>
 __device__ __forceinline__ bool fused_demod_tol_ex(const TrxTables *__restrict__ T, cx *P, int N, cx amp, float toa, int hl, float *sb,
                                                    uint8_t *hbp, int nsoft, float xm_lane, STAGE stage_raw) {
@@ -400,7 +401,7 @@ __device__ __forceinline__ bool fused_demod_tol_ex(const TrxTables *__restrict__
   const float inv1 = fabsf(inv.r) + fabsf(inv.i);
   const float Z = xm * inv1;
   // (written so that a NaN or an infinity in amp / TOA fails; a NaN SAMPLE passes fmaxf unseen and is caught at the outputs below)
-  const bool eligible = (f < 512) && ((float)f == f512) && (lo >= 0) && (xm >= 1e-15f) && (xm <= 1e15f) && (inv1 >= 1e-15f) &&
+  const bool eligible = (f < 512) && ((float)f == f512) && (xm >= 1e-15f) && (xm <= 1e15f) && (inv1 >= 1e-15f) &&
                         (inv1 <= 1e15f) && (Z <= TRX_TOL_ZMAX);
   if (!__builtin_amdgcn_readfirstlane(eligible)) return false;
   f = __builtin_amdgcn_readfirstlane(f);
@@ -411,7 +412,7 @@ __device__ __forceinline__ bool fused_demod_tol_ex(const TrxTables *__restrict__
   // ---- stage the samples AS THEY ARE at position n + io + C (polyphase order); zero the positions left uncovered ----
   wave_lds_fence();
   for (int u = hl; u < lo && u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
-  for (int u = hi + hl; u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
+  for (int u = (hi > 0 ? hi : 0) + hl; u < D::U; u += 64) P[(u % SPS) * D::QLEN + u / SPS] = mk(0, 0);
   stage_raw(P, lo);
   wave_lds_fence();
 
@@ -494,14 +495,24 @@ __device__ __forceinline__ bool fused_demod_tol(const TrxTables *__restrict__ T,
     xm = max3_abs(v[i].z, v[i].w, xm);
   }
   auto stage_raw = [&](cx *P_, int lo) {
-    const int ua = 2 * hl + lo, ub = ua + 1;
-    cx *pa = P_ + (ua % SPS) * D::QLEN + ua / SPS;
-    cx *pb = P_ + (ub % SPS) * D::QLEN + ub / SPS;
+    if (lo >= 0) {                                          // the common case: nothing falls off the front
+      const int ua = 2 * hl + lo, ub = ua + 1;
+      cx *pa = P_ + (ua % SPS) * D::QLEN + ua / SPS;
+      cx *pb = P_ + (ub % SPS) * D::QLEN + ub / SPS;
 #pragma unroll
-    for (int i = 0; i < G::NLD; i++) {
-      if (2 * (hl + 64 * i) < N) {
-        if (ua + 128 * i < D::U) pa[i * (128 / SPS)] = mk(v[i].x, v[i].y);
-        if (ub + 128 * i < D::U) pb[i * (128 / SPS)] = mk(v[i].z, v[i].w);
+      for (int i = 0; i < G::NLD; i++) {
+        if (2 * (hl + 64 * i) < N) {
+          if (ua + 128 * i < D::U) pa[i * (128 / SPS)] = mk(v[i].x, v[i].y);
+          if (ub + 128 * i < D::U) pb[i * (128 / SPS)] = mk(v[i].z, v[i].w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < G::NLD; i++) {
+        const int n0 = 2 * (hl + 64 * i);
+        const int u0 = n0 + lo, u1 = u0 + 1;
+        if (n0 < N && u0 >= 0 && u0 < D::U) P_[(u0 % SPS) * D::QLEN + u0 / SPS] = mk(v[i].x, v[i].y);
+        if (n0 + 1 < N && u1 >= 0 && u1 < D::U) P_[(u1 % SPS) * D::QLEN + u1 / SPS] = mk(v[i].z, v[i].w);
       }
     }
   };

@@ -559,13 +559,21 @@ __global__ __launch_bounds__(64 * TRX_DEMOD_WAVES, TRX_RXD_WPS) void k_demod_rx(
 #pragma unroll
     for (int i = 0; i < NSL; i++)
       if (lane + 64 * i < N) xm = max3_abs(sv[i].r, sv[i].i, xm);
-    auto stage_raw = [&](cx *P, int lo) {                   // (lo >= 0: nothing falls off the front)
+    auto stage_raw = [&](cx *P, int lo) {
       typedef DemodGeom<SPS, 148> D;
       const int u0 = lane + lo;
-      cx *p0 = P + (u0 % SPS) * D::QLEN + u0 / SPS;
+      if (u0 >= 0) {
+        cx *p0 = P + (u0 % SPS) * D::QLEN + u0 / SPS;
 #pragma unroll
-      for (int i = 0; i < NSL; i++)
-        if (lane + 64 * i < N && u0 + 64 * i < D::U) p0[i * (64 / SPS)] = sv[i];
+        for (int i = 0; i < NSL; i++)
+          if (lane + 64 * i < N && u0 + 64 * i < D::U) p0[i * (64 / SPS)] = sv[i];
+      } else {                                              // (an access burst's delay: some of this lane's samples fall off the front)
+#pragma unroll
+        for (int i = 0; i < NSL; i++) {
+          const int uu = u0 + 64 * i;
+          if (lane + 64 * i < N && uu >= 0 && uu < D::U) P[(uu % SPS) * D::QLEN + uu / SPS] = sv[i];
+        }
+      }
     };
     if (fused_demod_tol_ex<SPS>(T, ph[wave], N, amp, toa, lane, sb, hb, nsoft, xm, stage_raw)) return;
   }

@@ -39,48 +39,78 @@ struct TrxqView {
   int32_t *fn;                                              // element i at fn[i * stride]
   int32_t *key;                                             // tn | id << 3
   int stride;
+  TRXQ_HD int32_t f(int i) const { return fn[i * stride]; }
+  TRXQ_HD int32_t k(int i) const { return key[i * stride]; }
+  TRXQ_HD void set(int i, int32_t vf, int32_t vk) const { fn[i * stride] = vf; key[i * stride] = vk; }
 };
+#if defined(__HIPCC__)
+// The same queue held by ONE WAVE in eight registers (device only, round 5): element i is lane i & 63 of register i >> 6 (fn and key
+// apart), read with v_readlane and written by a compare-and-select at a wave-uniform index -- a heap move costs a few scalar-ish
+// instructions instead of a round trip to LDS or memory.  Capacity 256 = the transmit queue's.
+struct TrxqWave {
+  int32_t f0, f1, f2, f3, k0, k1, k2, k3;
+  int lane;                                                 // this lane's number (a write is a compare + select on it: the compiler has no writelane builtin)
+  __device__ __forceinline__ int32_t f(int i) const {
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int r = i >> 6, l = i & 63;
+    return r == 0 ? __builtin_amdgcn_readlane(f0, l) : (r == 1 ? __builtin_amdgcn_readlane(f1, l) : (r == 2 ? __builtin_amdgcn_readlane(f2, l) : __builtin_amdgcn_readlane(f3, l)));
+  }
+  __device__ __forceinline__ int32_t k(int i) const {
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int r = i >> 6, l = i & 63;
+    return r == 0 ? __builtin_amdgcn_readlane(k0, l) : (r == 1 ? __builtin_amdgcn_readlane(k1, l) : (r == 2 ? __builtin_amdgcn_readlane(k2, l) : __builtin_amdgcn_readlane(k3, l)));
+  }
+  __device__ __forceinline__ void set(int i, int32_t vf, int32_t vk) {
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int r = i >> 6, l = i & 63;
+    const bool me = lane == l;
+    if (r == 0) { f0 = me ? vf : f0; k0 = me ? vk : k0; }
+    else if (r == 1) { f1 = me ? vf : f1; k1 = me ? vk : k1; }
+    else if (r == 2) { f2 = me ? vf : f2; k2 = me ? vk : k2; }
+    else { f3 = me ? vf : f3; k3 = me ? vk : k3; }
+  }
+};
+#endif
 TRXQ_HD bool trxq_cmp(int32_t fn1, int32_t key1, int32_t fn2, int32_t key2) {   // PointerCompare: *v1 > *v2
   return trxq_time_gt(fn1, key1 & 7, fn2, key2 & 7);
 }
 // std::__push_heap(first, holeIndex, topIndex, value, comp)
-TRXQ_HD void trxq_sift_up(const TrxqView &q, int hole, int top, int32_t vfn, int32_t vkey) {
+template <class Q>
+TRXQ_HD void trxq_sift_up(Q &q, int hole, int top, int32_t vfn, int32_t vkey) {
   int parent = (hole - 1) / 2;
-  while (hole > top && trxq_cmp(q.fn[parent * q.stride], q.key[parent * q.stride], vfn, vkey)) {
-    q.fn[hole * q.stride] = q.fn[parent * q.stride];
-    q.key[hole * q.stride] = q.key[parent * q.stride];
+  while (hole > top && trxq_cmp(q.f(parent), q.k(parent), vfn, vkey)) {
+    q.set(hole, q.f(parent), q.k(parent));
     hole = parent;
     parent = (hole - 1) / 2;
   }
-  q.fn[hole * q.stride] = vfn;
-  q.key[hole * q.stride] = vkey;
+  q.set(hole, vfn, vkey);
 }
 // priority_queue::push: c.push_back(value); std::push_heap(c.begin(), c.end()).  n = size before; returns the new size
-TRXQ_HD int trxq_push(const TrxqView &q, int n, int32_t vfn, int32_t vkey) {
+template <class Q>
+TRXQ_HD int trxq_push(Q &q, int n, int32_t vfn, int32_t vkey) {
   trxq_sift_up(q, n, 0, vfn, vkey);
   return n + 1;
 }
 // priority_queue::pop: std::pop_heap(c.begin(), c.end()); c.pop_back().  The top (element 0) is handed out through
 // *tfn / *tkey; n = size before (> 0); returns the new size
-TRXQ_HD int trxq_pop(const TrxqView &q, int n, int32_t *tfn, int32_t *tkey) {
-  *tfn = q.fn[0];
-  *tkey = q.key[0];
+template <class Q>
+TRXQ_HD int trxq_pop(Q &q, int n, int32_t *tfn, int32_t *tkey) {
+  *tfn = q.f(0);
+  *tkey = q.k(0);
   if (n > 1) {
     // __pop_heap(first, last - 1, last - 1): value = *(last - 1); __adjust_heap(first, 0, len = n - 1, value)
     const int len = n - 1;
-    const int32_t vfn = q.fn[len * q.stride], vkey = q.key[len * q.stride];
+    const int32_t vfn = q.f(len), vkey = q.k(len);
     int hole = 0, second = 0;
     while (second < (len - 1) / 2) {
       second = 2 * (second + 1);
-      if (trxq_cmp(q.fn[second * q.stride], q.key[second * q.stride], q.fn[(second - 1) * q.stride], q.key[(second - 1) * q.stride])) second--;
-      q.fn[hole * q.stride] = q.fn[second * q.stride];
-      q.key[hole * q.stride] = q.key[second * q.stride];
+      if (trxq_cmp(q.f(second), q.k(second), q.f(second - 1), q.k(second - 1))) second--;
+      q.set(hole, q.f(second), q.k(second));
       hole = second;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
       second = 2 * (second + 1);
-      q.fn[hole * q.stride] = q.fn[(second - 1) * q.stride];
-      q.key[hole * q.stride] = q.key[(second - 1) * q.stride];
+      q.set(hole, q.f(second - 1), q.k(second - 1));
       hole = second - 1;
     }
     trxq_sift_up(q, hole, 0, vfn, vkey);

@@ -152,12 +152,13 @@ def test_hostile_bursts_equal_the_exact_mode(pkg):
     amp[27] *= np.float32(0.01); cases["Z far above 8"] = [27]
     toa[28] = np.float32(-2.0); cases["integer delay (no filter)"] = [28]
     toa[29] = np.float32(1.00390625); cases["fraction 0.996"] = [29]
-    toa[30] = np.float32(14.5); cases["samples fall off the front of the staging area"] = [30]
+    toa[30] = np.float32(14.5); cases["samples fall off the front of the staging area"] = [30]    # (an access burst's kind of delay)
+    toa[35] = np.float32(200.25); cases["samples fall off the front of the staging area"].append(35)
     toa[31] = np.float32(-3.5); cases["the first soft symbol reads before the burst"] = [31]
     toa[32] = np.float32(-0.001953125); cases["fraction 1/512: below the filter threshold"] = [32]
     x[burst(33)] *= np.float32(1e-30); amp[33] *= np.float32(1e-30); cases["1/amp beyond 1e15"] = [33]
     x[burst(34)][::2] = 0; cases["every other sample zero"] = [34]
-    cases["ordinary, second half"] = list(range(35, 64))
+    cases["ordinary, second half"] = list(range(36, 64))
 
     def run(t):
         gb = GpuBatch(x, off, length, nsoft=148, stride=148)
@@ -172,7 +173,7 @@ def test_hostile_bursts_equal_the_exact_mode(pkg):
     assert np.array_equal(he, ht), "hard bits"
     must_be_exact = [k for k in cases if k not in ("ordinary", "ordinary, second half", "integer delay (no filter)", "fraction 0.996",
                                                    "the first soft symbol reads before the burst", "fraction 1/512: below the filter threshold",
-                                                   "every other sample zero")]
+                                                   "every other sample zero", "samples fall off the front of the staging area")]
     for k in must_be_exact:
         for b in cases[k]:
             assert np.array_equal(_bits(se[b]), _bits(st[b])), k

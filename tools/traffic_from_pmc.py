@@ -38,7 +38,7 @@ def main():
     cache = {}
     for wl, prefix, key, units, extra in WANT:
         if wl not in cache:
-            newest = [os.path.join(P, "r%02d_pmc_%s.txt" % (r, wl)) for r in (4, 3, 2)]   # the latest round that profiled this workload
+            newest = [os.path.join(P, "r%02d_pmc_%s.txt" % (r, wl)) for r in (5, 4, 3, 2)]   # the latest round that profiled this workload
             cache[wl] = parse([f for f in newest if os.path.exists(f)][0])
         hit = [k for k in cache[wl] if k.startswith(prefix) and "FETCH_SIZE" in cache[wl][k] and "WRITE_SIZE" in cache[wl][k]]
         if not hit:
@@ -49,8 +49,8 @@ def main():
                  hbm_bytes_per_launch=int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)))
         e["bursts_per_launch"] = units
         kernels[key] = e
-    doc = {"source": "profiles/r04_pmc_<workload>.txt (r03_, r02_ for workloads a later round did not profile) (rocprofv3 --pmc FETCH_SIZE / "
-                     "WRITE_SIZE in separate passes with --kernel-trace only, tools/pmc.sh via tools/r04_profiles.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; units KiB); "
+    doc = {"source": "profiles/r05_pmc_<workload>.txt (r04_, r03_, r02_ for workloads a later round did not profile; `normal` = the tolerance-mode demodulator, the headline's) (rocprofv3 --pmc FETCH_SIZE / "
+                     "WRITE_SIZE in separate passes with --kernel-trace only, tools/pmc.sh via tools/r05_profiles.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; units KiB); "
                      "rebuilt by tools/traffic_from_pmc.py", "kernels": kernels}
     json.dump(doc, open(os.path.join(P, "traffic.json"), "w"), indent=1)
     for k, v in kernels.items():
