@@ -57,6 +57,8 @@ struct TrxGroupReplay {
   int32_t *tap_ix;                                         // tap-table entry the burst is equalised with
   float *snr;                                              // SNRestimate[ts] (:340) of an estimating burst
   double *thr_after;                                       // mEnergyThreshold after the burst
+  int *err;                                                // device word: bit 0 = a time-parallel replay left its loop at the round bound without a
+                                                           // validated result (never observed: the proof says at most K rounds); trxsig_trxgroup_collect reports it
 };
 // packed: scratch of n_slots * S float4 (the detectors' answers in (slot, ARFCN) order)
 // thr_g / verdict_g (and tix_g on the equalising leg, else NULL): trx_group_replay_scratch(S, n_slots) entries each, the replay's

@@ -314,7 +314,11 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
              __longlong_as_double(u_thr[first_bad < 0 ? 0 : first_bad][ai]), u_pf[first_bad < 0 ? 0 : first_bad][ai], sflag[first_bad < 0 ? 0 : first_bad][ai]);
     }
 #endif
-    if (all_done[par] || round > K + 1) return;                   // (at most K rounds; the bound only makes the exit unconditional)
+    if (all_done[par]) return;
+    if (round > K + 1) {                                          // (at most K rounds by construction; the bound only makes the exit unconditional --
+      if (tid == 0 && a.err) atomicOr(a.err, 1);                  //  and if it is ever hit, the host hears of it instead of getting unvalidated thresholds)
+      return;
+    }
   }
 }
 

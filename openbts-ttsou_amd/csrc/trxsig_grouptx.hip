@@ -4,15 +4,14 @@
 //   k_group_tx_ingest : driveTransmitPriorityQueue's parsing (:596-620) + addRadioVector (:100-113) ON THE DEVICE (round 5) from the
 //                       raw 154-byte datagrams and their ARFCN ids, as they arrived: a workgroup owns sixteen ARFCNs, finds
 //                       its datagrams (a stable counting sort by wave ballots: arrival order is kept inside an ARFCN),
-//                       parses TN / big-endian FN / RSSI, and a WAVE per ARFCN enters them in its queue -- the queue
-//                       (trxsig_txq.h: std::priority_queue's moves) sits in the wave's REGISTERS for the duration (TrxqWave:
-//                       v_readlane / v_writelane at uniform indices), the payload slots to hand out are fetched ahead --
-//                       then every thread copies payload words (148 bits + gain) to the slots;
-//   k_group_tx_push   : a wave per ARFCN walks n_slots timeslots: stale entries leave the queue for the filler table, the
+//                       parses TN / big-endian FN / RSSI, and a lane per ARFCN enters them in its queue -- the queue
+//                       (trxsig_txq.h: std::priority_queue's moves) sits in LDS for the duration, the payload slots to hand
+//                       out are fetched ahead -- then every thread copies payload words (148 bits + gain) to the slots;
+//   k_group_tx_push   : a lane per ARFCN walks n_slots timeslots: stale entries leave the queue for the filler table, the
 //                       entry for exactly this time (if any) replaces the filler entry and goes out, else the filler entry
-//                       goes out (:142-177) -- as payload REFERENCES, nothing is copied on the serial path; the queue is
-//                       in the wave's registers, the sixteen filler tables in LDS for the walk (round 4: a dependent global
-//                       access per queue move and per slot was the whole kernel);
+//                       goes out (:142-177) -- as payload REFERENCES, nothing is copied on the serial path; the sixteen
+//                       ARFCNs' queues AND filler tables are in LDS for the walk (round 5: a dependent global access per
+//                       queue move and per slot was the whole kernel);
 //   k_group_tx_gather : the referenced payloads into the layout trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n]
 //                       gains): what the fused transmit back end then modulates, resamples and packs to int16.
 // What is kept per burst is its bits and its gain, never its modulated samples: modulateBurst + scaleVector of the same bits
@@ -30,26 +29,29 @@ constexpr int kTxChunks = kTxWin / 64;
 
 struct TxGainTab { float v[26]; };                          // pow(10, q), q = -12 .. 13 (host: the reference's double pow, rounded to float)
 
-// an ARFCN's queue, memory <-> the eight registers of the wave that owns it (element i of ARFCN a lives at [i * S + a]; TrxqWave, trxsig_txq.h)
-__device__ __forceinline__ void txq_wave_load(TrxqWave &q, const TrxGroupTx &x, int a, int nq, int lane) {
-  q.lane = lane;
-  q.f0 = lane < nq ? x.q_fn[(size_t)lane * x.S + a] : 0;               q.k0 = lane < nq ? x.q_key[(size_t)lane * x.S + a] : 0;
-  q.f1 = lane + 64 < nq ? x.q_fn[(size_t)(lane + 64) * x.S + a] : 0;   q.k1 = lane + 64 < nq ? x.q_key[(size_t)(lane + 64) * x.S + a] : 0;
-  q.f2 = lane + 128 < nq ? x.q_fn[(size_t)(lane + 128) * x.S + a] : 0; q.k2 = lane + 128 < nq ? x.q_key[(size_t)(lane + 128) * x.S + a] : 0;
-  q.f3 = lane + 192 < nq ? x.q_fn[(size_t)(lane + 192) * x.S + a] : 0; q.k3 = lane + 192 < nq ? x.q_key[(size_t)(lane + 192) * x.S + a] : 0;
+// the sixteen queues of a workgroup, LDS <-> memory (element i of ARFCN a lives at [i * S + a])
+__device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, int32_t (*qf)[kTxQ], int32_t (*qk)[kTxQ], const int *nq) {
+  const int k = threadIdx.x & (kTxA - 1);
+  if (a0 + k < x.S)
+    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+      qf[k][i] = x.q_fn[(size_t)i * x.S + a0 + k];
+      qk[k][i] = x.q_key[(size_t)i * x.S + a0 + k];
+    }
 }
-__device__ __forceinline__ void txq_wave_store(const TrxqWave &q, const TrxGroupTx &x, int a, int nq, int lane) {
-  if (lane < nq) { x.q_fn[(size_t)lane * x.S + a] = q.f0; x.q_key[(size_t)lane * x.S + a] = q.k0; }
-  if (lane + 64 < nq) { x.q_fn[(size_t)(lane + 64) * x.S + a] = q.f1; x.q_key[(size_t)(lane + 64) * x.S + a] = q.k1; }
-  if (lane + 128 < nq) { x.q_fn[(size_t)(lane + 128) * x.S + a] = q.f2; x.q_key[(size_t)(lane + 128) * x.S + a] = q.k2; }
-  if (lane + 192 < nq) { x.q_fn[(size_t)(lane + 192) * x.S + a] = q.f3; x.q_key[(size_t)(lane + 192) * x.S + a] = q.k3; }
+__device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const int32_t (*qf)[kTxQ], const int32_t (*qk)[kTxQ], const int *nq) {
+  const int k = threadIdx.x & (kTxA - 1);
+  if (a0 + k < x.S)
+    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+      x.q_fn[(size_t)i * x.S + a0 + k] = qf[k][i];
+      x.q_key[(size_t)i * x.S + a0 + k] = qk[k][i];
+    }
 }
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // dgram: n x 154 bytes as they arrived ([0] TN, [1..4] FN big-endian, [5] RSSI, [6..153] one bit per byte); arfcn: n ids (the host
 // has checked every header: a call with a bad one queues nothing).
 __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn,
                                                           TxGainTab gt) {
+  __shared__ int32_t qf[kTxA][kTxQ], qk[kTxA][kTxQ];
   __shared__ int32_t lf[kTxWin], lk[kTxWin];                // this round's entries, ARFCN by ARFCN: frame number (then payload slot), key
   __shared__ int16_t fs[kTxWin];                            // the payload slots those entries will be handed, fetched ahead
   __shared__ int32_t cnt[kTxChunks][kTxA];
@@ -63,13 +65,8 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     st_[tid] = 0;
   }
   __syncthreads();
-  // wave k owns ARFCN a0 + k: its queue lives in the wave's registers from here to the end of the kernel
-  static_assert(kTxA == 16, "a wave per ARFCN");
-  const int my_a = a0 + wave;
-  const bool have_a = my_a < x.S;
-  TrxqWave q;
-  txq_wave_load(q, x, have_a ? my_a : 0, have_a ? nq[wave] : 0, lane);
-  for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 8,192 datagrams (LDS is sized for one)
+  tx_queues_load(x, a0, qf, qk, nq);
+  for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 4096 datagrams (LDS is sized for one)
     // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN) by ballots ----
     constexpr int CPW = kTxChunks / 16;                     // chunks per wave
     int my_i[CPW], my_k[CPW], my_rank[CPW];
@@ -136,32 +133,23 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
         for (int j = tid / kTxA; j < want; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf0[k] - 1 - j) * x.S + a0 + k];
     }
     __syncthreads();
-    // ---- addRadioVector: wave k enters ARFCN k's bursts, in arrival order, into the queue it holds in registers; 64 entries at a time
-    //      come out of LDS into a register each (lane j: entry j) and are read with v_readlane ----
-    if (have_a) {
-      const int k = wave;
-      int n_q = rfl(nq[k]), n_f = rfl(nf[k]), stt = rfl(st_[k]), used = 0;
-      const int e_end = rfl(lbase[k + 1]), fs0 = rfl(lbase[k]);
-      for (int e0 = fs0; e0 < e_end; e0 += 64) {
-        const int cntb = e_end - e0 < 64 ? e_end - e0 : 64;
-        const int fr = lane < cntb ? lf[e0 + lane] : 0, kr = lane < cntb ? lk[e0 + lane] : 0;
-        const int sr = fs[fs0 + used + lane < kTxWin ? fs0 + used + lane : kTxWin - 1];   // (entries past the fetched ones are never handed out)
-        int pr = -1, s_b = 0;
-        for (int j = 0; j < cntb; j++) {
-          int pid = -1;
-          if (n_q >= x.qcap || n_f == 0) {                  // queue or payload pool full: the burst is dropped and the ARFCN marked
-            stt |= 1;
-          } else {
-            n_f--;
-            pid = __builtin_amdgcn_readlane(sr, s_b); s_b++;
-            n_q = trxq_push(q, n_q, __builtin_amdgcn_readlane(fr, j), (__builtin_amdgcn_readlane(kr, j) & 7) | (pid << 3));   // mTransmitPriorityQueue.write(newVec) (:109)
-          }
-          pr = lane == j ? pid : pr;
+    // ---- addRadioVector, a lane per ARFCN, everything it touches in LDS ----
+    if (tid < kTxA && a0 + tid < x.S) {
+      const int k = tid;
+      const TrxqView q = {&qf[k][0], &qk[k][0], 1};
+      int n_q = nq[k], n_f = nf[k], used = 0, stt = st_[k];
+      for (int e = lbase[k]; e < lbase[k + 1]; e++) {
+        int pid = -1;
+        if (n_q >= x.qcap || n_f == 0) {                    // queue or payload pool full: the burst is dropped and the ARFCN marked
+          stt |= 1;
+        } else {
+          n_f--;
+          pid = fs[lbase[k] + used++];
+          n_q = trxq_push(q, n_q, lf[e], (lk[e] & 7) | (pid << 3));   // mTransmitPriorityQueue.write(newVec) (:109)
         }
-        used += s_b;
-        if (lane < cntb) lf[e0 + lane] = pr;
+        lf[e] = pid;
       }
-      if (lane == 0) { nq[k] = n_q; nf[k] = n_f; st_[k] = stt; }
+      nq[k] = n_q; nf[k] = n_f; st_[k] = stt;
     }
     __syncthreads();
     // ---- the payloads to their slots: every thread a word (37 words of bits, then the gain) ----
@@ -183,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     }
     __syncthreads();                                        // lf / lk / fs / cnt are the next round's
   }
-  if (have_a) txq_wave_store(q, x, my_a, rfl(nq[wave]), lane);
+  tx_queues_store(x, a0, qf, qk, nq);
   if (tid < kTxA && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
@@ -191,71 +179,77 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
   }
 }
 
+__device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int pid) {
+  if (pid < 0) return;                                      // the dummy burst is nobody's
+  x.free_stack[(size_t)nf * x.S + a] = (int16_t)pid;
+  nf++;
+}
+
 constexpr int kTxCells = 102 * 8;                           // fillerTable[102][8] (Transceiver.h:79)
-__global__ __launch_bounds__(1024) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
-                                                        uint8_t *__restrict__ out_fq) {
+__global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
+                                                       uint8_t *__restrict__ out_fq) {
+  __shared__ int32_t qf[kTxA][kTxQ], qk[kTxA][kTxQ];
   __shared__ int16_t fl[kTxA][kTxCells];                    // the sixteen filler tables
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a0 = blockIdx.x * kTxA;
+  __shared__ int nq[kTxA], nf[kTxA];
+  const int tid = threadIdx.x, a0 = blockIdx.x * kTxA;
+  if (tid < kTxA) {
+    const bool mine = a0 + tid < x.S;
+    nq[tid] = mine ? x.q_n[a0 + tid] : 0;
+    nf[tid] = mine ? x.free_n[a0 + tid] : 0;
+  }
+  __syncthreads();
+  tx_queues_load(x, a0, qf, qk, nq);
   {
     const int k = tid & (kTxA - 1);
     if (a0 + k < x.S)
-      for (int c = tid / kTxA; c < kTxCells; c += 1024 / kTxA) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
+      for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
   }
   __syncthreads();
-  // wave k walks ARFCN a0 + k's timeslots with the queue in its registers (TrxqWave): every value below is wave-uniform
-  const int a = a0 + wave;
-  if (a < x.S) {
-    const int k = wave;
-    int n_q = rfl(x.q_n[a]), n_f = rfl(x.free_n[a]);
-    TrxqWave q;
-    txq_wave_load(q, x, a, n_q, lane);
+  if (tid < kTxA && a0 + tid < x.S) {
+    const int k = tid, a = a0 + tid;
+    const TrxqView q = {&qf[k][0], &qk[k][0], 1};
+    int n_q = nq[k], n_f = nf[k];
     int mod[8];
 #pragma unroll
-    for (int m = 0; m < 8; m++) mod[m] = rfl(x.fmod[m * x.S + a]);
-    auto free_slot = [&](int pid) {                         // the payload slot a filler entry gives up goes back on the ARFCN's stack
-      if (pid < 0) return;                                  // (the dummy burst is nobody's)
-      if (lane == 0) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)pid;
-      n_f++;
-    };
+    for (int m = 0; m < 8; m++) mod[m] = x.fmod[m * x.S + a];
     for (int t = 0; t < n_slots; t++) {
       const int tn = (tn0 + t) & 7;
       int fn = fn0 + ((tn0 + t) >> 3);
       fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;    // (n_slots < 8 * gHyperframe: trxsig_trxgroup_push checks)
       fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
       // dump stale bursts, if any: "even if the burst is stale, put it in the filler table" (:142-153)
-      while (n_q > 0 && trxq_time_lt(q.f(0), q.k(0) & 7, fn, tn)) {
+      while (n_q > 0 && trxq_time_lt(q.fn[0], q.key[0] & 7, fn, tn)) {
         int32_t efn, ekey;
         n_q = trxq_pop(q, n_q, &efn, &ekey);
         const int etn = ekey & 7;
-        const int ci = (efn % mod[etn]) * 8 + etn;
-        free_slot(rfl((int)fl[k][ci]));
-        if (lane == 0) fl[k][ci] = (int16_t)(ekey >> 3);
-        __builtin_amdgcn_wave_barrier();
+        int16_t *cell = &fl[k][(efn % mod[etn]) * 8 + etn];
+        tx_free(x, a, n_f, *cell);
+        *cell = (int16_t)(ekey >> 3);
       }
-      const int ci = (fn % mod[tn]) * 8 + tn;
-      int cur = rfl((int)fl[k][ci]);
+      int16_t *cell = &fl[k][(fn % mod[tn]) * 8 + tn];
       int fq = 0;
-      if (n_q > 0 && q.f(0) == fn && (q.k(0) & 7) == tn) {  // data at the desired timestamp (:159-173)
+      if (n_q > 0 && q.fn[0] == fn && (q.key[0] & 7) == tn) {   // data at the desired timestamp (:159-173)
         int32_t efn, ekey;
         n_q = trxq_pop(q, n_q, &efn, &ekey);
-        free_slot(cur);
-        cur = ekey >> 3;
-        if (lane == 0) fl[k][ci] = (int16_t)cur;
+        tx_free(x, a, n_f, *cell);
+        *cell = (int16_t)(ekey >> 3);
         fq = 1;
       }
-      if (lane == 0) {
-        out_pid[(size_t)t * x.S + a] = (int16_t)cur;        // otherwise the filler entry (:175-177)
-        out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
-      }
+      out_pid[(size_t)t * x.S + a] = *cell;                 // otherwise the filler entry (:175-177)
+      out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
     }
-    txq_wave_store(q, x, a, n_q, lane);
-    if (lane == 0) { x.q_n[a] = n_q; x.free_n[a] = n_f; }
+    nq[k] = n_q; nf[k] = n_f;
   }
   __syncthreads();
+  tx_queues_store(x, a0, qf, qk, nq);
   {
     const int k = tid & (kTxA - 1);
     if (a0 + k < x.S)
-      for (int c = tid / kTxA; c < kTxCells; c += 1024 / kTxA) x.filler[(size_t)c * x.S + a0 + k] = fl[k][c];
+      for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) x.filler[(size_t)c * x.S + a0 + k] = fl[k][c];
+  }
+  if (tid < kTxA && a0 + tid < x.S) {
+    x.q_n[a0 + tid] = nq[tid];
+    x.free_n[a0 + tid] = nf[tid];
   }
 }
 
@@ -293,7 +287,7 @@ hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0
                                     uint8_t *bits_out, float *gain_out, uint8_t *fq_out) {
   if (n_slots <= 0) return hipSuccess;
   if (x.qcap != kTxQ) return hipErrorInvalidValue;
-  k_group_tx_push<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq);
+  k_group_tx_push<<<dim3((x.S + kTxA - 1) / kTxA), dim3(256), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq);
   const long long words = (long long)x.S * n_slots * TRXG_PAYLOAD_WORDS;
   k_group_tx_gather<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(x, n_slots, out_pid, out_fq, (uint32_t *)bits_out, gain_out,
                                                                                    fq_out);

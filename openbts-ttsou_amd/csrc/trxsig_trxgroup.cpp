@@ -65,6 +65,7 @@ struct trxsig_trxgroup {
   int32_t *d_pos = nullptr;                                 // [8][S]
   TrxGroupArfcn *d_state = nullptr;
   double *d_exp = nullptr;
+  int *d_err = nullptr;                                     // TrxGroupReplay::err
   // the demodulating leg runs the state machine (two waves, latency-bound) BESIDE demodulateBurst: a side stream, forked
   // from and joined back into the context's stream inside every pull
   hipStream_t side = nullptr;
@@ -197,6 +198,7 @@ int trxsig_trxgroup_create(trxsig_trxgroup **out, trxsig_ctx *c, int n_arfcn, in
   if (hipMalloc((void **)&g->d_gid, sizeof(uint16_t) * S8) != hipSuccess || hipMalloc((void **)&g->d_pos, sizeof(int32_t) * S8) != hipSuccess ||
       hipMalloc((void **)&g->d_state, sizeof(TrxGroupArfcn) * (size_t)S) != hipSuccess ||
       hipMalloc((void **)&g->d_exp, sizeof(double) * TRXG_EXP_N) != hipSuccess ||
+      hipMalloc((void **)&g->d_err, sizeof(int)) != hipSuccess || hipMemset(g->d_err, 0, sizeof(int)) != hipSuccess ||
       hipMemcpy(g->d_state, st.data(), sizeof(TrxGroupArfcn) * (size_t)S, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(g->d_exp, ex.data(), sizeof(double) * TRXG_EXP_N, hipMemcpyHostToDevice) != hipSuccess ||
       g->w_tab.need(S8 * 7, nullptr) != hipSuccess || g->b_tab.need(S8 * 5, nullptr) != hipSuccess || g->chan_off.need(S8, nullptr) != hipSuccess ||
@@ -221,7 +223,7 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     if (g->side) { (void)hipStreamSynchronize(g->side); (void)hipStreamDestroy(g->side); }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp);
+    (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp); (void)hipFree(g->d_err);
     for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
     g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
     if (g->tx_ready) {
@@ -390,7 +392,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   TrxGroupReplay rp = {};
   rp.S = S; rp.n_slots = n_slots; rp.fn0 = fn; rp.tn0 = tn; rp.equalize = equalize; rp.n_tsc_rows = n_tsc;
   rp.rowmap = W.rowmap.p; rp.flags = W.flags.p; rp.amp = W.amp.p; rp.avgpwr = W.avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
-  rp.gate = W.gate.p; rp.ev = W.ev.p; rp.tap_ix = W.tap_ix.p; rp.snr = W.snr.p; rp.thr_after = W.thr_after.p;
+  rp.gate = W.gate.p; rp.ev = W.ev.p; rp.tap_ix = W.tap_ix.p; rp.snr = W.snr.p; rp.thr_after = W.thr_after.p; rp.err = g->d_err;
   // Demodulating leg: demodulateBurst needs nothing the state machine decides except WHETHER a burst is handed up, and every
   // burst the machine accepts is one the stateless detector flagged -- so the rows the detectors flagged are demodulated on
   // the context's stream while the machine replays on the side stream (two waves for ~0.1 us per slot: it fills no CU), and
@@ -540,6 +542,8 @@ int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft,
   std::vector<trx_c32> amp(R);
   std::vector<float> toa(R), soft(h_soft ? R * kSoft : 0);
   std::vector<double> thr(h_threshold ? R : 0);
+  int replay_err = 0;
+  G_HIP(g, hipMemcpyAsync(&replay_err, g->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
   G_HIP(g, hipMemcpyAsync(row.data(), W.rowmap.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, st));
   if (R) {
     G_HIP(g, hipMemcpyAsync(gate.data(), W.gate.p, R, hipMemcpyDeviceToHost, st));
@@ -549,6 +553,10 @@ int trxsig_trxgroup_collect(trxsig_trxgroup *g, uint8_t *h_valid, float *h_soft,
     if (h_threshold) G_HIP(g, hipMemcpyAsync(thr.data(), W.thr_after.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
   }
   G_HIP(g, hipStreamSynchronize(st));
+  if (replay_err) {                                         // (k_group_replay_seg's round bound: the thresholds of that pull are not validated)
+    (void)hipMemsetAsync(g->d_err, 0, sizeof(int), st);
+    return trx_ctx_fail(c, TRXSIG_EHIP, "trxsig_trxgroup: the time-parallel replay of the state machine did not converge within its round bound", hipSuccess);
+  }
   for (size_t i = 0; i < cells; i++) {
     const int r = row[i];
     const bool ok = r >= 0 && (gate[(size_t)r] & TRXSIG_F_DETECT);

@@ -43,34 +43,10 @@ struct TrxqView {
   TRXQ_HD int32_t k(int i) const { return key[i * stride]; }
   TRXQ_HD void set(int i, int32_t vf, int32_t vk) const { fn[i * stride] = vf; key[i * stride] = vk; }
 };
-#if defined(__HIPCC__)
-// The same queue held by ONE WAVE in eight registers (device only, round 5): element i is lane i & 63 of register i >> 6 (fn and key
-// apart), read with v_readlane and written by a compare-and-select at a wave-uniform index -- a heap move costs a few scalar-ish
-// instructions instead of a round trip to LDS or memory.  Capacity 256 = the transmit queue's.
-struct TrxqWave {
-  int32_t f0, f1, f2, f3, k0, k1, k2, k3;
-  int lane;                                                 // this lane's number (a write is a compare + select on it: the compiler has no writelane builtin)
-  __device__ __forceinline__ int32_t f(int i) const {
-    i = __builtin_amdgcn_readfirstlane(i);
-    const int r = i >> 6, l = i & 63;
-    return r == 0 ? __builtin_amdgcn_readlane(f0, l) : (r == 1 ? __builtin_amdgcn_readlane(f1, l) : (r == 2 ? __builtin_amdgcn_readlane(f2, l) : __builtin_amdgcn_readlane(f3, l)));
-  }
-  __device__ __forceinline__ int32_t k(int i) const {
-    i = __builtin_amdgcn_readfirstlane(i);
-    const int r = i >> 6, l = i & 63;
-    return r == 0 ? __builtin_amdgcn_readlane(k0, l) : (r == 1 ? __builtin_amdgcn_readlane(k1, l) : (r == 2 ? __builtin_amdgcn_readlane(k2, l) : __builtin_amdgcn_readlane(k3, l)));
-  }
-  __device__ __forceinline__ void set(int i, int32_t vf, int32_t vk) {
-    i = __builtin_amdgcn_readfirstlane(i);
-    const int r = i >> 6, l = i & 63;
-    const bool me = lane == l;
-    if (r == 0) { f0 = me ? vf : f0; k0 = me ? vk : k0; }
-    else if (r == 1) { f1 = me ? vf : f1; k1 = me ? vk : k1; }
-    else if (r == 2) { f2 = me ? vf : f2; k2 = me ? vk : k2; }
-    else { f3 = me ? vf : f3; k3 = me ? vk : k3; }
-  }
-};
-#endif
+// (Round 5 also tried the queue in ONE WAVE's registers -- element i in lane i & 63 of register i >> 6, v_readlane reads, compare-and-select
+//  writes, a wave per ARFCN: rocprofv3 put k_group_tx_push at 247 us against 126 with the queues in LDS -- every access a readfirstlane,
+//  a four-way register select and a lane read, ~10 dependent scalar-vector hops where LDS needs one round trip; not kept.  The heap
+//  moves below are templates over the queue's storage since then.)
 TRXQ_HD bool trxq_cmp(int32_t fn1, int32_t key1, int32_t fn2, int32_t key2) {   // PointerCompare: *v1 > *v2
   return trxq_time_gt(fn1, key1 & 7, fn2, key2 & 7);
 }

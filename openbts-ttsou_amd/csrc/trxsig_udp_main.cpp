@@ -228,6 +228,8 @@ int main(int argc, char **argv) {
     for (;;) {
       int pfn = 0, ptn = 0;
       const int n = trxsig_txclock_advance(&txc, fn, 0, &pending_underrun, 64, &pfn, &ptn);
+      // (the loopback ring holds R frames: a latency the controller has grown beyond R - 2 frames would overwrite frames still on the air)
+      if (txc.latency_fn > air.R - 2) { txc.latency_fn = air.R - 2; txc.latency_tn = 0; }
       if (n <= 0) break;
       const uint8_t *d_bits = nullptr, *d_fq = nullptr;
       const float *d_gain = nullptr;
@@ -258,6 +260,9 @@ int main(int argc, char **argv) {
     const double busy = std::chrono::duration<double, std::micro>(clock_t_::now() - t0).count();
     busy_sum += busy; busy_max = std::max(busy_max, busy);
   }
+  int arfcns_dropped = 0;                                   // (a transmit queue holds 256 bursts per ARFCN; what did not fit was dropped and marked)
+  for (int i = 0; i < N; i++) { int d = 0; if (trxsig_trxgroup_tx_queue_size(grp, i, &d) >= 0 && d) arfcns_dropped++; }
+  if (arfcns_dropped) std::printf("WARNING: %d ARFCN(s) dropped transmit bursts (queue of 256 per ARFCN full)\n", arfcns_dropped);
   std::printf("frames %ld  arfcns %d  tx bursts received %ld  rx bursts sent %ld  malformed %ld  clock indications %ld  under-runs %ld  "
               "transmit latency %d:%d  service time per frame avg %.1f us max %.1f us (frame = %d us)\n",
               k, N, tx_recv, rx_sent, bad_len, clock_inds, underruns, txc.latency_fn, txc.latency_tn, k ? busy_sum / k : 0.0, busy_max, frame_us);

@@ -13,6 +13,15 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursi
     for row in csv.DictReader(open(f)):
         n = row["Name"]
         if "(anonymous namespace)::k_" in n:
-            short = n.split("::")[1].split("(")[0]
+            # `void (anonymous namespace)::k_demod<4, false, 148, (anonymous namespace)::SmpC32, true>(TrxTables const*, ...)` -> `k_demod<4, false, 148, SmpC32, true>`
+            t = n.replace("(anonymous namespace)::", "")
+            t = t[5:] if t.startswith("void ") else t
+            depth, cut = 0, len(t)
+            for i, ch in enumerate(t):
+                if ch == "<": depth += 1
+                elif ch == ">": depth -= 1
+                elif ch == "(" and depth == 0:
+                    cut = i; break
+            short = t[:cut]
             w.writerow([short, row["Calls"], row["TotalDurationNs"], row["AverageNs"], row["Percentage"],
                         row["MinNs"], row["MaxNs"], row["StdDev"]])
