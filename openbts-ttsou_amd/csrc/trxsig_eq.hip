@@ -1764,6 +1764,11 @@ __global__ __launch_bounds__(256) void k_eq_dfe3(const TrxTables *__restrict__ T
 #define TRX_D4_EXP 0          /* 1, 2, 3: timing experiments (wrong results): the delay / feed-forward / recursion role with most of its arithmetic left out */
 #endif
 #define EQ4_NT 20             /* 160 >= 157 symbols */
+#ifdef TRX_D4_PROBE
+#define D4_BARRIER() do { const long long a_ = clock64(); d4_work += a_ - d4_t; __syncthreads(); d4_t = clock64(); d4_wait += d4_t - a_; } while (0)
+#else
+#define D4_BARRIER() __syncthreads()
+#endif
 template <typename SMP>
 __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict__ T, const void *__restrict__ samples,
                                                     const int32_t *__restrict__ offset, const int32_t *__restrict__ length, int B,
@@ -1777,6 +1782,10 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
   __shared__ float sft[2][64][TK + 1];                      // consumer -> feed-forward wave (soft bits on their way out)
   __shared__ __attribute__((aligned(8))) float tapl[2][64][22];   // a delay wave's 21 taps per lane (registers are what the delay waves are short of)
   const int lane = threadIdx.x & 63;
+#ifdef TRX_D4_PROBE                                         // tools/dfe4_probe.py: per role, cycles between barriers (work) and at them (wait)
+  long long d4_t = clock64(), d4_work = 0, d4_wait = 0;
+  const long long d4_t0 = d4_t;
+#endif
   // (the roles rotate from workgroup to workgroup: a SIMD then hosts one wave of each role instead of four of a kind, and what it has to
   //  issue per step is the roles' average, not the heaviest role's)
   // (workgroups 256 apart tend to share a CU -- the dispatcher deals them out round-robin over 8 XCDs x 32 CUs --: those get different rotations)
@@ -1907,19 +1916,19 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
       outputs(u, ph_, std::integral_constant<int, 0>(), std::integral_constant<int, NC1>());
       const bool more = k + 1 < n_own;
       if (more) issue16(n0 + 16 * k + 32);                 // (after the sums: sixteen more live registers they have no room for) a step to land
-      __syncthreads();
+      D4_BARRIER();
       outputs(u, ph_, std::integral_constant<int, NC1>(), std::integral_constant<int, TK - NC1>());
       if (more) take16(n0 + 16 * k + 32, std::integral_constant<int, PH>());
-      __syncthreads();
+      D4_BARRIER();
     };
     constexpr int STEPS = S1 - S0 + 1;
     const int lead = d == 1 ? 0 : 1;                       // wave 3's tile -1 starts in step S0, wave 2's tile 0 a step later
-    for (int i = 0; i < lead; i++) __syncthreads();
+    for (int i = 0; i < lead; i++) D4_BARRIER();
     for (int k = 0; k < n_own; k += 2) {
       own_tile(k, std::integral_constant<int, 0>());
       if (k + 1 < n_own) own_tile(k + 1, std::integral_constant<int, 16>());
     }
-    for (int i = lead + 2 * n_own; i < STEPS; i++) __syncthreads();
+    for (int i = lead + 2 * n_own; i < STEPS; i++) D4_BARRIER();
   } else if (wave == 1) {
     // ---- the feed-forward FIR (k_eq_dfe2's producer) and the soft bits' way out ----
     const size_t tb = (tap_ix && det) ? (size_t)tap_ix[bb] : (tap_ix ? (size_t)0 : (size_t)bb);
@@ -1962,7 +1971,7 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
         for (int m = 0; m < 6; m++) win[m] = xa[TK - 1 - m];  // delayed samples 8 u + 13 - m: the next tile's x[k + 6 - j], j > i
       }
       if (s - 2 >= 0 && s - 2 <= NT - 1) write_out(s - 2);
-      __syncthreads();
+      D4_BARRIER();
     }
   } else {
     // ---- the decision-feedback recursion (k_eq_dfe2's consumer) ----
@@ -1984,10 +1993,19 @@ __global__ __launch_bounds__(256, 4) void k_eq_dfe4(const TrxTables *__restrict_
 #pragma unroll
         for (int i = 0; i < (TRX_D4_EXP == 3 ? 1 : TK); i++) sft[u & 1][lane][i] = dfe_step(TK * u + i, nout, ffv[i], rv[i], rt[i], bq, hist);
       }
-      __syncthreads();
+      D4_BARRIER();
     }
   }
+#ifdef TRX_D4_PROBE
+  // (the probe build hands the stamps back through the soft bits of the workgroup's first four bursts: row b0 + role = {work, wait, total})
+  if (lane == 0 && b0 + wave < B) {
+    float *o = soft + (size_t)(b0 + wave) * stride;
+    o[0] = (float)d4_work; o[1] = (float)d4_wait; o[2] = (float)(clock64() - d4_t0); o[3] = (float)wave;
+  }
+#endif
 }
+
+#undef D4_BARRIER
 
 // TRXSIG_EQ_DFE_VARIANT=1 (environment, A/B): the lane-per-burst k_eq_dfe instead of the producer/consumer k_eq_dfe2
 void launch_eq_dfe(hipStream_t st, const TrxTables *dT, const cx *xd, int xstride, const int32_t *len, int B, const uint8_t *flags,
