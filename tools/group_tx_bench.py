@@ -37,22 +37,35 @@ base[:, 0] = tn
 perm = rng.permutation(n)                                   # arrival order: ARFCNs interleaved
 base, arf, fo = base[perm], arf[perm], fo[perm]
 fn = 1000
-t_add = t_push = t_recv = 0.0
+t_add = t_push = t_recv = t_stage = t_pushonly = 0.0
 seen = set()
 
 
+K = 100
+# the frame numbers of every step's datagrams, made BEFORE the timed loop (this script's own numpy work is not the library's step)
+hdrs = []
+for k in range(K + 10):
+    f = (fn + F * k + fo).astype(np.uint32)
+    hdrs.append(np.stack([f >> 24, (f >> 16) & 255, (f >> 8) & 255, f & 255], axis=1).astype(np.uint8))
+step_no = 0
+
+
 def step():
-    global fn, t_add, t_push, t_recv
-    f = (fn + fo).astype(np.uint32)
-    base[:, 1] = f >> 24; base[:, 2] = (f >> 16) & 255; base[:, 3] = (f >> 8) & 255; base[:, 4] = f & 255
-    tr = time.perf_counter()
-    if STAGED:                                              # the datagrams "arrive" in the group's pinned block (a host would recvfrom() there)
+    global fn, t_add, t_push, t_recv, step_no
+    h = hdrs[step_no]; step_no += 1
+    global t_stage, t_pushonly
+    ts = time.perf_counter()
+    if STAGED:                                              # (the call may wait for the upload that last used this block: the library's time, counted)
         d, a = grp.tx_staging(n)
+    tr = time.perf_counter()
+    t_stage += tr - ts
+    if STAGED:                                              # the datagrams "arrive" in the group's pinned block (a host would recvfrom() there)
         key = d.ctypes.data
         if key not in seen:                                 # (two blocks alternate: the payloads are the same every step, written once per block)
             d[:] = base; a[:] = arf; seen.add(key)
-        else:
-            d[:, 1:5] = base[:, 1:5]                        # this step's frame numbers
+        d[:, 1:5] = h                                       # this step's frame numbers
+    else:
+        base[:, 1:5] = h
     t0 = time.perf_counter()
     t_recv += t0 - tr
     if STAGED:
@@ -61,23 +74,35 @@ def step():
         grp.add_bursts(base, arf)
     t1 = time.perf_counter()
     grp.push_txbe(be, fn, 0, 8 * F)
+    t2 = time.perf_counter()
     iq = be.pop_samples()
-    t_add += t1 - t0; t_push += time.perf_counter() - t1
+    t_add += t1 - t0; t_push += time.perf_counter() - t1; t_pushonly += t2 - t1
     fn += F
     return iq
 
 for _ in range(10): iq = step()
 torch.cuda.synchronize()
-K = 100
-t_add = t_push = t_recv = 0.0
+t_add = t_push = t_recv = t_stage = t_pushonly = 0.0
 t0 = time.perf_counter()
 for _ in range(K): iq = step()
 torch.cuda.synchronize()
 dt_all = (time.perf_counter() - t0) / K
-dt = dt_all - t_recv / K                                    # the emulated arrival of the datagrams (the socket's work) is not the library's step
+dt = dt_all                                                 # the step's wall time, the emulated arrival of the datagrams included (~35 us of numpy at
+                                                            # 8,192 datagrams).  (Until r05 session 17 this line subtracted the time spent in the arrival
+                                                            # block, which then also held trxsig_trxgroup_tx_staging's wait for the DEVICE: the 85 us steps
+                                                            # that accounting reported were ~350 us steps.  rocprofv3's kernel times had said so.)
 q, dropped = grp.tx_queue_size(0)
-print(json.dumps({"arfcns": S, "frames_per_step": F, "add": "trxsig_trxgroup_add_staged (received into the pinned block)" if STAGED else "trxsig_trxgroup_add_bursts (copy from a pageable array)", "bursts_per_step": n, "us_per_step": round(dt * 1e6, 1), "us_per_step_with_emulated_arrival": round(dt_all * 1e6, 1),
+# one step at a time (a synchronize after each): the step's latency on an idle device, for comparison with the pipelined rate
+K2 = 10
+hdrs += hdrs[:K2]
+for k in range(K2):
+    f = (fn + F * k + fo).astype(np.uint32)
+    hdrs[step_no + k] = np.stack([f >> 24, (f >> 16) & 255, (f >> 8) & 255, f & 255], axis=1).astype(np.uint8)
+tl = 0.0
+for _ in range(K2):
+    ta = time.perf_counter(); step(); torch.cuda.synchronize(); tl += time.perf_counter() - ta
+print(json.dumps({"arfcns": S, "frames_per_step": F, "add": "trxsig_trxgroup_add_staged (received into the pinned block)" if STAGED else "trxsig_trxgroup_add_bursts (copy from a pageable array)", "bursts_per_step": n, "us_per_step": round(dt * 1e6, 1), "host_us_emulating_arrival": round(t_recv / K * 1e6, 1),
                   "Mbursts_per_s": round(n / dt / 1e6, 2), "host_us_in_add_bursts": round(t_add / K * 1e6, 1),
-                  "host_us_in_push_and_pop": round(t_push / K * 1e6, 1), "int16_pairs_out_per_stream": int(iq.shape[1]),
-                  "queue_left": q, "dropped": dropped,
+                  "host_us_in_push_and_pop": round(t_push / K * 1e6, 1), "host_us_in_tx_staging": round(t_stage / K * 1e6, 1), "host_us_in_push_txbe": round(t_pushonly / K * 1e6, 1), "int16_pairs_out_per_stream": int(iq.shape[1]),
+                  "us_per_step_synchronised": round(tl / K2 * 1e6, 1), "queue_left": q, "dropped": dropped,
                   "one_burst_per_call_object": "trxsig_trx_add_radio_vector + _push_radio_vector: ~40 + ~10 us per burst (tools/host_path_bench.py)"}))
