@@ -19,31 +19,43 @@
 #include "trxsig_dev.h"
 #include "trxsig_group.h"
 #include "trxsig_txq.h"
+#include "trxsig_txq_lds.h"
+
+#ifdef TRX_TX_PROBE
+// probe build (make probe_tx, tools/group_tx_probe.py): clock64() at the phase boundaries of the two serial kernels, workgroup 0's wave 0
+__device__ unsigned long long g_txprobe[2][8];
+#define TX_STAMP(kern, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_txprobe[kern][i] = clock64(); } while (0)
+extern "C" int trx_txprobe_read(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_txprobe), sizeof(g_txprobe)); }
+#else
+#define TX_STAMP(kern, i) do { } while (0)
+#endif
 
 namespace {
 
 constexpr int kTxA = 16;                                   // ARFCNs per workgroup
-constexpr int kTxQ = 256;                                   // queue entries per ARFCN held in LDS (= the queue's capacity, trxsig_trxgroup.cpp)
+constexpr int kTxQ = TRXQ_LDS_CAP;                          // queue entries per ARFCN held in LDS (= the queue's capacity, trxsig_trxgroup.cpp)
 constexpr int kTxWin = 8192;                                // datagrams per round: 128 chunks of a wave's width (120 KB of LDS in all)
 constexpr int kTxChunks = kTxWin / 64;
 
 struct TxGainTab { float v[26]; };                          // pow(10, q), q = -12 .. 13 (host: the reference's double pow, rounded to float)
 
-// the sixteen queues of a workgroup, LDS <-> memory (element i of ARFCN a lives at [i * S + a])
-__device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, int32_t (*qf)[kTxQ], int32_t (*qk)[kTxQ], const int *nq) {
+constexpr int kTxRow = kTxQ + 1;                            // an ARFCN's row in LDS: one entry of padding (the rows start on different banks;
+                                                            // speculative reads past the queue's end land on it)
+
+// the sixteen queues of a workgroup, LDS <-> memory (element i of ARFCN a lives at [i * S + a]; in LDS an entry is the pair (fn, key))
+__device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, TrxqEnt (*q)[kTxRow], const int *nq) {
   const int k = threadIdx.x & (kTxA - 1);
   if (a0 + k < x.S)
-    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
-      qf[k][i] = x.q_fn[(size_t)i * x.S + a0 + k];
-      qk[k][i] = x.q_key[(size_t)i * x.S + a0 + k];
-    }
+    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA)
+      q[k][i] = trxq_ent(x.q_fn[(size_t)i * x.S + a0 + k], x.q_key[(size_t)i * x.S + a0 + k]);
 }
-__device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const int32_t (*qf)[kTxQ], const int32_t (*qk)[kTxQ], const int *nq) {
+__device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const TrxqEnt (*q)[kTxRow], const int *nq) {
   const int k = threadIdx.x & (kTxA - 1);
   if (a0 + k < x.S)
     for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
-      x.q_fn[(size_t)i * x.S + a0 + k] = qf[k][i];
-      x.q_key[(size_t)i * x.S + a0 + k] = qk[k][i];
+      const TrxqEnt e = q[k][i];
+      x.q_fn[(size_t)i * x.S + a0 + k] = e.x;
+      x.q_key[(size_t)i * x.S + a0 + k] = e.y;
     }
 }
 
@@ -51,13 +63,14 @@ __device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, con
 // has checked every header: a call with a bad one queues nothing).
 __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn,
                                                           TxGainTab gt) {
-  __shared__ int32_t qf[kTxA][kTxQ], qk[kTxA][kTxQ];
+  __shared__ TrxqEnt q[kTxA][kTxRow];
   __shared__ int32_t lf[kTxWin], lk[kTxWin];                // this round's entries, ARFCN by ARFCN: frame number (then payload slot), key
   __shared__ int16_t fs[kTxWin];                            // the payload slots those entries will be handed, fetched ahead
   __shared__ int32_t cnt[kTxChunks][kTxA];
   __shared__ int nq[kTxA], nf[kTxA], nf0[kTxA], tot[kTxA], lbase[kTxA + 1], st_[kTxA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a0 = blockIdx.x * kTxA;
+  TX_STAMP(0, 0);
   if (tid < kTxA) {
     const bool mine = a0 + tid < x.S;
     nq[tid] = mine ? x.q_n[a0 + tid] : 0;
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     st_[tid] = 0;
   }
   __syncthreads();
-  tx_queues_load(x, a0, qf, qk, nq);
+  tx_queues_load(x, a0, q, nq);
   for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 4096 datagrams (LDS is sized for one)
     // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN) by ballots ----
     constexpr int CPW = kTxChunks / 16;                     // chunks per wave
@@ -87,6 +100,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       my_i[cc] = i; my_k[cc] = valid ? local : -1; my_rank[cc] = rank;
     }
     __syncthreads();
+    TX_STAMP(0, 1);
     {                                                       // exclusive scan over the chunks, per ARFCN: wave k scans ARFCN k's column
       static_assert(kTxChunks % 64 == 0 && kTxA == 16, "a wave per ARFCN, whole waves of chunks");
       const int k = wave;
@@ -111,6 +125,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       lbase[kTxA] = run;
     }
     __syncthreads();
+    TX_STAMP(0, 2);
     // ---- every datagram's header into its place (arrival order inside an ARFCN); the payload slots fetched ahead ----
 #pragma unroll
     for (int cc = 0; cc < CPW; cc++) {
@@ -133,10 +148,11 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
         for (int j = tid / kTxA; j < want; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf0[k] - 1 - j) * x.S + a0 + k];
     }
     __syncthreads();
+    TX_STAMP(0, 3);
     // ---- addRadioVector, a lane per ARFCN, everything it touches in LDS ----
     if (tid < kTxA && a0 + tid < x.S) {
       const int k = tid;
-      const TrxqView q = {&qf[k][0], &qk[k][0], 1};
+      TrxqEnt *row = &q[k][0];
       int n_q = nq[k], n_f = nf[k], used = 0, stt = st_[k];
       for (int e = lbase[k]; e < lbase[k + 1]; e++) {
         int pid = -1;
@@ -145,13 +161,14 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
         } else {
           n_f--;
           pid = fs[lbase[k] + used++];
-          n_q = trxq_push(q, n_q, lf[e], (lk[e] & 7) | (pid << 3));   // mTransmitPriorityQueue.write(newVec) (:109)
+          n_q = tx_heap_push(row, n_q, trxq_ent(lf[e], (lk[e] & 7) | (pid << 3)));   // mTransmitPriorityQueue.write(newVec) (:109)
         }
         lf[e] = pid;
       }
       nq[k] = n_q; nf[k] = n_f; st_[k] = stt;
     }
     __syncthreads();
+    TX_STAMP(0, 4);
     // ---- the payloads to their slots: every thread a word (37 words of bits, then the gain) ----
     const int total = lbase[kTxA] * TRXG_PAYLOAD_WORDS;
     for (int idx = tid; idx < total; idx += 1024) {
@@ -170,13 +187,15 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       x.pool[((size_t)(a0 + k) * x.npool + pid) * TRXG_PAYLOAD_WORDS + w] = v;
     }
     __syncthreads();                                        // lf / lk / fs / cnt are the next round's
+    TX_STAMP(0, 5);
   }
-  tx_queues_store(x, a0, qf, qk, nq);
+  tx_queues_store(x, a0, q, nq);
   if (tid < kTxA && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
     if (st_[tid]) x.status[a0 + tid] |= 1u;
   }
+  TX_STAMP(0, 6);
 }
 
 __device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int pid) {
@@ -186,62 +205,93 @@ __device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int
 }
 
 constexpr int kTxCells = 102 * 8;                           // fillerTable[102][8] (Transceiver.h:79)
+// n % m for 0 <= n < 2^22 (a frame number), 1 <= m <= 102 (a filler modulus): the float quotient is off by one at most
+__device__ __forceinline__ int tx_fn_mod(int n, int m) {
+  int r = n - (int)((float)n * (1.0f / (float)m)) * m;
+  r += r < 0 ? m : 0;
+  r -= r >= m ? m : 0;
+  return r;
+}
 __global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
                                                        uint8_t *__restrict__ out_fq) {
-  __shared__ int32_t qf[kTxA][kTxQ], qk[kTxA][kTxQ];
+  __shared__ TrxqEnt q[kTxA][kTxRow];
   __shared__ int16_t fl[kTxA][kTxCells];                    // the sixteen filler tables
   __shared__ int nq[kTxA], nf[kTxA];
   const int tid = threadIdx.x, a0 = blockIdx.x * kTxA;
+  TX_STAMP(1, 0);
   if (tid < kTxA) {
     const bool mine = a0 + tid < x.S;
     nq[tid] = mine ? x.q_n[a0 + tid] : 0;
     nf[tid] = mine ? x.free_n[a0 + tid] : 0;
   }
   __syncthreads();
-  tx_queues_load(x, a0, qf, qk, nq);
+  tx_queues_load(x, a0, q, nq);
   {
     const int k = tid & (kTxA - 1);
     if (a0 + k < x.S)
       for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
   }
   __syncthreads();
+  TX_STAMP(1, 1);
   if (tid < kTxA && a0 + tid < x.S) {
     const int k = tid, a = a0 + tid;
-    const TrxqView q = {&qf[k][0], &qk[k][0], 1};
+    TrxqEnt *row = &q[k][0];
+    int16_t *flk = &fl[k][0];
     int n_q = nq[k], n_f = nf[k];
-    int mod[8];
+    int mod[8], r[8];
+    int fnc = fn0;                                          // the frame on the air (fn0 < gHyperframe: trxsig_trxgroup_push checks)
 #pragma unroll
-    for (int m = 0; m < 8; m++) mod[m] = x.fmod[m * x.S + a];
-    for (int t = 0; t < n_slots; t++) {
-      const int tn = (tn0 + t) & 7;
-      int fn = fn0 + ((tn0 + t) >> 3);
-      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;    // (n_slots < 8 * gHyperframe: trxsig_trxgroup_push checks)
-      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
-      // dump stale bursts, if any: "even if the burst is stale, put it in the filler table" (:142-153)
-      while (n_q > 0 && trxq_time_lt(q.fn[0], q.key[0] & 7, fn, tn)) {
-        int32_t efn, ekey;
-        n_q = trxq_pop(q, n_q, &efn, &ekey);
-        const int etn = ekey & 7;
-        int16_t *cell = &fl[k][(efn % mod[etn]) * 8 + etn];
-        tx_free(x, a, n_f, *cell);
-        *cell = (int16_t)(ekey >> 3);
+    for (int m = 0; m < 8; m++) {
+      mod[m] = x.fmod[m * x.S + a];
+      r[m] = tx_fn_mod(fnc, mod[m]);                        // fnc % fillerModulus[TN], kept up frame by frame
+    }
+    TrxqEnt top = row[0], c[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) c[i] = row[1 + i];
+    const int t_end = tn0 + n_slots;
+    for (int base = 0; base < t_end; base += 8) {           // a frame a turn, its timeslots unrolled (TN is a constant in the body)
+#pragma unroll
+      for (int tn = 0; tn < 8; tn++) {
+        const int tt = base + tn;
+        if (tt < tn0 || tt >= t_end) continue;
+        const int t = tt - tn0;
+        // dump stale bursts, if any: "even if the burst is stale, put it in the filler table" (:142-153)
+        while (n_q > 0 && trxq_time_lt(top.x, top.y & 7, fnc, tn)) {
+          TrxqEnt e;
+          n_q = tx_heap_pop(row, n_q, top, c, e);
+          const int etn = e.y & 7;
+          int em = mod[0];
+#pragma unroll
+          for (int m = 1; m < 8; m++) em = etn == m ? mod[m] : em;
+          int16_t *cell = &flk[tx_fn_mod(e.x, em) * 8 + etn];
+          tx_free(x, a, n_f, *cell);
+          *cell = (int16_t)(e.y >> 3);
+        }
+        int16_t *cell = &flk[r[tn] * 8 + tn];
+        int pid = *cell;                                    // the filler entry (:175-177) ...
+        int fq = 0;
+        if (n_q > 0 && top.x == fnc && (top.y & 7) == tn) {   // ... unless there is data at the desired timestamp (:159-173)
+          TrxqEnt e;
+          n_q = tx_heap_pop(row, n_q, top, c, e);
+          tx_free(x, a, n_f, pid);
+          pid = e.y >> 3;
+          *cell = (int16_t)pid;
+          fq = 1;
+        }
+        out_pid[(size_t)t * x.S + a] = (int16_t)pid;
+        out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
       }
-      int16_t *cell = &fl[k][(fn % mod[tn]) * 8 + tn];
-      int fq = 0;
-      if (n_q > 0 && q.fn[0] == fn && (q.key[0] & 7) == tn) {   // data at the desired timestamp (:159-173)
-        int32_t efn, ekey;
-        n_q = trxq_pop(q, n_q, &efn, &ekey);
-        tx_free(x, a, n_f, *cell);
-        *cell = (int16_t)(ekey >> 3);
-        fq = 1;
-      }
-      out_pid[(size_t)t * x.S + a] = *cell;                 // otherwise the filler entry (:175-177)
-      out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+      fnc++;
+      const bool wrap = fnc == TRXQ_HYPERFRAME;
+      fnc = wrap ? 0 : fnc;
+#pragma unroll
+      for (int m = 0; m < 8; m++) r[m] = (wrap || r[m] + 1 == mod[m]) ? 0 : r[m] + 1;
     }
     nq[k] = n_q; nf[k] = n_f;
   }
+  TX_STAMP(1, 2);
   __syncthreads();
-  tx_queues_store(x, a0, qf, qk, nq);
+  tx_queues_store(x, a0, q, nq);
   {
     const int k = tid & (kTxA - 1);
     if (a0 + k < x.S)
@@ -251,6 +301,7 @@ __global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, in
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
   }
+  TX_STAMP(1, 3);
 }
 
 // bits_out [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (the transposes of out_pid / out_fq's [n_slots][S])

@@ -10,7 +10,8 @@ value for value -- and the int16 stream the fused transmit back end makes of the
 S = 128 ARFCNs x 208 frames, channel combinations I / II / IV / V / VI / VII / NONE (filler moduli 26 / 51 / 102), bursts on
 time, LATE (stale on arrival: they must still land in the filler table), EARLY (many frames ahead), DUPLICATES (two bursts
 for one timestamp: the heap's shape decides which goes out), RSSI over the whole signed byte, pushes of 1 ... 40 timeslots
-starting on any timeslot, a start just below the hyperframe wrap."""
+starting on any timeslot, a start just below the hyperframe wrap.  A third case keeps ~120 bursts queued per ARFCN (ties among
+them): every level of the LDS heap moves in csrc/trxsig_grouptx.hip (tx_heap_push / tx_heap_pop) is walked."""
 import numpy as np
 import pytest
 
@@ -39,7 +40,7 @@ def datagram(tn, fn, rssi, bits):
     return d
 
 
-def traffic(rng, S, fn, chan_used, tame=()):
+def traffic(rng, S, fn, chan_used, tame=(), deep=False):
     """The datagrams the GSM core sends while frame `fn` is on the air: (arfcn, datagram) in arrival order.  RSSI (an
     attenuation in dB) covers the whole signed byte except on the ARFCNs in `tame`, whose int16 stream is compared: a negative
     RSSI is a gain of up to 10^12, the samples leave the int16 range and the reference's (short) cast is undefined there."""
@@ -61,12 +62,16 @@ def traffic(rng, S, fn, chan_used, tame=()):
                 out.append((a, datagram(tn, (fn - 1 - int(rng.integers(0, 4))) % H, rssi, bits())))
             elif r < 0.73:                                               # early
                 out.append((a, datagram(tn, (fn + 4 + int(rng.integers(0, 25))) % H, rssi, bits())))
+            if deep and rng.random() < 0.9:                              # a DEEP queue: ~120 bursts waiting per ARFCN (seven heap levels),
+                for _ in range(1 + (rng.random() < 0.15)):               # ties among them
+                    out.append((a, datagram(tn, (fn + 4 + int(rng.integers(0, 18))) % H, rssi, bits())))
     order = rng.permutation(len(out))
     return [out[i] for i in order]
 
 
-@pytest.mark.parametrize("sps,S,frames,fn0", [(1, 128, 208, tm.HYPERFRAME - 90), (4, 8, 40, 1234)])
-def test_group_transmit_half(pkg, golden, sps, S, frames, fn0):
+@pytest.mark.parametrize("sps,S,frames,fn0,deep", [(1, 128, 208, tm.HYPERFRAME - 90, False), (4, 8, 40, 1234, False),
+                                                   (1, 20, 90, tm.HYPERFRAME - 50, True)])
+def test_group_transmit_half(pkg, golden, sps, S, frames, fn0, deep):
     import torch
     from openbts_ttsou_amd.frontend import TxBackEnd, OUTHISTORY
     dev = torch.device("cuda:0")
@@ -100,7 +105,7 @@ def test_group_transmit_half(pkg, golden, sps, S, frames, fn0):
         # the core's traffic up to the frame the push ends in (adds before pushes, as the two service loops interleave)
         dgs, arf = [], []
         for f in range(fed_until + 1, last_frame + 1):
-            for a, d in traffic(rng, S, (fn0 + f) % H, chan_used, tame=streams):
+            for a, d in traffic(rng, S, (fn0 + f) % H, chan_used, tame=streams, deep=deep):
                 dgs.append(d); arf.append(a)
         fed_until = max(fed_until, last_frame)
         if dgs:
@@ -133,7 +138,7 @@ def test_group_transmit_half(pkg, golden, sps, S, frames, fn0):
                 k = a * n + t
                 mine = xs[off[k]:off[k] + length[k]]
                 assert bool(fq[a, t]) == wfq == mfq, (a, sfn, stn)
-                assert np.array_equal(mine, want) and np.array_equal(mine, mwant), (a, sfn, stn)
+                assert np.array_equal(mine, want) and np.array_equal(mine, mwant), (a, sfn, stn, grp.tx_queue_size(a), len(models[a].queue))
                 n_fq += wfq
                 if a in send:
                     send[a] = np.concatenate([send[a], mwant])
@@ -156,9 +161,12 @@ def test_group_transmit_half(pkg, golden, sps, S, frames, fn0):
         pos += n
     assert pos == n_slots_total and n_cells == (n_slots_total - first) * S
     assert n_fq > n_cells // 4 and n_int16 > 1000
+    deepest = 0
     for a in (0, S // 2, S - 1):                                # what is left queued (the early bursts) agrees too, nothing was dropped
         q, dropped = grp.tx_queue_size(a)
         assert q == objs[a].L.trxsig_trx_queue_size(objs[a].h) == len(models[a].queue) and not dropped
+        deepest = max(deepest, q)
+    assert not deep or 64 < deepest < 256, deepest
     for x in objs:
         x.close()
     be.close(); grp.close(); grp_b.close(); ctx.close()

@@ -1,8 +1,10 @@
 """The transmit priority queue's ORDER: the reference queues bursts in a std::priority_queue of pointers
 compared by timestamp (CommonLibs/Interthread.h:432-528, Transceiver/radioInterface.h:58-72), so bursts with equal timestamps
-leave in an order the heap's shape decides.  Three implementations must agree on every pop of random write / read scripts with
+leave in an order the heap's shape decides.  Four implementations must agree on every pop of random write / read scripts with
 many ties: std::priority_queue itself (tests/txqueue_order.cpp, this image's libstdc++ -- what the one-ARFCN object uses), the
-array form the Transceiver group runs on the device (csrc/trxsig_txq.h, compiled into the same program for the host), and the
+array form of the queue (csrc/trxsig_txq.h), the form the Transceiver group's kernels keep in LDS (csrc/trxsig_txq_lds.h: the same
+moves with fewer dependent reads; its array must equal the array form's after every operation) -- both compiled into the same
+program for the host -- and the
 Python model's heapq (oracle/transceiver_model.py)."""
 import heapq
 import os
@@ -30,7 +32,7 @@ def test_three_queues_agree(prog, seed, base_fn):
     script, ops = [], []
     live = 0
     for i in range(6000):
-        if live == 0 or (rng.random() < 0.56 and live < 200):
+        if live == 0 or (rng.random() < 0.56 and live < 250):
             fn = int(base_fn + rng.integers(0, 12)) % tm.HYPERFRAME      # few distinct times: ties everywhere, some across the wrap
             tn = int(rng.integers(0, 8))
             script.append("a %d %d %d" % (fn, tn, i)); ops.append(("a", fn, tn, i)); live += 1
@@ -44,6 +46,6 @@ def test_three_queues_agree(prog, seed, base_fn):
             heapq.heappush(heap, tm.Queued((op[1], op[2]), op[3]))
         else:
             mine = heapq.heappop(heap).payload if heap else -1
-            std_id, arr_id = (int(v) for v in out[k].split()); k += 1
-            assert std_id == arr_id == mine, (k, std_id, arr_id, mine)
+            std_id, arr_id, lds_id = (int(v) for v in out[k].split()); k += 1
+            assert std_id == arr_id == lds_id == mine, (k, std_id, arr_id, lds_id, mine)
     assert k == sum(1 for op in ops if op[0] == "p")

@@ -1,0 +1,50 @@
+"""Where does the time of k_group_tx_ingest / k_group_tx_push go?  Needs the probe build (clock64() stamps at the phase boundaries,
+workgroup 0's first thread):
+    make -C openbts-ttsou_amd/csrc probe_tx
+    TRXSIG_LIB=openbts-ttsou_amd/csrc/build_probe/libtrxsig_txprobe.so python tools/group_tx_probe.py [S] [frames per step]
+clock64() counts at 100 MHz on gfx950 (s_memrealtime): the phases are printed in microseconds."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+import numpy as np
+import torch
+import _pkg
+pkg = _pkg.load()
+from openbts_ttsou_amd.frontend import TxBackEnd
+from openbts_ttsou_amd import synth
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ctx = pkg.TrxSig(4, 0); ctx.use_torch_stream()
+grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+for a in range(S):
+    for tn in range(8):
+        grp.control(a, "CMD SETSLOT %d %d" % (tn, 5 if (tn == 0 and a % 8 == 0) else 1))
+be = TxBackEnd(ctx, S, synth.design_lpf(651, 96), max_bursts=8 * F)
+rng = np.random.default_rng(3)
+n = S * 8 * F
+base = np.zeros((n, 154), np.uint8)
+base[:, 6:] = rng.integers(0, 2, (n, 148)); base[:, 5] = rng.integers(0, 30, n)
+arf = np.repeat(np.arange(S, dtype=np.int32), 8 * F)
+fo = np.tile(np.repeat(np.arange(F), 8), S)
+base[:, 0] = np.tile(np.tile(np.arange(8), F), S)
+perm = rng.permutation(n)
+base, arf, fo = base[perm], arf[perm], fo[perm]
+L = ctx.L
+L.trx_txprobe_read.argtypes = [C.c_void_p]
+acc = np.zeros((2, 8)); K = 20
+fn = 1000
+for it in range(K + 3):
+    f = (fn + fo).astype(np.uint32)
+    base[:, 1:5] = np.stack([f >> 24, (f >> 16) & 255, (f >> 8) & 255, f & 255], axis=1)
+    grp.add_bursts(base, arf); grp.push_txbe(be, fn, 0, 8 * F); be.pop_samples(); fn += F
+    torch.cuda.synchronize()
+    st = np.zeros((2, 8), np.uint64)
+    assert L.trx_txprobe_read(st.ctypes.data) == 0
+    if it >= 3: acc += st.astype(np.float64)
+st = acc / K
+def us(k, i, j): return (st[k, j] - st[k, i]) / 100.0
+print("S = %d, %d frames per step (%d bursts); workgroup 0, microseconds (clock64 at 100 MHz), mean of %d steps" % (S, F, n, K))
+print("k_group_tx_ingest: counts by ballots %.1f | scan + bases %.1f | headers + free slots %.1f | the pushes (a lane per ARFCN) %.1f | payload copy %.1f | queues back %.1f | total %.1f" % (
+    us(0, 0, 1), us(0, 1, 2), us(0, 2, 3), us(0, 3, 4), us(0, 4, 5), us(0, 5, 6), us(0, 0, 6)))
+print("k_group_tx_push  : queues + filler tables in %.1f | the walk (a lane per ARFCN) %.1f | queues + filler tables back %.1f | total %.1f" % (
+    us(1, 0, 1), us(1, 1, 2), us(1, 2, 3), us(1, 0, 3)))
