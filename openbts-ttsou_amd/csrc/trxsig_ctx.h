@@ -5,6 +5,49 @@
 #include "trxsig_launch.h"
 
 int trx_ctx_fail(trxsig_ctx *c, int code, const char *what, hipError_t e);
+
+// Small tables a call makes on the host and a kernel of the same call reads: pinned staging blocks taken in turn, each free again
+// when the upload that read it has run.  (A PAGEABLE source makes hipMemcpyAsync wait until the stream has drained -- the host then
+// cannot run ahead of the device at all: ~0.5 ms a call with the device busy, profiles/r05_group_tx_bench.txt.)
+struct TrxPinRing {
+  static constexpr int kSlots = 4;
+  void *p[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[kSlots] = {0, 0, 0, 0};
+  hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  bool armed[kSlots] = {false, false, false, false};
+  unsigned turn = 0;
+  // the next block, at least `bytes` long (waits for the upload that used it four calls ago, if that has not run yet)
+  hipError_t take(size_t bytes, void **out, int *slot) {
+    const int k = (int)(turn++ % kSlots);
+    hipError_t e = hipSuccess;
+    if (!ev[k] && (e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+    if (armed[k]) { if ((e = hipEventSynchronize(ev[k])) != hipSuccess) return e; armed[k] = false; }
+    if (bytes > cap[k]) {
+      void *q = nullptr;
+      const size_t want = bytes + bytes / 4 + 256;
+      if ((e = hipHostMalloc(&q, want, hipHostMallocDefault)) != hipSuccess) return e;
+      if (p[k]) (void)hipHostFree(p[k]);
+      p[k] = q; cap[k] = want;
+    }
+    *out = p[k]; *slot = k;
+    return hipSuccess;
+  }
+  // hipMemcpyAsync(dst, block, bytes) on st, and the block's event behind it
+  hipError_t upload(int slot, void *dst, size_t bytes, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst, p[slot], bytes, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    if ((e = hipEventRecord(ev[slot], st)) != hipSuccess) return e;
+    armed[slot] = true;
+    return hipSuccess;
+  }
+  void release() {
+    for (int k = 0; k < kSlots; k++) {
+      if (ev[k]) { if (armed[k]) (void)hipEventSynchronize(ev[k]); (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
+      if (p[k]) { (void)hipHostFree(p[k]); p[k] = nullptr; }
+      cap[k] = 0; armed[k] = false;
+    }
+  }
+};
 TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
 // the normal-burst leg on bursts computed from the raw int16 stream (trxsig_rxfe_push_detect_demod_normal)
 int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,

@@ -71,6 +71,7 @@ struct trxsig_txbe {
   float *d_rgain = nullptr;                                 // [S][ring_cap]
   int32_t *d_tab = nullptr;                                 // start[tab_cap] then meta[tab_cap]
   int tab_cap = 0;
+  TrxPinRing tab_up;                                        // the table's way up (pinned: trxsig_ctx.h)
   std::vector<TxBurst> live;
   long long stride = 0, iq_stride = 0;
   int fill = 0;                                             // modulated samples behind the history, per stream
@@ -458,6 +459,7 @@ void trxsig_txbe_destroy(trxsig_txbe *be) {
     Guard g(trxsig_device(be->c));
     (void)hipFree(be->d_send[0]); (void)hipFree(be->d_send[1]); (void)hipFree(be->d_lpf); (void)hipFree(be->d_iq); (void)hipFree(be->d_meta);
     (void)hipFree(be->d_ring); (void)hipFree(be->d_rgain); (void)hipFree(be->d_tab);
+    be->tab_up.release();
   }
   trx_ctx_release(be->c);
   delete be;
@@ -558,7 +560,11 @@ int trxsig_txbe_pop(trxsig_txbe *be, const int16_t **d_iq, int64_t *stream_strid
   if (be->fused) {
     // the window [history | whole chunks] as a list of bursts: where each starts, its ring slot, guard and gain flag
     const int M = (int)be->live.size();
-    std::vector<int32_t> tab(2 * (size_t)be->tab_cap, 0);
+    void *tab_p = nullptr;
+    int tab_slot = 0;
+    FE_HIP(c, be->tab_up.take(sizeof(int32_t) * 2 * (size_t)be->tab_cap, &tab_p, &tab_slot));
+    int32_t *tab = (int32_t *)tab_p;
+    std::memset(tab, 0, sizeof(int32_t) * 2 * (size_t)be->tab_cap);
     int m_used = 0;
     for (int m = 0; m < M && m_used < be->tab_cap; m++) {
       const TxBurst &b = be->live[(size_t)m];
@@ -567,7 +573,7 @@ int trxsig_txbe_pop(trxsig_txbe *be, const int16_t **d_iq, int64_t *stream_strid
       tab[(size_t)be->tab_cap + m_used] = b.slot | (b.guard << 16) | (b.has_gain << 20);
       m_used++;
     }
-    FE_HIP(c, hipMemcpyAsync(be->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, st));   // (pageable source: consumed at return)
+    FE_HIP(c, be->tab_up.upload(tab_slot, be->d_tab, sizeof(int32_t) * 2 * (size_t)be->tab_cap, st));
     a.in = be->d_ring; a.in_stride = be->ring_cap;
     a.tx_tables = (const TrxTables *)trxsig_tables_device(c); a.tx_gain = be->d_rgain; a.tx_start = be->d_tab; a.tx_meta = be->d_tab + be->tab_cap;
     a.tx_n = m_used; a.tx_sps = be->sps;

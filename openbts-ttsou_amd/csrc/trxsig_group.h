@@ -96,9 +96,11 @@ struct TrxGroupTx {
 };
 // n new bursts as they arrived: dgram n x 154 bytes (TN, FN big-endian, RSSI, 148 bits one per byte), arfcn[n] the ARFCN each came
 // for (all checked by the host); gain_tab26[q + 12] = (float)pow(10, q), q = -12 .. 13.  Parsing, the per-ARFCN sort (arrival order
-// kept), queue insertion and the payload copies are one launch.
+// kept), queue insertion and the payload copies are one launch.  ref_fn: a frame number near the datagrams' (the first one's); far != 0:
+// some datagram lies 2^17 frames or more from it (trxsig_txq_lds.h's packed entries cannot say it: the kernel works on the arrays in
+// memory -- same results, slower).
 hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn,
-                                      const float *gain_tab26);
+                                      const float *gain_tab26, int ref_fn, int far);
 // pushRadioVector for n_slots timeslots from (fn0, tn0) on every ARFCN: out_pid / out_fq [n_slots][S] scratch; bits_out
 // [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (1 = the burst came from the queue)
 hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,

@@ -34,40 +34,45 @@ namespace {
 
 constexpr int kTxA = 16;                                   // ARFCNs per workgroup
 constexpr int kTxQ = TRXQ_LDS_CAP;                          // queue entries per ARFCN held in LDS (= the queue's capacity, trxsig_trxgroup.cpp)
-constexpr int kTxWin = 8192;                                // datagrams per round: 128 chunks of a wave's width (120 KB of LDS in all)
+constexpr int kTxRow = kTxQ + 1;                            // an ARFCN's row in LDS: one word of padding (the rows start on different banks;
+                                                            // speculative reads past the queue's end land on it)
+constexpr int kTxWin = 8192;                                // datagrams per round: 128 chunks of a wave's width
 constexpr int kTxChunks = kTxWin / 64;
+constexpr int kTxCopyAhead = 6;                             // payload words a thread has in flight
 
 struct TxGainTab { float v[26]; };                          // pow(10, q), q = -12 .. 13 (host: the reference's double pow, rounded to float)
 
-constexpr int kTxRow = kTxQ + 1;                            // an ARFCN's row in LDS: one entry of padding (the rows start on different banks;
-                                                            // speculative reads past the queue's end land on it)
-
-// the sixteen queues of a workgroup, LDS <-> memory (element i of ARFCN a lives at [i * S + a]; in LDS an entry is the pair (fn, key))
-__device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, TrxqEnt (*q)[kTxRow], const int *nq) {
-  const int k = threadIdx.x & (kTxA - 1);
-  if (a0 + k < x.S)
-    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA)
-      q[k][i] = trxq_ent(x.q_fn[(size_t)i * x.S + a0 + k], x.q_key[(size_t)i * x.S + a0 + k]);
-}
-__device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const TrxqEnt (*q)[kTxRow], const int *nq) {
+// the sixteen queues of a workgroup, memory -> LDS, packed relative to frame `ref` (trxsig_txq_lds.h); *far is set when an entry
+// lies outside the packed form's window (the workgroup then works on the arrays in memory: the slow path)
+__device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, TrxqPk (*q)[kTxRow], const int *nq, int ref, int *far) {
   const int k = threadIdx.x & (kTxA - 1);
   if (a0 + k < x.S)
     for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
-      const TrxqEnt e = q[k][i];
-      x.q_fn[(size_t)i * x.S + a0 + k] = e.x;
-      x.q_key[(size_t)i * x.S + a0 + k] = e.y;
+      const int32_t fn = x.q_fn[(size_t)i * x.S + a0 + k], key = x.q_key[(size_t)i * x.S + a0 + k];
+      if (!trxq_pk_ok(fn, ref) || (key >> 3) >= TRXQ_PK_IDS) *far = 1;
+      q[k][i] = trxq_pk(fn, key & 7, (key >> 3) & (TRXQ_PK_IDS - 1), ref);
+    }
+}
+__device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const TrxqPk (*q)[kTxRow], const int *nq, int ref) {
+  const int k = threadIdx.x & (kTxA - 1);
+  if (a0 + k < x.S)
+    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+      const TrxqPk e = q[k][i];
+      x.q_fn[(size_t)i * x.S + a0 + k] = trxq_pk_fn(e, ref);
+      x.q_key[(size_t)i * x.S + a0 + k] = trxq_pk_tn(e) | (trxq_pk_id(e) << 3);
     }
 }
 
 // dgram: n x 154 bytes as they arrived ([0] TN, [1..4] FN big-endian, [5] RSSI, [6..153] one bit per byte); arfcn: n ids (the host
-// has checked every header: a call with a bad one queues nothing).
+// has checked every header: a call with a bad one queues nothing).  ref: the frame the packed queue entries are relative to (the
+// first datagram's); far != 0: the host saw a datagram outside the packed window (every workgroup takes the slow path).
 __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn,
-                                                          TxGainTab gt) {
-  __shared__ TrxqEnt q[kTxA][kTxRow];
-  __shared__ int32_t lf[kTxWin], lk[kTxWin];                // this round's entries, ARFCN by ARFCN: frame number (then payload slot), key
-  __shared__ int16_t fs[kTxWin];                            // the payload slots those entries will be handed, fetched ahead
+                                                          TxGainTab gt, int ref, int far_in) {
+  __shared__ TrxqPk q[kTxA][kTxRow];
+  __shared__ int32_t lf[kTxWin], lk[kTxWin];                // this round's entries, ARFCN by ARFCN: frame number, key
+  __shared__ int16_t fs[kTxWin];                            // the payload slots those entries are handed, fetched ahead
   __shared__ int32_t cnt[kTxChunks][kTxA];
-  __shared__ int nq[kTxA], nf[kTxA], nf0[kTxA], tot[kTxA], lbase[kTxA + 1], st_[kTxA];
+  __shared__ int nq[kTxA], nf[kTxA], tot[kTxA], acc[kTxA], lbase[kTxA + 1], st_[kTxA], far;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a0 = blockIdx.x * kTxA;
   TX_STAMP(0, 0);
@@ -77,10 +82,11 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     nf[tid] = mine ? x.free_n[a0 + tid] : 0;
     st_[tid] = 0;
   }
+  if (tid == 0) far = far_in;
   __syncthreads();
-  tx_queues_load(x, a0, q, nq);
-  for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 4096 datagrams (LDS is sized for one)
-    // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN) by ballots ----
+  tx_queues_load(x, a0, q, nq, ref, &far);
+  for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 8,192 datagrams (LDS is sized for one)
+    // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN), ranks inside a chunk ----
     constexpr int CPW = kTxChunks / 16;                     // chunks per wave
     int my_i[CPW], my_k[CPW], my_rank[CPW];
 #pragma unroll
@@ -89,14 +95,16 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       const int i = w0 + c * 64 + lane;
       const int local = (i < n ? arfcn[i] : -1) - a0;
       const bool valid = (unsigned)local < (unsigned)kTxA;
-      int mycount = 0, rank = 0;
+      // the lanes holding the same ARFCN as this one: four ballots, one per bit of the local id
+      unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
-      for (int k = 0; k < kTxA; k++) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(valid && local == k);
-        if (lane == k) mycount = __builtin_popcountll(m);
-        if (local == k) rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      for (int b = 0; b < 4; b++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((local >> b) & 1);
+        peers &= ((local >> b) & 1) ? m : ~m;
       }
-      if (lane < kTxA) cnt[c][lane] = mycount;
+      const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+      if (lane < kTxA) cnt[c][lane] = 0;
+      if (valid && rank == 0) cnt[c][local] = __builtin_popcountll(peers);   // (same wave, after the zeros: LDS keeps a wave's order)
       my_i[cc] = i; my_k[cc] = valid ? local : -1; my_rank[cc] = rank;
     }
     __syncthreads();
@@ -116,7 +124,13 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
         cnt[c0 + lane][k] = carry + incl - v;
         carry += __shfl(incl, 63, 64);
       }
-      if (lane == 0) { tot[k] = carry; nf0[k] = nf[k]; }
+      if (lane == 0) {
+        tot[k] = carry;
+        // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
+        // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
+        const int room = min(x.qcap - nq[k], nf[k]);
+        acc[k] = carry < room ? carry : (room > 0 ? room : 0);
+      }
     }
     __syncthreads();
     if (tid == 0) {
@@ -143,53 +157,61 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     }
     {
       const int k = tid & (kTxA - 1);
-      const int want = tot[k] < nf0[k] ? tot[k] : nf0[k];
       if (a0 + k < x.S)
-        for (int j = tid / kTxA; j < want; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf0[k] - 1 - j) * x.S + a0 + k];
+        for (int j = tid / kTxA; j < acc[k]; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf[k] - 1 - j) * x.S + a0 + k];
     }
     __syncthreads();
     TX_STAMP(0, 3);
-    // ---- addRadioVector, a lane per ARFCN, everything it touches in LDS ----
-    if (tid < kTxA && a0 + tid < x.S) {
-      const int k = tid;
-      TrxqEnt *row = &q[k][0];
-      int n_q = nq[k], n_f = nf[k], used = 0, stt = st_[k];
-      for (int e = lbase[k]; e < lbase[k + 1]; e++) {
-        int pid = -1;
-        if (n_q >= x.qcap || n_f == 0) {                    // queue or payload pool full: the burst is dropped and the ARFCN marked
-          stt |= 1;
+    if (wave == 0) {
+      // ---- addRadioVector, a lane per ARFCN, everything it touches in LDS (the other waves copy the payloads meanwhile) ----
+      if (tid < kTxA && a0 + tid < x.S) {
+        const int k = tid, e0 = lbase[k], m = acc[k];
+        int n_q = nq[k];
+        if (!far) {
+          TrxqPk *row = &q[k][0];
+          for (int j = 0; j < m; j++)                       // mTransmitPriorityQueue.write(newVec) (:109)
+            n_q = tx_heap_push(row, n_q, trxq_pk(lf[e0 + j], lk[e0 + j] & 7, fs[e0 + j], ref));
         } else {
-          n_f--;
-          pid = fs[lbase[k] + used++];
-          n_q = tx_heap_push(row, n_q, trxq_ent(lf[e], (lk[e] & 7) | (pid << 3)));   // mTransmitPriorityQueue.write(newVec) (:109)
+          const TrxqView gq = {x.q_fn + a0 + k, x.q_key + a0 + k, x.S};
+          for (int j = 0; j < m; j++) n_q = trxq_push(gq, n_q, lf[e0 + j], (lk[e0 + j] & 7) | ((int)fs[e0 + j] << 3));
         }
-        lf[e] = pid;
+        nq[k] = n_q; nf[k] -= m;
+        if (m < tot[k]) st_[k] |= 1;                        // queue or payload pool full: the rest is dropped and the ARFCN marked
       }
-      nq[k] = n_q; nf[k] = n_f; st_[k] = stt;
-    }
-    __syncthreads();
-    TX_STAMP(0, 4);
-    // ---- the payloads to their slots: every thread a word (37 words of bits, then the gain) ----
-    const int total = lbase[kTxA] * TRXG_PAYLOAD_WORDS;
-    for (int idx = tid; idx < total; idx += 1024) {
-      const int e = idx / TRXG_PAYLOAD_WORDS, w = idx - e * TRXG_PAYLOAD_WORDS;
-      const int pid = lf[e];
-      if (pid < 0) continue;
-      const int key = lk[e];
-      const int k = (key >> 8) & 15, src = w0 + (key >> 12);
-      uint32_t v;
-      if (w < 37) {
-        const uint16_t *p = reinterpret_cast<const uint16_t *>(dgram + (size_t)src * 154 + 6) + 2 * w;
-        v = (uint32_t)p[0] | ((uint32_t)p[1] << 16);        // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
-      } else {
-        v = __float_as_uint(gt.v[(key >> 3) & 31]);
+      TX_STAMP(0, 4);
+    } else {
+      // ---- the payloads to their slots: a word a thread (37 words of bits, then the gain), several in flight ----
+      const int total = lbase[kTxA] * TRXG_PAYLOAD_WORDS;
+      for (int base = tid - 64; base < total; base += 960 * kTxCopyAhead) {
+        uint32_t v[kTxCopyAhead];
+        long long dst[kTxCopyAhead];
+#pragma unroll
+        for (int u = 0; u < kTxCopyAhead; u++) {
+          const int idx = base + u * 960;
+          dst[u] = -1;
+          v[u] = 0;
+          if (idx >= total) continue;
+          const int e = idx / TRXG_PAYLOAD_WORDS, w = idx - e * TRXG_PAYLOAD_WORDS;
+          const int key = lk[e];
+          const int k = (key >> 8) & 15, src = w0 + (key >> 12);
+          if (e - lbase[k] >= acc[k]) continue;             // dropped
+          dst[u] = ((long long)(a0 + k) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS + w;
+          if (w < 37) {
+            const uint16_t *p = reinterpret_cast<const uint16_t *>(dgram + (size_t)src * 154 + 6) + 2 * w;
+            v[u] = (uint32_t)p[0] | ((uint32_t)p[1] << 16);  // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
+          } else {
+            v[u] = __float_as_uint(gt.v[(key >> 3) & 31]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kTxCopyAhead; u++)
+          if (dst[u] >= 0) x.pool[dst[u]] = v[u];
       }
-      x.pool[((size_t)(a0 + k) * x.npool + pid) * TRXG_PAYLOAD_WORDS + w] = v;
     }
     __syncthreads();                                        // lf / lk / fs / cnt are the next round's
     TX_STAMP(0, 5);
   }
-  tx_queues_store(x, a0, q, nq);
+  if (!far) tx_queues_store(x, a0, q, nq, ref);
   if (tid < kTxA && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
@@ -205,18 +227,22 @@ __device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int
 }
 
 constexpr int kTxCells = 102 * 8;                           // fillerTable[102][8] (Transceiver.h:79)
-// n % m for 0 <= n < 2^22 (a frame number), 1 <= m <= 102 (a filler modulus): the float quotient is off by one at most
-__device__ __forceinline__ int tx_fn_mod(int n, int m) {
-  int r = n - (int)((float)n * (1.0f / (float)m)) * m;
+// n % m for 0 <= n < 2^22 (a frame number), 1 <= m <= 102 (a filler modulus), rm = (float)(1 / m): the float quotient is off by
+// one at most
+__device__ __forceinline__ int tx_fn_mod(int n, int m, float rm) {
+  int r = n - (int)((float)n * rm) * m;
   r += r < 0 ? m : 0;
   r -= r >= m ? m : 0;
   return r;
 }
+// far_in != 0: the walk is too long for the packed form's window (the host's check)
 __global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
-                                                       uint8_t *__restrict__ out_fq) {
-  __shared__ TrxqEnt q[kTxA][kTxRow];
+                                                       uint8_t *__restrict__ out_fq, int far_in) {
+  __shared__ TrxqPk q[kTxA][kTxRow];                        // packed relative to fn0: the slot on the air at step t has time tn0 + t
   __shared__ int16_t fl[kTxA][kTxCells];                    // the sixteen filler tables
-  __shared__ int nq[kTxA], nf[kTxA];
+  __shared__ int md[kTxA][8];
+  __shared__ float mdr[kTxA][8];
+  __shared__ int nq[kTxA], nf[kTxA], far;
   const int tid = threadIdx.x, a0 = blockIdx.x * kTxA;
   TX_STAMP(1, 0);
   if (tid < kTxA) {
@@ -224,8 +250,15 @@ __global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, in
     nq[tid] = mine ? x.q_n[a0 + tid] : 0;
     nf[tid] = mine ? x.free_n[a0 + tid] : 0;
   }
+  if (tid < kTxA * 8) {
+    const int k = tid & (kTxA - 1), m = tid / kTxA;
+    const int v = a0 + k < x.S ? x.fmod[m * x.S + a0 + k] : 1;
+    md[k][m] = v;
+    mdr[k][m] = 1.0f / (float)v;
+  }
+  if (tid == 0) far = far_in;
   __syncthreads();
-  tx_queues_load(x, a0, q, nq);
+  tx_queues_load(x, a0, q, nq, fn0, &far);
   {
     const int k = tid & (kTxA - 1);
     if (a0 + k < x.S)
@@ -235,63 +268,62 @@ __global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, in
   TX_STAMP(1, 1);
   if (tid < kTxA && a0 + tid < x.S) {
     const int k = tid, a = a0 + tid;
-    TrxqEnt *row = &q[k][0];
     int16_t *flk = &fl[k][0];
     int n_q = nq[k], n_f = nf[k];
-    int mod[8], r[8];
     int fnc = fn0;                                          // the frame on the air (fn0 < gHyperframe: trxsig_trxgroup_push checks)
+    if (!far) {
+      TrxqPk *row = &q[k][0];
+      TrxqPk top = row[0], c[6];
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      mod[m] = x.fmod[m * x.S + a];
-      r[m] = tx_fn_mod(fnc, mod[m]);                        // fnc % fillerModulus[TN], kept up frame by frame
-    }
-    TrxqEnt top = row[0], c[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) c[i] = row[1 + i];
-    const int t_end = tn0 + n_slots;
-    for (int base = 0; base < t_end; base += 8) {           // a frame a turn, its timeslots unrolled (TN is a constant in the body)
-#pragma unroll
-      for (int tn = 0; tn < 8; tn++) {
-        const int tt = base + tn;
-        if (tt < tn0 || tt >= t_end) continue;
-        const int t = tt - tn0;
-        // dump stale bursts, if any: "even if the burst is stale, put it in the filler table" (:142-153)
-        while (n_q > 0 && trxq_time_lt(top.x, top.y & 7, fnc, tn)) {
-          TrxqEnt e;
-          n_q = tx_heap_pop(row, n_q, top, c, e);
-          const int etn = e.y & 7;
-          int em = mod[0];
-#pragma unroll
-          for (int m = 1; m < 8; m++) em = etn == m ? mod[m] : em;
-          int16_t *cell = &flk[tx_fn_mod(e.x, em) * 8 + etn];
-          tx_free(x, a, n_f, *cell);
-          *cell = (int16_t)(e.y >> 3);
-        }
-        int16_t *cell = &flk[r[tn] * 8 + tn];
-        int pid = *cell;                                    // the filler entry (:175-177) ...
+      for (int i = 0; i < 6; i++) c[i] = row[1 + i];
+      for (int t = 0; t < n_slots; t++) {
+        const int now = tn0 + t, tn = now & 7;              // (packed relative to fn0: the time of this slot IS tn0 + t)
+        if (t > 0 && tn == 0) { fnc++; fnc = fnc == TRXQ_HYPERFRAME ? 0 : fnc; }
         int fq = 0;
-        if (n_q > 0 && top.x == fnc && (top.y & 7) == tn) {   // ... unless there is data at the desired timestamp (:159-173)
-          TrxqEnt e;
+        while (n_q > 0) {
+          const int tk = trxq_pk_time(top);
+          if (tk > now) break;
+          // a stale burst (tk < now): "even if the burst is stale, put it in the filler table" (:142-153) -- or the burst for
+          // exactly this slot (:159-173): either way it replaces its filler entry, [FN % modulus][TN] of ITS time
+          TrxqPk e;
           n_q = tx_heap_pop(row, n_q, top, c, e);
-          tx_free(x, a, n_f, pid);
-          pid = e.y >> 3;
-          *cell = (int16_t)pid;
-          fq = 1;
+          const int etn = trxq_pk_tn(e);
+          int16_t *cell = &flk[tx_fn_mod(trxq_pk_fn(e, fn0), md[k][etn], mdr[k][etn]) * 8 + etn];
+          tx_free(x, a, n_f, *cell);
+          *cell = (int16_t)trxq_pk_id(e);
+          if (tk == now) { fq = 1; break; }
         }
-        out_pid[(size_t)t * x.S + a] = (int16_t)pid;
+        out_pid[(size_t)t * x.S + a] = flk[tx_fn_mod(fnc, md[k][tn], mdr[k][tn]) * 8 + tn];   // the filler entry (:175-177), the burst itself if it was there
         out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
       }
-      fnc++;
-      const bool wrap = fnc == TRXQ_HYPERFRAME;
-      fnc = wrap ? 0 : fnc;
-#pragma unroll
-      for (int m = 0; m < 8; m++) r[m] = (wrap || r[m] + 1 == mod[m]) ? 0 : r[m] + 1;
+    } else {
+      // the slow path: the queue where it lives (trxsig_txq.h's moves on the arrays in memory, a dependent access a move)
+      const TrxqView gq = {x.q_fn + a, x.q_key + a, x.S};
+      for (int t = 0; t < n_slots; t++) {
+        const int tn = (tn0 + t) & 7;
+        if (t > 0 && tn == 0) { fnc++; fnc = fnc == TRXQ_HYPERFRAME ? 0 : fnc; }
+        int fq = 0;
+        while (n_q > 0) {
+          const int32_t tfn = gq.f(0), tkey = gq.k(0);
+          const bool stale = trxq_time_lt(tfn, tkey & 7, fnc, tn), hit = tfn == fnc && (tkey & 7) == tn;
+          if (!stale && !hit) break;
+          int32_t efn, ekey;
+          n_q = trxq_pop(gq, n_q, &efn, &ekey);
+          const int etn = ekey & 7;
+          int16_t *cell = &flk[(efn % md[k][etn]) * 8 + etn];
+          tx_free(x, a, n_f, *cell);
+          *cell = (int16_t)(ekey >> 3);
+          if (!stale) { fq = 1; break; }
+        }
+        out_pid[(size_t)t * x.S + a] = flk[(fnc % md[k][tn]) * 8 + tn];
+        out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+      }
     }
     nq[k] = n_q; nf[k] = n_f;
   }
   TX_STAMP(1, 2);
   __syncthreads();
-  tx_queues_store(x, a0, q, nq);
+  if (!far) tx_queues_store(x, a0, q, nq, fn0);
   {
     const int k = tid & (kTxA - 1);
     if (a0 + k < x.S)
@@ -325,20 +357,22 @@ __global__ __launch_bounds__(256) void k_group_tx_gather(TrxGroupTx x, int n_slo
 
 }  // namespace
 
-hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn, const float *gain_tab26) {
+hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn, const float *gain_tab26,
+                                      int ref_fn, int far) {
   if (n <= 0) return hipSuccess;
-  if (x.qcap != kTxQ) return hipErrorInvalidValue;          // (the kernel's LDS copy of a queue)
+  if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;   // (the kernel's LDS copy of a queue, a packed entry's id field)
   TxGainTab gt;
   for (int q = 0; q < 26; q++) gt.v[q] = gain_tab26[q];
-  k_group_tx_ingest<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, n, dgram, arfcn, gt);
+  k_group_tx_ingest<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, n, dgram, arfcn, gt, ref_fn, far);
   return hipGetLastError();
 }
 
 hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,
                                     uint8_t *bits_out, float *gain_out, uint8_t *fq_out) {
   if (n_slots <= 0) return hipSuccess;
-  if (x.qcap != kTxQ) return hipErrorInvalidValue;
-  k_group_tx_push<<<dim3((x.S + kTxA - 1) / kTxA), dim3(256), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq);
+  if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;
+  const int far = (long long)tn0 + n_slots >= 8LL * TRXQ_PK_WIN;    // the walk's own times must fit the packed form
+  k_group_tx_push<<<dim3((x.S + kTxA - 1) / kTxA), dim3(256), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq, far);
   const long long words = (long long)x.S * n_slots * TRXG_PAYLOAD_WORDS;
   k_group_tx_gather<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(x, n_slots, out_pid, out_fq, (uint32_t *)bits_out, gain_out,
                                                                                    fq_out);

@@ -15,6 +15,7 @@
 #include "trxsig_group.h"
 #include "trxsig_trxgroup.h"
 #include "trxsig_trxstate.h"
+#include "trxsig_txq_lds.h"
 
 namespace {
 constexpr int kHyperframe = 2048 * 26 * 51;                 // GSM/GSMCommon.h:306
@@ -93,6 +94,7 @@ struct trxsig_trxgroup {
   DevBuf<trx_c32> w_tab, b_tab, in;
   DevBuf<float> chan_off;
   std::vector<int32_t> h_seg;
+  TrxPinRing seg_up;                 // h_seg's way up (pinned: trxsig_ctx.h)
   // the last pull
   int n_slots = 0, n_rows = 0, n_tsc_rows = 0;
   bool have = false;
@@ -225,7 +227,7 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     (void)hipFree(g->d_gid); (void)hipFree(g->d_pos); (void)hipFree(g->d_state); (void)hipFree(g->d_exp); (void)hipFree(g->d_err);
     for (int k = 0; k < 2; k++) { g->wk[k].release(); if (g->wk[k].done) (void)hipEventDestroy(g->wk[k].done); }
-    g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release();
+    g->w_tab.release(); g->b_tab.release(); g->in.release(); g->chan_off.release(); g->seg_up.release();
     if (g->tx_ready) {
       (void)hipFree(g->tx.q_fn); (void)hipFree(g->tx.q_key); (void)hipFree(g->tx.q_n); (void)hipFree(g->tx.free_stack);
       (void)hipFree(g->tx.free_n); (void)hipFree(g->tx.filler); (void)hipFree(g->tx.fmod); (void)hipFree(g->tx.pool);
@@ -353,8 +355,14 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   G_HIP(g, g->w_tab.need((S8 + R) * 7, st, S8 * 7)); G_HIP(g, g->b_tab.need((S8 + R) * 5, st, S8 * 5));
   G_HIP(g, g->chan_off.need(S8 + R, st, S8));
 
-  // (pageable source: the copy has consumed h_seg when the call returns)
-  G_HIP(g, hipMemcpyAsync(W.seg.p, g->h_seg.data(), sizeof(int32_t) * g->h_seg.size(), hipMemcpyHostToDevice, st));
+  {
+    void *up = nullptr;
+    int slot = 0;
+    const size_t bytes = sizeof(int32_t) * g->h_seg.size();
+    G_HIP(g, g->seg_up.take(bytes, &up, &slot));
+    std::memcpy(up, g->h_seg.data(), bytes);
+    G_HIP(g, g->seg_up.upload(slot, W.seg.p, bytes, st));
+  }
   TrxGroupExpand ex = {};
   ex.S = S; ex.n_slots = n_slots; ex.tn0 = tn; ex.sps = sps; ex.fixed_len = burst_len; ex.G = G;
   ex.slot_stride = src.slot_stride; ex.arfcn_stride = src.arfcn_stride; ex.base = 0; ex.rx_nb = src.gen ? src.gen->nb : 0;
@@ -749,12 +757,15 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   const int S = g->S, k = g->tx_set;
   const int32_t *h_arfcn = (const int32_t *)g->tx_pin[k];
   const uint8_t *h_d = g->tx_pin[k] + (size_t)4 * g->tx_pin_cap[k];
+  int ref_fn = 0, far = 0;                                  // (the kernel's packed queue entries are relative to the first datagram's frame)
   for (int i = 0; i < n; i++) {
     const uint8_t *d = h_d + (size_t)i * TRXSIG_TX_DATAGRAM_BYTES;
     const int a = h_arfcn[i], tn = (int)(int8_t)d[0];
     const uint32_t fn = ((uint32_t)d[1] << 24) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 8) | d[4];
     if (a < 0 || a >= S || tn < 0 || tn > 7 || fn >= (uint32_t)kHyperframe)
       return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: ARFCN, timeslot or frame number out of range (nothing was queued)", hipSuccess);
+    if (i == 0) ref_fn = (int)fn;
+    far |= !trxq_pk_ok((int32_t)fn, ref_fn);
   }
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   G_LIB(tx_sync_modulus(g, st));
@@ -766,7 +777,7 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   G_HIP(g, hipMemcpyAsync(g->tx_dgram.p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, st));
   G_LIB(tx_seal_set(g, k, st));
   g->tx_stage_held = false;                                 // (the set is the DMA's until its event has passed: the next staging call takes the other)
-  G_HIP(g, trx_launch_group_tx_ingest(st, g->tx, n, g->tx_dgram.p, g->tx_arfcn.p, g->gain_tab));
+  G_HIP(g, trx_launch_group_tx_ingest(st, g->tx, n, g->tx_dgram.p, g->tx_arfcn.p, g->gain_tab, ref_fn, far));
   return TRXSIG_OK;
 }
 

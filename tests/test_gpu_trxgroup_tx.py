@@ -11,7 +11,8 @@ S = 128 ARFCNs x 208 frames, channel combinations I / II / IV / V / VI / VII / N
 time, LATE (stale on arrival: they must still land in the filler table), EARLY (many frames ahead), DUPLICATES (two bursts
 for one timestamp: the heap's shape decides which goes out), RSSI over the whole signed byte, pushes of 1 ... 40 timeslots
 starting on any timeslot, a start just below the hyperframe wrap.  A third case keeps ~120 bursts queued per ARFCN (ties among
-them): every level of the LDS heap moves in csrc/trxsig_grouptx.hip (tx_heap_push / tx_heap_pop) is walked."""
+them): every level of the LDS heap moves (csrc/trxsig_txq_lds.h: tx_heap_push / tx_heap_pop) is walked.  A fourth queues bursts a
+third of a hyperframe from the rest: the kernels' slow path (the queue's arrays in memory, trxsig_txq.h's moves)."""
 import numpy as np
 import pytest
 
@@ -70,7 +71,7 @@ def traffic(rng, S, fn, chan_used, tame=(), deep=False):
 
 
 @pytest.mark.parametrize("sps,S,frames,fn0,deep", [(1, 128, 208, tm.HYPERFRAME - 90, False), (4, 8, 40, 1234, False),
-                                                   (1, 20, 90, tm.HYPERFRAME - 50, True)])
+                                                   (1, 20, 90, tm.HYPERFRAME - 50, True), (1, 20, 30, 4321, "far")])
 def test_group_transmit_half(pkg, golden, sps, S, frames, fn0, deep):
     import torch
     from openbts_ttsou_amd.frontend import TxBackEnd, OUTHISTORY
@@ -105,8 +106,15 @@ def test_group_transmit_half(pkg, golden, sps, S, frames, fn0, deep):
         # the core's traffic up to the frame the push ends in (adds before pushes, as the two service loops interleave)
         dgs, arf = [], []
         for f in range(fed_until + 1, last_frame + 1):
-            for a, d in traffic(rng, S, (fn0 + f) % H, chan_used, tame=streams, deep=deep):
+            for a, d in traffic(rng, S, (fn0 + f) % H, chan_used, tame=streams, deep=deep is True):
                 dgs.append(d); arf.append(a)
+            if deep == "far" and f in (2, 11):
+                # a burst a third of a hyperframe away, then one of its timestamp's neighbours: the kernels' packed queue entries
+                # cannot say such a time (csrc/trxsig_txq_lds.h) -- frame 2: the CALL takes the slow path (the host sees the
+                # datagram), afterwards ARFCN 3's workgroup does whenever it loads its queue (the entry stays queued); frame 11:
+                # a call whose first datagram is the far one (every other datagram is far from the reference then)
+                at = len(dgs) if f == 2 else 0
+                dgs.insert(at, datagram(5, (fn0 + f + H // 3) % H, 7, rng.integers(0, 2, 148).astype(np.uint8))); arf.insert(at, 3)
         fed_until = max(fed_until, last_frame)
         if dgs:
             dg = np.stack(dgs); ar = np.array(arf, np.int32)
@@ -166,7 +174,7 @@ def test_group_transmit_half(pkg, golden, sps, S, frames, fn0, deep):
         q, dropped = grp.tx_queue_size(a)
         assert q == objs[a].L.trxsig_trx_queue_size(objs[a].h) == len(models[a].queue) and not dropped
         deepest = max(deepest, q)
-    assert not deep or 64 < deepest < 256, deepest
+    assert deep is not True or 64 < deepest < 256, deepest
     for x in objs:
         x.close()
     be.close(); grp.close(); grp_b.close(); ctx.close()

@@ -4,7 +4,7 @@
 // The third column is the same queue in the form the kernels keep it in LDS (csrc/trxsig_txq_lds.h: tx_heap_push / tx_heap_pop, ancestors
 // fetched at once, two levels a turn): besides the popped ids, its ARRAY must equal trxsig_txq.h's after every operation (exit code 3).
 // stdin: "a fn tn id" = write, "p" = readNoBlock; stdout per p: "<id from std::priority_queue> <id from trxsig_txq.h> <id from the LDS form>"
-// (-1: empty).  Writes beyond TRXQ_LDS_CAP - 1 entries are not sent to the LDS form's queue (the kernels drop them before the push).
+// (-1: empty; the LDS form's id is the low 11 bits).  Writes beyond TRXQ_LDS_CAP - 1 entries are not sent to the LDS form's queue (the kernels drop them before the push).
 #include <cstdio>
 #include <queue>
 #include <vector>
@@ -22,13 +22,16 @@ int main() {
   std::vector<int32_t> fn(1 << 16), key(1 << 16);
   TrxqView q = {fn.data(), key.data(), 1};
   int n = 0;
-  std::vector<TrxqEnt> row(TRXQ_LDS_CAP + 1);
-  TrxqEnt top = trxq_ent(0, 0), c[6];
-  for (int i = 0; i < 6; i++) c[i] = trxq_ent(0, 0);
+  std::vector<TrxqPk> row(TRXQ_LDS_CAP + 1);                // the packed form: one word an entry, relative to the first write's frame
+  TrxqPk top = 0, c[6] = {0, 0, 0, 0, 0, 0};
+  int ref = -1;
+  auto is = [&](TrxqPk e, int i) {
+    return trxq_pk_fn(e, ref) == fn[i] && trxq_pk_tn(e) == (key[i] & 7) && trxq_pk_id(e) == ((key[i] >> 3) & (TRXQ_PK_IDS - 1));
+  };
   auto same = [&]() {
-    for (int i = 0; i < n; i++) if (row[i].x != fn[i] || row[i].y != key[i]) return false;
-    if (n > 0 && (top.x != fn[0] || top.y != key[0])) return false;
-    for (int i = 0; i < 6 && 1 + i < n; i++) if (c[i].x != fn[1 + i] || c[i].y != key[1 + i]) return false;
+    for (int i = 0; i < n; i++) if (!is(row[i], i)) return false;
+    if (n > 0 && !is(top, 0)) return false;
+    for (int i = 0; i < 6 && 1 + i < n; i++) if (!is(c[i], 1 + i)) return false;
     return true;
   };
   char op;
@@ -38,7 +41,9 @@ int main() {
       if (std::scanf("%d %d %d", &it->fn, &it->tn, &it->id) != 3) return 2;
       pq.push(it);
       if (n >= TRXQ_LDS_CAP) return 4;
-      const int m = tx_heap_push(row.data(), n, trxq_ent(it->fn, it->tn | (it->id << 3)));
+      if (ref < 0) ref = it->fn;
+      if (!trxq_pk_ok(it->fn, ref)) return 5;
+      const int m = tx_heap_push(row.data(), n, trxq_pk(it->fn, it->tn, it->id & (TRXQ_PK_IDS - 1), ref));
       n = trxq_push(q, n, it->fn, it->tn | (it->id << 3));
       top = row[0];                                         // (the kernels that push do not pop: the walk loads these when it starts)
       for (int i = 0; i < 6; i++) c[i] = row[1 + i];
@@ -47,11 +52,11 @@ int main() {
       int a = -1, b = -1, l = -1;
       if (!pq.empty()) { Item *it = pq.top(); pq.pop(); a = it->id; delete it; }
       if (n > 0) {
-        TrxqEnt e;
+        TrxqPk e;
         const int m = tx_heap_pop(row.data(), n, top, c, e);
-        l = e.y >> 3;
+        l = trxq_pk_id(e);
         int32_t f, k; n = trxq_pop(q, n, &f, &k); b = k >> 3;
-        if (m != n || e.x != f || e.y != k || !same()) return 3;
+        if (m != n || trxq_pk_fn(e, ref) != f || trxq_pk_tn(e) != (k & 7) || l != (b & (TRXQ_PK_IDS - 1)) || !same()) return 3;
       }
       std::printf("%d %d %d\n", a, b, l);
     }
