@@ -38,25 +38,26 @@ constexpr int kTxRow = kTxQ + 1;                            // an ARFCN's row in
                                                             // speculative reads past the queue's end land on it)
 constexpr int kTxWin = 8192;                                // datagrams per round: 128 chunks of a wave's width
 constexpr int kTxChunks = kTxWin / 64;
-constexpr int kTxCopyAhead = 6;                             // payload words a thread has in flight
 
 struct TxGainTab { float v[26]; };                          // pow(10, q), q = -12 .. 13 (host: the reference's double pow, rounded to float)
 
 // the sixteen queues of a workgroup, memory -> LDS, packed relative to frame `ref` (trxsig_txq_lds.h); *far is set when an entry
 // lies outside the packed form's window (the workgroup then works on the arrays in memory: the slow path)
+template <int A>
 __device__ __forceinline__ void tx_queues_load(const TrxGroupTx &x, int a0, TrxqPk (*q)[kTxRow], const int *nq, int ref, int *far) {
-  const int k = threadIdx.x & (kTxA - 1);
+  const int k = threadIdx.x & (A - 1);
   if (a0 + k < x.S)
-    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+    for (int i = threadIdx.x / A; i < nq[k]; i += blockDim.x / A) {
       const int32_t fn = x.q_fn[(size_t)i * x.S + a0 + k], key = x.q_key[(size_t)i * x.S + a0 + k];
       if (!trxq_pk_ok(fn, ref) || (key >> 3) >= TRXQ_PK_IDS) *far = 1;
       q[k][i] = trxq_pk(fn, key & 7, (key >> 3) & (TRXQ_PK_IDS - 1), ref);
     }
 }
+template <int A>
 __device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, const TrxqPk (*q)[kTxRow], const int *nq, int ref) {
-  const int k = threadIdx.x & (kTxA - 1);
+  const int k = threadIdx.x & (A - 1);
   if (a0 + k < x.S)
-    for (int i = threadIdx.x / kTxA; i < nq[k]; i += blockDim.x / kTxA) {
+    for (int i = threadIdx.x / A; i < nq[k]; i += blockDim.x / A) {
       const TrxqPk e = q[k][i];
       x.q_fn[(size_t)i * x.S + a0 + k] = trxq_pk_fn(e, ref);
       x.q_key[(size_t)i * x.S + a0 + k] = trxq_pk_tn(e) | (trxq_pk_id(e) << 3);
@@ -69,8 +70,8 @@ __device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, con
 __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn,
                                                           TxGainTab gt, int ref, int far_in) {
   __shared__ TrxqPk q[kTxA][kTxRow];
-  __shared__ int32_t lf[kTxWin], lk[kTxWin];                // this round's entries, ARFCN by ARFCN: frame number, key
-  __shared__ int16_t fs[kTxWin];                            // the payload slots those entries are handed, fetched ahead
+  __shared__ int32_t lf[kTxWin + 1], lk[kTxWin + 1];        // this round's entries, ARFCN by ARFCN: frame number, key
+  __shared__ int16_t fs[kTxWin + 2];                            // the payload slots those entries are handed, fetched ahead
   __shared__ int32_t cnt[kTxChunks][kTxA];
   __shared__ int nq[kTxA], nf[kTxA], tot[kTxA], acc[kTxA], lbase[kTxA + 1], st_[kTxA], far;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
   }
   if (tid == 0) far = far_in;
   __syncthreads();
-  tx_queues_load(x, a0, q, nq, ref, &far);
+  tx_queues_load<kTxA>(x, a0, q, nq, ref, &far);
   for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 8,192 datagrams (LDS is sized for one)
     // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN), ranks inside a chunk ----
     constexpr int CPW = kTxChunks / 16;                     // chunks per wave
@@ -162,56 +163,56 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     }
     __syncthreads();
     TX_STAMP(0, 3);
-    if (wave == 0) {
-      // ---- addRadioVector, a lane per ARFCN, everything it touches in LDS (the other waves copy the payloads meanwhile) ----
-      if (tid < kTxA && a0 + tid < x.S) {
-        const int k = tid, e0 = lbase[k], m = acc[k];
+    {
+      // ---- addRadioVector: WAVE k enters ARFCN k's bursts (every value the same in all its lanes: scalar branches, see k_group_tx_push;
+      //      lane 0's stores count) ----
+      const int k = __builtin_amdgcn_readfirstlane(wave);
+      if (a0 + k < x.S) {
+        const int e0 = lbase[k], m = acc[k];
         int n_q = nq[k];
         if (!far) {
           TrxqPk *row = &q[k][0];
-          for (int j = 0; j < m; j++)                       // mTransmitPriorityQueue.write(newVec) (:109)
-            n_q = tx_heap_push(row, n_q, trxq_pk(lf[e0 + j], lk[e0 + j] & 7, fs[e0 + j], ref));
-        } else {
+          int32_t f1 = lf[e0], k1 = lk[e0];
+          int s1 = fs[e0];
+          for (int j = 0; j < m; j++) {                     // mTransmitPriorityQueue.write(newVec) (:109); the next entry fetched meanwhile
+            const TrxqPk v = trxq_pk(f1, k1 & 7, s1, ref);
+            f1 = lf[e0 + j + 1]; k1 = lk[e0 + j + 1]; s1 = fs[e0 + j + 1];   // (one past the ARFCN's last: the next ARFCN's or padding, unused)
+            n_q = tx_heap_push(row, n_q, v);
+          }
+        } else if (lane == 0) {
           const TrxqView gq = {x.q_fn + a0 + k, x.q_key + a0 + k, x.S};
           for (int j = 0; j < m; j++) n_q = trxq_push(gq, n_q, lf[e0 + j], (lk[e0 + j] & 7) | ((int)fs[e0 + j] << 3));
         }
-        nq[k] = n_q; nf[k] -= m;
-        if (m < tot[k]) st_[k] |= 1;                        // queue or payload pool full: the rest is dropped and the ARFCN marked
+        n_q = __builtin_amdgcn_readfirstlane(n_q);
+        if (lane == 0) {
+          nq[k] = n_q; nf[k] -= m;
+          if (m < tot[k]) st_[k] |= 1;                      // queue or payload pool full: the rest is dropped and the ARFCN marked
+        }
       }
       TX_STAMP(0, 4);
-    } else {
-      // ---- the payloads to their slots: a word a thread (37 words of bits, then the gain), several in flight ----
-      const int total = lbase[kTxA] * TRXG_PAYLOAD_WORDS;
-      for (int base = tid - 64; base < total; base += 960 * kTxCopyAhead) {
-        uint32_t v[kTxCopyAhead];
-        long long dst[kTxCopyAhead];
+      // ---- the payloads to their slots: a burst a thread -- its 148 bytes as nine sixteen-byte loads and a four-byte one, all in
+      //      flight at once (the datagrams start on even addresses only: unaligned loads), then the gain ----
+      // (acc / lbase / fs / lk are not written above; nq / nf are not read below)
+      for (int e = tid; e < lbase[kTxA]; e += 1024) {
+        const int key = lk[e];
+        const int kk = (key >> 8) & 15, src = w0 + (key >> 12);
+        if (e - lbase[kk] >= acc[kk]) continue;             // dropped
+        const uint8_t *p = dgram + (size_t)src * 154 + 6;   // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
+        uint32_t v[TRXG_PAYLOAD_WORDS];
 #pragma unroll
-        for (int u = 0; u < kTxCopyAhead; u++) {
-          const int idx = base + u * 960;
-          dst[u] = -1;
-          v[u] = 0;
-          if (idx >= total) continue;
-          const int e = idx / TRXG_PAYLOAD_WORDS, w = idx - e * TRXG_PAYLOAD_WORDS;
-          const int key = lk[e];
-          const int k = (key >> 8) & 15, src = w0 + (key >> 12);
-          if (e - lbase[k] >= acc[k]) continue;             // dropped
-          dst[u] = ((long long)(a0 + k) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS + w;
-          if (w < 37) {
-            const uint16_t *p = reinterpret_cast<const uint16_t *>(dgram + (size_t)src * 154 + 6) + 2 * w;
-            v[u] = (uint32_t)p[0] | ((uint32_t)p[1] << 16);  // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
-          } else {
-            v[u] = __float_as_uint(gt.v[(key >> 3) & 31]);
-          }
-        }
+        for (int w = 0; w < 37; w++) __builtin_memcpy(&v[w], p + 4 * w, 4);
+        v[37] = __float_as_uint(gt.v[(key >> 3) & 31]);
+        uint32_t *dst = x.pool + ((size_t)(a0 + kk) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS;
+        static_assert(TRXG_PAYLOAD_WORDS == 38, "nine sixteen-byte stores and an eight-byte one");
 #pragma unroll
-        for (int u = 0; u < kTxCopyAhead; u++)
-          if (dst[u] >= 0) x.pool[dst[u]] = v[u];
+        for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);   // (a slot starts on a multiple of 8 bytes)
+        __builtin_memcpy(dst + 36, &v[36], 8);
       }
     }
     __syncthreads();                                        // lf / lk / fs / cnt are the next round's
     TX_STAMP(0, 5);
   }
-  if (!far) tx_queues_store(x, a0, q, nq, ref);
+  if (!far) tx_queues_store<kTxA>(x, a0, q, nq, ref);
   if (tid < kTxA && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
@@ -235,101 +236,146 @@ __device__ __forceinline__ int tx_fn_mod(int n, int m, float rm) {
   r -= r >= m ? m : 0;
   return r;
 }
+constexpr int kTxWalk = 128;                                // timeslots a turn of the walk (their filler cells are worked out ahead, by every thread)
+constexpr int kTxP = 4;                                     // ARFCNs per workgroup of the walk: a WAVE each
+// The walk of an ARFCN's queue is one thread's work, a chain of dependent instructions; what it costs is the instructions the wave
+// issues (~8 cycles each with nothing to hide them behind).  A wave per ARFCN, every value the same in all its lanes
+// (readfirstlane'd ARFCN index, LDS addresses that do not depend on the lane): the branches are scalar branches, no execution
+// masks to save, combine and restore as with a lane per ARFCN (where every branch some lane takes all sixteen pay for).
 // far_in != 0: the walk is too long for the packed form's window (the host's check)
-__global__ __launch_bounds__(256) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
-                                                       uint8_t *__restrict__ out_fq, int far_in) {
-  __shared__ TrxqPk q[kTxA][kTxRow];                        // packed relative to fn0: the slot on the air at step t has time tn0 + t
-  __shared__ int16_t fl[kTxA][kTxCells];                    // the sixteen filler tables
-  __shared__ int md[kTxA][8];
-  __shared__ float mdr[kTxA][8];
-  __shared__ int nq[kTxA], nf[kTxA], far;
-  const int tid = threadIdx.x, a0 = blockIdx.x * kTxA;
+__global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
+                                                             uint8_t *__restrict__ out_fq, int far_in) {
+  __shared__ TrxqPk q[kTxP][kTxRow];                        // packed relative to fn0: the slot on the air at step t has time tn0 + t
+  __shared__ int16_t fl[kTxP][kTxCells];                    // the filler tables
+  __shared__ uint16_t cidx[kTxP][kTxWalk + 2];              // [FN % modulus][TN] of the slots of this turn (+ the next turn's first)
+  __shared__ int md[kTxP][8];
+  __shared__ float mdr[kTxP][8];
+  __shared__ int nq[kTxP], nf[kTxP], far;
+  const int tid = threadIdx.x, a0 = blockIdx.x * kTxP;
+  constexpr int NT = 64 * kTxP;
   TX_STAMP(1, 0);
-  if (tid < kTxA) {
+  if (tid < kTxP) {
     const bool mine = a0 + tid < x.S;
     nq[tid] = mine ? x.q_n[a0 + tid] : 0;
     nf[tid] = mine ? x.free_n[a0 + tid] : 0;
   }
-  if (tid < kTxA * 8) {
-    const int k = tid & (kTxA - 1), m = tid / kTxA;
+  if (tid < kTxP * 8) {
+    const int k = tid & (kTxP - 1), m = tid / kTxP;
     const int v = a0 + k < x.S ? x.fmod[m * x.S + a0 + k] : 1;
     md[k][m] = v;
     mdr[k][m] = 1.0f / (float)v;
   }
   if (tid == 0) far = far_in;
   __syncthreads();
-  tx_queues_load(x, a0, q, nq, fn0, &far);
+  tx_queues_load<kTxP>(x, a0, q, nq, fn0, &far);
   {
-    const int k = tid & (kTxA - 1);
+    const int k = tid & (kTxP - 1);
     if (a0 + k < x.S)
-      for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
+      for (int c = tid / kTxP; c < kTxCells; c += NT / kTxP) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
   }
   __syncthreads();
   TX_STAMP(1, 1);
-  if (tid < kTxA && a0 + tid < x.S) {
-    const int k = tid, a = a0 + tid;
-    int16_t *flk = &fl[k][0];
-    int n_q = nq[k], n_f = nf[k];
-    int fnc = fn0;                                          // the frame on the air (fn0 < gHyperframe: trxsig_trxgroup_push checks)
-    if (!far) {
-      TrxqPk *row = &q[k][0];
-      TrxqPk top = row[0], c[6];
+  // wave k walks ARFCN a0 + k; what it keeps between the turns (the same in every lane):
+  const int k = __builtin_amdgcn_readfirstlane(tid >> 6), a = a0 + k;
+  const bool walker = a < x.S;
+  const bool writer = (tid & 63) == 0;                      // (one lane stores; all of them compute)
+  TrxqPk *row = &q[k][0];
+  int16_t *flk = &fl[k][0];
+  int n_q = nq[k], n_f = nf[k];
+  const int is_far = far;
+  TrxqPk top = 0, last = 0, c[6] = {0, 0, 0, 0, 0, 0};
+  if (walker && !is_far && n_q > 0) {
+    top = row[0]; last = row[n_q - 1];
 #pragma unroll
-      for (int i = 0; i < 6; i++) c[i] = row[1 + i];
-      for (int t = 0; t < n_slots; t++) {
-        const int now = tn0 + t, tn = now & 7;              // (packed relative to fn0: the time of this slot IS tn0 + t)
-        if (t > 0 && tn == 0) { fnc++; fnc = fnc == TRXQ_HYPERFRAME ? 0 : fnc; }
+    for (int i = 0; i < 6; i++) c[i] = row[1 + i];
+  }
+  const TrxqView gq = {x.q_fn + a, x.q_key + a, x.S};       // (the slow path: the queue where it lives)
+  for (int t0 = 0; t0 < n_slots; t0 += kTxWalk) {
+    const int nt = min(kTxWalk, n_slots - t0);
+    for (int i = tid; i < kTxP * (nt + 1); i += NT) {       // the filler cell of every slot of the turn: [FN % modulus][TN]
+      const int kk = i & (kTxP - 1), j = i / kTxP, now = tn0 + t0 + j, tn = now & 7;
+      int fn = fn0 + (now >> 3);                            // (fn0 < gHyperframe, n_slots < 8 gHyperframe: trxsig_trxgroup_push checks)
+      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+      cidx[kk][j] = (uint16_t)(tx_fn_mod(fn, md[kk][tn], mdr[kk][tn]) * 8 + tn);
+    }
+    __syncthreads();
+    if (walker && !is_far) {
+      int cell = cidx[k][0];
+      int pid = flk[cell];                                  // the filler entry of the slot (:175-177), read ahead
+      for (int j = 0; j < nt; j++) {
+        const int t = t0 + j, now = tn0 + t;                // (packed relative to fn0: the time of this slot IS tn0 + t)
+        const int cell_next = cidx[k][j + 1];
         int fq = 0;
+        bool reread = false;
         while (n_q > 0) {
           const int tk = trxq_pk_time(top);
           if (tk > now) break;
-          // a stale burst (tk < now): "even if the burst is stale, put it in the filler table" (:142-153) -- or the burst for
-          // exactly this slot (:159-173): either way it replaces its filler entry, [FN % modulus][TN] of ITS time
           TrxqPk e;
-          n_q = tx_heap_pop(row, n_q, top, c, e);
+          n_q = tx_heap_pop(row, n_q, top, c, last, e);
+          if (tk == now) {                                  // the burst for exactly this slot (:159-173): it replaces the filler entry and goes out
+            const int old = reread ? (int)flk[cell] : pid;
+            if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
+            pid = trxq_pk_id(e);
+            flk[cell] = (int16_t)pid;
+            reread = false;
+            fq = 1;
+            break;
+          }
+          // a stale burst: "even if the burst is stale, put it in the filler table" (:142-153), [FN % modulus][TN] of ITS time
           const int etn = trxq_pk_tn(e);
-          int16_t *cell = &flk[tx_fn_mod(trxq_pk_fn(e, fn0), md[k][etn], mdr[k][etn]) * 8 + etn];
-          tx_free(x, a, n_f, *cell);
-          *cell = (int16_t)trxq_pk_id(e);
-          if (tk == now) { fq = 1; break; }
+          const int ecell = tx_fn_mod(trxq_pk_fn(e, fn0), md[k][etn], mdr[k][etn]) * 8 + etn;
+          const int old = flk[ecell];
+          if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
+          flk[ecell] = (int16_t)trxq_pk_id(e);
+          reread = reread || ecell == cell;
         }
-        out_pid[(size_t)t * x.S + a] = flk[tx_fn_mod(fnc, md[k][tn], mdr[k][tn]) * 8 + tn];   // the filler entry (:175-177), the burst itself if it was there
-        out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
-      }
-    } else {
-      // the slow path: the queue where it lives (trxsig_txq.h's moves on the arrays in memory, a dependent access a move)
-      const TrxqView gq = {x.q_fn + a, x.q_key + a, x.S};
-      for (int t = 0; t < n_slots; t++) {
-        const int tn = (tn0 + t) & 7;
-        if (t > 0 && tn == 0) { fnc++; fnc = fnc == TRXQ_HYPERFRAME ? 0 : fnc; }
-        int fq = 0;
-        while (n_q > 0) {
-          const int32_t tfn = gq.f(0), tkey = gq.k(0);
-          const bool stale = trxq_time_lt(tfn, tkey & 7, fnc, tn), hit = tfn == fnc && (tkey & 7) == tn;
-          if (!stale && !hit) break;
-          int32_t efn, ekey;
-          n_q = trxq_pop(gq, n_q, &efn, &ekey);
-          const int etn = ekey & 7;
-          int16_t *cell = &flk[(efn % md[k][etn]) * 8 + etn];
-          tx_free(x, a, n_f, *cell);
-          *cell = (int16_t)(ekey >> 3);
-          if (!stale) { fq = 1; break; }
+        if (reread) pid = flk[cell];
+        if (writer) {
+          out_pid[(size_t)t * x.S + a] = (int16_t)pid;
+          out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
         }
-        out_pid[(size_t)t * x.S + a] = flk[(fnc % md[k][tn]) * 8 + tn];
-        out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+        cell = cell_next;
+        pid = flk[cell];                                    // (after this slot's writes: LDS keeps a wave's order)
       }
+    } else if (walker) {
+      // the slow path: trxsig_txq.h's moves on the arrays in memory, a dependent access a move (lane 0 alone: the moves store)
+      if (writer)
+        for (int j = 0; j < nt; j++) {
+          const int t = t0 + j, tn = (tn0 + t) & 7;
+          int fnc = fn0 + ((tn0 + t) >> 3);
+          fnc -= fnc >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+          fnc -= fnc >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+          int fq = 0;
+          while (n_q > 0) {
+            const int32_t tfn = gq.f(0), tkey = gq.k(0);
+            const bool stale = trxq_time_lt(tfn, tkey & 7, fnc, tn), hit = tfn == fnc && (tkey & 7) == tn;
+            if (!stale && !hit) break;
+            int32_t efn, ekey;
+            n_q = trxq_pop(gq, n_q, &efn, &ekey);
+            const int etn = ekey & 7;
+            int16_t *cl = &flk[(efn % md[k][etn]) * 8 + etn];
+            tx_free(x, a, n_f, *cl);
+            *cl = (int16_t)(ekey >> 3);
+            if (!stale) { fq = 1; break; }
+          }
+          out_pid[(size_t)t * x.S + a] = flk[cidx[k][j]];
+          out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+        }
+      n_q = __builtin_amdgcn_readfirstlane(n_q); n_f = __builtin_amdgcn_readfirstlane(n_f);
     }
-    nq[k] = n_q; nf[k] = n_f;
+    __syncthreads();
   }
+  if (walker && writer) { nq[k] = n_q; nf[k] = n_f; }
   TX_STAMP(1, 2);
   __syncthreads();
-  if (!far) tx_queues_store(x, a0, q, nq, fn0);
+  if (!far) tx_queues_store<kTxP>(x, a0, q, nq, fn0);
   {
-    const int k = tid & (kTxA - 1);
-    if (a0 + k < x.S)
-      for (int c = tid / kTxA; c < kTxCells; c += 256 / kTxA) x.filler[(size_t)c * x.S + a0 + k] = fl[k][c];
+    const int kk = tid & (kTxP - 1);
+    if (a0 + kk < x.S)
+      for (int c2 = tid / kTxP; c2 < kTxCells; c2 += NT / kTxP) x.filler[(size_t)c2 * x.S + a0 + kk] = fl[kk][c2];
   }
-  if (tid < kTxA && a0 + tid < x.S) {
+  if (tid < kTxP && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
   }
@@ -372,7 +418,7 @@ hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0
   if (n_slots <= 0) return hipSuccess;
   if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;
   const int far = (long long)tn0 + n_slots >= 8LL * TRXQ_PK_WIN;    // the walk's own times must fit the packed form
-  k_group_tx_push<<<dim3((x.S + kTxA - 1) / kTxA), dim3(256), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq, far);
+  k_group_tx_push<<<dim3((x.S + kTxP - 1) / kTxP), dim3(64 * kTxP), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq, far);
   const long long words = (long long)x.S * n_slots * TRXG_PAYLOAD_WORDS;
   k_group_tx_gather<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(x, n_slots, out_pid, out_fq, (uint32_t *)bits_out, gain_out,
                                                                                    fq_out);

@@ -103,8 +103,16 @@ struct trxsig_trxgroup {
   bool fmod_dirty = true;                                   // a SETSLOT changed some fillerModulus (setModulus, :183-204)
   TrxGroupTx tx = {};
   uint32_t *d_dummy = nullptr;
-  DevBuf<int32_t> tx_arfcn;
-  DevBuf<uint8_t> tx_dgram;          // the datagrams of an add call as they arrived (k_group_tx_ingest parses and sorts them)
+  // the datagrams of an add call as they arrived (k_group_tx_ingest parses and sorts them) and their ARFCN ids: two device sets in
+  // turn.  Uploads AND ingest run on a stream of the add calls' own: batch i + 1's DMA and queue insertion run beside batch i's
+  // back end (ring store, modulate + resample) on the context's stream.  An event each way: the ingest waits for the last push's
+  // GATHER (the walk changes the queues; the gather reads payload slots the walk has already freed for the ingest to hand out
+  // again), whatever touches the transmit state on the context's stream waits for the last ingest.
+  DevBuf<int32_t> tx_arfcn[2];
+  DevBuf<uint8_t> tx_dgram[2];
+  hipStream_t tx_up = nullptr;
+  hipEvent_t tx_ingest_ev = nullptr, tx_gather_ev = nullptr;
+  bool tx_ingest_armed = false, tx_gather_armed = false;
   uint8_t *tx_pin[2] = {nullptr, nullptr};   // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), two in turn
   int tx_pin_cap[2] = {0, 0};
   bool tx_stage_held = false;        // the current set has been handed out and not yet added
@@ -235,7 +243,10 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     }
     for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
     if (g->tx_fm_ev) (void)hipEventDestroy(g->tx_fm_ev);
-    g->tx_arfcn.release(); g->tx_dgram.release();
+    if (g->tx_up) { (void)hipStreamSynchronize(g->tx_up); (void)hipStreamDestroy(g->tx_up); }
+    for (int k = 0; k < 2; k++) { g->tx_arfcn[k].release(); g->tx_dgram[k].release(); }
+    if (g->tx_ingest_ev) (void)hipEventDestroy(g->tx_ingest_ev);
+    if (g->tx_gather_ev) (void)hipEventDestroy(g->tx_gather_ev);
     for (int k = 0; k < 2; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
     g->tx_opid.release(); g->tx_ofq.release(); g->tx_bits.release(); g->tx_fq.release(); g->tx_gain.release();
   }
@@ -703,6 +714,11 @@ int tx_seal_set(trxsig_trxgroup *g, int k, hipStream_t st) {
   g->tx_ev_armed[k] = true;
   return TRXSIG_OK;
 }
+// the context's stream behind the last ingest (which ran on the add calls' stream)
+int tx_join(trxsig_trxgroup *g, hipStream_t st) {
+  if (g->tx_ingest_armed) { G_HIP(g, hipStreamWaitEvent(st, g->tx_ingest_ev, 0)); g->tx_ingest_armed = false; }
+  return TRXSIG_OK;
+}
 // fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT (rare: its own host staging vector, waited for before it is refilled)
 int tx_sync_modulus(trxsig_trxgroup *g, hipStream_t st) {
   if (!g->fmod_dirty) return TRXSIG_OK;
@@ -769,15 +785,23 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   }
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   G_LIB(tx_sync_modulus(g, st));
-  // (everything on the context's stream: the upload on a stream of its own, so that batch i + 1's DMA would run beside batch i's
-  //  kernels, was measured -- 170 instead of 85 us per 8,192-burst step: the cross-stream waits cost the host calls and the queue
-  //  more than the 25 us of DMA they hide, profiles/r05_group_tx_bench.txt)
-  G_HIP(g, g->tx_dgram.need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES, st)); G_HIP(g, g->tx_arfcn.need((size_t)n, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_arfcn.p, h_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-  G_HIP(g, hipMemcpyAsync(g->tx_dgram.p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, st));
-  G_LIB(tx_seal_set(g, k, st));
-  g->tx_stage_held = false;                                 // (the set is the DMA's until its event has passed: the next staging call takes the other)
-  G_HIP(g, trx_launch_group_tx_ingest(st, g->tx, n, g->tx_dgram.p, g->tx_arfcn.p, g->gain_tab, ref_fn, far));
+  if (!g->tx_up) {
+    G_HIP(g, hipStreamCreateWithFlags(&g->tx_up, hipStreamNonBlocking));
+    G_HIP(g, hipEventCreateWithFlags(&g->tx_ingest_ev, hipEventDisableTiming));
+    G_HIP(g, hipEventCreateWithFlags(&g->tx_gather_ev, hipEventDisableTiming));
+  }
+  hipStream_t up = g->tx_up;
+  // (set k's device arrays were last read by the ingest two calls ago, on this stream; growing them waits for both streams)
+  if ((size_t)n * TRXSIG_TX_DATAGRAM_BYTES > g->tx_dgram[k].cap || (size_t)n > g->tx_arfcn[k].cap) G_HIP(g, hipStreamSynchronize(up));
+  G_HIP(g, g->tx_dgram[k].need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES, st)); G_HIP(g, g->tx_arfcn[k].need((size_t)n, st));
+  G_HIP(g, hipMemcpyAsync(g->tx_arfcn[k].p, h_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, up));
+  G_HIP(g, hipMemcpyAsync(g->tx_dgram[k].p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, up));
+  G_LIB(tx_seal_set(g, k, up));                             // (the pinned set is the DMA's until this event has passed: the next staging call takes the other)
+  g->tx_stage_held = false;
+  if (g->tx_gather_armed) { G_HIP(g, hipStreamWaitEvent(up, g->tx_gather_ev, 0)); g->tx_gather_armed = false; }
+  G_HIP(g, trx_launch_group_tx_ingest(up, g->tx, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->gain_tab, ref_fn, far));
+  G_HIP(g, hipEventRecord(g->tx_ingest_ev, up));
+  g->tx_ingest_armed = true;
   return TRXSIG_OK;
 }
 
@@ -820,7 +844,9 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
   const size_t cells = (size_t)n_slots * g->S;
   G_HIP(g, g->tx_opid.need(cells, st)); G_HIP(g, g->tx_ofq.need(cells, st)); G_HIP(g, g->tx_bits.need(cells * 148, st));
   G_HIP(g, g->tx_gain.need(cells, st)); G_HIP(g, g->tx_fq.need(cells, st));
+  G_LIB(tx_join(g, st));
   G_HIP(g, trx_launch_group_tx_push(st, g->tx, fn, tn, n_slots, g->tx_opid.p, g->tx_ofq.p, g->tx_bits.p, g->tx_gain.p, g->tx_fq.p));
+  if (g->tx_gather_ev) { G_HIP(g, hipEventRecord(g->tx_gather_ev, st)); g->tx_gather_armed = true; }
   if (d_bits) *d_bits = g->tx_bits.p;
   if (d_gain) *d_gain = g->tx_gain.p;
   if (d_from_queue) *d_from_queue = g->tx_fq.p;
@@ -853,6 +879,7 @@ int trxsig_trxgroup_tx_queue_size(trxsig_trxgroup *g, int arfcn, int *dropped) {
   Guard gd(trxsig_device(g->c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(g->c);
   int32_t n = 0; uint32_t stt = 0;
+  G_LIB(tx_join(g, st));
   G_HIP(g, hipMemcpyAsync(&n, g->tx.q_n + arfcn, 4, hipMemcpyDeviceToHost, st));
   G_HIP(g, hipMemcpyAsync(&stt, g->tx.status + arfcn, 4, hipMemcpyDeviceToHost, st));
   G_HIP(g, hipStreamSynchronize(st));

@@ -15,8 +15,9 @@
 //     push -- the path from the new leaf to the root is known before any comparison: every ancestor is fetched at once, the
 //             comparisons run on registers (one round trip a push);
 //     pop  -- __adjust_heap's hole goes down two levels a round trip (children and grandchildren fetched together; the first two
-//             levels come from registers, fetched after the previous pop), and the element last moved up is still in a register
-//             when __push_heap's climb back starts: its first comparison -- usually the only one -- reads nothing.
+//             levels and the queue's last element come from registers, fetched after the previous pop), and the element last moved
+//             up is still in a register when __push_heap's climb back starts: its first comparison -- usually the only one --
+//             reads nothing.
 // The array after every operation is trxq_push's / trxq_pop's array (unpacked), which is std::priority_queue's.
 #pragma once
 #include "trxsig_txq.h"
@@ -71,12 +72,13 @@ TRXQ_HD int tx_heap_push(TrxqPk *row, int n, TrxqPk v) {
 }
 
 // priority_queue::pop.  top: element 0 (in: as it is; out: as it is after the pop, undefined when the queue empties); c[0..5]: elements
-// 1 .. 6 likewise (whatever lies past the queue's end is never looked at).  popped = the element handed out.  n = size before (> 0).
-TRXQ_HD int tx_heap_pop(TrxqPk *row, int n, TrxqPk &top, TrxqPk (&c)[6], TrxqPk &popped) {
+// 1 .. 6 likewise (whatever lies past the queue's end is never looked at); last: element n - 1 likewise.  popped = the element
+// handed out.  n = size before (> 0).
+TRXQ_HD int tx_heap_pop(TrxqPk *row, int n, TrxqPk &top, TrxqPk (&c)[6], TrxqPk &last, TrxqPk &popped) {
   popped = top;
   const int len = n - 1;
   if (len == 0) return 0;
-  const TrxqPk v = row[len];                                // __pop_heap: value = *(last - 1), then __adjust_heap(first, 0, len, value)
+  const TrxqPk v = last;                                    // __pop_heap: value = *(last - 1), then __adjust_heap(first, 0, len, value)
   const int half = (len - 1) >> 1;                          // "while (secondChild < (len - 1) / 2)": both children exist
   const int lone = (len & 1) ? -1 : (len - 2) >> 1;         // the hole whose only child is element len - 1 (len even)
   int hole = 0;
@@ -115,5 +117,6 @@ TRXQ_HD int tx_heap_pop(TrxqPk *row, int n, TrxqPk &top, TrxqPk (&c)[6], TrxqPk 
   top = hole == 0 ? v : w0;
 #pragma unroll
   for (int i = 0; i < 6; i++) c[i] = row[1 + i];
+  last = row[len - 1];
   return len;
 }

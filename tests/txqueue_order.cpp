@@ -23,14 +23,14 @@ int main() {
   TrxqView q = {fn.data(), key.data(), 1};
   int n = 0;
   std::vector<TrxqPk> row(TRXQ_LDS_CAP + 1);                // the packed form: one word an entry, relative to the first write's frame
-  TrxqPk top = 0, c[6] = {0, 0, 0, 0, 0, 0};
+  TrxqPk top = 0, c[6] = {0, 0, 0, 0, 0, 0}, last = 0;
   int ref = -1;
   auto is = [&](TrxqPk e, int i) {
     return trxq_pk_fn(e, ref) == fn[i] && trxq_pk_tn(e) == (key[i] & 7) && trxq_pk_id(e) == ((key[i] >> 3) & (TRXQ_PK_IDS - 1));
   };
   auto same = [&]() {
     for (int i = 0; i < n; i++) if (!is(row[i], i)) return false;
-    if (n > 0 && !is(top, 0)) return false;
+    if (n > 0 && (!is(top, 0) || !is(last, n - 1))) return false;
     for (int i = 0; i < 6 && 1 + i < n; i++) if (!is(c[i], 1 + i)) return false;
     return true;
   };
@@ -47,13 +47,14 @@ int main() {
       n = trxq_push(q, n, it->fn, it->tn | (it->id << 3));
       top = row[0];                                         // (the kernels that push do not pop: the walk loads these when it starts)
       for (int i = 0; i < 6; i++) c[i] = row[1 + i];
+      last = row[n - 1];
       if (m != n || !same()) return 3;
     } else {
       int a = -1, b = -1, l = -1;
       if (!pq.empty()) { Item *it = pq.top(); pq.pop(); a = it->id; delete it; }
       if (n > 0) {
         TrxqPk e;
-        const int m = tx_heap_pop(row.data(), n, top, c, e);
+        const int m = tx_heap_pop(row.data(), n, top, c, last, e);
         l = trxq_pk_id(e);
         int32_t f, k; n = trxq_pop(q, n, &f, &k); b = k >> 3;
         if (m != n || trxq_pk_fn(e, ref) != f || trxq_pk_tn(e) != (k & 7) || l != (b & (TRXQ_PK_IDS - 1)) || !same()) return 3;
