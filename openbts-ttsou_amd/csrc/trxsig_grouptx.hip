@@ -25,9 +25,17 @@
 // probe build (make probe_tx, tools/group_tx_probe.py): clock64() at the phase boundaries of the two serial kernels, workgroup 0's wave 0
 __device__ unsigned long long g_txprobe[2][8];
 #define TX_STAMP(kern, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_txprobe[kern][i] = clock64(); } while (0)
+#define TX_ACC_BEGIN() const unsigned long long acc_t0_ = clock64()
+#define TX_ACC_END(kern, i) do { acc_[i - 4] += clock64() - acc_t0_; } while (0)
+#define TX_ACC_DECL() unsigned long long acc_[4] = {0, 0, 0, 0}
+#define TX_ACC_OUT(kern) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 4; i_++) g_txprobe[kern][4 + i_] = acc_[i_]; } while (0)
 extern "C" int trx_txprobe_read(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_txprobe), sizeof(g_txprobe)); }
 #else
 #define TX_STAMP(kern, i) do { } while (0)
+#define TX_ACC_BEGIN() do { } while (0)
+#define TX_ACC_END(kern, i) do { } while (0)
+#define TX_ACC_DECL() do { } while (0)
+#define TX_ACC_OUT(kern) do { } while (0)
 #endif
 
 namespace {
@@ -164,6 +172,42 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
     __syncthreads();
     TX_STAMP(0, 3);
     {
+      // ---- the payloads to their slots, a burst a thread: its 148 bytes as aligned sixteen-byte loads, all in flight at once; the
+      //      thread's FIRST burst is loaded before the queue insertions below and stored after them (the loads land meanwhile) ----
+      // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548).  Datagram src's payload starts at byte 154 src + 6: on a
+      // multiple of four for odd src, two past one for even src -- aligned words are loaded and shifted by two bytes then
+      uint32_t aw[38];
+      auto load = [&](int e, bool &odd2, long long &slot, uint32_t &gain) {
+        slot = -1; odd2 = false; gain = 0;
+        if (e >= lbase[kTxA]) return;
+        const int key = lk[e];
+        const int kk = (key >> 8) & 15, src = w0 + (key >> 12);
+        if (e - lbase[kk] >= acc[kk]) return;               // dropped
+        const size_t pb = (size_t)src * 154 + 6;
+        odd2 = (pb & 2) != 0;
+        const uint32_t *pa = reinterpret_cast<const uint32_t *>(dgram + (pb & ~(size_t)3));
+#pragma unroll
+        for (int w = 0; w < 36; w += 4) __builtin_memcpy(&aw[w], pa + w, 16);
+        __builtin_memcpy(&aw[36], pa + 36, 8);              // (up to four bytes past the last datagram's end: the array is allocated eight longer)
+        gain = __float_as_uint(gt.v[(key >> 3) & 31]);
+        slot = ((long long)(a0 + kk) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS;
+      };
+      auto store = [&](bool odd2, long long slot, uint32_t gain) {
+        if (slot < 0) return;
+        uint32_t v[TRXG_PAYLOAD_WORDS];
+#pragma unroll
+        for (int w = 0; w < 37; w++) v[w] = odd2 ? __builtin_amdgcn_alignbyte(aw[w + 1], aw[w], 2) : aw[w];
+        v[37] = gain;
+        uint32_t *dst = x.pool + slot;
+        static_assert(TRXG_PAYLOAD_WORDS == 38, "nine sixteen-byte stores and an eight-byte one");
+#pragma unroll
+        for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);   // (a slot starts on a multiple of 8 bytes)
+        __builtin_memcpy(dst + 36, &v[36], 8);
+      };
+      bool odd2;
+      long long slot;
+      uint32_t gain;
+      load(tid, odd2, slot, gain);
       // ---- addRadioVector: WAVE k enters ARFCN k's bursts (every value the same in all its lanes: scalar branches, see k_group_tx_push;
       //      lane 0's stores count) ----
       const int k = __builtin_amdgcn_readfirstlane(wave);
@@ -184,31 +228,19 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
           for (int j = 0; j < m; j++) n_q = trxq_push(gq, n_q, lf[e0 + j], (lk[e0 + j] & 7) | ((int)fs[e0 + j] << 3));
         }
         n_q = __builtin_amdgcn_readfirstlane(n_q);
-        if (lane == 0) {
+        if (lane == 0) {                                    // (nq / nf / st_ are not read by the copy)
           nq[k] = n_q; nf[k] -= m;
           if (m < tot[k]) st_[k] |= 1;                      // queue or payload pool full: the rest is dropped and the ARFCN marked
         }
       }
       TX_STAMP(0, 4);
-      // ---- the payloads to their slots: a burst a thread -- its 148 bytes as nine sixteen-byte loads and a four-byte one, all in
-      //      flight at once (the datagrams start on even addresses only: unaligned loads), then the gain ----
-      // (acc / lbase / fs / lk are not written above; nq / nf are not read below)
-      for (int e = tid; e < lbase[kTxA]; e += 1024) {
-        const int key = lk[e];
-        const int kk = (key >> 8) & 15, src = w0 + (key >> 12);
-        if (e - lbase[kk] >= acc[kk]) continue;             // dropped
-        const uint8_t *p = dgram + (size_t)src * 154 + 6;   // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548)
-        uint32_t v[TRXG_PAYLOAD_WORDS];
-#pragma unroll
-        for (int w = 0; w < 37; w++) __builtin_memcpy(&v[w], p + 4 * w, 4);
-        v[37] = __float_as_uint(gt.v[(key >> 3) & 31]);
-        uint32_t *dst = x.pool + ((size_t)(a0 + kk) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS;
-        static_assert(TRXG_PAYLOAD_WORDS == 38, "nine sixteen-byte stores and an eight-byte one");
-#pragma unroll
-        for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);   // (a slot starts on a multiple of 8 bytes)
-        __builtin_memcpy(dst + 36, &v[36], 8);
+      store(odd2, slot, gain);
+      for (int e = tid + 1024; e < lbase[kTxA]; e += 1024) {   // (acc / lbase / fs / lk are not written above)
+        load(e, odd2, slot, gain);
+        store(odd2, slot, gain);
       }
     }
+    __syncthreads();                                        // lf / lk / fs / cnt are the next round's
     __syncthreads();                                        // lf / lk / fs / cnt are the next round's
     TX_STAMP(0, 5);
   }
@@ -290,6 +322,7 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
     for (int i = 0; i < 6; i++) c[i] = row[1 + i];
   }
   const TrxqView gq = {x.q_fn + a, x.q_key + a, x.S};       // (the slow path: the queue where it lives)
+  TX_ACC_DECL();
   for (int t0 = 0; t0 < n_slots; t0 += kTxWalk) {
     const int nt = min(kTxWalk, n_slots - t0);
     for (int i = tid; i < kTxP * (nt + 1); i += NT) {       // the filler cell of every slot of the turn: [FN % modulus][TN]
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
           const int tk = trxq_pk_time(top);
           if (tk > now) break;
           TrxqPk e;
-          n_q = tx_heap_pop(row, n_q, top, c, last, e);
+          { TX_ACC_BEGIN(); n_q = tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
           if (tk == now) {                                  // the burst for exactly this slot (:159-173): it replaces the filler entry and goes out
             const int old = reread ? (int)flk[cell] : pid;
             if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
@@ -368,6 +401,7 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
   }
   if (walker && writer) { nq[k] = n_q; nf[k] = n_f; }
   TX_STAMP(1, 2);
+  TX_ACC_OUT(1);
   __syncthreads();
   if (!far) tx_queues_store<kTxP>(x, a0, q, nq, fn0);
   {

@@ -104,15 +104,17 @@ struct trxsig_trxgroup {
   TrxGroupTx tx = {};
   uint32_t *d_dummy = nullptr;
   // the datagrams of an add call as they arrived (k_group_tx_ingest parses and sorts them) and their ARFCN ids: two device sets in
-  // turn.  Uploads AND ingest run on a stream of the add calls' own: batch i + 1's DMA and queue insertion run beside batch i's
-  // back end (ring store, modulate + resample) on the context's stream.  An event each way: the ingest waits for the last push's
-  // GATHER (the walk changes the queues; the gather reads payload slots the walk has already freed for the ingest to hand out
-  // again), whatever touches the transmit state on the context's stream waits for the last ingest.
+  // turn.  The uploads run on a stream of their own (tx_up: nothing but copies -- a copy enqueued behind a kernel or an event wait
+  // was seen to hold the HOST until that had run), the ingest on another (tx_in): batch i + 1's DMA and queue insertion run beside
+  // batch i's back end (ring store, modulate + resample) on the context's stream.  Events: the ingest waits for its upload and for
+  // the last push's GATHER (the walk changes the queues; the gather reads payload slots the walk has already freed for the ingest
+  // to hand out again); whatever touches the transmit state on the context's stream waits for the last ingest; a set's device
+  // arrays are uploaded into again when the ingest that read them (two calls ago) has run -- the host waits for that one.
   DevBuf<int32_t> tx_arfcn[2];
   DevBuf<uint8_t> tx_dgram[2];
-  hipStream_t tx_up = nullptr;
-  hipEvent_t tx_ingest_ev = nullptr, tx_gather_ev = nullptr;
-  bool tx_ingest_armed = false, tx_gather_armed = false;
+  hipStream_t tx_up = nullptr, tx_in = nullptr;
+  hipEvent_t tx_ingest_ev = nullptr, tx_gather_ev = nullptr, tx_read_ev[2] = {nullptr, nullptr};
+  bool tx_ingest_armed = false, tx_gather_armed = false, tx_read_armed[2] = {false, false};
   uint8_t *tx_pin[2] = {nullptr, nullptr};   // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), two in turn
   int tx_pin_cap[2] = {0, 0};
   bool tx_stage_held = false;        // the current set has been handed out and not yet added
@@ -244,7 +246,8 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
     if (g->tx_fm_ev) (void)hipEventDestroy(g->tx_fm_ev);
     if (g->tx_up) { (void)hipStreamSynchronize(g->tx_up); (void)hipStreamDestroy(g->tx_up); }
-    for (int k = 0; k < 2; k++) { g->tx_arfcn[k].release(); g->tx_dgram[k].release(); }
+    if (g->tx_in) { (void)hipStreamSynchronize(g->tx_in); (void)hipStreamDestroy(g->tx_in); }
+    for (int k = 0; k < 2; k++) { g->tx_arfcn[k].release(); g->tx_dgram[k].release(); if (g->tx_read_ev[k]) (void)hipEventDestroy(g->tx_read_ev[k]); }
     if (g->tx_ingest_ev) (void)hipEventDestroy(g->tx_ingest_ev);
     if (g->tx_gather_ev) (void)hipEventDestroy(g->tx_gather_ev);
     for (int k = 0; k < 2; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
@@ -707,6 +710,9 @@ int tx_setup(trxsig_trxgroup *g) {
 int tx_take_set(trxsig_trxgroup *g, int *k) {
   *k = g->tx_set ^= 1;
   if (g->tx_ev_armed[*k]) { G_HIP(g, hipEventSynchronize(g->tx_ev[*k])); g->tx_ev_armed[*k] = false; }
+  // ... and its device arrays: free when the ingest that read them two calls ago has run (here the host is held back when the
+  // device is more than a batch behind)
+  if (g->tx_read_armed[*k]) { G_HIP(g, hipEventSynchronize(g->tx_read_ev[*k])); g->tx_read_armed[*k] = false; }
   return TRXSIG_OK;
 }
 int tx_seal_set(trxsig_trxgroup *g, int k, hipStream_t st) {
@@ -787,21 +793,26 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   G_LIB(tx_sync_modulus(g, st));
   if (!g->tx_up) {
     G_HIP(g, hipStreamCreateWithFlags(&g->tx_up, hipStreamNonBlocking));
+    G_HIP(g, hipStreamCreateWithFlags(&g->tx_in, hipStreamNonBlocking));
     G_HIP(g, hipEventCreateWithFlags(&g->tx_ingest_ev, hipEventDisableTiming));
     G_HIP(g, hipEventCreateWithFlags(&g->tx_gather_ev, hipEventDisableTiming));
+    for (int j = 0; j < 2; j++) G_HIP(g, hipEventCreateWithFlags(&g->tx_read_ev[j], hipEventDisableTiming));
   }
-  hipStream_t up = g->tx_up;
-  // (set k's device arrays were last read by the ingest two calls ago, on this stream; growing them waits for both streams)
-  if ((size_t)n * TRXSIG_TX_DATAGRAM_BYTES > g->tx_dgram[k].cap || (size_t)n > g->tx_arfcn[k].cap) G_HIP(g, hipStreamSynchronize(up));
-  G_HIP(g, g->tx_dgram[k].need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES, st)); G_HIP(g, g->tx_arfcn[k].need((size_t)n, st));
+  hipStream_t up = g->tx_up, in = g->tx_in;
+  // (set k's device arrays are free: tx_take_set has waited for the ingest that read them two calls ago)
+  G_HIP(g, g->tx_dgram[k].need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES + 8, up));   // (+ 8: the ingest kernel reads whole aligned words round the last payload)
+  G_HIP(g, g->tx_arfcn[k].need((size_t)n, up));
   G_HIP(g, hipMemcpyAsync(g->tx_arfcn[k].p, h_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, up));
   G_HIP(g, hipMemcpyAsync(g->tx_dgram[k].p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, up));
   G_LIB(tx_seal_set(g, k, up));                             // (the pinned set is the DMA's until this event has passed: the next staging call takes the other)
   g->tx_stage_held = false;
-  if (g->tx_gather_armed) { G_HIP(g, hipStreamWaitEvent(up, g->tx_gather_ev, 0)); g->tx_gather_armed = false; }
-  G_HIP(g, trx_launch_group_tx_ingest(up, g->tx, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->gain_tab, ref_fn, far));
-  G_HIP(g, hipEventRecord(g->tx_ingest_ev, up));
+  G_HIP(g, hipStreamWaitEvent(in, g->tx_ev[k], 0));
+  if (g->tx_gather_armed) { G_HIP(g, hipStreamWaitEvent(in, g->tx_gather_ev, 0)); g->tx_gather_armed = false; }
+  G_HIP(g, trx_launch_group_tx_ingest(in, g->tx, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->gain_tab, ref_fn, far));
+  G_HIP(g, hipEventRecord(g->tx_ingest_ev, in));
   g->tx_ingest_armed = true;
+  G_HIP(g, hipEventRecord(g->tx_read_ev[k], in));
+  g->tx_read_armed[k] = true;
   return TRXSIG_OK;
 }
 

@@ -48,3 +48,4 @@ print("k_group_tx_ingest: counts by ballots %.1f | scan + bases %.1f | headers +
     us(0, 0, 1), us(0, 1, 2), us(0, 2, 3), us(0, 3, 4), us(0, 4, 5), us(0, 5, 6), us(0, 0, 6)))
 print("k_group_tx_push  : queues + filler tables in %.1f | the walk (a lane per ARFCN) %.1f | queues + filler tables back %.1f | total %.1f" % (
     us(1, 0, 1), us(1, 1, 2), us(1, 2, 3), us(1, 0, 3)))
+print("                   of the walk, inside tx_heap_pop: %.1f" % (st[1, 4] / 100.0))
