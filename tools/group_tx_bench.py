@@ -4,7 +4,10 @@ device) and the same F frames are pushed straight into the fused transmit back e
 dump / filler table on the device, then ONE kernel bits -> modulate -> resample -> int16 at the pop).
     python tools/group_tx_bench.py [S] [frames per step] [staged|copy]
 (staged, the default since round 5: the datagrams are written into the group's pinned staging block -- where a host would
- recvfrom() them -- outside the timed add call; copy: handed over in a pageable array, which the call copies first)"""
+ recvfrom() them; copy: handed over in a pageable array, which the call copies first)
+us_per_step is the loop's wall time per step, everything included (the ~30 us of numpy that write the frame numbers too); the
+host_us_* fields split the HOST's time by call -- trxsig_trxgroup_tx_staging is where the host is held back when the device is
+more than a batch behind; us_per_step_synchronised is a step with a device synchronise behind it (its latency on an idle device)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
@@ -37,7 +40,7 @@ base[:, 0] = tn
 perm = rng.permutation(n)                                   # arrival order: ARFCNs interleaved
 base, arf, fo = base[perm], arf[perm], fo[perm]
 fn = 1000
-t_add = t_push = t_recv = t_stage = t_pushonly = t_popc = 0.0
+t_add = t_push = t_recv = t_stage = t_pushonly = 0.0
 seen = set()
 
 
@@ -75,22 +78,14 @@ def step():
     t1 = time.perf_counter()
     grp.push_txbe(be, fn, 0, 8 * F)
     t2 = time.perf_counter()
-    if os.environ.get("TXB_SPLIT_POP"):
-        import ctypes as C
-        global t_popc
-        pp = C.c_void_p(); stride = C.c_int64(); nn = C.c_int()
-        be.L.trxsig_txbe_pop(be.h, C.byref(pp), C.byref(stride), C.byref(nn))
-        t_popc += time.perf_counter() - t2
-        iq = torch.zeros(S, 14688 if F == 8 else 2592, 2)
-    else:
-        iq = be.pop_samples()
+    iq = be.pop_samples()
     t_add += t1 - t0; t_push += time.perf_counter() - t1; t_pushonly += t2 - t1
     fn += F
     return iq
 
 for _ in range(10): iq = step()
 torch.cuda.synchronize()
-t_add = t_push = t_recv = t_stage = t_pushonly = t_popc = 0.0
+t_add = t_push = t_recv = t_stage = t_pushonly = 0.0
 t0 = time.perf_counter()
 for _ in range(K): iq = step()
 torch.cuda.synchronize()
@@ -111,6 +106,6 @@ for _ in range(K2):
     ta = time.perf_counter(); step(); torch.cuda.synchronize(); tl += time.perf_counter() - ta
 print(json.dumps({"arfcns": S, "frames_per_step": F, "add": "trxsig_trxgroup_add_staged (received into the pinned block)" if STAGED else "trxsig_trxgroup_add_bursts (copy from a pageable array)", "bursts_per_step": n, "us_per_step": round(dt * 1e6, 1), "host_us_emulating_arrival": round(t_recv / K * 1e6, 1),
                   "Mbursts_per_s": round(n / dt / 1e6, 2), "host_us_in_add_bursts": round(t_add / K * 1e6, 1),
-                  "host_us_in_push_and_pop": round(t_push / K * 1e6, 1), "host_us_in_tx_staging": round(t_stage / K * 1e6, 1), "host_us_in_push_txbe": round(t_pushonly / K * 1e6, 1), "host_us_in_txbe_pop_c_call": round(t_popc / K * 1e6, 1), "int16_pairs_out_per_stream": int(iq.shape[1]),
+                  "host_us_in_push_and_pop": round(t_push / K * 1e6, 1), "host_us_in_tx_staging": round(t_stage / K * 1e6, 1), "host_us_in_push_txbe": round(t_pushonly / K * 1e6, 1), "int16_pairs_out_per_stream": int(iq.shape[1]),
                   "us_per_step_synchronised": round(tl / K2 * 1e6, 1), "queue_left": q, "dropped": dropped,
                   "one_burst_per_call_object": "trxsig_trx_add_radio_vector + _push_radio_vector: ~40 + ~10 us per burst (tools/host_path_bench.py)"}))

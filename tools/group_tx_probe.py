@@ -2,7 +2,8 @@
 workgroup 0's first thread):
     make -C openbts-ttsou_amd/csrc probe_tx
     TRXSIG_LIB=openbts-ttsou_amd/csrc/build_probe/libtrxsig_txprobe.so python tools/group_tx_probe.py [S] [frames per step]
-clock64() counts at 100 MHz on gfx950 (s_memrealtime): the phases are printed in microseconds."""
+The stamps are clock64() = s_memtime, the shader clock (~2.15 GHz under this load: k_group_tx_ingest's 999 hundreds are the 45 us
+rocprofv3 gives it); the phases are printed in HUNDREDS of shader clocks (21.5 of them a microsecond)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
@@ -43,9 +44,9 @@ for it in range(K + 3):
     if it >= 3: acc += st.astype(np.float64)
 st = acc / K
 def us(k, i, j): return (st[k, j] - st[k, i]) / 100.0
-print("S = %d, %d frames per step (%d bursts); workgroup 0, microseconds (clock64 at 100 MHz), mean of %d steps" % (S, F, n, K))
-print("k_group_tx_ingest: counts by ballots %.1f | scan + bases %.1f | headers + free slots %.1f | the pushes (a lane per ARFCN) %.1f | payload copy %.1f | queues back %.1f | total %.1f" % (
+print("S = %d, %d frames per step (%d bursts); workgroup 0, hundreds of shader clocks (clock64; ~21.5 a microsecond), mean of %d steps" % (S, F, n, K))
+print("k_group_tx_ingest: counts by ballots %.1f | scan + bases %.1f | headers + free slots %.1f | the pushes (a wave per ARFCN) %.1f | wait for the slowest wave's pushes + payload stores %.1f | queues back %.1f | total %.1f" % (
     us(0, 0, 1), us(0, 1, 2), us(0, 2, 3), us(0, 3, 4), us(0, 4, 5), us(0, 5, 6), us(0, 0, 6)))
-print("k_group_tx_push  : queues + filler tables in %.1f | the walk (a lane per ARFCN) %.1f | queues + filler tables back %.1f | total %.1f" % (
+print("k_group_tx_push  : queues + filler tables in %.1f | the walk (a wave per ARFCN) %.1f | queues + filler tables back %.1f | total %.1f" % (
     us(1, 0, 1), us(1, 1, 2), us(1, 2, 3), us(1, 0, 3)))
 print("                   of the walk, inside tx_heap_pop: %.1f" % (st[1, 4] / 100.0))
