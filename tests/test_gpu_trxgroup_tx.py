@@ -251,7 +251,7 @@ def test_push_txbe_refusals_leave_the_queue_alone(pkg):
 
 def test_staged_add_equals_the_copying_add(pkg):
     """trxsig_trxgroup_tx_staging + _add_staged (the datagrams received straight into the group's pinned block) against
-    trxsig_trxgroup_add_bursts on the same datagrams -- more than one round of the ingest kernel (10,000 > 4,096 per round), ARFCNs
+    trxsig_trxgroup_add_bursts on the same datagrams -- more than one round of the ingest kernel (9,900 > 8,192 per round), ARFCNs
     interleaved, late, early and duplicate bursts, a run that overflows one ARFCN's queue: the pushes hand out the same bits, gains
     and from-queue marks, the queues end up the same size, the same ARFCN reports the drop; a bad header in the staged block
     refuses the batch and leaves the block with the caller."""
@@ -275,7 +275,7 @@ def test_staged_add_equals_the_copying_add(pkg):
     extra = np.repeat(dg[:1], 300, axis=0); extra[:, 1:5] = [0, 0, 0x0c, 0x00]       # 300 more for one ARFCN: its queue overflows
     dg = np.concatenate([dg, extra]); arf = np.concatenate([arf, np.full(300, 7, np.int32)])
     n = len(dg)
-    assert n > 2 * 4096
+    assert n > 8192
     ga.add_bursts(dg, arf)
     d, a = gb.tx_staging(n)
     d[:] = dg; a[:] = arf
@@ -296,3 +296,42 @@ def test_staged_add_equals_the_copying_add(pkg):
     for a_ in range(S):
         assert ga.tx_queue_size(a_) == gb.tx_queue_size(a_)
     ga.close(); gb.close(); ctx.close()
+
+
+def test_one_add_of_twenty_frames_then_one_push(pkg):
+    """Three rounds of the ingest kernel in ONE add call (128 ARFCNs x 20 frames x 8 timeslots = 20,480 datagrams in a random arrival
+    order, every (ARFCN, frame, timeslot) once: 160 entries a queue), then ONE push of the 160 timeslots: every cell must be exactly
+    the burst that was sent for it (bits, gain pow(10, -RSSI/10) with the reference's integer division), every one from the queue,
+    the queues empty afterwards -- an expectation that needs no second implementation."""
+    import torch
+    rng = np.random.default_rng(99)
+    S, F, fn0 = 128, 20, tm.HYPERFRAME - 7                  # across the hyperframe wrap
+    ctx = pkg.TrxSig(1, 0); ctx.use_torch_stream()
+    grp = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD)
+    for a in range(S):
+        configure(lambda c, a=a: grp.control(a, c), a)
+    n = S * F * 8
+    arf = np.repeat(np.arange(S, dtype=np.int32), F * 8)
+    f = np.tile(np.repeat(np.arange(F), 8), S)
+    tn = np.tile(np.arange(8), S * F)
+    fn = (fn0 + f) % tm.HYPERFRAME
+    rssi = rng.integers(0, 60, n)
+    dg = np.zeros((n, 154), np.uint8)
+    dg[:, 0] = tn
+    dg[:, 1] = fn >> 24; dg[:, 2] = (fn >> 16) & 255; dg[:, 3] = (fn >> 8) & 255; dg[:, 4] = fn & 255
+    dg[:, 5] = rssi
+    dg[:, 6:] = rng.integers(0, 2, (n, 148))
+    order = rng.permutation(n)
+    grp.add_bursts(dg[order], arf[order])
+    bits_d, gain_d, fq_d = grp.push(fn0, 0, F * 8)
+    torch.cuda.synchronize()
+    bits = bits_d.cpu().numpy().reshape(S, F * 8, 148)
+    gain = gain_d.cpu().numpy().reshape(S, F * 8)
+    fq = fq_d.cpu().numpy().reshape(S, F * 8)
+    assert fq.all()
+    assert np.array_equal(bits, dg[:, 6:].reshape(S, F * 8, 148))
+    want_gain = np.array([np.float32(10.0 ** int(-int(r) / 10)) for r in rssi], np.float32).reshape(S, F * 8)   # (C's -RSSI / 10 truncates towards zero)
+    assert np.array_equal(gain, want_gain)
+    for a in (0, 63, 127):
+        assert grp.tx_queue_size(a) == (0, False)
+    grp.close(); ctx.close()
