@@ -101,7 +101,7 @@ struct TrxGroupTx {
 // memory -- same results, slower).
 hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn,
                                       const float *gain_tab26, int ref_fn, int far);
-// pushRadioVector for n_slots timeslots from (fn0, tn0) on every ARFCN: out_pid / out_fq [n_slots][S] scratch; bits_out
-// [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (1 = the burst came from the queue)
-hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,
-                                    uint8_t *bits_out, float *gain_out, uint8_t *fq_out);
+// pushRadioVector for n_slots timeslots from (fn0, tn0) on every ARFCN: bits_out [S][n_slots][148], gain_out [S][n_slots], fq_out
+// [S][n_slots] (1 = the burst came from the queue)
+hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, uint8_t *bits_out, float *gain_out,
+                                    uint8_t *fq_out);

@@ -12,8 +12,9 @@
 //                       goes out (:142-177) -- as payload REFERENCES, nothing is copied on the serial path; the sixteen
 //                       ARFCNs' queues AND filler tables are in LDS for the walk (round 5: a dependent global access per
 //                       queue move and per slot was the whole kernel);
-//   k_group_tx_gather : the referenced payloads into the layout trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n]
-//                       gains): what the fused transmit back end then modulates, resamples and packs to int16.
+//                       at the end of every turn of the walk the referenced payloads are copied into the layout
+//                       trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n] gains): what the fused transmit back end then
+//                       modulates, resamples and packs to int16.
 // What is kept per burst is its bits and its gain, never its modulated samples: modulateBurst + scaleVector of the same bits
 // and gain give the same samples every time they are formed, so the filler table's "copy of the burst" (:165) is a reference.
 #include "trxsig_dev.h"
@@ -275,11 +276,13 @@ constexpr int kTxP = 4;                                     // ARFCNs per workgr
 // (readfirstlane'd ARFCN index, LDS addresses that do not depend on the lane): the branches are scalar branches, no execution
 // masks to save, combine and restore as with a lane per ARFCN (where every branch some lane takes all sixteen pay for).
 // far_in != 0: the walk is too long for the packed form's window (the host's check)
-__global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, int16_t *__restrict__ out_pid,
-                                                             uint8_t *__restrict__ out_fq, int far_in) {
+__global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, uint32_t *__restrict__ bits_out,
+                                                             float *__restrict__ gain_out, uint8_t *__restrict__ fq_out, int far_in) {
   __shared__ TrxqPk q[kTxP][kTxRow];                        // packed relative to fn0: the slot on the air at step t has time tn0 + t
   __shared__ int16_t fl[kTxP][kTxCells];                    // the filler tables
   __shared__ uint16_t cidx[kTxP][kTxWalk + 2];              // [FN % modulus][TN] of the slots of this turn (+ the next turn's first)
+  __shared__ int16_t opid[kTxP][kTxWalk];                   // what goes out at each slot of the turn: a payload reference (-1: the dummy burst) ...
+  __shared__ uint8_t ofq[kTxP][kTxWalk];                    // ... and whether it came from the queue
   __shared__ int md[kTxP][8];
   __shared__ float mdr[kTxP][8];
   __shared__ int nq[kTxP], nf[kTxP], far;
@@ -364,10 +367,7 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
           reread = reread || ecell == cell;
         }
         if (reread) pid = flk[cell];
-        if (writer) {
-          out_pid[(size_t)t * x.S + a] = (int16_t)pid;
-          out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
-        }
+        if (writer) { opid[k][j] = (int16_t)pid; ofq[k][j] = (uint8_t)fq; }
         cell = cell_next;
         pid = flk[cell];                                    // (after this slot's writes: LDS keeps a wave's order)
       }
@@ -392,12 +392,32 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
             *cl = (int16_t)(ekey >> 3);
             if (!stale) { fq = 1; break; }
           }
-          out_pid[(size_t)t * x.S + a] = flk[cidx[k][j]];
-          out_fq[(size_t)t * x.S + a] = (uint8_t)fq;
+          opid[k][j] = flk[cidx[k][j]];
+          ofq[k][j] = (uint8_t)fq;
         }
       n_q = __builtin_amdgcn_readfirstlane(n_q); n_f = __builtin_amdgcn_readfirstlane(n_f);
     }
     __syncthreads();
+    // ---- the turn's output: the referenced payloads into the layout trxsig_txbe_push_bursts takes -- bits_out [S][n_slots][148],
+    //      gain_out / fq_out [S][n_slots] -- a (slot, ARFCN) cell a thread, its 152 bytes in flight at once.  (A separate kernel until
+    //      round 5: a launch more on the chain the next batch's ingest waits for.) ----
+    for (int i = tid; i < kTxP * nt; i += NT) {
+      const int kk = i / nt, j = i - kk * nt, aa = a0 + kk;
+      if (aa >= x.S) continue;
+      const int pid = opid[kk][j];
+      const uint32_t *src = pid < 0 ? x.dummy : x.pool + ((size_t)aa * x.npool + pid) * TRXG_PAYLOAD_WORDS;
+      uint32_t v[TRXG_PAYLOAD_WORDS];
+#pragma unroll
+      for (int w = 0; w < 36; w += 4) __builtin_memcpy(&v[w], src + w, 16);
+      __builtin_memcpy(&v[36], src + 36, 8);
+      const size_t cell = (size_t)aa * n_slots + (t0 + j);
+      uint32_t *dst = bits_out + cell * 37;
+#pragma unroll
+      for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);
+      dst[36] = v[36];
+      gain_out[cell] = __uint_as_float(v[37]);
+      fq_out[cell] = ofq[kk][j];
+    }
   }
   if (walker && writer) { nq[k] = n_q; nf[k] = n_f; }
   TX_STAMP(1, 2);
@@ -416,25 +436,6 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
   TX_STAMP(1, 3);
 }
 
-// bits_out [S][n_slots][148], gain_out [S][n_slots], fq_out [S][n_slots] (the transposes of out_pid / out_fq's [n_slots][S])
-__global__ __launch_bounds__(256) void k_group_tx_gather(TrxGroupTx x, int n_slots, const int16_t *__restrict__ out_pid,
-                                                         const uint8_t *__restrict__ out_fq, uint32_t *__restrict__ bits_out,
-                                                         float *__restrict__ gain_out, uint8_t *__restrict__ fq_out) {
-  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (g >= (long long)x.S * n_slots * TRXG_PAYLOAD_WORDS) return;
-  const long long cell = g / TRXG_PAYLOAD_WORDS;
-  const int w = (int)(g - cell * TRXG_PAYLOAD_WORDS);
-  const int a = (int)(cell / n_slots), t = (int)(cell - (long long)a * n_slots);
-  const int pid = out_pid[(size_t)t * x.S + a];
-  const uint32_t *src = pid < 0 ? x.dummy : x.pool + ((size_t)a * x.npool + pid) * TRXG_PAYLOAD_WORDS;
-  const uint32_t v = src[w];
-  if (w < 37) bits_out[cell * 37 + w] = v;
-  else {
-    gain_out[cell] = __uint_as_float(v);
-    fq_out[cell] = out_fq[(size_t)t * x.S + a];
-  }
-}
-
 }  // namespace
 
 hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn, const float *gain_tab26,
@@ -447,14 +448,11 @@ hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n
   return hipGetLastError();
 }
 
-hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, int16_t *out_pid, uint8_t *out_fq,
-                                    uint8_t *bits_out, float *gain_out, uint8_t *fq_out) {
+hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, uint8_t *bits_out, float *gain_out,
+                                    uint8_t *fq_out) {
   if (n_slots <= 0) return hipSuccess;
   if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;
   const int far = (long long)tn0 + n_slots >= 8LL * TRXQ_PK_WIN;    // the walk's own times must fit the packed form
-  k_group_tx_push<<<dim3((x.S + kTxP - 1) / kTxP), dim3(64 * kTxP), 0, st>>>(x, fn0, tn0, n_slots, out_pid, out_fq, far);
-  const long long words = (long long)x.S * n_slots * TRXG_PAYLOAD_WORDS;
-  k_group_tx_gather<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st>>>(x, n_slots, out_pid, out_fq, (uint32_t *)bits_out, gain_out,
-                                                                                   fq_out);
+  k_group_tx_push<<<dim3((x.S + kTxP - 1) / kTxP), dim3(64 * kTxP), 0, st>>>(x, fn0, tn0, n_slots, (uint32_t *)bits_out, gain_out, fq_out, far);
   return hipGetLastError();
 }

@@ -104,23 +104,27 @@ struct trxsig_trxgroup {
   TrxGroupTx tx = {};
   uint32_t *d_dummy = nullptr;
   // the datagrams of an add call as they arrived (k_group_tx_ingest parses and sorts them) and their ARFCN ids: two device sets in
-  // turn.  The uploads run on a stream of their own (tx_up: nothing but copies -- a copy enqueued behind a kernel or an event wait
-  // was seen to hold the HOST until that had run), the ingest on another (tx_in): batch i + 1's DMA and queue insertion run beside
-  // batch i's back end (ring store, modulate + resample) on the context's stream.  Events: the ingest waits for its upload and for
-  // the last push's GATHER (the walk changes the queues; the gather reads payload slots the walk has already freed for the ingest
-  // to hand out again); whatever touches the transmit state on the context's stream waits for the last ingest; a set's device
-  // arrays are uploaded into again when the ingest that read them (two calls ago) has run -- the host waits for that one.
+  // turn.  Three streams besides the context's:
+  //   tx_up  nothing but the uploads (a copy enqueued behind a kernel or an event wait was seen to hold the HOST until that had run);
+  //   tx_q   everything that touches the queues, in call order: ingest, walk, gather, (rarely) the filler moduli's upload -- the chain
+  //          std::priority_queue's moves make serial runs without a cross-stream hop inside it;
+  //   the context's stream: what the CALLER does with a push's output (the transmit back end: ring store, modulate + resample) --
+  //          batch i's back end runs beside batch i + 1's ingest and walk.
+  // Events: the ingest waits for its upload; the context's stream waits for the gather whose output the call returns; a push writes
+  // one of TWO output sets in turn and waits for whatever the context's stream had been given when the push before it was called
+  // (the output's contract: valid until the next push); a staging set is handed out again when its upload and the ingest that read
+  // it have run (the host waits there: that is where it is held back when the device is more than a batch behind).
   DevBuf<int32_t> tx_arfcn[2];
   DevBuf<uint8_t> tx_dgram[2];
-  hipStream_t tx_up = nullptr, tx_in = nullptr;
-  hipEvent_t tx_ingest_ev = nullptr, tx_gather_ev = nullptr, tx_read_ev[2] = {nullptr, nullptr};
-  bool tx_ingest_armed = false, tx_gather_armed = false, tx_read_armed[2] = {false, false};
+  hipStream_t tx_up = nullptr, tx_q = nullptr;
+  hipEvent_t tx_q_ev = nullptr, tx_out_ev[2] = {nullptr, nullptr}, tx_read_ev[2] = {nullptr, nullptr};
+  bool tx_q_armed = false, tx_out_armed[2] = {false, false}, tx_read_armed[2] = {false, false};
+  unsigned tx_pushes = 0;
   uint8_t *tx_pin[2] = {nullptr, nullptr};   // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), two in turn
   int tx_pin_cap[2] = {0, 0};
   bool tx_stage_held = false;        // the current set has been handed out and not yet added
-  DevBuf<int16_t> tx_opid;
-  DevBuf<uint8_t> tx_ofq, tx_bits, tx_fq;
-  DevBuf<float> tx_gain;
+  DevBuf<uint8_t> tx_bits[2], tx_fq[2];
+  DevBuf<float> tx_gain[2];
   // host staging of an add call: two sets in turn, each guarded by an event recorded behind its uploads -- a set is refilled only
   // when the copies that read it have run (the library does not rely on pageable hipMemcpyAsync being synchronous)
   std::vector<uint8_t> h_fmod;
@@ -246,12 +250,15 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
     if (g->tx_fm_ev) (void)hipEventDestroy(g->tx_fm_ev);
     if (g->tx_up) { (void)hipStreamSynchronize(g->tx_up); (void)hipStreamDestroy(g->tx_up); }
-    if (g->tx_in) { (void)hipStreamSynchronize(g->tx_in); (void)hipStreamDestroy(g->tx_in); }
-    for (int k = 0; k < 2; k++) { g->tx_arfcn[k].release(); g->tx_dgram[k].release(); if (g->tx_read_ev[k]) (void)hipEventDestroy(g->tx_read_ev[k]); }
-    if (g->tx_ingest_ev) (void)hipEventDestroy(g->tx_ingest_ev);
-    if (g->tx_gather_ev) (void)hipEventDestroy(g->tx_gather_ev);
+    if (g->tx_q) { (void)hipStreamSynchronize(g->tx_q); (void)hipStreamDestroy(g->tx_q); }
+    for (int k = 0; k < 2; k++) {
+      g->tx_arfcn[k].release(); g->tx_dgram[k].release();
+      if (g->tx_read_ev[k]) (void)hipEventDestroy(g->tx_read_ev[k]);
+      if (g->tx_out_ev[k]) (void)hipEventDestroy(g->tx_out_ev[k]);
+    }
+    if (g->tx_q_ev) (void)hipEventDestroy(g->tx_q_ev);
     for (int k = 0; k < 2; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
-    g->tx_opid.release(); g->tx_ofq.release(); g->tx_bits.release(); g->tx_fq.release(); g->tx_gain.release();
+    for (int k = 0; k < 2; k++) { g->tx_bits[k].release(); g->tx_fq[k].release(); g->tx_gain[k].release(); }
   }
   trx_ctx_release(g->c);
   delete g;
@@ -720,9 +727,25 @@ int tx_seal_set(trxsig_trxgroup *g, int k, hipStream_t st) {
   g->tx_ev_armed[k] = true;
   return TRXSIG_OK;
 }
-// the context's stream behind the last ingest (which ran on the add calls' stream)
+// the queues' stream (created on first use, with the events), and the context's stream behind everything it has been given
+int tx_streams(trxsig_trxgroup *g) {
+  if (g->tx_q) return TRXSIG_OK;
+  G_HIP(g, hipStreamCreateWithFlags(&g->tx_up, hipStreamNonBlocking));
+  G_HIP(g, hipStreamCreateWithFlags(&g->tx_q, hipStreamNonBlocking));
+  G_HIP(g, hipEventCreateWithFlags(&g->tx_q_ev, hipEventDisableTiming));
+  for (int j = 0; j < 2; j++) {
+    G_HIP(g, hipEventCreateWithFlags(&g->tx_read_ev[j], hipEventDisableTiming));
+    G_HIP(g, hipEventCreateWithFlags(&g->tx_out_ev[j], hipEventDisableTiming));
+  }
+  return TRXSIG_OK;
+}
+int tx_q_mark(trxsig_trxgroup *g) {                         // "the queues' stream has run up to here"
+  G_HIP(g, hipEventRecord(g->tx_q_ev, g->tx_q));
+  g->tx_q_armed = true;
+  return TRXSIG_OK;
+}
 int tx_join(trxsig_trxgroup *g, hipStream_t st) {
-  if (g->tx_ingest_armed) { G_HIP(g, hipStreamWaitEvent(st, g->tx_ingest_ev, 0)); g->tx_ingest_armed = false; }
+  if (g->tx_q_armed) { G_HIP(g, hipStreamWaitEvent(st, g->tx_q_ev, 0)); g->tx_q_armed = false; }
   return TRXSIG_OK;
 }
 // fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT (rare: its own host staging vector, waited for before it is refilled)
@@ -789,16 +812,8 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
     if (i == 0) ref_fn = (int)fn;
     far |= !trxq_pk_ok((int32_t)fn, ref_fn);
   }
-  hipStream_t st = (hipStream_t)trxsig_get_stream(c);
-  G_LIB(tx_sync_modulus(g, st));
-  if (!g->tx_up) {
-    G_HIP(g, hipStreamCreateWithFlags(&g->tx_up, hipStreamNonBlocking));
-    G_HIP(g, hipStreamCreateWithFlags(&g->tx_in, hipStreamNonBlocking));
-    G_HIP(g, hipEventCreateWithFlags(&g->tx_ingest_ev, hipEventDisableTiming));
-    G_HIP(g, hipEventCreateWithFlags(&g->tx_gather_ev, hipEventDisableTiming));
-    for (int j = 0; j < 2; j++) G_HIP(g, hipEventCreateWithFlags(&g->tx_read_ev[j], hipEventDisableTiming));
-  }
-  hipStream_t up = g->tx_up, in = g->tx_in;
+  G_LIB(tx_streams(g));                                     // (the filler moduli are the walk's business: trxsig_trxgroup_push uploads them)
+  hipStream_t up = g->tx_up, q = g->tx_q;
   // (set k's device arrays are free: tx_take_set has waited for the ingest that read them two calls ago)
   G_HIP(g, g->tx_dgram[k].need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES + 8, up));   // (+ 8: the ingest kernel reads whole aligned words round the last payload)
   G_HIP(g, g->tx_arfcn[k].need((size_t)n, up));
@@ -806,13 +821,11 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   G_HIP(g, hipMemcpyAsync(g->tx_dgram[k].p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, up));
   G_LIB(tx_seal_set(g, k, up));                             // (the pinned set is the DMA's until this event has passed: the next staging call takes the other)
   g->tx_stage_held = false;
-  G_HIP(g, hipStreamWaitEvent(in, g->tx_ev[k], 0));
-  if (g->tx_gather_armed) { G_HIP(g, hipStreamWaitEvent(in, g->tx_gather_ev, 0)); g->tx_gather_armed = false; }
-  G_HIP(g, trx_launch_group_tx_ingest(in, g->tx, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->gain_tab, ref_fn, far));
-  G_HIP(g, hipEventRecord(g->tx_ingest_ev, in));
-  g->tx_ingest_armed = true;
-  G_HIP(g, hipEventRecord(g->tx_read_ev[k], in));
+  G_HIP(g, hipStreamWaitEvent(q, g->tx_ev[k], 0));
+  G_HIP(g, trx_launch_group_tx_ingest(q, g->tx, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->gain_tab, ref_fn, far));
+  G_HIP(g, hipEventRecord(g->tx_read_ev[k], q));
   g->tx_read_armed[k] = true;
+  G_LIB(tx_q_mark(g));
   return TRXSIG_OK;
 }
 
@@ -851,16 +864,25 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
   Guard gd(trxsig_device(c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(c);
   G_LIB(tx_setup(g));
-  G_LIB(tx_sync_modulus(g, st));
+  G_LIB(tx_streams(g));
+  hipStream_t q = g->tx_q;
+  // what the context's stream has been given so far is what may still read the output of the push before this one: the push after
+  // this one (same output set) waits for it
+  const int o = (int)(g->tx_pushes & 1u);
+  G_HIP(g, hipEventRecord(g->tx_out_ev[o ^ 1], st));
+  g->tx_out_armed[o ^ 1] = true;
+  if (g->tx_out_armed[o]) { G_HIP(g, hipStreamWaitEvent(q, g->tx_out_ev[o], 0)); g->tx_out_armed[o] = false; }
+  g->tx_pushes++;
+  G_LIB(tx_sync_modulus(g, q));
   const size_t cells = (size_t)n_slots * g->S;
-  G_HIP(g, g->tx_opid.need(cells, st)); G_HIP(g, g->tx_ofq.need(cells, st)); G_HIP(g, g->tx_bits.need(cells * 148, st));
-  G_HIP(g, g->tx_gain.need(cells, st)); G_HIP(g, g->tx_fq.need(cells, st));
-  G_LIB(tx_join(g, st));
-  G_HIP(g, trx_launch_group_tx_push(st, g->tx, fn, tn, n_slots, g->tx_opid.p, g->tx_ofq.p, g->tx_bits.p, g->tx_gain.p, g->tx_fq.p));
-  if (g->tx_gather_ev) { G_HIP(g, hipEventRecord(g->tx_gather_ev, st)); g->tx_gather_armed = true; }
-  if (d_bits) *d_bits = g->tx_bits.p;
-  if (d_gain) *d_gain = g->tx_gain.p;
-  if (d_from_queue) *d_from_queue = g->tx_fq.p;
+  G_HIP(g, g->tx_bits[o].need(cells * 148, q));
+  G_HIP(g, g->tx_gain[o].need(cells, q)); G_HIP(g, g->tx_fq[o].need(cells, q));
+  G_HIP(g, trx_launch_group_tx_push(q, g->tx, fn, tn, n_slots, g->tx_bits[o].p, g->tx_gain[o].p, g->tx_fq[o].p));
+  G_LIB(tx_q_mark(g));
+  G_LIB(tx_join(g, st));                                    // the caller reads the output on the context's stream
+  if (d_bits) *d_bits = g->tx_bits[o].p;
+  if (d_gain) *d_gain = g->tx_gain[o].p;
+  if (d_from_queue) *d_from_queue = g->tx_fq[o].p;
   return TRXSIG_OK;
 }
 
