@@ -502,6 +502,12 @@ class Config4:
                                 % (self.S // self.wide, self.wide, self.S, self.K, 864 * 8, form, self.tsc, NSOFT),
                     "streams_per_gpu": self.S, "wideband_streams_per_gpu": self.S // self.wide, "carriers": self.wide,
                     "chunks_per_step": self.K, "bursts_per_step_per_gpu": round(self.units_per_step(), 1),
+                    # the shared-filter form is NOT the form pinned on the reference's primitives (the per-carrier one is:
+                    # --per-carrier-channeliser); the CPU baseline beside this line runs the reference's exact per-carrier chain
+                    "approximate_form": bool(getattr(self, "shared", False)),
+                    "approximate_form_error": ("samples within 1e-4 of the signal's scale of the per-carrier form's, soft bits within 1e-4, "
+                                               "detection flags and hard bits equal (tests/test_gpu_channeliser.py::"
+                                               "test_shared_filter_form_against_the_per_carrier_form)") if getattr(self, "shared", False) else None,
                     "sps": self.sps, "parallelism": "stream-sharded x%d, one stream set per rank (no data-path collective)" % world}
         return {"workload": "config4: %d ARFCN streams/GPU x %d chunks of 864 int16 I/Q samples per step (400 kS/s), unUSRPify + "
                             "polyphase resample 260:96 (961-tap Kaiser LPF) + 157/156/156/156 slicing + TSC %d detect (thr 3.0) + demod to "
