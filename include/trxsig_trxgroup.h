@@ -121,6 +121,12 @@ int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on);
  * least `rows` (slot, ARFCN) rows; 0 = never (the default since round 4: a long call's replay is parallel in time and one stream
  * is faster).  An implementation choice for A/B measurements and for pipelined mode; same values either way. */
 int trxsig_trxgroup_set_beside_rows(trxsig_trxgroup *g, int rows);
+/* Which pulls on a fused front end (trxsig_trxgroup_pull_fused) detect their access bursts BESIDE their normal bursts: those with at
+ * least `rows` rows that hold both kinds (the access-burst class goes first on the context's stream, the normal-burst classes
+ * follow on the group's side stream and are joined before the state machine; two cross-stream hops of ~10 us are what it costs).
+ * 0 = never, the default: measured slower than the classes in series (DESIGN "What else was tried").  An implementation choice for
+ * A/B measurements; same values either way (tested). */
+int trxsig_trxgroup_set_split_rows(trxsig_trxgroup *g, int rows);
 /* the context's stream waits for every replay still in flight on the side stream (no host wait) */
 int trxsig_trxgroup_sync(trxsig_trxgroup *g);
 /* mEnergyThreshold of one ARFCN now (synchronises) */

@@ -695,6 +695,7 @@ class TrxGroup:
         L.trxsig_trxgroup_energy_threshold.argtypes = [vp, i32, C.POINTER(C.c_double)]
         L.trxsig_trxgroup_set_pipelined.argtypes = [vp, i32]
         L.trxsig_trxgroup_set_beside_rows.argtypes = [vp, i32]
+        L.trxsig_trxgroup_set_split_rows.argtypes = [vp, i32]
         L.trxsig_trxgroup_sync.argtypes = [vp]
         L.trxsig_trxgroup_add_bursts.argtypes = [vp, vp, vp, i32]
         L.trxsig_trxgroup_tx_staging.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
@@ -819,6 +820,10 @@ class TrxGroup:
     def set_beside_rows(self, rows):
         """Pulls with at least `rows` rows replay the state machine on the group's side stream (0 = never, the default)."""
         self._chk(self.L.trxsig_trxgroup_set_beside_rows(self.h, int(rows)), "trxsig_trxgroup_set_beside_rows")
+
+    def set_split_rows(self, rows):
+        """Fused pulls with at least `rows` rows and both kinds of burst detect the access bursts beside the normal ones (0 = never)."""
+        self._chk(self.L.trxsig_trxgroup_set_split_rows(self.h, int(rows)), "trxsig_trxgroup_set_split_rows")
 
     def sync(self):
         self._chk(self.L.trxsig_trxgroup_sync(self.h), "trxsig_trxgroup_sync")

@@ -65,6 +65,8 @@ struct trxsig_ctx {
   // workspace (device)
   int cap_bursts = 0;
   trx_c32 *d_rec = nullptr;          // [slots][cap_bursts] detect -> peak records
+  trx_c32 *d_rec2 = nullptr;         // a second one (cap2_bursts): the Transceiver group's access-burst class beside its normal-burst classes
+  int cap2_bursts = 0;
   // equaliser scratch: toa_eq [B], w [B*7], b [B*5], xd [B*160]
   int eq_cap = 0;
   char *d_eq = nullptr;
@@ -186,6 +188,18 @@ int ensure_ws(trxsig_ctx *c, int B) {
   if (rach > per_burst) per_burst = rach;
   HIPCHK(c, hipMalloc((void **)&c->d_rec, per_burst * cap));
   c->cap_bursts = cap;
+  return TRXSIG_OK;
+}
+
+int ensure_ws2(trxsig_ctx *c, int B) {
+  if (B <= c->cap2_bursts) return TRXSIG_OK;
+  const int cap = (B + 255) & ~255;
+  if (c->d_rec2) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(c->d_rec2)); c->d_rec2 = nullptr; c->cap2_bursts = 0; }
+  size_t per_burst = sizeof(trx_c32) * (size_t)trx_rec_slots(c->sps);
+  const size_t rach = sizeof(float) * (size_t)trx_rach_rec_floats(c->sps);
+  if (rach > per_burst) per_burst = rach;
+  HIPCHK(c, hipMalloc((void **)&c->d_rec2, per_burst * cap));
+  c->cap2_bursts = cap;
   return TRXSIG_OK;
 }
 
@@ -402,6 +416,7 @@ static void destroy_now(trxsig_ctx *c) {
     DeviceGuard g(c->device);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_rec2) (void)hipFree(c->d_rec2);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_eq) (void)hipFree(c->d_eq);
     if (c->d_det) (void)hipFree(c->d_det);
@@ -578,7 +593,8 @@ int trxsig_detect_demod_normal_batch(trxsig_ctx *c, const trxsig_c32 *d_samples,
 // the normal-burst leg on bursts that are computed from the raw int16 stream (trxsig_rxfe_push_detect_demod_normal,
 // trxsig_frontend.cpp): same kernels, same scratch, no complex float32 stream in HBM
 int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
-                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride) {
+                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride,
+                      hipStream_t on) {
   if (!c) return TRXSIG_EINVAL;
   if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
   if (tsc < 0 || tsc > 7 || nsoft < 0 || nsoft > 148 || soft_stride < nsoft || B < 0 ||
@@ -588,22 +604,23 @@ int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float 
   DeviceGuard g(c->device);
   int rc = ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
-  HIPCHK(c, trx_launch_rx_normal(c->stream, c->d_tables, c->h_tables, gen, B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts,
+  HIPCHK(c, trx_launch_rx_normal(on ? on : c->stream, c->d_tables, c->h_tables, gen, B, tsc, detect_thresh, energy_thresh, c->d_rec, c->cap_bursts,
                                  d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, d_soft, d_hard, nsoft, soft_stride, c->generic_taps, c->prof,
                                  c->soft_mode));
   return TRXSIG_OK;
 }
 int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
-                    uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr) {
+                    uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, int own_records) {
   if (!c) return TRXSIG_EINVAL;
   if (c->sps != 4) return fail(c, TRXSIG_EINVAL, "the fused receive front end needs sps == 4");
   if (B < 0 || (B > 0 && (!d_len || !d_flags || !d_amp || !d_toa))) return fail(c, TRXSIG_EINVAL, "trx_ctx_rx_rach: bad argument");
   if (B == 0) return TRXSIG_OK;
   DeviceGuard g(c->device);
-  int rc = ensure_ws(c, B);
+  int rc = own_records ? ensure_ws2(c, B) : ensure_ws(c, B);
   if (rc != TRXSIG_OK) return rc;
-  HIPCHK(c, trx_launch_rx_rach(c->stream, c->d_tables, gen, d_len, B, detect_thresh, energy_thresh, c->rach_amp_err, (float *)c->d_rec,
-                               c->cap_bursts, d_flags, (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
+  HIPCHK(c, trx_launch_rx_rach(c->stream, c->d_tables, gen, d_len, B, detect_thresh, energy_thresh, c->rach_amp_err,
+                               (float *)(own_records ? c->d_rec2 : c->d_rec), own_records ? c->cap2_bursts : c->cap_bursts, d_flags,
+                               (trx_c32 *)d_amp, d_toa, d_avgpwr, c->prof));
   return TRXSIG_OK;
 }
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,

@@ -50,12 +50,15 @@ struct TrxPinRing {
 };
 TrxProfiler *trx_ctx_profiler(trxsig_ctx *c);
 // the normal-burst leg on bursts computed from the raw int16 stream (trxsig_rxfe_push_detect_demod_normal)
+// (on != nullptr: launched on that stream instead of the context's; the caller orders it against the context's stream)
 int trx_ctx_rx_normal(trxsig_ctx *c, const TrxRxGen &gen, int B, int tsc, float detect_thresh, float energy_thresh, uint8_t *d_flags,
-                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride);
+                      trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, float *d_soft, uint8_t *d_hard, int nsoft, int soft_stride,
+                      hipStream_t on = nullptr);
 // ... detectRACHBurst (d_len[b] = the burst's length as the front end cuts it) and demodulateBurst with caller-supplied
 // amplitude / TOA for the bursts whose d_enable[b] != 0, on such bursts
+// (own_records != 0: the detect -> peak records go to a scratch of the call's own, so that it may run beside trx_ctx_rx_normal)
 int trx_ctx_rx_rach(trxsig_ctx *c, const TrxRxGen &gen, const int32_t *d_len, int B, float detect_thresh, float energy_thresh,
-                    uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr);
+                    uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa, float *d_avgpwr, int own_records = 0);
 int trx_ctx_rx_demod(trxsig_ctx *c, const TrxRxGen &gen, int B, const trxsig_c32 *d_amp, const float *d_toa, const uint8_t *d_enable,
                      int need_mask, float *d_soft, int nsoft, int soft_stride);
 int trx_ctx_demod_masked(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,

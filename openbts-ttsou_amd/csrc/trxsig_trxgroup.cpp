@@ -90,6 +90,7 @@ struct trxsig_trxgroup {
   } wk[2];
   int cur = 0;                                              // the set of the last pull
   bool pipelined = false;
+  int split_rows = 0;                // trxsig_trxgroup_set_split_rows: fused pulls with at least this many rows detect their access bursts beside the normal bursts (0, the default: never)
   int beside_rows = 0x7fffffff;      // trxsig_trxgroup_set_beside_rows: calls with at least this many rows replay on the side stream (kBesideRows)
   DevBuf<trx_c32> w_tab, b_tab, in;
   DevBuf<float> chan_off;
@@ -396,7 +397,38 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
     hipStream_t s = nullptr;
     ~SideGuard() { if (s) (void)hipStreamSynchronize(s); }
   } side_guard;
-  for (int k = 0; k < TRXG_NCLASS; k++) {
+  // Selectable (trxsig_trxgroup_set_split_rows; OFF by default): a fused pull with both kinds of burst in it detects them side by side --
+  // the access-burst class goes FIRST on the context's stream, so that its ~500 waves are resident before the correlator fills the
+  // machine, the normal-burst classes follow on the side stream and are joined before the state machine.  Measured (round 5, config 4):
+  // 195 us per step against 191 in series -- the 39 us of access-burst kernels are hidden, but two cross-stream hops (~20 us) and
+  // the kernels slowing each other (correlator 43 -> 46, access-burst chain 40 -> 51) take it back.  (The other way round -- the access
+  // bursts on the side stream, arriving behind a correlator that has filled every SIMD -- loses more: they run at half speed and
+  // become the critical path, profiles/r05_config4_ab_rach_beside.txt.)
+  const bool split = src.gen && g->split_rows > 0 && n_rows >= g->split_rows && count[TRXG_CLASS_RACH] > 0 && n_tsc > 0;
+  if (split) {
+    G_HIP(g, hipEventRecord(g->ev_fork, st));
+    G_HIP(g, hipStreamWaitEvent(g->side, g->ev_fork, 0));
+    side_guard.s = g->side;
+    {
+      const int k = TRXG_CLASS_RACH, b0 = base[k];
+      TrxRxGen gen = *src.gen;
+      gen.sel = W.off.p + b0;
+      G_LIB(trx_ctx_rx_rach(c, gen, W.len.p + b0, count[k], 5.0f, -1.0f, W.flags.p + b0, (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0,
+                            W.avgpwr.p + b0, 1));
+    }
+    for (int k = 0; k < TRXG_CLASS_RACH; k++) {
+      if (!count[k]) continue;
+      const int b0 = base[k];
+      TrxRxGen gen = *src.gen;
+      gen.sel = W.off.p + b0;
+      G_LIB(trx_ctx_rx_normal(c, gen, count[k], k, 3.0f, -1.0f, W.flags.p + b0, (trxsig_c32 *)W.amp.p + b0, W.toa.p + b0, W.avgpwr.p + b0,
+                              nullptr, nullptr, 0, 0, g->side));
+    }
+    G_HIP(g, hipEventRecord(g->ev_join, g->side));
+    G_HIP(g, hipStreamWaitEvent(st, g->ev_join, 0));
+    side_guard.s = nullptr;
+  }
+  for (int k = 0; k < TRXG_NCLASS && !split; k++) {
     if (!count[k]) continue;
     const int b0 = base[k];
     if (src.gen) {                                          // the detectors compute their samples from the raw stream; off = the selection
@@ -628,6 +660,13 @@ int trxsig_trxgroup_set_pipelined(trxsig_trxgroup *g, int on) {
   Guard gd(trxsig_device(g->c));
   G_LIB(join_side(g, (hipStream_t)trxsig_get_stream(g->c)));
   g->pipelined = on != 0;
+  return TRXSIG_OK;
+}
+
+int trxsig_trxgroup_set_split_rows(trxsig_trxgroup *g, int rows) {
+  if (!g) return TRXSIG_EINVAL;
+  if (rows < 0) return trx_ctx_fail(g->c, TRXSIG_EINVAL, "trxsig_trxgroup_set_split_rows: negative threshold", hipSuccess);
+  g->split_rows = rows;
   return TRXSIG_OK;
 }
 

@@ -467,9 +467,13 @@ def test_pipelined_mode_on_the_fused_front_end(pkg):
     iq = torch.stack([lo.imag, lo.real], dim=2).round().clamp(-32768, 32767).to(torch.int16).contiguous()
     lpf = synth.design_lpf(961, 65 * sps)
     outs = []
-    for piped in (False, True):
+    for piped, split in ((False, False), (True, False), (False, True)):
+        # (third pass: trxsig_trxgroup_set_split_rows -- the access-burst class first and BESIDE the normal-burst classes, which run on the
+        #  side stream, instead of in series with them)
         ctx = pkg.TrxSig(sps, 0); ctx.use_torch_stream()
         g = pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD, start=(0, 0))
+        if split:
+            g.set_split_rows(16384)
         g.set_beside_rows(24576)                                         # (the side-stream arrangement, no longer the default)
         fe = RxFrontEnd(ctx, S, lpf, max_chunks=K)
         for a in range(S):
@@ -495,12 +499,13 @@ def test_pipelined_mode_on_the_fused_front_end(pkg):
         thr = np.array([g.energy_threshold(a) for a in range(S)])
         outs.append((got, thr))
         g.close(); fe.close() if hasattr(fe, "close") else None; ctx.close()
-    (ga, ta), (gb, tb) = outs
-    assert np.array_equal(ta, tb)
-    for ra, rb in zip(ga, gb):
+    (ga, ta), (gb, tb), (gc, tc) = outs
+    assert np.array_equal(ta, tb) and np.array_equal(ta, tc)
+    for ra, rb, rc in zip(ga, gb, gc):
         assert ra["valid"].sum() > 1000
         for key in ra:
             assert np.array_equal(ra[key], rb[key], equal_nan=True), key
+            assert np.array_equal(ra[key], rc[key], equal_nan=True), key
 
 
 def test_group_on_a_front_end_at_one_sample_per_symbol(pkg, golden):
