@@ -152,15 +152,20 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
  * datagrams: the host only checks the headers (the refusal rule above), the block goes up in one DMA as it arrived, and parsing
  * (TN, big-endian FN, RSSI -> pow(10, -RSSI/10) with the integer division), the per-ARFCN sort that keeps the arrival order, the
  * queue insertion and the payload copies are ONE kernel (k_group_tx_ingest).  Two blocks alternate: after add_staged the
- * pointers are the DMA's; ask again for the next batch (the call waits, if it must, for the upload that last used that block).
- * trxsig_trxgroup_add_bursts is this with a copy into the block first. */
+ * pointers are the DMA's; ask again for the next batch (the call waits, if it must, for the upload and the ingest that last used
+ * that block's set: that is where a host is held back when the device is more than a batch behind).
+ * trxsig_trxgroup_add_bursts is this with a copy into the block first.
+ * Streams: the uploads and the queue's kernels (this call's ingest, trxsig_trxgroup_push's walk) run on streams of the group's
+ * own, in call order, beside whatever the context's stream is doing (the transmit back end of the batch before); everything
+ * that hands results to the caller (trxsig_trxgroup_push, _push_txbe, _tx_queue_size) orders them on the context's stream. */
 int trxsig_trxgroup_tx_staging(trxsig_trxgroup *g, int n_max, uint8_t **h_datagrams, int32_t **h_arfcn);
 int trxsig_trxgroup_add_staged(trxsig_trxgroup *g, int n);
 
 /* pushRadioVector(nowTime) for n_slots consecutive timeslots from (fn, tn), every ARFCN, in time order per ARFCN: stale bursts
  * (earlier than the slot) move to the filler table at THEIR time's entry, a burst for exactly the slot replaces the slot's
- * filler entry and goes out, otherwise the filler entry goes out.  What goes out, device resident, owned by the group, valid
- * until its next push: *d_bits [n_arfcn][n_slots][148] (one bit per byte), *d_gain [n_arfcn][n_slots], *d_from_queue
+ * filler entry and goes out, otherwise the filler entry goes out.  What goes out, device resident, owned by the group, ordered on
+ * the context's stream, valid until its next push (work enqueued on the context's stream BEFORE that push may still read it: two
+ * output sets alternate): *d_bits [n_arfcn][n_slots][148] (one bit per byte), *d_gain [n_arfcn][n_slots], *d_from_queue
  * [n_arfcn][n_slots] (1: from the queue, 0: filler) -- the layout trxsig_txbe_push_bursts / trxsig_modulate_batch take. */
 int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const uint8_t **d_bits, const float **d_gain,
                          const uint8_t **d_from_queue);
