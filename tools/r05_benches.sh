@@ -13,7 +13,7 @@ except Exception as e:
     print("$name: no line", e)
 PY
 }
-run normal_driverstyle --steps 20 --warmup 3
+run normal_driverstyle --steps 20 --warmup 5
 run normal
 run normal_exact --soft-mode exact
 run rach --workload rach
