@@ -95,12 +95,17 @@ struct TrxGroupTx {
   uint32_t *status;                // [S] bit 0: a burst was dropped because the queue / pool was full
 };
 // n new bursts as they arrived: dgram n x 154 bytes (TN, FN big-endian, RSSI, 148 bits one per byte), arfcn[n] the ARFCN each came
-// for (all checked by the host); gain_tab26[q + 12] = (float)pow(10, q), q = -12 .. 13.  Parsing, the per-ARFCN sort (arrival order
-// kept), queue insertion and the payload copies are one launch.  ref_fn: a frame number near the datagrams' (the first one's); far != 0:
-// some datagram lies 2^17 frames or more from it (trxsig_txq_lds.h's packed entries cannot say it: the kernel works on the arrays in
-// memory -- same results, slower).
-hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn,
-                                      const float *gain_tab26, int ref_fn, int far);
+// for (all checked by the host); gain_tab26[q + 12] = (float)pow(10, q), q = -12 .. 13.  Two launches: ARRIVE -- parsing and the
+// per-ARFCN sort (arrival order kept), nothing of the queues' state in it, so it may run on another stream than the queues' --
+// leaves its lists in a_lf / a_lk (trx_group_tx_arrive_ints(S, n, &t) ints each) and a_tot (t ints); INGEST enters them in the
+// queues and copies the payloads.  ref_fn: a frame number near the datagrams' (the first one's); far != 0: some datagram lies
+// 2^17 frames or more from it (trxsig_txq_lds.h's packed entries cannot say it: the kernel works on the arrays in memory -- same
+// results, slower).
+size_t trx_group_tx_arrive_ints(int S, int n, size_t *tot_ints);
+hipError_t trx_launch_group_tx_arrive(hipStream_t st, int S, int n, const uint8_t *dgram, const int32_t *arfcn, int32_t *a_lf, int32_t *a_lk,
+                                      int32_t *a_tot);
+hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *a_lf, const int32_t *a_lk,
+                                      const int32_t *a_tot, const float *gain_tab26, int ref_fn, int far);
 // pushRadioVector for n_slots timeslots from (fn0, tn0) on every ARFCN: bits_out [S][n_slots][148], gain_out [S][n_slots], fq_out
 // [S][n_slots] (1 = the burst came from the queue)
 hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, uint8_t *bits_out, float *gain_out,

@@ -1,8 +1,9 @@
 // trxsig_grouptx.hip -- the TRANSMIT half of the Transceiver group (include/trxsig_trxgroup.h): addRadioVector /
 // pushRadioVector (Transceiver/Transceiver.cpp:100-113, 138-181) for S ARFCNs with the priority queue, the stale-burst dump
 // and the filler table [FN % modulus][TN] on the device.
-//   k_group_tx_ingest : driveTransmitPriorityQueue's parsing (:596-620) + addRadioVector (:100-113) ON THE DEVICE (round 5) from the
-//                       raw 154-byte datagrams and their ARFCN ids, as they arrived: a workgroup owns sixteen ARFCNs, finds
+//   k_group_tx_arrive + k_group_tx_ingest : driveTransmitPriorityQueue's parsing (:596-620) + addRadioVector (:100-113) ON THE DEVICE
+//                       (round 5) from the raw 154-byte datagrams and their ARFCN ids, as they arrived -- the first kernel everything that
+//                       needs no queue state (it runs on the uploads' stream), the second the rest: a workgroup owns sixteen ARFCNs, finds
 //                       its datagrams (a stable counting sort by wave ballots: arrival order is kept inside an ARFCN),
 //                       parses TN / big-endian FN / RSSI, and a lane per ARFCN enters them in its queue -- the queue
 //                       (trxsig_txq.h: std::priority_queue's moves) sits in LDS for the duration, the payload slots to hand
@@ -73,29 +74,24 @@ __device__ __forceinline__ void tx_queues_store(const TrxGroupTx &x, int a0, con
     }
 }
 
+// ---- the arrival half of an add call (no queue state in it: it runs on the uploads' stream, beside the previous batch's walk) ----
 // dgram: n x 154 bytes as they arrived ([0] TN, [1..4] FN big-endian, [5] RSSI, [6..153] one bit per byte); arfcn: n ids (the host
-// has checked every header: a call with a bad one queues nothing).  ref: the frame the packed queue entries are relative to (the
-// first datagram's); far != 0: the host saw a datagram outside the packed window (every workgroup takes the slow path).
-__global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn,
-                                                          TxGainTab gt, int ref, int far_in) {
-  __shared__ TrxqPk q[kTxA][kTxRow];
-  __shared__ int32_t lf[kTxWin + 1], lk[kTxWin + 1];        // this round's entries, ARFCN by ARFCN: frame number, key
-  __shared__ int16_t fs[kTxWin + 2];                            // the payload slots those entries are handed, fetched ahead
+// has checked every header: a call with a bad one queues nothing).  A workgroup owns sixteen ARFCNs; per round of 8,192 datagrams it
+// leaves, in memory: tot[16] (how many datagrams each of its ARFCNs got) and the round's entries ARFCN by ARFCN, arrival order kept
+// inside an ARFCN -- lf (frame number), lk (tn | gain index << 3 | local ARFCN << 8 | position in the round << 12).
+struct TxArrive {
+  int32_t *lf, *lk;                                         // [workgroups][n_pad]
+  int32_t *tot;                                             // [workgroups][rounds][16]
+  int n_pad, rounds;                                        // n_pad = rounds * kTxWin
+};
+__global__ __launch_bounds__(1024) void k_group_tx_arrive(int S, int n, const uint8_t *__restrict__ dgram, const int32_t *__restrict__ arfcn, TxArrive ar) {
   __shared__ int32_t cnt[kTxChunks][kTxA];
-  __shared__ int nq[kTxA], nf[kTxA], tot[kTxA], acc[kTxA], lbase[kTxA + 1], st_[kTxA], far;
+  __shared__ int tot[kTxA], lbase[kTxA + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a0 = blockIdx.x * kTxA;
-  TX_STAMP(0, 0);
-  if (tid < kTxA) {
-    const bool mine = a0 + tid < x.S;
-    nq[tid] = mine ? x.q_n[a0 + tid] : 0;
-    nf[tid] = mine ? x.free_n[a0 + tid] : 0;
-    st_[tid] = 0;
-  }
-  if (tid == 0) far = far_in;
-  __syncthreads();
-  tx_queues_load<kTxA>(x, a0, q, nq, ref, &far);
-  for (int w0 = 0; w0 < n; w0 += kTxWin) {                  // rounds of 8,192 datagrams (LDS is sized for one)
+  int32_t *const olf = ar.lf + (size_t)blockIdx.x * ar.n_pad, *const olk = ar.lk + (size_t)blockIdx.x * ar.n_pad;
+  int round = 0;
+  for (int w0 = 0; w0 < n; w0 += kTxWin, round++) {         // rounds of 8,192 datagrams (the ingest kernel's LDS is sized for one)
     // ---- which of this round's datagrams are ours, and where each goes: counts per (chunk, ARFCN), ranks inside a chunk ----
     constexpr int CPW = kTxChunks / 16;                     // chunks per wave
     int my_i[CPW], my_k[CPW], my_rank[CPW];
@@ -118,7 +114,6 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       my_i[cc] = i; my_k[cc] = valid ? local : -1; my_rank[cc] = rank;
     }
     __syncthreads();
-    TX_STAMP(0, 1);
     {                                                       // exclusive scan over the chunks, per ARFCN: wave k scans ARFCN k's column
       static_assert(kTxChunks % 64 == 0 && kTxA == 16, "a wave per ARFCN, whole waves of chunks");
       const int k = wave;
@@ -136,10 +131,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       }
       if (lane == 0) {
         tot[k] = carry;
-        // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
-        // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
-        const int room = min(x.qcap - nq[k], nf[k]);
-        acc[k] = carry < room ? carry : (room > 0 ? room : 0);
+        ar.tot[((size_t)blockIdx.x * ar.rounds + round) * kTxA + k] = a0 + k < S ? carry : 0;
       }
     }
     __syncthreads();
@@ -149,8 +141,7 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       lbase[kTxA] = run;
     }
     __syncthreads();
-    TX_STAMP(0, 2);
-    // ---- every datagram's header into its place (arrival order inside an ARFCN); the payload slots fetched ahead ----
+    // ---- every datagram's header into its place (arrival order inside an ARFCN) ----
 #pragma unroll
     for (int cc = 0; cc < CPW; cc++) {
       if (my_k[cc] < 0) continue;
@@ -162,10 +153,56 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       const unsigned fn = ((h0 >> 8) << 24) | ((h1 & 255) << 16) | ((h1 >> 8) << 8) | (h2 & 255);
       const int RSSI = (int)(int8_t)(h2 >> 8);              // `int RSSI = (int) buffer[5]` on a char buffer (:617)
       const int gi = -RSSI / 10 + 12;                       // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division
-      lf[lp] = (int32_t)fn;
-      lk[lp] = (tn & 7) | (gi << 3) | (k << 8) | ((my_i[cc] - w0) << 12);   // (13 bits of position: a round is 8,192 datagrams)
+      olf[w0 + lp] = (int32_t)fn;
+      olk[w0 + lp] = (tn & 7) | (gi << 3) | (k << 8) | ((my_i[cc] - w0) << 12);   // (13 bits of position: a round is 8,192 datagrams)
     }
-    {
+    __syncthreads();                                        // cnt / tot / lbase are the next round's
+  }
+}
+
+// ---- the queue half (the queues' stream): addRadioVector for what k_group_tx_arrive sorted, the payloads to their slots.
+// ref: the frame the packed queue entries are relative to (the first datagram's); far != 0: the host saw a datagram outside the packed
+// window (every workgroup takes the slow path).
+__global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, TxArrive ar,
+                                                          TxGainTab gt, int ref, int far_in) {
+  __shared__ TrxqPk q[kTxA][kTxRow];
+  __shared__ int32_t lf[kTxWin + 1], lk[kTxWin + 1];        // this round's entries, ARFCN by ARFCN: frame number, key
+  __shared__ int16_t fs[kTxWin + 2];                        // the payload slots those entries are handed, fetched ahead
+  __shared__ int nq[kTxA], nf[kTxA], tot[kTxA], acc[kTxA], lbase[kTxA + 1], st_[kTxA], far;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a0 = blockIdx.x * kTxA;
+  const int32_t *const ilf = ar.lf + (size_t)blockIdx.x * ar.n_pad, *const ilk = ar.lk + (size_t)blockIdx.x * ar.n_pad;
+  TX_STAMP(0, 0);
+  if (tid < kTxA) {
+    const bool mine = a0 + tid < x.S;
+    nq[tid] = mine ? x.q_n[a0 + tid] : 0;
+    nf[tid] = mine ? x.free_n[a0 + tid] : 0;
+    st_[tid] = 0;
+  }
+  if (tid == 0) far = far_in;
+  __syncthreads();
+  tx_queues_load<kTxA>(x, a0, q, nq, ref, &far);
+  int round = 0;
+  for (int w0 = 0; w0 < n; w0 += kTxWin, round++) {         // rounds of 8,192 datagrams (LDS is sized for one)
+    if (tid < kTxA) {
+      const int k = tid, t = ar.tot[((size_t)blockIdx.x * ar.rounds + round) * kTxA + k];
+      tot[k] = t;
+      // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
+      // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
+      const int room = min(x.qcap - nq[k], nf[k]);
+      acc[k] = t < room ? t : (room > 0 ? room : 0);
+    }
+    __syncthreads();
+    TX_STAMP(0, 1);
+    if (tid == 0) {
+      int run = 0;
+      for (int k = 0; k < kTxA; k++) { lbase[k] = run; run += tot[k]; }
+      lbase[kTxA] = run;
+    }
+    __syncthreads();
+    TX_STAMP(0, 2);
+    for (int e = tid; e < lbase[kTxA]; e += 1024) { lf[e] = ilf[w0 + e]; lk[e] = ilk[w0 + e]; }
+    {                                                       // the payload slots fetched ahead
       const int k = tid & (kTxA - 1);
       if (a0 + k < x.S)
         for (int j = tid / kTxA; j < acc[k]; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf[k] - 1 - j) * x.S + a0 + k];
@@ -438,13 +475,35 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
 
 }  // namespace
 
-hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *arfcn, const float *gain_tab26,
-                                      int ref_fn, int far) {
+size_t trx_group_tx_arrive_ints(int S, int n, size_t *tot_ints) {
+  const size_t nblk = (size_t)(S + kTxA - 1) / kTxA, rounds = ((size_t)n + kTxWin - 1) / kTxWin;
+  if (tot_ints) *tot_ints = nblk * rounds * kTxA;
+  return nblk * rounds * kTxWin;
+}
+
+static TxArrive tx_arrive_args(int n, int32_t *a_lf, int32_t *a_lk, int32_t *a_tot) {
+  TxArrive ar;
+  ar.lf = a_lf; ar.lk = a_lk; ar.tot = a_tot;
+  ar.rounds = (n + kTxWin - 1) / kTxWin;
+  ar.n_pad = ar.rounds * kTxWin;
+  return ar;
+}
+
+hipError_t trx_launch_group_tx_arrive(hipStream_t st, int S, int n, const uint8_t *dgram, const int32_t *arfcn, int32_t *a_lf, int32_t *a_lk,
+                                      int32_t *a_tot) {
+  if (n <= 0) return hipSuccess;
+  k_group_tx_arrive<<<dim3((S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(S, n, dgram, arfcn, tx_arrive_args(n, a_lf, a_lk, a_tot));
+  return hipGetLastError();
+}
+
+hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *a_lf, const int32_t *a_lk,
+                                      const int32_t *a_tot, const float *gain_tab26, int ref_fn, int far) {
   if (n <= 0) return hipSuccess;
   if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;   // (the kernel's LDS copy of a queue, a packed entry's id field)
   TxGainTab gt;
   for (int q = 0; q < 26; q++) gt.v[q] = gain_tab26[q];
-  k_group_tx_ingest<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, n, dgram, arfcn, gt, ref_fn, far);
+  k_group_tx_ingest<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, n, dgram, tx_arrive_args(n, (int32_t *)a_lf, (int32_t *)a_lk, (int32_t *)a_tot), gt, ref_fn,
+                                                                          far);
   return hipGetLastError();
 }
 

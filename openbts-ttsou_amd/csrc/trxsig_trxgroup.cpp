@@ -115,7 +115,7 @@ struct trxsig_trxgroup {
   // one of TWO output sets in turn and waits for whatever the context's stream had been given when the push before it was called
   // (the output's contract: valid until the next push); a staging set is handed out again when its upload and the ingest that read
   // it have run (the host waits there: that is where it is held back when the device is more than a batch behind).
-  DevBuf<int32_t> tx_arfcn[2];
+  DevBuf<int32_t> tx_arfcn[2], tx_alf[2], tx_alk[2], tx_atot[2];   // (+ what k_group_tx_arrive leaves for k_group_tx_ingest, per set)
   DevBuf<uint8_t> tx_dgram[2];
   hipStream_t tx_up = nullptr, tx_q = nullptr;
   hipEvent_t tx_q_ev = nullptr, tx_out_ev[2] = {nullptr, nullptr}, tx_read_ev[2] = {nullptr, nullptr};
@@ -253,7 +253,7 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
     if (g->tx_up) { (void)hipStreamSynchronize(g->tx_up); (void)hipStreamDestroy(g->tx_up); }
     if (g->tx_q) { (void)hipStreamSynchronize(g->tx_q); (void)hipStreamDestroy(g->tx_q); }
     for (int k = 0; k < 2; k++) {
-      g->tx_arfcn[k].release(); g->tx_dgram[k].release();
+      g->tx_arfcn[k].release(); g->tx_dgram[k].release(); g->tx_alf[k].release(); g->tx_alk[k].release(); g->tx_atot[k].release();
       if (g->tx_read_ev[k]) (void)hipEventDestroy(g->tx_read_ev[k]);
       if (g->tx_out_ev[k]) (void)hipEventDestroy(g->tx_out_ev[k]);
     }
@@ -856,12 +856,17 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   // (set k's device arrays are free: tx_take_set has waited for the ingest that read them two calls ago)
   G_HIP(g, g->tx_dgram[k].need((size_t)n * TRXSIG_TX_DATAGRAM_BYTES + 8, up));   // (+ 8: the ingest kernel reads whole aligned words round the last payload)
   G_HIP(g, g->tx_arfcn[k].need((size_t)n, up));
+  size_t tot_ints = 0;
+  const size_t list_ints = trx_group_tx_arrive_ints(S, n, &tot_ints);
+  G_HIP(g, g->tx_alf[k].need(list_ints, up)); G_HIP(g, g->tx_alk[k].need(list_ints, up)); G_HIP(g, g->tx_atot[k].need(tot_ints, up));
   G_HIP(g, hipMemcpyAsync(g->tx_arfcn[k].p, h_arfcn, 4 * (size_t)n, hipMemcpyHostToDevice, up));
   G_HIP(g, hipMemcpyAsync(g->tx_dgram[k].p, h_d, (size_t)n * TRXSIG_TX_DATAGRAM_BYTES, hipMemcpyHostToDevice, up));
+  // the arrival half -- parse, sort by ARFCN -- needs nothing of the queues: it runs here, behind its upload, beside the previous batch's walk
+  G_HIP(g, trx_launch_group_tx_arrive(up, S, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p));
   G_LIB(tx_seal_set(g, k, up));                             // (the pinned set is the DMA's until this event has passed: the next staging call takes the other)
   g->tx_stage_held = false;
   G_HIP(g, hipStreamWaitEvent(q, g->tx_ev[k], 0));
-  G_HIP(g, trx_launch_group_tx_ingest(q, g->tx, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->gain_tab, ref_fn, far));
+  G_HIP(g, trx_launch_group_tx_ingest(q, g->tx, n, g->tx_dgram[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p, g->gain_tab, ref_fn, far));
   G_HIP(g, hipEventRecord(g->tx_read_ev[k], q));
   g->tx_read_armed[k] = true;
   G_LIB(tx_q_mark(g));

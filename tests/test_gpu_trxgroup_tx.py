@@ -13,6 +13,8 @@ for one timestamp: the heap's shape decides which goes out), RSSI over the whole
 starting on any timeslot, a start just below the hyperframe wrap.  A third case keeps ~120 bursts queued per ARFCN (ties among
 them): every level of the LDS heap moves (csrc/trxsig_txq_lds.h: tx_heap_push / tx_heap_pop) is walked.  A fourth queues bursts a
 third of a hyperframe from the rest: the kernels' slow path (the queue's arrays in memory, trxsig_txq.h's moves)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -89,7 +91,7 @@ def test_group_transmit_half(pkg, golden, sps, S, frames, fn0, deep):
         ra = configure(lambda m: grp.control(a, m), a)
         assert ra == configure(lambda m: grp_b.control(a, m), a) == configure(objs[a].control, a) == configure(models[a].control, a)
         chan_used.append([models[a].chan_type[tn] != tm.NONE or (a + tn) % 5 == 0 for tn in range(8)])   # (some traffic on idle slots too)
-    rng = np.random.default_rng(2024 + sps)
+    rng = np.random.default_rng(2024 + sps + 1000 * int(os.environ.get("TRXSIG_TX_SOAK_SEED", "0")))   # (tools/r05_tx_soak.sh: more seeds)
     H = tm.HYPERFRAME
     n_slots_total = frames * 8
     pos = first = int(rng.integers(0, 8))                       # the first push starts on any timeslot
