@@ -151,7 +151,8 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
  * (*h_datagrams)[154 i], the socket's ARFCN into (*h_arfcn)[i], i < n_max -- and trxsig_trxgroup_add_staged(g, n) adds its first n
  * datagrams: the host only checks the headers (the refusal rule above), the block goes up in one DMA as it arrived, and parsing
  * (TN, big-endian FN, RSSI -> pow(10, -RSSI/10) with the integer division), the per-ARFCN sort that keeps the arrival order, the
- * queue insertion and the payload copies are ONE kernel (k_group_tx_ingest).  Two blocks alternate: after add_staged the
+ * queue insertion and the payload copies are two kernels (k_group_tx_arrive behind the upload, k_group_tx_ingest on the queues'
+ * stream).  Two blocks alternate: after add_staged the
  * pointers are the DMA's; ask again for the next batch (the call waits, if it must, for the upload and the ingest that last used
  * that block's set: that is where a host is held back when the device is more than a batch behind).
  * trxsig_trxgroup_add_bursts is this with a copy into the block first.
