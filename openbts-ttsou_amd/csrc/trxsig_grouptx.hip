@@ -1,21 +1,23 @@
 // trxsig_grouptx.hip -- the TRANSMIT half of the Transceiver group (include/trxsig_trxgroup.h): addRadioVector /
 // pushRadioVector (Transceiver/Transceiver.cpp:100-113, 138-181) for S ARFCNs with the priority queue, the stale-burst dump
 // and the filler table [FN % modulus][TN] on the device.
-//   k_group_tx_arrive + k_group_tx_ingest : driveTransmitPriorityQueue's parsing (:596-620) + addRadioVector (:100-113) ON THE DEVICE
-//                       (round 5) from the raw 154-byte datagrams and their ARFCN ids, as they arrived -- the first kernel everything that
-//                       needs no queue state (it runs on the uploads' stream), the second the rest: a workgroup owns sixteen ARFCNs, finds
-//                       its datagrams (a stable counting sort by wave ballots: arrival order is kept inside an ARFCN),
-//                       parses TN / big-endian FN / RSSI, and a lane per ARFCN enters them in its queue -- the queue
-//                       (trxsig_txq.h: std::priority_queue's moves) sits in LDS for the duration, the payload slots to hand
-//                       out are fetched ahead -- then every thread copies payload words (148 bits + gain) to the slots;
-//   k_group_tx_push   : a lane per ARFCN walks n_slots timeslots: stale entries leave the queue for the filler table, the
-//                       entry for exactly this time (if any) replaces the filler entry and goes out, else the filler entry
-//                       goes out (:142-177) -- as payload REFERENCES, nothing is copied on the serial path; the sixteen
-//                       ARFCNs' queues AND filler tables are in LDS for the walk (round 5: a dependent global access per
-//                       queue move and per slot was the whole kernel);
-//                       at the end of every turn of the walk the referenced payloads are copied into the layout
-//                       trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n] gains): what the fused transmit back end then
-//                       modulates, resamples and packs to int16.
+//   k_group_tx_arrive : driveTransmitPriorityQueue's parsing (:596-620) ON THE DEVICE (round 5) from the raw 154-byte datagrams and
+//                       their ARFCN ids, as they arrived -- everything that needs no queue state, so it runs on the uploads' stream: a
+//                       workgroup owns sixteen ARFCNs, finds its datagrams (a stable counting sort by wave ballots: arrival order is
+//                       kept inside an ARFCN) and parses TN / big-endian FN / RSSI into per-ARFCN lists;
+//   k_group_tx_ingest : addRadioVector (:100-113) for those lists: WAVE k enters ARFCN k's bursts in its queue -- the queue sits in LDS
+//                       for the duration, one word an entry (trxsig_txq_lds.h: std::priority_queue's moves, comparisons as integer
+//                       comparisons), the payload slots to hand out fetched ahead -- while a thread per burst copies the payload (148
+//                       bits + gain) to its slot;
+//   k_group_tx_push   : a WAVE per ARFCN walks n_slots timeslots, every value uniform across its lanes (scalar branches): stale
+//                       entries leave the queue for the filler table, the entry for exactly this time (if any) replaces the filler
+//                       entry and goes out, else the filler entry goes out (:142-177) -- as payload REFERENCES, nothing is copied on
+//                       the serial path; queues AND filler tables are in LDS for the walk (round 4: a dependent global access per
+//                       queue move and per slot was the whole kernel); at the end of every turn of the walk the referenced payloads
+//                       are copied into the layout trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n] gains): what the fused
+//                       transmit back end then modulates, resamples and packs to int16.
+// A queue holding a burst 2^17 frames or more from the call's own frame cannot be said in one-word entries: its workgroup works on the
+// arrays in memory with trxsig_txq.h's moves instead (the slow path: same results).
 // What is kept per burst is its bits and its gain, never its modulated samples: modulateBurst + scaleVector of the same bits
 // and gain give the same samples every time they are formed, so the filler table's "copy of the burst" (:165) is a reference.
 #include "trxsig_dev.h"
