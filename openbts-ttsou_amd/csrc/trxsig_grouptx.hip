@@ -165,17 +165,23 @@ __global__ __launch_bounds__(1024) void k_group_tx_arrive(int S, int n, const ui
 // ---- the queue half (the queues' stream): addRadioVector for what k_group_tx_arrive sorted, the payloads to their slots.
 // ref: the frame the packed queue entries are relative to (the first datagram's); far != 0: the host saw a datagram outside the packed
 // window (every workgroup takes the slow path).
-__global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, TxArrive ar,
-                                                          TxGainTab gt, int ref, int far_in) {
-  __shared__ TrxqPk q[kTxA][kTxRow];
+constexpr int kTxI = 4;                                     // ARFCNs per workgroup of the ingest: a WAVE each, a SIMD each (sixteen waves of this
+                                                            // scalar code on one CU's four scalar units took ~1.6 times as long per push, and the
+                                                            // workgroup waited for the slowest of sixteen)
+__global__ __launch_bounds__(64 * kTxI) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, TxArrive ar,
+                                                               TxGainTab gt, int ref, int far_in) {
+  static_assert(kTxA % kTxI == 0, "an ingest workgroup's ARFCNs lie inside one arrival workgroup's sixteen");
+  constexpr int NT = 64 * kTxI;
+  __shared__ TrxqPk q[kTxI][kTxRow];
   __shared__ int32_t lf[kTxWin + 1], lk[kTxWin + 1];        // this round's entries, ARFCN by ARFCN: frame number, key
   __shared__ int16_t fs[kTxWin + 2];                        // the payload slots those entries are handed, fetched ahead
-  __shared__ int nq[kTxA], nf[kTxA], tot[kTxA], acc[kTxA], lbase[kTxA + 1], st_[kTxA], far;
+  __shared__ int nq[kTxI], nf[kTxI], tot[kTxI], acc[kTxI], lbase[kTxI + 1], st_[kTxI], far, gbase;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int a0 = blockIdx.x * kTxA;
-  const int32_t *const ilf = ar.lf + (size_t)blockIdx.x * ar.n_pad, *const ilk = ar.lk + (size_t)blockIdx.x * ar.n_pad;
+  const int a0 = blockIdx.x * kTxI;
+  const int g16 = a0 / kTxA, k0 = a0 - g16 * kTxA;          // the arrival workgroup whose lists hold this workgroup's ARFCNs, and where in its sixteen
+  const int32_t *const ilf = ar.lf + (size_t)g16 * ar.n_pad, *const ilk = ar.lk + (size_t)g16 * ar.n_pad;
   TX_STAMP(0, 0);
-  if (tid < kTxA) {
+  if (tid < kTxI) {
     const bool mine = a0 + tid < x.S;
     nq[tid] = mine ? x.q_n[a0 + tid] : 0;
     nf[tid] = mine ? x.free_n[a0 + tid] : 0;
@@ -183,31 +189,32 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
   }
   if (tid == 0) far = far_in;
   __syncthreads();
-  tx_queues_load<kTxA>(x, a0, q, nq, ref, &far);
+  tx_queues_load<kTxI>(x, a0, q, nq, ref, &far);
   int round = 0;
   for (int w0 = 0; w0 < n; w0 += kTxWin, round++) {         // rounds of 8,192 datagrams (LDS is sized for one)
-    if (tid < kTxA) {
-      const int k = tid, t = ar.tot[((size_t)blockIdx.x * ar.rounds + round) * kTxA + k];
-      tot[k] = t;
-      // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
-      // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
-      const int room = min(x.qcap - nq[k], nf[k]);
-      acc[k] = t < room ? t : (room > 0 ? room : 0);
-    }
-    __syncthreads();
-    TX_STAMP(0, 1);
-    if (tid == 0) {
+    if (tid == 0) {                                         // this workgroup's part of the arrival workgroup's lists
+      const int32_t *t16 = ar.tot + ((size_t)g16 * ar.rounds + round) * kTxA;
       int run = 0;
-      for (int k = 0; k < kTxA; k++) { lbase[k] = run; run += tot[k]; }
-      lbase[kTxA] = run;
+      for (int k = 0; k < k0; k++) run += t16[k];
+      gbase = run;
+      int loc = 0;
+      for (int k = 0; k < kTxI; k++) {
+        const int t = t16[k0 + k];
+        tot[k] = t; lbase[k] = loc; loc += t;
+        // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
+        // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
+        const int room = min(x.qcap - nq[k], nf[k]);
+        acc[k] = t < room ? t : (room > 0 ? room : 0);
+      }
+      lbase[kTxI] = loc;
     }
     __syncthreads();
     TX_STAMP(0, 2);
-    for (int e = tid; e < lbase[kTxA]; e += 1024) { lf[e] = ilf[w0 + e]; lk[e] = ilk[w0 + e]; }
+    for (int e = tid; e < lbase[kTxI]; e += NT) { lf[e] = ilf[w0 + gbase + e]; lk[e] = ilk[w0 + gbase + e]; }
     {                                                       // the payload slots fetched ahead
-      const int k = tid & (kTxA - 1);
+      const int k = tid & (kTxI - 1);
       if (a0 + k < x.S)
-        for (int j = tid / kTxA; j < acc[k]; j += 1024 / kTxA) fs[lbase[k] + j] = x.free_stack[(size_t)(nf[k] - 1 - j) * x.S + a0 + k];
+        for (int j = tid / kTxI; j < acc[k]; j += NT / kTxI) fs[lbase[k] + j] = x.free_stack[(size_t)(nf[k] - 1 - j) * x.S + a0 + k];
     }
     __syncthreads();
     TX_STAMP(0, 3);
@@ -219,9 +226,9 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       uint32_t aw[38];
       auto load = [&](int e, bool &odd2, long long &slot, uint32_t &gain) {
         slot = -1; odd2 = false; gain = 0;
-        if (e >= lbase[kTxA]) return;
+        if (e >= lbase[kTxI]) return;
         const int key = lk[e];
-        const int kk = (key >> 8) & 15, src = w0 + (key >> 12);
+        const int kk = ((key >> 8) & 15) - k0, src = w0 + (key >> 12);
         if (e - lbase[kk] >= acc[kk]) return;               // dropped
         const size_t pb = (size_t)src * 154 + 6;
         odd2 = (pb & 2) != 0;
@@ -275,17 +282,16 @@ __global__ __launch_bounds__(1024) void k_group_tx_ingest(TrxGroupTx x, int n, c
       }
       TX_STAMP(0, 4);
       store(odd2, slot, gain);
-      for (int e = tid + 1024; e < lbase[kTxA]; e += 1024) {   // (acc / lbase / fs / lk are not written above)
+      for (int e = tid + NT; e < lbase[kTxI]; e += NT) {    // (acc / lbase / fs / lk are not written above)
         load(e, odd2, slot, gain);
         store(odd2, slot, gain);
       }
     }
-    __syncthreads();                                        // lf / lk / fs / cnt are the next round's
-    __syncthreads();                                        // lf / lk / fs / cnt are the next round's
+    __syncthreads();                                        // lf / lk / fs are the next round's
     TX_STAMP(0, 5);
   }
-  if (!far) tx_queues_store<kTxA>(x, a0, q, nq, ref);
-  if (tid < kTxA && a0 + tid < x.S) {
+  if (!far) tx_queues_store<kTxI>(x, a0, q, nq, ref);
+  if (tid < kTxI && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
     if (st_[tid]) x.status[a0 + tid] |= 1u;
@@ -504,7 +510,7 @@ hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n
   if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;   // (the kernel's LDS copy of a queue, a packed entry's id field)
   TxGainTab gt;
   for (int q = 0; q < 26; q++) gt.v[q] = gain_tab26[q];
-  k_group_tx_ingest<<<dim3((x.S + kTxA - 1) / kTxA), dim3(1024), 0, st>>>(x, n, dgram, tx_arrive_args(n, (int32_t *)a_lf, (int32_t *)a_lk, (int32_t *)a_tot), gt, ref_fn,
+  k_group_tx_ingest<<<dim3((x.S + kTxI - 1) / kTxI), dim3(64 * kTxI), 0, st>>>(x, n, dgram, tx_arrive_args(n, (int32_t *)a_lf, (int32_t *)a_lk, (int32_t *)a_tot), gt, ref_fn,
                                                                           far);
   return hipGetLastError();
 }
