@@ -120,6 +120,7 @@ struct trxsig_trxgroup {
   hipStream_t tx_up = nullptr, tx_q = nullptr;
   hipEvent_t tx_q_ev = nullptr, tx_out_ev[2] = {nullptr, nullptr}, tx_read_ev[2] = {nullptr, nullptr};
   bool tx_q_armed = false, tx_out_armed[2] = {false, false}, tx_read_armed[2] = {false, false};
+  hipEvent_t tx_q_last = nullptr;    // the event behind the queues' stream's latest work (an ingest's tx_read_ev or a walk's tx_q_ev): one record per kernel
   unsigned tx_pushes = 0;
   uint8_t *tx_pin[2] = {nullptr, nullptr};   // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), two in turn
   int tx_pin_cap[2] = {0, 0};
@@ -778,13 +779,16 @@ int tx_streams(trxsig_trxgroup *g) {
   }
   return TRXSIG_OK;
 }
-int tx_q_mark(trxsig_trxgroup *g) {                         // "the queues' stream has run up to here"
-  G_HIP(g, hipEventRecord(g->tx_q_ev, g->tx_q));
+// "the queues' stream has run up to here": ONE event record behind every kernel of that stream (each record, each wait is a packet
+// the stream's dependent launches queue up behind: ~3 us apiece on the serial chain)
+int tx_q_mark(trxsig_trxgroup *g, hipEvent_t ev) {
+  G_HIP(g, hipEventRecord(ev, g->tx_q));
+  g->tx_q_last = ev;
   g->tx_q_armed = true;
   return TRXSIG_OK;
 }
 int tx_join(trxsig_trxgroup *g, hipStream_t st) {
-  if (g->tx_q_armed) { G_HIP(g, hipStreamWaitEvent(st, g->tx_q_ev, 0)); g->tx_q_armed = false; }
+  if (g->tx_q_armed) { G_HIP(g, hipStreamWaitEvent(st, g->tx_q_last, 0)); g->tx_q_armed = false; }
   return TRXSIG_OK;
 }
 // fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT (rare: its own host staging vector, waited for before it is refilled)
@@ -867,9 +871,8 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   g->tx_stage_held = false;
   G_HIP(g, hipStreamWaitEvent(q, g->tx_ev[k], 0));
   G_HIP(g, trx_launch_group_tx_ingest(q, g->tx, n, g->tx_dgram[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p, g->gain_tab, ref_fn, far));
-  G_HIP(g, hipEventRecord(g->tx_read_ev[k], q));
+  G_LIB(tx_q_mark(g, g->tx_read_ev[k]));                   // (the set's device arrays are free behind it; the context's stream joins on it)
   g->tx_read_armed[k] = true;
-  G_LIB(tx_q_mark(g));
   return TRXSIG_OK;
 }
 
@@ -915,14 +918,19 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
   const int o = (int)(g->tx_pushes & 1u);
   G_HIP(g, hipEventRecord(g->tx_out_ev[o ^ 1], st));
   g->tx_out_armed[o ^ 1] = true;
-  if (g->tx_out_armed[o]) { G_HIP(g, hipStreamWaitEvent(q, g->tx_out_ev[o], 0)); g->tx_out_armed[o] = false; }
+  if (g->tx_out_armed[o]) {                                 // (a step later that work has normally run: then the queues' stream is spared the wait)
+    const bool ran = hipEventQuery(g->tx_out_ev[o]) == hipSuccess;
+    (void)hipGetLastError();                                // (hipErrorNotReady is an answer, not an error to be found by the next launch check)
+    if (!ran) G_HIP(g, hipStreamWaitEvent(q, g->tx_out_ev[o], 0));
+    g->tx_out_armed[o] = false;
+  }
   g->tx_pushes++;
   G_LIB(tx_sync_modulus(g, q));
   const size_t cells = (size_t)n_slots * g->S;
   G_HIP(g, g->tx_bits[o].need(cells * 148, q));
   G_HIP(g, g->tx_gain[o].need(cells, q)); G_HIP(g, g->tx_fq[o].need(cells, q));
   G_HIP(g, trx_launch_group_tx_push(q, g->tx, fn, tn, n_slots, g->tx_bits[o].p, g->tx_gain[o].p, g->tx_fq[o].p));
-  G_LIB(tx_q_mark(g));
+  G_LIB(tx_q_mark(g, g->tx_q_ev));
   G_LIB(tx_join(g, st));                                    // the caller reads the output on the context's stream
   if (d_bits) *d_bits = g->tx_bits[o].p;
   if (d_gain) *d_gain = g->tx_gain[o].p;
