@@ -314,6 +314,59 @@ __device__ __forceinline__ int tx_fn_mod(int n, int m, float rm) {
   r -= r >= m ? m : 0;
   return r;
 }
+// ---- std::pop_heap on a queue of at most 64 entries held ACROSS THE WAVE'S LANES (entry i in lane i of hv), every lane working on the
+// one pop.  The walk is a lone wave's dependent instructions (profiles/r05_group_tx_probe.txt: ~1,300 clocks a pop with the queue in
+// LDS and everything on the scalar unit); here the comparisons of ALL sibling pairs are one vector compare and a ballot, the hole's way
+// down is read off the ballot by a few scalar bit operations, and the moves are one ds_bpermute:
+//   B  bit e (even e >= 2)  comp(first[e], first[e - 1]): the hole, arriving at their parent, goes LEFT ("secondChild--") -- the pairs
+//      the hole meets are untouched by the pop so far, so the bits taken before the descent are the ones __adjust_heap would form;
+//   G  bit i  comp(first[i], value) for the queue's last element `value`: what __push_heap's climb back asks of the elements moved up;
+//   the descent: hole -> 2 hole + 2 - B[2 hole + 2] while hole < (len - 1) / 2, then the lone left child (len even) -- positions grow
+//   with the level, so the path is kept as a 64-bit SET; the climb stops at the deepest path position (or the root) whose element
+//   is not later than value: the highest bit of path & ~G; the elements above it move up one level each (lane pos[l] takes lane
+//   pos[l + 1]'s entry: one bpermute), value lands there, the levels below keep what they had.
+// The same comparisons on the same elements as trxq_pop / tx_heap_pop, the same array afterwards (the tests hold the kernels against
+// std::priority_queue: ties, queues up to 64 deep here, deeper ones on the LDS form).  n = size before (1 .. 64); top in / out as in
+// tx_heap_pop.
+__device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqPk &popped) {
+  const int lane = (int)(threadIdx.x & 63);
+  popped = top;
+  const int len = n - 1;
+  if (len == 0) return 0;
+  const TrxqPk v = __builtin_amdgcn_readlane(hv, len);
+  const int half = (len - 1) >> 1;
+  const int lone = (len & 1) ? -1 : (len - 2) >> 1;
+  const TrxqPk left = __shfl_up(hv, 1, 64);                 // lane e: the entry of lane e - 1 (its left sibling when e is even)
+  const unsigned long long B = __builtin_amdgcn_ballot_w64(tx_gt(hv, left));   // (bits at odd lanes, lane 0: never looked at)
+  const unsigned long long G = __builtin_amdgcn_ballot_w64(tx_gt(hv, v));
+  // the hole's way down: a level's position is larger than the level's above, so the path is a SET of lane numbers, bottom = highest bit
+  int hole = 0, lonepos = -1;
+  unsigned long long path = 0;                              // pos[1 .. D]
+  while (hole < half) {
+    const int r = 2 * hole + 2;
+    hole = r - (int)((B >> r) & 1ull);
+    path |= 1ull << hole;
+  }
+  if (hole == lone) {
+    lonepos = hole;
+    hole = 2 * hole + 1;
+    path |= 1ull << hole;
+  }
+  // the climb back stops at the deepest level of the path (the root included) whose element is NOT later than value
+  const unsigned long long stop = (path & ~G) | 1ull;
+  const int posj = 63 - __builtin_clzll(stop);
+  const unsigned long long moved = (path | 1ull) & ((1ull << posj) - 1ull);   // the levels above it take their chosen child's entry
+  const int sh = 2 * lane + 2;
+  const int mybit = sh < 64 ? (int)((B >> sh) & 1ull) : 0;
+  const int child = lane == lonepos ? 2 * lane + 1 : sh - mybit;
+  const int src = ((moved >> lane) & 1ull) ? child : lane;
+  TrxqPk hn = __builtin_amdgcn_ds_bpermute(src << 2, hv);
+  hn = lane == posj ? v : hn;
+  hv = hn;
+  top = __builtin_amdgcn_readlane(hv, 0);
+  return len;
+}
+
 constexpr int kTxWalk = 128;                                // timeslots a turn of the walk (their filler cells are worked out ahead, by every thread)
 constexpr int kTxP = 4;                                     // ARFCNs per workgroup of the walk: a WAVE each
 // The walk of an ARFCN's queue is one thread's work, a chain of dependent instructions; what it costs is the instructions the wave
@@ -364,7 +417,13 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
   int n_q = nq[k], n_f = nf[k];
   const int is_far = far;
   TrxqPk top = 0, last = 0, c[6] = {0, 0, 0, 0, 0, 0};
-  if (walker && !is_far && n_q > 0) {
+  // a queue of at most 64 entries is walked across the wave's lanes (tx_lane_pop), a longer one in LDS (tx_heap_pop): a walk only pops
+  const bool lanes = walker && !is_far && n_q <= 64;
+  TrxqPk hv = 0;
+  if (lanes) {
+    hv = row[tid & 63];                                     // (entries past the queue's end: whatever the row holds, never looked at)
+    top = __builtin_amdgcn_readlane(hv, 0);
+  } else if (walker && !is_far && n_q > 0) {
     top = row[0]; last = row[n_q - 1];
 #pragma unroll
     for (int i = 0; i < 6; i++) c[i] = row[1 + i];
@@ -393,7 +452,7 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
           const int tk = trxq_pk_time(top);
           if (tk > now) break;
           TrxqPk e;
-          { TX_ACC_BEGIN(); n_q = tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
+          { TX_ACC_BEGIN(); n_q = lanes ? tx_lane_pop(hv, n_q, top, e) : tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
           if (tk == now) {                                  // the burst for exactly this slot (:159-173): it replaces the filler entry and goes out
             const int old = reread ? (int)flk[cell] : pid;
             if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
@@ -464,6 +523,7 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
       fq_out[cell] = ofq[kk][j];
     }
   }
+  if (lanes && (int)(tid & 63) < n_q) row[tid & 63] = hv;   // the queue back to its row
   if (walker && writer) { nq[k] = n_q; nf[k] = n_f; }
   TX_STAMP(1, 2);
   TX_ACC_OUT(1);
