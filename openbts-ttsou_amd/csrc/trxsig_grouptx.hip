@@ -336,7 +336,7 @@ __device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqP
   const TrxqPk v = __builtin_amdgcn_readlane(hv, len);
   const int half = (len - 1) >> 1;
   const int lone = (len & 1) ? -1 : (len - 2) >> 1;
-  const TrxqPk left = __shfl_up(hv, 1, 64);                 // lane e: the entry of lane e - 1 (its left sibling when e is even)
+  const TrxqPk left = __builtin_amdgcn_update_dpp(0, hv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane e: the entry of lane e - 1 (its left sibling when e is even)
   const unsigned long long B = __builtin_amdgcn_ballot_w64(tx_gt(hv, left));   // (bits at odd lanes, lane 0: never looked at)
   const unsigned long long G = __builtin_amdgcn_ballot_w64(tx_gt(hv, v));
   // the hole's way down: a level's position is larger than the level's above, so the path is a SET of lane numbers, bottom = highest bit
