@@ -152,7 +152,7 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
  * datagrams: the host only checks the headers (the refusal rule above), the block goes up in one DMA as it arrived, and parsing
  * (TN, big-endian FN, RSSI -> pow(10, -RSSI/10) with the integer division), the per-ARFCN sort that keeps the arrival order, the
  * queue insertion and the payload copies are two kernels (k_group_tx_arrive behind the upload, k_group_tx_ingest on the queues'
- * stream).  Two blocks alternate: after add_staged the
+ * stream).  Three blocks take turns: after add_staged the
  * pointers are the DMA's; ask again for the next batch (the call waits, if it must, for the upload and the ingest that last used
  * that block's set: that is where a host is held back when the device is more than a batch behind).
  * trxsig_trxgroup_add_bursts is this with a copy into the block first.

@@ -110,3 +110,8 @@ hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n
 // [S][n_slots] (1 = the burst came from the queue)
 hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0, int tn0, int n_slots, uint8_t *bits_out, float *gain_out,
                                     uint8_t *fq_out);
+// the add call's ingest and the push that follows it in ONE launch (the queues go to LDS and back once); far_add != 0: some datagram
+// of the add call lies TRXQ_PK_WIN frames or more from fn0
+hipError_t trx_launch_group_tx_both(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *a_lf, const int32_t *a_lk,
+                                    const int32_t *a_tot, const float *gain_tab26, int far_add, int fn0, int tn0, int n_slots, uint8_t *bits_out,
+                                    float *gain_out, uint8_t *fq_out);

@@ -165,140 +165,6 @@ __global__ __launch_bounds__(1024) void k_group_tx_arrive(int S, int n, const ui
 // ---- the queue half (the queues' stream): addRadioVector for what k_group_tx_arrive sorted, the payloads to their slots.
 // ref: the frame the packed queue entries are relative to (the first datagram's); far != 0: the host saw a datagram outside the packed
 // window (every workgroup takes the slow path).
-constexpr int kTxI = 4;                                     // ARFCNs per workgroup of the ingest: a WAVE each, a SIMD each (sixteen waves of this
-                                                            // scalar code on one CU's four scalar units took ~1.6 times as long per push, and the
-                                                            // workgroup waited for the slowest of sixteen)
-__global__ __launch_bounds__(64 * kTxI) void k_group_tx_ingest(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, TxArrive ar,
-                                                               TxGainTab gt, int ref, int far_in) {
-  static_assert(kTxA % kTxI == 0, "an ingest workgroup's ARFCNs lie inside one arrival workgroup's sixteen");
-  constexpr int NT = 64 * kTxI;
-  __shared__ TrxqPk q[kTxI][kTxRow];
-  __shared__ int32_t lf[kTxWin + 1], lk[kTxWin + 1];        // this round's entries, ARFCN by ARFCN: frame number, key
-  __shared__ int16_t fs[kTxWin + 2];                        // the payload slots those entries are handed, fetched ahead
-  __shared__ int nq[kTxI], nf[kTxI], tot[kTxI], acc[kTxI], lbase[kTxI + 1], st_[kTxI], far, gbase;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int a0 = blockIdx.x * kTxI;
-  const int g16 = a0 / kTxA, k0 = a0 - g16 * kTxA;          // the arrival workgroup whose lists hold this workgroup's ARFCNs, and where in its sixteen
-  const int32_t *const ilf = ar.lf + (size_t)g16 * ar.n_pad, *const ilk = ar.lk + (size_t)g16 * ar.n_pad;
-  TX_STAMP(0, 0);
-  if (tid < kTxI) {
-    const bool mine = a0 + tid < x.S;
-    nq[tid] = mine ? x.q_n[a0 + tid] : 0;
-    nf[tid] = mine ? x.free_n[a0 + tid] : 0;
-    st_[tid] = 0;
-  }
-  if (tid == 0) far = far_in;
-  __syncthreads();
-  tx_queues_load<kTxI>(x, a0, q, nq, ref, &far);
-  int round = 0;
-  for (int w0 = 0; w0 < n; w0 += kTxWin, round++) {         // rounds of 8,192 datagrams (LDS is sized for one)
-    if (tid == 0) {                                         // this workgroup's part of the arrival workgroup's lists
-      const int32_t *t16 = ar.tot + ((size_t)g16 * ar.rounds + round) * kTxA;
-      int run = 0;
-      for (int k = 0; k < k0; k++) run += t16[k];
-      gbase = run;
-      int loc = 0;
-      for (int k = 0; k < kTxI; k++) {
-        const int t = t16[k0 + k];
-        tot[k] = t; lbase[k] = loc; loc += t;
-        // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
-        // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
-        const int room = min(x.qcap - nq[k], nf[k]);
-        acc[k] = t < room ? t : (room > 0 ? room : 0);
-      }
-      lbase[kTxI] = loc;
-    }
-    __syncthreads();
-    TX_STAMP(0, 2);
-    for (int e = tid; e < lbase[kTxI]; e += NT) { lf[e] = ilf[w0 + gbase + e]; lk[e] = ilk[w0 + gbase + e]; }
-    {                                                       // the payload slots fetched ahead
-      const int k = tid & (kTxI - 1);
-      if (a0 + k < x.S)
-        for (int j = tid / kTxI; j < acc[k]; j += NT / kTxI) fs[lbase[k] + j] = x.free_stack[(size_t)(nf[k] - 1 - j) * x.S + a0 + k];
-    }
-    __syncthreads();
-    TX_STAMP(0, 3);
-    {
-      // ---- the payloads to their slots, a burst a thread: its 148 bytes as aligned sixteen-byte loads, all in flight at once; the
-      //      thread's FIRST burst is loaded before the queue insertions below and stored after them (the loads land meanwhile) ----
-      // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548).  Datagram src's payload starts at byte 154 src + 6: on a
-      // multiple of four for odd src, two past one for even src -- aligned words are loaded and shifted by two bytes then
-      uint32_t aw[38];
-      auto load = [&](int e, bool &odd2, long long &slot, uint32_t &gain) {
-        slot = -1; odd2 = false; gain = 0;
-        if (e >= lbase[kTxI]) return;
-        const int key = lk[e];
-        const int kk = ((key >> 8) & 15) - k0, src = w0 + (key >> 12);
-        if (e - lbase[kk] >= acc[kk]) return;               // dropped
-        const size_t pb = (size_t)src * 154 + 6;
-        odd2 = (pb & 2) != 0;
-        const uint32_t *pa = reinterpret_cast<const uint32_t *>(dgram + (pb & ~(size_t)3));
-#pragma unroll
-        for (int w = 0; w < 36; w += 4) __builtin_memcpy(&aw[w], pa + w, 16);
-        __builtin_memcpy(&aw[36], pa + 36, 8);              // (up to four bytes past the last datagram's end: the array is allocated eight longer)
-        gain = __float_as_uint(gt.v[(key >> 3) & 31]);
-        slot = ((long long)(a0 + kk) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS;
-      };
-      auto store = [&](bool odd2, long long slot, uint32_t gain) {
-        if (slot < 0) return;
-        uint32_t v[TRXG_PAYLOAD_WORDS];
-#pragma unroll
-        for (int w = 0; w < 37; w++) v[w] = odd2 ? __builtin_amdgcn_alignbyte(aw[w + 1], aw[w], 2) : aw[w];
-        v[37] = gain;
-        uint32_t *dst = x.pool + slot;
-        static_assert(TRXG_PAYLOAD_WORDS == 38, "nine sixteen-byte stores and an eight-byte one");
-#pragma unroll
-        for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);   // (a slot starts on a multiple of 8 bytes)
-        __builtin_memcpy(dst + 36, &v[36], 8);
-      };
-      bool odd2;
-      long long slot;
-      uint32_t gain;
-      load(tid, odd2, slot, gain);
-      // ---- addRadioVector: WAVE k enters ARFCN k's bursts (every value the same in all its lanes: scalar branches, see k_group_tx_push;
-      //      lane 0's stores count) ----
-      const int k = __builtin_amdgcn_readfirstlane(wave);
-      if (a0 + k < x.S) {
-        const int e0 = lbase[k], m = acc[k];
-        int n_q = nq[k];
-        if (!far) {
-          TrxqPk *row = &q[k][0];
-          int32_t f1 = lf[e0], k1 = lk[e0];
-          int s1 = fs[e0];
-          for (int j = 0; j < m; j++) {                     // mTransmitPriorityQueue.write(newVec) (:109); the next entry fetched meanwhile
-            const TrxqPk v = trxq_pk(f1, k1 & 7, s1, ref);
-            f1 = lf[e0 + j + 1]; k1 = lk[e0 + j + 1]; s1 = fs[e0 + j + 1];   // (one past the ARFCN's last: the next ARFCN's or padding, unused)
-            n_q = tx_heap_push(row, n_q, v);
-          }
-        } else if (lane == 0) {
-          const TrxqView gq = {x.q_fn + a0 + k, x.q_key + a0 + k, x.S};
-          for (int j = 0; j < m; j++) n_q = trxq_push(gq, n_q, lf[e0 + j], (lk[e0 + j] & 7) | ((int)fs[e0 + j] << 3));
-        }
-        n_q = __builtin_amdgcn_readfirstlane(n_q);
-        if (lane == 0) {                                    // (nq / nf / st_ are not read by the copy)
-          nq[k] = n_q; nf[k] -= m;
-          if (m < tot[k]) st_[k] |= 1;                      // queue or payload pool full: the rest is dropped and the ARFCN marked
-        }
-      }
-      TX_STAMP(0, 4);
-      store(odd2, slot, gain);
-      for (int e = tid + NT; e < lbase[kTxI]; e += NT) {    // (acc / lbase / fs / lk are not written above)
-        load(e, odd2, slot, gain);
-        store(odd2, slot, gain);
-      }
-    }
-    __syncthreads();                                        // lf / lk / fs are the next round's
-    TX_STAMP(0, 5);
-  }
-  if (!far) tx_queues_store<kTxI>(x, a0, q, nq, ref);
-  if (tid < kTxI && a0 + tid < x.S) {
-    x.q_n[a0 + tid] = nq[tid];
-    x.free_n[a0 + tid] = nf[tid];
-    if (st_[tid]) x.status[a0 + tid] |= 1u;
-  }
-  TX_STAMP(0, 6);
-}
-
 __device__ __forceinline__ void tx_free(const TrxGroupTx &x, int a, int &nf, int pid) {
   if (pid < 0) return;                                      // the dummy burst is nobody's
   x.free_stack[(size_t)nf * x.S + a] = (int16_t)pid;
@@ -367,32 +233,55 @@ __device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqP
   return len;
 }
 
+constexpr int kTxI = 4;                                     // ARFCNs per workgroup of the queues' kernel: a WAVE each, a SIMD each (sixteen waves of
+                                                            // this scalar code on one CU took ~1.6 times as long per push, and the workgroup
+                                                            // waited for the slowest of sixteen)
 constexpr int kTxWalk = 128;                                // timeslots a turn of the walk (their filler cells are worked out ahead, by every thread)
-constexpr int kTxP = 4;                                     // ARFCNs per workgroup of the walk: a WAVE each
+constexpr int kTxP = kTxI;
 // The walk of an ARFCN's queue is one thread's work, a chain of dependent instructions; what it costs is the instructions the wave
 // issues (~8 cycles each with nothing to hide them behind).  A wave per ARFCN, every value the same in all its lanes
 // (readfirstlane'd ARFCN index, LDS addresses that do not depend on the lane): the branches are scalar branches, no execution
 // masks to save, combine and restore as with a lane per ARFCN (where every branch some lane takes all sixteen pay for).
 // far_in != 0: the walk is too long for the packed form's window (the host's check)
-__global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int fn0, int tn0, int n_slots, uint32_t *__restrict__ bits_out,
-                                                             float *__restrict__ gain_out, uint8_t *__restrict__ fq_out, int far_in) {
-  __shared__ TrxqPk q[kTxP][kTxRow];                        // packed relative to fn0: the slot on the air at step t has time tn0 + t
-  __shared__ int16_t fl[kTxP][kTxCells];                    // the filler tables
+// ONE kernel for the queues' stream, in three forms:
+//   <true, false>  addRadioVector for what k_group_tx_arrive sorted (ref: the frame the packed queue entries are relative to -- the
+//                  first datagram's);
+//   <false, true>  pushRadioVector for n_slots timeslots from (fn0, tn0);
+//   <true, true>   both, the add call's ingest left pending until the push that follows it (trxsig_trxgroup.cpp: the usual order of a
+//                  transmit loop): the queues go to LDS once, are entered into and walked, and go back once -- a dependent launch
+//                  and a round trip of the queues less on the serial chain.  The packed entries are relative to fn0 then.
+// far_in != 0: some datagram lies outside the packed entries' window round the reference frame (the host's check), or the walk is
+// too long for it: every workgroup works on the arrays in memory (trxsig_txq.h's moves; same results, slow).
+template <bool INGEST, bool WALK>
+__global__ __launch_bounds__(64 * kTxI) void k_group_tx(TrxGroupTx x, int n, const uint8_t *__restrict__ dgram, TxArrive ar, TxGainTab gt, int ref_in,
+                                                        int fn0, int tn0, int n_slots, uint32_t *__restrict__ bits_out, float *__restrict__ gain_out,
+                                                        uint8_t *__restrict__ fq_out, int far_in) {
+  static_assert(kTxA % kTxI == 0, "a workgroup's ARFCNs lie inside one arrival workgroup's sixteen");
+  constexpr int NT = 64 * kTxI;
+  __shared__ TrxqPk q[kTxI][kTxRow];                        // the queues, packed relative to `ref`
+  __shared__ int nq[kTxI], nf[kTxI], st_[kTxI], far;
+  // the ingest's
+  __shared__ int32_t lf[INGEST ? kTxWin + 1 : 1], lk[INGEST ? kTxWin + 1 : 1];   // this round's entries, ARFCN by ARFCN: frame number, key
+  __shared__ int16_t fs[INGEST ? kTxWin + 2 : 2];           // the payload slots those entries are handed, fetched ahead
+  __shared__ int tot[kTxI], acc[kTxI], lbase[kTxI + 1], gbase;
+  // the walk's
+  __shared__ int16_t fl[WALK ? kTxP : 1][kTxCells];         // the filler tables
   __shared__ uint16_t cidx[kTxP][kTxWalk + 2];              // [FN % modulus][TN] of the slots of this turn (+ the next turn's first)
   __shared__ int16_t opid[kTxP][kTxWalk];                   // what goes out at each slot of the turn: a payload reference (-1: the dummy burst) ...
   __shared__ uint8_t ofq[kTxP][kTxWalk];                    // ... and whether it came from the queue
   __shared__ int md[kTxP][8];
   __shared__ float mdr[kTxP][8];
-  __shared__ int nq[kTxP], nf[kTxP], far;
-  const int tid = threadIdx.x, a0 = blockIdx.x * kTxP;
-  constexpr int NT = 64 * kTxP;
-  TX_STAMP(1, 0);
-  if (tid < kTxP) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a0 = blockIdx.x * kTxI;
+  const int ref = WALK ? fn0 : ref_in;                      // (the walk's slot times are tn0 + t when the entries are relative to fn0)
+  TX_STAMP(WALK ? 1 : 0, 0);
+  if (tid < kTxI) {
     const bool mine = a0 + tid < x.S;
     nq[tid] = mine ? x.q_n[a0 + tid] : 0;
     nf[tid] = mine ? x.free_n[a0 + tid] : 0;
+    st_[tid] = 0;
   }
-  if (tid < kTxP * 8) {
+  if (WALK && tid < kTxP * 8) {
     const int k = tid & (kTxP - 1), m = tid / kTxP;
     const int v = a0 + k < x.S ? x.fmod[m * x.S + a0 + k] : 1;
     md[k][m] = v;
@@ -400,145 +289,256 @@ __global__ __launch_bounds__(64 * kTxP) void k_group_tx_push(TrxGroupTx x, int f
   }
   if (tid == 0) far = far_in;
   __syncthreads();
-  tx_queues_load<kTxP>(x, a0, q, nq, fn0, &far);
-  {
+  tx_queues_load<kTxI>(x, a0, q, nq, ref, &far);
+  if (WALK) {
     const int k = tid & (kTxP - 1);
     if (a0 + k < x.S)
       for (int c = tid / kTxP; c < kTxCells; c += NT / kTxP) fl[k][c] = x.filler[(size_t)c * x.S + a0 + k];
   }
+  if (INGEST) {
+    // ================= addRadioVector for what k_group_tx_arrive sorted =================
+    const int g16 = a0 / kTxA, k0 = a0 - g16 * kTxA;        // the arrival workgroup whose lists hold this workgroup's ARFCNs, and where in its sixteen
+    const int32_t *const ilf = ar.lf + (size_t)g16 * ar.n_pad, *const ilk = ar.lk + (size_t)g16 * ar.n_pad;
+    int round = 0;
+    for (int w0 = 0; w0 < n; w0 += kTxWin, round++) {         // rounds of 8,192 datagrams (LDS is sized for one)
+      if (tid == 0) {                                         // this workgroup's part of the arrival workgroup's lists
+        const int32_t *t16 = ar.tot + ((size_t)g16 * ar.rounds + round) * kTxA;
+        int run = 0;
+        for (int k = 0; k < k0; k++) run += t16[k];
+        gbase = run;
+        int loc = 0;
+        for (int k = 0; k < kTxI; k++) {
+          const int t = t16[k0 + k];
+          tot[k] = t; lbase[k] = loc; loc += t;
+          // the queue and the payload pool only fill up during a call: what is accepted is a PREFIX of the ARFCN's arrivals
+          // ("if the queue or the pool is full the burst is dropped and the ARFCN marked")
+          const int room = min(x.qcap - nq[k], nf[k]);
+          acc[k] = t < room ? t : (room > 0 ? room : 0);
+        }
+        lbase[kTxI] = loc;
+      }
+      __syncthreads();
+      TX_STAMP(0, 2);
+      for (int e = tid; e < lbase[kTxI]; e += NT) { lf[e] = ilf[w0 + gbase + e]; lk[e] = ilk[w0 + gbase + e]; }
+      {                                                       // the payload slots fetched ahead
+        const int k = tid & (kTxI - 1);
+        if (a0 + k < x.S)
+          for (int j = tid / kTxI; j < acc[k]; j += NT / kTxI) fs[lbase[k] + j] = x.free_stack[(size_t)(nf[k] - 1 - j) * x.S + a0 + k];
+      }
+      __syncthreads();
+      TX_STAMP(0, 3);
+      {
+        // ---- the payloads to their slots, a burst a thread: its 148 bytes as aligned sixteen-byte loads, all in flight at once; the
+        //      thread's FIRST burst is loaded before the queue insertions below and stored after them (the loads land meanwhile) ----
+        // the bits as they arrive (modulateBurst masks them, sigProcLib.cpp:548).  Datagram src's payload starts at byte 154 src + 6: on a
+        // multiple of four for odd src, two past one for even src -- aligned words are loaded and shifted by two bytes then
+        uint32_t aw[38];
+        auto load = [&](int e, bool &odd2, long long &slot, uint32_t &gain) {
+          slot = -1; odd2 = false; gain = 0;
+          if (e >= lbase[kTxI]) return;
+          const int key = lk[e];
+          const int kk = ((key >> 8) & 15) - k0, src = w0 + (key >> 12);
+          if (e - lbase[kk] >= acc[kk]) return;               // dropped
+          const size_t pb = (size_t)src * 154 + 6;
+          odd2 = (pb & 2) != 0;
+          const uint32_t *pa = reinterpret_cast<const uint32_t *>(dgram + (pb & ~(size_t)3));
+  #pragma unroll
+          for (int w = 0; w < 36; w += 4) __builtin_memcpy(&aw[w], pa + w, 16);
+          __builtin_memcpy(&aw[36], pa + 36, 8);              // (up to four bytes past the last datagram's end: the array is allocated eight longer)
+          gain = __float_as_uint(gt.v[(key >> 3) & 31]);
+          slot = ((long long)(a0 + kk) * x.npool + fs[e]) * TRXG_PAYLOAD_WORDS;
+        };
+        auto store = [&](bool odd2, long long slot, uint32_t gain) {
+          if (slot < 0) return;
+          uint32_t v[TRXG_PAYLOAD_WORDS];
+  #pragma unroll
+          for (int w = 0; w < 37; w++) v[w] = odd2 ? __builtin_amdgcn_alignbyte(aw[w + 1], aw[w], 2) : aw[w];
+          v[37] = gain;
+          uint32_t *dst = x.pool + slot;
+          static_assert(TRXG_PAYLOAD_WORDS == 38, "nine sixteen-byte stores and an eight-byte one");
+  #pragma unroll
+          for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);   // (a slot starts on a multiple of 8 bytes)
+          __builtin_memcpy(dst + 36, &v[36], 8);
+        };
+        bool odd2;
+        long long slot;
+        uint32_t gain;
+        load(tid, odd2, slot, gain);
+        // ---- addRadioVector: WAVE k enters ARFCN k's bursts (every value the same in all its lanes: scalar branches, see k_group_tx_push;
+        //      lane 0's stores count) ----
+        const int k = __builtin_amdgcn_readfirstlane(wave);
+        if (a0 + k < x.S) {
+          const int e0 = lbase[k], m = acc[k];
+          int n_q = nq[k];
+          if (!far) {
+            TrxqPk *row = &q[k][0];
+            int32_t f1 = lf[e0], k1 = lk[e0];
+            int s1 = fs[e0];
+            for (int j = 0; j < m; j++) {                     // mTransmitPriorityQueue.write(newVec) (:109); the next entry fetched meanwhile
+              const TrxqPk v = trxq_pk(f1, k1 & 7, s1, ref);
+              f1 = lf[e0 + j + 1]; k1 = lk[e0 + j + 1]; s1 = fs[e0 + j + 1];   // (one past the ARFCN's last: the next ARFCN's or padding, unused)
+              n_q = tx_heap_push(row, n_q, v);
+            }
+          } else if (lane == 0) {
+            const TrxqView gq = {x.q_fn + a0 + k, x.q_key + a0 + k, x.S};
+            for (int j = 0; j < m; j++) n_q = trxq_push(gq, n_q, lf[e0 + j], (lk[e0 + j] & 7) | ((int)fs[e0 + j] << 3));
+          }
+          n_q = __builtin_amdgcn_readfirstlane(n_q);
+          if (lane == 0) {                                    // (nq / nf / st_ are not read by the copy)
+            nq[k] = n_q; nf[k] -= m;
+            if (m < tot[k]) st_[k] |= 1;                      // queue or payload pool full: the rest is dropped and the ARFCN marked
+          }
+        }
+        TX_STAMP(0, 4);
+        store(odd2, slot, gain);
+        for (int e = tid + NT; e < lbase[kTxI]; e += NT) {    // (acc / lbase / fs / lk are not written above)
+          load(e, odd2, slot, gain);
+          store(odd2, slot, gain);
+        }
+      }
+      __syncthreads();                                        // lf / lk / fs are the next round's
+      TX_STAMP(0, 5);
+    }
+
+  }
   __syncthreads();
   TX_STAMP(1, 1);
-  // wave k walks ARFCN a0 + k; what it keeps between the turns (the same in every lane):
-  const int k = __builtin_amdgcn_readfirstlane(tid >> 6), a = a0 + k;
-  const bool walker = a < x.S;
-  const bool writer = (tid & 63) == 0;                      // (one lane stores; all of them compute)
-  TrxqPk *row = &q[k][0];
-  int16_t *flk = &fl[k][0];
-  int n_q = nq[k], n_f = nf[k];
-  const int is_far = far;
-  TrxqPk top = 0, last = 0, c[6] = {0, 0, 0, 0, 0, 0};
-  // a queue of at most 64 entries is walked across the wave's lanes (tx_lane_pop), a longer one in LDS (tx_heap_pop): a walk only pops
-  const bool lanes = walker && !is_far && n_q <= 64;
-  TrxqPk hv = 0;
-  if (lanes) {
-    hv = row[tid & 63];                                     // (entries past the queue's end: whatever the row holds, never looked at)
-    top = __builtin_amdgcn_readlane(hv, 0);
-  } else if (walker && !is_far && n_q > 0) {
-    top = row[0]; last = row[n_q - 1];
-#pragma unroll
-    for (int i = 0; i < 6; i++) c[i] = row[1 + i];
-  }
-  const TrxqView gq = {x.q_fn + a, x.q_key + a, x.S};       // (the slow path: the queue where it lives)
-  TX_ACC_DECL();
-  for (int t0 = 0; t0 < n_slots; t0 += kTxWalk) {
-    const int nt = min(kTxWalk, n_slots - t0);
-    for (int i = tid; i < kTxP * (nt + 1); i += NT) {       // the filler cell of every slot of the turn: [FN % modulus][TN]
-      const int kk = i & (kTxP - 1), j = i / kTxP, now = tn0 + t0 + j, tn = now & 7;
-      int fn = fn0 + (now >> 3);                            // (fn0 < gHyperframe, n_slots < 8 gHyperframe: trxsig_trxgroup_push checks)
-      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
-      fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
-      cidx[kk][j] = (uint16_t)(tx_fn_mod(fn, md[kk][tn], mdr[kk][tn]) * 8 + tn);
+  if (WALK) {
+    // ================= pushRadioVector for n_slots timeslots =================
+    // wave k walks ARFCN a0 + k; what it keeps between the turns (the same in every lane):
+    const int k = __builtin_amdgcn_readfirstlane(tid >> 6), a = a0 + k;
+    const bool walker = a < x.S;
+    const bool writer = (tid & 63) == 0;                      // (one lane stores; all of them compute)
+    TrxqPk *row = &q[k][0];
+    int16_t *flk = &fl[k][0];
+    int n_q = nq[k], n_f = nf[k];
+    const int is_far = far;
+    TrxqPk top = 0, last = 0, c[6] = {0, 0, 0, 0, 0, 0};
+    // a queue of at most 64 entries is walked across the wave's lanes (tx_lane_pop), a longer one in LDS (tx_heap_pop): a walk only pops
+    const bool lanes = walker && !is_far && n_q <= 64;
+    TrxqPk hv = 0;
+    if (lanes) {
+      hv = row[tid & 63];                                     // (entries past the queue's end: whatever the row holds, never looked at)
+      top = __builtin_amdgcn_readlane(hv, 0);
+    } else if (walker && !is_far && n_q > 0) {
+      top = row[0]; last = row[n_q - 1];
+  #pragma unroll
+      for (int i = 0; i < 6; i++) c[i] = row[1 + i];
     }
-    __syncthreads();
-    if (walker && !is_far) {
-      int cell = cidx[k][0];
-      int pid = flk[cell];                                  // the filler entry of the slot (:175-177), read ahead
-      for (int j = 0; j < nt; j++) {
-        const int t = t0 + j, now = tn0 + t;                // (packed relative to fn0: the time of this slot IS tn0 + t)
-        const int cell_next = cidx[k][j + 1];
-        int fq = 0;
-        bool reread = false;
-        while (n_q > 0) {
-          const int tk = trxq_pk_time(top);
-          if (tk > now) break;
-          TrxqPk e;
-          { TX_ACC_BEGIN(); n_q = lanes ? tx_lane_pop(hv, n_q, top, e) : tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
-          if (tk == now) {                                  // the burst for exactly this slot (:159-173): it replaces the filler entry and goes out
-            const int old = reread ? (int)flk[cell] : pid;
-            if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
-            pid = trxq_pk_id(e);
-            flk[cell] = (int16_t)pid;
-            reread = false;
-            fq = 1;
-            break;
-          }
-          // a stale burst: "even if the burst is stale, put it in the filler table" (:142-153), [FN % modulus][TN] of ITS time
-          const int etn = trxq_pk_tn(e);
-          const int ecell = tx_fn_mod(trxq_pk_fn(e, fn0), md[k][etn], mdr[k][etn]) * 8 + etn;
-          const int old = flk[ecell];
-          if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
-          flk[ecell] = (int16_t)trxq_pk_id(e);
-          reread = reread || ecell == cell;
-        }
-        if (reread) pid = flk[cell];
-        if (writer) { opid[k][j] = (int16_t)pid; ofq[k][j] = (uint8_t)fq; }
-        cell = cell_next;
-        pid = flk[cell];                                    // (after this slot's writes: LDS keeps a wave's order)
+    const TrxqView gq = {x.q_fn + a, x.q_key + a, x.S};       // (the slow path: the queue where it lives)
+    TX_ACC_DECL();
+    for (int t0 = 0; t0 < n_slots; t0 += kTxWalk) {
+      const int nt = min(kTxWalk, n_slots - t0);
+      for (int i = tid; i < kTxP * (nt + 1); i += NT) {       // the filler cell of every slot of the turn: [FN % modulus][TN]
+        const int kk = i & (kTxP - 1), j = i / kTxP, now = tn0 + t0 + j, tn = now & 7;
+        int fn = fn0 + (now >> 3);                            // (fn0 < gHyperframe, n_slots < 8 gHyperframe: trxsig_trxgroup_push checks)
+        fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+        fn -= fn >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+        cidx[kk][j] = (uint16_t)(tx_fn_mod(fn, md[kk][tn], mdr[kk][tn]) * 8 + tn);
       }
-    } else if (walker) {
-      // the slow path: trxsig_txq.h's moves on the arrays in memory, a dependent access a move (lane 0 alone: the moves store)
-      if (writer)
+      __syncthreads();
+      if (walker && !is_far) {
+        int cell = cidx[k][0];
+        int pid = flk[cell];                                  // the filler entry of the slot (:175-177), read ahead
         for (int j = 0; j < nt; j++) {
-          const int t = t0 + j, tn = (tn0 + t) & 7;
-          int fnc = fn0 + ((tn0 + t) >> 3);
-          fnc -= fnc >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
-          fnc -= fnc >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+          const int t = t0 + j, now = tn0 + t;                // (packed relative to fn0: the time of this slot IS tn0 + t)
+          const int cell_next = cidx[k][j + 1];
           int fq = 0;
+          bool reread = false;
           while (n_q > 0) {
-            const int32_t tfn = gq.f(0), tkey = gq.k(0);
-            const bool stale = trxq_time_lt(tfn, tkey & 7, fnc, tn), hit = tfn == fnc && (tkey & 7) == tn;
-            if (!stale && !hit) break;
-            int32_t efn, ekey;
-            n_q = trxq_pop(gq, n_q, &efn, &ekey);
-            const int etn = ekey & 7;
-            int16_t *cl = &flk[(efn % md[k][etn]) * 8 + etn];
-            tx_free(x, a, n_f, *cl);
-            *cl = (int16_t)(ekey >> 3);
-            if (!stale) { fq = 1; break; }
+            const int tk = trxq_pk_time(top);
+            if (tk > now) break;
+            TrxqPk e;
+            { TX_ACC_BEGIN(); n_q = lanes ? tx_lane_pop(hv, n_q, top, e) : tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
+            if (tk == now) {                                  // the burst for exactly this slot (:159-173): it replaces the filler entry and goes out
+              const int old = reread ? (int)flk[cell] : pid;
+              if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
+              pid = trxq_pk_id(e);
+              flk[cell] = (int16_t)pid;
+              reread = false;
+              fq = 1;
+              break;
+            }
+            // a stale burst: "even if the burst is stale, put it in the filler table" (:142-153), [FN % modulus][TN] of ITS time
+            const int etn = trxq_pk_tn(e);
+            const int ecell = tx_fn_mod(trxq_pk_fn(e, fn0), md[k][etn], mdr[k][etn]) * 8 + etn;
+            const int old = flk[ecell];
+            if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
+            flk[ecell] = (int16_t)trxq_pk_id(e);
+            reread = reread || ecell == cell;
           }
-          opid[k][j] = flk[cidx[k][j]];
-          ofq[k][j] = (uint8_t)fq;
+          if (reread) pid = flk[cell];
+          if (writer) { opid[k][j] = (int16_t)pid; ofq[k][j] = (uint8_t)fq; }
+          cell = cell_next;
+          pid = flk[cell];                                    // (after this slot's writes: LDS keeps a wave's order)
         }
-      n_q = __builtin_amdgcn_readfirstlane(n_q); n_f = __builtin_amdgcn_readfirstlane(n_f);
+      } else if (walker) {
+        // the slow path: trxsig_txq.h's moves on the arrays in memory, a dependent access a move (lane 0 alone: the moves store)
+        if (writer)
+          for (int j = 0; j < nt; j++) {
+            const int t = t0 + j, tn = (tn0 + t) & 7;
+            int fnc = fn0 + ((tn0 + t) >> 3);
+            fnc -= fnc >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+            fnc -= fnc >= TRXQ_HYPERFRAME ? TRXQ_HYPERFRAME : 0;
+            int fq = 0;
+            while (n_q > 0) {
+              const int32_t tfn = gq.f(0), tkey = gq.k(0);
+              const bool stale = trxq_time_lt(tfn, tkey & 7, fnc, tn), hit = tfn == fnc && (tkey & 7) == tn;
+              if (!stale && !hit) break;
+              int32_t efn, ekey;
+              n_q = trxq_pop(gq, n_q, &efn, &ekey);
+              const int etn = ekey & 7;
+              int16_t *cl = &flk[(efn % md[k][etn]) * 8 + etn];
+              tx_free(x, a, n_f, *cl);
+              *cl = (int16_t)(ekey >> 3);
+              if (!stale) { fq = 1; break; }
+            }
+            opid[k][j] = flk[cidx[k][j]];
+            ofq[k][j] = (uint8_t)fq;
+          }
+        n_q = __builtin_amdgcn_readfirstlane(n_q); n_f = __builtin_amdgcn_readfirstlane(n_f);
+      }
+      __syncthreads();
+      // ---- the turn's output: the referenced payloads into the layout trxsig_txbe_push_bursts takes -- bits_out [S][n_slots][148],
+      //      gain_out / fq_out [S][n_slots] -- a (slot, ARFCN) cell a thread, its 152 bytes in flight at once.  (A separate kernel until
+      //      round 5: a launch more on the chain the next batch's ingest waits for.) ----
+      for (int i = tid; i < kTxP * nt; i += NT) {
+        const int kk = i / nt, j = i - kk * nt, aa = a0 + kk;
+        if (aa >= x.S) continue;
+        const int pid = opid[kk][j];
+        const uint32_t *src = pid < 0 ? x.dummy : x.pool + ((size_t)aa * x.npool + pid) * TRXG_PAYLOAD_WORDS;
+        uint32_t v[TRXG_PAYLOAD_WORDS];
+  #pragma unroll
+        for (int w = 0; w < 36; w += 4) __builtin_memcpy(&v[w], src + w, 16);
+        __builtin_memcpy(&v[36], src + 36, 8);
+        const size_t cell = (size_t)aa * n_slots + (t0 + j);
+        uint32_t *dst = bits_out + cell * 37;
+  #pragma unroll
+        for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);
+        dst[36] = v[36];
+        gain_out[cell] = __uint_as_float(v[37]);
+        fq_out[cell] = ofq[kk][j];
+      }
     }
-    __syncthreads();
-    // ---- the turn's output: the referenced payloads into the layout trxsig_txbe_push_bursts takes -- bits_out [S][n_slots][148],
-    //      gain_out / fq_out [S][n_slots] -- a (slot, ARFCN) cell a thread, its 152 bytes in flight at once.  (A separate kernel until
-    //      round 5: a launch more on the chain the next batch's ingest waits for.) ----
-    for (int i = tid; i < kTxP * nt; i += NT) {
-      const int kk = i / nt, j = i - kk * nt, aa = a0 + kk;
-      if (aa >= x.S) continue;
-      const int pid = opid[kk][j];
-      const uint32_t *src = pid < 0 ? x.dummy : x.pool + ((size_t)aa * x.npool + pid) * TRXG_PAYLOAD_WORDS;
-      uint32_t v[TRXG_PAYLOAD_WORDS];
-#pragma unroll
-      for (int w = 0; w < 36; w += 4) __builtin_memcpy(&v[w], src + w, 16);
-      __builtin_memcpy(&v[36], src + 36, 8);
-      const size_t cell = (size_t)aa * n_slots + (t0 + j);
-      uint32_t *dst = bits_out + cell * 37;
-#pragma unroll
-      for (int w = 0; w < 36; w += 4) __builtin_memcpy(dst + w, &v[w], 16);
-      dst[36] = v[36];
-      gain_out[cell] = __uint_as_float(v[37]);
-      fq_out[cell] = ofq[kk][j];
-    }
+    if (lanes && (int)(tid & 63) < n_q) row[tid & 63] = hv;   // the queue back to its row
+    if (walker && writer) { nq[k] = n_q; nf[k] = n_f; }
+
+    TX_ACC_OUT(1);
   }
-  if (lanes && (int)(tid & 63) < n_q) row[tid & 63] = hv;   // the queue back to its row
-  if (walker && writer) { nq[k] = n_q; nf[k] = n_f; }
   TX_STAMP(1, 2);
-  TX_ACC_OUT(1);
   __syncthreads();
-  if (!far) tx_queues_store<kTxP>(x, a0, q, nq, fn0);
-  {
+  if (!far) tx_queues_store<kTxI>(x, a0, q, nq, ref);
+  if (WALK) {
     const int kk = tid & (kTxP - 1);
     if (a0 + kk < x.S)
       for (int c2 = tid / kTxP; c2 < kTxCells; c2 += NT / kTxP) x.filler[(size_t)c2 * x.S + a0 + kk] = fl[kk][c2];
   }
-  if (tid < kTxP && a0 + tid < x.S) {
+  if (tid < kTxI && a0 + tid < x.S) {
     x.q_n[a0 + tid] = nq[tid];
     x.free_n[a0 + tid] = nf[tid];
+    if (INGEST && st_[tid]) x.status[a0 + tid] |= 1u;
   }
-  TX_STAMP(1, 3);
+  TX_STAMP(WALK ? 1 : 0, WALK ? 3 : 6);
 }
 
 }  // namespace
@@ -570,8 +570,8 @@ hipError_t trx_launch_group_tx_ingest(hipStream_t st, const TrxGroupTx &x, int n
   if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;   // (the kernel's LDS copy of a queue, a packed entry's id field)
   TxGainTab gt;
   for (int q = 0; q < 26; q++) gt.v[q] = gain_tab26[q];
-  k_group_tx_ingest<<<dim3((x.S + kTxI - 1) / kTxI), dim3(64 * kTxI), 0, st>>>(x, n, dgram, tx_arrive_args(n, (int32_t *)a_lf, (int32_t *)a_lk, (int32_t *)a_tot), gt, ref_fn,
-                                                                          far);
+  k_group_tx<true, false><<<dim3((x.S + kTxI - 1) / kTxI), dim3(64 * kTxI), 0, st>>>(
+      x, n, dgram, tx_arrive_args(n, (int32_t *)a_lf, (int32_t *)a_lk, (int32_t *)a_tot), gt, ref_fn, 0, 0, 0, nullptr, nullptr, nullptr, far);
   return hipGetLastError();
 }
 
@@ -580,6 +580,24 @@ hipError_t trx_launch_group_tx_push(hipStream_t st, const TrxGroupTx &x, int fn0
   if (n_slots <= 0) return hipSuccess;
   if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;
   const int far = (long long)tn0 + n_slots >= 8LL * TRXQ_PK_WIN;    // the walk's own times must fit the packed form
-  k_group_tx_push<<<dim3((x.S + kTxP - 1) / kTxP), dim3(64 * kTxP), 0, st>>>(x, fn0, tn0, n_slots, (uint32_t *)bits_out, gain_out, fq_out, far);
+  TxGainTab gt = {};
+  TxArrive ar = {};
+  k_group_tx<false, true><<<dim3((x.S + kTxI - 1) / kTxI), dim3(64 * kTxI), 0, st>>>(x, 0, nullptr, ar, gt, 0, fn0, tn0, n_slots, (uint32_t *)bits_out, gain_out,
+                                                                                   fq_out, far);
+  return hipGetLastError();
+}
+
+// both in one launch: the add call's ingest (its lists as left by trx_launch_group_tx_arrive) and then the push.  The packed entries are
+// relative to fn0: the caller has seen to it that every datagram of the add call lies within TRXQ_PK_WIN frames of fn0 (else far).
+hipError_t trx_launch_group_tx_both(hipStream_t st, const TrxGroupTx &x, int n, const uint8_t *dgram, const int32_t *a_lf, const int32_t *a_lk,
+                                    const int32_t *a_tot, const float *gain_tab26, int far_add, int fn0, int tn0, int n_slots, uint8_t *bits_out,
+                                    float *gain_out, uint8_t *fq_out) {
+  if (n <= 0 || n_slots <= 0) return hipErrorInvalidValue;
+  if (x.qcap != kTxQ || x.npool > TRXQ_PK_IDS) return hipErrorInvalidValue;
+  const int far = far_add || (long long)tn0 + n_slots >= 8LL * TRXQ_PK_WIN;
+  TxGainTab gt;
+  for (int q = 0; q < 26; q++) gt.v[q] = gain_tab26[q];
+  k_group_tx<true, true><<<dim3((x.S + kTxI - 1) / kTxI), dim3(64 * kTxI), 0, st>>>(
+      x, n, dgram, tx_arrive_args(n, (int32_t *)a_lf, (int32_t *)a_lk, (int32_t *)a_tot), gt, fn0, fn0, tn0, n_slots, (uint32_t *)bits_out, gain_out, fq_out, far);
   return hipGetLastError();
 }

@@ -115,25 +115,32 @@ struct trxsig_trxgroup {
   // one of TWO output sets in turn and waits for whatever the context's stream had been given when the push before it was called
   // (the output's contract: valid until the next push); a staging set is handed out again when its upload and the ingest that read
   // it have run (the host waits there: that is where it is held back when the device is more than a batch behind).
-  DevBuf<int32_t> tx_arfcn[2], tx_alf[2], tx_alk[2], tx_atot[2];   // (+ what k_group_tx_arrive leaves for k_group_tx_ingest, per set)
-  DevBuf<uint8_t> tx_dgram[2];
+  static constexpr int kTxSets = 3;  // staging sets in turn: the host fills set i + 2 while set i's ingest runs (with two, the upload + arrival chain of a
+                                     // batch -- ~100 us from the staging call to the arrival kernel's end -- could only start when the batch two before it was through)
+  DevBuf<int32_t> tx_arfcn[kTxSets], tx_alf[kTxSets], tx_alk[kTxSets], tx_atot[kTxSets];   // (+ what k_group_tx_arrive leaves for k_group_tx_ingest, per set)
+  DevBuf<uint8_t> tx_dgram[kTxSets];
   hipStream_t tx_up = nullptr, tx_q = nullptr;
-  hipEvent_t tx_q_ev = nullptr, tx_out_ev[2] = {nullptr, nullptr}, tx_read_ev[2] = {nullptr, nullptr};
-  bool tx_q_armed = false, tx_out_armed[2] = {false, false}, tx_read_armed[2] = {false, false};
+  hipEvent_t tx_q_ev = nullptr, tx_out_ev[2] = {nullptr, nullptr}, tx_read_ev[kTxSets] = {};
+  bool tx_q_armed = false, tx_out_armed[2] = {false, false}, tx_read_armed[kTxSets] = {};
   hipEvent_t tx_q_last = nullptr;    // the event behind the queues' stream's latest work (an ingest's tx_read_ev or a walk's tx_q_ev): one record per kernel
   unsigned tx_pushes = 0;
-  uint8_t *tx_pin[2] = {nullptr, nullptr};   // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), two in turn
-  int tx_pin_cap[2] = {0, 0};
+  // an add call's ingest is left PENDING (its upload and arrival kernel are under way): the push that usually follows takes it into
+  // its own launch (trx_launch_group_tx_both); anything else that needs the queues -- another add, a queue-size query, the end --
+  // launches it on its own first (tx_flush_pending)
+  bool tx_pend = false;
+  int tx_pend_k = 0, tx_pend_n = 0, tx_pend_ref = 0, tx_pend_far = 0;
+  uint8_t *tx_pin[kTxSets] = {};     // pinned staging blocks the caller receives into (trxsig_trxgroup_tx_staging), in turn
+  int tx_pin_cap[kTxSets] = {};
   bool tx_stage_held = false;        // the current set has been handed out and not yet added
   DevBuf<uint8_t> tx_bits[2], tx_fq[2];
   DevBuf<float> tx_gain[2];
-  // host staging of an add call: two sets in turn, each guarded by an event recorded behind its uploads -- a set is refilled only
+  // host staging of an add call: kTxSets sets in turn, each guarded by an event recorded behind its uploads -- a set is refilled only
   // when the copies that read it have run (the library does not rely on pageable hipMemcpyAsync being synchronous)
   std::vector<uint8_t> h_fmod;
   hipEvent_t tx_fm_ev = nullptr;
   bool tx_fm_armed = false;
-  hipEvent_t tx_ev[2] = {nullptr, nullptr};
-  bool tx_ev_armed[2] = {false, false};
+  hipEvent_t tx_ev[kTxSets] = {};
+  bool tx_ev_armed[kTxSets] = {};
   int tx_set = 0;
   float gain_tab[26] = {0};                                 // pow(10, q), q = -12..13: every value -RSSI/10 of a signed char can take
 };
@@ -249,17 +256,17 @@ void trxsig_trxgroup_destroy(trxsig_trxgroup *g) {
       (void)hipFree(g->tx.free_n); (void)hipFree(g->tx.filler); (void)hipFree(g->tx.fmod); (void)hipFree(g->tx.pool);
       (void)hipFree(g->tx.status); (void)hipFree(g->d_dummy);
     }
-    for (int k = 0; k < 2; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
+    for (int k = 0; k < trxsig_trxgroup::kTxSets; k++) if (g->tx_ev[k]) (void)hipEventDestroy(g->tx_ev[k]);
     if (g->tx_fm_ev) (void)hipEventDestroy(g->tx_fm_ev);
     if (g->tx_up) { (void)hipStreamSynchronize(g->tx_up); (void)hipStreamDestroy(g->tx_up); }
     if (g->tx_q) { (void)hipStreamSynchronize(g->tx_q); (void)hipStreamDestroy(g->tx_q); }
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < trxsig_trxgroup::kTxSets; k++) {
       g->tx_arfcn[k].release(); g->tx_dgram[k].release(); g->tx_alf[k].release(); g->tx_alk[k].release(); g->tx_atot[k].release();
       if (g->tx_read_ev[k]) (void)hipEventDestroy(g->tx_read_ev[k]);
-      if (g->tx_out_ev[k]) (void)hipEventDestroy(g->tx_out_ev[k]);
     }
+    for (int k = 0; k < 2; k++) if (g->tx_out_ev[k]) (void)hipEventDestroy(g->tx_out_ev[k]);
     if (g->tx_q_ev) (void)hipEventDestroy(g->tx_q_ev);
-    for (int k = 0; k < 2; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
+    for (int k = 0; k < trxsig_trxgroup::kTxSets; k++) if (g->tx_pin[k]) (void)hipHostFree(g->tx_pin[k]);
     for (int k = 0; k < 2; k++) { g->tx_bits[k].release(); g->tx_fq[k].release(); g->tx_gain[k].release(); }
   }
   trx_ctx_release(g->c);
@@ -745,7 +752,7 @@ int tx_setup(trxsig_trxgroup *g) {
   x.dummy = g->d_dummy;
   // scaleVector(*modBurst, pow(10, -RSSI/10)) (:108): integer division, pow in double, the scale a Complex<float>
   for (int q = -12; q <= 13; q++) g->gain_tab[q + 12] = (float)std::pow(10, q);
-  for (int k = 0; k < 2; k++) G_HIP(g, hipEventCreateWithFlags(&g->tx_ev[k], hipEventDisableTiming));
+  for (int k = 0; k < trxsig_trxgroup::kTxSets; k++) G_HIP(g, hipEventCreateWithFlags(&g->tx_ev[k], hipEventDisableTiming));
   G_HIP(g, hipEventCreateWithFlags(&g->tx_fm_ev, hipEventDisableTiming));
 
   g->tx_ready = true;
@@ -755,7 +762,7 @@ int tx_setup(trxsig_trxgroup *g) {
 
 // the next host staging set, free to be refilled (its previous uploads have run)
 int tx_take_set(trxsig_trxgroup *g, int *k) {
-  *k = g->tx_set ^= 1;
+  *k = g->tx_set = (g->tx_set + 1) % trxsig_trxgroup::kTxSets;
   if (g->tx_ev_armed[*k]) { G_HIP(g, hipEventSynchronize(g->tx_ev[*k])); g->tx_ev_armed[*k] = false; }
   // ... and its device arrays: free when the ingest that read them two calls ago has run (here the host is held back when the
   // device is more than a batch behind)
@@ -773,10 +780,8 @@ int tx_streams(trxsig_trxgroup *g) {
   G_HIP(g, hipStreamCreateWithFlags(&g->tx_up, hipStreamNonBlocking));
   G_HIP(g, hipStreamCreateWithFlags(&g->tx_q, hipStreamNonBlocking));
   G_HIP(g, hipEventCreateWithFlags(&g->tx_q_ev, hipEventDisableTiming));
-  for (int j = 0; j < 2; j++) {
-    G_HIP(g, hipEventCreateWithFlags(&g->tx_read_ev[j], hipEventDisableTiming));
-    G_HIP(g, hipEventCreateWithFlags(&g->tx_out_ev[j], hipEventDisableTiming));
-  }
+  for (int j = 0; j < trxsig_trxgroup::kTxSets; j++) G_HIP(g, hipEventCreateWithFlags(&g->tx_read_ev[j], hipEventDisableTiming));
+  for (int j = 0; j < 2; j++) G_HIP(g, hipEventCreateWithFlags(&g->tx_out_ev[j], hipEventDisableTiming));
   return TRXSIG_OK;
 }
 // "the queues' stream has run up to here": ONE event record behind every kernel of that stream (each record, each wait is a packet
@@ -789,6 +794,25 @@ int tx_q_mark(trxsig_trxgroup *g, hipEvent_t ev) {
 }
 int tx_join(trxsig_trxgroup *g, hipStream_t st) {
   if (g->tx_q_armed) { G_HIP(g, hipStreamWaitEvent(st, g->tx_q_last, 0)); g->tx_q_armed = false; }
+  return TRXSIG_OK;
+}
+// the queues' stream behind set k's upload and arrival kernel (spared when they have run)
+int tx_wait_arrival(trxsig_trxgroup *g, int k) {
+  const bool ran = hipEventQuery(g->tx_ev[k]) == hipSuccess;
+  (void)hipGetLastError();                                  // (hipErrorNotReady is an answer, not an error to be found by the next launch check)
+  if (!ran) G_HIP(g, hipStreamWaitEvent(g->tx_q, g->tx_ev[k], 0));
+  return TRXSIG_OK;
+}
+// the pending ingest as a launch of its own
+int tx_flush_pending(trxsig_trxgroup *g) {
+  if (!g->tx_pend) return TRXSIG_OK;
+  const int k = g->tx_pend_k;
+  g->tx_pend = false;
+  G_LIB(tx_wait_arrival(g, k));
+  G_HIP(g, trx_launch_group_tx_ingest(g->tx_q, g->tx, g->tx_pend_n, g->tx_dgram[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p, g->gain_tab,
+                                      g->tx_pend_ref, g->tx_pend_far));
+  G_LIB(tx_q_mark(g, g->tx_read_ev[k]));                   // (the set's device arrays are free behind it; the context's stream joins on it)
+  g->tx_read_armed[k] = true;
   return TRXSIG_OK;
 }
 // fillerModulus[TN] of every ARFCN (setModulus, :183-204) after a SETSLOT (rare: its own host staging vector, waited for before it is refilled)
@@ -853,7 +877,8 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
     if (a < 0 || a >= S || tn < 0 || tn > 7 || fn >= (uint32_t)kHyperframe)
       return trx_ctx_fail(c, TRXSIG_EINVAL, "trxsig_trxgroup_add_bursts: ARFCN, timeslot or frame number out of range (nothing was queued)", hipSuccess);
     if (i == 0) ref_fn = (int)fn;
-    far |= !trxq_pk_ok((int32_t)fn, ref_fn);
+    const int32_t dd = trxq_fn_delta((int32_t)fn, ref_fn);  // (half the packed entries' window: the push that takes this ingest into its launch
+    far |= dd < -TRXQ_PK_WIN / 2 || dd >= TRXQ_PK_WIN / 2;  //  may start up to the other half away from ref_fn)
   }
   G_LIB(tx_streams(g));                                     // (the filler moduli are the walk's business: trxsig_trxgroup_push uploads them)
   hipStream_t up = g->tx_up, q = g->tx_q;
@@ -869,10 +894,9 @@ static int tx_add_staged(trxsig_trxgroup *g, int n) {
   G_HIP(g, trx_launch_group_tx_arrive(up, S, n, g->tx_dgram[k].p, g->tx_arfcn[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p));
   G_LIB(tx_seal_set(g, k, up));                             // (the pinned set is the DMA's until this event has passed: the next staging call takes the other)
   g->tx_stage_held = false;
-  G_HIP(g, hipStreamWaitEvent(q, g->tx_ev[k], 0));
-  G_HIP(g, trx_launch_group_tx_ingest(q, g->tx, n, g->tx_dgram[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p, g->gain_tab, ref_fn, far));
-  G_LIB(tx_q_mark(g, g->tx_read_ev[k]));                   // (the set's device arrays are free behind it; the context's stream joins on it)
-  g->tx_read_armed[k] = true;
+  (void)q;
+  G_LIB(tx_flush_pending(g));                               // (an add behind an add: the earlier one's ingest goes first)
+  g->tx_pend = true; g->tx_pend_k = k; g->tx_pend_n = n; g->tx_pend_ref = ref_fn; g->tx_pend_far = far;
   return TRXSIG_OK;
 }
 
@@ -929,8 +953,22 @@ int trxsig_trxgroup_push(trxsig_trxgroup *g, int fn, int tn, int n_slots, const 
   const size_t cells = (size_t)n_slots * g->S;
   G_HIP(g, g->tx_bits[o].need(cells * 148, q));
   G_HIP(g, g->tx_gain[o].need(cells, q)); G_HIP(g, g->tx_fq[o].need(cells, q));
-  G_HIP(g, trx_launch_group_tx_push(q, g->tx, fn, tn, n_slots, g->tx_bits[o].p, g->tx_gain[o].p, g->tx_fq[o].p));
-  G_LIB(tx_q_mark(g, g->tx_q_ev));
+  // an add call's ingest still pending, and its datagrams near this push's start (all of them then lie inside the packed entries'
+  // window round fn): ingest and walk are ONE launch; else the ingest goes first on its own
+  const int32_t dref = g->tx_pend ? trxq_fn_delta(g->tx_pend_ref, fn) : 0;
+  if (g->tx_pend && dref >= -TRXQ_PK_WIN / 2 && dref < TRXQ_PK_WIN / 2) {
+    const int k = g->tx_pend_k;
+    g->tx_pend = false;
+    G_LIB(tx_wait_arrival(g, k));
+    G_HIP(g, trx_launch_group_tx_both(q, g->tx, g->tx_pend_n, g->tx_dgram[k].p, g->tx_alf[k].p, g->tx_alk[k].p, g->tx_atot[k].p, g->gain_tab,
+                                      g->tx_pend_far, fn, tn, n_slots, g->tx_bits[o].p, g->tx_gain[o].p, g->tx_fq[o].p));
+    G_LIB(tx_q_mark(g, g->tx_read_ev[k]));
+    g->tx_read_armed[k] = true;
+  } else {
+    G_LIB(tx_flush_pending(g));
+    G_HIP(g, trx_launch_group_tx_push(q, g->tx, fn, tn, n_slots, g->tx_bits[o].p, g->tx_gain[o].p, g->tx_fq[o].p));
+    G_LIB(tx_q_mark(g, g->tx_q_ev));
+  }
   G_LIB(tx_join(g, st));                                    // the caller reads the output on the context's stream
   if (d_bits) *d_bits = g->tx_bits[o].p;
   if (d_gain) *d_gain = g->tx_gain[o].p;
@@ -964,6 +1002,7 @@ int trxsig_trxgroup_tx_queue_size(trxsig_trxgroup *g, int arfcn, int *dropped) {
   Guard gd(trxsig_device(g->c));
   hipStream_t st = (hipStream_t)trxsig_get_stream(g->c);
   int32_t n = 0; uint32_t stt = 0;
+  G_LIB(tx_flush_pending(g));
   G_LIB(tx_join(g, st));
   G_HIP(g, hipMemcpyAsync(&n, g->tx.q_n + arfcn, 4, hipMemcpyDeviceToHost, st));
   G_HIP(g, hipMemcpyAsync(&stt, g->tx.status + arfcn, 4, hipMemcpyDeviceToHost, st));

@@ -60,8 +60,8 @@ int main(int argc, char **argv) {
     d[0] = (uint8_t)tn[perm[i]]; d[5] = (uint8_t)(rng() % 30);
     for (int b = 0; b < 148; b++) d[6 + b] = (uint8_t)(rng() & 1);
   }
-  int fn = 1000, filled[2] = {0, 0};
-  uint8_t *seen[2] = {nullptr, nullptr};
+  int fn = 1000, filled[4] = {0, 0, 0, 0};
+  uint8_t *seen[4] = {nullptr, nullptr, nullptr, nullptr};
   double t_stage = 0, t_recv = 0, t_add = 0, t_push = 0, t_pop = 0, t0 = 0;
   int n_out = 0;
   for (int it = 0; it < K + 10; it++) {
@@ -71,9 +71,9 @@ int main(int argc, char **argv) {
     OK(trxsig_trxgroup_tx_staging(grp, n, &d, &ar));
     const double a1 = now_us();
     int k = -1;
-    for (int j = 0; j < 2; j++) if (seen[j] == d) k = j;
-    if (k < 0) { k = seen[0] ? 1 : 0; seen[k] = d; filled[k] = 0; }
-    if (!filled[k]) {                                       // (two blocks alternate: the payloads are the same every step, written once per block)
+    for (int j = 0; j < 4; j++) if (seen[j] == d) k = j;
+    if (k < 0) { k = 0; while (k < 3 && seen[k]) k++; seen[k] = d; filled[k] = 0; }
+    if (!filled[k]) {                                       // (a few blocks take turns: the payloads are the same every step, written once per block)
       std::memcpy(d, base.data(), base.size());
       for (int i = 0; i < n; i++) ar[i] = arf[perm[i]];
       filled[k] = 1;
