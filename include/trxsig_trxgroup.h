@@ -151,8 +151,9 @@ int trxsig_trxgroup_add_bursts(trxsig_trxgroup *g, const uint8_t *h_datagrams, c
  * (*h_datagrams)[154 i], the socket's ARFCN into (*h_arfcn)[i], i < n_max -- and trxsig_trxgroup_add_staged(g, n) adds its first n
  * datagrams: the host only checks the headers (the refusal rule above), the block goes up in one DMA as it arrived, and parsing
  * (TN, big-endian FN, RSSI -> pow(10, -RSSI/10) with the integer division), the per-ARFCN sort that keeps the arrival order, the
- * queue insertion and the payload copies are two kernels (k_group_tx_arrive behind the upload, k_group_tx_ingest on the queues'
- * stream).  Three blocks take turns: after add_staged the
+ * queue insertion and the payload copies are the device's: a kernel behind the upload (k_group_tx_arrive), and the queues' kernel --
+ * whose launch is left to the call that next needs the queues: the trxsig_trxgroup_push that follows takes the insertions into its own
+ * launch (the usual order of a transmit loop; results do not depend on it), another add or trxsig_trxgroup_tx_queue_size launch them first.  Three blocks take turns: after add_staged the
  * pointers are the DMA's; ask again for the next batch (the call waits, if it must, for the upload and the ingest that last used
  * that block's set: that is where a host is held back when the device is more than a batch behind).
  * trxsig_trxgroup_add_bursts is this with a copy into the block first.

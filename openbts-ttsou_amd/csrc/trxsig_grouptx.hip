@@ -5,17 +5,20 @@
 //                       their ARFCN ids, as they arrived -- everything that needs no queue state, so it runs on the uploads' stream: a
 //                       workgroup owns sixteen ARFCNs, finds its datagrams (a stable counting sort by wave ballots: arrival order is
 //                       kept inside an ARFCN) and parses TN / big-endian FN / RSSI into per-ARFCN lists;
-//   k_group_tx_ingest : addRadioVector (:100-113) for those lists: WAVE k enters ARFCN k's bursts in its queue -- the queue sits in LDS
+//   k_group_tx<INGEST, WALK> : the queues' kernel, a workgroup of four waves for four ARFCNs, in three forms -- the add call's part
+//                       alone, the push's alone, or both in one launch (the add call's part stays pending until the push that follows):
+//     INGEST            addRadioVector (:100-113) for those lists: WAVE k enters ARFCN k's bursts in its queue -- the queue sits in LDS
 //                       for the duration, one word an entry (trxsig_txq_lds.h: std::priority_queue's moves, comparisons as integer
 //                       comparisons), the payload slots to hand out fetched ahead -- while a thread per burst copies the payload (148
 //                       bits + gain) to its slot;
-//   k_group_tx_push   : a WAVE per ARFCN walks n_slots timeslots, every value uniform across its lanes (scalar branches): stale
-//                       entries leave the queue for the filler table, the entry for exactly this time (if any) replaces the filler
-//                       entry and goes out, else the filler entry goes out (:142-177) -- as payload REFERENCES, nothing is copied on
-//                       the serial path; queues AND filler tables are in LDS for the walk (round 4: a dependent global access per
-//                       queue move and per slot was the whole kernel); at the end of every turn of the walk the referenced payloads
-//                       are copied into the layout trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n] gains): what the fused
-//                       transmit back end then modulates, resamples and packs to int16.
+//     WALK              pushRadioVector: WAVE k walks ARFCN k's n_slots timeslots, every value uniform across its lanes (scalar
+//                       branches): stale entries leave the queue for the filler table, the entry for exactly this time (if any)
+//                       replaces the filler entry and goes out, else the filler entry goes out (:142-177) -- as payload REFERENCES,
+//                       nothing is copied on the serial path; queues AND filler tables are in LDS for the walk (round 4: a dependent
+//                       global access per queue move and per slot was the whole kernel); a queue of at most 64 entries is popped
+//                       ACROSS the wave's lanes (tx_lane_pop); at the end of every turn of the walk the referenced payloads are copied
+//                       into the layout trxsig_txbe_push_bursts takes ([S][n][148] bits, [S][n] gains): what the fused transmit back
+//                       end then modulates, resamples and packs to int16.
 // A queue holding a burst 2^17 frames or more from the call's own frame cannot be said in one-word entries: its workgroup works on the
 // arrays in memory with trxsig_txq.h's moves instead (the slow path: same results).
 // What is kept per burst is its bits and its gain, never its modulated samples: modulateBurst + scaleVector of the same bits

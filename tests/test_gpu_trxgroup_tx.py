@@ -337,3 +337,47 @@ def test_one_add_of_twenty_frames_then_one_push(pkg):
     for a in (0, 63, 127):
         assert grp.tx_queue_size(a) == (0, False)
     grp.close(); ctx.close()
+
+
+def test_pending_ingest_taken_into_the_push_or_launched_alone(pkg):
+    """An add call's ingest stays pending until the push that follows takes it into its own launch (k_group_tx<true, true>); another
+    add, a queue-size query or a push that starts far from the datagrams' frames launch it on its own first.  Same datagrams four
+    ways -- add + push (one launch); add + add (the halves) + push; add + tx_queue_size + push; add + a push 70,000 frames earlier
+    (too far to share the launch: nothing is due, everything stays queued) + the real push -- must hand out the same bits, gains and
+    from-queue marks and leave the same queues."""
+    import torch
+    rng = np.random.default_rng(41)
+    S, F, fn0 = 24, 6, 90000
+    ctx = pkg.TrxSig(1, 0); ctx.use_torch_stream()
+    groups = [pkg.TrxGroup(ctx, S, tsc_leg=pkg.TSCLEG_DEMOD) for _ in range(4)]
+    for g in groups:
+        for a in range(S):
+            configure(lambda c, a=a: g.control(a, c), a)
+    n = S * 8 * F
+    arf = rng.integers(0, S, n).astype(np.int32)
+    fn = fn0 + rng.integers(-2, F + 2, n)                   # some stale, some beyond the frames pushed
+    dg = np.zeros((n, 154), np.uint8)
+    dg[:, 0] = rng.integers(0, 8, n)
+    dg[:, 1] = fn >> 24; dg[:, 2] = (fn >> 16) & 255; dg[:, 3] = (fn >> 8) & 255; dg[:, 4] = fn & 255
+    dg[:, 5] = rng.integers(0, 50, n)
+    dg[:, 6:] = rng.integers(0, 2, (n, 148))
+    ga, gb, gc, gd = groups
+    ga.add_bursts(dg, arf)
+    gb.add_bursts(dg[:n // 2], arf[:n // 2]); gb.add_bursts(dg[n // 2:], arf[n // 2:])
+    gc.add_bursts(dg, arf); sizes = [gc.tx_queue_size(a) for a in range(S)]
+    gd.add_bursts(dg, arf)
+    bits_e, gain_e, fq_e = gd.push(fn0 - 70000, 3, 5)       # nothing is due 70,000 frames earlier: five filler slots
+    torch.cuda.synchronize()
+    assert not fq_e.cpu().numpy().any()
+    assert [gd.tx_queue_size(a) for a in range(S)] == sizes and sum(q for q, _ in sizes) == n
+    outs = []
+    for g in groups:
+        b, ga_, fq = g.push(fn0, 0, 8 * F)
+        torch.cuda.synchronize()
+        outs.append((b.cpu().numpy().copy(), ga_.cpu().numpy().copy(), fq.cpu().numpy().copy(), [g.tx_queue_size(a) for a in range(S)]))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2]) and o[3] == outs[0][3]
+    assert outs[0][2].sum() > n // 4                       # (random (ARFCN, frame, timeslot) triples collide: a slot sends one of its bursts)
+    for g in groups:
+        g.close()
+    ctx.close()

@@ -45,8 +45,8 @@ for it in range(K + 3):
 st = acc / K
 def us(k, i, j): return (st[k, j] - st[k, i]) / 100.0
 print("S = %d, %d frames per step (%d bursts); workgroup 0, hundreds of shader clocks (clock64; ~21.5 a microsecond), mean of %d steps" % (S, F, n, K))
-print("k_group_tx_ingest: queues in + the arrival kernel's totals and bases %.1f | its lists in + free slots %.1f | the pushes (a wave per ARFCN) %.1f | wait for the slowest wave's pushes + payload stores %.1f | queues back %.1f | total %.1f" % (
-    us(0, 0, 2), us(0, 2, 3), us(0, 3, 4), us(0, 4, 5), us(0, 5, 6), us(0, 0, 6)))
-print("k_group_tx_push  : queues + filler tables in %.1f | the walk (a wave per ARFCN) %.1f | queues + filler tables back %.1f | total %.1f" % (
-    us(1, 0, 1), us(1, 1, 2), us(1, 2, 3), us(1, 0, 3)))
-print("                   of the walk, inside tx_heap_pop: %.1f" % (st[1, 4] / 100.0))
+def f(k1, i1, k2, i2): return (st[k2, i2] - st[k1, i1]) / 100.0
+print("k_group_tx<ingest, walk> (one launch: the add call's ingest taken into the push): queues + filler tables in, the arrival kernel's totals %.1f | its lists in + free slots %.1f | "
+      "the pushes (a wave per ARFCN) %.1f | wait for the slowest wave's pushes + payload stores %.1f | the walk (a wave per ARFCN; the gather its tail) %.1f, of it inside the pops %.1f | "
+      "queues + filler tables back %.1f | total %.1f" % (
+    f(1, 0, 0, 2), f(0, 2, 0, 3), f(0, 3, 0, 4), f(0, 4, 0, 5), f(1, 1, 1, 2), st[1, 4] / 100.0, f(1, 2, 1, 3), f(1, 0, 1, 3)))
