@@ -236,6 +236,28 @@ __device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqP
   return len;
 }
 
+// ---- std::push_heap the same way.  The path from the new leaf (position n) to the root is the set A of its ancestors: lane i is one
+// exactly when i + 1 is a proper binary prefix of n + 1 -- one shift and a compare a lane, one ballot.  G bit i = comp(first[i], value).
+// __push_heap climbs while the parent is later than value: it stops under the deepest ancestor that is NOT later (the highest bit of
+// A & ~G), or at the root; the ancestors below that point move down one level along the path (a path position takes its parent's entry:
+// one bpermute), value lands in the gap.  n = size before (0 .. 63); returns n + 1.  bl = 32 - clz(lane + 1), par = (lane - 1) >> 1.
+__device__ __forceinline__ int tx_lane_push(TrxqPk &hv, int n, TrxqPk v, int bl, int par) {
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned long long G = __builtin_amdgcn_ballot_w64(tx_gt(hv, v));
+  const int m1 = n + 1, sh = (32 - __builtin_clz(m1)) - bl;
+  const unsigned long long A = __builtin_amdgcn_ballot_w64(sh > 0 && (m1 >> sh) == lane + 1);
+  const unsigned long long pathset = A | (1ull << n);
+  const unsigned long long stop = A & ~G;
+  const unsigned long long upto = stop ? (2ull << (63 - __builtin_clzll(stop))) - 1ull : 0ull;   // the positions up to the stopping ancestor
+  const unsigned long long below = pathset & ~upto;         // the path under it: its lowest position takes value, the others their parent's entry
+  const int land = __builtin_ctzll(below);
+  const unsigned long long takers = below & (below - 1ull);
+  const int src = ((takers >> lane) & 1ull) ? par : lane;
+  const TrxqPk hn = __builtin_amdgcn_ds_bpermute(src << 2, hv);
+  hv = lane == land ? v : hn;
+  return n + 1;
+}
+
 constexpr int kTxI = 4;                                     // ARFCNs per workgroup of the queues' kernel: a WAVE each, a SIMD each (sixteen waves of
                                                             // this scalar code on one CU took ~1.6 times as long per push, and the workgroup
                                                             // waited for the slowest of sixteen)
@@ -373,11 +395,21 @@ __global__ __launch_bounds__(64 * kTxI) void k_group_tx(TrxGroupTx x, int n, con
         if (a0 + k < x.S) {
           const int e0 = lbase[k], m = acc[k];
           int n_q = nq[k];
-          if (!far) {
+          if (!far && n_q + m <= 64) {
+            // the queue fits the wave's lanes, this round's bursts included: entry i in lane i, the round's new entries packed side by
+            // side in another register (lane j the j-th), and every push the work of all lanes (tx_lane_push)
+            TrxqPk *row = &q[k][0];
+            TrxqPk hv = row[lane];                            // (entries past the queue's end: whatever the row holds, never looked at)
+            const int e = e0 + (lane < m ? lane : 0);
+            const TrxqPk vpk = trxq_pk(lf[e], lk[e] & 7, fs[e], ref);
+            const int bl = 32 - __builtin_clz(lane + 1), par = (lane - 1) >> 1;
+            for (int j = 0; j < m; j++) n_q = tx_lane_push(hv, n_q, __builtin_amdgcn_readlane(vpk, j), bl, par);   // mTransmitPriorityQueue.write(newVec) (:109)
+            if (lane < n_q) row[lane] = hv;
+          } else if (!far) {
             TrxqPk *row = &q[k][0];
             int32_t f1 = lf[e0], k1 = lk[e0];
             int s1 = fs[e0];
-            for (int j = 0; j < m; j++) {                     // mTransmitPriorityQueue.write(newVec) (:109); the next entry fetched meanwhile
+            for (int j = 0; j < m; j++) {                     // the same with the queue in LDS; the next entry fetched meanwhile
               const TrxqPk v = trxq_pk(f1, k1 & 7, s1, ref);
               f1 = lf[e0 + j + 1]; k1 = lk[e0 + j + 1]; s1 = fs[e0 + j + 1];   // (one past the ARFCN's last: the next ARFCN's or padding, unused)
               n_q = tx_heap_push(row, n_q, v);
