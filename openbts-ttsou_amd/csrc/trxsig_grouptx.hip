@@ -184,20 +184,23 @@ __device__ __forceinline__ int tx_fn_mod(int n, int m, float rm) {
   return r;
 }
 // ---- std::pop_heap on a queue of at most 64 entries held ACROSS THE WAVE'S LANES (entry i in lane i of hv), every lane working on the
-// one pop.  The walk is a lone wave's dependent instructions (profiles/r05_group_tx_probe.txt: ~1,300 clocks a pop with the queue in
-// LDS and everything on the scalar unit); here the comparisons of ALL sibling pairs are one vector compare and a ballot, the hole's way
-// down is read off the ballot by a few scalar bit operations, and the moves are one ds_bpermute:
-//   B  bit e (even e >= 2)  comp(first[e], first[e - 1]): the hole, arriving at their parent, goes LEFT ("secondChild--") -- the pairs
-//      the hole meets are untouched by the pop so far, so the bits taken before the descent are the ones __adjust_heap would form;
-//   G  bit i  comp(first[i], value) for the queue's last element `value`: what __push_heap's climb back asks of the elements moved up;
-//   the descent: hole -> 2 hole + 2 - B[2 hole + 2] while hole < (len - 1) / 2, then the lone left child (len even) -- positions grow
-//   with the level, so the path is kept as a 64-bit SET; the climb stops at the deepest path position (or the root) whose element
-//   is not later than value: the highest bit of path & ~G; the elements above it move up one level each (lane pos[l] takes lane
-//   pos[l + 1]'s entry: one bpermute), value lands there, the levels below keep what they had.
+// one pop.  A lone wave issues an instruction every four clocks at best, whichever unit executes it: the walk's time is its instruction
+// count (profiles/r05_group_tx_probe.txt: ~330 instructions, ~1,300 clocks a pop with the queue in LDS).  Here
+//   pref  bit c (c >= 1): the hole, arriving at c's parent, goes to c -- for the right child (even c) unless comp(first[c], first[c - 1]),
+//         for the left child (odd c) if comp(first[c + 1], first[c]): one vector compare for all the pairs (the neighbours' entries and
+//         answers by DPP wave shifts) and a ballot.  The pairs the hole meets are untouched by the pop so far, so the answers taken
+//         before the descent are the ones __adjust_heap would form;
+//   path  the hole's way down = the chain of preferred nodes from the root: lane c is on it when c and all its ancestors but the root
+//         are preferred (their positions: a constant of the lane) -- a second ballot -- cut where the descent stops (hole < (len - 1) / 2
+//         fails), then the lone left child (len even).  A level's position exceeds the level's above: the path is a 64-bit SET;
+//   G     bit i: comp(first[i], value) for the queue's last element `value`.  __push_heap's climb back stops at the deepest path
+//         position (or the root) whose element is not later than value: the highest bit of path & ~G;
+//   the elements above that position move up one level each (lane pos[l] takes lane pos[l + 1]'s entry: one ds_bpermute), value lands
+//   there, the levels below keep what they had.
 // The same comparisons on the same elements as trxq_pop / tx_heap_pop, the same array afterwards (the tests hold the kernels against
-// std::priority_queue: ties, queues up to 64 deep here, deeper ones on the LDS form).  n = size before (1 .. 64); top in / out as in
-// tx_heap_pop.
-__device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqPk &popped) {
+// std::priority_queue: ties, queues up to 64 deep here, deeper ones on the LDS form).  ~60 instructions and no loop.  n = size before
+// (1 .. 64); top in / out as in tx_heap_pop; anc: the lane's own position and its ancestors' but the root's.
+__device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqPk &popped, unsigned long long anc) {
   const int lane = (int)(threadIdx.x & 63);
   popped = top;
   const int len = n - 1;
@@ -205,17 +208,18 @@ __device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqP
   const TrxqPk v = __builtin_amdgcn_readlane(hv, len);
   const int half = (len - 1) >> 1;
   const int lone = (len & 1) ? -1 : (len - 2) >> 1;
-  const TrxqPk left = __builtin_amdgcn_update_dpp(0, hv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane e: the entry of lane e - 1 (its left sibling when e is even)
-  const unsigned long long B = __builtin_amdgcn_ballot_w64(tx_gt(hv, left));   // (bits at odd lanes, lane 0: never looked at)
+  // which child the hole would take at every node at once: lane c (c >= 1) is PREFERRED when the hole, arriving at c's parent, goes to
+  // c -- the right child (even c) unless comp(first[c], first[c - 1]), the left child (odd c) if comp(first[c + 1], first[c])
+  const TrxqPk left = __builtin_amdgcn_update_dpp(0, hv, 0x138, 0xf, 0xf, false);    // wave_shr:1 -- lane c: the entry of lane c - 1
+  const int later = tx_gt(hv, left) ? 1 : 0;                                          // comp(first[c], first[c - 1])
+  const int later_r = __builtin_amdgcn_update_dpp(0, later, 0x130, 0xf, 0xf, false);  // wave_shl:1 -- lane c: that of lane c + 1
+  const unsigned long long pref = __builtin_amdgcn_ballot_w64((lane & 1) ? later_r != 0 : later == 0);
   const unsigned long long G = __builtin_amdgcn_ballot_w64(tx_gt(hv, v));
-  // the hole's way down: a level's position is larger than the level's above, so the path is a SET of lane numbers, bottom = highest bit
-  int hole = 0, lonepos = -1;
-  unsigned long long path = 0;                              // pos[1 .. D]
-  while (hole < half) {
-    const int r = 2 * hole + 2;
-    hole = r - (int)((B >> r) & 1ull);
-    path |= 1ull << hole;
-  }
+  // the hole's way down is the chain of preferred nodes from the root: lane c is on it when c and all its ancestors but the root are
+  // preferred (anc: their positions, a constant of the lane) -- cut where the descent stops, at the first hole without two children
+  // (a node is reached when its parent is < half, i.e. when its position is <= 2 half)
+  unsigned long long path = __builtin_amdgcn_ballot_w64(lane >= 1 && (pref & anc) == anc) & ((2ull << (2 * half)) - 1ull);
+  int hole = path ? 63 - __builtin_clzll(path) : 0, lonepos = -1;
   if (hole == lone) {
     lonepos = hole;
     hole = 2 * hole + 1;
@@ -226,8 +230,8 @@ __device__ __forceinline__ int tx_lane_pop(TrxqPk &hv, int n, TrxqPk &top, TrxqP
   const int posj = 63 - __builtin_clzll(stop);
   const unsigned long long moved = (path | 1ull) & ((1ull << posj) - 1ull);   // the levels above it take their chosen child's entry
   const int sh = 2 * lane + 2;
-  const int mybit = sh < 64 ? (int)((B >> sh) & 1ull) : 0;
-  const int child = lane == lonepos ? 2 * lane + 1 : sh - mybit;
+  const int right = sh < 64 ? (int)((pref >> sh) & 1ull) : 0;                 // this node's right child is the preferred one
+  const int child = lane == lonepos ? 2 * lane + 1 : 2 * lane + 1 + right;
   const int src = ((moved >> lane) & 1ull) ? child : lane;
   TrxqPk hn = __builtin_amdgcn_ds_bpermute(src << 2, hv);
   hn = lane == posj ? v : hn;
@@ -452,6 +456,8 @@ __global__ __launch_bounds__(64 * kTxI) void k_group_tx(TrxGroupTx x, int n, con
     // a queue of at most 64 entries is walked across the wave's lanes (tx_lane_pop), a longer one in LDS (tx_heap_pop): a walk only pops
     const bool lanes = walker && !is_far && n_q <= 64;
     TrxqPk hv = 0;
+    unsigned long long anc = 0;                               // this lane's position and its ancestors' but the root's (tx_lane_pop)
+    for (int p = tid & 63; p > 0; p = (p - 1) >> 1) anc |= 1ull << p;
     if (lanes) {
       hv = row[tid & 63];                                     // (entries past the queue's end: whatever the row holds, never looked at)
       top = __builtin_amdgcn_readlane(hv, 0);
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(64 * kTxI) void k_group_tx(TrxGroupTx x, int n, con
             const int tk = trxq_pk_time(top);
             if (tk > now) break;
             TrxqPk e;
-            { TX_ACC_BEGIN(); n_q = lanes ? tx_lane_pop(hv, n_q, top, e) : tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
+            { TX_ACC_BEGIN(); n_q = lanes ? tx_lane_pop(hv, n_q, top, e, anc) : tx_heap_pop(row, n_q, top, c, last, e); TX_ACC_END(1, 4); }
             if (tk == now) {                                  // the burst for exactly this slot (:159-173): it replaces the filler entry and goes out
               const int old = reread ? (int)flk[cell] : pid;
               if (old >= 0) { if (writer) x.free_stack[(size_t)n_f * x.S + a] = (int16_t)old; n_f++; }
