@@ -773,6 +773,8 @@ def main():
                     help="A/B, path 0's peak kernel: 0 = two lanes per burst (default), 1 = eight lanes, speculative, 2 = a lane per burst")
     ap.add_argument("--eq-tail", type=int, default=1, choices=[1, 2], help="A/B (config5, reference chain): 1 = k_eq_dfe4 (default), 2 = k_eq_delay + k_eq_dfe2 "
                     "(trxsig_set_tuning(TRXSIG_TUNE_EQ_TAIL))")
+    ap.add_argument("--group-replay", type=int, default=0, choices=[0, 1], help="A/B (config4): the Transceiver group's state machine, 0 = the wave-per-segment "
+                    "kernel (default), 1 = the kernels that step through every timeslot (trxsig_set_tuning(TRXSIG_TUNE_GROUP_REPLAY))")
     ap.add_argument("--soft-mode", choices=["tolerance", "exact"], default="tolerance",
                     help="normal / rach: demodulateBurst's arithmetic (trxsig_set_soft_mode).  tolerance (default): flags, amp, TOA and hard bits "
                          "bit-exact, soft bits within 7.4e-5 of the reference's (north_star's bar is 1e-4); exact: every soft bit IEEE-equal.  The "
@@ -847,6 +849,8 @@ def main():
         ctx.set_tuning(spec_peak=args.spec_peak)
     if args.eq_tail != 1:
         ctx.set_tuning(eq_tail=args.eq_tail)
+    if args.group_replay:
+        ctx.set_tuning(group_replay=args.group_replay)
     # demodulateBurst's arithmetic (normal, rach and config 4's demodulating legs; config 5 and the reference chain equalise instead)
     ctx.set_soft_mode(pkg.SOFT_TOLERANCE if args.soft_mode == "tolerance" else pkg.SOFT_EXACT)
 

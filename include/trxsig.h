@@ -520,11 +520,14 @@ int trxsig_kernel_count(void);
  *     k_eq_dfe2 through the scratch rows.  TRXSIG_TUNE_EQ_DENSE: marked bursts per call above which the Transceiver group's channel
  *     estimate runs a lane per burst instead of a wave per burst (default 4096).  TRXSIG_TUNE_RXRES_WPB: windows per workgroup of the
  *     receive resampler (0 = chosen from the launch size); TRXSIG_TUNE_RXRES_ROWS: 1 = its tap rows in visiting order (default),
- *     0 = in branch order.  TRXSIG_TUNE_CHAN_TPW: tiles per workgroup of the shared-filter channeliser (0 = chosen from the launch size). */
+ *     0 = in branch order.  TRXSIG_TUNE_CHAN_TPW: tiles per workgroup of the shared-filter channeliser (0 = chosen from the launch size).
+ *   TRXSIG_TUNE_GROUP_REPLAY: the Transceiver group's receive state machine (trxsig_trxgroup.h).  0 = a wave per ARFCN and 64-timeslot
+ *     segment that visits only the timeslots at which the state can move (calls of up to 1,024 timeslots; the default), 1 = a lane per
+ *     ARFCN (and segment) stepping through every timeslot (round 4's kernels, also what longer calls take). */
 enum { TRXSIG_TUNE_NORMAL_PATH = 0, TRXSIG_TUNE_RACH_PATH = 1, TRXSIG_TUNE_GENERIC_TAPS = 2, TRXSIG_TUNE_SPECULATIVE_PEAK = 3,
        TRXSIG_TUNE_CHAIN_LAG = 4, TRXSIG_TUNE_CHAIN_SPIN = 5, TRXSIG_TUNE_DEMOD_BESIDE = 7, TRXSIG_TUNE_BESIDE_DET_CUS = 8,
        TRXSIG_TUNE_CU_LAYOUT = 9, TRXSIG_TUNE_BESIDE_PRIORITY = 11, TRXSIG_TUNE_EQ_TAIL = 12, TRXSIG_TUNE_EQ_DENSE = 13,
-       TRXSIG_TUNE_RXRES_WPB = 14, TRXSIG_TUNE_RXRES_ROWS = 15, TRXSIG_TUNE_CHAN_TPW = 16 };
+       TRXSIG_TUNE_RXRES_WPB = 14, TRXSIG_TUNE_RXRES_ROWS = 15, TRXSIG_TUNE_CHAN_TPW = 16, TRXSIG_TUNE_GROUP_REPLAY = 17 };
 int trxsig_set_tuning(trxsig_ctx *ctx, int key, int value);
 /* 1 in libtrxsig_tune.so (every implementation above selectable), 0 in the product library libtrxsig.so, which carries the
  * defaults only (normal path 0 with the two-lane peak kernel, RACH paths 1 and 2) and answers TRXSIG_EINVAL to the rest. */

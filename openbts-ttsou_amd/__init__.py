@@ -497,10 +497,10 @@ class TrxSig:
 
     def set_tuning(self, normal_path=None, rach_path=None, generic_taps=None, spec_peak=None, chain_lag=None,
                    chain_spin=None, demod_beside=None, beside_det_cus=None, cu_layout=None, beside_priority=None,
-                   eq_tail=None, eq_dense=None, rxres_wpb=None, rxres_rows=None, chan_tpw=None):
-        """A/B implementation choice (results are bit-identical): see trxsig_set_tuning.  eq_tail / eq_dense / rxres_* / chan_tpw
-        are LIBRARY-WIDE (every context of the process): restore the default (1 / 4096 / 0 / 1 / 0) when done."""
-        for key, v in ((12, eq_tail), (13, eq_dense), (14, rxres_wpb), (15, rxres_rows), (16, chan_tpw)):
+                   eq_tail=None, eq_dense=None, rxres_wpb=None, rxres_rows=None, chan_tpw=None, group_replay=None):
+        """A/B implementation choice (results are bit-identical): see trxsig_set_tuning.  eq_tail / eq_dense / rxres_* / chan_tpw /
+        group_replay are LIBRARY-WIDE (every context of the process): restore the default (1 / 4096 / 0 / 1 / 0 / 0) when done."""
+        for key, v in ((12, eq_tail), (13, eq_dense), (14, rxres_wpb), (15, rxres_rows), (16, chan_tpw), (17, group_replay)):
             if v is not None:
                 self._chk(self.L.trxsig_set_tuning(self.h, key, int(v)), "trxsig_set_tuning")
         if demod_beside is not None:

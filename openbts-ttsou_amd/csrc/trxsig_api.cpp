@@ -1276,7 +1276,7 @@ int trxsig_tuning_build(void) {
 }
 
 // library-wide implementation knobs (trxsig_launch.h): plain atomics, defaults here
-static std::atomic<int> g_knob[TRX_KNOB_COUNT] = {{1}, {4096}, {0}, {1}, {0}};
+static std::atomic<int> g_knob[TRX_KNOB_COUNT] = {{1}, {4096}, {0}, {1}, {0}, {0}};
 extern "C++" {
 int trx_knob(int id) { return (id >= 0 && id < TRX_KNOB_COUNT) ? g_knob[id].load(std::memory_order_relaxed) : 0; }
 void trx_knob_set(int id, int value) { if (id >= 0 && id < TRX_KNOB_COUNT) g_knob[id].store(value, std::memory_order_relaxed); }
@@ -1320,6 +1320,7 @@ int trxsig_set_tuning(trxsig_ctx *c, int key, int value) {
   if (key == TRXSIG_TUNE_RXRES_WPB && value >= 0 && value <= 64) { trx_knob_set(TRX_KNOB_RXRES_WPB, value); return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_RXRES_ROWS && value >= 0 && value <= 1) { trx_knob_set(TRX_KNOB_RXRES_ROWS, value); return TRXSIG_OK; }
   if (key == TRXSIG_TUNE_CHAN_TPW && value >= 0 && value <= 64) { trx_knob_set(TRX_KNOB_CHAN_TPW, value); return TRXSIG_OK; }
+  if (key == TRXSIG_TUNE_GROUP_REPLAY && value >= 0 && value <= 1) { trx_knob_set(TRX_KNOB_GROUP_REPLAY, value); return TRXSIG_OK; }
   if ((key == TRXSIG_TUNE_BESIDE_DET_CUS && value >= 0 && value <= 504) || (key == TRXSIG_TUNE_CU_LAYOUT && value >= 0 && value <= 1) ||
       (key == TRXSIG_TUNE_BESIDE_PRIORITY && value >= 0 && value <= 2)) {
     DeviceGuard g(c->device);

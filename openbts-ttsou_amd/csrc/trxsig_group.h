@@ -48,6 +48,8 @@ hipError_t trx_launch_group_expand(hipStream_t st, const TrxGroupExpand &a);
 
 struct TrxGroupReplay {
   int S, n_slots, fn0, tn0, equalize, n_tsc_rows;          // rows < n_tsc_rows are normal bursts, the rest access bursts
+  int form;                                                // trx_group_replay_form(n_slots), decided ONCE per call: 0 = k_group_replay_wave (gathers the detectors'
+                                                           // answers itself and leaves the rows' gate / threshold: no k_group_pack, no k_group_scatter), 1 = the stepping forms
   const int32_t *rowmap;
   const uint8_t *flags; const trx_c32 *amp; const float *avgpwr;   // the stateless detectors' answers (energy gate off)
   const double *exp_tab;
@@ -64,6 +66,7 @@ struct TrxGroupReplay {
 // thr_g / verdict_g (and tix_g on the equalising leg, else NULL): trx_group_replay_scratch(S, n_slots) entries each, the replay's
 // (slot, ARFCN)-ordered outputs before k_group_scatter moves them to the rows
 size_t trx_group_replay_scratch(int S, int n_slots);
+int trx_group_replay_form(int n_slots);
 // the gather first, on its own: on a large call it runs on the context's stream BEFORE the fork, so that the side stream's first
 // kernel is the replay itself and starts together with the demodulator -- once that kernel has filled the machine, the replay's
 // few workgroups wait for it to drain (measured: 80 us instead of 15)

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_group_pack(long long n, int n_tsc_rows,
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kReplayDepth = 16;                            // two frames: a group starts on the call's first timeslot number
 constexpr int kExpLds = 64;                                 // exp(-k), k = 0 .. 63, sits in LDS (false detections come in runs)
-enum { RV_SUCC = TRXSIG_F_DETECT, RV_CONS = 0x08, RV_MARK = 0x10, RV_PASS = 0x20, RV_EVT = 0x40 };   // the verdict byte: the gate's value, + "energy gate open", + "this burst estimates"
+enum { RV_SUCC = TRXSIG_F_DETECT, RV_CONS = 0x08, RV_MARK = 0x10, RV_PASS = 0x20, RV_EVT = 0x40, RV_TSC = 0x80 };   // the verdict byte: the gate's value, + "energy gate open", + (for k_group_cache) "a normal burst's slot"
 
 // One burst's step of the machine: (thr, prev_false, dcur) -> the same after the burst; returns the verdict byte.
 // exp_s: exp(-k), k = 0 .. kExpLds-1 in LDS; exp_tab: the whole table in memory (trxsig_group.h).
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_group_replay(TrxGroupReplay a, const flo
       }
       const int v = replay_step(thr, prev_false, dcur, __float_as_int(cur[i].x), cur[i].y, fn, exp_s, a.exp_tab);
       thr_row[(size_t)i * Spad + col] = thr;
-      v_row[(size_t)i * Spad + col] = (uint8_t)(v & (RV_SUCC | RV_PASS));
+      v_row[(size_t)i * Spad + col] = (uint8_t)((v & (RV_SUCC | RV_PASS)) | ((__float_as_int(cur[i].x) & RP_TSC) ? RV_TSC : 0));
     }
     fnA += kReplayDepth / 8;
     fnA -= fnA >= kHyperframe ? kHyperframe : 0;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
           seen |= ((seen & RV_MARK) ? 0 : (v & RV_CONS)) | (v & RV_MARK);
           if (i < n_valid) {
             pt[(size_t)i * Spad] = thr;
-            pv[(size_t)i * Spad] = (uint8_t)(v & (RV_SUCC | RV_PASS));
+            pv[(size_t)i * Spad] = (uint8_t)((v & (RV_SUCC | RV_PASS)) | ((__float_as_int(w[i].x) & RP_TSC) ? RV_TSC : 0));
           }
         }
         pt += (size_t)8 * Spad; pv += (size_t)8 * Spad;
@@ -322,6 +322,192 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_group_replay_wave (round 5): the same machine, the same validated segments -- but a WAVE per (ARFCN, segment of 64 timeslots), its lanes
+// the segment's 64 slots, and the serial part visits only the slots at which the state CAN move.  What round 4's debug timing said
+// of k_group_replay_seg: a slot-step is ~60 dependent instructions behind two mask reads, ~0.3 us, whether or not anything happens
+// in it -- and in a running cell almost nothing does: the threshold sits on its floor of 0, every active burst passes the energy
+// gate, a detected burst takes 1 from a threshold that is 0 already.  Here everything about a segment that does not depend on the
+// state is one instruction across the lanes (the slots' codes and powers: one load each; which slots start a frame: a constant
+// mask), energyDetect's decision for all 64 slots against the CURRENT threshold is one compare and a ballot, and the slots that can
+// change the state under it are a mask:
+//     a burst the correlator missed behind an open gate (the threshold rises, the clock is re-based),
+//     an active burst under the threshold once 50 quiet frames have passed (re-bases the clock, lowers the threshold; before that it
+//       only LOOKS at the clock, which is remembered for the boundary walk and costs no visit),
+//     a detected burst while the threshold is not 0 (the threshold falls by one).
+// The wave jumps from one such slot to the next (find-first-bit), the frame difference to prevFalseDetectionTime at a slot is a
+// population count of the frame-start mask, and all of it is wave-uniform: scalar branches, no execution masks.  A slot's
+// threshold-after is handed to the lanes from the slot of the change onwards; its verdict is formed afterwards, a lane per slot,
+// from the threshold the slot before it left (the same float arithmetic as the step's).  Segments, assumed start states, the
+// boundary walk and the proof that it ends with the serial result are k_group_replay_seg's, word for word; the walk is done by
+// every wave for itself (K <= 16 boundaries from LDS, uniform), two buffers by round parity, one barrier a round.
+// Workgroup = one ARFCN, K = ceil(n_slots / 64) waves.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kWaveSegs = 16;                               // n_slots <= 1024
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupReplay a, double *__restrict__ thr_g, uint8_t *__restrict__ verdict_g, int Spad,
+                                                                      int K) {
+  enum { SF_CONS = 1, SF_MARK = 2 };
+  __shared__ long long b_uthr[2][kWaveSegs], b_ethr[2][kWaveSegs];
+  __shared__ int b_upf[2][kWaveSegs], b_epf[2][kWaveSegs], b_fl[2][kWaveSegs];
+  __builtin_amdgcn_s_setprio(3);
+  typedef unsigned long long u64;
+  const int lane = threadIdx.x & 63;
+  const int j = uni(threadIdx.x >> 6);                      // this wave's segment
+  const int col = blockIdx.x;                               // the ARFCN
+  const int ts = j * 64, t = ts + lane;
+  const bool in = t < a.n_slots;
+  // the slot's row and, through it, the stateless detectors' answers (k_group_pack's gather, done here: one launch less)
+  const int row = in ? a.rowmap[(size_t)t * a.S + col] : -1;
+  int code = 0;
+  float avg = 0.0f;
+  if (row >= 0) {
+    const int f = a.flags[row];
+    avg = a.avgpwr[row];
+    code = ((f & TRXSIG_F_BADLEN) ? 0 : RP_ACT) | ((f & TRXSIG_F_DETECT) ? RP_DET : 0) | (row < a.n_tsc_rows ? RP_TSC : 0);
+  }
+  const bool act_l = (code & RP_ACT) != 0;
+  const u64 act_m = __builtin_amdgcn_ballot_w64(act_l);
+  const u64 det_m = __builtin_amdgcn_ballot_w64((code & RP_DET) != 0);
+  const long long s0_thr = uni64(__double_as_longlong(a.state[col].thr));
+  const int s0_pf = uni(a.state[col].prev_false_fn);
+  // slots that start a frame: the frame number and the frame difference move on by one BEFORE such a burst is looked at
+  const int i0 = (8 - (a.tn0 & 7)) & 7;
+  const u64 frame_m = 0x0101010101010101ull << i0;
+  constexpr int half = kHyperframe / 2;
+  int fn_seg = (a.fn0 + ((a.tn0 + ts) >> 3)) % kHyperframe; // the frame of the segment's first slot ...
+  const int fn_first = fn_seg;
+  fn_seg -= i0 == 0 ? 1 : 0;                                // ... and one behind it where that slot itself starts the frame
+  fn_seg += fn_seg < 0 ? kHyperframe : 0;
+  // this wave's last run: the state it started from, the state it ended with, what it saw
+  long long u_thr = 0, e_thr = 0;
+  int u_pf = 0, e_pf = 0, fl = 0;
+  long long n_thr = s0_thr;
+  int n_pf = s0_pf;
+  bool need = true;
+  double o_thr = 0.0;                                        // this lane's slot: the threshold after it
+  double first_thr = 0.0;                                    // the threshold the segment's first slot meets
+#ifdef TRX_REPLAY_DEBUG
+  const long long dk0 = wall_clock64();
+  long long d_run = 0, d_load = 0;
+  int d_events = 0, d_runs = 0;
+  if (act_m || true) d_load = wall_clock64() - dk0;
+#endif
+  for (int round = 0;; round++) {
+#ifdef TRX_REPLAY_DEBUG
+    const long long dr0 = wall_clock64();
+    d_runs += need ? 1 : 0;
+#endif
+    if (need) {
+      double thr = __longlong_as_double(n_thr);
+      int pf = n_pf;
+      first_thr = thr;
+      o_thr = thr;
+      // frame difference at slot i = wrap(dbase + frames started in (mark, i]); before any re-basing: FNDelta(first frame, pf) (- 1, see above)
+      int dbase = fn_delta(fn_first, pf) - (i0 == 0 ? 1 : 0);
+      int nbm = 0;
+      int seen = 0;
+      u64 todo = ~0ull;                                     // slots not yet passed
+      for (;;) {
+        const float thrF = (float)thr;
+        const float thr2 = thrF * thrF;
+        const u64 pass_m = __builtin_amdgcn_ballot_w64(act_l && (avg > thr2));
+        const bool tnz = __builtin_amdgcn_ballot_w64(thr != 0.0) != 0;
+        // a burst under the threshold only LOOKS at the clock (that is remembered: SF_CONS) unless 50 quiet frames have passed -- which
+        // they cannot have anywhere in this segment while the frame difference at its END, with the clock as it stands, is no more than 50
+        const u64 under_m = act_m & ~pass_m;
+        const bool may_quiet = dbase + 8 - nbm > 50;
+        const u64 ev_m = ((pass_m & ~det_m) | (may_quiet ? under_m : 0ull) | (tnz ? (pass_m & det_m) : 0ull)) & todo;
+        if (ev_m == 0) {
+          seen |= (!(seen & SF_MARK) && (under_m & todo) != 0) ? SF_CONS : 0;
+          break;
+        }
+        const int i = __builtin_ctzll(ev_m);
+        seen |= (!(seen & SF_MARK) && (under_m & todo & ((1ull << i) - 1)) != 0) ? SF_CONS : 0;
+        const u64 upto = (2ull << i) - 1;                   // slots 0 .. i (i = 63: all)
+        const int nb = __builtin_popcountll(frame_m & upto);
+        int d = dbase + nb - nbm;
+        d -= d >= half ? kHyperframe : 0;
+        int fn = fn_seg + nb;
+        fn -= fn >= kHyperframe ? kHyperframe : 0;
+        const bool pass = (pass_m >> i) & 1, det = (det_m >> i) & 1;
+        bool mark = false;
+        if (pass && det) {                                  // mEnergyThreshold -= 1.0F; floor 0 (:338-339, 368-369)
+          const double t1 = thr - 1.0;
+          thr = t1 < 0.0 ? 0.0 : t1;
+        } else if (pass) {                                  // a false detection: + 10.0F*exp(-framesElapsed) (:355, 374)
+          const int k = d < -TRXG_EXP_LO ? -TRXG_EXP_LO : (d > TRXG_EXP_HI ? TRXG_EXP_HI : d);
+          thr = thr + 10.0 * a.exp_tab[k + TRXG_EXP_LO];
+          seen |= (seen & SF_MARK) ? 0 : SF_CONS;
+          mark = true;
+        } else {                                            // under the threshold: 50 quiet frames take 10 off it (:300-304)
+          seen |= (seen & SF_MARK) ? 0 : SF_CONS;
+          if (d > 50) { thr = thr - 10.0; mark = true; }
+        }
+        if (mark) { pf = fn; dbase = 0; nbm = nb; seen |= SF_MARK; }
+#ifdef TRX_REPLAY_DEBUG
+        d_events++;
+#endif
+        o_thr = lane >= i ? thr : o_thr;
+        todo = ~upto;
+        if (i == 63) break;
+      }
+      u_thr = n_thr; u_pf = n_pf;
+      e_thr = uni64(__double_as_longlong(thr)); e_pf = pf; fl = seen;
+    }
+#ifdef TRX_REPLAY_DEBUG
+    d_run += wall_clock64() - dr0;
+#endif
+    const int par = round & 1;
+    if (lane == 0) { b_uthr[par][j] = u_thr; b_upf[par][j] = u_pf; b_ethr[par][j] = e_thr; b_epf[par][j] = e_pf; b_fl[par][j] = fl; }
+    __syncthreads();
+    long long w_thr = s0_thr;
+    int w_pf = s0_pf;
+    bool prefix = true;
+    for (int jj = 0; jj < K; jj++) {                         // the walk over the boundaries (every wave for itself; uniform)
+      const int f = uni(b_fl[par][jj]);
+      const bool ok = uni64(b_uthr[par][jj]) == w_thr && (uni(b_upf[par][jj]) == w_pf || !(f & SF_CONS));
+      if (jj == j) { need = !ok; n_thr = w_thr; n_pf = w_pf; }
+      prefix = prefix && ok;
+      w_thr = uni64(b_ethr[par][jj]);
+      w_pf = (f & SF_MARK) ? uni(b_epf[par][jj]) : w_pf;
+    }
+#ifdef TRX_REPLAY_DEBUG
+    if ((prefix || round > K + 1) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 77))
+      printf("replay_wave block %d wave %d: %d rounds, %d runs, %d events, act %d; ticks (100 MHz): load %lld runs %lld total %lld\n", blockIdx.x, j, round + 1, d_runs, d_events,
+             (int)__builtin_popcountll(act_m), d_load, d_run, wall_clock64() - dk0);
+#endif
+    if (prefix) {
+      if (threadIdx.x == 0) { a.state[col].thr = __longlong_as_double(w_thr); a.state[col].prev_false_fn = w_pf; }
+      break;
+    }
+    if (round > K + 1) {                                    // (at most K rounds by construction; as k_group_replay_seg: the exit is unconditional and the host hears of it)
+      if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+      break;
+    }
+  }
+  // the slot's verdict from the threshold the slot before it left: energyDetect's decision and the correlator's answer behind it
+  double prev = __shfl_up(o_thr, 1);
+  prev = lane == 0 ? first_thr : prev;
+  const float pF = (float)prev;
+  const bool pass_l = act_l && (avg > pF * pF);
+  if (in) {
+    const int v = pass_l ? (RV_PASS | ((code & RP_DET) ? RV_SUCC : 0)) : 0;
+    thr_g[(size_t)t * Spad + col] = o_thr;
+    verdict_g[(size_t)t * Spad + col] = (uint8_t)(v | ((code & RP_TSC) ? RV_TSC : 0));
+    if (row >= 0) {                                         // ... and the row's own results (the other forms leave this to k_group_scatter / k_group_cache)
+      a.gate[row] = (uint8_t)(v & RV_SUCC);
+      a.thr_after[row] = o_thr;
+    }
+  }
+}
+
 // The per-timeslot channel cache of the equalising leg (:313-325, 341-349, 357, 370).  What it needs from the threshold
 // recurrence is only each burst's verdict (energy gate open? correlator detected?), and a timeslot's cache entry is touched by
 // that timeslot's bursts alone -- so it is NOT part of the serial chain: a lane per (ARFCN, timeslot) walks its own bursts, one
@@ -329,8 +515,8 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
 // (slot, ARFCN) order.  Per burst: the entry is stale when 50 frames have passed since its estimate or it is empty (:317); a
 // detected normal burst behind a stale entry estimates the channel (RV_EVT; its row's taps become the entry); tix = the
 // tap-table entry that equalises the burst; a missed normal burst or a detected access burst drops the entry (:357, :370).
-__global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const float4 *__restrict__ packed, const uint8_t *__restrict__ verdict_g,
-                                                     const double *__restrict__ thr_g, int Spad) {
+__global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const uint8_t *__restrict__ verdict_g, const double *__restrict__ thr_g, int Spad,
+                                                     int rows_done) {
   const int id = blockIdx.x * 256 + threadIdx.x;            // timeslot-major: neighbouring lanes are neighbouring ARFCNs
   if (id >= 8 * a.S) return;
   const int tn = id / a.S, col = id - tn * a.S;
@@ -339,62 +525,86 @@ __global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const flo
   const int t_first = (tn - a.tn0) & 7;                     // the call's first slot with this timeslot number
   int fn = a.fn0 + ((a.tn0 + t_first) >> 3);
   fn -= fn >= kHyperframe ? kHyperframe : 0;
-  // eight frames' inputs are loaded together (their addresses do not depend on the cache's state) and the next eight are in
-  // flight while these are walked
-  int code[8], ver[8], row[8], ncode[8], nver[8], nrow[8];
-  double thr[8], nthr[8];
-  auto fetch = [&](int tb, int (&c)[8], int (&v)[8], int (&r)[8], double (&th)[8]) {
+#ifdef TRX_REPLAY_DEBUG
+  const long long ck0 = wall_clock64();
+  int c_evt = 0;
+#endif
+  // What the walk needs of a burst is its verdict byte (which says "normal burst" too: RV_TSC) and its row: kFr frames' worth are
+  // loaded TOGETHER, before the walk looks at any (round 4 had eight in flight and the next eight behind them: the walk is short,
+  // so it waited 2 us for memory every eight steps -- 20 us for 58 frames, profiles/r05_replay_probe.txt).  The threshold and the
+  // amplitude are only needed where a burst estimates (a few steps of a call): fetched there.
+  constexpr int kFr = 64;
+  for (int tb = t_first; tb < a.n_slots; tb += 8 * kFr) {
+    int ver[kFr], row[kFr];
+    // (unconditional loads: a slot past the call's end reads the chunk's first cell again and is not looked at)
+    const uint8_t *pv = verdict_g + (size_t)tb * Spad + col;
+    const int32_t *pr = a.rowmap + (size_t)tb * a.S + col;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int t = tb + 8 * i;
-      const bool in = t < a.n_slots;
-      const size_t g = (size_t)(in ? t : 0) * a.S + col, q = (size_t)(in ? t : 0) * Spad + col;
-      c[i] = in ? __float_as_int(*reinterpret_cast<const float *>(packed + g)) : 0;
-      v[i] = in ? verdict_g[q] : 0;
-      r[i] = in ? a.rowmap[g] : -1;
-      th[i] = thr_g[q];
+    for (int i = 0; i < kFr; i++) {
+      const bool in = tb + 8 * i < a.n_slots;
+      ver[i] = pv[in ? (size_t)(8 * i) * Spad : 0];
+      row[i] = pr[in ? (size_t)(8 * i) * a.S : 0];
     }
-  };
-  fetch(t_first, code, ver, row, thr);
-  for (int tb = t_first; tb < a.n_slots; tb += 64) {
-    fetch(tb + 64, ncode, nver, nrow, nthr);
+    // every value is taken delivery of HERE: the walk below stores as it goes, stores and loads share one counter, and a wait for a
+    // load left pending across the walk's branches becomes a wait for the previous step's stores (0.35 us a step: what round 4's walk
+    // spent its 20 us on)
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < kFr; i++) asm volatile("" ::"v"(ver[i]), "v"(row[i]));
+    if (!rows_done) {                                       // (the replay kernel did not know the rows: the threshold after each burst moves there now)
+      const double *pt = thr_g + (size_t)tb * Spad + col;
+#pragma unroll
+      for (int i0 = 0; i0 < kFr; i0 += 16) {
+        double th[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) th[k] = pt[(tb + 8 * (i0 + k) < a.n_slots) ? (size_t)(8 * (i0 + k)) * Spad : 0];
+#pragma unroll
+        for (int k = 0; k < 16; k++) asm volatile("" ::"v"(th[k]));
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (tb + 8 * (i0 + k) < a.n_slots && row[i0 + k] >= 0) a.thr_after[row[i0 + k]] = th[k];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kFr; i++) {
       const int t = tb + 8 * i;
-      if (t < a.n_slots) {
+      if (t < a.n_slots) {                                  // (uniform)
         const int v = ver[i];
-        const bool is_tsc = (code[i] & RP_TSC) != 0;
+        const bool is_tsc = (v & RV_TSC) != 0;
         const bool pass = (v & RV_PASS) != 0, succ = (v & RV_SUCC) != 0, fail = pass && !succ;
         const bool stale = pass && is_tsc && (fn_delta(fn, est) > 50 || src < 0);   // ((double)d > 50 of an integer d)
         int sr = stale ? -1 : src;
         const bool evt = succ && stale;                      // this burst estimates the channel
+#ifdef TRX_REPLAY_DEBUG
+        c_evt += __any(evt) ? 1 : 0;
+#endif
         sr = evt ? S8 + row[i] : sr;
         est = evt ? fn : est;
         const int tix = (succ && is_tsc) ? sr : 0;
         sr = ((fail && is_tsc) || (succ && !is_tsc)) ? -1 : sr;
         src = sr;
-        // ... and what k_group_scatter does on the other leg, for this cell's row: the gate, the threshold after the burst, the
-        // estimation event, the tap index, SNRestimate = |amp|^2 / (thr^2 + 1) in double with the threshold AFTER its decrement (:340)
+        // ... and the cell's row: the gate, the estimation event, the tap index, SNRestimate = |amp|^2 / (thr^2 + 1) in double with the
+        // threshold AFTER its decrement (:340)
         const int rw = row[i];
         if (rw >= 0) {
           a.gate[rw] = (uint8_t)(v & RV_SUCC);
-          a.thr_after[rw] = thr[i];
           a.ev[rw] = evt ? 1 : 0;
           a.tap_ix[rw] = tix;
           if (evt) {
             const trx_c32 am = a.amp[rw];
+            const double th = thr_g[(size_t)t * Spad + col];
             const float n2 = am.i * am.i + am.r * am.r;       // Complex::norm2 (Complex.h:119)
-            a.snr[rw] = (float)((double)n2 / (thr[i] * thr[i] + 1.0));
+            a.snr[rw] = (float)((double)n2 / (th * th + 1.0));
           }
         }
       }
       fn += 1; fn -= fn >= kHyperframe ? kHyperframe : 0;   // the next frame's slot with this timeslot number
     }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { code[i] = ncode[i]; ver[i] = nver[i]; row[i] = nrow[i]; thr[i] = nthr[i]; }
   }
   a.state[col].est_fn[tn] = est;
   a.state[col].tap_src[tn] = src;
+#ifdef TRX_REPLAY_DEBUG
+  if (id == 0) printf("group_cache: %d slots, steps with an estimating lane %d, ticks (100 MHz) %lld\n", a.n_slots, c_evt, wall_clock64() - ck0);
+#endif
 }
 
 // (slot, ARFCN) order -> rows on the demodulating leg: gate and the threshold after the burst (the equalising leg: k_group_cache)
@@ -446,9 +656,15 @@ size_t trx_group_replay_scratch(int S, int n_slots) {         // entries of thr_
   return (size_t)((n_slots + kReplayDepth - 1) / kReplayDepth * kReplayDepth) * (size_t)((S + 63) / 64 * 64);
 }
 
+// the wave form (k_group_replay_wave) for calls of up to 1,024 timeslots; otherwise, and under TRXSIG_TUNE_GROUP_REPLAY = 1, the forms that
+// step through every slot
+int trx_group_replay_form(int n_slots) { return (n_slots <= 64 * kWaveSegs && trx_knob(TRX_KNOB_GROUP_REPLAY) == 0) ? 0 : 1; }
+static bool replay_wave_form(const TrxGroupReplay &a) { return a.form == 0; }
+
 hipError_t trx_launch_group_pack(hipStream_t st, const TrxGroupReplay &a, float4 *packed) {
   const long long n = (long long)a.n_slots * a.S;
   if (n <= 0) return hipSuccess;
+  if (replay_wave_form(a)) return hipSuccess;               // (k_group_replay_wave gathers for itself)
   k_group_pack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(n, a.n_tsc_rows, a.rowmap, a.flags, a.avgpwr, a.amp, packed);
   return hipGetLastError();
 }
@@ -459,15 +675,21 @@ hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, floa
   if (n <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_GROUP, st);
   const int Spad = (a.S + 63) / 64 * 64;
-  // long calls replay parallel in time (k_group_replay_seg), short ones one step after the other
-  // (segment length: a multiple of eight timeslots, so that every segment starts on the same timeslot number)
-  if (a.n_slots >= 384) k_group_replay_seg<16><<<dim3((a.S + 15) / 16), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 15) / 16 + 7) / 8 * 8);
+  // the wave form (k_group_replay_wave) for calls of up to 1,024 timeslots; otherwise (and under TRXSIG_TUNE_GROUP_REPLAY = 1)
+  // long calls replay parallel in time, short ones one step after the other (the forms that step through every slot; segment length: a
+  // multiple of eight timeslots, so that every segment starts on the same timeslot number)
+  const bool wave = replay_wave_form(a);
+  if (wave) {
+    const int K = (a.n_slots + 63) / 64;
+    k_group_replay_wave<<<dim3(a.S), dim3(64 * K), 0, st>>>(a, thr_g, verdict_g, Spad, K);
+  } else if (a.n_slots >= 384) k_group_replay_seg<16><<<dim3((a.S + 15) / 16), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 15) / 16 + 7) / 8 * 8);
   else if (a.n_slots >= 128) k_group_replay_seg<8><<<dim3((a.S + 31) / 32), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 7) / 8 + 7) / 8 * 8);
   else k_group_replay<<<dim3(Spad / 64), dim3(64), 0, st>>>(a, packed, thr_g, verdict_g, Spad);
-  // the equalising leg's cache walk visits every (slot, ARFCN) cell once and leaves the rows' results itself; the other leg scatters
+  // the equalising leg's cache walk visits every (slot, ARFCN) cell once and leaves the rows' results itself; on the other leg the wave form
+  // has left them already, the other forms scatter
   (void)tix_g;
-  if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, packed, verdict_g, thr_g, Spad);
-  else k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g);
+  if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, verdict_g, thr_g, Spad, wave ? 1 : 0);
+  else if (!wave) k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g);
   if (prof) prof->end(TRXSIG_K_GROUP, st);
   return hipGetLastError();
 }

@@ -101,7 +101,9 @@ enum { TRX_KNOB_EQ_TAIL = 0,      // 1 = k_eq_dfe4 (scale + delay + DFE in one k
        TRX_KNOB_RXRES_WPB = 2,    // k_rx_resample: windows per workgroup; 0 = chosen from the launch size
        TRX_KNOB_RXRES_ROWS = 3,   // k_rx_resample: 1 = tap rows in visiting order (default), 0 = in branch order
        TRX_KNOB_CHAN_TPW = 4,     // k_channelise16: tiles per workgroup; 0 = chosen from the launch size
-       TRX_KNOB_COUNT = 5 };
+       TRX_KNOB_GROUP_REPLAY = 5, // the Transceiver group's state machine: 0 = a wave per 64-slot segment visiting the slots that move the state
+                                  // (k_group_replay_wave, default), 1 = a lane per ARFCN (and segment) stepping through every slot (round 4)
+       TRX_KNOB_COUNT = 6 };
 int trx_knob(int id);
 void trx_knob_set(int id, int value);
 

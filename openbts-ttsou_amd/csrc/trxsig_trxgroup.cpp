@@ -460,6 +460,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   const bool equalize = g->leg == TRXSIG_TSCLEG_EQUALIZE;
   TrxGroupReplay rp = {};
   rp.S = S; rp.n_slots = n_slots; rp.fn0 = fn; rp.tn0 = tn; rp.equalize = equalize; rp.n_tsc_rows = n_tsc;
+  rp.form = trx_group_replay_form(n_slots);
   rp.rowmap = W.rowmap.p; rp.flags = W.flags.p; rp.amp = W.amp.p; rp.avgpwr = W.avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
   rp.gate = W.gate.p; rp.ev = W.ev.p; rp.tap_ix = W.tap_ix.p; rp.snr = W.snr.p; rp.thr_after = W.thr_after.p; rp.err = g->d_err;
   // Demodulating leg: demodulateBurst needs nothing the state machine decides except WHETHER a burst is handed up, and every

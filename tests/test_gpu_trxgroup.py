@@ -198,6 +198,34 @@ def test_group_equals_single_objects_and_model(pkg, sps, leg, frames, dense, req
     assert seen["tsc"] > 1000 and seen["rach"] > 100, seen
 
 
+@pytest.mark.parametrize("sps,leg,tn0,wrap", [(4, 1, 3, False), (4, 1, 0, True), (1, 0, 6, False)])
+def test_both_forms_of_the_state_machine_give_the_same(pkg, sps, leg, tn0, wrap, request):
+    """TRXSIG_TUNE_GROUP_REPLAY: the wave-per-segment kernel that visits only the timeslots at which the state can move (the default, calls of
+    up to 1,024 timeslots) against the kernels that step through every timeslot (round 4; the tests above hold BOTH against single objects
+    and the model through the default) -- every output of every call bit for bit, calls of 1 ... 1,500 timeslots (one segment, a ragged
+    last segment, sixteen segments, and past the wave form's limit), a silence of 60 frames and the hyperframe wrap inside a call."""
+    S = 64
+    frames = 470
+    n_slots = 8 * frames
+    fn0 = tm.HYPERFRAME - 100 if wrap else 4321
+    x, ctype = build_cells(sps, S, n_slots, fn0, tn0, seed=4242 + sps + tn0, quiet_slots=(900, 1400))
+    calls = (64, 1, 65, 128, 200, 1024, 9, 511, 1500, 63)
+    knob = pkg.TrxSig(sps, 0)
+    request.addfinalizer(lambda: (knob.set_tuning(group_replay=0), knob.close()))
+    outs = []
+    for form in (0, 1):
+        knob.set_tuning(group_replay=form)
+        outs.append(run_group(pkg, sps, leg, S, n_slots, fn0, tn0, x, calls=calls))
+    knob.set_tuning(group_replay=0)
+    (o0, r0, f0), (o1, r1, f1) = outs
+    thr = o0["threshold"][~np.isnan(o0["threshold"])]
+    assert thr.min() < 245 and thr.max() > 255
+    assert o0["valid"].sum() > 1000
+    for key in o0:
+        assert np.array_equal(o0[key], o1[key], equal_nan=(key == "threshold")), key
+    assert np.array_equal(f0, f1)
+
+
 @pytest.mark.parametrize("tn0", [0, 5])
 def test_group_across_the_hyperframe_wrap(pkg, tn0):
     """The frame number wraps (GSM::Time, hyperframe 2,715,648) in the middle of the run, with a 60-frame silence across it: the
