@@ -391,8 +391,8 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
   long long n_thr = s0_thr;
   int n_pf = s0_pf;
   bool need = true;
-  double o_thr = 0.0;                                        // this lane's slot: the threshold after it
-  double first_thr = 0.0;                                    // the threshold the segment's first slot meets
+  double o_thr = 0.0;                                        // this lane's slot: the threshold after it, and its verdict
+  int o_v = 0;
 #ifdef TRX_REPLAY_DEBUG
   const long long dk0 = wall_clock64();
   long long d_run = 0, d_load = 0;
@@ -406,58 +406,65 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
 #endif
     if (need) {
       double thr = __longlong_as_double(n_thr);
+      const double thr0 = thr;                              // the threshold the segment's first slot meets
       int pf = n_pf;
-      first_thr = thr;
+      int seen;
       o_thr = thr;
       // frame difference at slot i = wrap(dbase + frames started in (mark, i]); before any re-basing: FNDelta(first frame, pf) (- 1, see above)
       int dbase = fn_delta(fn_first, pf) - (i0 == 0 ? 1 : 0);
       int nbm = 0;
-      int seen = 0;
+      int fm = 64;                                          // the first slot that re-based the clock
       u64 todo = ~0ull;                                     // slots not yet passed
       for (;;) {
         const float thrF = (float)thr;
         const float thr2 = thrF * thrF;
-        const u64 pass_m = __builtin_amdgcn_ballot_w64(act_l && (avg > thr2));
+        const u64 pass_m = __builtin_amdgcn_ballot_w64(avg > thr2) & act_m;
+        const u64 succ_m = pass_m & det_m;
         const bool tnz = __builtin_amdgcn_ballot_w64(thr != 0.0) != 0;
-        // a burst under the threshold only LOOKS at the clock (that is remembered: SF_CONS) unless 50 quiet frames have passed -- which
-        // they cannot have anywhere in this segment while the frame difference at its END, with the clock as it stands, is no more than 50
-        const u64 under_m = act_m & ~pass_m;
+        // a burst under the threshold only LOOKS at the clock unless 50 quiet frames have passed -- which they cannot have anywhere in
+        // this segment while the frame difference at its END, with the clock as it stands, is no more than 50
         const bool may_quiet = dbase + 8 - nbm > 50;
-        const u64 ev_m = ((pass_m & ~det_m) | (may_quiet ? under_m : 0ull) | (tnz ? (pass_m & det_m) : 0ull)) & todo;
-        if (ev_m == 0) {
-          seen |= (!(seen & SF_MARK) && (under_m & todo) != 0) ? SF_CONS : 0;
-          break;
-        }
+        const u64 ev_m = ((pass_m & ~det_m) | (may_quiet ? act_m & ~pass_m : 0ull) | (tnz ? succ_m : 0ull)) & todo;
+        if (ev_m == 0) break;
         const int i = __builtin_ctzll(ev_m);
-        seen |= (!(seen & SF_MARK) && (under_m & todo & ((1ull << i) - 1)) != 0) ? SF_CONS : 0;
-        const u64 upto = (2ull << i) - 1;                   // slots 0 .. i (i = 63: all)
-        const int nb = __builtin_popcountll(frame_m & upto);
-        int d = dbase + nb - nbm;
-        d -= d >= half ? kHyperframe : 0;
-        int fn = fn_seg + nb;
-        fn -= fn >= kHyperframe ? kHyperframe : 0;
-        const bool pass = (pass_m >> i) & 1, det = (det_m >> i) & 1;
-        bool mark = false;
-        if (pass && det) {                                  // mEnergyThreshold -= 1.0F; floor 0 (:338-339, 368-369)
+        const u64 bit = 1ull << i;
+        if (succ_m & bit) {                                 // mEnergyThreshold -= 1.0F; floor 0 (:338-339, 368-369)
           const double t1 = thr - 1.0;
           thr = t1 < 0.0 ? 0.0 : t1;
-        } else if (pass) {                                  // a false detection: + 10.0F*exp(-framesElapsed) (:355, 374)
-          const int k = d < -TRXG_EXP_LO ? -TRXG_EXP_LO : (d > TRXG_EXP_HI ? TRXG_EXP_HI : d);
-          thr = thr + 10.0 * a.exp_tab[k + TRXG_EXP_LO];
-          seen |= (seen & SF_MARK) ? 0 : SF_CONS;
-          mark = true;
-        } else {                                            // under the threshold: 50 quiet frames take 10 off it (:300-304)
-          seen |= (seen & SF_MARK) ? 0 : SF_CONS;
-          if (d > 50) { thr = thr - 10.0; mark = true; }
+        } else {
+          const int nb = __builtin_popcountll(frame_m & ((bit << 1) - 1));   // frames started in slots 0 .. i
+          int d = dbase + nb - nbm;
+          d -= d >= half ? kHyperframe : 0;
+          bool mark = true;
+          if (pass_m & bit) {                               // a false detection: + 10.0F*exp(-framesElapsed) (:355, 374)
+            const int k = d < -TRXG_EXP_LO ? -TRXG_EXP_LO : (d > TRXG_EXP_HI ? TRXG_EXP_HI : d);
+            thr = thr + 10.0 * a.exp_tab[k + TRXG_EXP_LO];
+          } else if (d > 50) thr = thr - 10.0;              // under the threshold, 50 quiet frames: 10 off it (:300-304)
+          else mark = false;
+          if (mark) {                                       // prevFalseDetectionTime = this burst's time
+            int fn = fn_seg + nb;
+            fn -= fn >= kHyperframe ? kHyperframe : 0;
+            pf = fn; dbase = 0; nbm = nb;
+            fm = fm < i ? fm : i;
+          }
         }
-        if (mark) { pf = fn; dbase = 0; nbm = nb; seen |= SF_MARK; }
 #ifdef TRX_REPLAY_DEBUG
         d_events++;
 #endif
         o_thr = lane >= i ? thr : o_thr;
-        todo = ~upto;
-        if (i == 63) break;
+        todo = ~((bit << 1) - 1);                           // (i = 63: nothing left)
       }
+      // each slot's verdict from the threshold the slot before it left (energyDetect's decision and the correlator's answer behind it: the
+      // walk's own float arithmetic); and what the boundary walk wants to know of the run: did a slot LOOK at the clock (a burst under
+      // the threshold, a false detection) before or when the first one re-based it; did one re-base it
+      double prev = __shfl_up(o_thr, 1);
+      prev = lane == 0 ? thr0 : prev;
+      const float pF = (float)prev;
+      const bool pass_l = act_l && (avg > pF * pF);
+      o_v = pass_l ? (RV_PASS | ((code & RP_DET) ? RV_SUCC : 0)) : 0;
+      const u64 looked_m = act_m & ~(__builtin_amdgcn_ballot_w64(pass_l) & det_m);
+      const u64 first_m = fm < 64 ? ((2ull << fm) - 1) : ~0ull;
+      seen = ((looked_m & first_m) != 0 ? SF_CONS : 0) | (fm < 64 ? SF_MARK : 0);
       u_thr = n_thr; u_pf = n_pf;
       e_thr = uni64(__double_as_longlong(thr)); e_pf = pf; fl = seen;
     }
@@ -492,13 +499,8 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
       break;
     }
   }
-  // the slot's verdict from the threshold the slot before it left: energyDetect's decision and the correlator's answer behind it
-  double prev = __shfl_up(o_thr, 1);
-  prev = lane == 0 ? first_thr : prev;
-  const float pF = (float)prev;
-  const bool pass_l = act_l && (avg > pF * pF);
   if (in) {
-    const int v = pass_l ? (RV_PASS | ((code & RP_DET) ? RV_SUCC : 0)) : 0;
+    const int v = o_v;
     thr_g[(size_t)t * Spad + col] = o_thr;
     verdict_g[(size_t)t * Spad + col] = (uint8_t)(v | ((code & RP_TSC) ? RV_TSC : 0));
     if (row >= 0) {                                         // ... and the row's own results (the other forms leave this to k_group_scatter / k_group_cache)
