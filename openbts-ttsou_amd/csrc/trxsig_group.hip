@@ -609,6 +609,83 @@ __global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const uin
 #endif
 }
 
+// k_group_cache_wave (round 5): the same cache walk, a WAVE per (ARFCN, timeslot) with the timeslot's bursts -- one a frame -- in its lanes.
+// k_group_cache above is bound by its instruction count (~60 dependent instructions a burst on a lone wave: 19 us for 58 frames,
+// profiles/r05_replay_probe.txt) although next to nothing happens in it: the entry changes only where a burst ESTIMATES (the first
+// detected normal burst behind an empty or 50-frame-old entry) or DROPS it (a missed normal burst, a detected access burst).  Those
+// are masks over the lanes: which bursts are detected normal bursts, which drop the entry, which are more than 50 frames past the
+// current estimate (a compare against est, a lane per frame).  The next estimating burst is a find-first-bit -- behind the next
+// drop if one comes first -- and everything between two of them takes the entry as it stands: tap index, event flag and SNRestimate
+// leave a lane per burst, all estimating bursts' divisions side by side.
+__global__ __launch_bounds__(256) void k_group_cache_wave(TrxGroupReplay a, const uint8_t *__restrict__ verdict_g, const double *__restrict__ thr_g, int Spad,
+                                                          int rows_done) {
+  typedef unsigned long long u64;
+  const int lane = threadIdx.x & 63;
+  const int id = uni(blockIdx.x * 4 + (threadIdx.x >> 6));  // (ARFCN, timeslot), timeslot-major as k_group_cache
+  if (id >= 8 * a.S) return;
+  const int tn = id / a.S, col = id - tn * a.S;
+  const int S8 = a.S * 8;
+  int est = uni(a.state[col].est_fn[tn]), src = uni(a.state[col].tap_src[tn]);
+  const int t_first = (tn - a.tn0) & 7;                     // the call's first slot with this timeslot number
+  int fn0 = a.fn0 + ((a.tn0 + t_first) >> 3);               // ... and its frame
+  fn0 -= fn0 >= kHyperframe ? kHyperframe : 0;
+  for (int tb = t_first; tb < a.n_slots; tb += 8 * 64) {     // 64 frames a turn (uniform)
+    const int t = tb + 8 * lane;
+    const bool in = t < a.n_slots;
+    const int v = in ? verdict_g[(size_t)t * Spad + col] : 0;
+    const int row = in ? a.rowmap[(size_t)t * a.S + col] : -1;
+    int fn = fn0 + lane;
+    fn -= fn >= kHyperframe ? kHyperframe : 0;
+    const bool c_l = (v & (RV_TSC | RV_PASS | RV_SUCC)) == (RV_TSC | RV_PASS | RV_SUCC);   // a detected normal burst behind an open gate
+    const bool drop_l = (v & (RV_TSC | RV_PASS | RV_SUCC)) == (RV_TSC | RV_PASS) || (v & (RV_TSC | RV_SUCC)) == RV_SUCC;   // (:357, :370)
+    const u64 c_m = __builtin_amdgcn_ballot_w64(c_l), drop_m = __builtin_amdgcn_ballot_w64(drop_l);
+    int src_l = src;                                        // the entry as this lane's burst finds it (after its own estimate)
+    u64 evt_m = 0, todo = ~0ull;
+    for (;;) {
+      // the next burst that estimates: with an entry, the first detected normal burst more than 50 frames past its estimate -- or the
+      // first one behind the next drop, if that comes earlier; without one, the first detected normal burst
+      u64 cand = c_m & todo;
+      if (src >= 0) {
+        const u64 old_m = __builtin_amdgcn_ballot_w64(fn_delta(fn, est) > 50);   // ((double)d > 50 of an integer d)
+        const u64 dr = drop_m & todo;
+        const u64 behind = dr ? ~((2ull << __builtin_ctzll(dr)) - 1) : 0ull;     // (a drop in lane 63: nothing behind it)
+        cand &= old_m | behind;
+      }
+      if (cand == 0) break;
+      const int i = __builtin_ctzll(cand);
+      src = S8 + __builtin_amdgcn_readlane(row, i);
+      est = __builtin_amdgcn_readlane(fn, i);
+      evt_m |= 1ull << i;
+      src_l = lane >= i ? src : src_l;
+      todo = ~((2ull << i) - 1);
+    }
+    // the entry behind the turn's last burst: dropped if a drop follows the last estimate
+    const u64 after = evt_m ? ~((2ull << (63 - __builtin_clzll(evt_m))) - 1) : ~0ull;
+    src = (drop_m & after) ? -1 : src;
+    if (row >= 0) {
+      const bool evt = (evt_m >> lane) & 1;
+      const double th = thr_g[(size_t)t * Spad + col];
+      if (!rows_done) {
+        a.gate[row] = (uint8_t)(v & RV_SUCC);
+        a.thr_after[row] = th;
+      }
+      a.ev[row] = evt ? 1 : 0;
+      a.tap_ix[row] = c_l ? src_l : 0;
+      if (evt) {                                            // SNRestimate = |amp|^2 / (thr^2 + 1) in double, the threshold AFTER its decrement (:340)
+        const trx_c32 am = a.amp[row];
+        const float n2 = am.i * am.i + am.r * am.r;         // Complex::norm2 (Complex.h:119)
+        a.snr[row] = (float)((double)n2 / (th * th + 1.0));
+      }
+    }
+    fn0 += 64;
+    fn0 -= fn0 >= kHyperframe ? kHyperframe : 0;
+  }
+  if (lane == 0) {
+    a.state[col].est_fn[tn] = est;
+    a.state[col].tap_src[tn] = src;
+  }
+}
+
 // (slot, ARFCN) order -> rows on the demodulating leg: gate and the threshold after the burst (the equalising leg: k_group_cache)
 __global__ __launch_bounds__(256) void k_group_scatter(TrxGroupReplay a, int Spad, const double *__restrict__ thr_g,
                                                        const uint8_t *__restrict__ verdict_g) {
@@ -690,7 +767,8 @@ hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, floa
   // the equalising leg's cache walk visits every (slot, ARFCN) cell once and leaves the rows' results itself; on the other leg the wave form
   // has left them already, the other forms scatter
   (void)tix_g;
-  if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, verdict_g, thr_g, Spad, wave ? 1 : 0);
+  if (a.equalize && wave) k_group_cache_wave<<<dim3((8 * a.S + 3) / 4), dim3(256), 0, st>>>(a, verdict_g, thr_g, Spad, 1);
+  else if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, verdict_g, thr_g, Spad, 0);
   else if (!wave) k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g);
   if (prof) prof->end(TRXSIG_K_GROUP, st);
   return hipGetLastError();
