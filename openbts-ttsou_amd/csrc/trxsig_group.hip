@@ -352,7 +352,7 @@ __device__ __forceinline__ long long uni64(long long v) {
 }
 
 __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupReplay a, double *__restrict__ thr_g, uint8_t *__restrict__ verdict_g, int Spad,
-                                                                      int K) {
+                                                                      int K, int seg) {
   enum { SF_CONS = 1, SF_MARK = 2 };
   __shared__ long long b_uthr[2][kWaveSegs], b_ethr[2][kWaveSegs];
   __shared__ int b_upf[2][kWaveSegs], b_epf[2][kWaveSegs], b_fl[2][kWaveSegs];
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
   const int lane = threadIdx.x & 63;
   const int j = uni(threadIdx.x >> 6);                      // this wave's segment
   const int col = blockIdx.x;                               // the ARFCN
-  const int ts = j * 64, t = ts + lane;
-  const bool in = t < a.n_slots;
+  const int ts = j * seg, t = ts + lane;                     // (seg = 64, or 32: the upper half of the lanes idles -- see the launcher)
+  const bool in = lane < seg && t < a.n_slots;
   // the slot's row and, through it, the stateless detectors' answers (k_group_pack's gather, done here: one launch less)
   const int row = in ? a.rowmap[(size_t)t * a.S + col] : -1;
   int code = 0;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
   const int s0_pf = uni(a.state[col].prev_false_fn);
   // slots that start a frame: the frame number and the frame difference move on by one BEFORE such a burst is looked at
   const int i0 = (8 - (a.tn0 & 7)) & 7;
-  const u64 frame_m = 0x0101010101010101ull << i0;
+  const u64 frame_m = (0x0101010101010101ull << i0) & (seg == 64 ? ~0ull : 0xffffffffull);
   constexpr int half = kHyperframe / 2;
   int fn_seg = (a.fn0 + ((a.tn0 + ts) >> 3)) % kHyperframe; // the frame of the segment's first slot ...
   const int fn_first = fn_seg;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
         const bool tnz = __builtin_amdgcn_ballot_w64(thr != 0.0) != 0;
         // a burst under the threshold only LOOKS at the clock unless 50 quiet frames have passed -- which they cannot have anywhere in
         // this segment while the frame difference at its END, with the clock as it stands, is no more than 50
-        const bool may_quiet = dbase + 8 - nbm > 50;
+        const bool may_quiet = dbase + (seg >> 3) - nbm > 50;
         const u64 ev_m = ((pass_m & ~det_m) | (may_quiet ? act_m & ~pass_m : 0ull) | (tnz ? succ_m : 0ull)) & todo;
         if (ev_m == 0) break;
         const int i = __builtin_ctzll(ev_m);
@@ -759,8 +759,11 @@ hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, floa
   // multiple of eight timeslots, so that every segment starts on the same timeslot number)
   const bool wave = replay_wave_form(a);
   if (wave) {
-    const int K = (a.n_slots + 63) / 64;
-    k_group_replay_wave<<<dim3(a.S), dim3(64 * K), 0, st>>>(a, thr_g, verdict_g, Spad, K);
+    // segments of 32 timeslots while sixteen of them cover the call: a busy ARFCN's wave visits most of its slots, one after the other,
+    // and the kernel lasts as long as the busiest wave (profiles/r05_replay_probe.txt)
+    const int seg = a.n_slots <= 32 * kWaveSegs ? 32 : 64;
+    const int K = (a.n_slots + seg - 1) / seg;
+    k_group_replay_wave<<<dim3(a.S), dim3(64 * K), 0, st>>>(a, thr_g, verdict_g, Spad, K, seg);
   } else if (a.n_slots >= 384) k_group_replay_seg<16><<<dim3((a.S + 15) / 16), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 15) / 16 + 7) / 8 * 8);
   else if (a.n_slots >= 128) k_group_replay_seg<8><<<dim3((a.S + 31) / 32), dim3(256), 0, st>>>(a, packed, thr_g, verdict_g, Spad, ((a.n_slots + 7) / 8 + 7) / 8 * 8);
   else k_group_replay<<<dim3(Spad / 64), dim3(64), 0, st>>>(a, packed, thr_g, verdict_g, Spad);
