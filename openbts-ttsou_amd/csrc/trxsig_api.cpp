@@ -831,7 +831,7 @@ int trxsig_equalize_normal_batch_fmt(trxsig_ctx *c, const void *d_samples, int s
 // the equalising TSC leg of the Transceiver group (trxsig_ctx.h)
 int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B, int tsc,
                            const uint8_t *d_enable, const float *d_snr, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
-                           float *d_toa_eq, float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b) {
+                           float *d_toa_eq, float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b, int32_t *d_listed) {
   if (!c) return TRXSIG_EINVAL;
   if (c->sps != 1) return fail(c, TRXSIG_EINVAL, "the channel estimate / DFE path needs sps == 1");
   if (B <= 0) return TRXSIG_OK;
@@ -842,7 +842,8 @@ int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int
   int32_t *work = (int32_t *)(c->d_eq + (size_t)c->eq_cap * (4 + 56 + 40));
   HIPCHK(c, trx_launch_estimate_dfe(c->stream, c->d_tables, d_samples, TRXSIG_SAMPLES_C32, d_offset, d_length, B, tsc, 3.0f, -1.0f, 1.0f,
                                     0, 0, d_flags, (trx_c32 *)d_amp, d_toa, d_toa_eq, d_chan_off, (trx_c32 *)d_w, (trx_c32 *)d_b,
-                                    nullptr, c->prof, d_enable, d_snr, trx_eq52_geometry(c->h_tables, tsc), d_enable ? work : nullptr));
+                                    nullptr, c->prof, d_enable, d_snr, trx_eq52_geometry(c->h_tables, tsc), d_enable ? (d_listed ? d_listed : work) : nullptr,
+                                    d_enable && d_listed));
   return TRXSIG_OK;
 }
 int trx_ctx_group_equalize(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,

@@ -85,7 +85,8 @@ int trx_rxfe_next_tn(const trxsig_rxfe *fe);
 //     TRXSIG_F_DETECT, burst b with the taps at entry d_tap_ix[b] of the tap table.
 int trx_ctx_group_estimate(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B, int tsc,
                            const uint8_t *d_enable, const float *d_snr, uint8_t *d_flags, trxsig_c32 *d_amp, float *d_toa,
-                           float *d_toa_eq, float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b);
+                           float *d_toa_eq, float *d_chan_off, trxsig_c32 *d_w, trxsig_c32 *d_b,
+                           int32_t *d_listed = nullptr /* the marked bursts already listed: their count, then their indices (any order) */);
 int trx_ctx_group_equalize(trxsig_ctx *c, const trxsig_c32 *d_samples, const int32_t *d_offset, const int32_t *d_length, int B,
                            const trxsig_c32 *d_amp, const float *d_toa_eq, const uint8_t *d_gate, const trxsig_c32 *d_w_tab,
                            const trxsig_c32 *d_b_tab, const int32_t *d_tap_ix, float *d_soft, int nsoft, int soft_stride);

@@ -2143,14 +2143,14 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
                                    const int32_t *len, int B, int tsc, float detect_thresh, float snr_thresh,
                                    float snr_value, int variant52m, int max_toa, uint8_t *flags, trx_c32 *amp, float *toa,
                                    float *toa_eq, float *chan_off, trx_c32 *w, trx_c32 *bq, trx_c32 *chan, TrxProfiler *prof,
-                                   const uint8_t *enable, const float *snr_in, bool geom52, int32_t *work) {
+                                   const uint8_t *enable, const float *snr_in, bool geom52, int32_t *work, bool listed) {
   if (B <= 0) return hipSuccess;
   if (prof) prof->begin(TRXSIG_K_EQUALIZE, st);
   // few bursts (the Transceiver/ variant): a wave per burst -- a marked subset (listed first; `work`: B + 1 ints) or a small call
   if (!variant52m && eq_detect_generic() == 0 && ((enable && work) || (!enable && B <= kEqWaveMax))) {
     const int32_t *list = nullptr, *count = nullptr;
     if (enable) {
-      k_eq_list<<<dim3(1), dim3(1024), 0, st>>>(enable, B, work + 1, work);
+      if (!listed) k_eq_list<<<dim3(1), dim3(1024), 0, st>>>(enable, B, work + 1, work);
       list = work + 1; count = work;
     }
     const int waves = B < kEqWaveMax ? B : kEqWaveMax;

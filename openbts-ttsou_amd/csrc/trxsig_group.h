@@ -59,6 +59,8 @@ struct TrxGroupReplay {
   int32_t *tap_ix;                                         // tap-table entry the burst is equalised with
   float *snr;                                              // SNRestimate[ts] (:340) of an estimating burst
   double *thr_after;                                       // mEnergyThreshold after the burst
+  int32_t *ev_list;                                        // (wave form, equalising leg; else NULL) the estimating bursts LISTED per class for the channel estimate:
+  int class_base[TRXG_NCLASS + 1];                         // class k's count at ev_list[class_base[k] + k], its rows (relative to class_base[k]) behind it
   int *err;                                                // device word: bit 0 = a time-parallel replay left its loop at the round bound without a
                                                            // validated result (never observed: the proof says at most K rounds); trxsig_trxgroup_collect reports it
 };

@@ -377,6 +377,8 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
   const u64 det_m = __builtin_amdgcn_ballot_w64((code & RP_DET) != 0);
   const long long s0_thr = uni64(__double_as_longlong(a.state[col].thr));
   const int s0_pf = uni(a.state[col].prev_false_fn);
+  if (a.ev_list && blockIdx.x == 0 && threadIdx.x < TRXG_CLASS_RACH)   // k_group_cache_wave lists the estimating bursts behind these counts
+    a.ev_list[a.class_base[threadIdx.x] + threadIdx.x] = 0;
   // slots that start a frame: the frame number and the frame difference move on by one BEFORE such a burst is looked at
   const int i0 = (8 - (a.tn0 & 7)) & 7;
   const u64 frame_m = (0x0101010101010101ull << i0) & (seg == 64 ? ~0ull : 0xffffffffull);
@@ -617,23 +619,27 @@ __global__ __launch_bounds__(256) void k_group_cache(TrxGroupReplay a, const uin
 // current estimate (a compare against est, a lane per frame).  The next estimating burst is a find-first-bit -- behind the next
 // drop if one comes first -- and everything between two of them takes the entry as it stands: tap index, event flag and SNRestimate
 // leave a lane per burst, all estimating bursts' divisions side by side.
-__global__ __launch_bounds__(256) void k_group_cache_wave(TrxGroupReplay a, const uint8_t *__restrict__ verdict_g, const double *__restrict__ thr_g, int Spad,
-                                                          int rows_done) {
+__global__ __launch_bounds__(1024) void k_group_cache_wave(TrxGroupReplay a, const uint8_t *__restrict__ verdict_g, const double *__restrict__ thr_g, int Spad,
+                                                           int rows_done) {
   typedef unsigned long long u64;
+  __shared__ int l_cnt[TRXG_CLASS_RACH], l_base[TRXG_CLASS_RACH];   // this workgroup's estimating bursts per class, and where its share of the class's list starts
   const int lane = threadIdx.x & 63;
-  const int id = uni(blockIdx.x * 4 + (threadIdx.x >> 6));  // (ARFCN, timeslot), timeslot-major as k_group_cache
-  if (id >= 8 * a.S) return;
+  const int idr = uni(blockIdx.x * 16 + (threadIdx.x >> 6)); // (ARFCN, timeslot), timeslot-major as k_group_cache
+  const bool mine = idr < 8 * a.S;                           // (a spare wave shadows the last pair and stores nothing: the workgroup's barriers are everyone's)
+  const int id = mine ? idr : 8 * a.S - 1;
   const int tn = id / a.S, col = id - tn * a.S;
   const int S8 = a.S * 8;
   int est = uni(a.state[col].est_fn[tn]), src = uni(a.state[col].tap_src[tn]);
   const int t_first = (tn - a.tn0) & 7;                     // the call's first slot with this timeslot number
   int fn0 = a.fn0 + ((a.tn0 + t_first) >> 3);               // ... and its frame
   fn0 -= fn0 >= kHyperframe ? kHyperframe : 0;
-  for (int tb = t_first; tb < a.n_slots; tb += 8 * 64) {     // 64 frames a turn (uniform)
-    const int t = tb + 8 * lane;
+  const int turns = (a.n_slots + 511) / 512;                 // 64 frames a turn; the same number of turns for every wave (a turn may hold nothing of a late timeslot)
+  for (int c = 0; c < turns; c++) {
+    const int t = t_first + 512 * c + 8 * lane;
     const bool in = t < a.n_slots;
     const int v = in ? verdict_g[(size_t)t * Spad + col] : 0;
-    const int row = in ? a.rowmap[(size_t)t * a.S + col] : -1;
+    const int row = (in && mine) ? a.rowmap[(size_t)t * a.S + col] : -1;
+    if (threadIdx.x < TRXG_CLASS_RACH) l_cnt[threadIdx.x] = 0;
     int fn = fn0 + lane;
     fn -= fn >= kHyperframe ? kHyperframe : 0;
     const bool c_l = (v & (RV_TSC | RV_PASS | RV_SUCC)) == (RV_TSC | RV_PASS | RV_SUCC);   // a detected normal burst behind an open gate
@@ -662,8 +668,10 @@ __global__ __launch_bounds__(256) void k_group_cache_wave(TrxGroupReplay a, cons
     // the entry behind the turn's last burst: dropped if a drop follows the last estimate
     const u64 after = evt_m ? ~((2ull << (63 - __builtin_clzll(evt_m))) - 1) : ~0ull;
     src = (drop_m & after) ? -1 : src;
+    const bool evt = row >= 0 && ((evt_m >> lane) & 1);
+    int k = 0, lp = 0;
+    __syncthreads();                                        // l_cnt is zero
     if (row >= 0) {
-      const bool evt = (evt_m >> lane) & 1;
       const double th = thr_g[(size_t)t * Spad + col];
       if (!rows_done) {
         a.gate[row] = (uint8_t)(v & RV_SUCC);
@@ -675,12 +683,23 @@ __global__ __launch_bounds__(256) void k_group_cache_wave(TrxGroupReplay a, cons
         const trx_c32 am = a.amp[row];
         const float n2 = am.i * am.i + am.r * am.r;         // Complex::norm2 (Complex.h:119)
         a.snr[row] = (float)((double)n2 / (th * th + 1.0));
+#pragma unroll
+        for (int q = 1; q < TRXG_CLASS_RACH; q++) k += row >= a.class_base[q] ? 1 : 0;
+        lp = atomicAdd(&l_cnt[k], 1);
       }
     }
+    // ... and the estimating bursts go on their class's list for the channel estimate (k_eq_list's job; the order of a list decides which
+    // wave estimates which burst, nothing else): counted per workgroup in LDS, ONE addition to the class's count per workgroup and class
+    // (an addition per burst -- a thousand to one address -- cost 14 us)
+    __syncthreads();
+    if (a.ev_list && threadIdx.x < TRXG_CLASS_RACH && l_cnt[threadIdx.x] > 0)
+      l_base[threadIdx.x] = atomicAdd(a.ev_list + a.class_base[threadIdx.x] + threadIdx.x, l_cnt[threadIdx.x]);
+    __syncthreads();
+    if (a.ev_list && evt) a.ev_list[a.class_base[k] + k + 1 + l_base[k] + lp] = row - a.class_base[k];
     fn0 += 64;
     fn0 -= fn0 >= kHyperframe ? kHyperframe : 0;
   }
-  if (lane == 0) {
+  if (lane == 0 && mine) {
     a.state[col].est_fn[tn] = est;
     a.state[col].tap_src[tn] = src;
   }
@@ -770,7 +789,7 @@ hipError_t trx_launch_group_replay(hipStream_t st, const TrxGroupReplay &a, floa
   // the equalising leg's cache walk visits every (slot, ARFCN) cell once and leaves the rows' results itself; on the other leg the wave form
   // has left them already, the other forms scatter
   (void)tix_g;
-  if (a.equalize && wave) k_group_cache_wave<<<dim3((8 * a.S + 3) / 4), dim3(256), 0, st>>>(a, verdict_g, thr_g, Spad, 1);
+  if (a.equalize && wave) k_group_cache_wave<<<dim3((8 * a.S + 15) / 16), dim3(1024), 0, st>>>(a, verdict_g, thr_g, Spad, 1);
   else if (a.equalize) k_group_cache<<<dim3((8 * a.S + 255) / 256), dim3(256), 0, st>>>(a, verdict_g, thr_g, Spad, 0);
   else if (!wave) k_group_scatter<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a, Spad, thr_g, verdict_g);
   if (prof) prof->end(TRXSIG_K_GROUP, st);

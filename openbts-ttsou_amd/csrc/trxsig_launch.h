@@ -212,7 +212,8 @@ hipError_t trx_launch_estimate_dfe(hipStream_t st, const TrxTables *dT, const vo
                                    TrxProfiler *prof, const uint8_t *enable = nullptr /* only bursts with enable[b] != 0; nothing
                                    is written for the others */, const float *snr_in = nullptr /* SNR estimate per burst */,
                                    bool geom52 = false, int32_t *work = nullptr /* B + 1 ints of scratch: lets a marked subset (enable) of
-                                   the Transceiver/ variant be listed and estimated a wave per burst (k_eq_estimate_wave) */);
+                                   the Transceiver/ variant be listed and estimated a wave per burst (k_eq_estimate_wave) */,
+                                   bool listed = false /* work holds the list already: the count, then the marked bursts in any order */);
 // designDFE(chan, snr, 7) alone; amp != NULL: scaleVector(chan, 1/amp) first
 hipError_t trx_launch_design_dfe(hipStream_t st, const trx_c32 *chan, const trx_c32 *amp, const float *snr, int B, trx_c32 *w,
                                  trx_c32 *bq, TrxProfiler *prof);

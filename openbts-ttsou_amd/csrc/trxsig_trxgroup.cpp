@@ -380,7 +380,7 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   {
     const size_t ns = trx_group_replay_scratch(S, n_slots);
     G_HIP(g, W.thr_g.need(ns, st)); G_HIP(g, W.succ_g.need(ns, st));
-    if (g->leg == TRXSIG_TSCLEG_EQUALIZE) G_HIP(g, W.tix_g.need(ns, st));
+    if (g->leg == TRXSIG_TSCLEG_EQUALIZE) G_HIP(g, W.tix_g.need(ns > R + 16 ? ns : R + 16, st));
   }
   G_HIP(g, g->w_tab.need((S8 + R) * 7, st, S8 * 7)); G_HIP(g, g->b_tab.need((S8 + R) * 5, st, S8 * 5));
   G_HIP(g, g->chan_off.need(S8 + R, st, S8));
@@ -461,6 +461,9 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
   TrxGroupReplay rp = {};
   rp.S = S; rp.n_slots = n_slots; rp.fn0 = fn; rp.tn0 = tn; rp.equalize = equalize; rp.n_tsc_rows = n_tsc;
   rp.form = trx_group_replay_form(n_slots);
+  // the wave form's cache walk lists the estimating bursts itself (a class's count and rows at tix_g + base[k] + k: n_rows + 8 ints at most)
+  rp.ev_list = (equalize && rp.form == 0) ? W.tix_g.p : nullptr;
+  for (int k = 0; k <= TRXG_NCLASS; k++) rp.class_base[k] = base[k];
   rp.rowmap = W.rowmap.p; rp.flags = W.flags.p; rp.amp = W.amp.p; rp.avgpwr = W.avgpwr.p; rp.exp_tab = g->d_exp; rp.state = g->d_state;
   rp.gate = W.gate.p; rp.ev = W.ev.p; rp.tap_ix = W.tap_ix.p; rp.snr = W.snr.p; rp.thr_after = W.thr_after.p; rp.err = g->d_err;
   // Demodulating leg: demodulateBurst needs nothing the state machine decides except WHETHER a burst is handed up, and every
@@ -492,7 +495,8 @@ int pull_core(trxsig_trxgroup *g, const PullSource &src, int fn, int tn, int n_s
         const int b0 = base[k];
         G_LIB(trx_ctx_group_estimate(c, d_samples, W.off.p + b0, W.len.p + b0, count[k], k, W.ev.p + b0, W.snr.p + b0, W.ev_flags.p + b0,
                                      (trxsig_c32 *)W.ev_amp.p + b0, W.ev_toa.p + b0, W.ev_toaeq.p + b0, g->chan_off.p + S8 + b0,
-                                     (trxsig_c32 *)g->w_tab.p + (S8 + b0) * 7, (trxsig_c32 *)g->b_tab.p + (S8 + b0) * 5));
+                                     (trxsig_c32 *)g->w_tab.p + (S8 + b0) * 7, (trxsig_c32 *)g->b_tab.p + (S8 + b0) * 5,
+                                     rp.ev_list ? rp.ev_list + b0 + k : nullptr));
       }
       G_HIP(g, trx_launch_group_toa_eq(st, n_tsc, W.gate.p, W.toa.p, W.tap_ix.p, g->chan_off.p, W.toa_eq.p));
       G_LIB(trx_ctx_group_equalize(c, d_samples, W.off.p, W.len.p, n_tsc, (const trxsig_c32 *)W.amp.p, W.toa_eq.p, W.gate.p,
