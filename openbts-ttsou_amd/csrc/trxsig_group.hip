@@ -323,17 +323,17 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_group_replay_wave (round 5): the same machine, the same validated segments -- but a WAVE per (ARFCN, segment of 64 timeslots), its lanes
-// the segment's 64 slots, and the serial part visits only the slots at which the state CAN move.  What round 4's debug timing said
+// k_group_replay_wave (round 5): the same machine, the same validated segments -- but a WAVE per (ARFCN, segment of 32 or 64 timeslots), its
+// lanes the segment's slots, and the serial part visits only the slots at which the state CAN move.  What round 4's debug timing said
 // of k_group_replay_seg: a slot-step is ~60 dependent instructions behind two mask reads, ~0.3 us, whether or not anything happens
 // in it -- and in a running cell almost nothing does: the threshold sits on its floor of 0, every active burst passes the energy
 // gate, a detected burst takes 1 from a threshold that is 0 already.  Here everything about a segment that does not depend on the
 // state is one instruction across the lanes (the slots' codes and powers: one load each; which slots start a frame: a constant
-// mask), energyDetect's decision for all 64 slots against the CURRENT threshold is one compare and a ballot, and the slots that can
+// mask), energyDetect's decision for all the slots against the CURRENT threshold is one compare and a ballot, and the slots that can
 // change the state under it are a mask:
 //     a burst the correlator missed behind an open gate (the threshold rises, the clock is re-based),
-//     an active burst under the threshold once 50 quiet frames have passed (re-bases the clock, lowers the threshold; before that it
-//       only LOOKS at the clock, which is remembered for the boundary walk and costs no visit),
+//     an active burst under the threshold once 50 quiet frames CAN have passed (re-bases the clock, lowers the threshold; before that it
+//       only LOOKS at the clock, which the boundary walk wants to know -- found after the run, a lane per slot -- and costs no visit),
 //     a detected burst while the threshold is not 0 (the threshold falls by one).
 // The wave jumps from one such slot to the next (find-first-bit), the frame difference to prevFalseDetectionTime at a slot is a
 // population count of the frame-start mask, and all of it is wave-uniform: scalar branches, no execution masks.  A slot's
@@ -341,9 +341,11 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
 // from the threshold the slot before it left (the same float arithmetic as the step's).  Segments, assumed start states, the
 // boundary walk and the proof that it ends with the serial result are k_group_replay_seg's, word for word; the walk is done by
 // every wave for itself (K <= 16 boundaries from LDS, uniform), two buffers by round parity, one barrier a round.
-// Workgroup = one ARFCN, K = ceil(n_slots / 64) waves.
+// Workgroup = one ARFCN, K = ceil(n_slots / seg) <= 16 waves; seg = 32 while sixteen segments of 32 cover the call (the kernel lasts as long as
+// its busiest wave, and a busy ARFCN's wave visits most of its slots), else 64.  The kernel gathers the detectors' answers through the row
+// map itself (k_group_pack is not launched) and leaves the rows' gate and threshold (nor k_group_scatter).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kWaveSegs = 16;                               // n_slots <= 1024
+constexpr int kWaveSegs = 16;                               // waves per workgroup: calls of up to 64 * 16 = 1,024 timeslots
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long uni64(long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
