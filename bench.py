@@ -559,6 +559,29 @@ class Config4:
                 "steps": steps, "what": "trxsig_trxgroup_set_beside_rows(24576) (the replay on the group's side stream) + trxsig_trxgroup_set_pipelined(1): d_valid / d_threshold of step i are complete after "
                                         "trxsig_trxgroup_sync, its replay overlaps step i+1's detectors; same values (tests/test_gpu_trxgroup.py)"}
 
+    def stepping_state_machine(self, steps):
+        """Side measurement (never `value`): the same steps with the round-4 kernels of the group's state machine (they step through every
+        timeslot; trxsig_set_tuning(TRXSIG_TUNE_GROUP_REPLAY, 1)) instead of the wave-per-segment kernels that visit only the timeslots
+        at which the state can move.  Same values (tests/test_gpu_trxgroup.py holds the two bit for bit against each other)."""
+        if not self.group:
+            return None
+        import torch
+        self.ctx.set_tuning(group_replay=1)
+        try:
+            for _ in range(max(steps // 10, 5)):
+                self.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            self.ctx.set_tuning(group_replay=0)
+        return {"value": round(self.units_per_step() * steps / dt / 1e6, 3), "unit": "Mbursts/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+                "what": "trxsig_set_tuning(TRXSIG_TUNE_GROUP_REPLAY, 1): k_group_replay_seg + k_group_pack + k_group_scatter / k_group_cache + k_eq_list "
+                        "(round 4) instead of k_group_replay_wave / k_group_cache_wave"}
+
     def cpu_baseline(self, check):
         """The oracle's polyphaseResampleVector + analyzeTrafficBurst + demodulateBurst chain on ONE host core over a bounded
         sample of the streams (chunk by chunk with history, as RadioInterface::pullBuffer)."""
@@ -908,6 +931,8 @@ def main():
         prof_fresh = fresh.pop("prof")
     piped = wl.pipelined(args.steps) if (world == 1 and hasattr(wl, "pipelined") and not args.no_lever) else None
     other_mode = wl.other_soft_mode(args.steps) if (world == 1 and hasattr(wl, "other_soft_mode") and not args.no_lever) else None
+    stepping = (wl.stepping_state_machine(args.steps)
+                if (world == 1 and hasattr(wl, "stepping_state_machine") and not args.no_lever and not args.group_replay) else None)
     sanity = wl.sanity()
     if rank != 0:
         return
@@ -979,6 +1004,8 @@ def main():
         out[getattr(wl, "pipelined_key", "pipelined")] = piped
     if other_mode:
         out["other_soft_mode"] = other_mode
+    if stepping:
+        out["stepping_state_machine"] = stepping
     if args.rehearse_one_gpu:
         out["rehearsal"] = "all %d ranks shared cuda:0 (gloo collectives): launch-path check, not a scaling number" % world
     if not args.no_cpu_baseline and world == 1:
