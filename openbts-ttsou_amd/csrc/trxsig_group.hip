@@ -335,8 +335,11 @@ __global__ __launch_bounds__(256) void k_group_replay_seg(TrxGroupReplay a, cons
 //     an active burst under the threshold once 50 quiet frames CAN have passed (re-bases the clock, lowers the threshold; before that it
 //       only LOOKS at the clock, which the boundary walk wants to know -- found after the run, a lane per slot -- and costs no visit),
 //     a detected burst while the threshold is not 0 (the threshold falls by one).
-// The wave jumps from one such slot to the next (find-first-bit), the frame difference to prevFalseDetectionTime at a slot is a
-// population count of the frame-start mask, and all of it is wave-uniform: scalar branches, no execution masks.  A slot's
+// Of those the last kind needs no visit either: c detected bursts in a row take max(thr - c, 0) from the threshold, exactly (see the loop),
+// so every lane forms the threshold its slot meets from the number of detected bursts ahead of it, and a turn of the loop takes the whole
+// run of slots up to the first one that does something else.  The wave jumps from one such slot to the next (find-first-bit), the frame
+// difference to prevFalseDetectionTime at a slot is a population count of the frame-start mask, and all of it is wave-uniform: scalar
+// branches, no execution masks.  A slot's
 // threshold-after is handed to the lanes from the slot of the change onwards; its verdict is formed afterwards, a lane per slot,
 // from the threshold the slot before it left (the same float arithmetic as the step's).  Segments, assumed start states, the
 // boundary walk and the proof that it ends with the serial result are k_group_replay_seg's, word for word; the walk is done by
@@ -420,22 +423,44 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
       int fm = 64;                                          // the first slot that re-based the clock
       u64 todo = ~0ull;                                     // slots not yet passed
       for (;;) {
-        const float thrF = (float)thr;
-        const float thr2 = thrF * thrF;
-        const u64 pass_m = __builtin_amdgcn_ballot_w64(avg > thr2) & act_m;
-        const u64 succ_m = pass_m & det_m;
-        const bool tnz = __builtin_amdgcn_ballot_w64(thr != 0.0) != 0;
-        // a burst under the threshold only LOOKS at the clock unless 50 quiet frames have passed -- which they cannot have anywhere in
-        // this segment while the frame difference at its END, with the clock as it stands, is no more than 50
+        // A turn takes a whole RUN of slots: up to the next slot that does something else, the only thing that moves the state is a
+        // detected burst behind an open gate taking 1 from the threshold (floor 0) -- and c such steps from thr are max(thr - c, 0) in ONE
+        // subtraction, exactly: x - 1 is exact for x >= 1 (and negative, hence floored, below), and thr - c is a multiple of thr's last
+        // place no larger than thr.  So every lane forms the threshold its slot meets from the number of detected bursts ahead of it, and
+        // energyDetect's decision from that; the run ends at the first slot that breaks the hypothesis -- a false detection, a detected
+        // burst UNDER its threshold (it was counted as a step and is none), a burst under the threshold where 50 quiet frames can have
+        // passed -- which is then handled on its own.
+        const u64 dm = act_m & det_m & todo;
+        const int c_l = __builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0));   // detected bursts ahead of this lane's slot
+        double thr_l = thr - (double)c_l;
+        thr_l = c_l > 0 ? (thr_l < 0.0 ? 0.0 : thr_l) : thr;
+        const float thrF = (float)thr_l;
+        const u64 pass_m = __builtin_amdgcn_ballot_w64(avg > thrF * thrF) & act_m;
+        const u64 under_m = act_m & ~pass_m;
         const bool may_quiet = dbase + (seg >> 3) - nbm > 50;
-        const u64 ev_m = ((pass_m & ~det_m) | (may_quiet ? act_m & ~pass_m : 0ull) | (tnz ? succ_m : 0ull)) & todo;
-        if (ev_m == 0) break;
-        const int i = __builtin_ctzll(ev_m);
+        // (the one subtraction stands for the steps while they are exact: below 2^52.  A threshold can be anything -- 10 exp(-d) of a clock
+        // that runs AHEAD of the bursts, d = -35 .. -39, lands between 2^53 and 2^59, where x - 1 rounds and c of them are not x - c: there
+        // every detected burst ends the run and takes its step on its own)
+        const bool exact = __builtin_amdgcn_ballot_w64(thr < 4503599627370496.0) != 0;
+        const u64 brk_m = ((det_m & under_m) | (pass_m & ~det_m) | (may_quiet ? under_m : 0ull) | (exact ? 0ull : dm)) & todo;
+        const int i = brk_m ? __builtin_ctzll(brk_m) : 64;
+        // the run's slots: the threshold after each (a detected burst's own step included)
+        const double t1 = thr_l - 1.0;
+        const double after_l = (act_l && (code & RP_DET)) ? (t1 < 0.0 ? 0.0 : t1) : thr_l;
+        const u64 run_m = todo & (i < 64 ? (1ull << i) - 1 : ~0ull);
+        o_thr = ((run_m >> lane) & 1) ? after_l : o_thr;
+        if (i == 64) {                                      // nothing breaks the run: the state behind the segment is the last lane's
+          thr = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(after_l) >> 32), 63) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(after_l), 63));
+          break;
+        }
+        thr = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(thr_l) >> 32), i) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(thr_l), i));   // the threshold slot i meets
         const u64 bit = 1ull << i;
-        if (succ_m & bit) {                                 // mEnergyThreshold -= 1.0F; floor 0 (:338-339, 368-369)
-          const double t1 = thr - 1.0;
-          thr = t1 < 0.0 ? 0.0 : t1;
-        } else {
+        if (det_m & pass_m & bit) {                         // (only where the run could not take it: mEnergyThreshold -= 1.0F; floor 0, :338-339, 368-369)
+          const double t = thr - 1.0;
+          thr = t < 0.0 ? 0.0 : t;
+        } else if (!(det_m & bit) || may_quiet) {           // (a detected burst under its threshold only looks at the clock unless it is quiet)
           const int nb = __builtin_popcountll(frame_m & ((bit << 1) - 1));   // frames started in slots 0 .. i
           int d = dbase + nb - nbm;
           d -= d >= half ? kHyperframe : 0;
@@ -457,6 +482,7 @@ __global__ __launch_bounds__(64 * kWaveSegs) void k_group_replay_wave(TrxGroupRe
 #endif
         o_thr = lane >= i ? thr : o_thr;
         todo = ~((bit << 1) - 1);                           // (i = 63: nothing left)
+        if (todo == 0) break;
       }
       // each slot's verdict from the threshold the slot before it left (energyDetect's decision and the correlator's answer behind it: the
       // walk's own float arithmetic); and what the boundary walk wants to know of the run: did a slot LOOK at the clock (a burst under

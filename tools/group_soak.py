@@ -2,7 +2,7 @@
 random schedules are those of tests/test_gpu_trxgroup.py (combinations I / II / IV / V / VI / VII / NONE, four TSCs), here over
 several seeds, start frames (incl. across the hyperframe wrap), random call sizes, both TSC legs and the pipelined mode --
 every SoftVector, RSSI, timing offset, verdict and the threshold after every burst compared for equality.
-    python tools/group_soak.py [seeds]"""
+    python tools/group_soak.py [seeds [first seed]]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -13,9 +13,10 @@ import transceiver_model as tm
 
 pkg = _pkg.load()
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # first seed (a second run with other seeds: tools/group_soak.py 8 8)
 total = 0
 t00 = time.time()
-for seed in range(nseeds):
+for seed in range(seed0, seed0 + nseeds):
     rng = np.random.default_rng(1000 + seed)
     for sps, leg in ((4, 1), (1, 0)):
         S = 128
